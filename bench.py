@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- Mvoxel-channels/s of the voxel-descriptor hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5] [--batch B]
+
+A "step" is one pass of the hot path (bin -> scan -> fill -> tile kernel, all on the GPU) over one
+batch of synthetic items that is ALREADY resident in HBM; features stay resident in HBM (float32
+[B,V,C]).  Default workload = BASELINE.json configs[1] ("cfg2"): independent 50k-atom solvated-protein
+systems, 64^3 grid @ 1 A, 8 channels, B systems per GPU per step (SURVEY.md section 8d generators).
+N > 1: one process per GPU (torchrun), every rank owns its own B items (weak scaling), no collective
+inside the timed region (the trivial gather of feature tensors is timed separately as `gather_ms`).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded around the tile
+kernel on the stream it runs on; `cpu_baseline` times the oracle (oracle/liboracle.so, a port of the
+reference's serial Cython kernel) on a bounded sample of the same workload on 1 host core.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+FP32_VALU_PEAK_TFLOPS = 157.3  # vector FP32 peak (secondary roofline: cfg2/cfg4 are VALU-bound)
+
+DEFAULT_BATCH = {"cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096}
+
+
+def make_workload(name, batch, seed):
+    from tests.synth import grid_origin, synth_config
+    cfg = int(name[3:])
+    p = synth_config(cfg, batch, seed=seed)
+    origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    return p, origins, nv
+
+
+def algorithmic_bytes(p, nv, C=8):
+    """per grid V*C*4 (one float32 write per voxel-channel) + N*(12 + 4*C)
+    (coords + per-channel sigmas read once); summed over the batch."""
+    B = len(p["atom_offsets"]) - 1
+    V = int(np.prod(nv))
+    return B * V * C * 4 + int(p["atom_offsets"][-1]) * (12 + 4 * C)
+
+
+def cpu_baseline(name):
+    """Oracle (port of occupancy_utils.pyx:34-61, serial like the reference) on a bounded sample."""
+    from oracle import oracle
+    from tests.synth import grid_origin, synth_config
+    cfg = int(name[3:])
+    p = synth_config(cfg, 1)
+    o, nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])
+    s, e = p["atom_offsets"][0], p["atom_offsets"][1]
+    if cfg in (2, 4):     # one grid costs ~40 s on one core: time a central z-slab of it, all atoms
+        nz = 16
+        o = o.copy(); o[2] += (nv[2] - nz) // 2 * p["voxelsize"]
+        nv = np.array([nv[0], nv[1], nz])
+        sample = f"1 item of {name}: all {e - s} atoms, central {nv[0]}x{nv[1]}x{nz} voxel slab of the grid"
+        reps = 1
+    else:                 # small molecules: whole grids, repeated
+        reps = 200
+        sample = f"{reps} items of {name} ({e - s} atoms each, full {nv[0]}x{nv[1]}x{nv[2]} grid)"
+    centers = oracle.grid_centers(o, nv, p["voxelsize"])
+    box = None if p["box"] is None else p["box"][0]
+    oracle.calculate_occupancy(centers[:64], p["coords"][s:e], p["sigmas"][s:e], box=box)   # warm
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.calculate_occupancy(centers, p["coords"][s:e], p["sigmas"][s:e], box=box)
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * centers.shape[0] * 8 / dt / 1e6, 4), "unit": "Mvoxel-channels/s",
+            "cores": 1, "kind": "port", "sample": sample, "seconds": round(dt, 2),
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(DEFAULT_BATCH))
+    ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (0 = workload default)")
+    ap.add_argument("--tile-k", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from moleculekit_amd import _lib, batch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch or DEFAULT_BATCH[args.workload]
+    p, origins, nv = make_workload(args.workload, B, seed=1000 * int(args.workload[3:]) + rank)
+    V, C = int(np.prod(nv)), 8
+    ctx = _lib.default_context(local)
+    ctx.set_tile_k(args.tile_k)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    d_coords, d_offs = t(p["coords"], np.float32), t(p["atom_offsets"], np.int64)
+    d_sig, d_org = t(p["sigmas"], np.float32), t(origins, np.float64)
+    d_box, max_images = None, 1
+    if p["box"] is not None:
+        d_box = t(p["box"], np.float32)
+        max_images = batch.max_images_per_atom(p["box"], nv, p["voxelsize"])
+    out = torch.empty((B, V, C), dtype=torch.float32, device=dev)
+
+    def step():
+        batch.voxelize_lattice_torch(d_coords, d_offs, d_sig, d_org, nv, p["voxelsize"], box=d_box,
+                                     max_images=max_images, out=out, ctx=ctx)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()                     # also surfaces asynchronous errors of the warm-up
+    ctx.enable_kernel_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.enable_kernel_timing(False)
+    k_ms, k_n = ctx.read_kernel_timing()
+    ctx.synchronize()
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # sanity of what was produced inside the timed region (never a cached / skipped result)
+    chk = out[0].double().sum().item()
+    assert np.isfinite(chk) and chk > 0, "bench produced an empty grid"
+
+    gather_ms = None
+    if world > 1 and not args.no_gather:
+        from moleculekit_amd.distributed import gather_features
+        bounds = np.arange(world + 1) * B
+        fence()
+        g0 = time.perf_counter()
+        full = gather_features(out, bounds)
+        fence()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert full.shape[0] == world * B
+        del full
+
+    single_us = None
+    if rank == 0:
+        # latency of ONE grid (a single 64^3 grid cannot fill 256 CUs for long)
+        o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
+        n1 = int(p["atom_offsets"][1])
+        offs1 = t(p["atom_offsets"][:2], np.int64)
+        args1 = (d_coords[:n1], offs1, d_sig[:n1], d_org[:1], nv, p["voxelsize"])
+        kw1 = dict(box=None if d_box is None else d_box[:1], max_images=max_images, out=o1, ctx=ctx)
+        for _ in range(3):
+            batch.voxelize_lattice_torch(*args1, **kw1)
+        torch.cuda.synchronize(dev)
+        s0 = time.perf_counter()
+        for _ in range(20):
+            batch.voxelize_lattice_torch(*args1, **kw1)
+        torch.cuda.synchronize(dev)
+        single_us = (time.perf_counter() - s0) / 20 * 1e6
+
+    if rank == 0:
+        total_vc = world * B * V * C * args.steps
+        alg = algorithmic_bytes(p, nv, C)
+        k_avg_ms = k_ms / max(k_n, 1)
+        achieved = alg / (k_avg_ms * 1e-3) / 1e9 if k_n else None
+        info = ctx.device_info()
+        line = {
+            "metric": "Mvoxel-channels/s (64^3 grid, 8 ch)" if args.workload == "cfg2" else f"Mvoxel-channels/s ({args.workload})",
+            "value": round(total_vc / elapsed / 1e6, 2),
+            "unit": "Mvoxel-channels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: BASELINE.json configs[{int(args.workload[3:]) - 1}]",
+                       "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
+                       "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
+                       "periodic": p["box"] is not None, "tile_k": args.tile_k, "parallelism": f"dp{world} (items sharded, no collective in the timed region)",
+                       "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                         "traffic": None, "kernel": "k_voxelize_tiles", "kernel_avg_ms": round(k_avg_ms, 5),
+                         "kernel_launches": int(k_n), "algorithmic_bytes_per_launch": int(alg)},
+            "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if k_n else None,
+            "single_grid_latency_us": round(single_us, 2) if single_us else None,
+            "gather_ms": round(gather_ms, 3) if gather_ms is not None else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

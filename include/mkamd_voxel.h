@@ -1,0 +1,125 @@
+/*
+ * mkamd_voxel.h -- C ABI of libmkamd.so: MI355X (gfx950) voxel-descriptor kernels.
+ *
+ * This is the drop-in boundary for ONE hot path of Acellera/moleculekit:
+ *   moleculekit.occupancy_utils.calculate_occupancy          (occupancy_utils/occupancy_utils.pyx:34-61)
+ *   called from tools.voxeldescriptors._getOccupancyC         (tools/voxeldescriptors.py:515-533)
+ *   under tools.voxeldescriptors.getVoxelDescriptors          (tools/voxeldescriptors.py:251-365)
+ *   with lattice centres from getCenters/_getGridCenters      (tools/voxeldescriptors.py:125-132,197-248)
+ *   and, for periodic frames, the orthorhombic minimum image  (distance_utils/distance_utils.pyx:49-52).
+ *
+ * Plain pointers and sizes only (no torch / numpy types).  Every function returns an int status
+ * (MKAMD_OK == 0) and never throws; mkamd_last_error() gives the message for the calling thread.
+ * All device work is enqueued on the context's HIP stream.  "_host" entry points take host
+ * pointers, copy in/out and synchronise; "_dev" entry points take device pointers, are
+ * asynchronous and leave results resident in HBM.
+ *
+ * Array layouts (all C-contiguous):
+ *   coords   float32 [N,3]          (Molecule.coords[:, :, frame], molecule.py:205-232)
+ *   sigmas   float64|float32 [N,C]  per-atom per-channel radius, 0 = atom not in channel
+ *                                   (voxeldescriptors.py:332-335)
+ *   centers  float64 [V,3]
+ *   features float32 [V,C]          voxel-major / channel-minor, V flattened x slowest, z fastest
+ *                                   (same order as the reference's float64 [V,C], voxeldescriptors.py:531)
+ */
+#ifndef MKAMD_VOXEL_H
+#define MKAMD_VOXEL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKAMD_OK 0
+#define MKAMD_EINVAL 1    /* bad argument (message says which) */
+#define MKAMD_EHIP 2      /* HIP runtime error */
+#define MKAMD_ENODEV 3    /* no usable GPU */
+#define MKAMD_EOVERFLOW 4 /* more periodic images than max_images_per_atom allowed */
+#define MKAMD_EBOX 5      /* periodic box edge <= 2 x cutoff (10 A) or too many images */
+
+typedef struct mkamd_ctx mkamd_ctx;
+
+/* library / device --------------------------------------------------------------------------- */
+const char* mkamd_version(void);
+const char* mkamd_last_error(void);
+int mkamd_device_count(int* count);
+
+/* One context per device (and per host thread that wants to drive it concurrently). Owns the
+ * workspace (cell lists, staging buffers) and a HIP stream. */
+int mkamd_ctx_create(int device, mkamd_ctx** ctx);
+int mkamd_ctx_destroy(mkamd_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
+ * the context's own stream. */
+int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream);
+/* Wait for the stream and report asynchronous errors of "_dev" calls (MKAMD_EOVERFLOW/EBOX). */
+int mkamd_ctx_synchronize(mkamd_ctx* ctx);
+/* name (<= len bytes), compute units, HBM bytes, gcn arch string e.g. "gfx950..." */
+int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_units,
+                          uint64_t* hbm_bytes, char* arch, size_t arch_len);
+/* Tile depth K (x-planes per lane) of the lattice kernel: 0 = automatic, 4 or 8. */
+int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k);
+/* Per-kernel timing of the tile kernel with HIP events on the context's stream (bench.py's
+ * roofline leg): enable, run, then read back the accumulated time and launch count (resets). */
+int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable);
+int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* launches);
+
+/* (1) calculate_occupancy, exact reference contract -------------------------------------------
+ * Replaces occupancy_utils.pyx:34-61: for every centre/channel
+ *     results[v,c] = max(results[v,c], max_a{ 1-exp(-(sigmas[a,c]/|coords[a]-centers[v]|)^12) :
+ *                                               |.|^2 < 25, sigmas[a,c] != 0 })
+ * max-accumulating IN PLACE into the caller's float64 results (caller zero-fills, voxeldescriptors.py:531).
+ * Distances are evaluated in double on the GPU; values are float32-accurate (<= 1e-6 abs). */
+int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t n_centers,
+                              const float* coords, int64_t n_atoms, const double* sigmas,
+                              int32_t n_channels, double* results);
+
+/* (2) explicit (arbitrary) centres, float32 output, optional orthorhombic box (double[3], A;
+ * NULL = not periodic).  sigmas_are_f64: 1 -> const double*, 0 -> const float*. */
+int mkamd_occupancy_centers_host(mkamd_ctx* ctx, const double* centers, int64_t n_centers,
+                                 const float* coords, int64_t n_atoms, const void* sigmas,
+                                 int sigmas_are_f64, int32_t n_channels, const double* box,
+                                 float* features);
+int mkamd_occupancy_centers_dev(mkamd_ctx* ctx, const double* d_centers, int64_t n_centers,
+                                const float* d_coords, int64_t n_atoms, const void* d_sigmas,
+                                int sigmas_are_f64, int32_t n_channels, const double* box_host,
+                                float* d_features);
+
+/* (3) lattice grids, batched: the hot path ------------------------------------------------------
+ * B independent items (molecules / poses / trajectory frames) packed back to back:
+ *   coords        float32 [sumN,3]
+ *   atom_offsets  int64   [B+1]      item b owns atoms [atom_offsets[b], atom_offsets[b+1])
+ *   sigmas        [sumN,C]
+ *   origins       float64 [B,3]      bb_min of item b: voxel (0,0,0)'s centre (getCenters :234-243;
+ *                                    NO half-voxel shift, voxel i sits at origin + i*voxelsize)
+ *   nvoxels       int32   [3]        grid size shared by the batch (getCenters :236-242)
+ *   box           float32 [B,3] or NULL: per-item orthorhombic box (Molecule.box[:, frame]); when
+ *                                    given, coord-centre is minimum-imaged (every edge must be > 10 A)
+ *   features      float32 [B,V,C]    V = nx*ny*nz
+ * max_images_per_atom bounds the periodic images of one atom that can fall inside the grid+halo
+ * (1 when every box edge >= grid extent + 10 A; ignored without box).  Pass 0 to let the "_host"
+ * variant compute it from the boxes. */
+int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t n_items, const float* coords,
+                                const int64_t* atom_offsets, const void* sigmas,
+                                int sigmas_are_f64, int32_t n_channels, const double* origins,
+                                const int32_t* nvoxels, double voxelsize, const float* box,
+                                int32_t max_images_per_atom, float* features);
+int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_coords,
+                               const int64_t* d_atom_offsets, int64_t total_atoms,
+                               const void* d_sigmas, int sigmas_are_f64, int32_t n_channels,
+                               const double* d_origins, const int32_t* nvoxels, double voxelsize,
+                               const float* d_box, int32_t max_images_per_atom,
+                               float* d_features);
+
+/* (4) lattice centres (voxeldescriptors.py:125-132 + :245-247), float64 [V,3], bit-exact with the
+ * reference's numpy arithmetic: centre = fl64(index*voxelsize) + bb_min. */
+int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels,
+                            double voxelsize, double* centers);
+int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels,
+                           double voxelsize, double* d_centers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKAMD_VOXEL_H */

@@ -1,0 +1,195 @@
+"""ctypes binding of ``libmkamd.so`` -- the C ABI declared in ``include/mkamd_voxel.h``.
+
+The library holds the hand-written HIP kernels (gfx950) of the voxel-descriptor hot path.  There
+is NO CPU compute path behind this module: if the shared library is missing, or no MI355X/HIP
+device is visible, every compute entry point raises ``RuntimeError`` -- loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MKAMD_LIB", os.path.join(_HERE, "csrc", "libmkamd.so"))
+
+MKAMD_OK, MKAMD_EINVAL, MKAMD_EHIP, MKAMD_ENODEV, MKAMD_EOVERFLOW, MKAMD_EBOX = range(6)
+
+_c_int, _c_i32, _c_i64, _c_dbl, _vp = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+
+# name -> (restype, argtypes): every symbol include/mkamd_voxel.h declares
+SIGNATURES = {
+    "mkamd_version": (ctypes.c_char_p, []),
+    "mkamd_last_error": (ctypes.c_char_p, []),
+    "mkamd_device_count": (_c_int, [ctypes.POINTER(_c_int)]),
+    "mkamd_ctx_create": (_c_int, [_c_int, ctypes.POINTER(_vp)]),
+    "mkamd_ctx_destroy": (_c_int, [_vp]),
+    "mkamd_ctx_set_stream": (_c_int, [_vp, _vp]),
+    "mkamd_ctx_synchronize": (_c_int, [_vp]),
+    "mkamd_ctx_device_info": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_c_int),
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
+    "mkamd_ctx_set_tile_k": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
+    "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
+    "mkamd_occupancy_centers_host": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp]),
+    "mkamd_occupancy_centers_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp]),
+    "mkamd_voxelize_lattice_host": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl,
+                                             _vp, _c_i32, _vp]),
+    "mkamd_voxelize_lattice_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
+                                            _c_dbl, _vp, _c_i32, _vp]),
+    "mkamd_grid_centers_host": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
+    "mkamd_grid_centers_dev": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> ctypes.CDLL:
+    """Load libmkamd.so (built by ``__graft_entry__.build()`` / ``moleculekit_amd._build``)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"moleculekit_amd: HIP library not found at {LIB_PATH}. Build it with "
+                    f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                    f"There is no CPU fallback.")
+            L = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(L, name)          # AttributeError if a declared symbol is missing
+                fn.restype, fn.argtypes = res, args
+            _lib = L
+    return _lib
+
+
+class MkamdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmkamd error {code}: {msg}")
+        self.code = code
+
+
+def _check(st):
+    if st != MKAMD_OK:
+        msg = load().mkamd_last_error().decode(errors="replace")
+        if st == MKAMD_EINVAL:
+            raise ValueError(f"libmkamd: {msg}")
+        raise MkamdError(st, msg)
+
+
+def device_count() -> int:
+    n = _c_int(0)
+    st = load().mkamd_device_count(ctypes.byref(n))
+    return n.value if st == MKAMD_OK else 0
+
+
+def _ptr(a):
+    """void* of a numpy array / int address / None."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(_vp)
+    return _vp(int(a))
+
+
+class Context:
+    """One device context (``mkamd_ctx``): a HIP stream plus a grow-only workspace."""
+
+    def __init__(self, device: int = 0):
+        self._h = _vp(None)
+        L = load()
+        h = _vp(None)
+        _check(L.mkamd_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            load().mkamd_ctx_destroy(self._h)
+            self._h = _vp(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- control -----------------------------------------------------------------------------
+    def set_stream(self, hip_stream):
+        _check(load().mkamd_ctx_set_stream(self._h, _vp(int(hip_stream) if hip_stream else None)))
+
+    def synchronize(self):
+        _check(load().mkamd_ctx_synchronize(self._h))
+
+    def set_tile_k(self, k: int):
+        _check(load().mkamd_ctx_set_tile_k(self._h, int(k)))
+
+    def enable_kernel_timing(self, on=True):
+        _check(load().mkamd_ctx_enable_kernel_timing(self._h, int(bool(on))))
+
+    def read_kernel_timing(self):
+        ms, n = _c_dbl(0.0), _c_i64(0)
+        _check(load().mkamd_ctx_read_kernel_timing(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        arch = ctypes.create_string_buffer(256)
+        cus, mem = _c_int(0), ctypes.c_uint64(0)
+        _check(load().mkamd_ctx_device_info(self._h, name, 256, ctypes.byref(cus), ctypes.byref(mem), arch, 256))
+        return dict(name=name.value.decode(), arch=arch.value.decode(), compute_units=cus.value,
+                    hbm_bytes=int(mem.value))
+
+    # -- compute (raw pointers; see moleculekit_amd.batch for the numpy/torch wrappers) ---------
+    def calculate_occupancy(self, centers, coords, sigmas, results):
+        V, N, C = centers.shape[0], coords.shape[0], sigmas.shape[1]
+        _check(load().mkamd_calculate_occupancy(self._h, _ptr(centers), V, _ptr(coords), N, _ptr(sigmas), C,
+                                                _ptr(results)))
+
+    def occupancy_centers_host(self, centers, coords, sigmas, sig_f64, C, box, out):
+        _check(load().mkamd_occupancy_centers_host(self._h, _ptr(centers), centers.shape[0], _ptr(coords),
+                                                   coords.shape[0], _ptr(sigmas), int(sig_f64), C, _ptr(box),
+                                                   _ptr(out)))
+
+    def occupancy_centers_dev(self, d_centers, V, d_coords, N, d_sigmas, sig_f64, C, box_host, d_out):
+        _check(load().mkamd_occupancy_centers_dev(self._h, _ptr(d_centers), V, _ptr(d_coords), N, _ptr(d_sigmas),
+                                                  int(sig_f64), C, _ptr(box_host), _ptr(d_out)))
+
+    def voxelize_lattice_host(self, B, coords, offsets, sigmas, sig_f64, C, origins, nvox, voxelsize, box,
+                              max_images, out):
+        _check(load().mkamd_voxelize_lattice_host(self._h, B, _ptr(coords), _ptr(offsets), _ptr(sigmas),
+                                                  int(sig_f64), C, _ptr(origins), _ptr(nvox), float(voxelsize),
+                                                  _ptr(box), int(max_images), _ptr(out)))
+
+    def voxelize_lattice_dev(self, B, d_coords, d_offsets, total_atoms, d_sigmas, sig_f64, C, d_origins, nvox,
+                             voxelsize, d_box, max_images, d_out):
+        _check(load().mkamd_voxelize_lattice_dev(self._h, B, _ptr(d_coords), _ptr(d_offsets), int(total_atoms),
+                                                 _ptr(d_sigmas), int(sig_f64), C, _ptr(d_origins), _ptr(nvox),
+                                                 float(voxelsize), _ptr(d_box), int(max_images), _ptr(d_out)))
+
+    def grid_centers_host(self, bb_min, nvox, voxelsize, out):
+        _check(load().mkamd_grid_centers_host(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(out)))
+
+    def grid_centers_dev(self, bb_min, nvox, voxelsize, d_out):
+        _check(load().mkamd_grid_centers_dev(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(d_out)))
+
+
+_contexts = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    """Per-(process, device) shared context. ``device=None`` -> LOCAL_RANK env or 0."""
+    if device is None:
+        device = int(os.environ.get("MKAMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device %= n
+    key = (os.getpid(), int(device))
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = Context(device)
+        _contexts[key] = ctx
+    return ctx

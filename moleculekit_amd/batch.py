@@ -1,0 +1,196 @@
+"""Batched / device-resident entry points of the voxel-descriptor hot path.
+
+The reference voxelizes ONE molecule per Python call (tools/voxeldescriptors.py:251-365).  On an
+MI355X a single 24^3 grid is far too small to fill 256 CUs, so the native unit of work here is a
+BATCH of independent items (ligand poses, molecules of a virtual screen, trajectory frames) packed
+back to back and voxelized by one launch sequence of ``libmkamd.so``.
+
+Two flavours:
+  * numpy in / numpy out           -> ``voxelize_lattice``        (H2D + kernels + D2H)
+  * torch CUDA tensors in / out    -> ``voxelize_lattice_torch``  (inputs and features stay in HBM;
+                                      this is what bench.py and ML data loaders use)
+torch is plumbing only here: it owns device memory and the stream; all compute is in the HIP library.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+CUTOFF = 5.0  # A; occupancy_utils.pyx:53
+
+
+def pack_items(coords_list, sigmas_list):
+    """Pack per-item arrays back to back -> (coords f32 [sumN,3], sigmas [sumN,C], offsets i64 [B+1])."""
+    ns = [int(np.asarray(c).shape[0]) for c in coords_list]
+    offs = np.zeros(len(ns) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(ns)
+    if len(ns) == 0:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 1), np.float64), offs
+    coords = np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, 3) for c in coords_list])
+    sig = np.concatenate([np.asarray(s) for s in sigmas_list])
+    return coords, sig, offs
+
+
+def max_images_per_atom(box, nvoxels, voxelsize) -> int:
+    """Upper bound on the periodic images of one atom inside grid + cutoff halo (include/mkamd_voxel.h)."""
+    box = np.asarray(box, dtype=np.float64).reshape(-1, 3)
+    if box.size == 0:
+        return 1
+    if not np.all(box > 2 * CUTOFF):
+        raise ValueError("periodic box edges must be > 10 A (2 x cutoff)")
+    span = (np.maximum(np.asarray(nvoxels, dtype=np.float64) - 1, 0)) * voxelsize + 2 * CUTOFF + 2e-3 * voxelsize
+    m = np.prod(np.floor(span[None, :] / box) + 1, axis=1)
+    return int(m.max())
+
+
+def _sigma_array(sigmas):
+    sigmas = np.asarray(sigmas)
+    if sigmas.dtype == np.float32:
+        return np.ascontiguousarray(sigmas), 0
+    return np.ascontiguousarray(sigmas, dtype=np.float64), 1
+
+
+def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None, out=None, ctx=None):
+    """Voxelize B packed items onto identical lattice grids (host arrays in, float32 out).
+
+    coords f32 [sumN,3]; atom_offsets i64 [B+1]; sigmas f64|f32 [sumN,C]; origins f64 [B,3] =
+    position of voxel (0,0,0) of each item (``bb_min`` of getCenters, voxeldescriptors.py:234-243);
+    nvoxels (3,); box f32 [B,3] or None (orthorhombic minimum image, distance_utils.pyx:49-52).
+    Returns features float32 [B, V, C], V flattened x slowest / z fastest (reference layout).
+    """
+    ctx = ctx or _lib.default_context()
+    coords = np.ascontiguousarray(coords, dtype=np.float32).reshape(-1, 3)
+    atom_offsets = np.ascontiguousarray(atom_offsets, dtype=np.int64)
+    sigmas, sig64 = _sigma_array(sigmas)
+    if sigmas.ndim != 2 or sigmas.shape[0] != coords.shape[0]:
+        raise ValueError("sigmas must be (natoms, nchannels) matching coords")
+    origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    B = origins.shape[0]
+    if atom_offsets.shape != (B + 1,) or (B >= 0 and atom_offsets[-1] != coords.shape[0]):
+        raise ValueError("atom_offsets must have B+1 entries ending at the total atom count")
+    nv = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
+    C = int(sigmas.shape[1])
+    V = int(np.prod(nv.astype(np.int64)))
+    bx = None
+    if box is not None:
+        bx = np.ascontiguousarray(box, dtype=np.float32).reshape(B, 3)
+    if out is None:
+        out = np.empty((B, V, C), dtype=np.float32)
+    elif out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size != B * V * C:
+        raise ValueError("out must be a C-contiguous float32 array of B*V*C elements")
+    ctx.voxelize_lattice_host(B, coords, atom_offsets, sigmas, sig64, C, origins, nv, float(voxelsize), bx, 0, out)
+    return out.reshape(B, V, C)
+
+
+def occupancy_centers(centers, coords, sigmas, box=None, ctx=None):
+    """Arbitrary (non-lattice) centres: float32 [V, C] occupancies (calculate_occupancy semantics)."""
+    ctx = ctx or _lib.default_context()
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    sigmas, sig64 = _sigma_array(sigmas)
+    if centers.ndim != 2 or centers.shape[1] != 3 or coords.ndim != 2 or coords.shape[1] != 3:
+        raise ValueError("centers and coords must be (n, 3)")
+    if sigmas.ndim != 2 or sigmas.shape[0] != coords.shape[0]:
+        raise ValueError("sigmas must be (natoms, nchannels) matching coords")
+    out = np.empty((centers.shape[0], sigmas.shape[1]), dtype=np.float32)
+    bx = None if box is None else np.ascontiguousarray(box, dtype=np.float64).reshape(3)
+    ctx.occupancy_centers_host(centers, coords, sigmas, sig64, int(sigmas.shape[1]), bx, out)
+    return out
+
+
+def grid_centers(bb_min, nvoxels, voxelsize, ctx=None):
+    """float64 [V,3] lattice centres generated on the GPU, bit-exact with getCenters."""
+    ctx = ctx or _lib.default_context()
+    bb = np.ascontiguousarray(bb_min, dtype=np.float64).reshape(3)
+    nv = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
+    out = np.empty((int(np.prod(nv.astype(np.int64))), 3), dtype=np.float64)
+    ctx.grid_centers_host(bb, nv, float(voxelsize), out)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident flavour (torch tensors are only containers for HBM pointers)
+# ------------------------------------------------------------------------------------------------
+def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None,
+                           max_images=1, out=None, ctx=None, channel_first=False):
+    """Same as ``voxelize_lattice`` on torch CUDA tensors; asynchronous on torch's current stream.
+
+    coords float32 [sumN,3], atom_offsets int64 [B+1], sigmas float32|float64 [sumN,C],
+    origins float64 [B,3], box float32 [B,3] or None (pass ``max_images`` from
+    ``max_images_per_atom`` when the box is smaller than grid + 10 A).
+    Returns float32 [B,V,C] on the same device (or [B,C,nx,ny,nz] when ``channel_first``).
+    """
+    import torch
+
+    dev = coords.device
+    if dev.type != "cuda":
+        raise RuntimeError("voxelize_lattice_torch needs CUDA/HIP tensors (there is no CPU path)")
+    ctx = ctx or _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+    assert coords.dtype == torch.float32 and coords.is_contiguous()
+    assert atom_offsets.dtype == torch.int64 and atom_offsets.is_contiguous()
+    assert sigmas.dtype in (torch.float32, torch.float64) and sigmas.is_contiguous() and sigmas.dim() == 2
+    assert origins.dtype == torch.float64 and origins.is_contiguous()
+    B = int(origins.shape[0])
+    C = int(sigmas.shape[1])
+    nv = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
+    V = int(np.prod(nv.astype(np.int64)))
+    if out is None:
+        out = torch.empty((B, V, C), dtype=torch.float32, device=dev)
+    else:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == B * V * C
+    d_box = None
+    if box is not None:
+        assert box.dtype == torch.float32 and box.is_contiguous()
+        d_box = box.data_ptr()
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    ctx.voxelize_lattice_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]),
+                             sigmas.data_ptr(), sigmas.dtype == torch.float64, C, origins.data_ptr(), nv,
+                             float(voxelsize), d_box, int(max_images), out.data_ptr())
+    out = out.view(B, V, C)
+    if channel_first:   # what the reference's tutorial builds by hand before nn.Conv3d
+        return out.view(B, int(nv[0]), int(nv[1]), int(nv[2]), C).permute(0, 4, 1, 2, 3)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# convenience wrappers in the reference's vocabulary
+# ------------------------------------------------------------------------------------------------
+def getVoxelDescriptorsBatch(coords_list, channels_list, centers, boxsize, voxelsize=1, boxes=None, ctx=None):
+    """Batch analogue of ``getVoxelDescriptors(None, boxsize=..., center=..., usercoords=...,
+    userchannels=...)``: item b is voxelized on a ``boxsize`` box centred on ``centers[b]``.
+
+    Returns (features float32 [B,V,C], origins float64 [B,3], nvoxels int64 (3,)).
+    """
+    boxsize = np.array(boxsize, dtype=np.float64)
+    centers = np.asarray(centers, dtype=np.float64).reshape(-1, 3)
+    nvoxels = np.ceil(boxsize / voxelsize).astype(int)          # voxeldescriptors.py:242
+    origins = centers - boxsize / 2                             # voxeldescriptors.py:243
+    coords, sig, offs = pack_items(coords_list, channels_list)
+    feats = voxelize_lattice(coords, offs, sig, origins, nvoxels, voxelsize, box=boxes, ctx=ctx)
+    return feats, origins, nvoxels.astype(np.int64)
+
+
+def voxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None, frames=None, ctx=None):
+    """All frames of a trajectory: coords float32 [N,3,F] (Molecule.coords), channels [N,C] sigma
+    matrix shared by the frames, box float32 [3,F] (Molecule.box) or None.  Periodic frames use the
+    orthorhombic minimum image of distance_utils.pyx:49-52 per frame.
+    Returns (features float32 [F,V,C], origin float64 (3,), nvoxels)."""
+    coords = np.asarray(coords, dtype=np.float32)
+    if coords.ndim != 3 or coords.shape[1] != 3:
+        raise ValueError("coords must be (natoms, 3, nframes)")
+    fr = np.arange(coords.shape[2]) if frames is None else np.asarray(frames)
+    F, N = len(fr), coords.shape[0]
+    packed = np.ascontiguousarray(np.transpose(coords[:, :, fr], (2, 0, 1))).reshape(F * N, 3)
+    sig = np.asarray(channels)
+    sig_all = np.ascontiguousarray(np.broadcast_to(sig[None], (F,) + sig.shape)).reshape(F * N, sig.shape[1])
+    offs = np.arange(F + 1, dtype=np.int64) * N
+    boxsize = np.array(boxsize, dtype=np.float64)
+    nvoxels = np.ceil(boxsize / voxelsize).astype(int)
+    origin = np.asarray(center, dtype=np.float64) - boxsize / 2
+    bx = None
+    if box is not None:
+        bx = np.ascontiguousarray(np.asarray(box, dtype=np.float32)[:, fr].T)
+    feats = voxelize_lattice(packed, offs, sig_all, np.broadcast_to(origin, (F, 3)), nvoxels, voxelsize,
+                             box=bx, ctx=ctx)
+    return feats, origin, nvoxels.astype(np.int64)

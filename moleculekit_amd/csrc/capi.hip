@@ -1,0 +1,419 @@
+// capi.hip -- extern "C" boundary of libmkamd.so (see include/mkamd_voxel.h) and the HIP backend
+// that drives the launch sequences of pipeline.h on an MI355X.  One context = one device, one
+// stream, one grow-only workspace.  No CPU compute path exists here: without a GPU every entry
+// point fails with MKAMD_ENODEV / MKAMD_EHIP.
+#include "../../include/mkamd_voxel.h"
+#include "pipeline.h"
+
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace mkamd;
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+static int hip_fail(hipError_t e, const char* what)
+{
+    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MKAMD_ENODEV : MKAMD_EHIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+struct mkamd_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    void* bufs[WS_NSLOTS] = {};
+    size_t caps[WS_NSLOTS] = {};
+    int tile_k = 0;
+    // tile-kernel timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    hipEvent_t cur0 = nullptr, cur1 = nullptr;
+    int launch_status = 0;
+
+    // ---- backend concept (pipeline.h) ----
+    int ensure(int slot, size_t bytes, void** ptr)
+    {
+        if (bytes == 0) bytes = 16;
+        if (caps[slot] < bytes) {
+            if (bufs[slot]) {
+                HIP_TRY(hipStreamSynchronize(stream));       // buffer may still be in use
+                HIP_TRY(hipFree(bufs[slot]));
+                bufs[slot] = nullptr; caps[slot] = 0;
+            }
+            const size_t want = bytes + bytes / 4 + 256;     // grow-only, 25 % slack
+            hipError_t e = hipMalloc(&bufs[slot], want);
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
+            caps[slot] = want;
+        }
+        *ptr = bufs[slot];
+        return 0;
+    }
+    int zero(void* p, size_t bytes)
+    {
+        HIP_TRY(hipMemsetAsync(p, 0, bytes, stream));
+        return 0;
+    }
+    template <class... KA, class... A>
+    int launch(void (*kernel)(KA...), dim3 grid, dim3 block, A... args)
+    {
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    void hot_begin()
+    {
+        if (!timing) return;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!ev_free.empty()) { ev = ev_free.back(); ev_free.pop_back(); }
+        else {
+            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return;
+        }
+        cur0 = ev.first; cur1 = ev.second;
+        (void)hipEventRecord(cur0, stream);
+    }
+    void hot_end()
+    {
+        if (!timing || !cur0) return;
+        (void)hipEventRecord(cur1, stream);
+        ev_used.emplace_back(cur0, cur1);
+        cur0 = cur1 = nullptr;
+    }
+};
+
+static int check_ctx(mkamd_ctx* ctx)
+{
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+// read + clear the device-side error flag (after the stream has been synchronised)
+static int collect_async_errors(mkamd_ctx* ctx)
+{
+    if (!ctx->bufs[WS_ERR]) return 0;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, ctx->bufs[WS_ERR], sizeof(int), hipMemcpyDeviceToHost));
+    if (flag == 0) return 0;
+    HIP_TRY(hipMemset(ctx->bufs[WS_ERR], 0, sizeof(int)));
+    if (flag & MK_ERR_BAD_BOX) return fail(MKAMD_EBOX, "periodic box edges must be > 10 A (2 x cutoff)");
+    if (flag & MK_ERR_TOO_MANY_IMAGES) return fail(MKAMD_EBOX, "periodic box much smaller than the grid (too many images)");
+    return fail(MKAMD_EOVERFLOW, "more periodic images than max_images_per_atom allowed; results are incomplete");
+}
+
+static int ensure_err_flag(mkamd_ctx* ctx)
+{
+    if (ctx->bufs[WS_ERR]) return 0;
+    void* p = nullptr;
+    int st = ctx->ensure(WS_ERR, sizeof(int), &p);
+    if (st) return st;
+    HIP_TRY(hipMemsetAsync(p, 0, sizeof(int), ctx->stream));
+    return 0;
+}
+
+extern "C" {
+
+const char* mkamd_version(void) { return "moleculekit_amd 0.1.0 (gfx950, HIP)"; }
+
+const char* mkamd_last_error(void) { return g_last_error.c_str(); }
+
+int mkamd_device_count(int* count)
+{
+    if (!count) return fail(MKAMD_EINVAL, "count is NULL");
+    *count = 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+    *count = n;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_create(int device, mkamd_ctx** out)
+{
+    if (!out) return fail(MKAMD_EINVAL, "ctx out-pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MKAMD_ENODEV, std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    if (device < 0 || device >= n) return fail(MKAMD_EINVAL, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mkamd_ctx* c = new mkamd_ctx();
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
+    c->stream = c->own_stream;
+    *out = c;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_destroy(mkamd_ctx* ctx)
+{
+    if (!ctx) return MKAMD_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < WS_NSLOTS; ++i)
+        if (ctx->bufs[i]) (void)hipFree(ctx->bufs[i]);
+    for (auto& ev : ctx->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : ctx->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next == ctx->stream) return MKAMD_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));      // workspace is shared between the two streams
+    ctx->stream = next;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_synchronize(mkamd_ctx* ctx)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return collect_async_errors(ctx);
+}
+
+int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_units,
+                          uint64_t* hbm_bytes, char* arch, size_t arch_len)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, ctx->device));
+    if (name && len) { strncpy(name, p.name, len - 1); name[len - 1] = 0; }
+    if (arch && arch_len) { strncpy(arch, p.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k)
+{
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (k != 0 && k != 4 && k != 8) return fail(MKAMD_EINVAL, "tile K must be 0 (auto), 4 or 8");
+    ctx->tile_k = k;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    ctx->timing = enable != 0;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* launches)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& ev : ctx->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; ++n; }
+        ctx->ev_free.push_back(ev);
+    }
+    ctx->ev_used.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return MKAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// explicit centres
+// ---------------------------------------------------------------------------------------------
+int mkamd_occupancy_centers_dev(mkamd_ctx* ctx, const double* d_centers, int64_t n_centers,
+                                const float* d_coords, int64_t n_atoms, const void* d_sigmas,
+                                int sigmas_are_f64, int32_t n_channels, const double* box_host,
+                                float* d_features)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n_centers > 0 && (!d_centers || !d_features)) return fail(MKAMD_EINVAL, "centers/features pointer is NULL");
+    if (n_atoms > 0 && (!d_coords || !d_sigmas)) return fail(MKAMD_EINVAL, "coords/sigmas pointer is NULL");
+    std::string err;
+    st = run_centers(*ctx, d_centers, n_centers, d_coords, n_atoms, d_sigmas, sigmas_are_f64, n_channels,
+                     box_host, d_features, err);
+    if (st && !err.empty()) return fail(st, err);
+    return st;
+}
+
+int mkamd_occupancy_centers_host(mkamd_ctx* ctx, const double* centers, int64_t V, const float* coords,
+                                 int64_t N, const void* sigmas, int sigmas_are_f64, int32_t C,
+                                 const double* box, float* features)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
+    if (V == 0) return MKAMD_OK;
+    if (!centers || !features) return fail(MKAMD_EINVAL, "centers/features pointer is NULL");
+    if (N > 0 && (!coords || !sigmas)) return fail(MKAMD_EINVAL, "coords/sigmas pointer is NULL");
+    const size_t sz = sigmas_are_f64 ? 8 : 4;
+    void *dc = nullptr, *dx = nullptr, *ds = nullptr, *dout = nullptr;
+    if ((st = ctx->ensure(WS_H_CENTERS, (size_t)V * 24, &dc))) return st;
+    if ((st = ctx->ensure(WS_H_COORDS, (size_t)N * 12, &dx))) return st;
+    if ((st = ctx->ensure(WS_H_SIGMAS, (size_t)N * C * sz, &ds))) return st;
+    if ((st = ctx->ensure(WS_H_OUT, (size_t)V * C * 4, &dout))) return st;
+    HIP_TRY(hipMemcpyAsync(dc, centers, (size_t)V * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (N > 0) {
+        HIP_TRY(hipMemcpyAsync(dx, coords, (size_t)N * 12, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ds, sigmas, (size_t)N * C * sz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    st = mkamd_occupancy_centers_dev(ctx, (const double*)dc, V, (const float*)dx, N, ds, sigmas_are_f64, C, box, (float*)dout);
+    if (st) return st;
+    HIP_TRY(hipMemcpyAsync(features, dout, (size_t)V * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+}
+
+int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t V, const float* coords,
+                              int64_t N, const double* sigmas, int32_t C, double* results)
+{
+    if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
+    if (V == 0 || N == 0) return ctx ? MKAMD_OK : fail(MKAMD_EINVAL, "ctx is NULL");
+    if (!results) return fail(MKAMD_EINVAL, "results pointer is NULL");
+    std::vector<float> tmp((size_t)V * C);
+    int st = mkamd_occupancy_centers_host(ctx, centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data());
+    if (st) return st;
+    // in-place max-accumulate, `value > old ? value : old` as occupancy_utils.pyx:61
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        const double v = (double)tmp[i];
+        if (v > results[i]) results[i] = v;
+    }
+    return MKAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lattice grids (the hot path)
+// ---------------------------------------------------------------------------------------------
+int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
+                               const int64_t* d_atom_offsets, int64_t total_atoms, const void* d_sigmas,
+                               int sigmas_are_f64, int32_t C, const double* d_origins,
+                               const int32_t* nvoxels, double voxelsize, const float* d_box,
+                               int32_t max_images, float* d_features)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (!nvoxels) return fail(MKAMD_EINVAL, "nvoxels pointer is NULL");
+    if (B > 0 && (!d_atom_offsets || !d_origins || !d_features)) return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
+    if (total_atoms > 0 && (!d_coords || !d_sigmas)) return fail(MKAMD_EINVAL, "coords/sigmas pointer is NULL");
+    if ((st = ensure_err_flag(ctx))) return st;
+    LatticeProblem P;
+    P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
+    P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
+    P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
+    P.tile_k = ctx->tile_k;
+    P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
+    P.origins = d_origins; P.box = d_box; P.out = d_features;
+    std::string err;
+    st = run_lattice(*ctx, P, err);
+    if (st && !err.empty()) return fail(st, err);
+    return st;
+}
+
+int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                const int32_t* nvoxels, double voxelsize, const float* box,
+                                int32_t max_images, float* features)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (B < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_items must be >= 0 and n_channels > 0");
+    if (!nvoxels) return fail(MKAMD_EINVAL, "nvoxels pointer is NULL");
+    if (nvoxels[0] < 0 || nvoxels[1] < 0 || nvoxels[2] < 0) return fail(MKAMD_EINVAL, "nvoxels must be >= 0");
+    const long long V = (long long)nvoxels[0] * nvoxels[1] * nvoxels[2];
+    if (B == 0 || V == 0) return MKAMD_OK;
+    if (!atom_offsets || !origins || !features) return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
+    if (atom_offsets[0] != 0) return fail(MKAMD_EINVAL, "atom_offsets[0] must be 0");
+    for (int b = 0; b < B; ++b)
+        if (atom_offsets[b + 1] < atom_offsets[b]) return fail(MKAMD_EINVAL, "atom_offsets must be non-decreasing");
+    const int64_t N = atom_offsets[B];
+    if (N > 0 && (!coords || !sigmas)) return fail(MKAMD_EINVAL, "coords/sigmas pointer is NULL");
+    if (box && max_images <= 0) {
+        std::string err;
+        const int nv[3] = {nvoxels[0], nvoxels[1], nvoxels[2]};
+        max_images = max_images_from_boxes(box, B, nv, voxelsize, err);
+        if (max_images < 0) return fail(MKAMD_EBOX, err);
+    }
+    const size_t sz = sigmas_are_f64 ? 8 : 4;
+    const size_t out_bytes = (size_t)B * (size_t)V * (size_t)C * 4;
+    void *dx = nullptr, *ds = nullptr, *doff = nullptr, *dorg = nullptr, *dbox = nullptr, *dout = nullptr;
+    if ((st = ctx->ensure(WS_H_COORDS, (size_t)N * 12, &dx))) return st;
+    if ((st = ctx->ensure(WS_H_SIGMAS, (size_t)N * C * sz, &ds))) return st;
+    if ((st = ctx->ensure(WS_H_OFFSETS, (size_t)(B + 1) * 8, &doff))) return st;
+    if ((st = ctx->ensure(WS_H_ORIGINS, (size_t)B * 24, &dorg))) return st;
+    if (box && (st = ctx->ensure(WS_H_BOX, (size_t)B * 12, &dbox))) return st;
+    if ((st = ctx->ensure(WS_H_OUT, out_bytes, &dout))) return st;
+    if (N > 0) {
+        HIP_TRY(hipMemcpyAsync(dx, coords, (size_t)N * 12, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ds, sigmas, (size_t)N * C * sz, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(doff, atom_offsets, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dorg, origins, (size_t)B * 24, hipMemcpyHostToDevice, ctx->stream));
+    if (box) HIP_TRY(hipMemcpyAsync(dbox, box, (size_t)B * 12, hipMemcpyHostToDevice, ctx->stream));
+    st = mkamd_voxelize_lattice_dev(ctx, B, (const float*)dx, (const int64_t*)doff, N, ds, sigmas_are_f64, C,
+                                    (const double*)dorg, nvoxels, voxelsize, box ? (const float*)dbox : nullptr,
+                                    max_images, (float*)dout);
+    if (st) return st;
+    HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return collect_async_errors(ctx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lattice centres
+// ---------------------------------------------------------------------------------------------
+int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels, double voxelsize,
+                           double* d_centers)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (!bb_min || !nvoxels) return fail(MKAMD_EINVAL, "bb_min/nvoxels pointer is NULL");
+    const int nv[3] = {nvoxels[0], nvoxels[1], nvoxels[2]};
+    std::string err;
+    st = run_grid_centers(*ctx, bb_min, nv, voxelsize, d_centers, err);
+    if (st && !err.empty()) return fail(st, err);
+    return st;
+}
+
+int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels, double voxelsize,
+                            double* centers)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (!bb_min || !nvoxels) return fail(MKAMD_EINVAL, "bb_min/nvoxels pointer is NULL");
+    if (nvoxels[0] < 0 || nvoxels[1] < 0 || nvoxels[2] < 0) return fail(MKAMD_EINVAL, "nvoxels must be >= 0");
+    const long long V = (long long)nvoxels[0] * nvoxels[1] * nvoxels[2];
+    if (V == 0) return MKAMD_OK;
+    if (!centers) return fail(MKAMD_EINVAL, "centers pointer is NULL");
+    void* dc = nullptr;
+    if ((st = ctx->ensure(WS_H_CENTERS, (size_t)V * 24, &dc))) return st;
+    if ((st = mkamd_grid_centers_dev(ctx, bb_min, nvoxels, voxelsize, (double*)dc))) return st;
+    HIP_TRY(hipMemcpyAsync(centers, dc, (size_t)V * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+}
+
+}  // extern "C"

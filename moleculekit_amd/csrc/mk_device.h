@@ -1,0 +1,73 @@
+// mk_device.h -- gfx950 (CDNA4) device primitives used by kernels.h.
+//
+// Thin named wrappers over the wave64 / LDS / VALU builtins so that the kernels read in the
+// domain's terms.  wave = 64 lanes everywhere (MI355X); nothing here is portable on purpose.
+//
+// (tests/emu/ holds a host-thread SIMT emulation that shadows this header so the SAME kernel
+//  source can be exercised on a CPU-only box by the test-suite; it is test infrastructure and
+//  is never built into libmkamd.so.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MK_DEV __device__ __forceinline__
+#define MK_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+
+typedef float v2f __attribute__((ext_vector_type(2)));   // -> v_pk_{add,mul,fma}_f32
+
+namespace mkamd {
+
+constexpr int WAVE = 64;
+
+MK_DEV float mk_inf() { return __builtin_inff(); }
+
+// 64-bit lane mask of `pred` over the wave.
+MK_DEV unsigned long long mk_ballot(bool pred) { return __ballot(pred); }
+
+// number of set bits of `mask` below this lane (v_mbcnt_lo/hi).
+MK_DEV int mk_rank_in_mask(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+MK_DEV int mk_popc64(unsigned long long m) { return __popcll(m); }
+
+// v_rcp_f32 (1 ulp) + one Newton step -> ~0.5 ulp; rcp(inf)=0, rcp(0)=inf preserved.
+MK_DEV float mk_rcp_refined(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);          // 1 - x*r  (NaN when x*r is inf*0)
+    float r2 = __builtin_fmaf(r, e, r);
+    return (e == e) ? r2 : r;                       // keep 0 / inf results of the raw rcp
+}
+
+MK_DEV float mk_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
+
+MK_DEV float mk_min(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32: NaN-ignoring
+// min of a running bit pattern with a non-negative float (v_min_u32; see k_voxelize_tiles)
+MK_DEV unsigned mk_min_bits(unsigned q, float t)
+{
+    const unsigned b = __float_as_uint(t);
+    return b < q ? b : q;
+}
+MK_DEV float mk_uint_as_float(unsigned u) { return __uint_as_float(u); }
+
+// workgroup barrier (for the 64-thread tile kernel this is a single-wave s_barrier).
+MK_DEV void mk_block_sync() { __syncthreads(); }
+
+MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
+MK_DEV void mk_atomic_or(int* p, int v) { atomicOr(p, v); }
+
+MK_DEV unsigned mk_shfl_up(unsigned v, int delta) { return __shfl_up(v, delta, WAVE); }
+MK_DEV unsigned mk_shfl_down(unsigned v, int delta) { return __shfl_down(v, delta, WAVE); }
+
+// separately rounded double multiply / add (never contracted into an FMA)
+MK_DEV double mk_dmul_rn(double a, double b) { return __dmul_rn(a, b); }
+MK_DEV double mk_dadd_rn(double a, double b) { return __dadd_rn(a, b); }
+
+MK_DEV float mk_int_as_float(int i) { return __int_as_float(i); }
+MK_DEV int mk_float_as_int(float f) { return __float_as_int(f); }
+
+}  // namespace mkamd

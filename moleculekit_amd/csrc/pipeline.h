@@ -1,0 +1,224 @@
+// pipeline.h -- host-side planning and launch sequences for the kernels in kernels.h.
+//
+// Written against a small "backend" concept so the exact same planning / launch code drives
+//   * the HIP backend in capi.hip (the product: MI355X, one stream per context), and
+//   * the host-thread SIMT emulation under tests/emu (test infrastructure, CPU-only boxes).
+//
+// Backend concept:
+//   int  ensure(int slot, size_t bytes, void** ptr)     grow-only workspace buffer
+//   int  zero(void* p, size_t bytes)                    async memset on the stream
+//   int  launch(kernel, dim3 grid, dim3 block, args...) async launch on the stream
+//   void hot_begin() / hot_end()                        bracket the tile kernel (event timing)
+#pragma once
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <string>
+
+namespace mkamd {
+
+enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
+
+enum WsSlot {
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_ERR, WS_W_EXPLICIT,
+    // staging for the "_host" entry points
+    WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
+    WS_NSLOTS
+};
+
+constexpr double CUTOFF_A = 5.0;            // occupancy_utils.pyx:53 (d^2 < 25)
+
+struct LatticeProblem {
+    int B = 0;
+    long long total_atoms = 0;
+    int C = 0;
+    int sigmas_f64 = 0;
+    int nvox[3] = {0, 0, 0};
+    double voxelsize = 1.0;
+    int pbc = 0;
+    int max_images = 1;
+    int tile_k = 0;                         // 0 = auto
+    // device pointers
+    const float* coords = nullptr;
+    const long long* atom_offsets = nullptr;
+    const void* sigmas = nullptr;
+    const double* origins = nullptr;
+    const float* box = nullptr;
+    float* out = nullptr;
+};
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Fill the GridDesc for a batch; returns ST_OK or ST_EINVAL with a message.
+inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
+{
+    char buf[256];
+    if (P.B < 0 || P.total_atoms < 0 || P.C <= 0) { err = "n_items/total_atoms must be >= 0 and n_channels > 0"; return ST_EINVAL; }
+    if (!(P.voxelsize > 0.0) || !std::isfinite(P.voxelsize)) { err = "voxelsize must be a positive finite number"; return ST_EINVAL; }
+    for (int ax = 0; ax < 3; ++ax)
+        if (P.nvox[ax] < 0) { err = "nvoxels must be >= 0"; return ST_EINVAL; }
+    g = GridDesc{};
+    g.nx = P.nvox[0]; g.ny = P.nvox[1]; g.nz = P.nvox[2];
+    g.V = (long long)g.nx * g.ny * g.nz;
+    g.C = P.C; g.G = ceil_div(P.C, CHG);
+    g.B = P.B; g.pbc = P.pbc ? 1 : 0;
+    g.inv_res = 1.0 / P.voxelsize;
+    g.w_scale = P.voxelsize * P.voxelsize;
+    const double R = CUTOFF_A / P.voxelsize;                 // cutoff in voxel units
+    g.R2 = (float)(R * R);
+    g.R2cull = (float)(R * R * 1.0002 + 1e-3);
+    g.Rp = R + 1e-3;
+    g.rint = (int)std::ceil(R);
+    if (g.rint > 512) { err = "voxelsize too small (cutoff spans > 512 voxels)"; return ST_EINVAL; }
+    g.cs_log2 = 3;
+    while ((1 << g.cs_log2) < g.rint && g.cs_log2 < 9) ++g.cs_log2;
+    g.cs = 1 << g.cs_log2;
+    g.h = ceil_div((long long)g.rint + 1, g.cs);
+    g.ncx = ceil_div(g.nx, g.cs) + 2 * g.h;
+    g.ncy = ceil_div(g.ny, g.cs) + 2 * g.h;
+    g.ncz = ceil_div(g.nz, g.cs) + 2 * g.h;
+    if (g.ncx > 1023 || g.ncy > 1023 || g.ncz > 1023) { err = "grid too large (more than 1023 cells per axis)"; return ST_EINVAL; }
+    const long long ncell = (long long)g.ncx * g.ncy * g.ncz;
+    if (ncell * (long long)(P.B > 0 ? P.B : 1) > 0xFFFF0000LL) {
+        snprintf(buf, sizeof buf, "batch too large: %lld cells x %d items exceeds 2^32; split the batch", ncell, P.B);
+        err = buf; return ST_EINVAL;
+    }
+    g.ncell = (int)ncell;
+
+    // tile depth: K=8 unless the x extent pads badly or the launch would be too small to fill 256 CUs
+    int K = P.tile_k;
+    if (K != 4 && K != 8) {
+        const long long pad8 = (long long)ceil_div(g.nx, 8) * 8, pad4 = (long long)ceil_div(g.nx, 4) * 4;
+        const long long tiles8 = (long long)ceil_div(g.nx, 8) * ceil_div(g.ny, 8) * ceil_div(g.nz, 8) * P.B * g.G;
+        K = (pad4 < pad8 || tiles8 < 2048) ? 4 : 8;
+    }
+    g.K = K;
+    g.tnx = ceil_div(g.nx, K); g.tny = ceil_div(g.ny, 8); g.tnz = ceil_div(g.nz, 8);
+    const long long ntiles = (long long)g.tnx * g.tny * g.tnz;
+    if (ntiles * (long long)(P.B > 0 ? P.B : 1) > 0x7FFFFF00LL) { err = "batch too large: more than 2^31 tiles; split the batch"; return ST_EINVAL; }
+    g.ntiles = (int)ntiles;
+
+    long long images = 1;
+    if (g.pbc) {
+        if (P.max_images < 1) { err = "max_images_per_atom must be >= 1 for periodic items"; return ST_EINVAL; }
+        images = P.max_images;
+    }
+    const long long M = P.total_atoms * images;
+    if (M > 0xFFFF0000LL) { err = "batch too large: more than 2^32 atom records; split the batch"; return ST_EINVAL; }
+    g.M = (unsigned)(M > 0 ? M : 1);
+    return ST_OK;
+}
+
+// upper bound on periodic images of one atom inside grid+halo, from host-known boxes [B,3] (A)
+inline int max_images_from_boxes(const float* box, int B, const int* nvox, double voxelsize, std::string& err)
+{
+    long long worst = 1;
+    for (int b = 0; b < B; ++b) {
+        long long m = 1;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double L = (double)box[3 * b + ax];
+            if (!(L > 2.0 * CUTOFF_A)) { err = "periodic box edges must be > 10 A (2 x cutoff)"; return -1; }
+            const double span = (double)(nvox[ax] > 0 ? nvox[ax] - 1 : 0) * voxelsize + 2.0 * CUTOFF_A + 2e-3 * voxelsize;
+            m *= (long long)std::floor(span / L) + 1;
+        }
+        if (m > worst) worst = m;
+    }
+    if (worst > 4096) { err = "periodic box much smaller than the grid (more than 4096 images per atom)"; return -1; }
+    return (int)worst;
+}
+
+template <class BE>
+int run_scan(BE& be, const unsigned* counts, size_t n, unsigned* starts /* n+1 */)
+{
+    const size_t nchunks = (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    void* chunks = nullptr;
+    int st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks);
+    if (st) return st;
+    if ((st = be.launch(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (unsigned*)chunks))) return st;
+    if ((st = be.launch(k_scan_sums_inplace, dim3(1), dim3(SCAN_THREADS), (unsigned*)chunks, (unsigned)nchunks))) return st;
+    return be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (const unsigned*)chunks, starts);
+}
+
+// The lattice hot path: bin -> scan -> fill -> tile kernel.  All pointers in P are device pointers.
+template <class BE>
+int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
+{
+    GridDesc g;
+    int st = plan_lattice(P, g, err);
+    if (st) return st;
+    if (P.B == 0 || g.V == 0) return ST_OK;
+
+    const size_t ncells = (size_t)g.B * (size_t)g.ncell;
+    void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *eflag = nullptr;
+    if ((st = be.ensure(WS_CELL_COUNT, ncells * sizeof(unsigned), &count))) return st;
+    if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start))) return st;
+    if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos))) return st;
+    if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw))) return st;
+    if ((st = be.ensure(WS_ERR, sizeof(int), &eflag))) return st;
+
+    if ((st = be.zero(count, ncells * sizeof(unsigned)))) return st;
+    const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
+#define MK_BIN(PHASE)                                                                                   \
+    (P.sigmas_f64                                                                                       \
+         ? be.launch(k_bin_atoms<PHASE, double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, \
+                     (const double*)P.sigmas, P.origins, P.box, (unsigned*)count, (const unsigned*)start, \
+                     (float4*)rpos, (float4*)rw, (int*)eflag)                                            \
+         : be.launch(k_bin_atoms<PHASE, float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms,  \
+                     (const float*)P.sigmas, P.origins, P.box, (unsigned*)count, (const unsigned*)start,  \
+                     (float4*)rpos, (float4*)rw, (int*)eflag))
+    if (P.total_atoms > 0 && (st = MK_BIN(0))) return st;
+    if ((st = run_scan(be, (const unsigned*)count, ncells, (unsigned*)start))) return st;
+    if (P.total_atoms > 0 && (st = MK_BIN(1))) return st;
+#undef MK_BIN
+
+    const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
+    const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G), tblk(WAVE);
+    be.hot_begin();
+    if (g.K == 8)
+        st = be.launch(k_voxelize_tiles<8>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, P.out);
+    else
+        st = be.launch(k_voxelize_tiles<4>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, P.out);
+    be.hot_end();
+    return st;
+}
+
+// Explicit centres: sigma -> w, then the brute-force double-precision kernel.
+template <class BE>
+int run_centers(BE& be, const double* d_centers, long long V, const float* d_coords, long long N,
+                const void* d_sigmas, int sigmas_f64, int C, const double* box_host, float* d_out,
+                std::string& err)
+{
+    if (V < 0 || N < 0 || C <= 0) { err = "n_centers/n_atoms must be >= 0 and n_channels > 0"; return ST_EINVAL; }
+    if (V == 0) return ST_OK;
+    if (box_host)
+        for (int ax = 0; ax < 3; ++ax)
+            if (!(box_host[ax] > 2.0 * CUTOFF_A)) { err = "periodic box edges must be > 10 A (2 x cutoff)"; return ST_EBOX; }
+    const int G = ceil_div(C, CHG);
+    void* w = nullptr;
+    int st = be.ensure(WS_W_EXPLICIT, (size_t)(N > 0 ? N : 1) * sizeof(float4) * 2 * G, &w);
+    if (st) return st;
+    if (N > 0) {
+        const dim3 blk(256), grid((unsigned)ceil_div(N, 256));
+        st = sigmas_f64 ? be.launch(k_sigma_to_w<double>, grid, blk, (const double*)d_sigmas, N, C, G, 1.0, (float4*)w)
+                        : be.launch(k_sigma_to_w<float>, grid, blk, (const float*)d_sigmas, N, C, G, 1.0, (float4*)w);
+        if (st) return st;
+    }
+    const dim3 grid((unsigned)ceil_div(V, EXPL_THREADS), (unsigned)G), blk(EXPL_THREADS);
+    return be.launch(k_occupancy_centers, grid, blk, d_centers, V, d_coords, N, (const float4*)w, C,
+                     box_host ? 1 : 0, box_host ? box_host[0] : 0.0, box_host ? box_host[1] : 0.0,
+                     box_host ? box_host[2] : 0.0, d_out);
+}
+
+template <class BE>
+int run_grid_centers(BE& be, const double* bb_min, const int* nvox, double voxelsize, double* d_centers,
+                     std::string& err)
+{
+    if (nvox[0] < 0 || nvox[1] < 0 || nvox[2] < 0) { err = "nvoxels must be >= 0"; return ST_EINVAL; }
+    const long long V = (long long)nvox[0] * nvox[1] * nvox[2];
+    if (V == 0) return ST_OK;
+    return be.launch(k_grid_centers, dim3((unsigned)ceil_div(V, 256)), dim3(256), bb_min[0], bb_min[1],
+                     bb_min[2], nvox[0], nvox[1], nvox[2], voxelsize, d_centers);
+}
+
+}  // namespace mkamd

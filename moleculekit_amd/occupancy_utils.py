@@ -1,0 +1,43 @@
+"""``calculate_occupancy`` with the exact call contract of the reference's Cython kernel
+(moleculekit/occupancy_utils/occupancy_utils.pyx:34-61), executed on the MI355X.
+
+    calculate_occupancy(centers f64 [V,3], coords f32 [N,3], sigmas f64 [N,C], results f64 [V,C])
+
+max-accumulates IN PLACE into ``results`` and returns ``None``.  Like the typed-memoryview
+signature of the reference it raises ``ValueError`` on a dtype / ndim mismatch instead of converting.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def _require(name, a, dtype, ndim=2):
+    if not isinstance(a, np.ndarray):
+        raise TypeError(f"{name}: a numpy array is required")
+    if a.dtype != dtype:
+        raise ValueError(f"Buffer dtype mismatch for {name}: expected {np.dtype(dtype).name}, got {a.dtype.name}")
+    if a.ndim != ndim:
+        raise ValueError(f"Buffer has wrong number of dimensions for {name} (expected {ndim}, got {a.ndim})")
+
+
+def calculate_occupancy(centers, coords, sigmas, results, ctx=None):
+    _require("centers", centers, np.float64)
+    _require("coords", coords, np.float32)
+    _require("sigmas", sigmas, np.float64)
+    _require("results", results, np.float64)
+    V, N, C = centers.shape[0], coords.shape[0], sigmas.shape[1]
+    if centers.shape[1] != 3 or coords.shape[1] != 3 or sigmas.shape[0] != N or results.shape != (V, C):
+        raise ValueError("shape mismatch: centers [V,3], coords [N,3], sigmas [N,C], results [V,C]")
+    ctx = ctx or _lib.default_context()
+    cen = np.ascontiguousarray(centers)
+    xyz = np.ascontiguousarray(coords)
+    sig = np.ascontiguousarray(sigmas)
+    if results.flags["C_CONTIGUOUS"]:
+        ctx.calculate_occupancy(cen, xyz, sig, results)
+    else:  # strided memoryviews are legal in the reference
+        tmp = np.ascontiguousarray(results)
+        ctx.calculate_occupancy(cen, xyz, sig, tmp)
+        results[...] = tmp
+    return None

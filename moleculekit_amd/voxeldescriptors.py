@@ -1,0 +1,224 @@
+"""Drop-in for the voxel-descriptor path of ``moleculekit.tools.voxeldescriptors`` on MI355X.
+
+Same function names, arguments, error behaviour and returned ndarray layout as the reference
+(tools/voxeldescriptors.py): ``getVoxelDescriptors`` (:251-365), ``getCenters`` (:197-248),
+``rotateCoordinates`` (:78-114), ``_getGridCenters`` (:125-132), ``_getChannelRadii`` (:117-121),
+``_getOccupancyC`` (:515-533).  The occupancy computation itself runs in hand-written HIP kernels
+behind ``libmkamd.so`` (``method="C"`` -- the reference's only accepted value -- and ``method="HIP"``
+both select them; there is no CPU implementation in this package).
+
+Return order is the reference's: ``(features, centers)`` with ``usercenters`` else
+``(features, centers, nvoxels)``; features float64 ``[V, C]`` (float32-accurate values, <= 1e-5
+from the reference's float64), V flattened x slowest / z fastest, channel order ``_order``.
+
+Out of scope here: automatic atom typing (``getChannels``), which the
+reference builds on RDKit/OpenBabel -- pass ``userchannels`` (bool masks or float sigmas), or have
+moleculekit installed, in which case its own ``getChannels`` is used to produce them.
+"""
+from __future__ import annotations
+
+import logging
+from functools import lru_cache
+
+import numpy as np
+
+from . import batch as _batch
+from .util import boundingBox, rotationMatrix
+
+logger = logging.getLogger(__name__)
+
+_order = (
+    "hydrophobic", "aromatic", "hbond_acceptor", "hbond_donor",
+    "positive_ionizable", "negative_ionizable", "metal", "occupancies",
+)
+
+
+def rotateCoordinates(coords, rotations, center):
+    """Rotate ``coords`` (natoms, 3) about ``center`` by the angles ``rotations=[rx, ry, rz]``
+    (radians), applied one after the other around x, then y, then z (voxeldescriptors.py:78-114)."""
+    angles = list(rotations)
+    out = np.array(coords, copy=True)
+    for axis, ang in zip(([1, 0, 0], [0, 1, 0], [0, 0, 1]), angles):
+        rot = rotationMatrix(axis, ang)
+        out = np.dot(out - center, np.transpose(rot)) + center
+    return out
+
+
+def _getChannelRadii(molelements):
+    """Per-atom van der Waals radius from the element symbols (voxeldescriptors.py:117-121)."""
+    from ._vdw_radii import VDW_RADIUS
+
+    return np.array([VDW_RADIUS[e] for e in molelements])
+
+
+@lru_cache(maxsize=10)
+def _getGridCenters(x, y, z, resolution):
+    """Lattice offsets ``index * resolution`` as float64 [x, y, z, 3] (voxeldescriptors.py:125-132);
+    z is the fastest axis.  Cached like the reference (same grids recur for every molecule)."""
+    out = np.empty((int(x), int(y), int(z), 3), dtype=np.float64)
+    out[..., 0] = (np.arange(x) * resolution)[:, None, None]
+    out[..., 1] = (np.arange(y) * resolution)[None, :, None]
+    out[..., 2] = (np.arange(z) * resolution)[None, None, :]
+    return out
+
+
+def _gridSpec(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
+    """bb_min and nvoxels of the grid ``getCenters`` would build (voxeldescriptors.py:232-243).
+
+    bbox branch: float32 min/max of the coordinates, expanded by ``buffer`` IN float32, one extra
+    voxel (`+1`); boxsize branch: ``ceil(boxsize/voxelsize)`` voxels starting at center-boxsize/2.
+    Voxel 0's centre sits AT bb_min (no half-voxel shift)."""
+    if boxsize is None:
+        bb_min, bb_max = boundingBox(mol)
+        bb_min -= buffer
+        bb_max += buffer
+        nvoxels = np.ceil((bb_max - bb_min) / voxelsize).astype(int) + 1
+    else:
+        boxsize = np.array(boxsize)
+        center = np.array(center)
+        nvoxels = np.ceil(boxsize / voxelsize).astype(int)
+        bb_min = center - (boxsize / 2)
+    return bb_min, nvoxels
+
+
+def getCenters(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
+    """Voxel centres for voxelization: (centers float64 [V,3], nvoxels int (3,)) -- same arguments
+    and results as the reference (voxeldescriptors.py:197-248)."""
+    bb_min, nvoxels = _gridSpec(mol, buffer, boxsize, center, voxelsize)
+    centers = _getGridCenters(*list(nvoxels), voxelsize) + bb_min
+    centers = centers.reshape(np.prod(nvoxels), 3).copy()
+    return centers, nvoxels
+
+
+def _channels_from_moleculekit(mol, aromaticNitrogen, version, validitychecks):
+    try:
+        from moleculekit.tools.voxeldescriptors import getChannels
+    except Exception as e:  # pragma: no cover - depends on the user's environment
+        raise NotImplementedError(
+            "Automatic channel assignment (getChannels: RDKit/OpenBabel atom typing) is outside this "
+            "package's scope; pass `userchannels` (bool masks or float sigmas), or install moleculekit "
+            "so its getChannels can be used.") from e
+    return getChannels(mol, aromaticNitrogen, version, validitychecks)
+
+
+def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, usercenters=None,
+                        userchannels=None, usercoords=None, aromaticNitrogen=False, method="C",
+                        version=2, validitychecks=True):
+    """Voxel descriptors of a molecule -- the reference's signature and semantics
+    (voxeldescriptors.py:251-365), computed on the MI355X.
+
+    Returns ``(features, centers)`` when ``usercenters`` is given, else
+    ``(features, centers, nvoxels)``.
+    """
+    channels = userchannels
+    if channels is None:
+        channels, mol = _channels_from_moleculekit(mol, aromaticNitrogen, version, validitychecks)
+    channels = np.asarray(channels)
+
+    if channels.dtype == bool:   # bool masks -> per-channel sigma = vdW radius of the atom (:332-335)
+        sigmas = _getChannelRadii(mol.element)
+        channels = sigmas[:, np.newaxis] * channels.astype(float)
+
+    nvoxels = None
+    lattice = None
+    centers = usercenters
+    if centers is None:
+        bb_min, nvoxels = _gridSpec(mol, buffer, boxsize, center, voxelsize)
+        centers = _getGridCenters(*list(nvoxels), voxelsize) + bb_min
+        centers = centers.reshape(np.prod(nvoxels), 3).copy()
+        lattice = (np.asarray(bb_min, dtype=np.float64), nvoxels, voxelsize)
+
+    coords = usercoords
+    if coords is None:
+        coords = mol.get("coords")
+    coords = np.asarray(coords)
+    if coords.ndim == 3:
+        if coords.shape[2] != 1:
+            raise RuntimeError(
+                "Only a single set of coordinates should be passed for voxelixation. "
+                "Make sure your coordinates are either 3D with a last dim of 1 or 2D.")
+        coords = coords[:, :, 0]
+
+    if method.upper() in ("C", "HIP"):
+        features = _getOccupancyC(coords, centers, channels, _lattice=lattice)
+    else:
+        raise RuntimeError("As of moleculekit 0.9.2 we only support C implementation of voxelization")
+
+    if nvoxels is None:
+        return features, centers
+    return features, centers, nvoxels
+
+
+def _lattice_from_centers(centers):
+    """Recognise a getCenters-style lattice in an explicit (V,3) centre list.
+
+    Returns (bb_min float64 (3,), nvoxels int (3,), voxelsize) when ``centers`` equals, to ~1e-9 A,
+    ``bb_min + index*voxelsize`` in x-slowest / z-fastest order; else None."""
+    c = np.asarray(centers, dtype=np.float64)
+    V = c.shape[0]
+    if c.ndim != 2 or c.shape[1] != 3 or V < 2:
+        return None
+    z = c[:, 2]
+    breaks = np.nonzero(z[1:] <= z[:-1])[0]
+    nz = int(breaks[0]) + 1 if breaks.size else V
+    if V % nz:
+        return None
+    y = c[::nz, 1]
+    breaks = np.nonzero(y[1:] <= y[:-1])[0]
+    ny = int(breaks[0]) + 1 if breaks.size else y.shape[0]
+    if (V // nz) % ny:
+        return None
+    nx = V // (nz * ny)
+    steps = []
+    if nz > 1:
+        steps.append(c[1, 2] - c[0, 2])
+    if ny > 1:
+        steps.append(c[nz, 1] - c[0, 1])
+    if nx > 1:
+        steps.append(c[nz * ny, 0] - c[0, 0])
+    if not steps or not all(s > 0 for s in steps):
+        return None
+    vs = float(steps[0])
+    if any(abs(s - vs) > 1e-9 * max(1.0, abs(vs)) for s in steps):
+        return None
+    rebuilt = (_getGridCenters(nx, ny, nz, vs) + c[0]).reshape(V, 3)
+    tol = 1e-9 * max(1.0, float(np.abs(c).max()))
+    if np.abs(rebuilt - c).max() > tol:
+        return None
+    return c[0].copy(), np.array([nx, ny, nz]), vs
+
+
+def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
+    """Occupancy of every (centre, channel): float64 [V, C] -- the job of the reference's
+    ``_getOccupancyC`` (voxeldescriptors.py:515-533), executed by the HIP kernels.
+
+    Lattice centres (known from getCenters, or recognised in the array) take the tiled lattice
+    kernel; arbitrary centres take the explicit-centre kernel."""
+    coords = np.ascontiguousarray(np.asarray(coords).astype(np.float32))
+    centers = np.ascontiguousarray(np.asarray(centers).astype(np.float64))
+    channelsigmas = np.ascontiguousarray(np.asarray(channelsigmas).astype(np.float64))
+    if coords.ndim != 2 or coords.shape[1] != 3 or centers.ndim != 2 or centers.shape[1] != 3:
+        raise ValueError("coords and centers must be (n, 3) arrays")
+    if channelsigmas.ndim != 2 or channelsigmas.shape[0] != coords.shape[0]:
+        raise ValueError("channel sigmas must be (natoms, nchannels)")
+    lattice = _lattice if _lattice is not None else _lattice_from_centers(centers)
+    if lattice is not None:
+        bb_min, nvoxels, voxelsize = lattice
+        offs = np.array([0, coords.shape[0]], dtype=np.int64)
+        feats = _batch.voxelize_lattice(coords, offs, channelsigmas, np.asarray(bb_min, np.float64)[None, :],
+                                        nvoxels, voxelsize)[0]
+    else:
+        feats = _batch.occupancy_centers(centers, coords, channelsigmas)
+    return feats.astype(np.float64)
+
+
+def install():
+    """Make an installed moleculekit use the MI355X kernels: swaps
+    ``moleculekit.tools.voxeldescriptors._getOccupancyC`` (the sole caller of the Cython kernel,
+    voxeldescriptors.py:356) for this module's.  Returns the original function."""
+    import moleculekit.tools.voxeldescriptors as ref
+
+    original = ref._getOccupancyC
+    ref._getOccupancyC = lambda coords, centers, channelsigmas: _getOccupancyC(coords, centers, channelsigmas)
+    ref._getOccupancyC_reference = original
+    return original

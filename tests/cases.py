@@ -1,0 +1,207 @@
+"""Parity cases shared by the CPU (emulated-kernel) tier and the GPU tier.
+
+Each case is a dict: coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box (or None) and
+``expected`` float64 [B,V,C] -- either straight from a golden fixture (outputs of the REAL
+reference, tests/golden/make_golden.py) or computed by the oracle on the same seeded inputs.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from oracle import oracle
+from tests.synth import grid_origin, synth_config, synth_sigmas
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5   # BASELINE.json north_star: outputs within 1e-5 of the reference (float32 path)
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def oracle_lattice(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None):
+    B = len(atom_offsets) - 1
+    out = []
+    for b in range(B):
+        s, e = int(atom_offsets[b]), int(atom_offsets[b + 1])
+        centers = oracle.grid_centers(origins[b], nvoxels, voxelsize)
+        out.append(oracle.calculate_occupancy(centers, coords[s:e], sigmas[s:e],
+                                              box=None if box is None else box[b]))
+    return np.stack(out) if out else np.zeros((0, int(np.prod(nvoxels)), sigmas.shape[1]))
+
+
+def _case(coords, offs, sigmas, origins, nvox, vs, box=None, expected=None):
+    coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
+    offs = np.asarray(offs, np.int64)
+    origins = np.asarray(origins, np.float64).reshape(-1, 3)
+    nvox = np.asarray(nvox, np.int64)
+    if expected is None:
+        expected = oracle_lattice(coords, offs, np.asarray(sigmas, np.float64), origins, nvox, vs, box)
+    return dict(coords=coords, atom_offsets=offs, sigmas=sigmas, origins=origins, nvoxels=nvox,
+                voxelsize=float(vs), box=box, expected=expected)
+
+
+# ---- golden-backed cases (expected = real reference output) ---------------------------------------
+def case_cfg1_3ptb():
+    g = golden("cfg1_3ptb.npz")
+    o, nv = grid_origin(g["center"], g["boxsize"], 1.0)
+    assert np.array_equal(nv, g["nvoxels"])
+    return _case(g["coords"], [0, len(g["coords"])], g["sigmas"], o[None], nv, 1.0,
+                 expected=g["features"][None])
+
+
+def case_dense_mixed():
+    g = golden("dense_mixed.npz")
+    o, nv = grid_origin(g["center"], g["boxsize"], float(g["voxelsize"]))
+    return _case(g["coords"], [0, len(g["coords"])], g["sigmas"], o[None], nv, float(g["voxelsize"]),
+                 expected=g["features"][None])
+
+
+def case_cfg3_small():
+    g = golden("cfg3_small.npz")
+    o = np.stack([grid_origin(c, g["boxsize"], float(g["voxelsize"]))[0] for c in g["centers"]])
+    return _case(g["coords"], g["atom_offsets"], g["sigmas"], o, g["nvoxels"], float(g["voxelsize"]),
+                 expected=g["features"])
+
+
+def case_cfg5_small():
+    g = golden("cfg5_small.npz")
+    o = np.stack([grid_origin(c, g["boxsize"], float(g["voxelsize"]))[0] for c in g["centers"]])
+    return _case(g["coords"], g["atom_offsets"], g["sigmas"], o, g["nvoxels"], float(g["voxelsize"]),
+                 expected=g["features"])
+
+
+def case_pbc_small():
+    g = golden("pbc_small.npz")
+    o, nv = grid_origin(g["center"], g["boxsize"], 1.0)
+    return _case(g["coords"], [0, len(g["coords"])], g["sigmas"], o[None], nv, 1.0,
+                 box=g["box"][None].astype(np.float32), expected=g["features"][None])
+
+
+def case_celecoxib_bbox():
+    """Reference-held fixture: getCenters(mol, buffer=1) grid + channel 7 (test_voxeldescriptors.py:41-53)."""
+    g = golden("celecoxib_ch7.npz")
+    sig = np.zeros((len(g["coords"]), 8))
+    sig[:, 7] = g["radii"] * (g["element"] != "H")
+    exp = np.zeros((1, len(g["ref_centers"]), 8))
+    exp[0, :, 7] = g["ref_features_ch7"]
+    return _case(g["coords"], [0, len(g["coords"])], sig, g["ref_centers"][0][None], g["ref_nvoxels"], 1.0,
+                 expected=exp)
+
+
+# ---- oracle-backed cases (edge cases the fixtures do not cover) -------------------------------------
+def case_ragged_batch():
+    """Ragged batch incl. EMPTY items, a single-atom item, atoms far outside the grid, odd grid dims
+    (partial tiles in every axis), float32 sigmas."""
+    rng = np.random.default_rng(21)
+    ns = [0, 1, 37, 0, 200, 5]
+    coords = [rng.normal(0, 4, size=(n, 3)).astype(np.float32) for n in ns]
+    coords[4][:20] += 100.0                      # far outside: must be dropped by the binning
+    sig = np.concatenate([synth_sigmas(rng, n) for n in ns]).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(ns)])
+    origins = rng.uniform(-9, -5, size=(len(ns), 3))
+    return _case(np.concatenate(coords), offs, sig, origins, [13, 9, 21], 1.0)
+
+
+def case_voxel07():
+    """Non-dyadic voxel size (0.7 A) and a grid smaller than one tile."""
+    rng = np.random.default_rng(22)
+    n = 80
+    c = rng.normal(0, 2.5, size=(n, 3)).astype(np.float32)
+    return _case(c, [0, n], synth_sigmas(rng, n), [[-2.1, -1.4, -2.45]], [7, 5, 8], 0.7)
+
+
+def case_voxel025():
+    """Fine grid: 0.25 A voxels -> cutoff radius 20 voxels, 32-voxel cells."""
+    rng = np.random.default_rng(23)
+    n = 25
+    c = rng.normal(0, 1.5, size=(n, 3)).astype(np.float32)
+    return _case(c, [0, n], synth_sigmas(rng, n), [[-3.0, -3.0, -3.0]], [24, 24, 24], 0.25)
+
+
+def case_channels(C):
+    """Channel counts other than 8 (channel groups: 1 -> padded group, 11 -> two groups)."""
+    rng = np.random.default_rng(24 + C)
+    n = 150
+    c = rng.normal(0, 5, size=(n, 3)).astype(np.float32)
+    s = rng.choice([0, 0, 1.1, 1.7, 1.52, 2.0], size=(n, C)).astype(np.float64)
+    return _case(c, [0, n], s, [[-8.0, -8.0, -8.0]], [16, 17, 16], 1.0)
+
+
+def case_special_sigmas():
+    """sigma = 0 everywhere for some atoms, NaN, inf, negative, tiny and huge sigmas; an atom exactly
+    ON a voxel centre (d = 0 -> value 1); atoms exactly 5 A from voxel centres (strict d^2 < 25)."""
+    c = np.array([[0, 0, 0], [2.5, 2.5, 2.5], [-3, 1, 2], [4, -4, 0.5], [1, 1, 1], [-2, -2, -2],
+                  [3, 0, 0], [0.25, 0.5, 0.75]], np.float32)
+    s = np.zeros((8, 8))
+    s[0, 7] = 1.7                # on a voxel centre; (5,0,0),(3,4,0) ... sit exactly at d = 5
+    s[1, 0] = np.nan
+    s[2, 1] = np.inf
+    s[3, 2] = -1.52
+    s[4, 3] = 1e-30
+    s[5, 4] = 40.0
+    s[6, 5] = 2.75
+    # atom 7 keeps all-zero sigmas
+    return _case(c, [0, 8], s, [[-8.0, -8.0, -8.0]], [17, 17, 17], 1.0)
+
+
+def case_pbc_batch():
+    """Periodic frames with per-frame boxes, box smaller than the grid along one axis (several
+    images of one atom inside the grid) and unwrapped coordinates."""
+    rng = np.random.default_rng(25)
+    box = np.array([[18.0, 30.0, 26.0], [21.5, 24.0, 33.0]], np.float32)
+    ns = [400, 350]
+    coords, sig = [], []
+    for b, n in enumerate(ns):
+        x = rng.uniform(0, 1, size=(n, 3)) * box[b] + rng.integers(-2, 3, size=(n, 3)) * box[b]
+        coords.append(x.astype(np.float32))
+        sig.append(synth_sigmas(rng, n))
+    offs = np.concatenate([[0], np.cumsum(ns)])
+    origins = np.array([[-3.0, 2.0, 1.0], [0.5, -1.0, 4.0]])
+    return _case(np.concatenate(coords), offs, np.concatenate(sig), origins, [24, 16, 20], 1.0, box=box)
+
+
+def case_cfg4_small():
+    """cfg4-shaped frames (BASELINE.json configs[3]) at reduced size: 3 frames x 3000 atoms, 31 A box."""
+    rng = np.random.default_rng(26)
+    L, n, F = 31.0, 3000, 3
+    x = rng.uniform(0, L, size=(n, 3))
+    frames = []
+    for _ in range(F):
+        frames.append(x.astype(np.float32))
+        x = np.mod(x + rng.normal(0, 0.3, size=(n, 3)), L)
+    s1 = synth_sigmas(rng, n)
+    offs = np.arange(F + 1) * n
+    origin = np.full(3, L / 2) - 12.0
+    return _case(np.concatenate(frames), offs, np.concatenate([s1] * F), np.broadcast_to(origin, (F, 3)),
+                 [24, 24, 24], 1.0, box=np.full((F, 3), L, np.float32))
+
+
+LATTICE_CASES = {
+    "cfg1_3ptb": case_cfg1_3ptb,
+    "dense_mixed": case_dense_mixed,
+    "cfg3_small": case_cfg3_small,
+    "cfg5_small": case_cfg5_small,
+    "pbc_small": case_pbc_small,
+    "celecoxib_bbox": case_celecoxib_bbox,
+    "ragged_batch": case_ragged_batch,
+    "voxel07": case_voxel07,
+    "voxel025": case_voxel025,
+    "channels1": lambda: case_channels(1),
+    "channels3": lambda: case_channels(3),
+    "channels11": lambda: case_channels(11),
+    "special_sigmas": case_special_sigmas,
+    "pbc_batch": case_pbc_batch,
+    "cfg4_small": case_cfg4_small,
+}
+
+
+def check(case, got, tol=TOL):
+    exp = case["expected"]
+    got = np.asarray(got, np.float64).reshape(exp.shape)
+    assert np.all(np.isfinite(got)), "non-finite output"
+    err = np.abs(got - exp)
+    assert err.max() <= tol, f"max-abs-err {err.max():.3e} > {tol:g} at {np.unravel_index(err.argmax(), err.shape)}"
+    return float(err.max())

@@ -1,0 +1,111 @@
+// tests/emu/emu_capi.cpp -- TEST INFRASTRUCTURE ONLY.
+// Drives the product's launch sequences (moleculekit_amd/csrc/pipeline.h) and kernels
+// (kernels.h) through the host SIMT emulation of emu_device.h.  Same planning code, same kernel
+// source, host memory instead of HBM.  Built into tests/emu/libmkamd_emu.so by tests/emu_build.py.
+#include "emu_device.h"
+#include "../../moleculekit_amd/csrc/pipeline.h"
+
+#include <string>
+
+using namespace mkamd;
+
+namespace {
+
+struct EmuBackend {
+    void* bufs[WS_NSLOTS] = {};
+    size_t caps[WS_NSLOTS] = {};
+    ~EmuBackend() { for (void* p : bufs) free(p); }
+    int ensure(int slot, size_t bytes, void** ptr)
+    {
+        if (bytes == 0) bytes = 16;
+        if (caps[slot] < bytes) {
+            free(bufs[slot]);
+            bufs[slot] = malloc(bytes);
+            memset(bufs[slot], 0xCD, bytes);          // poison: catch reads of unwritten workspace
+            caps[slot] = bytes;
+        }
+        *ptr = bufs[slot];
+        return 0;
+    }
+    int zero(void* p, size_t bytes) { memset(p, 0, bytes); return 0; }
+    template <class... KA, class... A>
+    int launch(void (*kernel)(KA...), dim3 grid, dim3 block, A... args)
+    {
+        emu::launch(kernel, grid, block, args...);
+        return 0;
+    }
+    void hot_begin() {}
+    void hot_end() {}
+};
+
+thread_local std::string g_err;
+
+}  // namespace
+
+extern "C" {
+
+const char* emu_last_error(void) { return g_err.c_str(); }
+
+// mirrors mkamd_voxelize_lattice_host (pointers are host pointers; features is poisoned first)
+int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offsets, const void* sigmas,
+                         int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
+                         const float* box, int max_images, int tile_k, float* features, int* err_flag_out)
+{
+    EmuBackend be;
+    void* eflag = nullptr;
+    be.ensure(WS_ERR, sizeof(int), &eflag);
+    *(int*)eflag = 0;
+    LatticeProblem P;
+    P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
+    P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k;
+    if (box && max_images <= 0) {
+        max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);
+        if (max_images < 0) return ST_EBOX;
+    }
+    P.max_images = box ? max_images : 1;
+    P.coords = coords; P.atom_offsets = atom_offsets; P.sigmas = sigmas; P.origins = origins;
+    P.box = box; P.out = features;
+    const size_t nout = (size_t)B * nvox[0] * nvox[1] * nvox[2] * C;
+    for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;
+    const int st = run_lattice(be, P, g_err);
+    if (err_flag_out) *err_flag_out = *(int*)be.bufs[WS_ERR];
+    return st;
+}
+
+int emu_occupancy_centers(const double* centers, long long V, const float* coords, long long N,
+                          const void* sigmas, int sigmas_f64, int C, const double* box, float* features)
+{
+    EmuBackend be;
+    for (long long i = 0; i < V * C; ++i) features[i] = -123.0f;
+    return run_centers(be, centers, V, coords, N, sigmas, sigmas_f64, C, box, features, g_err);
+}
+
+int emu_grid_centers(const double* bb_min, const int* nvox, double voxelsize, double* centers)
+{
+    EmuBackend be;
+    return run_grid_centers(be, bb_min, nvox, voxelsize, centers, g_err);
+}
+
+int emu_exclusive_scan(const unsigned* in, long long n, unsigned* out /* n+1 */)
+{
+    EmuBackend be;
+    return run_scan(be, in, (size_t)n, out);
+}
+
+// planning only: lets the tests inspect the GridDesc the product would use
+int emu_plan(int B, long long total_atoms, int C, const int* nvox, double voxelsize, int pbc, int max_images,
+             int tile_k, int* out_ints /* 16 */)
+{
+    LatticeProblem P;
+    P.B = B; P.total_atoms = total_atoms; P.C = C; P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
+    P.voxelsize = voxelsize; P.pbc = pbc; P.max_images = max_images; P.tile_k = tile_k;
+    GridDesc g;
+    const int st = plan_lattice(P, g, g_err);
+    if (st) return st;
+    const int v[16] = {g.K, g.tnx, g.tny, g.tnz, g.ntiles, g.cs, g.h, g.ncx, g.ncy, g.ncz, g.ncell, g.rint, g.G, (int)g.M, 0, 0};
+    memcpy(out_ints, v, sizeof v);
+    return 0;
+}
+
+}  // extern "C"

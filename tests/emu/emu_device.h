@@ -1,0 +1,202 @@
+// tests/emu/emu_device.h -- TEST INFRASTRUCTURE ONLY (never part of libmkamd.so).
+//
+// A tiny host-side SIMT emulation that lets the test-suite run the REAL kernel source
+// (moleculekit_amd/csrc/kernels.h + pipeline.h) on a CPU-only box: every GPU thread of a
+// workgroup is a ucontext fiber inside one OS thread; wave collectives (ballot, shuffles) and
+// workgroup barriers are rendezvous points at which a fiber yields until its 64-lane wave /
+// its whole block has arrived.  Workgroups run one after the other.  It exists to catch
+// indexing / tiling / binning logic errors before a GPU run -- it says nothing about
+// performance and it is not a fallback: the product library has no CPU compute path.
+//
+// It provides exactly the names the product's mk_device.h provides (and shadows that header via
+// MK_DEVICE_API_PROVIDED).
+#pragma once
+#define MK_DEVICE_API_PROVIDED 1
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ucontext.h>
+#include <vector>
+
+#define MK_DEV static inline
+#define MK_KERNEL(bounds)
+#define __shared__ static
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+// "registers" of the fiber that is currently running
+struct EmuIdx { unsigned x, y, z; };
+static EmuIdx threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+
+constexpr int MAX_THREADS = 1024;
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+struct BlockState {
+    int nthreads = 0;
+    int cur = 0;                       // running lane
+    ucontext_t sched;
+    ucontext_t ctx[MAX_THREADS];
+    bool done[MAX_THREADS];
+    char* stacks = nullptr;
+    // rendezvous state: index 0..15 = waves, 16 = whole block
+    unsigned gen[17];
+    int arrived[17];
+    unsigned long long ballot_acc[16];
+    unsigned long long ballot_res[16];
+    unsigned xchg[MAX_THREADS];
+    void (*body)(void*) = nullptr;
+    void* body_arg = nullptr;
+};
+static BlockState g_blk;
+
+static inline void yield_to_scheduler()
+{
+    const int me = g_blk.cur;
+    swapcontext(&g_blk.ctx[me], &g_blk.sched);
+    threadIdx.x = (unsigned)me;        // restored by the scheduler too; belt and braces
+}
+
+// wait until `count` fibers of group `grp` have arrived
+static inline void rendezvous(int grp, int count)
+{
+    const unsigned my_gen = g_blk.gen[grp];
+    if (++g_blk.arrived[grp] == count) {
+        g_blk.arrived[grp] = 0;
+        ++g_blk.gen[grp];
+        return;
+    }
+    while (g_blk.gen[grp] == my_gen) yield_to_scheduler();
+}
+
+static void fiber_entry()
+{
+    g_blk.body(g_blk.body_arg);
+    g_blk.done[g_blk.cur] = true;
+    swapcontext(&g_blk.ctx[g_blk.cur], &g_blk.sched);
+}
+
+template <class F>
+static void run_block(int nthreads, F& f)
+{
+    if (nthreads > MAX_THREADS || (nthreads % 64) != 0) { fprintf(stderr, "emu: bad block size %d\n", nthreads); abort(); }
+    if (!g_blk.stacks) g_blk.stacks = (char*)malloc(STACK_BYTES * MAX_THREADS);
+    g_blk.nthreads = nthreads;
+    memset(g_blk.gen, 0, sizeof g_blk.gen);
+    memset(g_blk.arrived, 0, sizeof g_blk.arrived);
+    memset(g_blk.ballot_acc, 0, sizeof g_blk.ballot_acc);
+    g_blk.body = [](void* p) { (*(F*)p)(); };
+    g_blk.body_arg = &f;
+    for (int t = 0; t < nthreads; ++t) {
+        g_blk.done[t] = false;
+        getcontext(&g_blk.ctx[t]);
+        g_blk.ctx[t].uc_stack.ss_sp = g_blk.stacks + (size_t)t * STACK_BYTES;
+        g_blk.ctx[t].uc_stack.ss_size = STACK_BYTES;
+        g_blk.ctx[t].uc_link = &g_blk.sched;
+        makecontext(&g_blk.ctx[t], (void (*)())fiber_entry, 0);
+    }
+    int remaining = nthreads;
+    long spins = 0;
+    while (remaining > 0) {
+        int progressed = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            if (g_blk.done[t]) continue;
+            g_blk.cur = t;
+            threadIdx.x = (unsigned)t; threadIdx.y = threadIdx.z = 0;
+            swapcontext(&g_blk.sched, &g_blk.ctx[t]);
+            if (g_blk.done[t]) { --remaining; ++progressed; }
+        }
+        // a block whose live fibers all wait on lanes that already exited would spin forever
+        if (!progressed && ++spins > 100000000L) { fprintf(stderr, "emu: deadlock (divergent collective?)\n"); abort(); }
+    }
+}
+
+template <class K, class... A>
+static void launch(K kernel, dim3 grid, dim3 block, A... args)
+{
+    gridDim = EmuIdx{grid.x, grid.y, grid.z};
+    blockDim = EmuIdx{block.x, block.y, block.z};
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                blockIdx = EmuIdx{bx, by, bz};
+                auto body = [&]() { kernel(args...); };
+                run_block((int)block.x, body);
+            }
+}
+
+}  // namespace emu
+
+namespace mkamd {
+
+constexpr int WAVE = 64;
+
+MK_DEV float mk_inf() { return INFINITY; }
+
+MK_DEV unsigned long long mk_ballot(bool pred)
+{
+    const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    if (pred) emu::g_blk.ballot_acc[wv] |= 1ull << lane;
+    // last arriver publishes the result and clears the accumulator
+    if (emu::g_blk.arrived[wv] == WAVE - 1) { emu::g_blk.ballot_res[wv] = emu::g_blk.ballot_acc[wv]; emu::g_blk.ballot_acc[wv] = 0; }
+    emu::rendezvous(wv, WAVE);
+    const unsigned long long r = emu::g_blk.ballot_res[wv];
+    emu::rendezvous(wv, WAVE);          // nobody starts the next ballot before everyone has read
+    return r;
+}
+MK_DEV int mk_rank_in_mask(unsigned long long mask)
+{
+    const int lane = (int)threadIdx.x & 63;
+    return __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+}
+MK_DEV int mk_popc64(unsigned long long m) { return __builtin_popcountll(m); }
+MK_DEV float mk_rcp_refined(float x)
+{
+    float r = 1.0f / x;
+    return r;
+}
+MK_DEV float mk_exp2(float x) { return exp2f(x); }
+MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
+MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+MK_DEV unsigned mk_min_bits(unsigned q, float t) { const unsigned b = mk_float_bits(t); return b < q ? b : q; }
+MK_DEV float mk_uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+MK_DEV void mk_block_sync() { emu::rendezvous(16, emu::g_blk.nthreads); }
+MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
+MK_DEV void mk_atomic_or(int* p, int v) { *p |= v; }
+MK_DEV unsigned mk_shfl_up(unsigned v, int delta)
+{
+    const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    emu::g_blk.xchg[threadIdx.x] = v;
+    emu::rendezvous(wv, WAVE);
+    const unsigned r = lane >= delta ? emu::g_blk.xchg[threadIdx.x - delta] : v;
+    emu::rendezvous(wv, WAVE);
+    return r;
+}
+MK_DEV unsigned mk_shfl_down(unsigned v, int delta)
+{
+    const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    emu::g_blk.xchg[threadIdx.x] = v;
+    emu::rendezvous(wv, WAVE);
+    const unsigned r = lane + delta < WAVE ? emu::g_blk.xchg[threadIdx.x + delta] : v;
+    emu::rendezvous(wv, WAVE);
+    return r;
+}
+MK_DEV double mk_dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+MK_DEV double mk_dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+MK_DEV float mk_int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+MK_DEV int mk_float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+
+}  // namespace mkamd

@@ -1,0 +1,73 @@
+"""CPU tier: the N>1 path (item sharding + the trivial gather) under torch.distributed/gloo with
+world_size 2.  The per-rank compute is injected (the oracle stands in for the HIP kernels, which need
+a GPU); what is under test is moleculekit_amd.distributed: partition, shard slicing, padded all-gather
+and gather-to-root, ragged shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    from moleculekit_amd import distributed as D
+    from tests.cases import oracle_lattice
+    from tests.synth import grid_origin, synth_config
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = synth_config(5, B)                    # ragged molecules (20..50 atoms)
+        origins = np.stack([grid_origin(c, p["boxsize"], 1.0)[0] for c in p["centers"]])
+        nv = np.array([10, 9, 8])
+
+        def compute(c, offs, s, o, nvox, vs, bx):
+            return torch.from_numpy(oracle_lattice(c, offs, s, o, nvox, vs, bx).astype(np.float32))
+
+        full, bounds = D.voxelize_sharded(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0,
+                                          gather=True, compute=compute)
+        local, _ = D.voxelize_sharded(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0,
+                                      gather=False, compute=compute)
+        root = D.gather_features(local, bounds, dst=0)
+        ref = oracle_lattice(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0).astype(np.float32)
+        ok = (tuple(full.shape) == ref.shape and np.array_equal(full.numpy(), ref)
+              and local.shape[0] == bounds[rank + 1] - bounds[rank]
+              and np.array_equal(local.numpy(), ref[bounds[rank]:bounds[rank + 1]])
+              and ((root is None) if rank != 0 else np.array_equal(root.numpy(), ref)))
+        q.put((rank, bool(ok), [int(b) for b in bounds]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [7, 2, 1])
+def test_sharded_voxelization_world2_gloo(B):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    b = res[0][2]
+    assert b[0] == 0 and b[-1] == B and len(b) == 3

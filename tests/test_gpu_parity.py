@@ -1,0 +1,193 @@
+"""GPU tier (-m gpu): parity tests proper.  Every case goes through the C ABI of libmkamd.so
+(ctypes) on the MI355X and is compared with the oracle / the real reference's golden outputs at
+|err| <= 1e-5 (BASELINE.json north_star tolerance; float32 GPU path vs float64 reference)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.cases import LATTICE_CASES, TOL, check, golden, oracle_lattice
+from tests.synth import grid_origin, synth_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tile_k", [0, 4, 8])
+@pytest.mark.parametrize("name", sorted(LATTICE_CASES))
+def test_lattice_case(hip_ctx, name, tile_k):
+    from moleculekit_amd import batch
+    case = LATTICE_CASES[name]()
+    hip_ctx.set_tile_k(tile_k)
+    try:
+        got = batch.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"],
+                                     case["nvoxels"], case["voxelsize"], box=case["box"], ctx=hip_ctx)
+    finally:
+        hip_ctx.set_tile_k(0)
+    check(case, got)
+
+
+@pytest.mark.parametrize("C", [1, 3, 11])
+def test_explicit_centres_golden(hip_ctx, C):
+    from moleculekit_amd import batch
+    g = golden(f"explicit_C{C}.npz")
+    got = batch.occupancy_centers(g["centers"], g["coords"], g["sigmas"], ctx=hip_ctx)
+    assert np.abs(got - g["features"]).max() <= TOL
+
+
+def test_explicit_centres_pbc(hip_ctx):
+    from moleculekit_amd import batch
+    rng = np.random.default_rng(3)
+    c = rng.uniform(-20, 40, size=(700, 3)).astype(np.float32)
+    s = rng.choice([0, 1.1, 1.7, 1.8], size=(700, 8)).astype(np.float32)
+    centers = rng.uniform(0, 15, size=(1000, 3))
+    box = np.array([15.0, 17.0, 13.5])
+    got = batch.occupancy_centers(centers, c, s, box=box, ctx=hip_ctx)
+    exp = oracle.calculate_occupancy(centers, c, s.astype(np.float64), box=box)
+    assert np.abs(got - exp).max() <= TOL
+
+
+def test_calculate_occupancy_dropin_in_place_max(hip_ctx):
+    """Exact call contract of occupancy_utils.pyx:34-61, incl. max-accumulation into `results`."""
+    from moleculekit_amd.occupancy_utils import calculate_occupancy
+    g = golden("explicit_C3.npz")
+    centers = np.ascontiguousarray(g["centers"]); coords = np.ascontiguousarray(g["coords"], np.float32)
+    sig = np.ascontiguousarray(g["sigmas"])
+    res = np.zeros((centers.shape[0], 3))
+    assert calculate_occupancy(centers, coords, sig, res, ctx=hip_ctx) is None
+    assert np.abs(res - g["features"]).max() <= TOL
+    pre = np.full_like(res, 0.5)
+    calculate_occupancy(centers, coords, sig, pre, ctx=hip_ctx)
+    assert np.abs(pre - np.maximum(0.5, g["features"])).max() <= TOL
+    # PBC composition trick of SURVEY 8c works on the drop-in too: accumulate shifted calls
+    acc = np.zeros_like(res)
+    calculate_occupancy(centers, coords, sig, acc, ctx=hip_ctx)
+    calculate_occupancy(centers + 3.0, coords, sig, acc, ctx=hip_ctx)
+    ref = np.zeros_like(res)
+    oracle.calculate_occupancy(centers, coords, sig, ref)
+    oracle.calculate_occupancy(centers + 3.0, coords, sig, ref)
+    assert np.abs(acc - ref).max() <= TOL
+
+
+def test_grid_centers_bit_exact(hip_ctx):
+    from moleculekit_amd import batch
+    g = golden("getcenters_cases.npz")
+    for i in range(5):
+        bb = g[f"box{i}_center"] - g[f"box{i}_boxsize"] / 2
+        got = batch.grid_centers(bb, g[f"box{i}_nvoxels"], float(g[f"box{i}_voxelsize"]), ctx=hip_ctx)
+        assert np.array_equal(got, g[f"box{i}_centers"])
+
+
+def test_cfg2_full_size_against_reference_samples(hip_ctx):
+    """BASELINE.json configs[1] at FULL size (50k atoms, 64^3 x 8): 16384 sampled voxels + per-channel
+    checksums of the real reference's output (tests/golden/cfg2_sampled.npz)."""
+    from moleculekit_amd import batch
+    g = golden("cfg2_sampled.npz")
+    p = synth_config(2, 1)
+    o, nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])
+    for k in (4, 8):
+        hip_ctx.set_tile_k(k)
+        got = batch.voxelize_lattice(p["coords"], p["atom_offsets"], p["sigmas"], o[None], nv, p["voxelsize"],
+                                     ctx=hip_ctx)[0].astype(np.float64)
+        hip_ctx.set_tile_k(0)
+        assert np.abs(got[g["sample_idx"]] - g["sample_features"]).max() <= TOL
+        assert np.all(np.abs(got.sum(0) - g["channel_sums"]) <= 1e-6 * got.shape[0])   # mean |err| << 1e-6
+        assert np.array_equal(np.count_nonzero(got > 1e-6, axis=0) > 0, g["nonzero"] > 0)
+        assert np.abs(got.max(0) - g["channel_max"]).max() <= TOL
+
+
+def test_3ptb_bbox_buffer8_against_reference_samples(hip_ctx):
+    """The reference test's own call shape (test_voxeldescriptors.py:77-79: buffer=8 -> 60x55x65 grid)."""
+    from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
+    from tests.test_host_logic import Mol
+    g = golden("3ptb_bbox_buffer8.npz")
+    mol = Mol(g["coords"], element=g["element"])
+    feats, centers, nvox = getVoxelDescriptors(mol, buffer=8, voxelsize=1, userchannels=g["userchannels"])
+    assert feats.dtype == np.float64 and feats.shape == (int(np.prod(nvox)), 8)
+    assert np.array_equal(nvox, g["nvoxels"])
+    assert np.array_equal(centers[:4], g["centers_first"]) and np.array_equal(centers[-4:], g["centers_last"])
+    assert np.abs(feats[g["sample_idx"]] - g["sample_features"]).max() <= TOL
+    assert np.all(np.abs(feats.sum(0) - g["channel_sums"]) <= 1e-6 * feats.shape[0])
+
+
+def test_full_size_batches_size_independent_properties(hip_ctx):
+    """cfg3 at full batch (1024 poses): oracle on a handful of items + properties that hold at any size:
+    permutation equivariance over items, independence of batch composition, translation covariance,
+    range [0,1], and max-linearity (voxelizing A u B == max(vox A, vox B))."""
+    from moleculekit_amd import batch
+    B = 1024
+    p = synth_config(3, B)
+    origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    full = batch.voxelize_lattice(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, p["voxelsize"], ctx=hip_ctx)
+    assert full.shape == (B, 24 ** 3, 8) and np.all(np.isfinite(full)) and full.min() >= 0 and full.max() <= 1
+    pick = [0, 1, 511, 1023]
+    for b in pick:
+        s, e = p["atom_offsets"][b], p["atom_offsets"][b + 1]
+        exp = oracle_lattice(p["coords"][s:e], np.array([0, e - s]), p["sigmas"][s:e], origins[b:b + 1], nv, p["voxelsize"])
+        assert np.abs(full[b] - exp[0]).max() <= TOL
+    # batch composition / order must not matter: reversed batch gives reversed output, bit for bit
+    n = 60
+    rev_coords = p["coords"].reshape(B, n, 3)[::-1].reshape(-1, 3)
+    rev_sig = p["sigmas"].reshape(B, n, 8)[::-1].reshape(-1, 8)
+    rev = batch.voxelize_lattice(rev_coords, p["atom_offsets"], rev_sig, origins[::-1], nv, p["voxelsize"], ctx=hip_ctx)
+    assert np.array_equal(rev[::-1], full)
+    # translation covariance: shifting atoms and origin by whole voxels (exact in fp) is bit-identical
+    shift = np.array([16.0, -8.0, 32.0])
+    moved = batch.voxelize_lattice((p["coords"][: 8 * n] + shift).astype(np.float32), p["atom_offsets"][:9],
+                                   p["sigmas"][: 8 * n], origins[:8] + shift, nv, p["voxelsize"], ctx=hip_ctx)
+    assert np.abs(moved - full[:8]).max() <= 2e-6
+    # max-linearity: A u B == max(A, B), exactly (min/max are exact)
+    a = batch.voxelize_lattice(p["coords"][:30], np.array([0, 30]), p["sigmas"][:30], origins[:1], nv, 1.0, ctx=hip_ctx)
+    b = batch.voxelize_lattice(p["coords"][30:60], np.array([0, 30]), p["sigmas"][30:60], origins[:1], nv, 1.0, ctx=hip_ctx)
+    assert np.array_equal(np.maximum(a, b)[0], full[0])
+
+
+def test_cfg5_full_resolution_batch(hip_ctx):
+    """cfg5 shape (0.5 A voxels, ragged molecules) on a 2048-molecule batch, oracle on a sample."""
+    from moleculekit_amd import batch
+    B = 2048
+    p = synth_config(5, B)
+    origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    full = batch.voxelize_lattice(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, p["voxelsize"], ctx=hip_ctx)
+    for b in (0, 777, 2047):
+        s, e = p["atom_offsets"][b], p["atom_offsets"][b + 1]
+        exp = oracle_lattice(p["coords"][s:e], np.array([0, e - s]), p["sigmas"][s:e], origins[b:b + 1], nv, p["voxelsize"])
+        assert np.abs(full[b] - exp[0]).max() <= TOL
+
+
+def test_periodic_frames_match_27_image_composition_on_gpu(hip_ctx):
+    """PBC result == max over the 27 shifted NON-periodic GPU runs (the composition SURVEY 8c uses to
+    pin the extension on the reference kernel), when the grid lies inside the box."""
+    from moleculekit_amd import batch
+    rng = np.random.default_rng(9)
+    L = np.array([30.0, 28.0, 33.0], np.float32)
+    n = 2500
+    from tests.synth import synth_sigmas
+    c = (rng.uniform(0, 1, size=(n, 3)) * L).astype(np.float32)
+    s = synth_sigmas(rng, n)
+    origin = np.array([[2.0, 1.0, 3.0]])
+    nv = [24, 24, 24]
+    per = batch.voxelize_lattice(c, [0, n], s, origin, nv, 1.0, box=L[None], ctx=hip_ctx)[0]
+    acc = np.zeros_like(per)
+    for kx in (-1, 0, 1):
+        for ky in (-1, 0, 1):
+            for kz in (-1, 0, 1):
+                sh = (c.astype(np.float64) + np.array([kx, ky, kz]) * L.astype(np.float64)).astype(np.float32)
+                acc = np.maximum(acc, batch.voxelize_lattice(sh, [0, n], s, origin, nv, 1.0, ctx=hip_ctx)[0])
+    assert np.abs(per - acc).max() <= 2e-6     # float32 rounding of the shifted coordinates only
+
+
+def test_empty_and_degenerate_inputs(hip_ctx):
+    from moleculekit_amd import batch
+    z = batch.voxelize_lattice(np.zeros((0, 3), np.float32), [0], np.zeros((0, 8)), np.zeros((0, 3)), [8, 8, 8], 1.0, ctx=hip_ctx)
+    assert z.shape == (0, 512, 8)
+    z = batch.voxelize_lattice(np.zeros((0, 3), np.float32), [0, 0], np.zeros((0, 8)), [[0, 0, 0]], [5, 6, 7], 1.0, ctx=hip_ctx)
+    assert z.shape == (1, 210, 8) and not z.any()                   # no atoms -> all-zero grid, fully written
+    z = batch.voxelize_lattice(np.zeros((1, 3), np.float32), [0, 1], np.ones((1, 8)), [[0, 0, 0]], [4, 0, 4], 1.0, ctx=hip_ctx)
+    assert z.shape == (1, 0, 8)
+    with pytest.raises(ValueError):
+        batch.voxelize_lattice(np.zeros((1, 3), np.float32), [0, 1], np.ones((1, 8)), [[0, 0, 0]], [4, 4, 4], -1.0, ctx=hip_ctx)
+    from moleculekit_amd._lib import MkamdError
+    with pytest.raises(MkamdError):
+        batch.voxelize_lattice(np.zeros((1, 3), np.float32), [0, 1], np.ones((1, 8)), [[0, 0, 0]], [4, 4, 4], 1.0,
+                               box=np.array([[9.0, 30, 30]], np.float32), ctx=hip_ctx)

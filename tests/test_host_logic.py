@@ -1,0 +1,153 @@
+"""CPU tier: host-side logic of the drop-in (grid / centre generation, radii, rotation, argument
+handling) against golden outputs of the real reference; no GPU compute is called here."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from moleculekit_amd import batch, distributed
+from moleculekit_amd import voxeldescriptors as vd
+from moleculekit_amd.util import boundingBox, rotationMatrix
+from tests.cases import GOLDEN, golden
+
+
+class Mol:
+    """Duck-typed stand-in for moleculekit.molecule.Molecule (coords f32 [N,3,F], element, frame)."""
+
+    def __init__(self, coords, element=None):
+        self.coords = np.asarray(coords, np.float32)
+        if self.coords.ndim == 2:
+            self.coords = self.coords[:, :, None]
+        self.element = element
+        self.frame = 0
+
+    def get(self, field, sel=None):
+        assert field == "coords"
+        return self.coords[:, :, self.frame].copy()
+
+
+def test_getcenters_bbox_branch_bit_exact():
+    g = golden("getcenters_cases.npz")
+    for i in range(6):
+        buf, vs = g[f"bbox{i}_params"]
+        # the reference is called with python ints/floats; keep ints where the fixture used ints
+        buf = int(buf) if float(buf).is_integer() else float(buf)
+        vs = int(vs) if float(vs).is_integer() else float(vs)
+        centers, nvox = vd.getCenters(Mol(g[f"bbox{i}_coords"]), buffer=buf, voxelsize=vs)
+        assert np.array_equal(nvox, g[f"bbox{i}_nvoxels"])
+        assert centers.dtype == np.float64 and centers.flags["C_CONTIGUOUS"]
+        assert np.array_equal(centers, g[f"bbox{i}_centers"])
+
+
+def test_getcenters_boxsize_branch_bit_exact():
+    g = golden("getcenters_cases.npz")
+    for i in range(5):
+        vs = float(g[f"box{i}_voxelsize"])
+        vs = int(vs) if vs.is_integer() else vs
+        centers, nvox = vd.getCenters(None, boxsize=list(g[f"box{i}_boxsize"]), center=list(g[f"box{i}_center"]),
+                                      voxelsize=vs)
+        assert np.array_equal(nvox, g[f"box{i}_nvoxels"])
+        assert np.array_equal(centers, g[f"box{i}_centers"])
+
+
+@pytest.mark.parametrize("name", ["celecoxib", "ledipasvir"])
+def test_getcenters_reference_held_fixtures(name):
+    """centers and nvoxels must be EXACTLY equal (test_voxeldescriptors.py:52-53, :67-68)."""
+    g = golden(f"{name}_ch7.npz")
+    centers, nvox = vd.getCenters(Mol(g["coords"]), buffer=1)
+    assert np.array_equal(centers, g["ref_centers"])
+    assert np.array_equal(nvox, g["ref_nvoxels"])
+
+
+def test_bounding_box_and_3ptb_grid():
+    g = golden("3ptb_bbox_buffer8.npz")
+    mol = Mol(g["coords"])
+    bb = boundingBox(mol)
+    assert bb.dtype == np.float32 and np.array_equal(bb, g["bbox"])
+    centers, nvox = vd.getCenters(mol, buffer=8, voxelsize=1)
+    assert np.array_equal(nvox, g["nvoxels"])
+    assert np.array_equal(centers[:4], g["centers_first"]) and np.array_equal(centers[-4:], g["centers_last"])
+
+
+def test_channel_radii():
+    g = golden("3ptb_bbox_buffer8.npz")
+    assert np.array_equal(vd._getChannelRadii(g["element"]), g["radii"])
+    with open(os.path.join(GOLDEN, "vdw_radii.json")) as f:
+        ref = json.load(f)
+    from moleculekit_amd._vdw_radii import VDW_RADIUS
+    assert VDW_RADIUS == ref and len(ref) == 118
+    with pytest.raises(KeyError):
+        vd._getChannelRadii(["Xx"])
+
+
+def test_rotate_coordinates():
+    g = golden("rotate_cases.npz")
+    for r, exp in zip(g["rotations"], g["out"]):
+        got = vd.rotateCoordinates(g["coords"], list(r), g["center"])
+        assert np.allclose(got, exp, atol=1e-12)
+    m = rotationMatrix([0, 0, 1], 1.5708)
+    assert np.allclose(m.round(4), [[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+
+
+def test_grid_centers_cache_and_order():
+    a = vd._getGridCenters(2, 3, 4, 0.5)
+    assert a.shape == (2, 3, 4, 3) and a.dtype == np.float64
+    flat = a.reshape(-1, 3)
+    assert np.array_equal(flat[1], [0, 0, 0.5]) and np.array_equal(flat[4], [0, 0.5, 0])   # z fastest
+    assert vd._getGridCenters(2, 3, 4, 0.5) is a                                          # lru_cache
+
+
+def test_lattice_recognition():
+    centers, nvox = vd.getCenters(None, boxsize=[6, 5, 4], center=[0.3, 1.0, -2.0], voxelsize=0.5)
+    lat = vd._lattice_from_centers(centers)
+    assert lat is not None
+    bb, nv, vs = lat
+    assert np.array_equal(nv, nvox) and vs == 0.5 and np.array_equal(bb, centers[0])
+    assert vd._lattice_from_centers(centers[::-1]) is None
+    jig = centers.copy(); jig[7, 1] += 1e-3
+    assert vd._lattice_from_centers(jig) is None
+    assert vd._lattice_from_centers(np.array([[0.0, 0, 0], [16, 24, -5]])) is None
+
+
+def test_error_behaviour_matches_reference():
+    coords = np.zeros((3, 3, 2), np.float32)
+    ch = np.ones((3, 8))
+    with pytest.raises(RuntimeError, match="single set of coordinates"):
+        vd.getVoxelDescriptors(None, boxsize=[4, 4, 4], center=[0, 0, 0], usercoords=coords, userchannels=ch)
+    with pytest.raises(RuntimeError, match="only support C implementation"):
+        vd.getVoxelDescriptors(None, boxsize=[4, 4, 4], center=[0, 0, 0], usercoords=coords[:, :, 0],
+                               userchannels=ch, method="cuda")
+
+
+def test_calculate_occupancy_rejects_wrong_dtypes_like_cython():
+    from moleculekit_amd.occupancy_utils import calculate_occupancy
+    c, x, s, r = np.zeros((2, 3)), np.zeros((1, 3), np.float32), np.ones((1, 8)), np.zeros((2, 8))
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        calculate_occupancy(c.astype(np.float32), x, s, r)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        calculate_occupancy(c, x.astype(np.float64), s, r)
+    with pytest.raises(ValueError, match="dimensions"):
+        calculate_occupancy(c, x, s[0], r)
+
+
+def test_pack_items_and_max_images():
+    coords, sig, offs = batch.pack_items([np.zeros((2, 3)), np.zeros((0, 3)), np.ones((5, 3))],
+                                         [np.ones((2, 8)), np.ones((0, 8)), np.ones((5, 8))])
+    assert coords.dtype == np.float32 and coords.shape == (7, 3) and list(offs) == [0, 2, 2, 7]
+    assert batch.max_images_per_atom([[66.9] * 3], [48, 48, 48], 1.0) == 1
+    assert batch.max_images_per_atom([[12.0, 12.0, 12.0]], [40, 40, 40], 1.0) == 5 ** 3
+    with pytest.raises(ValueError):
+        batch.max_images_per_atom([[9.0, 20, 20]], [8, 8, 8], 1.0)
+
+
+def test_shard_bounds():
+    assert list(distributed.shard_bounds(10, 4)) == [0, 3, 6, 8, 10]
+    assert list(distributed.shard_bounds(3, 8)) == [0, 1, 2, 3, 3, 3, 3, 3, 3]
+    b = distributed.shard_bounds(6, 2, weights=[100, 1, 1, 1, 1, 1])
+    assert b[0] == 0 and b[-1] == 6 and b[1] == 1
+    rng = np.random.default_rng(0)
+    w = rng.integers(20, 51, size=1000)
+    b = distributed.shard_bounds(1000, 8, weights=w)
+    loads = [w[b[i]:b[i + 1]].sum() for i in range(8)]
+    assert max(loads) - min(loads) <= 100 and np.all(np.diff(b) > 0)
