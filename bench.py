@@ -115,6 +115,7 @@ def main():
     V, C = int(np.prod(nv)), 8
     ctx = _lib.default_context(local)
     ctx.set_tile_k(args.tile_k)
+    ctx.set_force_general(os.environ.get("MKAMD_FORCE_GENERAL", "0") == "1")
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
     d_coords, d_offs = t(p["coords"], np.float32), t(p["atom_offsets"], np.int64)
     d_sig, d_org = t(p["sigmas"], np.float32), t(origins, np.float64)

@@ -60,6 +60,9 @@ int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_u
                           uint64_t* hbm_bytes, char* arch, size_t arch_len);
 /* Tile depth K (x-planes per lane) of the lattice kernel: 0 = automatic, 4 or 8. */
 int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k);
+/* 1: always take the general tile-kernel path (per-pair cutoff test, arbitrary per-entry sigma)
+ * instead of the class-sorted one; results are bit-identical (testing / A-B benchmarking). */
+int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on);
 /* Per-kernel timing of the tile kernel with HIP events on the context's stream (bench.py's
  * roofline leg): enable, run, then read back the accumulated time and launch count (resets). */
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable);

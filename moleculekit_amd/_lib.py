@@ -31,6 +31,7 @@ SIGNATURES = {
     "mkamd_ctx_device_info": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_c_int),
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_ctx_set_tile_k": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_force_general": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
@@ -58,6 +59,14 @@ def load() -> ctypes.CDLL:
                     f"moleculekit_amd: HIP library not found at {LIB_PATH}. Build it with "
                     f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                     f"There is no CPU fallback.")
+            if os.environ.get("MKAMD_NO_TORCH_PRELOAD", "0") != "1":
+                # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; if ours
+                # (linked against /opt/rocm) initialises first, torch.cuda later reports "No HIP GPUs".
+                # Importing torch first makes the loader resolve our DT_NEEDED to the copy torch loaded.
+                try:
+                    import torch  # noqa: F401
+                except Exception:
+                    pass
             L = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if a declared symbol is missing
@@ -126,6 +135,9 @@ class Context:
 
     def set_tile_k(self, k: int):
         _check(load().mkamd_ctx_set_tile_k(self._h, int(k)))
+
+    def set_force_general(self, on: bool):
+        _check(load().mkamd_ctx_set_force_general(self._h, int(bool(on))))
 
     def enable_kernel_timing(self, on=True):
         _check(load().mkamd_ctx_enable_kernel_timing(self._h, int(bool(on))))

@@ -39,6 +39,7 @@ struct mkamd_ctx {
     void* bufs[WS_NSLOTS] = {};
     size_t caps[WS_NSLOTS] = {};
     int tile_k = 0;
+    int force_general = 0;
     // tile-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
@@ -63,9 +64,9 @@ struct mkamd_ctx {
         *ptr = bufs[slot];
         return 0;
     }
-    int zero(void* p, size_t bytes)
+    int fill(void* p, int byte, size_t bytes)
     {
-        HIP_TRY(hipMemsetAsync(p, 0, bytes, stream));
+        HIP_TRY(hipMemsetAsync(p, byte, bytes, stream));
         return 0;
     }
     template <class... KA, class... A>
@@ -216,6 +217,13 @@ int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k)
     return MKAMD_OK;
 }
 
+int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on)
+{
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    ctx->force_general = on != 0;
+    return MKAMD_OK;
+}
+
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable)
 {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
@@ -324,7 +332,7 @@ int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
     P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
-    P.tile_k = ctx->tile_k;
+    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.out = d_features;
     std::string err;

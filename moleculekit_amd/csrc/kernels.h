@@ -10,10 +10,14 @@
 //   here      :  q[v,c]   = min_a { |a-v|^2 * w[a,c]              : |a-v|^2 < 25 },  w = 1/sigma^2
 //                res[v,c] = 1 - exp(-q^-6)            (monotone => max f == f(min q), exact)
 //   so the inner loop has no transcendentals; rcp/exp run once per voxel-channel.
-//   It is a GATHER: one wave owns a K x 8 x 8 voxel tile, lane = (y,z), K x-planes in registers,
-//   candidate atoms come from a uniform cell list, are culled against the tile box, compacted per
-//   channel through LDS and broadcast-read by all 64 lanes.  No atomics on the grid, no zero-fill
-//   pass, one 32-byte store per voxel.  MFMA unused (neighbourhood min-reduction, not a contraction).
+//   Entries (atom x channel) that share the same sigma form a CLASS; inside a class
+//                min_a d2*w == w * min_a d2   and   "some in-range atom" == (min_a d2 < 25),
+//   bit for bit (w > 0, float rounding is monotone), so the cutoff test and the multiply by w also
+//   leave the inner loop: per (voxel, entry) it is  sub, fma, half a v_min3_u32.
+//   It is a GATHER: one wave owns a K x 8 x 8 voxel tile, lane = (y,z), K x-planes in registers;
+//   candidate atoms come from a uniform cell list, are culled against the tile box, counting-sorted
+//   by (channel, class) in LDS and broadcast-read by all 64 lanes.  No atomics on the grid, no
+//   zero-fill pass, one 32-byte store per voxel.  MFMA unused (a neighbourhood min-reduction).
 //
 // Coordinates: everything is in VOXEL units relative to the grid origin (voxel i's centre sits at
 // integer coordinate i).  Atoms are decomposed IN DOUBLE into (cell index, cell-centre-relative
@@ -25,7 +29,15 @@
 
 namespace mkamd {
 
-constexpr int CHG = 8;          // channels per channel-group (one group = one pass of the tile kernel)
+constexpr int CHG = 8;               // channels per channel-group (one group = one pass of the tile kernel)
+constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per call (4-bit ids)
+constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
+constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
+constexpr int ECAP = 1024;           // LDS entry capacity of a tile (3 x 4 KiB, structure of arrays)
+constexpr int SCAP = 512;            // LDS capacity for surviving candidate atoms of a tile
+constexpr unsigned CLS_EMPTY = 0xffffffffu;   // empty slot of the class table (never a valid w)
+constexpr int CLS_OVERFLOW = NCLS;   // word NCLS of the table buffer: CLS_EMPTY, or 0 once > NCLS classes were seen
+constexpr int CLS_TABLE_WORDS = NCLS + 1;
 
 // Everything the kernels need to know about the batch of lattice grids (passed by value).
 struct GridDesc {
@@ -39,6 +51,7 @@ struct GridDesc {
     int C, G;                   // channels, channel groups = ceil(C/8)
     int B;                      // items (molecules / poses / frames)
     int pbc;                    // 1: per-item orthorhombic box given
+    int force_general;          // 1: never use the class-sorted path (testing / A-B)
     float R2;                   // cutoff^2 in voxel units  (25 / res^2)
     float R2cull;               // slightly inflated cutoff^2 for tile culling
     double inv_res;             // 1 / voxelsize
@@ -55,12 +68,124 @@ constexpr float MK_W_MAX = 3.0e38f;
 
 enum { MK_ERR_RECORD_OVERFLOW = 1, MK_ERR_BAD_BOX = 2, MK_ERR_TOO_MANY_IMAGES = 4 };
 
+// w = voxelsize^2 / sigma^2 of one (atom, channel); +inf when the atom is not in the channel
+// (sigma == 0, occupancy_utils.pyx:55-56) or sigma is NaN (the reference never stores NaN).
+template <typename SigT>
+MK_DEV float sigma_to_w(SigT sigma, double w_scale)
+{
+    const double s = (double)sigma;
+    const float t = (float)(w_scale / (s * s));
+    return (s != 0.0 && t == t) ? fminf(t, MK_W_MAX) : mk_inf();
+}
+
+// Class table: NCLS slots of w bit patterns (CLS_EMPTY = unused), word NCLS = overflow marker.
+MK_DEV int class_lookup(const unsigned* table, unsigned bits)
+{
+    for (int s = 0; s < NCLS; ++s)
+        if (table[s] == bits) return s;
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Class discovery: the distinct w values of the batch -> cls_table (<= NCLS, else the overflow word
+// is raised and the call takes the general tile path).  Two tiny kernels and NO global atomics (a
+// shared table updated by thousands of blocks serialises on one cache line):
+//   k_collect_classes : grid-stride over atoms; duplicates removed per wave (ballot / readlane
+//                       election) and per block (LDS hash set); each block stores its set (<= 32 values)
+//   k_merge_classes   : one block merges the per-block sets into the final table
+// ------------------------------------------------------------------------------------------------
+constexpr int CLS_BLOCK_SET = 32;
+constexpr int CLS_MAX_BLOCKS = 512;
+
+MK_DEV unsigned class_hash(unsigned bits) { return (bits >> 9) ^ (bits >> 15) ^ (bits >> 21); }
+
+// insert into an LDS open-addressing set of `size` (power of two) slots; false when the set is full
+MK_DEV bool lds_set_insert(unsigned* set, unsigned size, unsigned bits)
+{
+    unsigned h = class_hash(bits) & (size - 1u);
+    for (unsigned probe = 0; probe < size; ++probe) {
+        if (set[h] == bits) return true;                               // common case: no atomic needed
+        const unsigned old = mk_lds_cas(&set[h], CLS_EMPTY, bits);
+        if (old == CLS_EMPTY || old == bits) return true;
+        h = (h + 1u) & (size - 1u);
+    }
+    return false;
+}
+
+template <typename SigT>
+MK_KERNEL(256) void k_collect_classes(const SigT* __restrict__ sigmas, long long total_atoms, int C,
+                                      double w_scale, unsigned* __restrict__ block_sets)
+{
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_full;
+    if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
+    if (threadIdx.x == 0) s_full = 0u;
+    mk_block_sync();
+    const int lane = threadIdx.x & (WAVE - 1);
+    for (long long base = (long long)blockIdx.x * blockDim.x; base < total_atoms;
+         base += (long long)gridDim.x * blockDim.x) {                 // block-uniform trip count
+        const long long a = base + threadIdx.x;
+        const bool act = a < total_atoms;
+        for (int c = 0; c < C; ++c) {
+            unsigned bits = CLS_EMPTY;
+            if (act) {
+                const float w = sigma_to_w(sigmas[(size_t)a * C + c], w_scale);
+                if (w < mk_inf()) bits = mk_float_bits(w);
+            }
+            bool pending = bits != CLS_EMPTY;
+            for (;;) {                                               // wave-uniform: one trip per distinct value
+                const unsigned long long mask = mk_ballot(pending);
+                if (mask == 0ull) break;
+                const int leader = __builtin_ctzll(mask);
+                const unsigned lb = mk_readlane(bits, leader);
+                if (bits == lb) pending = false;
+                if (lane == leader && !lds_set_insert(s_set, CLS_BLOCK_SET, lb)) s_full = 1u;
+            }
+        }
+    }
+    mk_block_sync();
+    // a block that saw more than 32 distinct values reports "too many" with a reserved marker (0xfffffffe)
+    if (threadIdx.x < CLS_BLOCK_SET)
+        block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? 0xfffffffeu : s_set[threadIdx.x];
+}
+
+MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ block_sets, unsigned nwords,
+                                    unsigned* __restrict__ cls_table)
+{
+    __shared__ unsigned s_set[64];
+    __shared__ unsigned s_over;
+    if (threadIdx.x < 64) s_set[threadIdx.x] = CLS_EMPTY;
+    if (threadIdx.x == 0) s_over = 0u;
+    mk_block_sync();
+    for (unsigned i = threadIdx.x; i < nwords; i += blockDim.x) {
+        const unsigned v = block_sets[i];
+        if (v == CLS_EMPTY) continue;
+        if (v == 0xfffffffeu || !lds_set_insert(s_set, 64u, v)) s_over = 1u;
+    }
+    mk_block_sync();
+    if (threadIdx.x == 0) {
+        unsigned n = 0;
+        bool over = s_over != 0u;
+        for (int i = 0; i < 64; ++i) {
+            const unsigned v = s_set[i];
+            if (v == CLS_EMPTY) continue;
+            if (n < (unsigned)NCLS) cls_table[n] = v;
+            ++n;
+        }
+        if (n > (unsigned)NCLS) over = true;
+        for (unsigned i = n; i < (unsigned)NCLS; ++i) cls_table[i] = CLS_EMPTY;
+        cls_table[CLS_OVERFLOW] = over ? 0u : CLS_EMPTY;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Binning: atoms (and, for periodic items, their images) -> padded uniform cell grid.
-// PHASE 0 counts, PHASE 1 fills the cell-sorted record arrays (counts are walked back to zero).
-// One thread per atom; one global atomic per atom-image.
+// PHASE 0 counts, PHASE 1 fills the
+// cell-sorted record arrays (counts are walked back to zero).  One thread per atom; one global
+// atomic per atom-image.
 // Record = pos (cell-centre-relative x,y,z as f32 ; packed padded cell coords)
-//          + per channel group two float4 of w = voxelsize^2 / sigma^2   (+inf: channel absent)
+//          + per channel group EITHER 8 class ids (4 bits each, 0 = absent)     [sorted path]
+//                              OR two float4 of w (+inf = absent)               [general path]
 // ------------------------------------------------------------------------------------------------
 template <int PHASE, typename SigT>
 MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
@@ -68,7 +193,8 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                 const float* __restrict__ box, unsigned* __restrict__ cell_count,
                                 const unsigned* __restrict__ cell_start, float4* __restrict__ rec_pos,
-                                float4* __restrict__ rec_w, int* __restrict__ err_flag)
+                                float4* __restrict__ rec_w, unsigned* __restrict__ rec_cls,
+                                unsigned* cls_table, int* __restrict__ err_flag)
 {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= total_atoms) return;
@@ -81,14 +207,10 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
     }
     const int b = lo;
 
-    // w per channel; an atom with no usable channel is dropped here (occupancy_utils.pyx:55-56)
+    // an atom with no usable channel is dropped here (occupancy_utils.pyx:55-56)
     const SigT* sg = sigmas + (size_t)a * g.C;
     bool any = false;
-    for (int c = 0; c < g.C; ++c) {
-        const double s = (double)sg[c];
-        const float w = (float)(g.w_scale / (s * s));
-        any |= (s != 0.0) && (w == w);
-    }
+    for (int c = 0; c < g.C; ++c) any |= sigma_to_w(sg[c], g.w_scale) < mk_inf();
     if (!any) return;
 
     double p[3], Lv[3] = {0.0, 0.0, 0.0};
@@ -136,21 +258,27 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
                     if (slot >= g.M) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
                     rec_pos[slot] = make_float4(rel[0], rel[1], rel[2],
                                                 mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
+                    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
                     for (int gq = 0; gq < g.G; ++gq) {
                         float w[CHG];
 #pragma unroll
                         for (int c = 0; c < CHG; ++c) {
                             const int ch = gq * CHG + c;
-                            float wc = mk_inf();
-                            if (ch < g.C) {
-                                const double s = (double)sg[ch];
-                                const float t = (float)(g.w_scale / (s * s));
-                                if (s != 0.0 && t == t) wc = fminf(t, MK_W_MAX);   // NaN sigma: absent
-                            }
-                            w[c] = wc;
+                            w[c] = ch < g.C ? sigma_to_w(sg[ch], g.w_scale) : mk_inf();
                         }
-                        rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
-                        rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
+                        if (general) {
+                            rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
+                            rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
+                        } else {
+                            unsigned ids = 0;
+#pragma unroll
+                            for (int c = 0; c < CHG; ++c) {
+                                unsigned id = 0;
+                                if (w[c] < mk_inf()) id = (unsigned)(class_lookup(cls_table, mk_float_bits(w[c])) + 1);
+                                ids |= id << (4 * c);
+                            }
+                            rec_cls[(size_t)gq * g.M + slot] = ids;
+                        }
                     }
                 }
             }
@@ -164,16 +292,23 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_PER_THREAD = 16;
 constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_PER_THREAD;   // 4096
 
+// inclusive scan across the 64 lanes of a wave
+MK_DEV unsigned wave_scan_inclusive(unsigned v)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned t = mk_shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
 // exclusive scan of one value per thread across a 256-thread block; *total gets the block sum.
 MK_DEV unsigned block_scan_exclusive(unsigned v, unsigned* total, unsigned* lds /* >= 8 */)
 {
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    unsigned incl = v;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        const unsigned t = mk_shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
+    const unsigned incl = wave_scan_inclusive(v);
     if (lane == WAVE - 1) lds[wv] = incl;
     mk_block_sync();
     unsigned woff = 0, tot = 0;
@@ -245,26 +380,111 @@ MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size
 // ------------------------------------------------------------------------------------------------
 // Occupancy value from the reduced q = min d^2/sigma^2 :  1 - exp(-q^-6)
 // (occupancy_utils.pyx:57-60 with x^12 = (sigma^2/d^2)^6).  q=+inf -> 0, q=0 -> 1.
+// For small x = q^-6 the float32 form 1-exp(-x) cancels (absolute error 6e-8 whatever x is), so the
+// tail uses the alternating series of -expm1(-x): relative accuracy ~1e-6 everywhere, which is
+// what lets the reference's own np.allclose(rtol=1e-5) style checks pass on float32 results.
 // ------------------------------------------------------------------------------------------------
 MK_DEV float occupancy_from_q(float q)
 {
     const float u = mk_rcp_refined(q);
     const float u3 = u * u * u;
-    const float u6 = u3 * u3;
-    return 1.0f - mk_exp2(-1.4426950408889634f * u6);
+    const float x = u3 * u3;
+    const float big = 1.0f - mk_exp2(-1.4426950408889634f * x);
+    // x - x^2/2 + x^3/6 - x^4/24 + x^5/120, Horner form; truncation < x^6/720 (1e-10 at x = 1/16)
+    const float small = x * (1.0f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.0083333338f))));
+    return x < 0.0625f ? small : big;
 }
 
 // ------------------------------------------------------------------------------------------------
 // THE hot kernel.  One 64-lane wave per K x 8 x 8 voxel tile (lane = (y,z), z fastest as in the
 // output layout, K x-planes per lane in registers); blockIdx.y = channel group.
 // ------------------------------------------------------------------------------------------------
+struct TileGeom {                     // wave-uniform description of the tile being voxelized
+    int b, x0, y0, z0;
+    int cx_lo, cx_hi, cy_lo, cy_hi, cz_lo, cz_hi;
+    float offx, offy, offz, fcs;
+};
+
+// Visit every candidate record of the tile in chunks of 64 (one record per lane).
+// The (cell-x, cell-y) columns around the tile each contribute one contiguous run of records (their
+// z-cells are adjacent in memory); the runs' bounds are fetched by one lane each, the chunks of all
+// runs are numbered 0..T-1, and the record loads run ONE chunk ahead of the chunk being processed
+// (the loads are L2/HBM round trips; without the look-ahead every chunk would pay ~1 us of latency).
+// f(survives, record index, tile-relative x,y,z, class ids) is called by ALL lanes for every chunk.
+template <int K, bool LOAD_CLS, class F>
+MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start,
+                               const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f)
+{
+    constexpr float HX = 0.5f * (float)(K - 1);
+    const int lane = threadIdx.x;
+    const int nyc = tg.cy_hi - tg.cy_lo + 1;
+    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 16 (cell edge >= cutoff radius)
+    unsigned my_r0 = 0, my_r1 = 0;
+    if (lane < ncols) {
+        const int pcx = tg.cx_lo + lane / nyc, pcy = tg.cy_lo + lane % nyc;
+        const size_t cbase = (size_t)tg.b * g.ncell + ((size_t)pcx * g.ncy + pcy) * g.ncz;
+        my_r0 = cell_start[cbase + tg.cz_lo];
+        my_r1 = cell_start[cbase + tg.cz_hi + 1];                 // z-run of cells is contiguous
+    }
+    const unsigned my_nch = (my_r1 - my_r0 + (WAVE - 1)) >> 6;
+    const unsigned incl = wave_scan_inclusive(my_nch);
+    const unsigned my_cb = incl - my_nch;
+    const unsigned T = mk_readlane(incl, WAVE - 1);
+
+    // depth-1 software pipeline: the loads of chunk t+1 are in flight while chunk t is processed
+    unsigned r_nxt = 0u, c_nxt = 0u;
+    bool v_nxt = false;
+    float4 P_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](unsigned t) {                                   // start the loads of chunk t
+        r_nxt = 0u; v_nxt = false; c_nxt = 0u;
+        P_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < T) {                                                 // wave-uniform
+            const unsigned long long own = mk_ballot(my_cb <= t && t < my_cb + my_nch);
+            const int j = __builtin_ctzll(own);
+            const unsigned r0 = mk_readlane(my_r0, j), r1 = mk_readlane(my_r1, j), cb = mk_readlane(my_cb, j);
+            r_nxt = r0 + ((t - cb) << 6) + (unsigned)lane;
+            v_nxt = r_nxt < r1;
+            if (v_nxt) {
+                P_nxt = rec_pos[r_nxt];
+                if (LOAD_CLS) c_nxt = rec_cls[r_nxt];
+            }
+        }
+    };
+    issue(0u);
+    for (unsigned t = 0; t < T; ++t) {
+        const float4 P = P_nxt;
+        const unsigned r = r_nxt, cls = c_nxt;
+        const bool valid = v_nxt;
+        issue(t + 1u);
+        const int pk = mk_float_as_int(P.w);
+        // (cell centre - tile centre) is an exact small half-integer; ONE rounding per axis
+        const float ex = P.x + ((float)(pk & 1023) * tg.fcs + tg.offx);
+        const float ey = P.y + ((float)((pk >> 10) & 1023) * tg.fcs + tg.offy);
+        const float ez = P.z + ((float)((pk >> 20) & 1023) * tg.fcs + tg.offz);
+        const float gx = fmaxf(fabsf(ex) - HX, 0.f);
+        const float gy = fmaxf(fabsf(ey) - 3.5f, 0.f);
+        const float gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
+        const bool surv = valid && (gx * gx + gy * gy + gz * gz < g.R2cull);
+        f(surv, r, ex, ey, ez, cls);
+    }
+}
+
 template <int K>
 MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cell_start,
                                     const float4* __restrict__ rec_pos,
-                                    const float4* __restrict__ rec_w, float* __restrict__ out)
+                                    const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
+                                    const unsigned* __restrict__ cls_table, float* __restrict__ out)
 {
     static_assert(K == 4 || K == 8, "K");
-    __shared__ float4 ebuf[WAVE + 1];             // per-channel compacted entries (x,y,z,w) + pad
+    // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
+    // broadcast reads (ds_read_b64: 2 LDS cycles each).  Sorted entries grow from index 0 up; the
+    // surviving candidate atoms of the (single) global traversal are parked from ECAP-1 down.
+    __shared__ __attribute__((aligned(16))) float sx[ECAP + 2];
+    __shared__ __attribute__((aligned(16))) float sy[ECAP + 2];
+    __shared__ __attribute__((aligned(16))) float sz[ECAP + 2];
+    __shared__ unsigned scls[SCAP];               // class ids of the parked survivors
+    __shared__ float4 ebuf[WAVE];                 // general path: one chunk's entries of one channel (x,y,z,w)
+    __shared__ unsigned bucket[NBUCKET];          // per-tile histogram, then placement cursors
 
     const int lane = threadIdx.x;
     // XCD-aware order: the dispatcher places block i on XCD i%8; give each XCD a contiguous run of
@@ -275,113 +495,209 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
     if (lt >= total_tiles) return;                // whole wave leaves together
     const int gq = blockIdx.y;
 
-    const int b = (int)(lt / (unsigned)g.ntiles);
-    int t = (int)(lt - (unsigned)b * (unsigned)g.ntiles);
-    const int tz = t % g.tnz; t /= g.tnz;
-    const int ty = t % g.tny;
-    const int tx = t / g.tny;
-    const int x0 = tx * K, y0 = ty * 8, z0 = tz * 8;
-
+    TileGeom tg;
+    tg.b = (int)(lt / (unsigned)g.ntiles);
+    {
+        int t = (int)(lt - (unsigned)tg.b * (unsigned)g.ntiles);
+        const int tz = t % g.tnz; t /= g.tnz;
+        const int ty = t % g.tny;
+        const int tx = t / g.tny;
+        tg.x0 = tx * K; tg.y0 = ty * 8; tg.z0 = tz * 8;
+    }
     const int ly = lane >> 3, lz = lane & 7;
     const float Y = (float)ly - 3.5f, Z = (float)lz - 3.5f;
     constexpr float HX = 0.5f * (float)(K - 1);
-    const float R2 = g.R2, R2cull = g.R2cull, INF = mk_inf();
+    const float R2 = g.R2, INF = mk_inf();
+    constexpr unsigned INF_BITS = 0x7f800000u;
+
+    // padded cell ranges that can hold atoms within the cutoff of this tile
+    {
+        const int h = g.h, csl = g.cs_log2;
+        tg.cx_lo = ((tg.x0 - g.rint) >> csl) + h; tg.cx_hi = ((tg.x0 + K - 1 + g.rint) >> csl) + h;
+        tg.cy_lo = ((tg.y0 - g.rint) >> csl) + h; tg.cy_hi = ((tg.y0 + 7 + g.rint) >> csl) + h;
+        tg.cz_lo = ((tg.z0 - g.rint) >> csl) + h; tg.cz_hi = ((tg.z0 + 7 + g.rint) >> csl) + h;
+        tg.cx_lo = tg.cx_lo < 0 ? 0 : tg.cx_lo; tg.cx_hi = tg.cx_hi > g.ncx - 1 ? g.ncx - 1 : tg.cx_hi;
+        tg.cy_lo = tg.cy_lo < 0 ? 0 : tg.cy_lo; tg.cy_hi = tg.cy_hi > g.ncy - 1 ? g.ncy - 1 : tg.cy_hi;
+        tg.cz_lo = tg.cz_lo < 0 ? 0 : tg.cz_lo; tg.cz_hi = tg.cz_hi > g.ncz - 1 ? g.ncz - 1 : tg.cz_hi;
+        // cell centre (voxel coords) minus tile centre, per axis:  (pc-h)*cs + (cs-1)/2 - (x0 + HX)
+        const float cmid = 0.5f * (float)(g.cs - 1);
+        tg.offx = cmid - (float)(h * g.cs) - ((float)tg.x0 + HX);
+        tg.offy = cmid - (float)(h * g.cs) - ((float)tg.y0 + 3.5f);
+        tg.offz = cmid - (float)(h * g.cs) - ((float)tg.z0 + 3.5f);
+        tg.fcs = (float)g.cs;
+    }
 
     // running minima kept as BIT PATTERNS: every candidate value is a non-negative float (or +inf /
     // NaN), for which unsigned-integer order == float order and NaN (0x7fc00000) sorts above +inf,
-    // so v_min_u32 is an exact NaN-ignoring float min with no canonicalisation op in front of it.
+    // so v_min_u32 / v_min3_u32 are exact NaN-ignoring float minima with no canonicalisation op.
     unsigned q[CHG][K];
 #pragma unroll
     for (int c = 0; c < CHG; ++c)
 #pragma unroll
-        for (int k = 0; k < K; ++k) q[c][k] = 0x7f800000u;
+        for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
 
-    // padded cell ranges that can hold atoms within the cutoff of this tile
-    const int h = g.h, csl = g.cs_log2;
-    int cx_lo = ((x0 - g.rint) >> csl) + h, cx_hi = ((x0 + K - 1 + g.rint) >> csl) + h;
-    int cy_lo = ((y0 - g.rint) >> csl) + h, cy_hi = ((y0 + 7 + g.rint) >> csl) + h;
-    int cz_lo = ((z0 - g.rint) >> csl) + h, cz_hi = ((z0 + 7 + g.rint) >> csl) + h;
-    cx_lo = cx_lo < 0 ? 0 : cx_lo; cx_hi = cx_hi > g.ncx - 1 ? g.ncx - 1 : cx_hi;
-    cy_lo = cy_lo < 0 ? 0 : cy_lo; cy_hi = cy_hi > g.ncy - 1 ? g.ncy - 1 : cy_hi;
-    cz_lo = cz_lo < 0 ? 0 : cz_lo; cz_hi = cz_hi > g.ncz - 1 ? g.ncz - 1 : cz_hi;
-
-    // cell centre (voxel coords) minus tile centre, per axis:  (pc-h)*cs + (cs-1)/2 - (x0 + HX)
-    const float cmid = 0.5f * (float)(g.cs - 1);
-    const float offx = cmid - (float)(h * g.cs) - ((float)x0 + HX);
-    const float offy = cmid - (float)(h * g.cs) - ((float)y0 + 3.5f);
-    const float offz = cmid - (float)(h * g.cs) - ((float)z0 + 3.5f);
-    const float fcs = (float)g.cs;
-
+    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+    const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
     const float4* __restrict__ w0p = rec_w + (size_t)(gq * 2 + 0) * g.M;
     const float4* __restrict__ w1p = rec_w + (size_t)(gq * 2 + 1) * g.M;
+    // lane s < NCLS holds the w bits of class s (read back with a uniform-lane register read)
+    const unsigned my_class_w = (!general && lane < NCLS) ? cls_table[lane] : INF_BITS;
 
-    for (int pcx = cx_lo; pcx <= cx_hi; ++pcx)
-        for (int pcy = cy_lo; pcy <= cy_hi; ++pcy) {
-            const size_t cbase = (size_t)b * g.ncell + ((size_t)pcx * g.ncy + pcy) * g.ncz;
-            const unsigned r0 = cell_start[cbase + cz_lo];
-            const unsigned r1 = cell_start[cbase + cz_hi + 1];     // z-run of cells is contiguous
-            for (unsigned rr = r0; rr < r1; rr += WAVE) {
-                const unsigned r = rr + lane;
-                const bool valid = r < r1;
-                // ---- stage: each lane takes one candidate record, makes it tile-relative, culls ----
-                float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) P = rec_pos[r];
-                const int pk = mk_float_as_int(P.w);
-                // (cell centre - tile centre) is an exact small half-integer; ONE rounding per axis
-                const float ex = P.x + ((float)(pk & 1023) * fcs + offx);
-                const float ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
-                const float ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
-                const float gx = fmaxf(fabsf(ex) - HX, 0.f);
-                const float gy = fmaxf(fabsf(ey) - 3.5f, 0.f);
-                const float gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
-                const bool surv = valid && (gx * gx + gy * gy + gz * gz < R2cull);
-                float4 W0 = make_float4(INF, INF, INF, INF), W1 = W0;
-                if (surv) { W0 = w0p[r]; W1 = w1p[r]; }
-                const float wv[CHG] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
-
+    bool sorted_done = false;
+    if (!general) {
+        // ---- the ONE global traversal: cull, park survivors in LDS, histogram the (channel, class) buckets ----
+        bucket[lane] = 0u; bucket[lane + WAVE] = 0u;
+        mk_block_sync();
+        unsigned nsurv = 0;                                               // wave-uniform
+        bool fits = true;
+        for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp,
+            [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
+                const unsigned long long mask = mk_ballot(surv);
+                const unsigned n = (unsigned)mk_popc64(mask);
+                if (nsurv + n > (unsigned)SCAP) fits = false;
+                if (fits && surv) {
+                    const unsigned j = nsurv + (unsigned)mk_rank_in_mask(mask);
+                    sx[ECAP - 1 - j] = ex; sy[ECAP - 1 - j] = ey; sz[ECAP - 1 - j] = ez;
+                    scls[j] = ids;
 #pragma unroll
-                for (int c = 0; c < CHG; ++c) {
-                    const float wc = wv[c];
-                    const bool has = surv && (wc < INF);                // false for +inf and NaN
-                    const unsigned long long mask = mk_ballot(has);
-                    if (mask == 0ull) continue;                          // wave-uniform
-                    const int n = mk_popc64(mask);
-                    // ---- compact this channel's entries through LDS ----
-                    if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
-                    mk_block_sync();
-                    // ---- every lane visits every entry (LDS broadcast read, next entry prefetched) ----
-                    float4 e = ebuf[0];
-                    for (int i = 0; i < n; ++i) {
-                        const float4 en = ebuf[i + 1];                   // slot n is padding
-                        const float dy = Y - e.y, dz = Z - e.z;
-                        const float dyz2 = dy * dy + dz * dz;
-#pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const float dx = ((float)k - HX) - e.x;
-                            const float d2 = dx * dx + dyz2;
-                            const float s = d2 * e.w;
-                            const float t = d2 < R2 ? s : INF;           // occupancy_utils.pyx:53
-                            q[c][k] = mk_min_bits(q[c][k], t);
-                        }
-                        e = en;
+                    for (int c = 0; c < CHG; ++c) {
+                        const unsigned id = (ids >> (4 * c)) & 0xfu;
+                        if (id) (void)mk_lds_add(&bucket[c * NSLOT + (int)id - 1], 1u);
                     }
-                    mk_block_sync();                                     // ebuf is rewritten next
+                }
+                nsurv += n;
+            });
+        mk_block_sync();
+        // ---- bucket starts: lane owns buckets 2*lane, 2*lane+1; every bucket padded to an even count ----
+        const unsigned cnt0 = bucket[2 * lane], cnt1 = bucket[2 * lane + 1];
+        const unsigned pad0 = (cnt0 + 1u) & ~1u, pad1 = (cnt1 + 1u) & ~1u;
+        const unsigned incl = wave_scan_inclusive(pad0 + pad1);
+        const unsigned start0 = incl - (pad0 + pad1), start1 = start0 + pad0;
+        const unsigned total = mk_readlane(incl, WAVE - 1);
+        if (fits && total + nsurv <= (unsigned)ECAP) {                   // wave-uniform; regions do not overlap
+            mk_block_sync();                                             // everyone has read the counts
+            bucket[2 * lane] = start0; bucket[2 * lane + 1] = start1;    // placement cursors
+            // odd buckets get one far-away sentinel so the pair loop never reads a foreign entry
+            if (cnt0 & 1u) { sx[start0 + cnt0] = 1.0e18f; sy[start0 + cnt0] = 0.f; sz[start0 + cnt0] = 0.f; }
+            if (cnt1 & 1u) { sx[start1 + cnt1] = 1.0e18f; sy[start1 + cnt1] = 0.f; sz[start1 + cnt1] = 0.f; }
+            mk_block_sync();
+            // ---- place the parked survivors' entries into their buckets (LDS -> LDS) ----
+            for (unsigned j0 = 0; j0 < nsurv; j0 += WAVE) {
+                const unsigned j = j0 + (unsigned)lane;
+                if (j < nsurv) {
+                    const float ex = sx[ECAP - 1 - j], ey = sy[ECAP - 1 - j], ez = sz[ECAP - 1 - j];
+                    const unsigned ids = scls[j];
+#pragma unroll
+                    for (int c = 0; c < CHG; ++c) {
+                        const unsigned id = (ids >> (4 * c)) & 0xfu;
+                        if (id) {
+                            const unsigned pos = mk_lds_add(&bucket[c * NSLOT + (int)id - 1], 1u);
+                            sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
+                        }
+                    }
                 }
             }
+            mk_block_sync();
+            // ---- process bucket by bucket: inner loop = sub, fma, half a min3 per (voxel, entry) ----
+            const unsigned long long ne0 = mk_ballot(cnt0 != 0u), ne1 = mk_ballot(cnt1 != 0u);
+#pragma unroll
+            for (int c = 0; c < CHG; ++c) {
+                // channel c owns buckets 16c..16c+15 = lanes 8c..8c+7 (two buckets each)
+                unsigned bits = 0;
+                {
+                    const unsigned e = (unsigned)(ne0 >> (8 * c)) & 0xffu, o = (unsigned)(ne1 >> (8 * c)) & 0xffu;
+                    for (int j = 0; j < 8; ++j) bits |= (((e >> j) & 1u) << (2 * j)) | (((o >> j) & 1u) << (2 * j + 1));
+                }
+                while (bits) {                                            // wave-uniform
+                    const int cls = __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    const int owner = 8 * c + (cls >> 1);
+                    const unsigned s = (cls & 1) ? mk_readlane(start1, owner) : mk_readlane(start0, owner);
+                    const unsigned n = (cls & 1) ? mk_readlane(pad1, owner) : mk_readlane(pad0, owner);
+                    const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
+                    unsigned m[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) m[k] = INF_BITS;
+                    for (unsigned i = s; i < s + n; i += 2) {
+                        const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
+                        const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
+                        const float2 pz = *reinterpret_cast<const float2*>(&sz[i]);
+                        const float dya = Y - py.x, dza = Z - pz.x, dyb = Y - py.y, dzb = Z - pz.y;
+                        const float ra = mk_fma(dya, dya, dza * dza), rb = mk_fma(dyb, dyb, dzb * dzb);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) {
+                            const float dxa = ((float)k - HX) - px.x, dxb = ((float)k - HX) - px.y;
+                            m[k] = mk_min3_bits(m[k], mk_fma(dxa, dxa, ra), mk_fma(dxb, dxb, rb));
+                        }
+                    }
+                    // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float d2 = mk_uint_as_float(m[k]);
+                        q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? d2 * wcls : INF);
+                    }
+                }
+            }
+            sorted_done = true;
         }
+    }
+
+    if (!sorted_done) {
+        // ---- general path (arbitrary per-entry sigma, or a tile too dense for the LDS buffers):
+        //      chunk by chunk, per-channel compaction through LDS, cutoff test per (voxel, entry) ----
+        mk_block_sync();
+        auto body = [&](bool surv, unsigned r, float ex, float ey, float ez, unsigned ids) {
+            float wv[CHG];
+            if (general) {
+                float4 W0 = make_float4(INF, INF, INF, INF), W1 = W0;
+                if (surv) { W0 = w0p[r]; W1 = w1p[r]; }
+                wv[0] = W0.x; wv[1] = W0.y; wv[2] = W0.z; wv[3] = W0.w;
+                wv[4] = W1.x; wv[5] = W1.y; wv[6] = W1.z; wv[7] = W1.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CHG; ++c) {
+                    const unsigned id = surv ? (ids >> (4 * c)) & 0xfu : 0u;
+                    wv[c] = id ? mk_uint_as_float(cls_table[id - 1u]) : INF;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CHG; ++c) {
+                const float wc = wv[c];
+                const bool has = surv && (wc < INF);                // false for +inf and NaN
+                const unsigned long long mask = mk_ballot(has);
+                if (mask == 0ull) continue;                          // wave-uniform
+                const int n = mk_popc64(mask);
+                if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
+                mk_block_sync();
+                for (int i = 0; i < n; ++i) {
+                    const float4 e = ebuf[i];
+                    const float dy = Y - e.y, dz = Z - e.z;
+                    const float dyz2 = mk_fma(dy, dy, dz * dz);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float dx = ((float)k - HX) - e.x;
+                        const float d2 = mk_fma(dx, dx, dyz2);               // same fma tree as the sorted path
+                        q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? d2 * e.w : INF);   // occupancy_utils.pyx:53
+                    }
+                }
+                mk_block_sync();                                     // ebuf is rewritten next
+            }
+        };
+        if (general) for_each_candidate<K, false>(g, tg, cell_start, rec_pos, clsp, body);
+        else for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp, body);
+    }
 
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
-    const int y = y0 + ly, z = z0 + lz;
+    const int y = tg.y0 + ly, z = tg.z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int x = x0 + k;
+        const int x = tg.x0 + k;
         float f[CHG];
 #pragma unroll
-        for (int c = 0; c < CHG; ++c)
-            f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
+        for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
         if (yz_in && x < g.nx) {
-            const size_t vox = (size_t)b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+            const size_t vox = (size_t)tg.b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
             if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
                 o[0] = make_float4(f[0], f[1], f[2], f[3]);
@@ -420,9 +736,9 @@ MK_KERNEL(EXPL_THREADS) void k_occupancy_centers(const double* __restrict__ cent
     double cx = 0, cy = 0, cz = 0;
     if (active) { cx = centers[3 * v]; cy = centers[3 * v + 1]; cz = centers[3 * v + 2]; }
     const float INF = mk_inf();
-    float q[CHG];
+    unsigned q[CHG];
 #pragma unroll
-    for (int c = 0; c < CHG; ++c) q[c] = INF;
+    for (int c = 0; c < CHG; ++c) q[c] = 0x7f800000u;
 
     for (long long a0 = 0; a0 < N; a0 += EXPL_THREADS) {
         const long long a = a0 + threadIdx.x;
@@ -447,17 +763,15 @@ MK_KERNEL(EXPL_THREADS) void k_occupancy_centers(const double* __restrict__ cent
             const float4 w0 = s_w0[i], w1 = s_w1[i];
             const float wv[CHG] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-            for (int c = 0; c < CHG; ++c) {
-                const float s = in ? d2f * wv[c] : INF;     // 0*inf = NaN is ignored by mk_min
-                q[c] = mk_min(q[c], s);
-            }
+            for (int c = 0; c < CHG; ++c)
+                q[c] = mk_min_bits(q[c], in ? d2f * wv[c] : INF);     // 0*inf = NaN sorts above +inf
         }
         mk_block_sync();
     }
     if (active) {
 #pragma unroll
         for (int c = 0; c < CHG; ++c)
-            if (gq * CHG + c < C) out[(size_t)v * C + gq * CHG + c] = occupancy_from_q(q[c]);
+            if (gq * CHG + c < C) out[(size_t)v * C + gq * CHG + c] = occupancy_from_q(mk_uint_as_float(q[c]));
     }
 }
 
@@ -473,13 +787,7 @@ MK_KERNEL(256) void k_sigma_to_w(const SigT* __restrict__ sigmas, long long N, i
 #pragma unroll
         for (int c = 0; c < CHG; ++c) {
             const int ch = gq * CHG + c;
-            float wc = mk_inf();
-            if (ch < C) {
-                const double s = (double)sigmas[(size_t)a * C + ch];
-                const float x = (float)(w_scale / (s * s));
-                if (s != 0.0 && x == x) wc = fminf(x, MK_W_MAX);       // NaN sigma: absent
-            }
-            t[c] = wc;
+            t[c] = ch < C ? sigma_to_w(sigmas[(size_t)a * C + ch], w_scale) : mk_inf();
         }
         w[(size_t)(gq * 2 + 0) * N + a] = make_float4(t[0], t[1], t[2], t[3]);
         w[(size_t)(gq * 2 + 1) * N + a] = make_float4(t[4], t[5], t[6], t[7]);

@@ -52,6 +52,14 @@ MK_DEV unsigned mk_min_bits(unsigned q, float t)
     return b < q ? b : q;
 }
 MK_DEV float mk_uint_as_float(unsigned u) { return __uint_as_float(u); }
+MK_DEV unsigned mk_float_bits(float f) { return __float_as_uint(f); }
+// running bit-pattern minimum with TWO non-negative floats (v_min3_u32)
+MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
+{
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    const unsigned t = ua < ub ? ua : ub;
+    return t < m ? t : m;
+}
 
 // workgroup barrier (for the 64-thread tile kernel this is a single-wave s_barrier).
 MK_DEV void mk_block_sync() { __syncthreads(); }
@@ -60,12 +68,31 @@ MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v);
 MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
 MK_DEV void mk_atomic_or(int* p, int v) { atomicOr(p, v); }
 
+MK_DEV unsigned mk_atomic_cas(unsigned* p, unsigned expect, unsigned val) { return atomicCAS(p, expect, val); }
+MK_DEV void mk_atomic_min(unsigned* p, unsigned v) { atomicMin(p, v); }
+// device-scope relaxed load (bypasses this CU's L1: sees other CUs' atomics)
+MK_DEV unsigned mk_load_relaxed(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { return atomicCAS(p, expect, val); }  // ds_cmpst_rtn
+MK_DEV float mk_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }                        // v_fma_f32, never split
+// LDS atomic add, returns the old value (ds_add_rtn_u32)
+MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+// value of `v` in lane `lane` (wave-uniform index) -> SGPR (v_readlane_b32)
+MK_DEV unsigned mk_readlane(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
+
 MK_DEV unsigned mk_shfl_up(unsigned v, int delta) { return __shfl_up(v, delta, WAVE); }
 MK_DEV unsigned mk_shfl_down(unsigned v, int delta) { return __shfl_down(v, delta, WAVE); }
 
 // separately rounded double multiply / add (never contracted into an FMA)
-MK_DEV double mk_dmul_rn(double a, double b) { return __dmul_rn(a, b); }
-MK_DEV double mk_dadd_rn(double a, double b) { return __dadd_rn(a, b); }
+MK_DEV double mk_dmul_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+MK_DEV double mk_dadd_rn(double a, double b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 MK_DEV float mk_int_as_float(int i) { return __int_as_float(i); }
 MK_DEV int mk_float_as_int(float f) { return __float_as_int(f); }

@@ -6,12 +6,13 @@
 //
 // Backend concept:
 //   int  ensure(int slot, size_t bytes, void** ptr)     grow-only workspace buffer
-//   int  zero(void* p, size_t bytes)                    async memset on the stream
+//   int  fill(void* p, int byte, size_t bytes)          async memset on the stream
 //   int  launch(kernel, dim3 grid, dim3 block, args...) async launch on the stream
 //   void hot_begin() / hot_end()                        bracket the tile kernel (event timing)
 #pragma once
 #include "kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <string>
@@ -21,7 +22,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_ERR, WS_W_EXPLICIT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
     WS_NSLOTS
@@ -39,6 +40,7 @@ struct LatticeProblem {
     int pbc = 0;
     int max_images = 1;
     int tile_k = 0;                         // 0 = auto
+    int force_general = 0;                  // 1 = never use the class-sorted path
     // device pointers
     const float* coords = nullptr;
     const long long* atom_offsets = nullptr;
@@ -62,7 +64,7 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     g.nx = P.nvox[0]; g.ny = P.nvox[1]; g.nz = P.nvox[2];
     g.V = (long long)g.nx * g.ny * g.nz;
     g.C = P.C; g.G = ceil_div(P.C, CHG);
-    g.B = P.B; g.pbc = P.pbc ? 1 : 0;
+    g.B = P.B; g.pbc = P.pbc ? 1 : 0; g.force_general = P.force_general ? 1 : 0;
     g.inv_res = 1.0 / P.voxelsize;
     g.w_scale = P.voxelsize * P.voxelsize;
     const double R = CUTOFF_A / P.voxelsize;                 // cutoff in voxel units
@@ -150,24 +152,36 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (P.B == 0 || g.V == 0) return ST_OK;
 
     const size_t ncells = (size_t)g.B * (size_t)g.ncell;
-    void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *eflag = nullptr;
+    void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
     if ((st = be.ensure(WS_CELL_COUNT, ncells * sizeof(unsigned), &count))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start))) return st;
     if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos))) return st;
     if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw))) return st;
+    if ((st = be.ensure(WS_REC_CLS, (size_t)g.M * sizeof(unsigned) * g.G, &rcls))) return st;
+    if ((st = be.ensure(WS_CLS_TABLE, CLS_TABLE_WORDS * sizeof(unsigned), &ctab))) return st;
     if ((st = be.ensure(WS_ERR, sizeof(int), &eflag))) return st;
 
-    if ((st = be.zero(count, ncells * sizeof(unsigned)))) return st;
+    if ((st = be.fill(count, 0, ncells * sizeof(unsigned)))) return st;
+    if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;     // all slots CLS_EMPTY
     const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
 #define MK_BIN(PHASE)                                                                                   \
     (P.sigmas_f64                                                                                       \
          ? be.launch(k_bin_atoms<PHASE, double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, \
                      (const double*)P.sigmas, P.origins, P.box, (unsigned*)count, (const unsigned*)start, \
-                     (float4*)rpos, (float4*)rw, (int*)eflag)                                            \
+                     (float4*)rpos, (float4*)rw, (unsigned*)rcls, (unsigned*)ctab, (int*)eflag)              \
          : be.launch(k_bin_atoms<PHASE, float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms,  \
                      (const float*)P.sigmas, P.origins, P.box, (unsigned*)count, (const unsigned*)start,  \
-                     (float4*)rpos, (float4*)rw, (int*)eflag))
+                     (float4*)rpos, (float4*)rw, (unsigned*)rcls, (unsigned*)ctab, (int*)eflag))
     if (P.total_atoms > 0 && (st = MK_BIN(0))) return st;
+    if (P.total_atoms > 0 && !g.force_general) {                      // distinct sigma values -> class table
+        const unsigned nb = (unsigned)std::min<long long>(CLS_MAX_BLOCKS, ceil_div(P.total_atoms, 256));
+        void* bsets = nullptr;
+        if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nb * CLS_BLOCK_SET * sizeof(unsigned), &bsets))) return st;
+        st = P.sigmas_f64 ? be.launch(k_collect_classes<double>, dim3(nb), ablk, (const double*)P.sigmas, P.total_atoms, g.C, g.w_scale, (unsigned*)bsets)
+                          : be.launch(k_collect_classes<float>, dim3(nb), ablk, (const float*)P.sigmas, P.total_atoms, g.C, g.w_scale, (unsigned*)bsets);
+        if (st) return st;
+        if ((st = be.launch(k_merge_classes, dim3(1), dim3(256), (const unsigned*)bsets, nb * (unsigned)CLS_BLOCK_SET, (unsigned*)ctab))) return st;
+    }
     if ((st = run_scan(be, (const unsigned*)count, ncells, (unsigned*)start))) return st;
     if (P.total_atoms > 0 && (st = MK_BIN(1))) return st;
 #undef MK_BIN
@@ -176,9 +190,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G), tblk(WAVE);
     be.hot_begin();
     if (g.K == 8)
-        st = be.launch(k_voxelize_tiles<8>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, P.out);
+        st = be.launch(k_voxelize_tiles<8>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, P.out);
     else
-        st = be.launch(k_voxelize_tiles<4>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, P.out);
+        st = be.launch(k_voxelize_tiles<4>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, P.out);
     be.hot_end();
     return st;
 }

@@ -27,7 +27,7 @@ struct EmuBackend {
         *ptr = bufs[slot];
         return 0;
     }
-    int zero(void* p, size_t bytes) { memset(p, 0, bytes); return 0; }
+    int fill(void* p, int byte, size_t bytes) { memset(p, byte, bytes); return 0; }
     template <class... KA, class... A>
     int launch(void (*kernel)(KA...), dim3 grid, dim3 block, A... args)
     {
@@ -49,7 +49,7 @@ const char* emu_last_error(void) { return g_err.c_str(); }
 // mirrors mkamd_voxelize_lattice_host (pointers are host pointers; features is poisoned first)
 int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offsets, const void* sigmas,
                          int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
-                         const float* box, int max_images, int tile_k, float* features, int* err_flag_out)
+                         const float* box, int max_images, int tile_k, int force_general, float* features, int* err_flag_out)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -58,7 +58,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     LatticeProblem P;
     P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
     P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
-    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k;
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general;
     if (box && max_images <= 0) {
         max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);
         if (max_images < 0) return ST_EBOX;

@@ -33,6 +33,9 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct float2 { float x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
 // "registers" of the fiber that is currently running
@@ -170,12 +173,33 @@ MK_DEV float mk_rcp_refined(float x)
 MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
+{
+    const unsigned ua = mk_float_bits(a), ub = mk_float_bits(b);
+    const unsigned t = ua < ub ? ua : ub;
+    return t < m ? t : m;
+}
 MK_DEV unsigned mk_min_bits(unsigned q, float t) { const unsigned b = mk_float_bits(t); return b < q ? b : q; }
 MK_DEV float mk_uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 MK_DEV void mk_block_sync() { emu::rendezvous(16, emu::g_blk.nthreads); }
 MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
 MK_DEV void mk_atomic_or(int* p, int v) { *p |= v; }
+MK_DEV unsigned mk_atomic_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
+MK_DEV void mk_atomic_min(unsigned* p, unsigned v) { if (v < *p) *p = v; }
+MK_DEV unsigned mk_load_relaxed(unsigned* p) { return *p; }
+MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
+MK_DEV float mk_fma(float a, float b, float c) { return fmaf(a, b, c); }
+MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+MK_DEV unsigned mk_readlane(unsigned v, int lane)
+{
+    const int wv = (int)threadIdx.x >> 6;
+    emu::g_blk.xchg[threadIdx.x] = v;
+    emu::rendezvous(wv, WAVE);
+    const unsigned r = emu::g_blk.xchg[(wv << 6) + lane];
+    emu::rendezvous(wv, WAVE);
+    return r;
+}
 MK_DEV unsigned mk_shfl_up(unsigned v, int delta)
 {
     const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;

@@ -89,3 +89,44 @@ def test_record_overflow_is_flagged():
     _, err = E.voxelize_lattice(c, [0, 50], s, [[0, 0, 0]], [40, 40, 40], 1.0,
                                 box=np.array([[12.0, 12.0, 12.0]], np.float32), max_images=1)
     assert err & 1
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "special_sigmas", "pbc_batch", "channels11"])
+def test_sorted_and_general_paths_are_bit_identical(name):
+    """The class-sorted tile path (cutoff and w hoisted out of the inner loop) must reproduce the
+    general per-pair path bit for bit: min commutes exactly with multiplication by w > 0."""
+    case = LATTICE_CASES[name]()
+    a, _ = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"],
+                              case["nvoxels"], case["voxelsize"], box=case["box"], tile_k=8)
+    b, _ = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"],
+                              case["nvoxels"], case["voxelsize"], box=case["box"], tile_k=8, force_general=True)
+    assert np.array_equal(a, b)
+
+
+def test_more_than_16_sigma_classes_falls_back_to_general_path():
+    rng = np.random.default_rng(31)
+    n = 120
+    c = rng.normal(0, 4, size=(n, 3)).astype(np.float32)
+    s = np.where(rng.random((n, 8)) < 0.3, rng.uniform(0.8, 2.5, size=(n, 8)), 0.0)   # ~290 distinct sigmas
+    case = dict(coords=c, atom_offsets=np.array([0, n]), sigmas=s, origins=np.array([[-8.0, -8, -8]]),
+                nvoxels=np.array([16, 16, 16]), voxelsize=1.0, box=None)
+    from tests.cases import oracle_lattice
+    case["expected"] = oracle_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0)
+    got, err = E.voxelize_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0)
+    assert err == 0
+    check(case, got)
+
+
+def test_tile_denser_than_lds_capacity_falls_back_per_tile():
+    """> 1024 entries within reach of one tile: that tile takes the chunked path, others stay sorted."""
+    rng = np.random.default_rng(32)
+    n = 900
+    c = rng.uniform(0, 7, size=(n, 3)).astype(np.float32)          # 900 atoms in a 7 A cube, 8 channels each
+    s = np.tile(rng.choice([1.1, 1.7, 1.52], size=(n, 1)), (1, 8))
+    case = dict(coords=c, atom_offsets=np.array([0, n]), sigmas=s, origins=np.array([[-4.0, -4, -4]]),
+                nvoxels=np.array([24, 16, 16]), voxelsize=1.0, box=None)
+    from tests.cases import oracle_lattice
+    case["expected"] = oracle_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0)
+    got, err = E.voxelize_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0, tile_k=8)
+    assert err == 0
+    check(case, got)

@@ -20,9 +20,33 @@ def test_lattice_case(hip_ctx, name, tile_k):
     try:
         got = batch.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"],
                                      case["nvoxels"], case["voxelsize"], box=case["box"], ctx=hip_ctx)
+        hip_ctx.set_force_general(True)
+        gen = batch.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"],
+                                     case["nvoxels"], case["voxelsize"], box=case["box"], ctx=hip_ctx)
     finally:
         hip_ctx.set_tile_k(0)
+        hip_ctx.set_force_general(False)
     check(case, got)
+    # class-sorted path (cutoff and w hoisted out of the inner loop) == general per-pair path, bit for bit
+    assert np.array_equal(got, gen)
+
+
+def test_many_sigma_classes_and_dense_tiles(hip_ctx):
+    """> 15 distinct sigmas -> general path for the call; > LDS capacity around one tile -> that tile only."""
+    from moleculekit_amd import batch
+    rng = np.random.default_rng(31)
+    n = 400
+    c = rng.normal(0, 4, size=(n, 3)).astype(np.float32)
+    s = np.where(rng.random((n, 8)) < 0.3, rng.uniform(0.8, 2.5, size=(n, 8)), 0.0)
+    o, nv = np.array([[-8.0, -8, -8]]), np.array([16, 16, 16])
+    got = batch.voxelize_lattice(c, [0, n], s, o, nv, 1.0, ctx=hip_ctx)
+    assert np.abs(got - oracle_lattice(c, np.array([0, n]), s, o, nv, 1.0)).max() <= TOL
+    n = 900
+    c = rng.uniform(0, 7, size=(n, 3)).astype(np.float32)
+    s = np.tile(rng.choice([1.1, 1.7, 1.52], size=(n, 1)), (1, 8))
+    o, nv = np.array([[-4.0, -4, -4]]), np.array([24, 16, 16])
+    got = batch.voxelize_lattice(c, [0, n], s, o, nv, 1.0, ctx=hip_ctx)
+    assert np.abs(got - oracle_lattice(c, np.array([0, n]), s, o, nv, 1.0)).max() <= TOL
 
 
 @pytest.mark.parametrize("C", [1, 3, 11])
@@ -130,14 +154,22 @@ def test_full_size_batches_size_independent_properties(hip_ctx):
     rev_sig = p["sigmas"].reshape(B, n, 8)[::-1].reshape(-1, 8)
     rev = batch.voxelize_lattice(rev_coords, p["atom_offsets"], rev_sig, origins[::-1], nv, p["voxelsize"], ctx=hip_ctx)
     assert np.array_equal(rev[::-1], full)
-    # translation covariance: shifting atoms and origin by whole voxels (exact in fp) is bit-identical
+    # translation covariance: with coordinates on a 1/1024 A lattice, shifting atoms and origin by whole
+    # voxels is exact in float32, so the result must not change at all (positions are handled relative
+    # to the grid, never as absolute float32 numbers)
     shift = np.array([16.0, -8.0, 32.0])
-    moved = batch.voxelize_lattice((p["coords"][: 8 * n] + shift).astype(np.float32), p["atom_offsets"][:9],
+    snapped = (np.round(p["coords"][: 8 * n] * 1024) / 1024).astype(np.float32)
+    base = batch.voxelize_lattice(snapped, p["atom_offsets"][:9], p["sigmas"][: 8 * n], origins[:8], nv,
+                                  p["voxelsize"], ctx=hip_ctx)
+    moved = batch.voxelize_lattice((snapped + shift).astype(np.float32), p["atom_offsets"][:9],
                                    p["sigmas"][: 8 * n], origins[:8] + shift, nv, p["voxelsize"], ctx=hip_ctx)
-    assert np.abs(moved - full[:8]).max() <= 2e-6
-    # max-linearity: A u B == max(A, B), exactly (min/max are exact)
+    assert np.array_equal((snapped + shift).astype(np.float32) - shift.astype(np.float32), snapped)
+    assert np.array_equal(moved, base)
+    # max-linearity: A u B == max(A, B), exactly (min/max are exact; same tile depth -> same roundings)
+    hip_ctx.set_tile_k(8)
     a = batch.voxelize_lattice(p["coords"][:30], np.array([0, 30]), p["sigmas"][:30], origins[:1], nv, 1.0, ctx=hip_ctx)
     b = batch.voxelize_lattice(p["coords"][30:60], np.array([0, 30]), p["sigmas"][30:60], origins[:1], nv, 1.0, ctx=hip_ctx)
+    hip_ctx.set_tile_k(0)
     assert np.array_equal(np.maximum(a, b)[0], full[0])
 
 
