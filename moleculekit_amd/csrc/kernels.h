@@ -33,8 +33,9 @@ constexpr int CHG = 8;               // channels per channel-group (one group = 
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per call (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
-constexpr int ECAP = 1024;           // LDS entry capacity of a tile (3 x 4 KiB, structure of arrays)
-constexpr int SCAP = 512;            // LDS capacity for surviving candidate atoms of a tile
+constexpr int ECAP = 768;            // LDS entry capacity of a tile (3 x 3 KiB, structure of arrays)
+constexpr int NXR = 3;               // x-reach sub-buckets: 0 = all K planes, 1 = low half only, 2 = high half only
+constexpr int NBUCKET3 = NBUCKET * NXR;
 constexpr unsigned CLS_EMPTY = 0xffffffffu;   // empty slot of the class table (never a valid w)
 constexpr int CLS_OVERFLOW = NCLS;   // word NCLS of the table buffer: CLS_EMPTY, or 0 once > NCLS classes were seen
 constexpr int CLS_TABLE_WORDS = NCLS + 1;
@@ -79,13 +80,6 @@ MK_DEV float sigma_to_w(SigT sigma, double w_scale)
 }
 
 // Class table: NCLS slots of w bit patterns (CLS_EMPTY = unused), word NCLS = overflow marker.
-MK_DEV int class_lookup(const unsigned* table, unsigned bits)
-{
-    for (int s = 0; s < NCLS; ++s)
-        if (table[s] == bits) return s;
-    return -1;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Class discovery: the distinct w values of the batch -> cls_table (<= NCLS, else the overflow word
 // is raised and the call takes the general tile path).  Two tiny kernels and NO global atomics (a
@@ -194,7 +188,7 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
                                 const float* __restrict__ box, unsigned* __restrict__ cell_count,
                                 const unsigned* __restrict__ cell_start, float4* __restrict__ rec_pos,
                                 float4* __restrict__ rec_w, unsigned* __restrict__ rec_cls,
-                                unsigned* cls_table, int* __restrict__ err_flag)
+                                const unsigned* __restrict__ cls_table, int* __restrict__ err_flag)
 {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= total_atoms) return;
@@ -234,6 +228,14 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
 
     const double inv_cs = 1.0 / (double)g.cs;
     const double cmid = 0.5 * (double)(g.cs - 1);
+    // class table -> registers (wave-uniform loads), so that a lookup is NCLS register compares
+    unsigned tab[NCLS];
+    bool general = true;
+    if (PHASE == 1) {
+        general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+#pragma unroll
+        for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
+    }
     for (int kx = k0[0]; kx <= k1[0]; ++kx)
         for (int ky = k0[1]; ky <= k1[1]; ++ky)
             for (int kz = k0[2]; kz <= k1[2]; ++kz) {
@@ -258,7 +260,6 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
                     if (slot >= g.M) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
                     rec_pos[slot] = make_float4(rel[0], rel[1], rel[2],
                                                 mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
-                    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
                     for (int gq = 0; gq < g.G; ++gq) {
                         float w[CHG];
 #pragma unroll
@@ -274,7 +275,11 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
 #pragma unroll
                             for (int c = 0; c < CHG; ++c) {
                                 unsigned id = 0;
-                                if (w[c] < mk_inf()) id = (unsigned)(class_lookup(cls_table, mk_float_bits(w[c])) + 1);
+                                if (w[c] < mk_inf()) {
+                                    const unsigned bits = mk_float_bits(w[c]);
+#pragma unroll
+                                    for (int i = 0; i < NCLS; ++i) id = (tab[i] == bits) ? (unsigned)(i + 1) : id;
+                                }
                                 ids |= id << (4 * c);
                             }
                             rec_cls[(size_t)gq * g.M + slot] = ids;
@@ -399,6 +404,8 @@ MK_DEV float occupancy_from_q(float q)
 // THE hot kernel.  One 64-lane wave per K x 8 x 8 voxel tile (lane = (y,z), z fastest as in the
 // output layout, K x-planes per lane in registers); blockIdx.y = channel group.
 // ------------------------------------------------------------------------------------------------
+template <int N> struct IntC { static constexpr int value = N; };   // compile-time int for generic lambdas
+
 struct TileGeom {                     // wave-uniform description of the tile being voxelized
     int b, x0, y0, z0;
     int cx_lo, cx_hi, cy_lo, cy_hi, cz_lo, cz_hi;
@@ -477,14 +484,19 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
 {
     static_assert(K == 4 || K == 8, "K");
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
-    // broadcast reads (ds_read_b64: 2 LDS cycles each).  Sorted entries grow from index 0 up; the
-    // surviving candidate atoms of the (single) global traversal are parked from ECAP-1 down.
+    // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
+    // (measured: 1.25 -> 2 waves/SIMD = 1.44x), hence the lean 12.7 KiB budget -> 3 waves/SIMD.
     __shared__ __attribute__((aligned(16))) float sx[ECAP + 2];
     __shared__ __attribute__((aligned(16))) float sy[ECAP + 2];
     __shared__ __attribute__((aligned(16))) float sz[ECAP + 2];
-    __shared__ unsigned scls[SCAP];               // class ids of the parked survivors
-    __shared__ float4 ebuf[WAVE];                 // general path: one chunk's entries of one channel (x,y,z,w)
-    __shared__ unsigned bucket[NBUCKET];          // per-tile histogram, then placement cursors
+    float4* const ebuf = reinterpret_cast<float4*>(sx);   // general path: one chunk's entries of one channel (x,y,z,w)
+#ifdef MK_LDS_PAD                                  // occupancy experiment knob (tools/): waste LDS on purpose
+    __shared__ unsigned lds_pad[MK_LDS_PAD / 4];
+    if (g.nx < 0) lds_pad[threadIdx.x] = 1u, out[0] = (float)lds_pad[(threadIdx.x + 1) & 63];
+#endif
+    __shared__ unsigned bucket[NBUCKET3];         // per-tile histogram, then placement cursors
+    // per (channel, class) group: start of {all-planes, low-half, high-half} sub-bucket and the group's end
+    __shared__ __attribute__((aligned(16))) unsigned bgroup[NBUCKET * 4];
 
     const int lane = threadIdx.x;
     // XCD-aware order: the dispatcher places block i on XCD i%8; give each XCD a contiguous run of
@@ -545,64 +557,80 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
 
     bool sorted_done = false;
     if (!general) {
-        // ---- the ONE global traversal: cull, park survivors in LDS, histogram the (channel, class) buckets ----
-        bucket[lane] = 0u; bucket[lane + WAVE] = 0u;
+        // ---- traversal 1: cull and histogram the buckets (traversal 2 places; the records are L2-hot then) ----
+        // bucket = (channel, class, x-reach): an entry whose x lies more than the cutoff below the
+        // middle of the tile cannot reach the upper K/2 planes (those pairs would fail d^2 < 25 on
+        // dx^2 alone) and vice versa, so such entries are only run against their half of the planes.
+        const float reach = sqrtf(R2) * 1.000001f;
+#pragma unroll
+        for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
         mk_block_sync();
-        unsigned nsurv = 0;                                               // wave-uniform
-        bool fits = true;
         for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp,
-            [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
-                const unsigned long long mask = mk_ballot(surv);
-                const unsigned n = (unsigned)mk_popc64(mask);
-                if (nsurv + n > (unsigned)SCAP) fits = false;
-                if (fits && surv) {
-                    const unsigned j = nsurv + (unsigned)mk_rank_in_mask(mask);
-                    sx[ECAP - 1 - j] = ex; sy[ECAP - 1 - j] = ey; sz[ECAP - 1 - j] = ez;
-                    scls[j] = ids;
+            [&](bool surv, unsigned, float ex, float, float, unsigned ids) {
+                if (surv) {
+                    const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
 #pragma unroll
                     for (int c = 0; c < CHG; ++c) {
                         const unsigned id = (ids >> (4 * c)) & 0xfu;
-                        if (id) (void)mk_lds_add(&bucket[c * NSLOT + (int)id - 1], 1u);
+                        if (id) (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                     }
                 }
-                nsurv += n;
             });
         mk_block_sync();
-        // ---- bucket starts: lane owns buckets 2*lane, 2*lane+1; every bucket padded to an even count ----
-        const unsigned cnt0 = bucket[2 * lane], cnt1 = bucket[2 * lane + 1];
-        const unsigned pad0 = (cnt0 + 1u) & ~1u, pad1 = (cnt1 + 1u) & ~1u;
-        const unsigned incl = wave_scan_inclusive(pad0 + pad1);
-        const unsigned start0 = incl - (pad0 + pad1), start1 = start0 + pad0;
-        const unsigned total = mk_readlane(incl, WAVE - 1);
-        if (fits && total + nsurv <= (unsigned)ECAP) {                   // wave-uniform; regions do not overlap
-            mk_block_sync();                                             // everyone has read the counts
-            bucket[2 * lane] = start0; bucket[2 * lane + 1] = start1;    // placement cursors
-            // odd buckets get one far-away sentinel so the pair loop never reads a foreign entry
-            if (cnt0 & 1u) { sx[start0 + cnt0] = 1.0e18f; sy[start0 + cnt0] = 0.f; sz[start0 + cnt0] = 0.f; }
-            if (cnt1 & 1u) { sx[start1 + cnt1] = 1.0e18f; sy[start1 + cnt1] = 0.f; sz[start1 + cnt1] = 0.f; }
-            mk_block_sync();
-            // ---- place the parked survivors' entries into their buckets (LDS -> LDS) ----
-            for (unsigned j0 = 0; j0 < nsurv; j0 += WAVE) {
-                const unsigned j = j0 + (unsigned)lane;
-                if (j < nsurv) {
-                    const float ex = sx[ECAP - 1 - j], ey = sy[ECAP - 1 - j], ez = sz[ECAP - 1 - j];
-                    const unsigned ids = scls[j];
+        // ---- bucket starts: lane owns groups 2*lane, 2*lane+1 (3 sub-buckets each); every sub-bucket
+        //      is padded to an even count so the pair loop never straddles two of them ----
+        unsigned cnt[2 * NXR], pad[2 * NXR], start[2 * NXR];
+        unsigned mine = 0;
 #pragma unroll
-                    for (int c = 0; c < CHG; ++c) {
-                        const unsigned id = (ids >> (4 * c)) & 0xfu;
-                        if (id) {
-                            const unsigned pos = mk_lds_add(&bucket[c * NSLOT + (int)id - 1], 1u);
-                            sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
-                        }
-                    }
-                }
+        for (int i = 0; i < 2 * NXR; ++i) {
+            cnt[i] = bucket[2 * NXR * lane + i];
+            pad[i] = (cnt[i] + 1u) & ~1u;
+            mine += pad[i];
+        }
+        const unsigned incl = wave_scan_inclusive(mine);
+        const unsigned total = mk_readlane(incl, WAVE - 1);
+        {
+            unsigned run = incl - mine;
+#pragma unroll
+            for (int i = 0; i < 2 * NXR; ++i) { start[i] = run; run += pad[i]; }
+        }
+        if (total <= (unsigned)ECAP) {                                   // wave-uniform
+            mk_block_sync();                                             // everyone has read the counts
+#pragma unroll
+            for (int i = 0; i < 2 * NXR; ++i) {
+                bucket[2 * NXR * lane + i] = start[i];                   // placement cursors
+                // odd sub-buckets get one far-away sentinel entry
+                if (cnt[i] & 1u) { sx[start[i] + cnt[i]] = 1.0e18f; sy[start[i] + cnt[i]] = 0.f; sz[start[i] + cnt[i]] = 0.f; }
+            }
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                unsigned* bg = &bgroup[(2 * lane + gi) * 4];
+                bg[0] = start[gi * NXR + 0]; bg[1] = start[gi * NXR + 1]; bg[2] = start[gi * NXR + 2];
+                bg[3] = start[gi * NXR + 2] + pad[gi * NXR + 2];
             }
             mk_block_sync();
-            // ---- process bucket by bucket: inner loop = sub, fma, half a min3 per (voxel, entry) ----
-            const unsigned long long ne0 = mk_ballot(cnt0 != 0u), ne1 = mk_ballot(cnt1 != 0u);
+            // ---- traversal 2: place the entries into their buckets ----
+            for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp,
+                [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
+                    if (surv) {
+                        const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+#pragma unroll
+                        for (int c = 0; c < CHG; ++c) {
+                            const unsigned id = (ids >> (4 * c)) & 0xfu;
+                            if (id) {
+                                const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+                                sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
+                            }
+                        }
+                    }
+                });
+            mk_block_sync();
+            // ---- process group by group: inner loop = sub, fma, half a min3 per (voxel, entry) ----
+            const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
+            const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u);
 #pragma unroll
             for (int c = 0; c < CHG; ++c) {
-                // channel c owns buckets 16c..16c+15 = lanes 8c..8c+7 (two buckets each)
+                // channel c owns groups 16c..16c+15 = lanes 8c..8c+7 (two groups each)
                 unsigned bits = 0;
                 {
                     const unsigned e = (unsigned)(ne0 >> (8 * c)) & 0xffu, o = (unsigned)(ne1 >> (8 * c)) & 0xffu;
@@ -611,25 +639,30 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                 while (bits) {                                            // wave-uniform
                     const int cls = __builtin_ctz(bits);
                     bits &= bits - 1u;
-                    const int owner = 8 * c + (cls >> 1);
-                    const unsigned s = (cls & 1) ? mk_readlane(start1, owner) : mk_readlane(start0, owner);
-                    const unsigned n = (cls & 1) ? mk_readlane(pad1, owner) : mk_readlane(pad0, owner);
+                    const uint4 bg = *reinterpret_cast<const uint4*>(&bgroup[(c * NSLOT + cls) * 4]);   // uniform read
                     const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
                     unsigned m[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) m[k] = INF_BITS;
-                    for (unsigned i = s; i < s + n; i += 2) {
-                        const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
-                        const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
-                        const float2 pz = *reinterpret_cast<const float2*>(&sz[i]);
-                        const float dya = Y - py.x, dza = Z - pz.x, dyb = Y - py.y, dzb = Z - pz.y;
-                        const float ra = mk_fma(dya, dya, dza * dza), rb = mk_fma(dyb, dyb, dzb * dzb);
+                    // planes [K0, K1) against the (even-length) entry range [s, e)
+                    auto run = [&](auto k0_, auto k1_, unsigned s0, unsigned e0) {
+                        constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+                        for (unsigned i = s0; i < e0; i += 2) {
+                            const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
+                            const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
+                            const float2 pz = *reinterpret_cast<const float2*>(&sz[i]);
+                            const float dya = Y - py.x, dza = Z - pz.x, dyb = Y - py.y, dzb = Z - pz.y;
+                            const float ra = mk_fma(dya, dya, dza * dza), rb = mk_fma(dyb, dyb, dzb * dzb);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const float dxa = ((float)k - HX) - px.x, dxb = ((float)k - HX) - px.y;
-                            m[k] = mk_min3_bits(m[k], mk_fma(dxa, dxa, ra), mk_fma(dxb, dxb, rb));
+                            for (int k = K0; k < K1; ++k) {
+                                const float dxa = ((float)k - HX) - px.x, dxb = ((float)k - HX) - px.y;
+                                m[k] = mk_min3_bits(m[k], mk_fma(dxa, dxa, ra), mk_fma(dxb, dxb, rb));
+                            }
                         }
-                    }
+                    };
+                    run(IntC<0>{}, IntC<K>{}, bg.x, bg.y);
+                    run(IntC<0>{}, IntC<K / 2>{}, bg.y, bg.z);
+                    run(IntC<K / 2>{}, IntC<K>{}, bg.z, bg.w);
                     // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
 #pragma unroll
                     for (int k = 0; k < K; ++k) {

@@ -35,6 +35,7 @@ struct dim3 {
 struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct float2 { float x, y; };
+struct uint4 { unsigned x, y, z, w; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
