@@ -35,7 +35,10 @@ static int hip_fail(hipError_t e, const char* what)
 struct mkamd_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // stream the launches of the current call go to (main or side)
+    hipStream_t main_stream = nullptr;     // the caller-visible stream
+    hipStream_t side_stream = nullptr;     // internal: independent pre-pass work (class discovery)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* bufs[WS_NSLOTS] = {};
     size_t caps[WS_NSLOTS] = {};
     int tile_k = 0;
@@ -52,7 +55,8 @@ struct mkamd_ctx {
         if (bytes == 0) bytes = 16;
         if (caps[slot] < bytes) {
             if (bufs[slot]) {
-                HIP_TRY(hipStreamSynchronize(stream));       // buffer may still be in use
+                HIP_TRY(hipStreamSynchronize(main_stream));  // buffer may still be in use
+                if (side_stream) HIP_TRY(hipStreamSynchronize(side_stream));
                 HIP_TRY(hipFree(bufs[slot]));
                 bufs[slot] = nullptr; caps[slot] = 0;
             }
@@ -75,6 +79,24 @@ struct mkamd_ctx {
         hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+    void side_begin()
+    {
+        if (!side_stream) return;
+        (void)hipEventRecord(ev_fork, main_stream);
+        (void)hipStreamWaitEvent(side_stream, ev_fork, 0);
+        stream = side_stream;
+    }
+    void side_end()
+    {
+        if (!side_stream) return;
+        (void)hipEventRecord(ev_join, side_stream);
+        stream = main_stream;
+    }
+    void side_join()
+    {
+        if (!side_stream) return;
+        (void)hipStreamWaitEvent(main_stream, ev_join, 0);
     }
     void hot_begin()
     {
@@ -100,6 +122,7 @@ static int check_ctx(mkamd_ctx* ctx)
 {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
+    ctx->stream = ctx->main_stream;           // a failed call may have left the side stream selected
     return 0;
 }
 
@@ -157,7 +180,12 @@ int mkamd_ctx_create(int device, mkamd_ctx** out)
     c->device = device;
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
-    c->stream = c->own_stream;
+    c->stream = c->main_stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        c->side_stream = nullptr;               // fall back to a single in-order stream
+    }
     *out = c;
     return MKAMD_OK;
 }
@@ -171,6 +199,9 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx)
         if (ctx->bufs[i]) (void)hipFree(ctx->bufs[i]);
     for (auto& ev : ctx->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MKAMD_OK;
@@ -181,9 +212,9 @@ int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream)
     int st = check_ctx(ctx);
     if (st) return st;
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
-    if (next == ctx->stream) return MKAMD_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));      // workspace is shared between the two streams
-    ctx->stream = next;
+    if (next == ctx->main_stream) return MKAMD_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->main_stream)); // workspace is shared between the two streams
+    ctx->stream = ctx->main_stream = next;
     return MKAMD_OK;
 }
 

@@ -59,7 +59,8 @@ struct GridDesc {
     double w_scale;             // voxelsize^2  (w = w_scale / sigma^2 -> q is in A^2/A^2)
     double Rp;                  // image acceptance radius, voxel units (cutoff + margin)
     long long V;                // nx*ny*nz
-    unsigned M;                 // capacity of the record arrays
+    unsigned M;                 // capacity of the record arrays (= total atoms x img_cap)
+    int img_cap;                // temp / record slots reserved per atom (1 unless periodic)
 };
 
 // w of a present channel is clamped to a finite value (+inf is the "channel absent" marker): a
@@ -89,7 +90,7 @@ MK_DEV float sigma_to_w(SigT sigma, double w_scale)
 //   k_merge_classes   : one block merges the per-block sets into the final table
 // ------------------------------------------------------------------------------------------------
 constexpr int CLS_BLOCK_SET = 32;
-constexpr int CLS_MAX_BLOCKS = 512;
+constexpr int CLS_MAX_BLOCKS = 1024;
 
 MK_DEV unsigned class_hash(unsigned bits) { return (bits >> 9) ^ (bits >> 15) ^ (bits >> 21); }
 
@@ -120,20 +121,35 @@ MK_KERNEL(256) void k_collect_classes(const SigT* __restrict__ sigmas, long long
          base += (long long)gridDim.x * blockDim.x) {                 // block-uniform trip count
         const long long a = base + threadIdx.x;
         const bool act = a < total_atoms;
-        for (int c = 0; c < C; ++c) {
-            unsigned bits = CLS_EMPTY;
-            if (act) {
-                const float w = sigma_to_w(sigmas[(size_t)a * C + c], w_scale);
-                if (w < mk_inf()) bits = mk_float_bits(w);
+        for (int c0 = 0; c0 < C; c0 += CHG) {
+            // fetch up to 8 sigmas of this atom in one go (independent loads), then deduplicate
+            unsigned wb[CHG];
+#pragma unroll
+            for (int j = 0; j < CHG; ++j) {
+                wb[j] = CLS_EMPTY;
+                if (act && c0 + j < C) {
+                    const float w = sigma_to_w(sigmas[(size_t)a * C + c0 + j], w_scale);
+                    if (w < mk_inf()) wb[j] = mk_float_bits(w);
+                }
             }
-            bool pending = bits != CLS_EMPTY;
-            for (;;) {                                               // wave-uniform: one trip per distinct value
-                const unsigned long long mask = mk_ballot(pending);
-                if (mask == 0ull) break;
-                const int leader = __builtin_ctzll(mask);
-                const unsigned lb = mk_readlane(bits, leader);
-                if (bits == lb) pending = false;
-                if (lane == leader && !lds_set_insert(s_set, CLS_BLOCK_SET, lb)) s_full = 1u;
+            // most atoms carry ONE radius in all their channels: collapse equal values inside the lane first
+#pragma unroll
+            for (int j = 1; j < CHG; ++j)
+#pragma unroll
+                for (int i = 0; i < j; ++i)
+                    if (wb[j] == wb[i]) wb[j] = CLS_EMPTY;
+#pragma unroll
+            for (int j = 0; j < CHG; ++j) {
+                const unsigned bits = wb[j];
+                bool pending = bits != CLS_EMPTY;
+                for (;;) {                                           // wave-uniform: one trip per distinct value
+                    const unsigned long long mask = mk_ballot(pending);
+                    if (mask == 0ull) break;
+                    const int leader = __builtin_ctzll(mask);
+                    const unsigned lb = mk_readlane(bits, leader);
+                    if (bits == lb) pending = false;
+                    if (lane == leader && !lds_set_insert(s_set, CLS_BLOCK_SET, lb)) s_full = 1u;
+                }
             }
         }
     }
@@ -143,18 +159,34 @@ MK_KERNEL(256) void k_collect_classes(const SigT* __restrict__ sigmas, long long
         block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? 0xfffffffeu : s_set[threadIdx.x];
 }
 
-MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ block_sets, unsigned nwords,
-                                    unsigned* __restrict__ cls_table)
+constexpr int MERGE_THREADS = 1024;
+constexpr int MERGE_PER_THREAD = (CLS_MAX_BLOCKS * CLS_BLOCK_SET / 4) / MERGE_THREADS;   // uint4 loads per thread
+
+MK_KERNEL(MERGE_THREADS) void k_merge_classes(const unsigned* __restrict__ block_sets, unsigned nwords,
+                                              unsigned* __restrict__ cls_table)
 {
     __shared__ unsigned s_set[64];
     __shared__ unsigned s_over;
     if (threadIdx.x < 64) s_set[threadIdx.x] = CLS_EMPTY;
     if (threadIdx.x == 0) s_over = 0u;
     mk_block_sync();
-    for (unsigned i = threadIdx.x; i < nwords; i += blockDim.x) {
-        const unsigned v = block_sets[i];
-        if (v == CLS_EMPTY) continue;
-        if (v == 0xfffffffeu || !lds_set_insert(s_set, 64u, v)) s_over = 1u;
+    const uint4* __restrict__ bs4 = reinterpret_cast<const uint4*>(block_sets);   // nwords is a multiple of 32
+    uint4 buf[MERGE_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < MERGE_PER_THREAD; ++k) {                   // all loads in flight before any is used
+        const unsigned i = threadIdx.x + (unsigned)k * MERGE_THREADS;
+        buf[k] = make_uint4(CLS_EMPTY, CLS_EMPTY, CLS_EMPTY, CLS_EMPTY);
+        if (i < nwords / 4u) buf[k] = bs4[i];
+    }
+#pragma unroll
+    for (int k = 0; k < MERGE_PER_THREAD; ++k) {
+        const unsigned vv[4] = {buf[k].x, buf[k].y, buf[k].z, buf[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned v = vv[j];
+            if (v == CLS_EMPTY) continue;
+            if (v == 0xfffffffeu || !lds_set_insert(s_set, 64u, v)) s_over = 1u;
+        }
     }
     mk_block_sync();
     if (threadIdx.x == 0) {
@@ -174,24 +206,34 @@ MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ block_sets, uns
 
 // ------------------------------------------------------------------------------------------------
 // Binning: atoms (and, for periodic items, their images) -> padded uniform cell grid.
-// PHASE 0 counts, PHASE 1 fills the
-// cell-sorted record arrays (counts are walked back to zero).  One thread per atom; one global
-// atomic per atom-image.
+//   k_bin_count : one thread per atom.  Decomposes the position IN DOUBLE into (cell, cell-centre-
+//                 relative float32 offset), takes its rank inside the cell from ONE returning
+//                 atomicAdd on the cell's counter and parks (offset, cell, rank) in a temp record
+//                 (img_cap temp slots per atom; unused slots are marked).
+//   (exclusive scan of the counts -> cell starts)
+//   k_bin_fill  : one thread per temp slot: a pure permutation into the cell-sorted record arrays
+//                 (no atomics, nothing recomputed) + the per-channel sigma classes of the atom.
 // Record = pos (cell-centre-relative x,y,z as f32 ; packed padded cell coords)
 //          + per channel group EITHER 8 class ids (4 bits each, 0 = absent)     [sorted path]
 //                              OR two float4 of w (+inf = absent)               [general path]
 // ------------------------------------------------------------------------------------------------
-template <int PHASE, typename SigT>
-MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
+constexpr unsigned TMP_UNUSED = 0xffffffffu;
+
+template <typename SigT>
+MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 const long long* __restrict__ atom_offsets, long long total_atoms,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                 const float* __restrict__ box, unsigned* __restrict__ cell_count,
-                                const unsigned* __restrict__ cell_start, float4* __restrict__ rec_pos,
-                                float4* __restrict__ rec_w, unsigned* __restrict__ rec_cls,
-                                const unsigned* __restrict__ cls_table, int* __restrict__ err_flag)
+                                float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
+                                int* __restrict__ err_flag)
 {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= total_atoms) return;
+    const size_t t0 = (size_t)a * (size_t)g.img_cap;          // this atom's temp slots
+    int used = 0;
+    auto mark_rest = [&]() {
+        for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
+    };
 
     // item of this atom: largest b with atom_offsets[b] <= a
     int lo = 0, hi = g.B;
@@ -205,37 +247,31 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
     const SigT* sg = sigmas + (size_t)a * g.C;
     bool any = false;
     for (int c = 0; c < g.C; ++c) any |= sigma_to_w(sg[c], g.w_scale) < mk_inf();
-    if (!any) return;
+    if (!any) { mark_rest(); return; }
 
     double p[3], Lv[3] = {0.0, 0.0, 0.0};
     int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
     const int nvox[3] = {g.nx, g.ny, g.nz};
+    bool drop = false;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         p[ax] = ((double)coords[3 * a + ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
         if (g.pbc) {
             const double L = (double)box[3 * (size_t)b + ax] * g.inv_res;
-            if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); return; }
+            if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); drop = true; }
             Lv[ax] = L;
             const double a0 = ceil((-g.Rp - p[ax]) / L);
             const double a1 = floor(((double)(nvox[ax] - 1) + g.Rp - p[ax]) / L);
-            if (a1 - a0 > 64.0) { mk_atomic_or(err_flag, MK_ERR_TOO_MANY_IMAGES); return; }
+            if (a1 - a0 > 64.0) { mk_atomic_or(err_flag, MK_ERR_TOO_MANY_IMAGES); drop = true; }
             k0[ax] = (int)a0; k1[ax] = (int)a1;          // empty range when a1 < a0
         } else {
-            if (p[ax] < -g.Rp || p[ax] > (double)(nvox[ax] - 1) + g.Rp) return;
+            if (p[ax] < -g.Rp || p[ax] > (double)(nvox[ax] - 1) + g.Rp) drop = true;
         }
     }
+    if (drop) { mark_rest(); return; }
 
     const double inv_cs = 1.0 / (double)g.cs;
     const double cmid = 0.5 * (double)(g.cs - 1);
-    // class table -> registers (wave-uniform loads), so that a lookup is NCLS register compares
-    unsigned tab[NCLS];
-    bool general = true;
-    if (PHASE == 1) {
-        general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
-#pragma unroll
-        for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
-    }
     for (int kx = k0[0]; kx <= k1[0]; ++kx)
         for (int ky = k0[1]; ky <= k1[1]; ++ky)
             for (int kz = k0[2]; kz <= k1[2]; ++kz) {
@@ -252,41 +288,62 @@ MK_KERNEL(256) void k_bin_atoms(GridDesc g, const float* __restrict__ coords,
                     rel[ax] = (float)(q[ax] - ((double)ci * (double)g.cs + cmid));
                 }
                 if (!inside) continue;
+                if (used >= g.img_cap) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
                 const size_t cell = (size_t)b * g.ncell + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2];
-                if (PHASE == 0) {
-                    mk_atomic_add(&cell_count[cell], 1u);
-                } else {
-                    const unsigned slot = cell_start[cell] + mk_atomic_sub(&cell_count[cell], 1u) - 1u;
-                    if (slot >= g.M) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
-                    rec_pos[slot] = make_float4(rel[0], rel[1], rel[2],
-                                                mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
-                    for (int gq = 0; gq < g.G; ++gq) {
-                        float w[CHG];
-#pragma unroll
-                        for (int c = 0; c < CHG; ++c) {
-                            const int ch = gq * CHG + c;
-                            w[c] = ch < g.C ? sigma_to_w(sg[ch], g.w_scale) : mk_inf();
-                        }
-                        if (general) {
-                            rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
-                            rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
-                        } else {
-                            unsigned ids = 0;
-#pragma unroll
-                            for (int c = 0; c < CHG; ++c) {
-                                unsigned id = 0;
-                                if (w[c] < mk_inf()) {
-                                    const unsigned bits = mk_float_bits(w[c]);
-#pragma unroll
-                                    for (int i = 0; i < NCLS; ++i) id = (tab[i] == bits) ? (unsigned)(i + 1) : id;
-                                }
-                                ids |= id << (4 * c);
-                            }
-                            rec_cls[(size_t)gq * g.M + slot] = ids;
-                        }
-                    }
-                }
+                const unsigned rank = mk_atomic_add(&cell_count[cell], 1u);
+                tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2],
+                                                 mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
+                tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
+                ++used;
             }
+    mark_rest();
+}
+
+template <typename SigT>
+MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
+                               const unsigned* __restrict__ cell_start,
+                               const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_idx,
+                               float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
+                               unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)g.M) return;
+    const uint2 ix = tmp_idx[t];
+    if (ix.x == TMP_UNUSED) return;
+    const unsigned slot = cell_start[ix.x] + ix.y;
+    rec_pos[slot] = tmp_pos[t];
+    const size_t a = t / (size_t)g.img_cap;
+    const SigT* sg = sigmas + a * (size_t)g.C;
+    // class table -> registers (wave-uniform loads), so that a lookup is NCLS register compares
+    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+    unsigned tab[NCLS];
+#pragma unroll
+    for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
+    for (int gq = 0; gq < g.G; ++gq) {
+        float w[CHG];
+#pragma unroll
+        for (int c = 0; c < CHG; ++c) {
+            const int ch = gq * CHG + c;
+            w[c] = ch < g.C ? sigma_to_w(sg[ch], g.w_scale) : mk_inf();
+        }
+        if (general) {
+            rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
+            rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
+        } else {
+            unsigned ids = 0;
+#pragma unroll
+            for (int c = 0; c < CHG; ++c) {
+                unsigned id = 0;
+                if (w[c] < mk_inf()) {
+                    const unsigned bits = mk_float_bits(w[c]);
+#pragma unroll
+                    for (int i = 0; i < NCLS; ++i) id = (tab[i] == bits) ? (unsigned)(i + 1) : id;
+                }
+                ids |= id << (4 * c);
+            }
+            rec_cls[(size_t)gq * g.M + slot] = ids;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,18 +443,19 @@ MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size
 // Occupancy value from the reduced q = min d^2/sigma^2 :  1 - exp(-q^-6)
 // (occupancy_utils.pyx:57-60 with x^12 = (sigma^2/d^2)^6).  q=+inf -> 0, q=0 -> 1.
 // For small x = q^-6 the float32 form 1-exp(-x) cancels (absolute error 6e-8 whatever x is), so the
-// tail uses the alternating series of -expm1(-x): relative accuracy ~1e-6 everywhere, which is
+// tail uses the alternating series of -expm1(-x): relative accuracy <= 4e-6 everywhere, which is
 // what lets the reference's own np.allclose(rtol=1e-5) style checks pass on float32 results.
 // ------------------------------------------------------------------------------------------------
 MK_DEV float occupancy_from_q(float q)
 {
-    const float u = mk_rcp_refined(q);
+    const float u = mk_rcp(q);                       // v_rcp_f32, 1 ulp: u^6 carries <= 1e-6 relative error
     const float u3 = u * u * u;
     const float x = u3 * u3;
     const float big = 1.0f - mk_exp2(-1.4426950408889634f * x);
-    // x - x^2/2 + x^3/6 - x^4/24 + x^5/120, Horner form; truncation < x^6/720 (1e-10 at x = 1/16)
-    const float small = x * (1.0f - x * (0.5f - x * (0.16666667f - x * (0.041666668f - x * 0.0083333338f))));
-    return x < 0.0625f ? small : big;
+    // x - x^2/2 + x^3/6 for x < 1/64 (truncation x^3/24 < 1.6e-7 relative); above that 1-exp(-x) is
+    // relatively accurate to 6e-8/x <= 4e-6
+    const float small = x * (1.0f - x * (0.5f - x * 0.16666667f));
+    return x < 0.015625f ? small : big;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -33,14 +33,7 @@ MK_DEV int mk_rank_in_mask(unsigned long long mask)
 
 MK_DEV int mk_popc64(unsigned long long m) { return __popcll(m); }
 
-// v_rcp_f32 (1 ulp) + one Newton step -> ~0.5 ulp; rcp(inf)=0, rcp(0)=inf preserved.
-MK_DEV float mk_rcp_refined(float x)
-{
-    float r = __builtin_amdgcn_rcpf(x);
-    float e = __builtin_fmaf(-x, r, 1.0f);          // 1 - x*r  (NaN when x*r is inf*0)
-    float r2 = __builtin_fmaf(r, e, r);
-    return (e == e) ? r2 : r;                       // keep 0 / inf results of the raw rcp
-}
+MK_DEV float mk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32 (1 ulp); rcp(inf)=0, rcp(0)=inf
 
 MK_DEV float mk_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 

@@ -9,6 +9,8 @@
 //   int  fill(void* p, int byte, size_t bytes)          async memset on the stream
 //   int  launch(kernel, dim3 grid, dim3 block, args...) async launch on the stream
 //   void hot_begin() / hot_end()                        bracket the tile kernel (event timing)
+//   void side_begin() / side_end() / side_join()        launches between begin/end may run concurrently
+//                                                       with the main sequence until side_join()
 #pragma once
 #include "kernels.h"
 
@@ -22,7 +24,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_ERR, WS_W_EXPLICIT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_TMP_POS, WS_TMP_IDX, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
     WS_NSLOTS
@@ -109,6 +111,7 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     const long long M = P.total_atoms * images;
     if (M > 0xFFFF0000LL) { err = "batch too large: more than 2^32 atom records; split the batch"; return ST_EINVAL; }
     g.M = (unsigned)(M > 0 ? M : 1);
+    g.img_cap = (int)images;
     return ST_OK;
 }
 
@@ -161,30 +164,45 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_CLS_TABLE, CLS_TABLE_WORDS * sizeof(unsigned), &ctab))) return st;
     if ((st = be.ensure(WS_ERR, sizeof(int), &eflag))) return st;
 
+    void *tpos = nullptr, *tidx = nullptr;
+    if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos))) return st;
+    if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx))) return st;
+
     if ((st = be.fill(count, 0, ncells * sizeof(unsigned)))) return st;
-    if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;     // all slots CLS_EMPTY
     const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
-#define MK_BIN(PHASE)                                                                                   \
-    (P.sigmas_f64                                                                                       \
-         ? be.launch(k_bin_atoms<PHASE, double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, \
-                     (const double*)P.sigmas, P.origins, P.box, (unsigned*)count, (const unsigned*)start, \
-                     (float4*)rpos, (float4*)rw, (unsigned*)rcls, (unsigned*)ctab, (int*)eflag)              \
-         : be.launch(k_bin_atoms<PHASE, float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms,  \
-                     (const float*)P.sigmas, P.origins, P.box, (unsigned*)count, (const unsigned*)start,  \
-                     (float4*)rpos, (float4*)rw, (unsigned*)rcls, (unsigned*)ctab, (int*)eflag))
-    if (P.total_atoms > 0 && (st = MK_BIN(0))) return st;
+    const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
+    // class discovery depends only on the sigmas: for big batches it runs beside the count + scan
+    // sequence on the side stream (the fork/join costs ~25 us of latency, too much for small calls)
+    const bool fork = P.total_atoms >= 200000;
+    if (fork) be.side_begin();
     if (P.total_atoms > 0 && !g.force_general) {                      // distinct sigma values -> class table
         const unsigned nb = (unsigned)std::min<long long>(CLS_MAX_BLOCKS, ceil_div(P.total_atoms, 256));
         void* bsets = nullptr;
-        if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nb * CLS_BLOCK_SET * sizeof(unsigned), &bsets))) return st;
+        if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)CLS_MAX_BLOCKS * CLS_BLOCK_SET * sizeof(unsigned), &bsets))) return st;
         st = P.sigmas_f64 ? be.launch(k_collect_classes<double>, dim3(nb), ablk, (const double*)P.sigmas, P.total_atoms, g.C, g.w_scale, (unsigned*)bsets)
                           : be.launch(k_collect_classes<float>, dim3(nb), ablk, (const float*)P.sigmas, P.total_atoms, g.C, g.w_scale, (unsigned*)bsets);
         if (st) return st;
-        if ((st = be.launch(k_merge_classes, dim3(1), dim3(256), (const unsigned*)bsets, nb * (unsigned)CLS_BLOCK_SET, (unsigned*)ctab))) return st;
+        if ((st = be.launch(k_merge_classes, dim3(1), dim3(MERGE_THREADS), (const unsigned*)bsets, nb * (unsigned)CLS_BLOCK_SET, (unsigned*)ctab))) return st;
+    } else {
+        if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
+    }
+    if (fork) be.side_end();
+    if (P.total_atoms > 0) {
+        st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
+                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (int*)eflag)
+                          : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
+                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (int*)eflag);
+        if (st) return st;
     }
     if ((st = run_scan(be, (const unsigned*)count, ncells, (unsigned*)start))) return st;
-    if (P.total_atoms > 0 && (st = MK_BIN(1))) return st;
-#undef MK_BIN
+    if (fork) be.side_join();
+    if (P.total_atoms > 0) {
+        st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
+                                      (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
+                          : be.launch(k_bin_fill<float>, fgrid, ablk, g, (const float*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
+                                      (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
+        if (st) return st;
+    }
 
     const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G), tblk(WAVE);

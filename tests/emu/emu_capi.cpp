@@ -36,6 +36,9 @@ struct EmuBackend {
     }
     void hot_begin() {}
     void hot_end() {}
+    void side_begin() {}
+    void side_end() {}
+    void side_join() {}
 };
 
 thread_local std::string g_err;

@@ -36,6 +36,7 @@ struct float4 { float x, y, z, w; };
 struct uint2 { unsigned x, y; };
 struct float2 { float x, y; };
 struct uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
@@ -166,11 +167,7 @@ MK_DEV int mk_rank_in_mask(unsigned long long mask)
     return __builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
 MK_DEV int mk_popc64(unsigned long long m) { return __builtin_popcountll(m); }
-MK_DEV float mk_rcp_refined(float x)
-{
-    float r = 1.0f / x;
-    return r;
-}
+MK_DEV float mk_rcp(float x) { return 1.0f / x; }
 MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
