@@ -33,7 +33,14 @@ constexpr int CHG = 8;               // channels per channel-group (one group = 
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per call (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
-constexpr int ECAP = 768;            // LDS entry capacity of a tile (3 x 3 KiB, structure of arrays)
+#ifndef MK_ECAP
+#define MK_ECAP 640
+#endif
+#ifndef MK_TRAV_BATCH
+#define MK_TRAV_BATCH 4
+#endif
+constexpr int ECAP = MK_ECAP;        // LDS entry capacity of a tile (3 x 3 KiB, structure of arrays)
+constexpr int TRAV_BATCH = MK_TRAV_BATCH;   // candidate chunks whose loads are in flight together
 constexpr int NXR = 3;               // x-reach sub-buckets: 0 = all K planes, 1 = low half only, 2 = high half only
 constexpr int NBUCKET3 = NBUCKET * NXR;
 constexpr unsigned CLS_EMPTY = 0xffffffffu;   // empty slot of the class table (never a valid w)
@@ -473,10 +480,16 @@ struct TileGeom {                     // wave-uniform description of the tile be
 // Visit every candidate record of the tile in chunks of 64 (one record per lane).
 // The (cell-x, cell-y) columns around the tile each contribute one contiguous run of records (their
 // z-cells are adjacent in memory); the runs' bounds are fetched by one lane each, the chunks of all
-// runs are numbered 0..T-1, and the record loads run ONE chunk ahead of the chunk being processed
-// (the loads are L2/HBM round trips; without the look-ahead every chunk would pay ~1 us of latency).
+// runs are numbered 0..T-1 and processed in batches whose loads are all issued up front (the loads
+// are L2 / fabric round trips; chunk-at-a-time every chunk would pay ~1 us of exposed latency).
 // f(survives, record index, tile-relative x,y,z, class ids) is called by ALL lanes for every chunk.
-template <int K, bool LOAD_CLS, class F>
+struct CandChunk {                    // one chunk of 64 candidate records (one per lane), loads in flight
+    float4 P;
+    unsigned r, ids;
+    bool valid;
+};
+
+template <int K, bool LOAD_CLS, int BATCH, class F>
 MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start,
                                const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f)
 {
@@ -496,41 +509,53 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const unsi
     const unsigned my_cb = incl - my_nch;
     const unsigned T = mk_readlane(incl, WAVE - 1);
 
-    // depth-1 software pipeline: the loads of chunk t+1 are in flight while chunk t is processed
-    unsigned r_nxt = 0u, c_nxt = 0u;
-    bool v_nxt = false;
-    float4 P_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto issue = [&](unsigned t) {                                   // start the loads of chunk t
-        r_nxt = 0u; v_nxt = false; c_nxt = 0u;
-        P_nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto issue = [&](unsigned t, CandChunk& ch) {                    // start the loads of chunk t
+        ch.r = 0u; ch.valid = false; ch.ids = 0u;
+        ch.P = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < T) {                                                 // wave-uniform
             const unsigned long long own = mk_ballot(my_cb <= t && t < my_cb + my_nch);
             const int j = __builtin_ctzll(own);
             const unsigned r0 = mk_readlane(my_r0, j), r1 = mk_readlane(my_r1, j), cb = mk_readlane(my_cb, j);
-            r_nxt = r0 + ((t - cb) << 6) + (unsigned)lane;
-            v_nxt = r_nxt < r1;
-            if (v_nxt) {
-                P_nxt = rec_pos[r_nxt];
-                if (LOAD_CLS) c_nxt = rec_cls[r_nxt];
+            ch.r = r0 + ((t - cb) << 6) + (unsigned)lane;
+            ch.valid = ch.r < r1;
+            if (ch.valid) {
+                ch.P = rec_pos[ch.r];
+                if (LOAD_CLS) ch.ids = rec_cls[ch.r];
             }
         }
     };
-    issue(0u);
-    for (unsigned t = 0; t < T; ++t) {
-        const float4 P = P_nxt;
-        const unsigned r = r_nxt, cls = c_nxt;
-        const bool valid = v_nxt;
-        issue(t + 1u);
-        const int pk = mk_float_as_int(P.w);
+    auto consume = [&](const CandChunk& ch) {
+        const int pk = mk_float_as_int(ch.P.w);
         // (cell centre - tile centre) is an exact small half-integer; ONE rounding per axis
-        const float ex = P.x + ((float)(pk & 1023) * tg.fcs + tg.offx);
-        const float ey = P.y + ((float)((pk >> 10) & 1023) * tg.fcs + tg.offy);
-        const float ez = P.z + ((float)((pk >> 20) & 1023) * tg.fcs + tg.offz);
+        const float ex = ch.P.x + ((float)(pk & 1023) * tg.fcs + tg.offx);
+        const float ey = ch.P.y + ((float)((pk >> 10) & 1023) * tg.fcs + tg.offy);
+        const float ez = ch.P.z + ((float)((pk >> 20) & 1023) * tg.fcs + tg.offz);
         const float gx = fmaxf(fabsf(ex) - HX, 0.f);
         const float gy = fmaxf(fabsf(ey) - 3.5f, 0.f);
         const float gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
-        const bool surv = valid && (gx * gx + gy * gy + gz * gz < g.R2cull);
-        f(surv, r, ex, ey, ez, cls);
+        const bool surv = ch.valid && (gx * gx + gy * gy + gz * gz < g.R2cull);
+        f(surv, ch.r, ex, ey, ez, ch.ids);
+    };
+    // BATCH chunks' loads are issued back to back, then the BATCH chunks are processed: the wave pays
+    // the L2 / fabric round trip once per batch instead of once per chunk
+    CandChunk ch[BATCH];
+    for (unsigned t = 0; t < T; t += BATCH) {
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) issue(t + (unsigned)k, ch[k]);
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k)
+            if (t + (unsigned)k < T) consume(ch[k]);                 // wave-uniform
+    }
+}
+
+// visit the present channels of a record's 8 x 4-bit class ids: f(channel, class id 1..15)
+template <class F>
+MK_DEV void for_each_present_channel(unsigned ids, F&& f)
+{
+    while (ids) {                                                    // per-lane trip count (<= 8)
+        const int sh = (__builtin_ctz(ids)) & ~3;
+        f(sh >> 2, (ids >> sh) & 0xfu);
+        ids &= ~(0xfu << sh);
     }
 }
 
@@ -543,7 +568,8 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
     static_assert(K == 4 || K == 8, "K");
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
     // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
-    // (measured: 1.25 -> 2 waves/SIMD = 1.44x), hence the lean 12.7 KiB budget -> 3 waves/SIMD.
+    // (measured: 1.25 -> 2 -> 2.75 -> 3.25 waves/SIMD = 0.69 -> 0.48 -> 0.43 -> 0.40 ms on cfg2), hence
+    // the lean ~9.3 KiB budget.
     __shared__ __attribute__((aligned(16))) float sx[ECAP + 2];
     __shared__ __attribute__((aligned(16))) float sy[ECAP + 2];
     __shared__ __attribute__((aligned(16))) float sz[ECAP + 2];
@@ -552,9 +578,8 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
     __shared__ unsigned lds_pad[MK_LDS_PAD / 4];
     if (g.nx < 0) lds_pad[threadIdx.x] = 1u, out[0] = (float)lds_pad[(threadIdx.x + 1) & 63];
 #endif
-    __shared__ unsigned bucket[NBUCKET3];         // per-tile histogram, then placement cursors
-    // per (channel, class) group: start of {all-planes, low-half, high-half} sub-bucket and the group's end
-    __shared__ __attribute__((aligned(16))) unsigned bgroup[NBUCKET * 4];
+    // per-tile histogram -> placement cursors -> (after placement) sub-bucket starts again; [NBUCKET3] = end
+    __shared__ unsigned bucket[NBUCKET3 + 1];
 
     const int lane = threadIdx.x;
     // XCD-aware order: the dispatcher places block i on XCD i%8; give each XCD a contiguous run of
@@ -623,16 +648,12 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
 #pragma unroll
         for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
         mk_block_sync();
-        for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp,
+        for_each_candidate<K, true, TRAV_BATCH>(g, tg, cell_start, rec_pos, clsp,
             [&](bool surv, unsigned, float ex, float, float, unsigned ids) {
-                if (surv) {
-                    const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
-#pragma unroll
-                    for (int c = 0; c < CHG; ++c) {
-                        const unsigned id = (ids >> (4 * c)) & 0xfu;
-                        if (id) (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
-                    }
-                }
+                const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+                for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
+                    (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+                });
             });
         mk_block_sync();
         // ---- bucket starts: lane owns groups 2*lane, 2*lane+1 (3 sub-buckets each); every sub-bucket
@@ -660,28 +681,22 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                 // odd sub-buckets get one far-away sentinel entry
                 if (cnt[i] & 1u) { sx[start[i] + cnt[i]] = 1.0e18f; sy[start[i] + cnt[i]] = 0.f; sz[start[i] + cnt[i]] = 0.f; }
             }
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                unsigned* bg = &bgroup[(2 * lane + gi) * 4];
-                bg[0] = start[gi * NXR + 0]; bg[1] = start[gi * NXR + 1]; bg[2] = start[gi * NXR + 2];
-                bg[3] = start[gi * NXR + 2] + pad[gi * NXR + 2];
-            }
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
-            for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp,
+            for_each_candidate<K, true, TRAV_BATCH>(g, tg, cell_start, rec_pos, clsp,
                 [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
-                    if (surv) {
-                        const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
-#pragma unroll
-                        for (int c = 0; c < CHG; ++c) {
-                            const unsigned id = (ids >> (4 * c)) & 0xfu;
-                            if (id) {
-                                const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
-                                sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
-                            }
-                        }
-                    }
+                    const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+                    for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
+                        const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+                        sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
+                    });
                 });
+            mk_block_sync();
+            // cursors are dead now: the array becomes the table of sub-bucket starts (sub-buckets are
+            // contiguous, so a group's three ranges are four consecutive words)
+#pragma unroll
+            for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i];
+            if (lane == WAVE - 1) bucket[NBUCKET3] = total;
             mk_block_sync();
             // ---- process group by group: inner loop = sub, fma, half a min3 per (voxel, entry) ----
             const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
@@ -697,7 +712,8 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                 while (bits) {                                            // wave-uniform
                     const int cls = __builtin_ctz(bits);
                     bits &= bits - 1u;
-                    const uint4 bg = *reinterpret_cast<const uint4*>(&bgroup[(c * NSLOT + cls) * 4]);   // uniform read
+                    const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
+                    const uint4 bg = make_uint4(bgp[0], bgp[1], bgp[2], bgp[3]);
                     const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
                     unsigned m[K];
 #pragma unroll
@@ -774,8 +790,8 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                 mk_block_sync();                                     // ebuf is rewritten next
             }
         };
-        if (general) for_each_candidate<K, false>(g, tg, cell_start, rec_pos, clsp, body);
-        else for_each_candidate<K, true>(g, tg, cell_start, rec_pos, clsp, body);
+        if (general) for_each_candidate<K, false, 1>(g, tg, cell_start, rec_pos, clsp, body);
+        else for_each_candidate<K, true, 1>(g, tg, cell_start, rec_pos, clsp, body);
     }
 
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
