@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--tile-k", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap step n+1's binning pre-pass with step n's tile kernel")
     args = ap.parse_args()
 
     import torch
@@ -116,6 +118,9 @@ def main():
     ctx = _lib.default_context(local)
     ctx.set_tile_k(args.tile_k)
     ctx.set_force_general(os.environ.get("MKAMD_FORCE_GENERAL", "0") == "1")
+    # steps are independent batches whose inputs are resident before the loop: the library may overlap the
+    # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)
+    ctx.set_pipelining(not args.no_pipeline)
     t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
     d_coords, d_offs = t(p["coords"], np.float32), t(p["atom_offsets"], np.int64)
     d_sig, d_org = t(p["sigmas"], np.float32), t(origins, np.float64)
@@ -173,6 +178,7 @@ def main():
     single_us = None
     if rank == 0:
         # latency of ONE grid (a single 64^3 grid cannot fill 256 CUs for long)
+        ctx.set_pipelining(False)
         o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
         n1 = int(p["atom_offsets"][1])
         offs1 = t(p["atom_offsets"][:2], np.int64)
@@ -204,7 +210,7 @@ def main():
             "config": {"workload": f"{args.workload}: BASELINE.json configs[{int(args.workload[3:]) - 1}]",
                        "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
                        "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
-                       "periodic": p["box"] is not None, "tile_k": args.tile_k, "parallelism": f"dp{world} (items sharded, no collective in the timed region)",
+                       "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline, "parallelism": f"dp{world} (items sharded, no collective in the timed region)",
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,

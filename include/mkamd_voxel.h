@@ -63,6 +63,13 @@ int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k);
 /* 1: always take the general tile-kernel path (per-pair cutoff test, arbitrary per-entry sigma)
  * instead of the class-sorted one; results are bit-identical (testing / A-B benchmarking). */
 int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on);
+/* Opt-in software pipelining ACROSS calls of mkamd_voxelize_lattice_dev (off by default): the binning
+ * pre-pass of a call (latency / atomic bound) runs on an internal stream beside the tile kernel (VALU bound)
+ * of the previous call, on a second workspace set.  Results still appear in order on the context's stream.
+ * Contract while it is on: the inputs of a call must not be produced by work enqueued on the context's
+ * stream AFTER the previous voxelize call (the pre-pass is only ordered after everything before that call's
+ * tile kernel) and must stay untouched until the call's features have been consumed. */
+int mkamd_ctx_set_pipelining(mkamd_ctx* ctx, int on);
 /* Per-kernel timing of the tile kernel with HIP events on the context's stream (bench.py's
  * roofline leg): enable, run, then read back the accumulated time and launch count (resets). */
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable);

@@ -32,6 +32,7 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_ctx_set_tile_k": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_force_general": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
@@ -138,6 +139,10 @@ class Context:
 
     def set_force_general(self, on: bool):
         _check(load().mkamd_ctx_set_force_general(self._h, int(bool(on))))
+
+    def set_pipelining(self, on: bool):
+        """Overlap the pre-pass of a call with the tile kernel of the previous one (see the header for the contract)."""
+        _check(load().mkamd_ctx_set_pipelining(self._h, int(bool(on))))
 
     def enable_kernel_timing(self, on=True):
         _check(load().mkamd_ctx_enable_kernel_timing(self._h, int(bool(on))))

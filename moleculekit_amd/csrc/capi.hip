@@ -37,10 +37,17 @@ struct mkamd_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;          // stream the launches of the current call go to (main or side)
     hipStream_t main_stream = nullptr;     // the caller-visible stream
-    hipStream_t side_stream = nullptr;     // internal: independent pre-pass work (class discovery)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    void* bufs[WS_NSLOTS] = {};
-    size_t caps[WS_NSLOTS] = {};
+    hipStream_t side_stream = nullptr;     // internal: pre-pass of pipelined calls
+    hipEvent_t ev_inputs = nullptr;        // main -> side: the call's inputs are ready
+    hipEvent_t ev_pre_done[2] = {};        // side -> main: workspace set s is filled
+    hipEvent_t ev_tile_done[2] = {};       // main -> side: the tile kernel that read set s has finished
+    bool tile_pending[2] = {false, false};
+    int next_set = 0;
+    bool in_pipelined_prepass = false;
+    bool pipelining = false;               // opt-in (mkamd_ctx_set_pipelining)
+    bool have_pre_tile_event = false;
+    void* bufs[2 * WS_NSLOTS] = {};        // two workspace sets (set 1 only used by pipelined calls)
+    size_t caps[2 * WS_NSLOTS] = {};
     int tile_k = 0;
     int force_general = 0;
     // tile-kernel timing
@@ -50,8 +57,9 @@ struct mkamd_ctx {
     int launch_status = 0;
 
     // ---- backend concept (pipeline.h) ----
-    int ensure(int slot, size_t bytes, void** ptr)
+    int ensure(int slot, size_t bytes, void** ptr, int set = 0)
     {
+        slot += set * WS_NSLOTS;
         if (bytes == 0) bytes = 16;
         if (caps[slot] < bytes) {
             if (bufs[slot]) {
@@ -80,23 +88,42 @@ struct mkamd_ctx {
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    void side_begin()
+    // ---- cross-call software pipeline (pipeline.h: acquire_set / prepass_done / tile_done) ----
+    int acquire_set(bool big_enough)
     {
-        if (!side_stream) return;
-        (void)hipEventRecord(ev_fork, main_stream);
-        (void)hipStreamWaitEvent(side_stream, ev_fork, 0);
+        in_pipelined_prepass = false;
+        if (!big_enough || !pipelining || !side_stream) {
+            // in-order call on the caller's stream, set 0 (any earlier pipelined call has already made the
+            // main stream wait for its pre-pass; its tile kernel is ahead of us on the same stream)
+            have_pre_tile_event = false;
+            return 0;
+        }
+        const int set = next_set;
+        next_set ^= 1;
+        // Inputs must not depend on work enqueued after the PREVIOUS call's tile kernel (the opt-in contract of
+        // mkamd_ctx_set_pipelining): the side stream is ordered after everything before that launch only.
+        if (!have_pre_tile_event) (void)hipEventRecord(ev_inputs, main_stream);
+        (void)hipStreamWaitEvent(side_stream, ev_inputs, 0);
+        if (tile_pending[set]) (void)hipStreamWaitEvent(side_stream, ev_tile_done[set], 0);
         stream = side_stream;
+        in_pipelined_prepass = true;
+        return set;
     }
-    void side_end()
+    void prepass_done(int set)
     {
-        if (!side_stream) return;
-        (void)hipEventRecord(ev_join, side_stream);
+        if (!in_pipelined_prepass) return;
+        (void)hipEventRecord(ev_pre_done[set], side_stream);
         stream = main_stream;
+        (void)hipStreamWaitEvent(main_stream, ev_pre_done[set], 0);
+        (void)hipEventRecord(ev_inputs, main_stream);                 // "everything before this call's tile kernel"
+        have_pre_tile_event = true;
     }
-    void side_join()
+    void tile_done(int set)
     {
         if (!side_stream) return;
-        (void)hipStreamWaitEvent(main_stream, ev_join, 0);
+        (void)hipEventRecord(ev_tile_done[set], main_stream);
+        tile_pending[set] = true;
+        in_pipelined_prepass = false;
     }
     void hot_begin()
     {
@@ -181,11 +208,16 @@ int mkamd_ctx_create(int device, mkamd_ctx** out)
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     c->stream = c->main_stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-        c->side_stream = nullptr;               // fall back to a single in-order stream
-    }
+    // the pre-pass kernels are small and latency-bound: give their queue the highest priority so that they
+    // get wave slots as the (huge) tile grid of the previous call retires waves, instead of waiting for it to drain
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    bool ok = hipStreamCreateWithPriority(&c->side_stream, hipStreamNonBlocking, prio_greatest) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_pre_done[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_tile_done[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) c->side_stream = nullptr;          // fall back to a single in-order stream
     *out = c;
     return MKAMD_OK;
 }
@@ -195,13 +227,17 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx)
     if (!ctx) return MKAMD_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < WS_NSLOTS; ++i)
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    for (int i = 0; i < 2 * WS_NSLOTS; ++i)
         if (ctx->bufs[i]) (void)hipFree(ctx->bufs[i]);
     for (auto& ev : ctx->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_inputs) (void)hipEventDestroy(ctx->ev_inputs);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->ev_pre_done[i]) (void)hipEventDestroy(ctx->ev_pre_done[i]);
+        if (ctx->ev_tile_done[i]) (void)hipEventDestroy(ctx->ev_tile_done[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return MKAMD_OK;
@@ -213,7 +249,9 @@ int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream)
     if (st) return st;
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     if (next == ctx->main_stream) return MKAMD_OK;
-    HIP_TRY(hipStreamSynchronize(ctx->main_stream)); // workspace is shared between the two streams
+    HIP_TRY(hipStreamSynchronize(ctx->main_stream)); // workspace is shared between the streams
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    ctx->tile_pending[0] = ctx->tile_pending[1] = false;
     ctx->stream = ctx->main_stream = next;
     return MKAMD_OK;
 }
@@ -222,7 +260,8 @@ int mkamd_ctx_synchronize(mkamd_ctx* ctx)
 {
     int st = check_ctx(ctx);
     if (st) return st;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->main_stream));
     return collect_async_errors(ctx);
 }
 
@@ -252,6 +291,17 @@ int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on)
 {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     ctx->force_general = on != 0;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_set_pipelining(mkamd_ctx* ctx, int on)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    HIP_TRY(hipStreamSynchronize(ctx->main_stream));
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    ctx->pipelining = on != 0;
+    ctx->have_pre_tile_event = false;
     return MKAMD_OK;
 }
 

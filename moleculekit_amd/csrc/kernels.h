@@ -92,12 +92,11 @@ MK_DEV float sigma_to_w(SigT sigma, double w_scale)
 // Class discovery: the distinct w values of the batch -> cls_table (<= NCLS, else the overflow word
 // is raised and the call takes the general tile path).  Two tiny kernels and NO global atomics (a
 // shared table updated by thousands of blocks serialises on one cache line):
-//   k_collect_classes : grid-stride over atoms; duplicates removed per wave (ballot / readlane
+//   k_bin_count       : (it reads the sigmas anyway) duplicates removed per wave (ballot / readlane
 //                       election) and per block (LDS hash set); each block stores its set (<= 32 values)
-//   k_merge_classes   : one block merges the per-block sets into the final table
+//   k_merge_classes   : two levels: 64-row slices -> 64-word sets, then one block -> the final table
 // ------------------------------------------------------------------------------------------------
 constexpr int CLS_BLOCK_SET = 32;
-constexpr int CLS_MAX_BLOCKS = 1024;
 
 MK_DEV unsigned class_hash(unsigned bits) { return (bits >> 9) ^ (bits >> 15) ^ (bits >> 21); }
 
@@ -114,92 +113,82 @@ MK_DEV bool lds_set_insert(unsigned* set, unsigned size, unsigned bits)
     return false;
 }
 
-template <typename SigT>
-MK_KERNEL(256) void k_collect_classes(const SigT* __restrict__ sigmas, long long total_atoms, int C,
-                                      double w_scale, unsigned* __restrict__ block_sets)
+// wave-cooperative registration of up to 8 w bit patterns per lane into the block's LDS set.
+// Must be called by ALL lanes of the wave (inactive lanes pass CLS_EMPTY everywhere).
+MK_DEV void wave_register_value(unsigned bits, unsigned* s_set, unsigned* s_full)
 {
-    __shared__ unsigned s_set[CLS_BLOCK_SET];
-    __shared__ unsigned s_full;
-    if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
-    if (threadIdx.x == 0) s_full = 0u;
-    mk_block_sync();
     const int lane = threadIdx.x & (WAVE - 1);
-    for (long long base = (long long)blockIdx.x * blockDim.x; base < total_atoms;
-         base += (long long)gridDim.x * blockDim.x) {                 // block-uniform trip count
-        const long long a = base + threadIdx.x;
-        const bool act = a < total_atoms;
-        for (int c0 = 0; c0 < C; c0 += CHG) {
-            // fetch up to 8 sigmas of this atom in one go (independent loads), then deduplicate
-            unsigned wb[CHG];
-#pragma unroll
-            for (int j = 0; j < CHG; ++j) {
-                wb[j] = CLS_EMPTY;
-                if (act && c0 + j < C) {
-                    const float w = sigma_to_w(sigmas[(size_t)a * C + c0 + j], w_scale);
-                    if (w < mk_inf()) wb[j] = mk_float_bits(w);
-                }
-            }
-            // most atoms carry ONE radius in all their channels: collapse equal values inside the lane first
-#pragma unroll
-            for (int j = 1; j < CHG; ++j)
-#pragma unroll
-                for (int i = 0; i < j; ++i)
-                    if (wb[j] == wb[i]) wb[j] = CLS_EMPTY;
-#pragma unroll
-            for (int j = 0; j < CHG; ++j) {
-                const unsigned bits = wb[j];
-                bool pending = bits != CLS_EMPTY;
-                for (;;) {                                           // wave-uniform: one trip per distinct value
-                    const unsigned long long mask = mk_ballot(pending);
-                    if (mask == 0ull) break;
-                    const int leader = __builtin_ctzll(mask);
-                    const unsigned lb = mk_readlane(bits, leader);
-                    if (bits == lb) pending = false;
-                    if (lane == leader && !lds_set_insert(s_set, CLS_BLOCK_SET, lb)) s_full = 1u;
-                }
-            }
-        }
+    bool pending = bits != CLS_EMPTY;
+    for (;;) {                                                   // wave-uniform: one trip per distinct value
+        const unsigned long long mask = mk_ballot(pending);
+        if (mask == 0ull) break;
+        const int leader = __builtin_ctzll(mask);
+        const unsigned lb = mk_readlane(bits, leader);
+        if (bits == lb) pending = false;
+        if (lane == leader && !lds_set_insert(s_set, CLS_BLOCK_SET, lb)) *s_full = 1u;
     }
-    mk_block_sync();
-    // a block that saw more than 32 distinct values reports "too many" with a reserved marker (0xfffffffe)
-    if (threadIdx.x < CLS_BLOCK_SET)
-        block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? 0xfffffffeu : s_set[threadIdx.x];
 }
 
-constexpr int MERGE_THREADS = 1024;
-constexpr int MERGE_PER_THREAD = (CLS_MAX_BLOCKS * CLS_BLOCK_SET / 4) / MERGE_THREADS;   // uint4 loads per thread
-
-MK_KERNEL(MERGE_THREADS) void k_merge_classes(const unsigned* __restrict__ block_sets, unsigned nwords,
-                                              unsigned* __restrict__ cls_table)
+MK_DEV void wave_register_classes(unsigned (&wb)[CHG], unsigned* s_set, unsigned* s_full)
 {
-    __shared__ unsigned s_set[64];
+    // most atoms carry ONE radius in all their channels: collapse equal values inside the lane first
+#pragma unroll
+    for (int j = 1; j < CHG; ++j)
+#pragma unroll
+        for (int i = 0; i < j; ++i)
+            if (wb[j] == wb[i]) wb[j] = CLS_EMPTY;
+    // the lane's first value goes through one election loop (a handful of trips per wave) ...
+    unsigned first = CLS_EMPTY;
+#pragma unroll
+    for (int j = CHG - 1; j >= 0; --j) first = (wb[j] != CLS_EMPTY) ? wb[j] : first;
+    wave_register_value(first, s_set, s_full);
+    // ... and only waves holding atoms with SEVERAL distinct sigmas pay for the remaining slots
+    bool more = false;
+#pragma unroll
+    for (int j = 0; j < CHG; ++j) more |= (wb[j] != CLS_EMPTY) && (wb[j] != first);
+    if (mk_ballot(more) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) wave_register_value((wb[j] != first) ? wb[j] : CLS_EMPTY, s_set, s_full);
+    }
+}
+
+constexpr unsigned CLS_TOO_MANY = 0xfffffffeu;     // a set that overflowed reports this marker instead of values
+constexpr int MERGE_SET = 64;                      // capacity of the merge kernels' LDS set (> NCLS)
+
+// Merge `rows_per_block` sets of `row_words` words each into one 64-word set per block.
+// Level 1: grid = ceil(nrows / rows_per_block) blocks over the per-block sets of k_bin_count;
+// level 2: one block over level 1's output, which also writes the final class table.
+MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned nrows, unsigned row_words,
+                                    unsigned rows_per_block, unsigned* __restrict__ out_sets,
+                                    unsigned* __restrict__ cls_table /* non-null: final level */)
+{
+    __shared__ unsigned s_set[MERGE_SET];
     __shared__ unsigned s_over;
-    if (threadIdx.x < 64) s_set[threadIdx.x] = CLS_EMPTY;
+    if (threadIdx.x < MERGE_SET) s_set[threadIdx.x] = CLS_EMPTY;
     if (threadIdx.x == 0) s_over = 0u;
     mk_block_sync();
-    const uint4* __restrict__ bs4 = reinterpret_cast<const uint4*>(block_sets);   // nwords is a multiple of 32
-    uint4 buf[MERGE_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < MERGE_PER_THREAD; ++k) {                   // all loads in flight before any is used
-        const unsigned i = threadIdx.x + (unsigned)k * MERGE_THREADS;
-        buf[k] = make_uint4(CLS_EMPTY, CLS_EMPTY, CLS_EMPTY, CLS_EMPTY);
-        if (i < nwords / 4u) buf[k] = bs4[i];
-    }
-#pragma unroll
-    for (int k = 0; k < MERGE_PER_THREAD; ++k) {
-        const unsigned vv[4] = {buf[k].x, buf[k].y, buf[k].z, buf[k].w};
+    const unsigned r0 = blockIdx.x * rows_per_block;
+    const unsigned r1 = r0 + rows_per_block < nrows ? r0 + rows_per_block : nrows;
+    const unsigned w0 = r0 * row_words, w1 = r1 * row_words;               // multiples of 4 words
+    const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(rows);
+    for (unsigned i = w0 / 4u + threadIdx.x; i < w1 / 4u; i += blockDim.x) {
+        const uint4 q4 = v4[i];
+        const unsigned vv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned v = vv[j];
             if (v == CLS_EMPTY) continue;
-            if (v == 0xfffffffeu || !lds_set_insert(s_set, 64u, v)) s_over = 1u;
+            if (v == CLS_TOO_MANY || !lds_set_insert(s_set, (unsigned)MERGE_SET, v)) s_over = 1u;
         }
     }
     mk_block_sync();
-    if (threadIdx.x == 0) {
+    if (cls_table == nullptr) {
+        if (threadIdx.x < MERGE_SET)
+            out_sets[(size_t)blockIdx.x * MERGE_SET + threadIdx.x] = s_over ? CLS_TOO_MANY : s_set[threadIdx.x];
+    } else if (threadIdx.x == 0) {
         unsigned n = 0;
         bool over = s_over != 0u;
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 0; i < MERGE_SET; ++i) {
             const unsigned v = s_set[i];
             if (v == CLS_EMPTY) continue;
             if (n < (unsigned)NCLS) cls_table[n] = v;
@@ -232,78 +221,104 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                 const float* __restrict__ box, unsigned* __restrict__ cell_count,
                                 float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
-                                int* __restrict__ err_flag)
+                                unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
 {
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_full;
+    const bool classes = !g.force_general;
+    if (classes) {
+        if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
+        if (threadIdx.x == 0) s_full = 0u;
+        mk_block_sync();
+    }
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= total_atoms) return;
-    const size_t t0 = (size_t)a * (size_t)g.img_cap;          // this atom's temp slots
-    int used = 0;
-    auto mark_rest = [&]() {
-        for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
-    };
+    const bool act = a < total_atoms;
 
-    // item of this atom: largest b with atom_offsets[b] <= a
-    int lo = 0, hi = g.B;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
-    }
-    const int b = lo;
-
-    // an atom with no usable channel is dropped here (occupancy_utils.pyx:55-56)
-    const SigT* sg = sigmas + (size_t)a * g.C;
+    // ---- the atom's channels: w bit patterns (one pass over the sigmas serves the drop test AND the class
+    //      discovery); registration is wave-cooperative, so every lane takes part ----
     bool any = false;
-    for (int c = 0; c < g.C; ++c) any |= sigma_to_w(sg[c], g.w_scale) < mk_inf();
-    if (!any) { mark_rest(); return; }
-
-    double p[3], Lv[3] = {0.0, 0.0, 0.0};
-    int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
-    const int nvox[3] = {g.nx, g.ny, g.nz};
-    bool drop = false;
+    for (int c0 = 0; c0 < g.C; c0 += CHG) {
+        unsigned wb[CHG];
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-        p[ax] = ((double)coords[3 * a + ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
-        if (g.pbc) {
-            const double L = (double)box[3 * (size_t)b + ax] * g.inv_res;
-            if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); drop = true; }
-            Lv[ax] = L;
-            const double a0 = ceil((-g.Rp - p[ax]) / L);
-            const double a1 = floor(((double)(nvox[ax] - 1) + g.Rp - p[ax]) / L);
-            if (a1 - a0 > 64.0) { mk_atomic_or(err_flag, MK_ERR_TOO_MANY_IMAGES); drop = true; }
-            k0[ax] = (int)a0; k1[ax] = (int)a1;          // empty range when a1 < a0
-        } else {
-            if (p[ax] < -g.Rp || p[ax] > (double)(nvox[ax] - 1) + g.Rp) drop = true;
-        }
-    }
-    if (drop) { mark_rest(); return; }
-
-    const double inv_cs = 1.0 / (double)g.cs;
-    const double cmid = 0.5 * (double)(g.cs - 1);
-    for (int kx = k0[0]; kx <= k1[0]; ++kx)
-        for (int ky = k0[1]; ky <= k1[1]; ++ky)
-            for (int kz = k0[2]; kz <= k1[2]; ++kz) {
-                const double q[3] = {p[0] + kx * Lv[0], p[1] + ky * Lv[1], p[2] + kz * Lv[2]};
-                int pc[3];
-                float rel[3];
-                bool inside = true;
-                const int nc[3] = {g.ncx, g.ncy, g.ncz};
-#pragma unroll
-                for (int ax = 0; ax < 3; ++ax) {
-                    const int ci = (int)floor((q[ax] + 0.5) * inv_cs);       // unpadded cell index
-                    pc[ax] = ci + g.h;
-                    inside &= (pc[ax] >= 0) && (pc[ax] < nc[ax]);
-                    rel[ax] = (float)(q[ax] - ((double)ci * (double)g.cs + cmid));
-                }
-                if (!inside) continue;
-                if (used >= g.img_cap) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
-                const size_t cell = (size_t)b * g.ncell + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2];
-                const unsigned rank = mk_atomic_add(&cell_count[cell], 1u);
-                tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2],
-                                                 mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
-                tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
-                ++used;
+        for (int j = 0; j < CHG; ++j) {
+            wb[j] = CLS_EMPTY;
+            if (act && c0 + j < g.C) {
+                const float w = sigma_to_w(sigmas[(size_t)a * g.C + c0 + j], g.w_scale);
+                if (w < mk_inf()) { wb[j] = mk_float_bits(w); any = true; }
             }
-    mark_rest();
+        }
+        if (classes) wave_register_classes(wb, s_set, &s_full);
+    }
+
+    if (act) {
+        const size_t t0 = (size_t)a * (size_t)g.img_cap;          // this atom's temp slots
+        int used = 0;
+        // an atom with no usable channel is dropped here (occupancy_utils.pyx:55-56)
+        bool drop = !any;
+        double p[3] = {0.0, 0.0, 0.0}, Lv[3] = {0.0, 0.0, 0.0};
+        int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
+        int b = 0;
+        if (!drop) {
+            // item of this atom: largest b with atom_offsets[b] <= a
+            int lo = 0, hi = g.B;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+            }
+            b = lo;
+            const int nvox[3] = {g.nx, g.ny, g.nz};
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) {
+                p[ax] = ((double)coords[3 * a + ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+                if (g.pbc) {
+                    const double L = (double)box[3 * (size_t)b + ax] * g.inv_res;
+                    if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); drop = true; }
+                    Lv[ax] = L;
+                    const double a0 = ceil((-g.Rp - p[ax]) / L);
+                    const double a1 = floor(((double)(nvox[ax] - 1) + g.Rp - p[ax]) / L);
+                    if (a1 - a0 > 64.0) { mk_atomic_or(err_flag, MK_ERR_TOO_MANY_IMAGES); drop = true; }
+                    k0[ax] = (int)a0; k1[ax] = (int)a1;          // empty range when a1 < a0
+                } else {
+                    if (p[ax] < -g.Rp || p[ax] > (double)(nvox[ax] - 1) + g.Rp) drop = true;
+                }
+            }
+        }
+        if (!drop) {
+            const double inv_cs = 1.0 / (double)g.cs;
+            const double cmid = 0.5 * (double)(g.cs - 1);
+            for (int kx = k0[0]; kx <= k1[0]; ++kx)
+                for (int ky = k0[1]; ky <= k1[1]; ++ky)
+                    for (int kz = k0[2]; kz <= k1[2]; ++kz) {
+                        const double q[3] = {p[0] + kx * Lv[0], p[1] + ky * Lv[1], p[2] + kz * Lv[2]};
+                        int pc[3];
+                        float rel[3];
+                        bool inside = true;
+                        const int nc[3] = {g.ncx, g.ncy, g.ncz};
+#pragma unroll
+                        for (int ax = 0; ax < 3; ++ax) {
+                            const int ci = (int)floor((q[ax] + 0.5) * inv_cs);       // unpadded cell index
+                            pc[ax] = ci + g.h;
+                            inside &= (pc[ax] >= 0) && (pc[ax] < nc[ax]);
+                            rel[ax] = (float)(q[ax] - ((double)ci * (double)g.cs + cmid));
+                        }
+                        if (!inside) continue;
+                        if (used >= g.img_cap) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
+                        const size_t cell = (size_t)b * g.ncell + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2];
+                        const unsigned rank = mk_atomic_add(&cell_count[cell], 1u);
+                        tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2],
+                                                         mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
+                        tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
+                        ++used;
+                    }
+        }
+        for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
+    }
+
+    if (classes) {
+        mk_block_sync();
+        if (threadIdx.x < CLS_BLOCK_SET)
+            block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
+    }
 }
 
 template <typename SigT>

@@ -9,8 +9,13 @@
 //   int  fill(void* p, int byte, size_t bytes)          async memset on the stream
 //   int  launch(kernel, dim3 grid, dim3 block, args...) async launch on the stream
 //   void hot_begin() / hot_end()                        bracket the tile kernel (event timing)
-//   void side_begin() / side_end() / side_join()        launches between begin/end may run concurrently
-//                                                       with the main sequence until side_join()
+//   int  acquire_set(bool pipelined)                    pick a workspace set (double-buffered); when
+//                                                       pipelined, following launches go to an internal
+//                                                       stream that may run beside the previous call's
+//                                                       tile kernel
+//   void prepass_done(int set)                          back to the caller's stream, which waits for the pre-pass
+//   void tile_done(int set)                             the set may be reused once the tile kernel has finished
+// ensure() takes the workspace set as its last argument.
 #pragma once
 #include "kernels.h"
 
@@ -24,7 +29,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_TMP_POS, WS_TMP_IDX, WS_ERR, WS_W_EXPLICIT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
     WS_NSLOTS
@@ -134,11 +139,11 @@ inline int max_images_from_boxes(const float* box, int B, const int* nvox, doubl
 }
 
 template <class BE>
-int run_scan(BE& be, const unsigned* counts, size_t n, unsigned* starts /* n+1 */)
+int run_scan(BE& be, const unsigned* counts, size_t n, unsigned* starts /* n+1 */, int set = 0)
 {
     const size_t nchunks = (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
     void* chunks = nullptr;
-    int st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks);
+    int st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set);
     if (st) return st;
     if ((st = be.launch(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (unsigned*)chunks))) return st;
     if ((st = be.launch(k_scan_sums_inplace, dim3(1), dim3(SCAN_THREADS), (unsigned*)chunks, (unsigned)nchunks))) return st;
@@ -154,48 +159,48 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (st) return st;
     if (P.B == 0 || g.V == 0) return ST_OK;
 
+    // Big batches are software-pipelined across calls: the pre-pass (latency / atomic bound) of this call
+    // runs on an internal stream beside the tile kernel (VALU bound) of the previous call, on the other
+    // workspace set.  Small calls stay in order on the caller's stream (the hand-over costs ~20 us).
+    const int set = be.acquire_set(P.total_atoms >= 200000);
     const size_t ncells = (size_t)g.B * (size_t)g.ncell;
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
-    if ((st = be.ensure(WS_CELL_COUNT, ncells * sizeof(unsigned), &count))) return st;
-    if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start))) return st;
-    if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos))) return st;
-    if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw))) return st;
-    if ((st = be.ensure(WS_REC_CLS, (size_t)g.M * sizeof(unsigned) * g.G, &rcls))) return st;
-    if ((st = be.ensure(WS_CLS_TABLE, CLS_TABLE_WORDS * sizeof(unsigned), &ctab))) return st;
-    if ((st = be.ensure(WS_ERR, sizeof(int), &eflag))) return st;
-
     void *tpos = nullptr, *tidx = nullptr;
-    if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos))) return st;
-    if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx))) return st;
+    if ((st = be.ensure(WS_CELL_COUNT, ncells * sizeof(unsigned), &count, set))) return st;
+    if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
+    if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos, set))) return st;
+    if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw, set))) return st;
+    if ((st = be.ensure(WS_REC_CLS, (size_t)g.M * sizeof(unsigned) * g.G, &rcls, set))) return st;
+    if ((st = be.ensure(WS_CLS_TABLE, CLS_TABLE_WORDS * sizeof(unsigned), &ctab, set))) return st;
+    if ((st = be.ensure(WS_ERR, sizeof(int), &eflag, 0))) return st;
+    if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos, set))) return st;
+    if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
 
     if ((st = be.fill(count, 0, ncells * sizeof(unsigned)))) return st;
     const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
     const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
-    // class discovery depends only on the sigmas: for big batches it runs beside the count + scan
-    // sequence on the side stream (the fork/join costs ~25 us of latency, too much for small calls)
-    const bool fork = P.total_atoms >= 200000;
-    if (fork) be.side_begin();
-    if (P.total_atoms > 0 && !g.force_general) {                      // distinct sigma values -> class table
-        const unsigned nb = (unsigned)std::min<long long>(CLS_MAX_BLOCKS, ceil_div(P.total_atoms, 256));
-        void* bsets = nullptr;
-        if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)CLS_MAX_BLOCKS * CLS_BLOCK_SET * sizeof(unsigned), &bsets))) return st;
-        st = P.sigmas_f64 ? be.launch(k_collect_classes<double>, dim3(nb), ablk, (const double*)P.sigmas, P.total_atoms, g.C, g.w_scale, (unsigned*)bsets)
-                          : be.launch(k_collect_classes<float>, dim3(nb), ablk, (const float*)P.sigmas, P.total_atoms, g.C, g.w_scale, (unsigned*)bsets);
+    const unsigned nblk = agrid.x;
+    const unsigned rows_per_block = 128;
+    const unsigned nl1 = (nblk + rows_per_block - 1) / rows_per_block;
+    void *bsets = nullptr, *l1sets = nullptr;
+    if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nblk * CLS_BLOCK_SET * sizeof(unsigned), &bsets, set))) return st;
+    if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
+    if (P.total_atoms > 0) {
+        st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
+                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag)
+                          : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
+                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
         if (st) return st;
-        if ((st = be.launch(k_merge_classes, dim3(1), dim3(MERGE_THREADS), (const unsigned*)bsets, nb * (unsigned)CLS_BLOCK_SET, (unsigned*)ctab))) return st;
+    }
+    if (P.total_atoms > 0 && !g.force_general) {                      // per-block sigma sets -> class table
+        if ((st = be.launch(k_merge_classes, dim3(nl1), dim3(256), (const unsigned*)bsets, nblk, (unsigned)CLS_BLOCK_SET,
+                            rows_per_block, (unsigned*)l1sets, (unsigned*)nullptr))) return st;
+        if ((st = be.launch(k_merge_classes, dim3(1), dim3(256), (const unsigned*)l1sets, nl1, (unsigned)MERGE_SET,
+                            nl1, (unsigned*)nullptr, (unsigned*)ctab))) return st;
     } else {
         if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
     }
-    if (fork) be.side_end();
-    if (P.total_atoms > 0) {
-        st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
-                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (int*)eflag)
-                          : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
-                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (int*)eflag);
-        if (st) return st;
-    }
-    if ((st = run_scan(be, (const unsigned*)count, ncells, (unsigned*)start))) return st;
-    if (fork) be.side_join();
+    if ((st = run_scan(be, (const unsigned*)count, ncells, (unsigned*)start, set))) return st;
     if (P.total_atoms > 0) {
         st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
                                       (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
@@ -203,6 +208,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                                       (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
         if (st) return st;
     }
+    be.prepass_done(set);
 
     const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G), tblk(WAVE);
@@ -212,6 +218,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     else
         st = be.launch(k_voxelize_tiles<4>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, P.out);
     be.hot_end();
+    be.tile_done(set);
     return st;
 }
 
@@ -228,7 +235,7 @@ int run_centers(BE& be, const double* d_centers, long long V, const float* d_coo
             if (!(box_host[ax] > 2.0 * CUTOFF_A)) { err = "periodic box edges must be > 10 A (2 x cutoff)"; return ST_EBOX; }
     const int G = ceil_div(C, CHG);
     void* w = nullptr;
-    int st = be.ensure(WS_W_EXPLICIT, (size_t)(N > 0 ? N : 1) * sizeof(float4) * 2 * G, &w);
+    int st = be.ensure(WS_W_EXPLICIT, (size_t)(N > 0 ? N : 1) * sizeof(float4) * 2 * G, &w, 0);
     if (st) return st;
     if (N > 0) {
         const dim3 blk(256), grid((unsigned)ceil_div(N, 256));

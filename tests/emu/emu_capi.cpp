@@ -15,7 +15,7 @@ struct EmuBackend {
     void* bufs[WS_NSLOTS] = {};
     size_t caps[WS_NSLOTS] = {};
     ~EmuBackend() { for (void* p : bufs) free(p); }
-    int ensure(int slot, size_t bytes, void** ptr)
+    int ensure(int slot, size_t bytes, void** ptr, int = 0)
     {
         if (bytes == 0) bytes = 16;
         if (caps[slot] < bytes) {
@@ -36,9 +36,9 @@ struct EmuBackend {
     }
     void hot_begin() {}
     void hot_end() {}
-    void side_begin() {}
-    void side_end() {}
-    void side_join() {}
+    int acquire_set(bool) { return 0; }
+    void prepass_done(int) {}
+    void tile_done(int) {}
 };
 
 thread_local std::string g_err;

@@ -223,3 +223,31 @@ def test_empty_and_degenerate_inputs(hip_ctx):
     with pytest.raises(MkamdError):
         batch.voxelize_lattice(np.zeros((1, 3), np.float32), [0, 1], np.ones((1, 8)), [[0, 0, 0]], [4, 4, 4], 1.0,
                                box=np.array([[9.0, 30, 30]], np.float32), ctx=hip_ctx)
+
+
+def test_pipelined_calls_match_in_order_calls(hip_ctx):
+    """Opt-in cross-call pipelining (pre-pass of call n+1 beside the tile kernel of call n, double-buffered
+    workspace) must not change a single bit, also when call sizes alternate and small in-order calls are mixed in."""
+    import torch
+    from moleculekit_amd import batch
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    work = []
+    for i, B in enumerate((6, 1, 5, 6, 4)):
+        p = synth_config(2, B, seed=50 + i)
+        o = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+        nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+        work.append((t(p["coords"], np.float32), t(p["atom_offsets"], np.int64), t(p["sigmas"], np.float32),
+                     t(o, np.float64), nv, p["voxelsize"]))
+    def run(pipelined):
+        hip_ctx.set_pipelining(pipelined)
+        outs = [batch.voxelize_lattice_torch(*w, ctx=hip_ctx) for w in work for _ in range(2)]
+        torch.cuda.synchronize()
+        hip_ctx.synchronize()
+        hip_ctx.set_pipelining(False)
+        return [o.cpu().numpy() for o in outs]
+    ref = run(False)
+    got = run(True)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert ref[0].max() > 0.5
