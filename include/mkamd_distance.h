@@ -1,0 +1,61 @@
+/*
+ * mkamd_distance.h -- C ABI of libmkamd.so, distance_utils row.
+ *
+ * GPU replacements for moleculekit/distance_utils/distance_utils.pyx:
+ *   dist_trajectory                  :126-155     -> mkamd_dist_trajectory_host
+ *   contacts_trajectory              :59-93       -> mkamd_dist_trajectory_host(squared = 1) + threshold on the host
+ *   dist_trajectory_reduction        :211-281 }   -> mkamd_dist_reduction_host (pairs = 0 / 1)
+ *   dist_trajectory_reduction_pairs  :286-350 }
+ *   cdist / get_collisions           :355-383, :98-121 -> mkamd_cdist_host
+ *   pdist                            :388-416     -> mkamd_pdist_host
+ * All float32, BIT-EXACT with the reference (same operation order, one rounding per operation).
+ *
+ * Layouts (C-contiguous, the reference's):  coords float32 [n_atoms, 3, n_frames] (Molecule.coords),
+ * box float32 [3, n_frames] (Molecule.box), results float32 [n_frames, n_pairs].
+ * Pair order: i over sel1, j over sel2 (from i+1 when selfdist) -- the reference's loop order.
+ * Host pointers in, host pointers out (copies + kernels + synchronise); status codes as mkamd_voxel.h.
+ */
+#ifndef MKAMD_DISTANCE_H
+#define MKAMD_DISTANCE_H
+
+#include "mkamd_voxel.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of (i,j) pairs the reference's loops visit (n1*n2, or sum_i max(n2-1-i,0) when selfdist) */
+int64_t mkamd_dist_count_pairs(int64_t n1, int64_t n2, int selfdist);
+
+/* dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, results);  squared != 0
+ * stores the squared distance (what contacts_trajectory compares with threshold^2) instead of its sqrt. */
+int mkamd_dist_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t n_atoms, int64_t n_frames,
+                               const float* box, const uint32_t* sel1, int64_t n1, const uint32_t* sel2,
+                               int64_t n2, const uint32_t* digitized_chains, int selfdist, int pbc,
+                               int squared, float* results);
+/* same on device pointers (asynchronous on the context's stream) */
+int mkamd_dist_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t n_frames, const float* d_box,
+                              const uint32_t* d_sel1, int64_t n1, const uint32_t* d_sel2, int64_t n2,
+                              const uint32_t* d_digitized_chains, int selfdist, int pbc, int squared,
+                              float* d_results);
+
+/* dist_trajectory_reduction / dist_trajectory_reduction_pairs.  The reference's vector<vector<int>> groups
+ * are passed as CSR: atoms int32 [sum of group sizes], offsets int64 [n_groups + 1].  reduction: 0 closest,
+ * 1 centre of mass (masses float32 [n_atoms]).  results float32 [n_frames, n_out], n_out = n_groups1 when
+ * pairs else mkamd_dist_count_pairs(n_groups1, n_groups2, selfdist). */
+int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t n_atoms, int64_t n_frames,
+                              const float* box, const int32_t* g1_atoms, const int64_t* g1_offsets,
+                              int64_t n_groups1, const int32_t* g2_atoms, const int64_t* g2_offsets,
+                              int64_t n_groups2, const uint32_t* digitized_chains1,
+                              const uint32_t* digitized_chains2, int selfdist, int pairs, int pbc,
+                              const float* masses, int reduction1, int reduction2, float* results);
+
+/* cdist(coords1 [n1,D], coords2 [n2,D]) -> results [n1,n2];  pdist(coords [n,D]) -> results [n(n-1)/2] */
+int mkamd_cdist_host(mkamd_ctx* ctx, const float* coords1, int64_t n1, const float* coords2, int64_t n2,
+                     int32_t dim, float* results);
+int mkamd_pdist_host(mkamd_ctx* ctx, const float* coords, int64_t n, int32_t dim, float* results);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKAMD_DISTANCE_H */

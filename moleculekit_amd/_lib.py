@@ -44,6 +44,15 @@ SIGNATURES = {
                                             _c_dbl, _vp, _c_i32, _vp]),
     "mkamd_grid_centers_host": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
     "mkamd_grid_centers_dev": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
+    # include/mkamd_distance.h
+    "mkamd_dist_count_pairs": (_c_i64, [_c_i64, _c_i64, _c_int]),
+    "mkamd_dist_trajectory_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int,
+                                            _c_int, _vp]),
+    "mkamd_dist_trajectory_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int, _c_int, _vp]),
+    "mkamd_dist_reduction_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _vp,
+                                           _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp]),
+    "mkamd_cdist_host": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _c_i32, _vp]),
+    "mkamd_pdist_host": (_c_int, [_vp, _vp, _c_i64, _c_i32, _vp]),
 }
 
 _lib = None
@@ -189,6 +198,28 @@ class Context:
 
     def grid_centers_host(self, bb_min, nvox, voxelsize, out):
         _check(load().mkamd_grid_centers_host(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(out)))
+
+    # -- distance_utils row (include/mkamd_distance.h) -------------------------------------------------
+    def dist_trajectory_host(self, coords, box, sel1, sel2, chains, selfdist, pbc, squared, out):
+        N, _, F = coords.shape
+        _check(load().mkamd_dist_trajectory_host(self._h, _ptr(coords), N, F, _ptr(box), _ptr(sel1), sel1.shape[0], _ptr(sel2),
+                                                 sel2.shape[0], _ptr(chains), int(selfdist), int(pbc), int(squared), _ptr(out)))
+
+    def dist_trajectory_dev(self, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_out):
+        _check(load().mkamd_dist_trajectory_dev(self._h, _ptr(d_coords), F, _ptr(d_box), _ptr(d_sel1), n1, _ptr(d_sel2), n2,
+                                                _ptr(d_chains), int(selfdist), int(pbc), int(squared), _ptr(d_out)))
+
+    def dist_reduction_host(self, coords, box, g1a, g1o, g2a, g2o, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out):
+        N, _, F = coords.shape
+        _check(load().mkamd_dist_reduction_host(self._h, _ptr(coords), N, F, _ptr(box), _ptr(g1a), _ptr(g1o), g1o.shape[0] - 1,
+                                                _ptr(g2a), _ptr(g2o), g2o.shape[0] - 1, _ptr(ch1), _ptr(ch2), int(selfdist),
+                                                int(pairs), int(pbc), _ptr(masses), int(r1), int(r2), _ptr(out)))
+
+    def cdist_host(self, c1, c2, out):
+        _check(load().mkamd_cdist_host(self._h, _ptr(c1), c1.shape[0], _ptr(c2), c2.shape[0], c1.shape[1], _ptr(out)))
+
+    def pdist_host(self, c, out):
+        _check(load().mkamd_pdist_host(self._h, _ptr(c), c.shape[0], c.shape[1], _ptr(out)))
 
     def grid_centers_dev(self, bb_min, nvox, voxelsize, d_out):
         _check(load().mkamd_grid_centers_dev(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(d_out)))

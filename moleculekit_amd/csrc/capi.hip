@@ -3,7 +3,9 @@
 // stream, one grow-only workspace.  No CPU compute path exists here: without a GPU every entry
 // point fails with MKAMD_ENODEV / MKAMD_EHIP.
 #include "../../include/mkamd_voxel.h"
+#include "../../include/mkamd_distance.h"
 #include "pipeline.h"
+#include "dist_pipeline.h"
 
 #include <cstring>
 #include <string>
@@ -501,6 +503,134 @@ int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t*
     if ((st = ctx->ensure(WS_H_CENTERS, (size_t)V * 24, &dc))) return st;
     if ((st = mkamd_grid_centers_dev(ctx, bb_min, nvoxels, voxelsize, (double*)dc))) return st;
     HIP_TRY(hipMemcpyAsync(centers, dc, (size_t)V * 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// distance_utils row (include/mkamd_distance.h)
+// ---------------------------------------------------------------------------------------------
+static int upload(mkamd_ctx* ctx, int slot, const void* src, size_t bytes, void** dst)
+{
+    int st = ctx->ensure(slot, bytes, dst, 0);
+    if (st) return st;
+    if (bytes) HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+int64_t mkamd_dist_count_pairs(int64_t n1, int64_t n2, int selfdist) { return count_pairs(n1, n2, selfdist); }
+
+int mkamd_dist_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t F, const float* d_box,
+                              const uint32_t* d_sel1, int64_t n1, const uint32_t* d_sel2, int64_t n2,
+                              const uint32_t* d_chains, int selfdist, int pbc, int squared, float* d_results)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    std::string err;
+    st = run_dist_trajectory(*ctx, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_results, err);
+    if (st && !err.empty()) return fail(st, err);
+    return st;
+}
+
+int mkamd_dist_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t N, int64_t F, const float* box,
+                               const uint32_t* sel1, int64_t n1, const uint32_t* sel2, int64_t n2,
+                               const uint32_t* chains, int selfdist, int pbc, int squared, float* results)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (N < 0 || F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
+    const int64_t P = count_pairs(n1, n2, selfdist);
+    if (F == 0 || P == 0) return MKAMD_OK;
+    if (!coords || !box || !sel1 || !sel2 || !chains || !results) return fail(MKAMD_EINVAL, "NULL pointer");
+    for (int64_t i = 0; i < n1; ++i) if (sel1[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel1 index out of range");
+    for (int64_t i = 0; i < n2; ++i) if (sel2[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel2 index out of range");
+    void *dc, *db, *d1, *d2, *dch, *dout;
+    if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+    if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
+    if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
+    if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
+    if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
+    if ((st = ctx->ensure(WS_H_OUT, (size_t)F * P * 4, &dout, 0))) return st;
+    st = mkamd_dist_trajectory_dev(ctx, (const float*)dc, F, (const float*)db, (const uint32_t*)d1, n1, (const uint32_t*)d2, n2,
+                                   (const uint32_t*)dch, selfdist, pbc, squared, (float*)dout);
+    if (st) return st;
+    HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+}
+
+int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t N, int64_t F, const float* box,
+                              const int32_t* g1_atoms, const int64_t* g1_off, int64_t ng1, const int32_t* g2_atoms,
+                              const int64_t* g2_off, int64_t ng2, const uint32_t* chains1, const uint32_t* chains2,
+                              int selfdist, int pairs, int pbc, const float* masses, int reduction1, int reduction2,
+                              float* results)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (N < 0 || F < 0 || ng1 < 0 || ng2 < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (pairs && ng1 != ng2) return fail(MKAMD_EINVAL, "pairs mode needs the same number of groups on both sides");
+    const int64_t P = pairs ? ng1 : count_pairs(ng1, ng2, selfdist);
+    if (F == 0 || P == 0) return MKAMD_OK;
+    if (!coords || !box || !g1_off || !g2_off || !chains1 || !chains2 || !results) return fail(MKAMD_EINVAL, "NULL pointer");
+    if ((reduction1 == 1 || reduction2 == 1) && !masses) return fail(MKAMD_EINVAL, "masses are required for the com reduction");
+    for (int64_t g = 0; g < ng1; ++g) if (g1_off[g + 1] <= g1_off[g]) return fail(MKAMD_EINVAL, "empty group in groups1");
+    for (int64_t g = 0; g < ng2; ++g) if (g2_off[g + 1] <= g2_off[g]) return fail(MKAMD_EINVAL, "empty group in groups2");
+    for (int64_t k = 0; k < g1_off[ng1]; ++k) if (g1_atoms[k] < 0 || g1_atoms[k] >= N) return fail(MKAMD_EINVAL, "groups1 atom index out of range");
+    for (int64_t k = 0; k < g2_off[ng2]; ++k) if (g2_atoms[k] < 0 || g2_atoms[k] >= N) return fail(MKAMD_EINVAL, "groups2 atom index out of range");
+    void *dc, *db, *a1, *o1, *a2, *o2, *c1, *c2, *dm = nullptr, *dout;
+    if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+    if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
+    if ((st = upload(ctx, WS_D_G1A, g1_atoms, (size_t)g1_off[ng1] * 4, &a1))) return st;
+    if ((st = upload(ctx, WS_D_G1O, g1_off, (size_t)(ng1 + 1) * 8, &o1))) return st;
+    if ((st = upload(ctx, WS_D_G2A, g2_atoms, (size_t)g2_off[ng2] * 4, &a2))) return st;
+    if ((st = upload(ctx, WS_D_G2O, g2_off, (size_t)(ng2 + 1) * 8, &o2))) return st;
+    if ((st = upload(ctx, WS_D_CHAINS, chains1, (size_t)ng1 * 4, &c1))) return st;
+    if ((st = upload(ctx, WS_D_CHAINS2, chains2, (size_t)ng2 * 4, &c2))) return st;
+    if (masses && (st = upload(ctx, WS_D_MASS, masses, (size_t)N * 4, &dm))) return st;
+    if ((st = ctx->ensure(WS_H_OUT, (size_t)F * P * 4, &dout, 0))) return st;
+    std::string err;
+    st = run_dist_reduction(*ctx, (const float*)dc, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, (const int*)a2,
+                            (const long long*)o2, ng2, (const unsigned*)c1, (const unsigned*)c2, selfdist, pairs, pbc,
+                            (const float*)dm, reduction1, reduction2, (float*)dout, err);
+    if (st) return err.empty() ? st : fail(st, err);
+    HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+}
+
+int mkamd_cdist_host(mkamd_ctx* ctx, const float* c1, int64_t n1, const float* c2, int64_t n2, int32_t D, float* results)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n1 < 0 || n2 < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (n1 == 0 || n2 == 0) return MKAMD_OK;
+    if (!c1 || !c2 || !results) return fail(MKAMD_EINVAL, "NULL pointer");
+    void *d1, *d2, *dout;
+    if ((st = upload(ctx, WS_H_COORDS, c1, (size_t)n1 * D * 4, &d1))) return st;
+    if ((st = upload(ctx, WS_H_SIGMAS, c2, (size_t)n2 * D * 4, &d2))) return st;
+    if ((st = ctx->ensure(WS_H_OUT, (size_t)n1 * n2 * 4, &dout, 0))) return st;
+    std::string err;
+    st = run_cdist(*ctx, (const float*)d1, n1, (const float*)d2, n2, D, (float*)dout, err);
+    if (st) return err.empty() ? st : fail(st, err);
+    HIP_TRY(hipMemcpyAsync(results, dout, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+}
+
+int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float* results)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (n < 2) return MKAMD_OK;
+    if (!c || !results) return fail(MKAMD_EINVAL, "NULL pointer");
+    void *d1, *dout;
+    if ((st = upload(ctx, WS_H_COORDS, c, (size_t)n * D * 4, &d1))) return st;
+    if ((st = ctx->ensure(WS_H_OUT, (size_t)n * (n - 1) / 2 * 4, &dout, 0))) return st;
+    std::string err;
+    st = run_pdist(*ctx, (const float*)d1, n, D, (float*)dout, err);
+    if (st) return err.empty() ? st : fail(st, err);
+    HIP_TRY(hipMemcpyAsync(results, dout, (size_t)n * (n - 1) / 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
 }

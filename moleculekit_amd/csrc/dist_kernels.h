@@ -1,0 +1,211 @@
+// dist_kernels.h -- HIP kernels for moleculekit/distance_utils/distance_utils.pyx on MI355X (gfx950)
+// (dist_trajectory, dist_trajectory_reduction[_pairs], cdist, pdist; the
+//  contact / collision lists and squareform are index work on top of these, moleculekit_amd/distance_utils.py).
+//
+// The reference computes in float32 with a fixed operation order, so these kernels are BIT-EXACT: every
+// multiply / add / divide / sqrt is a separately rounded round-to-nearest op (mk_f*_rn, never contracted
+// into an FMA), sums run in the reference's order, round() is half-away-from-zero.
+//
+// Layouts are the reference's: coords float32 [n_atoms, 3, n_frames] (frame fastest, Molecule.coords),
+// box float32 [3, n_frames], results float32 [n_frames, n_pairs].  Frames are the coalescing axis of the
+// inputs and pairs the one of the output, so every kernel computes a 64-frame x 64-pair tile with lanes
+// along frames, transposes it through LDS (65-float pitch: conflict-free) and stores with lanes along pairs.
+#pragma once
+#ifndef MK_DEVICE_API_PROVIDED
+#include "mk_device.h"
+#endif
+
+namespace mkamd {
+
+// distance_utils.pyx:34-54 (_dist) / :188-206 (_dist2)
+MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y2, float z2,
+                                 float bx, float by, float bz, bool wrap)
+{
+    float dx = mk_fsub_rn(x1, x2), dy = mk_fsub_rn(y1, y2), dz = mk_fsub_rn(z1, z2);
+    if (wrap) {
+        dx = mk_fsub_rn(dx, mk_fmul_rn(bx, roundf(mk_fdiv_rn(dx, bx))));
+        dy = mk_fsub_rn(dy, mk_fmul_rn(by, roundf(mk_fdiv_rn(dy, by))));
+        dz = mk_fsub_rn(dz, mk_fmul_rn(bz, roundf(mk_fdiv_rn(dz, bz))));
+    }
+    return mk_fadd_rn(mk_fadd_rn(mk_fmul_rn(dx, dx), mk_fmul_rn(dy, dy)), mk_fmul_rn(dz, dz));
+}
+
+constexpr int DT = 64;                 // tile edge (frames and pairs)
+constexpr int DT_THREADS = 256;
+
+// Compute value(f, p) for a DT x DT tile with lanes along frames, store it with lanes along pairs.
+// blockIdx.x = pair tile, blockIdx.y = frame tile.
+template <class Fn>
+MK_DEV void tile_frames_to_pairs(long long F, long long P, float* __restrict__ out, Fn&& value)
+{
+    __shared__ float tile[DT][DT + 1];
+    const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
+    {
+        const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
+        const long long f = f0 + fl;
+        for (int pp = pq; pp < DT; pp += DT_THREADS / DT) {
+            const long long p = p0 + pp;
+            if (f < F && p < P) tile[pp][fl] = value(f, p);
+        }
+    }
+    mk_block_sync();
+    {
+        const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
+        const long long p = p0 + pl;
+        for (int ff = fq; ff < DT; ff += DT_THREADS / DT) {
+            const long long f = f0 + ff;
+            if (f < F && p < P) out[f * P + p] = tile[pl][ff];
+        }
+    }
+}
+
+// Pair table of dist_trajectory (distance_utils.pyx:144-155): loop order i over sel1, j over sel2 from
+// (selfdist ? i+1 : 0).  One thread per (i, j); wrap = pbc && chains differ (:49).
+MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long long n1,
+                                       const unsigned* __restrict__ sel2, long long n2,
+                                       const unsigned* __restrict__ chains, int selfdist, int pbc,
+                                       unsigned* __restrict__ pa, unsigned* __restrict__ pb,
+                                       unsigned* __restrict__ wrap)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = blockIdx.y;
+    if (i >= n1 || j >= n2) return;
+    long long idx;
+    if (selfdist) {
+        if (j <= i) return;
+        // rows 0..i-1 hold max(n2-1-k, 0) entries each
+        const long long full = i < n2 ? i : n2;                     // rows with a positive count
+        idx = full * (n2 - 1) - full * (full - 1) / 2 + (j - i - 1);
+    } else {
+        idx = i * n2 + j;
+    }
+    const unsigned a = sel1[i], b = sel2[j];
+    pa[idx] = a; pb[idx] = b;
+    wrap[idx] = (pbc && chains[a] != chains[b]) ? 1u : 0u;
+}
+
+// dist_trajectory (distance_utils.pyx:126-155): results[f, p] = sqrt(_dist(...)) (or the square).
+MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
+                                        const float* __restrict__ box, const unsigned* __restrict__ pa,
+                                        const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
+                                        long long P, int squared, float* __restrict__ out)
+{
+    tile_frames_to_pairs(F, P, out, [&](long long f, long long p) {
+        const size_t a = pa[p], b = pb[p];
+        const float d2 = dist2_min_image_f32(coords[(a * 3 + 0) * F + f], coords[(a * 3 + 1) * F + f], coords[(a * 3 + 2) * F + f],
+                                             coords[(b * 3 + 0) * F + f], coords[(b * 3 + 1) * F + f], coords[(b * 3 + 2) * F + f],
+                                             box[0 * F + f], box[1 * F + f], box[2 * F + f], wrap[p] != 0u);
+        return squared ? d2 : mk_fsqrt_rn(d2);
+    });
+}
+
+// Centre of mass of every group in every frame (distance_utils.pyx:160-183): sequential float32
+// accumulation in group order.  com has the coords layout [n_groups, 3, F]; lanes along frames.
+MK_KERNEL(256) void k_group_com(const float* __restrict__ coords, long long F,
+                                const int* __restrict__ g_atoms, const long long* __restrict__ g_off,
+                                long long ng, const float* __restrict__ masses, float* __restrict__ com)
+{
+    const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long g = blockIdx.y;
+    if (f >= F || g >= ng) return;
+    float total = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+    for (long long k = g_off[g]; k < g_off[g + 1]; ++k) {
+        const size_t a = (size_t)g_atoms[k];
+        const float m = masses[a];
+        cx = mk_fadd_rn(cx, mk_fmul_rn(coords[(a * 3 + 0) * F + f], m));
+        cy = mk_fadd_rn(cy, mk_fmul_rn(coords[(a * 3 + 1) * F + f], m));
+        cz = mk_fadd_rn(cz, mk_fmul_rn(coords[(a * 3 + 2) * F + f], m));
+        total = mk_fadd_rn(total, m);
+    }
+    com[((size_t)g * 3 + 0) * F + f] = mk_fdiv_rn(cx, total);
+    com[((size_t)g * 3 + 1) * F + f] = mk_fdiv_rn(cy, total);
+    com[((size_t)g * 3 + 2) * F + f] = mk_fdiv_rn(cz, total);
+}
+
+// Group-pair table of dist_trajectory_reduction (:240-281) / _pairs (:312-350).
+MK_KERNEL(256) void k_build_group_pairs(long long ng1, long long ng2, const unsigned* __restrict__ chains1,
+                                        const unsigned* __restrict__ chains2, int selfdist, int pairs, int pbc,
+                                        unsigned* __restrict__ ga, unsigned* __restrict__ gb,
+                                        unsigned* __restrict__ wrap)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = blockIdx.y;
+    if (i >= ng1 || j >= ng2) return;
+    long long idx;
+    if (pairs) {
+        if (j != i) return;
+        idx = i;
+    } else if (selfdist) {
+        if (j <= i) return;
+        const long long full = i < ng2 ? i : ng2;
+        idx = full * (ng2 - 1) - full * (full - 1) / 2 + (j - i - 1);
+    } else {
+        idx = i * ng2 + j;
+    }
+    ga[idx] = (unsigned)i; gb[idx] = (unsigned)j;
+    wrap[idx] = (pbc && chains1[i] != chains2[j]) ? 1u : 0u;
+}
+
+// dist_trajectory_reduction[_pairs]: per (frame, group pair) the minimum squared distance over the atom
+// pairs (reduction 0, "closest") or between centres of mass (reduction 1; c1/c2 then point at COM arrays
+// and every group counts as one pseudo-atom indexed by its group id).  The reference's update rule
+// `if dist2 < mindist or mindist < 0` (mindist starts at -1) is kept verbatim, NaN behaviour included.
+MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const float* __restrict__ c2,
+                                            long long F, const float* __restrict__ box,
+                                            const int* __restrict__ g1_atoms, const long long* __restrict__ g1_off,
+                                            const int* __restrict__ g2_atoms, const long long* __restrict__ g2_off,
+                                            int com1, int com2, const unsigned* __restrict__ ga,
+                                            const unsigned* __restrict__ gb, const unsigned* __restrict__ wrap,
+                                            long long P, float* __restrict__ out)
+{
+    tile_frames_to_pairs(F, P, out, [&](long long f, long long p) {
+        const long long a = ga[p], b = gb[p];
+        const bool w = wrap[p] != 0u;
+        const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
+        const long long i0 = com1 ? a : g1_off[a], i1 = com1 ? a + 1 : g1_off[a + 1];
+        const long long j0 = com2 ? b : g2_off[b], j1 = com2 ? b + 1 : g2_off[b + 1];
+        float mindist = -1.f;
+        for (long long i = i0; i < i1; ++i) {
+            const size_t at1 = com1 ? (size_t)i : (size_t)g1_atoms[i];
+            const float x1 = c1[(at1 * 3 + 0) * F + f], y1 = c1[(at1 * 3 + 1) * F + f], z1 = c1[(at1 * 3 + 2) * F + f];
+            for (long long j = j0; j < j1; ++j) {
+                const size_t at2 = com2 ? (size_t)j : (size_t)g2_atoms[j];
+                const float d2 = dist2_min_image_f32(x1, y1, z1, c2[(at2 * 3 + 0) * F + f], c2[(at2 * 3 + 1) * F + f],
+                                                     c2[(at2 * 3 + 2) * F + f], bx, by, bz, w);
+                if (d2 < mindist || mindist < 0.f) mindist = d2;
+            }
+        }
+        return mk_fsqrt_rn(mindist);
+    });
+}
+
+// cdist (distance_utils.pyx:355-383): results[i, j]; any dimension D; lanes along j.
+MK_KERNEL(256) void k_cdist(const float* __restrict__ c1, long long n1, const float* __restrict__ c2,
+                            long long n2, int D, float* __restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = blockIdx.y;
+    if (i >= n1 || j >= n2) return;
+    float d2 = 0.f;
+    for (int k = 0; k < D; ++k) {
+        const float diff = mk_fsub_rn(c1[i * D + k], c2[j * D + k]);
+        d2 = mk_fadd_rn(d2, mk_fmul_rn(diff, diff));
+    }
+    out[i * n2 + j] = mk_fsqrt_rn(d2);
+}
+
+// pdist (distance_utils.pyx:388-416): condensed upper triangle, row i holds n-1-i entries.
+MK_KERNEL(256) void k_pdist(const float* __restrict__ c, long long n, int D, float* __restrict__ out)
+{
+    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i = blockIdx.y;
+    if (i >= n || j >= n || j <= i) return;
+    float d2 = 0.f;
+    for (int k = 0; k < D; ++k) {
+        const float diff = mk_fsub_rn(c[i * D + k], c[j * D + k]);
+        d2 = mk_fadd_rn(d2, mk_fmul_rn(diff, diff));
+    }
+    out[i * (n - 1) - i * (i - 1) / 2 + (j - i - 1)] = mk_fsqrt_rn(d2);
+}
+
+}  // namespace mkamd

@@ -1,0 +1,91 @@
+// dist_pipeline.h -- launch sequences for dist_kernels.h (same backend concept as pipeline.h).
+#pragma once
+#include "dist_kernels.h"
+#include "pipeline.h"
+
+namespace mkamd {
+
+inline long long count_pairs(long long n1, long long n2, int selfdist)
+{
+    if (!selfdist) return n1 * n2;
+    long long s = 0;
+    for (long long i = 0; i < n1; ++i) s += (n2 - 1 - i) > 0 ? (n2 - 1 - i) : 0;
+    return s;
+}
+
+// dist_trajectory on device pointers (coords [N,3,F], box [3,F], sel/chains uint32) -> out [F, P]
+template <class BE>
+int run_dist_trajectory(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
+                        const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
+                        float* out, std::string& err)
+{
+    if (F < 0 || n1 < 0 || n2 < 0) { err = "negative size"; return ST_EINVAL; }
+    const long long P = count_pairs(n1, n2, selfdist);
+    if (F == 0 || P == 0) return ST_OK;
+    if (P > 0x7fffffffLL * 32) { err = "too many pairs"; return ST_EINVAL; }
+    void *pa = nullptr, *pb = nullptr, *wr = nullptr;
+    int st;
+    if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
+    if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
+    if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
+    if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)n1), dim3(256), sel1, n1, sel2, n2,
+                        chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
+    return be.launch(k_dist_pairs, dim3((unsigned)ceil_div(P, DT), (unsigned)ceil_div(F, DT)), dim3(DT_THREADS), coords, F, box,
+                     (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
+}
+
+// dist_trajectory_reduction[_pairs] on device pointers; groups as CSR (atoms int32, offsets int64)
+template <class BE>
+int run_dist_reduction(BE& be, const float* coords, long long F, const float* box, const int* g1_atoms,
+                       const long long* g1_off, long long ng1, const int* g2_atoms, const long long* g2_off,
+                       long long ng2, const unsigned* chains1, const unsigned* chains2, int selfdist, int pairs, int pbc,
+                       const float* masses, int reduction1, int reduction2, float* out, std::string& err)
+{
+    if (F < 0 || ng1 < 0 || ng2 < 0) { err = "negative size"; return ST_EINVAL; }
+    if (pairs && ng1 != ng2) { err = "pairs mode needs the same number of groups on both sides"; return ST_EINVAL; }
+    if ((reduction1 | reduction2) & ~1) { err = "reduction must be 0 (closest) or 1 (com)"; return ST_EINVAL; }
+    const long long P = pairs ? ng1 : count_pairs(ng1, ng2, selfdist);
+    if (F == 0 || P == 0) return ST_OK;
+    void *ga = nullptr, *gb = nullptr, *wr = nullptr, *com1 = nullptr, *com2 = nullptr;
+    int st;
+    if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &ga, 0))) return st;
+    if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &gb, 0))) return st;
+    if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
+    if ((st = be.launch(k_build_group_pairs, dim3((unsigned)ceil_div(ng2, 256), (unsigned)ng1), dim3(256), ng1, ng2, chains1,
+                        chains2, selfdist, pairs, pbc, (unsigned*)ga, (unsigned*)gb, (unsigned*)wr))) return st;
+    const float *c1 = coords, *c2 = coords;
+    if (reduction1 == 1) {
+        if ((st = be.ensure(WS_D_COM1, (size_t)ng1 * 3 * F * 4, &com1, 0))) return st;
+        if ((st = be.launch(k_group_com, dim3((unsigned)ceil_div(F, 256), (unsigned)ng1), dim3(256), coords, F, g1_atoms, g1_off,
+                            ng1, masses, (float*)com1))) return st;
+        c1 = (const float*)com1;
+    }
+    if (reduction2 == 1) {
+        if ((st = be.ensure(WS_D_COM2, (size_t)ng2 * 3 * F * 4, &com2, 0))) return st;
+        if ((st = be.launch(k_group_com, dim3((unsigned)ceil_div(F, 256), (unsigned)ng2), dim3(256), coords, F, g2_atoms, g2_off,
+                            ng2, masses, (float*)com2))) return st;
+        c2 = (const float*)com2;
+    }
+    return be.launch(k_dist_reduction, dim3((unsigned)ceil_div(P, DT), (unsigned)ceil_div(F, DT)), dim3(DT_THREADS), c1, c2, F, box,
+                     g1_atoms, g1_off, g2_atoms, g2_off, reduction1, reduction2, (const unsigned*)ga, (const unsigned*)gb,
+                     (const unsigned*)wr, P, out);
+}
+
+template <class BE>
+int run_cdist(BE& be, const float* c1, long long n1, const float* c2, long long n2, int D, float* out, std::string& err)
+{
+    if (n1 < 0 || n2 < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
+    if (n1 == 0 || n2 == 0) return ST_OK;
+    if (n1 > 0x7fffffffLL) { err = "too many rows"; return ST_EINVAL; }
+    return be.launch(k_cdist, dim3((unsigned)ceil_div(n2, 256), (unsigned)n1), dim3(256), c1, n1, c2, n2, D, out);
+}
+
+template <class BE>
+int run_pdist(BE& be, const float* c, long long n, int D, float* out, std::string& err)
+{
+    if (n < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
+    if (n < 2) return ST_OK;
+    return be.launch(k_pdist, dim3((unsigned)ceil_div(n, 256), (unsigned)n), dim3(256), c, n, D, out);
+}
+
+}  // namespace mkamd

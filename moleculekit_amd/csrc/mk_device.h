@@ -87,6 +87,44 @@ MK_DEV double mk_dadd_rn(double a, double b)
     return a + b;
 }
 
+// float32 ops with exactly one rounding each and no FMA contraction (distance_utils parity is bit-exact)
+MK_DEV float mk_fadd_rn(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+MK_DEV float mk_fsub_rn(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
+MK_DEV float mk_fmul_rn(float a, float b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+MK_DEV float mk_fdiv_rn(float a, float b) { return __fdiv_rn(a, b); }     // IEEE correctly rounded
+// IEEE correctly rounded sqrt.  (hipcc lowers __fsqrt_rn / sqrtf in this build to a bare v_sqrt_f32, which
+// is only accurate to 1 ulp -- measured: 15 % of results off in the last bit.)  v_sqrt_f32 is within 1 ulp, so
+// the correctly rounded value is s or one of its neighbours; the sign of the exactly computed (FMA)
+// residuals x - s*s_down and x - s*s_up tells on which side of the two rounding midpoints x lies.
+MK_DEV float mk_fsqrt_rn(float x)
+{
+    // keep v_sqrt_f32 away from denormal inputs / results: scale tiny x by 2^64 (exact), result by 2^-32
+    const bool tiny = x < 0x1.0p-96f;
+    const float xs = tiny ? x * 0x1.0p+64f : x;
+    float s = __builtin_amdgcn_sqrtf(xs);
+    const float s_down = __uint_as_float(__float_as_uint(s) - 1u);
+    const float s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_down = __builtin_fmaf(-s_down, s, xs);
+    const float r_up = __builtin_fmaf(-s_up, s, xs);
+    float y = (r_down <= 0.0f) ? s_down : s;
+    y = (r_up > 0.0f) ? s_up : y;
+    y = tiny ? y * 0x1.0p-32f : y;
+    // 0, +inf, NaN and negative inputs: the hardware result is already the IEEE one
+    return (xs > 0.0f && xs < __builtin_inff()) ? y : s;
+}
+
 MK_DEV float mk_int_as_float(int i) { return __int_as_float(i); }
 MK_DEV int mk_float_as_int(float f) { return __float_as_int(f); }
 

@@ -32,6 +32,9 @@ enum WsSlot {
     WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
+    // distance_utils row (dist_pipeline.h)
+    WS_D_PA, WS_D_PB, WS_D_WRAP, WS_D_COM1, WS_D_COM2, WS_D_SEL1, WS_D_SEL2, WS_D_CHAINS, WS_D_CHAINS2, WS_D_G1A, WS_D_G1O,
+    WS_D_G2A, WS_D_G2O, WS_D_MASS,
     WS_NSLOTS
 };
 

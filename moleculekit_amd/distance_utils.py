@@ -1,0 +1,169 @@
+"""GPU drop-ins for the functions of ``moleculekit.distance_utils`` (Cython, distance_utils.pyx:59-434).
+
+Same names, argument order, dtypes and in-place ``results`` semantics as the reference's typed-memoryview
+functions; float32 results are BIT-EXACT with the reference (the kernels reproduce its float32 operation
+order with un-contracted round-to-nearest ops, see csrc/dist_kernels.h).  The all-pairs distance work runs
+in HIP kernels; the variable-length index lists of ``contacts_trajectory`` / ``get_collisions`` are
+extracted on the host from GPU-computed squared distances (``dist2 <= threshold^2`` in float32, as
+:82-90 and :111-120 do).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+FLOAT32, UINT32 = np.float32, np.uint32
+
+
+def _req(name, a, dtype, ndim):
+    if not isinstance(a, np.ndarray):
+        raise TypeError(f"{name}: a numpy array is required")
+    if a.dtype != dtype:
+        raise ValueError(f"Buffer dtype mismatch for {name}: expected {np.dtype(dtype).name}, got {a.dtype.name}")
+    if a.ndim != ndim:
+        raise ValueError(f"Buffer has wrong number of dimensions for {name} (expected {ndim}, got {a.ndim})")
+    return np.ascontiguousarray(a)
+
+
+def _csr(groups):
+    offs = np.zeros(len(groups) + 1, dtype=np.int64)
+    if len(groups):
+        offs[1:] = np.cumsum([len(g) for g in groups])
+    atoms = np.fromiter((a for g in groups for a in g), dtype=np.int32, count=int(offs[-1]))
+    return atoms, offs
+
+
+def _store(results, tmp):
+    if results.shape != tmp.shape:
+        raise ValueError(f"results must have shape {tmp.shape}, got {results.shape}")
+    results[...] = tmp
+
+
+def dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, results, ctx=None):
+    """distance_utils.pyx:126-155: ``results[f, idx] = |coords[sel1[i],:,f] - coords[sel2[j],:,f]|`` with the
+    orthorhombic minimum image across different chains when ``pbc``."""
+    coords = _req("coords", coords, np.float32, 3)
+    box = _req("box", box, np.float32, 2)
+    sel1 = _req("sel1", sel1, np.uint32, 1); sel2 = _req("sel2", sel2, np.uint32, 1)
+    chains = _req("digitized_chains", digitized_chains, np.uint32, 1)
+    _req("results", results, np.float32, 2)
+    ctx = ctx or _lib.default_context()
+    F = coords.shape[2]
+    npairs = int(_lib.load().mkamd_dist_count_pairs(len(sel1), len(sel2), int(bool(selfdist))))
+    tmp = np.zeros((F, npairs), dtype=np.float32)
+    ctx.dist_trajectory_host(coords, box, sel1, sel2, chains, bool(selfdist), bool(pbc), False, tmp)
+    _store(results, tmp)
+
+
+def _pair_atoms(sel1, sel2, selfdist):
+    n1, n2 = len(sel1), len(sel2)
+    if selfdist:
+        i, j = np.nonzero(np.arange(n2)[None, :] > np.arange(n1)[:, None])
+    else:
+        i, j = np.divmod(np.arange(n1 * n2), n2)
+    return sel1[i], sel2[j]
+
+
+def contacts_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, dist_threshold=5, ctx=None):
+    """distance_utils.pyx:59-93: per frame the flat list ``[a0, b0, a1, b1, ...]`` of atom pairs with
+    ``dist2 <= threshold^2`` (float32), in the reference's (i, j) loop order."""
+    coords = _req("coords", coords, np.float32, 3)
+    box = _req("box", box, np.float32, 2)
+    sel1 = _req("sel1", sel1, np.uint32, 1); sel2 = _req("sel2", sel2, np.uint32, 1)
+    chains = _req("digitized_chains", digitized_chains, np.uint32, 1)
+    ctx = ctx or _lib.default_context()
+    F = coords.shape[2]
+    npairs = int(_lib.load().mkamd_dist_count_pairs(len(sel1), len(sel2), int(bool(selfdist))))
+    d2 = np.zeros((F, npairs), dtype=np.float32)
+    ctx.dist_trajectory_host(coords, box, sel1, sel2, chains, bool(selfdist), bool(pbc), True, d2)
+    thr = np.float32(dist_threshold) * np.float32(dist_threshold)        # `float dist_threshold` squared in float
+    pa, pb = _pair_atoms(sel1, sel2, bool(selfdist))
+    out = []
+    for f in range(F):
+        hit = np.nonzero(d2[f] <= thr)[0]
+        flat = np.empty(2 * len(hit), dtype=np.int64)
+        flat[0::2] = pa[hit]; flat[1::2] = pb[hit]
+        out.append(flat.tolist())
+    return out
+
+
+def get_collisions(coords1, coords2, dist_threshold, ctx=None):
+    """distance_utils.pyx:98-121: flat ``[i0, j0, i1, j1, ...]`` (row indices) with dist2 <= threshold^2."""
+    c1 = _req("coords1", coords1, np.float32, 2); c2 = _req("coords2", coords2, np.float32, 2)
+    # squared distances in the reference's float32 order: reuse dist_trajectory on a one-frame pseudo trajectory
+    n1, n2 = c1.shape[0], c2.shape[0]
+    both = np.ascontiguousarray(np.concatenate([c1[:, :3], c2[:, :3]])[:, :, None])
+    sel1 = np.arange(n1, dtype=np.uint32); sel2 = np.arange(n1, n1 + n2, dtype=np.uint32)
+    d2 = np.zeros((1, n1 * n2), dtype=np.float32)
+    (ctx or _lib.default_context()).dist_trajectory_host(both, np.zeros((3, 1), np.float32), sel1, sel2,
+                                                         np.zeros(n1 + n2, np.uint32), False, False, True, d2)
+    thr = np.float32(dist_threshold) * np.float32(dist_threshold)
+    hit = np.nonzero(d2[0] <= thr)[0]
+    flat = np.empty(2 * len(hit), dtype=np.int64)
+    flat[0::2], flat[1::2] = np.divmod(hit, n2)
+    return flat.tolist()
+
+
+def _reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, results, ctx):
+    coords = _req("coords", coords, np.float32, 3)
+    box = _req("box", box, np.float32, 2)
+    ch1 = _req("digitized_chains1", ch1, np.uint32, 1); ch2 = _req("digitized_chains2", ch2, np.uint32, 1)
+    masses = _req("masses", masses, np.float32, 1)
+    _req("results", results, np.float32, 2)
+    a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)
+    ctx = ctx or _lib.default_context()
+    F = coords.shape[2]
+    nout = len(groups1) if pairs else int(_lib.load().mkamd_dist_count_pairs(len(groups1), len(groups2), int(bool(selfdist))))
+    tmp = np.zeros((F, nout), dtype=np.float32)
+    ctx.dist_reduction_host(coords, box, a1, o1, a2, o2, ch1, ch2, bool(selfdist), bool(pairs), bool(pbc), masses,
+                            int(r1), int(r2), tmp)
+    _store(results, tmp)
+    return results
+
+
+def dist_trajectory_reduction(coords, box, groups1, groups2, digitized_chains1, digitized_chains2, selfdist, pbc,
+                              masses, reduction1, reduction2, results, ctx=None):
+    """distance_utils.pyx:211-281: group-vs-group minimum ("closest", 0) or centre-of-mass (1) distances."""
+    return _reduction(coords, box, groups1, groups2, digitized_chains1, digitized_chains2, selfdist, False, pbc,
+                      masses, reduction1, reduction2, results, ctx)
+
+
+def dist_trajectory_reduction_pairs(coords, box, groups1, groups2, digitized_chains1, digitized_chains2, pbc, masses,
+                                    reduction1, reduction2, results, ctx=None):
+    """distance_utils.pyx:286-350: as above for the pairs (groups1[g], groups2[g])."""
+    return _reduction(coords, box, groups1, groups2, digitized_chains1, digitized_chains2, False, True, pbc, masses,
+                      reduction1, reduction2, results, ctx)
+
+
+def cdist(coords1, coords2, results, ctx=None):
+    """distance_utils.pyx:355-383."""
+    c1 = _req("coords1", coords1, np.float32, 2); c2 = _req("coords2", coords2, np.float32, 2)
+    _req("results", results, np.float32, 2)
+    if c1.shape[1] != c2.shape[1]:
+        raise ValueError("Second dimension of input arguments must match")
+    tmp = np.zeros((c1.shape[0], c2.shape[0]), dtype=np.float32)
+    (ctx or _lib.default_context()).cdist_host(c1, c2, tmp)
+    _store(results, tmp)
+
+
+def pdist(coords, results, ctx=None):
+    """distance_utils.pyx:388-416."""
+    c = _req("coords", coords, np.float32, 2)
+    _req("results", results, np.float32, 1)
+    n = c.shape[0]
+    tmp = np.zeros(n * (n - 1) // 2, dtype=np.float32)
+    (ctx or _lib.default_context()).pdist_host(c, tmp)
+    _store(results, tmp)
+
+
+def squareform(distances):
+    """distance_utils.pyx:421-434: condensed vector -> symmetric matrix (pure index work)."""
+    d = np.ascontiguousarray(distances, dtype=np.float32)
+    n = d.shape[0]
+    newdim = int((np.sqrt(8 * n + 1) + 1) / 2)
+    out = np.zeros((newdim, newdim), dtype=np.float32)
+    iu = np.triu_indices(newdim, k=1)
+    out[iu] = d[: len(iu[0])]
+    out[(iu[1], iu[0])] = d[: len(iu[0])]
+    return out

@@ -4,6 +4,7 @@
 // source, host memory instead of HBM.  Built into tests/emu/libmkamd_emu.so by tests/emu_build.py.
 #include "emu_device.h"
 #include "../../moleculekit_amd/csrc/pipeline.h"
+#include "../../moleculekit_amd/csrc/dist_pipeline.h"
 
 #include <string>
 
@@ -109,6 +110,35 @@ int emu_plan(int B, long long total_atoms, int C, const int* nvox, double voxels
     const int v[16] = {g.K, g.tnx, g.tny, g.tnz, g.ntiles, g.cs, g.h, g.ncx, g.ncy, g.ncz, g.ncell, g.rint, g.G, (int)g.M, 0, 0};
     memcpy(out_ints, v, sizeof v);
     return 0;
+}
+
+// ---- distance_utils row: same launch sequences on host memory ----
+int emu_dist_trajectory(const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
+                        const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
+                        float* out)
+{
+    EmuBackend be;
+    return run_dist_trajectory(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, squared, out, g_err);
+}
+
+int emu_dist_reduction(const float* coords, long long F, const float* box, const int* g1a, const long long* g1o, long long ng1,
+                       const int* g2a, const long long* g2o, long long ng2, const unsigned* ch1, const unsigned* ch2,
+                       int selfdist, int pairs, int pbc, const float* masses, int r1, int r2, float* out)
+{
+    EmuBackend be;
+    return run_dist_reduction(be, coords, F, box, g1a, g1o, ng1, g2a, g2o, ng2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out, g_err);
+}
+
+int emu_cdist(const float* c1, long long n1, const float* c2, long long n2, int D, float* out)
+{
+    EmuBackend be;
+    return run_cdist(be, c1, n1, c2, n2, D, out, g_err);
+}
+
+int emu_pdist(const float* c, long long n, int D, float* out)
+{
+    EmuBackend be;
+    return run_pdist(be, c, n, D, out, g_err);
 }
 
 }  // extern "C"

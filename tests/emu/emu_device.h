@@ -218,6 +218,11 @@ MK_DEV unsigned mk_shfl_down(unsigned v, int delta)
 }
 MK_DEV double mk_dmul_rn(double a, double b) { volatile double r = a * b; return r; }
 MK_DEV double mk_dadd_rn(double a, double b) { volatile double r = a + b; return r; }
+MK_DEV float mk_fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+MK_DEV float mk_fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+MK_DEV float mk_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+MK_DEV float mk_fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+MK_DEV float mk_fsqrt_rn(float a) { return sqrtf(a); }
 MK_DEV float mk_int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 MK_DEV int mk_float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 

@@ -21,7 +21,8 @@ _lib = None
 
 def build(force=False):
     srcs = [os.path.join(_EMU, "emu_capi.cpp"), os.path.join(_EMU, "emu_device.h"),
-            os.path.join(_CSRC, "kernels.h"), os.path.join(_CSRC, "pipeline.h")]
+            os.path.join(_CSRC, "kernels.h"), os.path.join(_CSRC, "pipeline.h"),
+            os.path.join(_CSRC, "dist_kernels.h"), os.path.join(_CSRC, "dist_pipeline.h")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         subprocess.check_call(
@@ -108,3 +109,57 @@ def plan(B, total_atoms, C, nvox, voxelsize, pbc=0, max_images=1, tile_k=0):
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     keys = ["K", "tnx", "tny", "tnz", "ntiles", "cs", "h", "ncx", "ncy", "ncz", "ncell", "rint", "G", "M"]
     return dict(zip(keys, out.tolist()))
+
+
+# ---- distance_utils row ---------------------------------------------------------------------------
+def _csr(groups):
+    offs = np.zeros(len(groups) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(g) for g in groups])
+    return np.array([a for g in groups for a in g], dtype=np.int32), offs
+
+
+def _npairs(n1, n2, selfdist):
+    return sum(max(n2 - 1 - i, 0) for i in range(n1)) if selfdist else n1 * n2
+
+
+def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=False):
+    coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
+    sel1 = np.ascontiguousarray(sel1, np.uint32); sel2 = np.ascontiguousarray(sel2, np.uint32)
+    chains = np.ascontiguousarray(chains, np.uint32)
+    F = coords.shape[2]
+    out = np.full((F, _npairs(len(sel1), len(sel2), selfdist)), -7.0, np.float32)
+    st = lib().emu_dist_trajectory(_p(coords), ctypes.c_longlong(F), _p(box), _p(sel1), ctypes.c_longlong(len(sel1)), _p(sel2),
+                                   ctypes.c_longlong(len(sel2)), _p(chains), ctypes.c_int(int(selfdist)), ctypes.c_int(int(pbc)),
+                                   ctypes.c_int(int(squared)), _p(out))
+    assert st == 0, lib().emu_last_error()
+    return out
+
+
+def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masses, r1, r2, pairs=False):
+    coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
+    a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)
+    ch1 = np.ascontiguousarray(ch1, np.uint32); ch2 = np.ascontiguousarray(ch2, np.uint32)
+    masses = np.ascontiguousarray(masses, np.float32)
+    F = coords.shape[2]
+    nout = len(groups1) if pairs else _npairs(len(groups1), len(groups2), selfdist)
+    out = np.full((F, nout), -7.0, np.float32)
+    st = lib().emu_dist_reduction(_p(coords), ctypes.c_longlong(F), _p(box), _p(a1), _p(o1), ctypes.c_longlong(len(groups1)),
+                                  _p(a2), _p(o2), ctypes.c_longlong(len(groups2)), _p(ch1), _p(ch2), ctypes.c_int(int(selfdist)),
+                                  ctypes.c_int(int(pairs)), ctypes.c_int(int(pbc)), _p(masses), ctypes.c_int(r1), ctypes.c_int(r2), _p(out))
+    assert st == 0, lib().emu_last_error()
+    return out
+
+
+def cdist(c1, c2):
+    c1 = np.ascontiguousarray(c1, np.float32); c2 = np.ascontiguousarray(c2, np.float32)
+    out = np.full((c1.shape[0], c2.shape[0]), -7.0, np.float32)
+    assert lib().emu_cdist(_p(c1), ctypes.c_longlong(c1.shape[0]), _p(c2), ctypes.c_longlong(c2.shape[0]), ctypes.c_int(c1.shape[1]), _p(out)) == 0
+    return out
+
+
+def pdist(c):
+    c = np.ascontiguousarray(c, np.float32)
+    n = c.shape[0]
+    out = np.full(n * (n - 1) // 2, -7.0, np.float32)
+    assert lib().emu_pdist(_p(c), ctypes.c_longlong(n), ctypes.c_int(c.shape[1]), _p(out)) == 0
+    return out

@@ -12,7 +12,7 @@ HEADER = os.path.join(ROOT, "include", "mkamd_voxel.h")
 
 
 def declared_symbols():
-    text = open(HEADER).read()
+    text = open(HEADER).read() + open(os.path.join(ROOT, "include", "mkamd_distance.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mkamd_[a-z0-9_]+)\s*\(", text)))
 

@@ -1,0 +1,93 @@
+"""CPU tier, distance_utils row: the float32 oracle (oracle/distance_oracle.c) and the
+emulated HIP kernels (csrc/dist_kernels.h through tests/emu) against outputs of the REAL reference's compiled
+distance_utils (tests/golden/distance_cases.npz) -- all comparisons are bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import emu_build as E
+from tests.cases import golden
+
+
+@pytest.fixture(scope="module")
+def g():
+    return golden("distance_cases.npz")
+
+
+def _groups(g):
+    return [list(x) for x in g["groups1"]], [list(x) for x in g["groups2"]]
+
+
+@pytest.mark.parametrize("impl", ["oracle", "emu"])
+def test_dist_trajectory_bit_exact(g, impl):
+    f = oracle.dist_trajectory if impl == "oracle" else E.dist_trajectory
+    c, b, ch = g["coords"], g["box"], g["chains"]
+    for pbc in (0, 1):
+        assert np.array_equal(f(c, b, g["sel1"], g["sel2"], ch, False, pbc), g[f"dist_cross_pbc{pbc}"])
+        assert np.array_equal(f(c, b, g["sel2"], g["sel2"], ch, True, pbc), g[f"dist_self_pbc{pbc}"])
+    assert np.array_equal(f(c, np.zeros_like(b), g["sel1"], g["sel2"], np.zeros(len(ch), np.uint32), False, False),
+                          g["dist_cross_zero_box"])
+
+
+@pytest.mark.parametrize("impl", ["oracle", "emu"])
+def test_reductions_bit_exact(g, impl):
+    f = oracle.dist_trajectory_reduction if impl == "oracle" else E.dist_reduction
+    c, b, m = g["coords"], g["box"], g["masses"]
+    g1, g2 = _groups(g)
+    for r1 in (0, 1):
+        for r2 in (0, 1):
+            for pbc in (0, 1):
+                got = f(c, b, g1, g2, g["gchains1"], g["gchains2"], False, pbc, m, r1, r2)
+                assert np.array_equal(got, g[f"red_{r1}{r2}_pbc{pbc}"]), (r1, r2, pbc)
+    assert np.array_equal(f(c, b, g2, g2, g["gchains2"], g["gchains2"], True, True, m, 0, 0), g["red_self"])
+    assert np.array_equal(f(c, b, g1, g2[:5], g["gchains1"], g["gchains2"][:5], False, True, m, 0, 1, pairs=True),
+                          g["red_pairs"])
+
+
+@pytest.mark.parametrize("impl", ["oracle", "emu"])
+def test_cdist_pdist_bit_exact(g, impl):
+    cd, pd = (oracle.cdist, oracle.pdist) if impl == "oracle" else (E.cdist, E.pdist)
+    for D in (1, 2, 3, 5):
+        assert np.array_equal(cd(g[f"cdist_a{D}"], g[f"cdist_b{D}"]), g[f"cdist_r{D}"])
+        assert np.array_equal(pd(g[f"cdist_b{D}"]), g[f"pdist_r{D}"])
+
+
+def test_contacts_from_squared_distances_match_reference_lists(g):
+    """contacts_trajectory (distance_utils.pyx:59-93) == threshold on the squared distances, in loop order."""
+    c, b, ch = g["coords"], g["box"], g["chains"]
+    d2 = E.dist_trajectory(c, b, g["sel1"], g["sel2"], ch, False, True, squared=True)
+    thr = np.float32(12.0) * np.float32(12.0)
+    flat, counts = [], []
+    n2 = len(g["sel2"])
+    for f in range(d2.shape[0]):
+        hit = np.nonzero(d2[f] <= thr)[0]
+        i, j = np.divmod(hit, n2)
+        counts.append(len(hit))
+        flat.extend(np.stack([g["sel1"][i], g["sel2"][j]], 1).ravel().tolist())
+    assert np.array_equal(counts, g["contacts_counts"]) and np.array_equal(flat, g["contacts_flat"])
+
+
+def test_squareform_and_known_answers():
+    """The reference's own known-answer tests (tests/test_distance.py:1-28) on the oracle + host squareform."""
+    from moleculekit_amd.distance_utils import squareform
+    g = golden("distance_cases.npz")
+    assert np.array_equal(squareform(g["pdist_r3"]), g["squareform"])
+    x = np.array([0, 1, 2], np.float32)[:, None]; y = np.array([3, 4, 5], np.float32)[:, None]
+    assert np.allclose(oracle.cdist(x, y), [[3, 4, 5], [2, 3, 4], [1, 2, 3]])
+    assert np.allclose(oracle.pdist(np.array([[4, 5], [6, 7], [8, 9]], np.float32)), [2.828427, 5.656854, 2.828427])
+
+
+def test_emu_larger_random_case_matches_oracle():
+    """Tile edges (frames / pairs not multiples of 64), self pairs with n1 != n2, NaN from a zero box."""
+    rng = np.random.default_rng(3)
+    N, F = 150, 70
+    c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(15, 25, size=(3, F)).astype(np.float32)
+    b[:, 5] = 0.0                                           # pbc with a zero box -> NaN, like the reference
+    ch = rng.integers(0, 3, size=N).astype(np.uint32)
+    s1 = np.arange(0, 90, dtype=np.uint32); s2 = np.arange(40, 150, dtype=np.uint32)
+    for selfd, a, bb in ((False, s1, s2), (True, s2, s2), (True, s1[:7], s2[:20])):
+        got = E.dist_trajectory(c, b, a, bb, ch, selfd, True)
+        exp = oracle.dist_trajectory(c, b, a, bb, ch, selfd, True)
+        assert np.array_equal(got, exp, equal_nan=True)
+        assert np.isnan(exp[5]).any()

@@ -1,0 +1,124 @@
+"""GPU tier (-m gpu), distance_utils row: every function through the C ABI on the MI355X, bit-exact against the
+real reference's outputs (tests/golden/distance_cases.npz) and against the oracle at larger sizes."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.cases import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    return golden("distance_cases.npz")
+
+
+def test_dist_trajectory_bit_exact(g):
+    from moleculekit_amd.distance_utils import dist_trajectory
+    c, b, ch = g["coords"], g["box"], g["chains"]
+    for pbc in (0, 1):
+        r = np.zeros_like(g[f"dist_cross_pbc{pbc}"])
+        assert dist_trajectory(c, b, g["sel1"], g["sel2"], ch, False, bool(pbc), r) is None
+        assert np.array_equal(r, g[f"dist_cross_pbc{pbc}"])
+        r = np.zeros_like(g[f"dist_self_pbc{pbc}"])
+        dist_trajectory(c, b, g["sel2"], g["sel2"], ch, True, bool(pbc), r)
+        assert np.array_equal(r, g[f"dist_self_pbc{pbc}"])
+
+
+def test_contacts_and_collisions_match_reference_lists(g):
+    from moleculekit_amd.distance_utils import contacts_trajectory, get_collisions
+    c, b, ch = g["coords"], g["box"], g["chains"]
+    res = contacts_trajectory(c, b, g["sel1"], g["sel2"], ch, False, True, 12.0)
+    assert np.array_equal([len(x) // 2 for x in res], g["contacts_counts"])
+    assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_flat"])
+    res = contacts_trajectory(c, b, g["sel2"], g["sel2"], ch, True, False, 15.0)
+    assert np.array_equal([len(x) // 2 for x in res], g["contacts_self_counts"])
+    assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_self_flat"])
+    col = get_collisions(np.ascontiguousarray(c[:20, :, 0]), np.ascontiguousarray(c[20:50, :, 0]), 14.0)
+    assert np.array_equal(col, g["collisions"])
+
+
+def test_reductions_bit_exact(g):
+    from moleculekit_amd.distance_utils import dist_trajectory_reduction, dist_trajectory_reduction_pairs
+    c, b, m = g["coords"], g["box"], g["masses"]
+    g1 = [list(x) for x in g["groups1"]]; g2 = [list(x) for x in g["groups2"]]
+    for r1 in (0, 1):
+        for r2 in (0, 1):
+            for pbc in (0, 1):
+                r = np.zeros_like(g[f"red_{r1}{r2}_pbc{pbc}"])
+                dist_trajectory_reduction(c, b, g1, g2, g["gchains1"], g["gchains2"], False, bool(pbc), m, r1, r2, r)
+                assert np.array_equal(r, g[f"red_{r1}{r2}_pbc{pbc}"]), (r1, r2, pbc)
+    r = np.zeros_like(g["red_self"])
+    dist_trajectory_reduction(c, b, g2, g2, g["gchains2"], g["gchains2"], True, True, m, 0, 0, r)
+    assert np.array_equal(r, g["red_self"])
+    r = np.zeros_like(g["red_pairs"])
+    dist_trajectory_reduction_pairs(c, b, g1, g2[:5], g["gchains1"], g["gchains2"][:5], True, m, 0, 1, r)
+    assert np.array_equal(r, g["red_pairs"])
+
+
+def test_cdist_pdist_squareform_like_reference_tests(g):
+    """tests/test_distance.py:1-28 (known answers) + bit-exact golden in 1, 2, 3 and 5 dimensions."""
+    from moleculekit_amd.distance import cdist, pdist, squareform
+    x = np.array([0, 1, 2])[:, None]; y = np.array([3, 4, 5])[:, None]
+    assert np.allclose(cdist(x, y), [[3.0, 4.0, 5.0], [2.0, 3.0, 4.0], [1.0, 2.0, 3.0]])
+    assert np.allclose(cdist(np.array([[0, 1], [2, 3]]), np.array([[4, 5], [6, 7], [8, 9]])),
+                       [[5.656854, 8.485281, 11.313708], [2.828427, 5.656854, 8.485281]])
+    assert np.allclose(pdist(np.array([[4, 5], [6, 7], [8, 9]])), [2.828427, 5.656854, 2.828427])
+    for D in (1, 2, 3, 5):
+        assert np.array_equal(cdist(g[f"cdist_a{D}"], g[f"cdist_b{D}"]), g[f"cdist_r{D}"])
+        assert np.array_equal(pdist(g[f"cdist_b{D}"]), g[f"pdist_r{D}"])
+    assert np.array_equal(squareform(g["pdist_r3"]), g["squareform"])
+
+
+def test_trajectory_scale_against_oracle():
+    """A cfg4-flavoured trajectory slice: 2000 atoms x 300 frames, 120 x 150 atom pairs, periodic by chain;
+    tile edges in both directions; bit-exact against the oracle."""
+    from moleculekit_amd.distance_utils import dist_trajectory
+    rng = np.random.default_rng(17)
+    N, F = 2000, 300
+    c = rng.uniform(0, 66.9, size=(N, 3, F)).astype(np.float32)
+    b = np.full((3, F), 66.9, np.float32)
+    ch = (np.arange(N) // 250).astype(np.uint32)
+    s1 = np.sort(rng.choice(N, 120, replace=False)).astype(np.uint32)
+    s2 = np.sort(rng.choice(N, 150, replace=False)).astype(np.uint32)
+    r = np.zeros((F, 120 * 150), np.float32)
+    dist_trajectory(c, b, s1, s2, ch, False, True, r)
+    assert np.array_equal(r, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
+    diff = ch[s1][:, None] != ch[s2][None, :]                 # minimum image only across chains (:49)
+    assert r.reshape(F, 120, 150)[:, diff].max() <= np.sqrt(3) * 66.9 / 2 + 1e-3
+    r2 = np.zeros((F, 150 * 149 // 2), np.float32)
+    dist_trajectory(c, b, s2, s2, ch, True, True, r2)
+    assert np.array_equal(r2, oracle.dist_trajectory(c, b, s2, s2, ch, True, True))
+
+
+def test_metricdistance_style_drivers():
+    """pp_calcDistances / get_reduced_distances / calculate_contacts (projections/util.py, distance.py) on a duck-typed
+    molecule, incl. the analytic 2 A-box case in the spirit of tests/test_metricdistance.py:99-135."""
+    from moleculekit_amd.distance import calculate_contacts, get_reduced_distances, pp_calcDistances
+
+    class M:
+        pass
+    m = M()
+    m.coords = np.zeros((4, 3, 2), np.float32)
+    m.coords[1, 0, :] = 1.5; m.coords[2, 1, :] = 0.5; m.coords[3, 2, 1] = 1.75
+    m.box = np.full((3, 2), 2.0, np.float32)
+    m.chain = np.array(["A", "B", "B", "C"]); m.element = np.array(["C", "N", "O", "C"])
+    m.numAtoms, m.numFrames = 4, 2
+    s1 = np.array([True, False, False, False]); s2 = np.array([False, True, True, True])
+    d = pp_calcDistances(m, s1, s2, None)
+    assert np.allclose(d, [[1.5, 0.5, 0.0], [1.5, 0.5, 1.75]])
+    d = pp_calcDistances(m, s1, s2, "chains")
+    assert np.allclose(d, [[0.5, 0.5, 0.0], [0.5, 0.5, 0.25]])
+    assert pp_calcDistances(m, s1, s2, "selections", metric="contacts", threshold=0.4).tolist() == [[False, False, True], [False, False, True]]
+    red = get_reduced_distances(m, s1, np.array([[False, True, True, False], [False, False, False, True]]), "chains")
+    assert np.allclose(red, [[0.5, 0.0], [0.5, 0.25]])
+    com = get_reduced_distances(m, s1, np.array([[False, True, True, False]]), None, reduction2="com")
+    w = np.array([14.0067, 15.9994], np.float32)
+    cx, cy = 1.5 * w[0] / w.sum(), 0.5 * w[1] / w.sum()
+    assert np.allclose(com, np.sqrt(cx * cx + cy * cy), atol=1e-6)
+    con = calculate_contacts(m, s1, s2, "chains", threshold=0.3)
+    assert [c.tolist() for c in con] == [[[0, 3]], [[0, 3]]]
+    with pytest.raises(RuntimeError):
+        m.box = np.zeros((3, 2), np.float32)
+        pp_calcDistances(m, s1, s2, "chains")
