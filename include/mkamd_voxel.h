@@ -50,8 +50,8 @@ int mkamd_device_count(int* count);
  * workspace (cell lists, staging buffers) and a HIP stream. */
 int mkamd_ctx_create(int device, mkamd_ctx** ctx);
 int mkamd_ctx_destroy(mkamd_ctx* ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
- * the context's own stream. */
+/* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is the legacy
+ * default stream (a valid choice); (void*)-1 restores the context's own stream. */
 int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream);
 /* Wait for the stream and report asynchronous errors of "_dev" calls (MKAMD_EOVERFLOW/EBOX). */
 int mkamd_ctx_synchronize(mkamd_ctx* ctx);

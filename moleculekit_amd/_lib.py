@@ -138,7 +138,9 @@ class Context:
 
     # -- control -----------------------------------------------------------------------------
     def set_stream(self, hip_stream):
-        _check(load().mkamd_ctx_set_stream(self._h, _vp(int(hip_stream) if hip_stream else None)))
+        """hip_stream: integer handle of a hipStream_t (0 = the legacy default stream); None = the context's own stream."""
+        h = _vp(-1 & 0xFFFFFFFFFFFFFFFF) if hip_stream is None else _vp(int(hip_stream))
+        _check(load().mkamd_ctx_set_stream(self._h, h))
 
     def synchronize(self):
         _check(load().mkamd_ctx_synchronize(self._h))

@@ -249,7 +249,9 @@ int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream)
 {
     int st = check_ctx(ctx);
     if (st) return st;
-    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    // NULL is a real stream (the legacy default stream, which is what torch.cuda.current_stream() usually is);
+    // (void*)-1 selects the context's own stream again
+    hipStream_t next = hip_stream == (void*)-1 ? ctx->own_stream : (hipStream_t)hip_stream;
     if (next == ctx->main_stream) return MKAMD_OK;
     HIP_TRY(hipStreamSynchronize(ctx->main_stream)); // workspace is shared between the streams
     if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));

@@ -85,18 +85,49 @@ MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long l
 }
 
 // dist_trajectory (distance_utils.pyx:126-155): results[f, p] = sqrt(_dist(...)) (or the square).
+// Lanes run along frames, so the atom indices of a pair are wave-uniform: pairs are visited in the reference's
+// i-major order and the first atom's coordinates (and the frame's box) stay in registers while i does not
+// change -- 3 instead of 6 coordinate loads per distance, the loads being what bounds this kernel (L1/L2).
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
                                         const float* __restrict__ box, const unsigned* __restrict__ pa,
                                         const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
                                         long long P, int squared, float* __restrict__ out)
 {
-    tile_frames_to_pairs(F, P, out, [&](long long f, long long p) {
-        const size_t a = pa[p], b = pb[p];
-        const float d2 = dist2_min_image_f32(coords[(a * 3 + 0) * F + f], coords[(a * 3 + 1) * F + f], coords[(a * 3 + 2) * F + f],
-                                             coords[(b * 3 + 0) * F + f], coords[(b * 3 + 1) * F + f], coords[(b * 3 + 2) * F + f],
-                                             box[0 * F + f], box[1 * F + f], box[2 * F + f], wrap[p] != 0u);
-        return squared ? d2 : mk_fsqrt_rn(d2);
-    });
+    __shared__ float tile[DT][DT + 1];
+    const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
+    {
+        const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
+        const long long f = f0 + fl;
+        const bool fin = f < F;
+        const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
+        unsigned cur_a = 0xffffffffu;
+        float xa = 0.f, ya = 0.f, za = 0.f;
+        // this wave takes 16 CONSECUTIVE pairs of the tile (they mostly share the first atom)
+        for (int k = 0; k < DT / (DT_THREADS / DT); ++k) {
+            const int pp = pq * (DT / (DT_THREADS / DT)) + k;
+            const long long p = p0 + pp;
+            if (p >= P) break;                                     // wave-uniform
+            const unsigned a = pa[p], b = pb[p];
+            if (a != cur_a) {                                      // wave-uniform
+                cur_a = a;
+                if (fin) { xa = coords[((size_t)a * 3 + 0) * F + f]; ya = coords[((size_t)a * 3 + 1) * F + f]; za = coords[((size_t)a * 3 + 2) * F + f]; }
+            }
+            if (fin) {
+                const float d2 = dist2_min_image_f32(xa, ya, za, coords[((size_t)b * 3 + 0) * F + f], coords[((size_t)b * 3 + 1) * F + f],
+                                                     coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, wrap[p] != 0u);
+                tile[pp][fl] = squared ? d2 : mk_fsqrt_rn(d2);
+            }
+        }
+    }
+    mk_block_sync();
+    {
+        const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
+        const long long p = p0 + pl;
+        for (int ff = fq; ff < DT; ff += DT_THREADS / DT) {
+            const long long f = f0 + ff;
+            if (f < F && p < P) out[f * P + p] = tile[pl][ff];
+        }
+    }
 }
 
 // Centre of mass of every group in every frame (distance_utils.pyx:160-183): sequential float32
