@@ -122,6 +122,16 @@ int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_c
                                const float* d_box, int32_t max_images_per_atom,
                                float* d_features);
 
+/* (3b) the same with a fused per-item rigid transform (data augmentation): affine float64 [B,12] = row-major
+ * 3x3 matrix M followed by a translation t; every atom of item b is voxelized at float32(M x + t) -- what
+ * `rotateCoordinates` (voxeldescriptors.py:78-114) followed by getVoxelDescriptors(usercoords=...) computes. NULL = none. */
+int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_coords,
+                                   const int64_t* d_atom_offsets, int64_t total_atoms,
+                                   const void* d_sigmas, int sigmas_are_f64, int32_t n_channels,
+                                   const double* d_origins, const int32_t* nvoxels, double voxelsize,
+                                   const float* d_box, int32_t max_images_per_atom,
+                                   const double* d_affine, float* d_features);
+
 /* (4) lattice centres (voxeldescriptors.py:125-132 + :245-247), float64 [V,3], bit-exact with the
  * reference's numpy arithmetic: centre = fl64(index*voxelsize) + bb_min. */
 int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels,

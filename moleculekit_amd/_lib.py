@@ -42,6 +42,8 @@ SIGNATURES = {
                                              _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
                                             _c_dbl, _vp, _c_i32, _vp]),
+    "mkamd_voxelize_lattice_aug_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
+                                                _c_dbl, _vp, _c_i32, _vp, _vp]),
     "mkamd_grid_centers_host": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
     "mkamd_grid_centers_dev": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
     # include/mkamd_distance.h
@@ -193,10 +195,11 @@ class Context:
                                                   _ptr(box), int(max_images), _ptr(out)))
 
     def voxelize_lattice_dev(self, B, d_coords, d_offsets, total_atoms, d_sigmas, sig_f64, C, d_origins, nvox,
-                             voxelsize, d_box, max_images, d_out):
-        _check(load().mkamd_voxelize_lattice_dev(self._h, B, _ptr(d_coords), _ptr(d_offsets), int(total_atoms),
-                                                 _ptr(d_sigmas), int(sig_f64), C, _ptr(d_origins), _ptr(nvox),
-                                                 float(voxelsize), _ptr(d_box), int(max_images), _ptr(d_out)))
+                             voxelsize, d_box, max_images, d_out, d_affine=None):
+        _check(load().mkamd_voxelize_lattice_aug_dev(self._h, B, _ptr(d_coords), _ptr(d_offsets), int(total_atoms),
+                                                     _ptr(d_sigmas), int(sig_f64), C, _ptr(d_origins), _ptr(nvox),
+                                                     float(voxelsize), _ptr(d_box), int(max_images), _ptr(d_affine),
+                                                     _ptr(d_out)))
 
     def grid_centers_host(self, bb_min, nvox, voxelsize, out):
         _check(load().mkamd_grid_centers_host(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(out)))

@@ -112,13 +112,30 @@ def grid_centers(bb_min, nvoxels, voxelsize, ctx=None):
 # ------------------------------------------------------------------------------------------------
 # device-resident flavour (torch tensors are only containers for HBM pointers)
 # ------------------------------------------------------------------------------------------------
+def rotation_affines(rotations, centers):
+    """float64 [B,12] rigid transforms equal to ``rotateCoordinates(coords, rotations[b], centers[b])``
+    (voxeldescriptors.py:78-114: rotations about x, then y, then z around ``center``): row-major 3x3 matrix,
+    then the translation."""
+    from .util import rotationMatrix
+    rotations = np.asarray(rotations, dtype=np.float64).reshape(-1, 3)
+    centers = np.broadcast_to(np.asarray(centers, dtype=np.float64).reshape(-1, 3), rotations.shape)
+    out = np.empty((rotations.shape[0], 12), dtype=np.float64)
+    for b, (r, c) in enumerate(zip(rotations, centers)):
+        m = rotationMatrix([0, 0, 1], r[2]) @ rotationMatrix([0, 1, 0], r[1]) @ rotationMatrix([1, 0, 0], r[0])
+        out[b, :9] = m.ravel()
+        out[b, 9:] = c - m @ c
+    return out
+
+
 def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None,
-                           max_images=1, out=None, ctx=None, channel_first=False):
+                           max_images=1, out=None, ctx=None, channel_first=False, affine=None):
     """Same as ``voxelize_lattice`` on torch CUDA tensors; asynchronous on torch's current stream.
 
     coords float32 [sumN,3], atom_offsets int64 [B+1], sigmas float32|float64 [sumN,C],
     origins float64 [B,3], box float32 [B,3] or None (pass ``max_images`` from
     ``max_images_per_atom`` when the box is smaller than grid + 10 A).
+    ``affine``: optional float64 [B,12] CUDA tensor of per-item rigid transforms (``rotation_affines``) fused into
+    the binning stage -- on-device augmentation, nothing leaves HBM.
     Returns float32 [B,V,C] on the same device (or [B,C,nx,ny,nz] when ``channel_first``).
     """
     import torch
@@ -143,10 +160,14 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     if box is not None:
         assert box.dtype == torch.float32 and box.is_contiguous()
         d_box = box.data_ptr()
+    d_aff = None
+    if affine is not None:
+        assert affine.dtype == torch.float64 and affine.is_contiguous() and tuple(affine.shape) == (B, 12)
+        d_aff = affine.data_ptr()
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     ctx.voxelize_lattice_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]),
                              sigmas.data_ptr(), sigmas.dtype == torch.float64, C, origins.data_ptr(), nv,
-                             float(voxelsize), d_box, int(max_images), out.data_ptr())
+                             float(voxelsize), d_box, int(max_images), out.data_ptr(), d_aff)
     out = out.view(B, V, C)
     if channel_first:   # what the reference's tutorial builds by hand before nn.Conv3d
         return out.view(B, int(nv[0]), int(nv[1]), int(nv[2]), C).permute(0, 4, 1, 2, 3)

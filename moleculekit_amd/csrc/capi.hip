@@ -407,6 +407,16 @@ int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
                                const int32_t* nvoxels, double voxelsize, const float* d_box,
                                int32_t max_images, float* d_features)
 {
+    return mkamd_voxelize_lattice_aug_dev(ctx, B, d_coords, d_atom_offsets, total_atoms, d_sigmas, sigmas_are_f64, C,
+                                          d_origins, nvoxels, voxelsize, d_box, max_images, nullptr, d_features);
+}
+
+int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
+                                   const int64_t* d_atom_offsets, int64_t total_atoms, const void* d_sigmas,
+                                   int sigmas_are_f64, int32_t C, const double* d_origins,
+                                   const int32_t* nvoxels, double voxelsize, const float* d_box,
+                                   int32_t max_images, const double* d_affine, float* d_features)
+{
     int st = check_ctx(ctx);
     if (st) return st;
     if (!nvoxels) return fail(MKAMD_EINVAL, "nvoxels pointer is NULL");
@@ -419,7 +429,7 @@ int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
     P.tile_k = ctx->tile_k; P.force_general = ctx->force_general;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
-    P.origins = d_origins; P.box = d_box; P.out = d_features;
+    P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;
     st = run_lattice(*ctx, P, err);
     if (st && !err.empty()) return fail(st, err);

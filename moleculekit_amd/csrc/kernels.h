@@ -219,7 +219,8 @@ template <typename SigT>
 MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 const long long* __restrict__ atom_offsets, long long total_atoms,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
-                                const float* __restrict__ box, unsigned* __restrict__ cell_count,
+                                const float* __restrict__ box, const double* __restrict__ affine,
+                                unsigned* __restrict__ cell_count,
                                 float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
                                 unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
 {
@@ -267,9 +268,19 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
             }
             b = lo;
             const int nvox[3] = {g.nx, g.ny, g.nz};
+            // fused augmentation (tools/voxeldescriptors.py:78-114 rotateCoordinates, then the astype(float32) of
+            // _getOccupancyC :519): x' = M x + t in double, rounded to float32 like the reference pipeline does
+            float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
+            if (affine != nullptr) {
+                const double* A = affine + 12 * (size_t)b;
+                const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+                xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+                xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+                xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+            }
 #pragma unroll
             for (int ax = 0; ax < 3; ++ax) {
-                p[ax] = ((double)coords[3 * a + ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+                p[ax] = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
                 if (g.pbc) {
                     const double L = (double)box[3 * (size_t)b + ax] * g.inv_res;
                     if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); drop = true; }

@@ -57,6 +57,7 @@ struct LatticeProblem {
     const void* sigmas = nullptr;
     const double* origins = nullptr;
     const float* box = nullptr;
+    const double* affine = nullptr;        // optional [B,12]: rotation (row-major 3x3) + translation per item
     float* out = nullptr;
 };
 
@@ -190,9 +191,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
     if (P.total_atoms > 0) {
         st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
-                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag)
+                                      P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag)
                           : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
-                                      P.origins, P.box, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
+                                      P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
         if (st) return st;
     }
     if (P.total_atoms > 0 && !g.force_general) {                      // per-block sigma sets -> class table

@@ -53,7 +53,8 @@ const char* emu_last_error(void) { return g_err.c_str(); }
 // mirrors mkamd_voxelize_lattice_host (pointers are host pointers; features is poisoned first)
 int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offsets, const void* sigmas,
                          int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
-                         const float* box, int max_images, int tile_k, int force_general, float* features, int* err_flag_out)
+                         const float* box, int max_images, int tile_k, int force_general, const double* affine, float* features,
+                         int* err_flag_out)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -69,7 +70,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     }
     P.max_images = box ? max_images : 1;
     P.coords = coords; P.atom_offsets = atom_offsets; P.sigmas = sigmas; P.origins = origins;
-    P.box = box; P.out = features;
+    P.box = box; P.affine = affine; P.out = features;
     const size_t nout = (size_t)B * nvox[0] * nvox[1] * nvox[2] * C;
     for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;
     const int st = run_lattice(be, P, g_err);

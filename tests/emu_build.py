@@ -46,7 +46,7 @@ def _p(a):
 
 
 def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box=None, max_images=0,
-                     tile_k=0, force_general=False):
+                     tile_k=0, force_general=False, affine=None):
     coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
     atom_offsets = np.ascontiguousarray(atom_offsets, np.int64)
     sig64 = sigmas.dtype == np.float64
@@ -61,7 +61,8 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
     st = lib().emu_voxelize_lattice(
         ctypes.c_int(B), _p(coords), _p(atom_offsets), _p(sigmas), ctypes.c_int(int(sig64)), ctypes.c_int(C),
         _p(origins), _p(nvox), ctypes.c_double(voxelsize), _p(bx), ctypes.c_int(max_images),
-        ctypes.c_int(tile_k), ctypes.c_int(int(force_general)), _p(out), ctypes.byref(err))
+        ctypes.c_int(tile_k), ctypes.c_int(int(force_general)),
+        _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out), ctypes.byref(err))
     if st != 0:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return out, err.value

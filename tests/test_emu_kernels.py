@@ -130,3 +130,27 @@ def test_tile_denser_than_lds_capacity_falls_back_per_tile():
     got, err = E.voxelize_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0, tile_k=8)
     assert err == 0
     check(case, got)
+
+
+def test_fused_rotation_matches_rotate_then_voxelize():
+    """rotateCoordinates (voxeldescriptors.py:78-114) fused into the binning stage == rotating on the
+    host (golden-checked host function), casting to float32 (:519) and voxelizing."""
+    from moleculekit_amd.batch import rotation_affines
+    from moleculekit_amd.voxeldescriptors import rotateCoordinates
+    case = LATTICE_CASES["cfg3_small"]()
+    B = len(case["atom_offsets"]) - 1
+    rng = np.random.default_rng(41)
+    rots = rng.uniform(-np.pi, np.pi, size=(B, 3))
+    cens = case["origins"] + 12.0
+    fused, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                    case["voxelsize"], affine=rotation_affines(rots, cens))
+    rc = case["coords"].copy()
+    for b in range(B):
+        s, e = case["atom_offsets"][b], case["atom_offsets"][b + 1]
+        rc[s:e] = rotateCoordinates(case["coords"][s:e], list(rots[b]), cens[b]).astype(np.float32)
+    plain, _ = E.voxelize_lattice(rc, case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    assert err == 0 and np.abs(fused - plain).max() <= 1e-5
+    from tests.cases import oracle_lattice
+    exp = oracle_lattice(rc, case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    assert np.abs(fused - exp).max() <= TOL
+    assert np.abs(fused - case["expected"]).max() > 0.1          # the rotation really changed the grids

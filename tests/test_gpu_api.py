@@ -105,3 +105,34 @@ def test_torch_device_resident_path_matches_host_path():
         nx, ny, nz = [int(v) for v in case["nvoxels"]]
         assert cf.shape == (out.shape[0], out.shape[2], nx, ny, nz)
         assert torch.equal(cf.permute(0, 2, 3, 4, 1).reshape(out.shape), out)
+
+
+def test_fused_rotation_augmentation_on_device():
+    """per-item rotateCoordinates (voxeldescriptors.py:78-114) fused into the device pipeline + the
+    channel-first view the reference's tutorial builds by hand before nn.Conv3d."""
+    import torch
+    from moleculekit_amd import batch
+    from moleculekit_amd.voxeldescriptors import rotateCoordinates
+    from tests.cases import LATTICE_CASES, oracle_lattice
+    case = LATTICE_CASES["cfg3_small"]()
+    B = len(case["atom_offsets"]) - 1
+    rng = np.random.default_rng(43)
+    rots = rng.uniform(-np.pi, np.pi, size=(B, 3))
+    cens = case["origins"] + 12.0
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    fused = batch.voxelize_lattice_torch(t(case["coords"], np.float32), t(case["atom_offsets"], np.int64),
+                                         t(case["sigmas"], np.float64), t(case["origins"], np.float64), case["nvoxels"],
+                                         case["voxelsize"], affine=t(batch.rotation_affines(rots, cens), np.float64),
+                                         channel_first=True)
+    torch.cuda.synchronize()
+    nx, ny, nz = [int(v) for v in case["nvoxels"]]
+    assert fused.shape == (B, 8, nx, ny, nz)
+    got = fused.permute(0, 2, 3, 4, 1).reshape(B, -1, 8).cpu().numpy()
+    rc = case["coords"].copy()
+    for b in range(B):
+        s, e = case["atom_offsets"][b], case["atom_offsets"][b + 1]
+        rc[s:e] = rotateCoordinates(case["coords"][s:e], list(rots[b]), cens[b]).astype(np.float32)
+    exp = oracle_lattice(rc, case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    assert np.abs(got - exp).max() <= TOL
+    assert np.abs(got - case["expected"]).max() > 0.1
