@@ -664,7 +664,7 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
     // lane s < NCLS holds the w bits of class s (read back with a uniform-lane register read)
     const unsigned my_class_w = (!general && lane < NCLS) ? cls_table[lane] : INF_BITS;
 
-    bool sorted_done = false;
+    unsigned gmask = general ? 0xffu : 0u;     // channels left to the general path (wave-uniform)
     if (!general) {
         // ---- traversal 1: cull and histogram the buckets (traversal 2 places; the records are L2-hot then) ----
         // bucket = (channel, class, x-reach): an entry whose x lies more than the cutoff below the
@@ -699,37 +699,57 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
 #pragma unroll
             for (int i = 0; i < 2 * NXR; ++i) { start[i] = run; run += pad[i]; }
         }
-        if (total <= (unsigned)ECAP) {                                   // wave-uniform
-            mk_block_sync();                                             // everyone has read the counts
+        (void)total;
+        // ---- rounds: consecutive channels whose padded entries fit the LDS arrays together are placed
+        //      and processed in one round (normally a single round takes all eight); a channel that
+        //      does not fit on its own is left to the general path ----
+        const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
+        const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u);
+        int c0 = 0;
+        while (c0 < CHG) {                                                   // wave-uniform
+            // channel c owns groups 16c..16c+15 = lanes 8c..8c+7 (two groups each)
+            const unsigned base = c0 ? mk_readlane(incl, 8 * c0 - 1) : 0u;
+            int c1 = c0;
+            while (c1 < CHG && mk_readlane(incl, 8 * c1 + 7) - base <= (unsigned)ECAP) ++c1;
+            if (c1 == c0) { gmask |= 1u << c0; ++c0; continue; }
+            const unsigned count = mk_readlane(incl, 8 * c1 - 1) - base;
+            if (count == 0u) { c0 = c1; continue; }
+            const bool in_round = (lane >> 3) >= c0 && (lane >> 3) < c1;
+            mk_block_sync();                                             // counts read; previous round done
+            if (in_round) {
 #pragma unroll
-            for (int i = 0; i < 2 * NXR; ++i) {
-                bucket[2 * NXR * lane + i] = start[i];                   // placement cursors
-                // odd sub-buckets get one far-away sentinel entry
-                if (cnt[i] & 1u) { sx[start[i] + cnt[i]] = 1.0e18f; sy[start[i] + cnt[i]] = 0.f; sz[start[i] + cnt[i]] = 0.f; }
+                for (int i = 0; i < 2 * NXR; ++i) {
+                    const unsigned s0 = start[i] - base;
+                    bucket[2 * NXR * lane + i] = s0;                         // placement cursors
+                    // odd sub-buckets get one far-away sentinel entry
+                    if (cnt[i] & 1u) { sx[s0 + cnt[i]] = 1.0e18f; sy[s0 + cnt[i]] = 0.f; sz[s0 + cnt[i]] = 0.f; }
+                }
             }
             mk_block_sync();
-            // ---- traversal 2: place the entries into their buckets ----
+            // ---- traversal 2: place the round's entries into their buckets ----
+            const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
             for_each_candidate<K, true, TRAV_BATCH>(g, tg, cell_start, rec_pos, clsp,
                 [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
                     const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
-                    for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
+                    for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
                         const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                         sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
                     });
                 });
             mk_block_sync();
             // cursors are dead now: the array becomes the table of sub-bucket starts (sub-buckets are
-            // contiguous, so a group's three ranges are four consecutive words)
+            // contiguous, so a group's three ranges are four consecutive words; the word after the
+            // round's last group belongs to a channel outside the round, whose counts live in registers)
+            if (in_round) {
 #pragma unroll
-            for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i];
-            if (lane == WAVE - 1) bucket[NBUCKET3] = total;
+                for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i] - base;
+            }
+            if (lane == 0) bucket[c1 * NSLOT * NXR] = count;
             mk_block_sync();
             // ---- process group by group: inner loop = sub, fma, half a min3 per (voxel, entry) ----
-            const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
-            const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u);
 #pragma unroll
             for (int c = 0; c < CHG; ++c) {
-                // channel c owns groups 16c..16c+15 = lanes 8c..8c+7 (two groups each)
+                if (c < c0 || c >= c1) continue;                          // wave-uniform
                 unsigned bits = 0;
                 {
                     const unsigned e = (unsigned)(ne0 >> (8 * c)) & 0xffu, o = (unsigned)(ne1 >> (8 * c)) & 0xffu;
@@ -771,11 +791,11 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                     }
                 }
             }
-            sorted_done = true;
+            c0 = c1;
         }
     }
 
-    if (!sorted_done) {
+    if (gmask) {                                                             // wave-uniform
         // ---- general path (arbitrary per-entry sigma, or a tile too dense for the LDS buffers):
         //      chunk by chunk, per-channel compaction through LDS, cutoff test per (voxel, entry) ----
         mk_block_sync();
@@ -795,6 +815,7 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
             }
 #pragma unroll
             for (int c = 0; c < CHG; ++c) {
+                if (!((gmask >> c) & 1u)) continue;                  // wave-uniform
                 const float wc = wv[c];
                 const bool has = surv && (wc < INF);                // false for +inf and NaN
                 const unsigned long long mask = mk_ballot(has);

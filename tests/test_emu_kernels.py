@@ -117,19 +117,34 @@ def test_more_than_16_sigma_classes_falls_back_to_general_path():
     check(case, got)
 
 
-def test_tile_denser_than_lds_capacity_falls_back_per_tile():
-    """> 1024 entries within reach of one tile: that tile takes the chunked path, others stay sorted."""
-    rng = np.random.default_rng(32)
-    n = 900
-    c = rng.uniform(0, 7, size=(n, 3)).astype(np.float32)          # 900 atoms in a 7 A cube, 8 channels each
+def _dense_case(n, chan_prob, seed):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(0, 7, size=(n, 3)).astype(np.float32)          # n atoms in a 7 A cube
     s = np.tile(rng.choice([1.1, 1.7, 1.52], size=(n, 1)), (1, 8))
+    s = np.where(rng.random((n, 8)) < np.asarray(chan_prob)[None, :], s, 0.0)
     case = dict(coords=c, atom_offsets=np.array([0, n]), sigmas=s, origins=np.array([[-4.0, -4, -4]]),
                 nvoxels=np.array([24, 16, 16]), voxelsize=1.0, box=None)
     from tests.cases import oracle_lattice
     case["expected"] = oracle_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0)
-    got, err = E.voxelize_lattice(c, case["atom_offsets"], s, case["origins"], case["nvoxels"], 1.0, tile_k=8)
+    return case
+
+
+@pytest.mark.parametrize("n,chan_prob", [
+    (900, [1.0] * 8),                                   # every channel alone exceeds the LDS arrays: all general
+    (250, [1.0] * 8),                                   # ~250 entries per channel: several class-sorted rounds
+    (900, [1.0, 0.1, 0.1, 0.3, 1.0, 0.05, 0.0, 0.2]),   # two oversized channels between channels that share rounds
+])
+def test_tile_denser_than_lds_capacity_runs_in_rounds(n, chan_prob):
+    """More entries within reach of one tile than the LDS arrays hold: the class-sorted path takes the
+    channels in rounds, a channel too dense on its own goes through the chunked path; other tiles are
+    unaffected and everything stays bit-identical to the general path."""
+    case = _dense_case(n, chan_prob, 32)
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], 1.0)
+    got, err = E.voxelize_lattice(*args, tile_k=8)
     assert err == 0
     check(case, got)
+    ref, _ = E.voxelize_lattice(*args, tile_k=8, force_general=True)
+    assert np.array_equal(got, ref)
 
 
 def test_fused_rotation_matches_rotate_then_voxelize():
