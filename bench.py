@@ -31,13 +31,40 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector FP32 peak (secondary roofline: cfg2/cfg4 are VALU-bound)
 
-DEFAULT_BATCH = {"cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096}
+DEFAULT_BATCH = {"cfg1": 1024, "cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096}
+
+
+def real_protein_config(batch, seed):
+    """BASELINE configs[0] scaled up: the reference's own 3PTB pocket case (real protein density and
+    channel typing, tests/golden/cfg1_3ptb.npz), `batch` randomly rotated copies (rotation about the
+    grid centre, what the reference's augmentation loop feeds getVoxelDescriptors)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_3ptb.npz"))
+    rng = np.random.default_rng(seed)
+    c0 = g["coords"].astype(np.float64) - g["center"][None, :]
+    q = rng.normal(size=(batch, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                  2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                  2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], axis=1).reshape(batch, 3, 3)
+    coords = (np.einsum("bij,nj->bni", R, c0) + g["center"][None, None, :]).astype(np.float32)
+    n = c0.shape[0]
+    return dict(coords=coords.reshape(-1, 3), sigmas=np.tile(g["sigmas"], (batch, 1)),
+                atom_offsets=np.arange(batch + 1, dtype=np.int64) * n,
+                centers=np.tile(g["center"][None, :], (batch, 1)).astype(np.float64),
+                boxsize=np.asarray(g["boxsize"], dtype=np.float64), voxelsize=float(g["voxelsize"]), box=None)
+
+
+def make_config(name, batch, seed=None):
+    from tests.synth import synth_config
+    if name == "cfg1":
+        return real_protein_config(batch, 1 if seed is None else seed)
+    return synth_config(int(name[3:]), batch, seed=seed)
 
 
 def make_workload(name, batch, seed):
-    from tests.synth import grid_origin, synth_config
-    cfg = int(name[3:])
-    p = synth_config(cfg, batch, seed=seed)
+    from tests.synth import grid_origin
+    p = make_config(name, batch, seed)
     origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
     nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
     return p, origins, nv
@@ -54,9 +81,9 @@ def algorithmic_bytes(p, nv, C=8):
 def cpu_baseline(name):
     """Oracle (port of occupancy_utils.pyx:34-61, serial like the reference) on a bounded sample."""
     from oracle import oracle
-    from tests.synth import grid_origin, synth_config
+    from tests.synth import grid_origin
     cfg = int(name[3:])
-    p = synth_config(cfg, 1)
+    p = make_config(name, 1)
     o, nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])
     s, e = p["atom_offsets"][0], p["atom_offsets"][1]
     if cfg in (2, 4):     # one grid costs ~40 s on one core: time a central z-slab of it, all atoms
@@ -66,7 +93,7 @@ def cpu_baseline(name):
         sample = f"1 item of {name}: all {e - s} atoms, central {nv[0]}x{nv[1]}x{nz} voxel slab of the grid"
         reps = 1
     else:                 # small molecules: whole grids, repeated
-        reps = 200
+        reps = 200 if cfg != 1 else 8
         sample = f"{reps} items of {name} ({e - s} atoms each, full {nv[0]}x{nv[1]}x{nv[2]} grid)"
     centers = oracle.grid_centers(o, nv, p["voxelsize"])
     box = None if p["box"] is None else p["box"][0]
@@ -88,6 +115,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(DEFAULT_BATCH))
     ap.add_argument("--batch", type=int, default=0, help="items per GPU per step (0 = workload default)")
     ap.add_argument("--tile-k", type=int, default=0)
+    ap.add_argument("--lds-tier", type=int, default=-1, help="-1 adaptive (default), 0/1/2 = 640/768/1024 LDS entries per tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -119,6 +147,7 @@ def main():
     V, C = int(np.prod(nv)), 8
     ctx = _lib.default_context(local)
     ctx.set_tile_k(args.tile_k)
+    ctx.set_lds_tier(args.lds_tier)
     ctx.set_force_general(os.environ.get("MKAMD_FORCE_GENERAL", "0") == "1")
     # steps are independent batches whose inputs are resident before the loop: the library may overlap the
     # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)

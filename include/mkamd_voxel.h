@@ -63,6 +63,11 @@ int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k);
 /* 1: always take the general tile-kernel path (per-pair cutoff test, arbitrary per-entry sigma)
  * instead of the class-sorted one; results are bit-identical (testing / A-B benchmarking). */
 int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on);
+/* LDS entry capacity of a tile of the lattice kernel: tier 0/1/2 = 640/768/1024 entries (leaner = more
+ * waves per CU = faster, as long as the tiles fit; tiles that do not are finished by a second, multi-round
+ * kernel).  -1 (default) = adaptive: the leanest tier that at most 5 % of the tiles of the previous calls
+ * on this context overflowed.  Results are bit-identical whatever the tier. */
+int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier);
 /* Opt-in software pipelining ACROSS calls of mkamd_voxelize_lattice_dev (off by default): the binning
  * pre-pass of a call (latency / atomic bound) runs on an internal stream beside the tile kernel (VALU bound)
  * of the previous call, on a second workspace set.  Results still appear in order on the context's stream.

@@ -32,6 +32,7 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_ctx_set_tile_k": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_force_general": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_lds_tier": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
@@ -149,6 +150,10 @@ class Context:
 
     def set_tile_k(self, k: int):
         _check(load().mkamd_ctx_set_tile_k(self._h, int(k)))
+
+    def set_lds_tier(self, tier: int):
+        """-1 adaptive (default), 0/1/2 = 640/768/1024 LDS entries per tile (include/mkamd_voxel.h)."""
+        _check(load().mkamd_ctx_set_lds_tier(self._h, int(tier)))
 
     def set_force_general(self, on: bool):
         _check(load().mkamd_ctx_set_force_general(self._h, int(bool(on))))

@@ -52,6 +52,9 @@ struct mkamd_ctx {
     size_t caps[2 * WS_NSLOTS] = {};
     int tile_k = 0;
     int force_general = 0;
+    int lds_tier = -1;                     // -1 = adaptive
+    unsigned* fb_host = nullptr;           // pinned, device-visible: tier statistics of the last finished call
+    unsigned* fb_dev = nullptr;
     // tile-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
@@ -59,6 +62,8 @@ struct mkamd_ctx {
     int launch_status = 0;
 
     // ---- backend concept (pipeline.h) ----
+    const volatile unsigned* feedback_host() const { return fb_host; }
+    unsigned* feedback_dev() const { return fb_dev; }
     int ensure(int slot, size_t bytes, void** ptr, int set = 0)
     {
         slot += set * WS_NSLOTS;
@@ -220,6 +225,14 @@ int mkamd_ctx_create(int device, mkamd_ctx** out)
         ok = hipEventCreateWithFlags(&c->ev_pre_done[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&c->ev_tile_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) c->side_stream = nullptr;          // fall back to a single in-order stream
+    // tier statistics come back through pinned host memory the dense kernel writes directly (no copy, no sync)
+    if (hipHostMalloc((void**)&c->fb_host, (NTIER + 1) * sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+        for (int i = 0; i <= NTIER; ++i) c->fb_host[i] = 0u;
+        if (hipHostGetDevicePointer((void**)&c->fb_dev, c->fb_host, 0) != hipSuccess) c->fb_dev = nullptr;
+    } else {
+        c->fb_host = nullptr;                   // no feedback: the leanest tier is always used
+    }
+    if (!c->fb_dev && c->fb_host) { (void)hipHostFree(c->fb_host); c->fb_host = nullptr; }
     *out = c;
     return MKAMD_OK;
 }
@@ -241,6 +254,7 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx)
         if (ctx->ev_tile_done[i]) (void)hipEventDestroy(ctx->ev_tile_done[i]);
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->fb_host) (void)hipHostFree(ctx->fb_host);
     delete ctx;
     return MKAMD_OK;
 }
@@ -288,6 +302,14 @@ int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k)
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     if (k != 0 && k != 4 && k != 8) return fail(MKAMD_EINVAL, "tile K must be 0 (auto), 4 or 8");
     ctx->tile_k = k;
+    return MKAMD_OK;
+}
+
+int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier)
+{
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (tier < -1 || tier >= NTIER) return fail(MKAMD_EINVAL, "LDS tier must be -1 (adaptive), 0, 1 or 2");
+    ctx->lds_tier = tier;
     return MKAMD_OK;
 }
 
@@ -427,7 +449,7 @@ int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coo
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
     P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
-    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general;
+    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;

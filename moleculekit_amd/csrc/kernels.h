@@ -33,13 +33,15 @@ constexpr int CHG = 8;               // channels per channel-group (one group = 
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per call (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
-#ifndef MK_ECAP
-#define MK_ECAP 640
-#endif
 #ifndef MK_TRAV_BATCH
 #define MK_TRAV_BATCH 4
 #endif
-constexpr int ECAP = MK_ECAP;        // LDS entry capacity of a tile (3 x 3 KiB, structure of arrays)
+// LDS entry capacity of a tile (three float arrays, structure of arrays) comes in tiers: LDS per tile is
+// what bounds the tile kernel's occupancy, so the leanest tier is the fastest as long as the tiles fit
+// it; the host moves up when too many tiles of the previous calls did not (pipeline.h, choose_tier).
+constexpr int NTIER = 3;
+constexpr int ECAP_TIER[NTIER] = {640, 768, 1024};
+constexpr int DENSE_WORDS = 1 + NTIER;   // [0] dense-list length, [1+t] tiles with more entries than tier t holds
 constexpr int TRAV_BATCH = MK_TRAV_BATCH;   // candidate chunks whose loads are in flight together
 constexpr int NXR = 3;               // x-reach sub-buckets: 0 = all K planes, 1 = low half only, 2 = high half only
 constexpr int NBUCKET3 = NBUCKET * NXR;
@@ -585,11 +587,16 @@ MK_DEV void for_each_present_channel(unsigned ids, F&& f)
     }
 }
 
-template <int K>
-MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cell_start,
-                                    const float4* __restrict__ rec_pos,
-                                    const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
-                                    const unsigned* __restrict__ cls_table, float* __restrict__ out)
+// DENSE = false: the tile kernel proper.  A class-sorted tile whose entries do not fit the LDS arrays
+// is only appended to dense_list (dense_count = its length) and left to the DENSE = true instance,
+// which runs afterwards over that list: keeping the rare multi-round code out of this kernel keeps
+// its register footprint at 4 waves/SIMD (one kernel holding both needed ~2x the VGPRs).
+template <int K, bool DENSE, int ECAP>
+MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, const unsigned* __restrict__ cell_start,
+                          const float4* __restrict__ rec_pos,
+                          const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
+                          const unsigned* __restrict__ cls_table, float* __restrict__ out,
+                          unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
 {
     static_assert(K == 4 || K == 8, "K");
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
@@ -608,13 +615,6 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
     __shared__ unsigned bucket[NBUCKET3 + 1];
 
     const int lane = threadIdx.x;
-    // XCD-aware order: the dispatcher places block i on XCD i%8; give each XCD a contiguous run of
-    // tiles so neighbouring tiles (which share candidate cells) hit the same 4 MiB L2.
-    const unsigned per_xcd = gridDim.x >> 3;      // gridDim.x is a multiple of 8 (host pads)
-    const unsigned lt = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
-    if (lt >= total_tiles) return;                // whole wave leaves together
-    const int gq = blockIdx.y;
 
     TileGeom tg;
     tg.b = (int)(lt / (unsigned)g.ntiles);
@@ -657,14 +657,13 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
 #pragma unroll
         for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
 
-    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+    const bool general = !DENSE && (g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY);
     const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
     const float4* __restrict__ w0p = rec_w + (size_t)(gq * 2 + 0) * g.M;
     const float4* __restrict__ w1p = rec_w + (size_t)(gq * 2 + 1) * g.M;
     // lane s < NCLS holds the w bits of class s (read back with a uniform-lane register read)
     const unsigned my_class_w = (!general && lane < NCLS) ? cls_table[lane] : INF_BITS;
 
-    unsigned gmask = general ? 0xffu : 0u;     // channels left to the general path (wave-uniform)
     if (!general) {
         // ---- traversal 1: cull and histogram the buckets (traversal 2 places; the records are L2-hot then) ----
         // bucket = (channel, class, x-reach): an entry whose x lies more than the cutoff below the
@@ -699,34 +698,94 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
 #pragma unroll
             for (int i = 0; i < 2 * NXR; ++i) { start[i] = run; run += pad[i]; }
         }
-        (void)total;
-        // ---- rounds: consecutive channels whose padded entries fit the LDS arrays together are placed
-        //      and processed in one round (normally a single round takes all eight); a channel that
-        //      does not fit on its own is left to the general path ----
+        if (!DENSE && total > (unsigned)ECAP_TIER[0]) {                      // wave-uniform; statistics for the tier choice
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < NTIER; ++t)
+                    if (total > (unsigned)ECAP_TIER[t]) (void)mk_atomic_add(&dense_count[1 + t], 1u);
+            }
+        }
+        if (!DENSE && total > (unsigned)ECAP) {                              // wave-uniform
+            // too dense for one round: hand the tile to the dense instance of this kernel
+            if (lane == 0) dense_list[mk_atomic_add(dense_count, 1u)] = lt + (unsigned)gq * ((unsigned)g.B * (unsigned)g.ntiles);
+            return;
+        }
         const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
         const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u);
-        int c0 = 0;
-        while (c0 < CHG) {                                                   // wave-uniform
-            // channel c owns groups 16c..16c+15 = lanes 8c..8c+7 (two groups each)
-            const unsigned base = c0 ? mk_readlane(incl, 8 * c0 - 1) : 0u;
-            int c1 = c0;
-            while (c1 < CHG && mk_readlane(incl, 8 * c1 + 7) - base <= (unsigned)ECAP) ++c1;
-            if (c1 == c0) { gmask |= 1u << c0; ++c0; continue; }
-            const unsigned count = mk_readlane(incl, 8 * c1 - 1) - base;
-            if (count == 0u) { c0 = c1; continue; }
+        // non-empty classes of channel c (which owns groups 16c..16c+15 = lanes 8c..8c+7, two groups each)
+        auto class_bits = [&](int c) {
+            const unsigned e = (unsigned)(ne0 >> (8 * c)) & 0xffu, o = (unsigned)(ne1 >> (8 * c)) & 0xffu;
+            unsigned bits = 0;
+            for (int j = 0; j < 8; ++j) bits |= (((e >> j) & 1u) << (2 * j)) | (((o >> j) & 1u) << (2 * j + 1));
+            return bits;
+        };
+        // ---- one channel, class by class: inner loop = sub, fma, half a min3 per (voxel, entry); the
+        //      class flush applies the cutoff to the class minimum and scales by w ----
+        auto process_classes = [&](int c, unsigned bits, unsigned (&acc)[K]) {
+            while (bits) {                                                // wave-uniform
+                const int cls = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
+                const uint4 bg = make_uint4(bgp[0], bgp[1], bgp[2], bgp[3]);
+                const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
+                unsigned m[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) m[k] = INF_BITS;
+                // planes [K0, K1) against the (even-length) entry range [s, e)
+                auto run = [&](auto k0_, auto k1_, unsigned s0, unsigned e0) {
+                    constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+                    for (unsigned i = s0; i < e0; i += 2) {
+                        const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
+                        const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
+                        const float2 pz = *reinterpret_cast<const float2*>(&sz[i]);
+                        const float dya = Y - py.x, dza = Z - pz.x, dyb = Y - py.y, dzb = Z - pz.y;
+                        const float ra = mk_fma(dya, dya, dza * dza), rb = mk_fma(dyb, dyb, dzb * dzb);
+#pragma unroll
+                        for (int k = K0; k < K1; ++k) {
+                            const float dxa = ((float)k - HX) - px.x, dxb = ((float)k - HX) - px.y;
+                            m[k] = mk_min3_bits(m[k], mk_fma(dxa, dxa, ra), mk_fma(dxb, dxb, rb));
+                        }
+                    }
+                };
+                run(IntC<0>{}, IntC<K>{}, bg.x, bg.y);
+                run(IntC<0>{}, IntC<K / 2>{}, bg.y, bg.z);
+                run(IntC<K / 2>{}, IntC<K>{}, bg.z, bg.w);
+                // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float d2 = mk_uint_as_float(m[k]);
+                    acc[k] = mk_min_bits(acc[k], d2 < R2 ? d2 * wcls : INF);
+                }
+            }
+        };
+        // dense tiles only: a finished channel goes straight to memory (4-byte stores, 32-byte stride)
+        auto store_channel = [&](int c, const unsigned (&acc)[K]) {
+            const int y = tg.y0 + ly, z = tg.z0 + lz;
+            if (y < g.ny && z < g.nz && gq * CHG + c < g.C) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int x = tg.x0 + k;
+                    const size_t vox = (size_t)tg.b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+                    if (x < g.nx) out[vox * (size_t)g.C + (size_t)(gq * CHG + c)] = occupancy_from_q(mk_uint_as_float(acc[k]));
+                }
+            }
+        };
+
+        // ---- placement of channels [c0, c1) (`count` padded entries starting at `base` of the scan) ----
+        auto place = [&](int c0, int c1, unsigned base, unsigned count) {
             const bool in_round = (lane >> 3) >= c0 && (lane >> 3) < c1;
-            mk_block_sync();                                             // counts read; previous round done
+            mk_block_sync();                                                 // counts read; previous round done
             if (in_round) {
 #pragma unroll
                 for (int i = 0; i < 2 * NXR; ++i) {
                     const unsigned s0 = start[i] - base;
-                    bucket[2 * NXR * lane + i] = s0;                         // placement cursors
+                    bucket[2 * NXR * lane + i] = s0;                             // placement cursors
                     // odd sub-buckets get one far-away sentinel entry
                     if (cnt[i] & 1u) { sx[s0 + cnt[i]] = 1.0e18f; sy[s0 + cnt[i]] = 0.f; sz[s0 + cnt[i]] = 0.f; }
                 }
             }
             mk_block_sync();
-            // ---- traversal 2: place the round's entries into their buckets ----
+            // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
             for_each_candidate<K, true, TRAV_BATCH>(g, tg, cell_start, rec_pos, clsp,
                 [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
@@ -739,83 +798,87 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
             mk_block_sync();
             // cursors are dead now: the array becomes the table of sub-bucket starts (sub-buckets are
             // contiguous, so a group's three ranges are four consecutive words; the word after the
-            // round's last group belongs to a channel outside the round, whose counts live in registers)
+            // last group placed belongs to a channel outside the round, whose counts live in registers)
             if (in_round) {
 #pragma unroll
                 for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i] - base;
             }
             if (lane == 0) bucket[c1 * NSLOT * NXR] = count;
             mk_block_sync();
-            // ---- process group by group: inner loop = sub, fma, half a min3 per (voxel, entry) ----
+        };
+
+        if (!DENSE) {
+            // ---- the normal case: one round takes all eight channels; minima stay in q for the epilogue ----
+            place(0, CHG, 0u, total);
 #pragma unroll
-            for (int c = 0; c < CHG; ++c) {
-                if (c < c0 || c >= c1) continue;                          // wave-uniform
-                unsigned bits = 0;
-                {
-                    const unsigned e = (unsigned)(ne0 >> (8 * c)) & 0xffu, o = (unsigned)(ne1 >> (8 * c)) & 0xffu;
-                    for (int j = 0; j < 8; ++j) bits |= (((e >> j) & 1u) << (2 * j)) | (((o >> j) & 1u) << (2 * j + 1));
-                }
-                while (bits) {                                            // wave-uniform
-                    const int cls = __builtin_ctz(bits);
-                    bits &= bits - 1u;
-                    const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
-                    const uint4 bg = make_uint4(bgp[0], bgp[1], bgp[2], bgp[3]);
-                    const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
+            for (int c = 0; c < CHG; ++c) process_classes(c, class_bits(c), q[c]);
+        } else {
+            // ---- dense tile: consecutive channels whose padded entries fit the LDS arrays together are
+            //      placed and processed in one round; a channel that does not fit on its own goes chunk
+            //      by chunk through LDS with the cutoff and w applied per (voxel, entry) (the general
+            //      path's values, bit for bit).  A finished channel is stored on the spot. ----
+            int c0 = 0;
+            while (c0 < CHG) {                                               // wave-uniform
+                const unsigned base = c0 ? mk_readlane(incl, 8 * c0 - 1) : 0u;
+                int c1 = c0;
+                while (c1 < CHG && mk_readlane(incl, 8 * c1 + 7) - base <= (unsigned)ECAP) ++c1;
+                if (c1 == c0) {
                     unsigned m[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) m[k] = INF_BITS;
-                    // planes [K0, K1) against the (even-length) entry range [s, e)
-                    auto run = [&](auto k0_, auto k1_, unsigned s0, unsigned e0) {
-                        constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
-                        for (unsigned i = s0; i < e0; i += 2) {
-                            const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
-                            const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
-                            const float2 pz = *reinterpret_cast<const float2*>(&sz[i]);
-                            const float dya = Y - py.x, dza = Z - pz.x, dyb = Y - py.y, dzb = Z - pz.y;
-                            const float ra = mk_fma(dya, dya, dza * dza), rb = mk_fma(dyb, dyb, dzb * dzb);
+                    mk_block_sync();
+                    for_each_candidate<K, true, 1>(g, tg, cell_start, rec_pos, clsp,
+                        [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
+                            const unsigned id = surv ? (ids >> (4 * c0)) & 0xfu : 0u;
+                            const float wc = id ? mk_uint_as_float(cls_table[id - 1u]) : INF;
+                            const bool has = wc < INF;                       // false for +inf and NaN
+                            const unsigned long long mask = mk_ballot(has);
+                            if (mask == 0ull) return;                        // wave-uniform
+                            const int n = mk_popc64(mask);
+                            if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
+                            mk_block_sync();
+                            for (int i = 0; i < n; ++i) {
+                                const float4 e = ebuf[i];
+                                const float dy = Y - e.y, dz = Z - e.z;
+                                const float dyz2 = mk_fma(dy, dy, dz * dz);
 #pragma unroll
-                            for (int k = K0; k < K1; ++k) {
-                                const float dxa = ((float)k - HX) - px.x, dxb = ((float)k - HX) - px.y;
-                                m[k] = mk_min3_bits(m[k], mk_fma(dxa, dxa, ra), mk_fma(dxb, dxb, rb));
+                                for (int k = 0; k < K; ++k) {
+                                    const float dx = ((float)k - HX) - e.x;
+                                    const float d2 = mk_fma(dx, dx, dyz2);
+                                    m[k] = mk_min_bits(m[k], d2 < R2 ? d2 * e.w : INF);   // occupancy_utils.pyx:53
+                                }
                             }
-                        }
-                    };
-                    run(IntC<0>{}, IntC<K>{}, bg.x, bg.y);
-                    run(IntC<0>{}, IntC<K / 2>{}, bg.y, bg.z);
-                    run(IntC<K / 2>{}, IntC<K>{}, bg.z, bg.w);
-                    // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
-#pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const float d2 = mk_uint_as_float(m[k]);
-                        q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? d2 * wcls : INF);
-                    }
+                            mk_block_sync();                                 // ebuf is rewritten next
+                        });
+                    store_channel(c0, m);
+                    ++c0;
+                    continue;
                 }
+                const unsigned count = mk_readlane(incl, 8 * c1 - 1) - base;
+                if (count != 0u) place(c0, c1, base, count);
+                for (int c = c0; c < c1; ++c) {                               // wave-uniform, not unrolled
+                    unsigned acc[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[k] = INF_BITS;
+                    if (count != 0u) process_classes(c, class_bits(c), acc);
+                    store_channel(c, acc);
+                }
+                c0 = c1;
             }
-            c0 = c1;
+            return;                                                          // every channel stored
         }
     }
 
-    if (gmask) {                                                             // wave-uniform
-        // ---- general path (arbitrary per-entry sigma, or a tile too dense for the LDS buffers):
+    if (general) {
+        // ---- general path (arbitrary per-entry sigma: more sigma classes than the id table holds):
         //      chunk by chunk, per-channel compaction through LDS, cutoff test per (voxel, entry) ----
         mk_block_sync();
-        auto body = [&](bool surv, unsigned r, float ex, float ey, float ez, unsigned ids) {
-            float wv[CHG];
-            if (general) {
-                float4 W0 = make_float4(INF, INF, INF, INF), W1 = W0;
-                if (surv) { W0 = w0p[r]; W1 = w1p[r]; }
-                wv[0] = W0.x; wv[1] = W0.y; wv[2] = W0.z; wv[3] = W0.w;
-                wv[4] = W1.x; wv[5] = W1.y; wv[6] = W1.z; wv[7] = W1.w;
-            } else {
-#pragma unroll
-                for (int c = 0; c < CHG; ++c) {
-                    const unsigned id = surv ? (ids >> (4 * c)) & 0xfu : 0u;
-                    wv[c] = id ? mk_uint_as_float(cls_table[id - 1u]) : INF;
-                }
-            }
+        auto body = [&](bool surv, unsigned r, float ex, float ey, float ez, unsigned) {
+            float4 W0 = make_float4(INF, INF, INF, INF), W1 = W0;
+            if (surv) { W0 = w0p[r]; W1 = w1p[r]; }
+            const float wv[CHG] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
 #pragma unroll
             for (int c = 0; c < CHG; ++c) {
-                if (!((gmask >> c) & 1u)) continue;                  // wave-uniform
                 const float wc = wv[c];
                 const bool has = surv && (wc < INF);                // false for +inf and NaN
                 const unsigned long long mask = mk_ballot(has);
@@ -837,8 +900,7 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                 mk_block_sync();                                     // ebuf is rewritten next
             }
         };
-        if (general) for_each_candidate<K, false, 1>(g, tg, cell_start, rec_pos, clsp, body);
-        else for_each_candidate<K, true, 1>(g, tg, cell_start, rec_pos, clsp, body);
+        for_each_candidate<K, false, 1>(g, tg, cell_start, rec_pos, clsp, body);
     }
 
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
@@ -863,6 +925,42 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
                     if (gq * CHG + c < g.C) o[c] = f[c];
             }
         }
+    }
+}
+
+template <int K, int ECAP>
+MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cell_start,
+                                    const float4* __restrict__ rec_pos,
+                                    const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
+                                    const unsigned* __restrict__ cls_table, float* __restrict__ out,
+                                    unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
+{
+    // XCD-aware order: the dispatcher places block i on XCD i%8; give each XCD a contiguous run of
+    // tiles so neighbouring tiles (which share candidate cells) hit the same 4 MiB L2.
+    const unsigned per_xcd = gridDim.x >> 3;      // gridDim.x is a multiple of 8 (host pads)
+    const unsigned lt = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (lt >= (unsigned)g.B * (unsigned)g.ntiles) return;                // whole wave leaves together
+    voxelize_tile<K, false, ECAP>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
+}
+
+// The tiles k_voxelize_tiles left behind (usually none: the launch then costs ~2 us).
+template <int K, int ECAP>
+MK_KERNEL(64) void k_voxelize_dense_tiles(GridDesc g, const unsigned* __restrict__ cell_start,
+                                          const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls,
+                                          const unsigned* __restrict__ cls_table, float* __restrict__ out,
+                                          const unsigned* __restrict__ dense_count, const unsigned* __restrict__ dense_list,
+                                          unsigned* __restrict__ feedback)
+{
+    const unsigned n = *dense_count, total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
+    if (feedback && blockIdx.x == 0 && threadIdx.x == 0) {               // host-visible: drives the next calls' tier
+#pragma unroll
+        for (int t = 0; t < NTIER; ++t) feedback[t] = dense_count[1 + t];
+        feedback[NTIER] = total_tiles * (unsigned)g.G;
+    }
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {               // wave-uniform
+        const unsigned e = dense_list[i];
+        voxelize_tile<K, true, ECAP>(g, e % total_tiles, (int)(e / total_tiles), cell_start, rec_pos, nullptr, rec_cls, cls_table, out, nullptr, nullptr);
+        mk_block_sync();                                                 // LDS arrays are reused by the next tile
     }
 }
 

@@ -29,7 +29,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_ERR, WS_W_EXPLICIT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
     // distance_utils row (dist_pipeline.h)
@@ -51,6 +51,7 @@ struct LatticeProblem {
     int max_images = 1;
     int tile_k = 0;                         // 0 = auto
     int force_general = 0;                  // 1 = never use the class-sorted path
+    int lds_tier = -1;                      // -1 = adaptive (choose_tier), else the ECAP_TIER index to use
     // device pointers
     const float* coords = nullptr;
     const long long* atom_offsets = nullptr;
@@ -154,6 +155,46 @@ int run_scan(BE& be, const unsigned* counts, size_t n, unsigned* starts /* n+1 *
     return be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (const unsigned*)chunks, starts);
 }
 
+// LDS tier of the tile kernel: forced (0..NTIER-1), or the leanest tier that at most 5 % of the tiles of
+// the most recent finished call overflowed (feedback = {tiles over tier 0, 1, 2, tiles} written by the
+// dense kernel into host-visible memory; stale or zero feedback only costs speed, never correctness:
+// all tiers and the dense path produce bit-identical values).
+inline int choose_tier(int forced, const volatile unsigned* feedback)
+{
+    if (forced >= 0) return forced < NTIER ? forced : NTIER - 1;
+    if (!feedback) return 0;
+    const unsigned tiles = feedback[NTIER];
+    if (tiles == 0) return 0;
+    int tier = 0;
+    while (tier < NTIER - 1 && (unsigned long long)feedback[tier] * 20ull > tiles) ++tier;
+    return tier;
+}
+
+template <int K, int T, class BE>
+int launch_tiles_tier(BE& be, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+                      void* ctab, float* out, unsigned* dcount, void* dlist)
+{
+    constexpr int E = ECAP_TIER[T];
+    int st = be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
+                       (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
+    if (!st && !g.force_general)      // the tiles left behind (usually none) + the statistics for the next call
+        st = be.launch(k_voxelize_dense_tiles<K, E>, dim3(dense_wgs), dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos,
+                       (const unsigned*)rcls, (const unsigned*)ctab, out, (const unsigned*)dcount, (const unsigned*)dlist,
+                       be.feedback_dev());
+    return st;
+}
+
+template <int K, class BE>
+int launch_tiles(BE& be, int tier, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+                 void* ctab, float* out, unsigned* dcount, void* dlist)
+{
+    switch (tier) {
+    case 0: return launch_tiles_tier<K, 0>(be, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    case 1: return launch_tiles_tier<K, 1>(be, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    default: return launch_tiles_tier<K, 2>(be, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    }
+}
+
 // The lattice hot path: bin -> scan -> fill -> tile kernel.  All pointers in P are device pointers.
 template <class BE>
 int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
@@ -170,7 +211,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     const size_t ncells = (size_t)g.B * (size_t)g.ncell;
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
     void *tpos = nullptr, *tidx = nullptr;
-    if ((st = be.ensure(WS_CELL_COUNT, ncells * sizeof(unsigned), &count, set))) return st;
+    // count[ncells ...] = length of the dense-tile list + tier statistics (zeroed with the counters)
+    if ((st = be.ensure(WS_CELL_COUNT, (ncells + DENSE_WORDS) * sizeof(unsigned), &count, set))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
     if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos, set))) return st;
     if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw, set))) return st;
@@ -180,7 +222,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos, set))) return st;
     if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
 
-    if ((st = be.fill(count, 0, ncells * sizeof(unsigned)))) return st;
+    if ((st = be.fill(count, 0, (ncells + DENSE_WORDS) * sizeof(unsigned)))) return st;
     const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
     const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
     const unsigned nblk = agrid.x;
@@ -215,12 +257,16 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     be.prepass_done(set);
 
     const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
-    const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G), tblk(WAVE);
+    const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G);
+    if ((unsigned long long)total_tiles * (unsigned)g.G > 0xFFFF0000ull) { err = "batch too large: more than 2^32 tiles x channel groups; split the batch"; return ST_EINVAL; }
+    void* dlist = nullptr;
+    if ((st = be.ensure(WS_DENSE_LIST, (size_t)total_tiles * g.G * sizeof(unsigned), &dlist, set))) return st;
+    unsigned* dcount = (unsigned*)count + ncells;
+    const unsigned dense_wgs = total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u;
+    const int tier = choose_tier(P.lds_tier, be.feedback_host());
     be.hot_begin();
-    if (g.K == 8)
-        st = be.launch(k_voxelize_tiles<8>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, P.out);
-    else
-        st = be.launch(k_voxelize_tiles<4>, tgrid, tblk, g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, P.out);
+    st = g.K == 8 ? launch_tiles<8>(be, tier, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist)
+                  : launch_tiles<4>(be, tier, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist);
     be.hot_end();
     be.tile_done(set);
     return st;

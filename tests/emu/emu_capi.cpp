@@ -15,6 +15,9 @@ namespace {
 struct EmuBackend {
     void* bufs[WS_NSLOTS] = {};
     size_t caps[WS_NSLOTS] = {};
+    unsigned feedback[NTIER + 1] = {};
+    const volatile unsigned* feedback_host() const { return feedback; }
+    unsigned* feedback_dev() { return feedback; }
     ~EmuBackend() { for (void* p : bufs) free(p); }
     int ensure(int slot, size_t bytes, void** ptr, int = 0)
     {
@@ -54,7 +57,7 @@ const char* emu_last_error(void) { return g_err.c_str(); }
 int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offsets, const void* sigmas,
                          int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
                          const float* box, int max_images, int tile_k, int force_general, const double* affine, float* features,
-                         int* err_flag_out)
+                         int* err_flag_out, int lds_tier, unsigned* feedback_io /* NTIER+1: in = previous call's, out = this call's */)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -63,7 +66,8 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     LatticeProblem P;
     P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
     P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
-    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general;
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier;
+    if (feedback_io) for (int i = 0; i <= NTIER; ++i) be.feedback[i] = feedback_io[i];
     if (box && max_images <= 0) {
         max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);
         if (max_images < 0) return ST_EBOX;
@@ -75,6 +79,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;
     const int st = run_lattice(be, P, g_err);
     if (err_flag_out) *err_flag_out = *(int*)be.bufs[WS_ERR];
+    if (feedback_io) for (int i = 0; i <= NTIER; ++i) feedback_io[i] = be.feedback[i];
     return st;
 }
 
@@ -85,6 +90,8 @@ int emu_occupancy_centers(const double* centers, long long V, const float* coord
     for (long long i = 0; i < V * C; ++i) features[i] = -123.0f;
     return run_centers(be, centers, V, coords, N, sigmas, sigmas_f64, C, box, features, g_err);
 }
+
+int emu_choose_tier(int forced, const unsigned* feedback) { return choose_tier(forced, feedback); }
 
 int emu_grid_centers(const double* bb_min, const int* nvox, double voxelsize, double* centers)
 {

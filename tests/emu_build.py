@@ -46,7 +46,8 @@ def _p(a):
 
 
 def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box=None, max_images=0,
-                     tile_k=0, force_general=False, affine=None):
+                     tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None):
+    """feedback: optional uint32[4] array, in = tier statistics of the 'previous call', out = this call's."""
     coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
     atom_offsets = np.ascontiguousarray(atom_offsets, np.int64)
     sig64 = sigmas.dtype == np.float64
@@ -62,10 +63,15 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
         ctypes.c_int(B), _p(coords), _p(atom_offsets), _p(sigmas), ctypes.c_int(int(sig64)), ctypes.c_int(C),
         _p(origins), _p(nvox), ctypes.c_double(voxelsize), _p(bx), ctypes.c_int(max_images),
         ctypes.c_int(tile_k), ctypes.c_int(int(force_general)),
-        _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out), ctypes.byref(err))
+        _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out), ctypes.byref(err),
+        ctypes.c_int(lds_tier), _p(feedback))
     if st != 0:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return out, err.value
+
+
+def choose_tier(forced, feedback):
+    return int(lib().emu_choose_tier(ctypes.c_int(forced), _p(np.ascontiguousarray(feedback, np.uint32))))
 
 
 def occupancy_centers(centers, coords, sigmas, box=None):

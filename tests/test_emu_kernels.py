@@ -147,6 +147,39 @@ def test_tile_denser_than_lds_capacity_runs_in_rounds(n, chan_prob):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("tile_k", [4, 8])
+def test_lds_tiers_are_bit_identical_and_report_overflow_statistics(tile_k):
+    """The LDS tier (640/768/1024 entries per tile) only decides which tiles take the multi-round dense
+    kernel; values do not depend on it. The statistics the dense kernel reports (tiles with more padded
+    entries than each tier holds) are what the adaptive choice of the next call is based on."""
+    case = _dense_case(110, [1.0] * 8, 33)           # ~880 entries near the cube: over tiers 0 and 1, under tier 2
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], 1.0)
+    outs, fbs = [], []
+    for tier in (0, 1, 2):
+        fb = np.zeros(4, np.uint32)
+        got, err = E.voxelize_lattice(*args, tile_k=tile_k, lds_tier=tier, feedback=fb)
+        assert err == 0
+        outs.append(got); fbs.append(fb.copy())
+    check(case, outs[0])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert all(np.array_equal(fbs[0], f) for f in fbs[1:])               # statistics do not depend on the tier run
+    ntiles = int(np.prod(np.ceil(case["nvoxels"] / np.array([tile_k, 8, 8]))))
+    assert fbs[0][3] == ntiles
+    assert fbs[0][0] >= fbs[0][1] >= fbs[0][2] and fbs[0][0] > 0
+    # adaptive: with these statistics as "previous call" the leanest tier with <= 5 % overflow is picked
+    want = 0
+    while want < 2 and fbs[0][want] * 20 > ntiles:
+        want += 1
+    assert E.choose_tier(-1, fbs[0]) == want
+    assert E.choose_tier(1, fbs[0]) == 1
+    assert E.choose_tier(-1, np.zeros(4, np.uint32)) == 0
+    assert E.choose_tier(-1, np.array([100, 100, 100, 1000], np.uint32)) == 2
+    assert E.choose_tier(-1, np.array([100, 10, 0, 1000], np.uint32)) == 1
+    fb = fbs[0].copy()
+    got, _ = E.voxelize_lattice(*args, tile_k=tile_k, lds_tier=-1, feedback=fb)
+    assert np.array_equal(got, outs[0])
+
+
 def test_fused_rotation_matches_rotate_then_voxelize():
     """rotateCoordinates (voxeldescriptors.py:78-114) fused into the binning stage == rotating on the
     host (golden-checked host function), casting to float32 (:519) and voxelizing."""

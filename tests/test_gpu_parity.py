@@ -49,6 +49,37 @@ def test_many_sigma_classes_and_dense_tiles(hip_ctx):
     assert np.abs(got - oracle_lattice(c, np.array([0, n]), s, o, nv, 1.0)).max() <= TOL
 
 
+@pytest.mark.parametrize("n,chan_prob", [
+    (250, [1.0] * 8),                                   # several class-sorted rounds per dense tile
+    (110, [1.0] * 8),                                   # over the 640 and 768 tiers, under the 1024 one
+    (900, [1.0, 0.1, 0.1, 0.3, 1.0, 0.05, 0.0, 0.2]),   # two channels too dense even on their own
+])
+def test_dense_tiles_all_lds_tiers_bit_identical(hip_ctx, n, chan_prob):
+    """Tiles with more entries than the LDS arrays hold go through the multi-round dense kernel; whatever
+    the tier (forced or adaptive) the values are the general path's, bit for bit, and within TOL of the
+    oracle (tests/test_emu_kernels.py holds the same cases for the CPU tier)."""
+    from moleculekit_amd import batch
+    rng = np.random.default_rng(32)
+    c = rng.uniform(0, 7, size=(n, 3)).astype(np.float32)
+    s = np.tile(rng.choice([1.1, 1.7, 1.52], size=(n, 1)), (1, 8))
+    s = np.where(rng.random((n, 8)) < np.asarray(chan_prob)[None, :], s, 0.0)
+    o, nv = np.array([[-4.0, -4, -4]]), np.array([24, 16, 16])
+    want = oracle_lattice(c, np.array([0, n]), s, o, nv, 1.0)
+    outs = []
+    try:
+        for tier in (0, 1, 2, -1, -1):
+            hip_ctx.set_lds_tier(tier)
+            outs.append(batch.voxelize_lattice(c, [0, n], s, o, nv, 1.0, ctx=hip_ctx))
+        hip_ctx.set_force_general(True)
+        outs.append(batch.voxelize_lattice(c, [0, n], s, o, nv, 1.0, ctx=hip_ctx))
+    finally:
+        hip_ctx.set_lds_tier(-1)
+        hip_ctx.set_force_general(False)
+    assert np.abs(outs[0] - want).max() <= TOL
+    for other in outs[1:]:
+        assert np.array_equal(outs[0], other)
+
+
 @pytest.mark.parametrize("C", [1, 3, 11])
 def test_explicit_centres_golden(hip_ctx, C):
     from moleculekit_amd import batch

@@ -1,8 +1,14 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for wl in cfg2 cfg3 cfg5 cfg4; do
-  timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $wl > gpurun_out/bench_$wl.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+for wl in cfg1 cfg2 cfg3; do
+  for t in -1 0 1 2; do
+    timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $wl --lds-tier $t > gpurun_out/bench_${wl}_t$t.log 2>&1
+  done
 done
-timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipeline > gpurun_out/bench_cfg2_nopipe.log 2>&1
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/rocprof_cfg2.log 2>&1)
-timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+for f in gpurun_out/bench_cfg[123]_t*.log; do echo "== $f"; tail -1 $f | python -c "
+import sys,json
+try:
+    d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'])
+except Exception as e: print('ERR', e)
+"; done
