@@ -116,6 +116,7 @@ struct mkamd_ctx {
         in_pipelined_prepass = true;
         return set;
     }
+    bool set_is_pipelined(int) const { return in_pipelined_prepass; }
     void prepass_done(int set)
     {
         if (!in_pipelined_prepass) return;

@@ -734,6 +734,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 // planes [K0, K1) against the (even-length) entry range [s, e)
                 auto run = [&](auto k0_, auto k1_, unsigned s0, unsigned e0) {
                     constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+                    // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
+                    //  have to be merged after every one of these short runs -- measured 7 % slower)
+#pragma clang loop vectorize(disable) interleave(disable)
                     for (unsigned i = s0; i < e0; i += 2) {
                         const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
                         const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
@@ -837,6 +840,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                             const int n = mk_popc64(mask);
                             if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
                             mk_block_sync();
+#pragma clang loop vectorize(disable) interleave(disable)
                             for (int i = 0; i < n; ++i) {
                                 const float4 e = ebuf[i];
                                 const float dy = Y - e.y, dz = Z - e.z;
@@ -886,6 +890,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 const int n = mk_popc64(mask);
                 if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
                 mk_block_sync();
+#pragma clang loop vectorize(disable) interleave(disable)
                 for (int i = 0; i < n; ++i) {
                     const float4 e = ebuf[i];
                     const float dy = Y - e.y, dz = Z - e.z;
@@ -930,6 +935,25 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 
 template <int K, int ECAP>
 MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cell_start,
+                                    const float4* __restrict__ rec_pos,
+                                    const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
+                                    const unsigned* __restrict__ cls_table, float* __restrict__ out,
+                                    unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
+{
+    // XCD-aware order: the dispatcher places block i on XCD i%8; give each XCD a contiguous run of
+    // tiles so neighbouring tiles (which share candidate cells) hit the same 4 MiB L2.
+    const unsigned per_xcd = gridDim.x >> 3;      // gridDim.x is a multiple of 8 (host pads)
+    const unsigned lt = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (lt >= (unsigned)g.B * (unsigned)g.ntiles) return;                // whole wave leaves together
+    voxelize_tile<K, false, ECAP>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
+}
+
+// Same kernel held to 96 VGPRs (5 waves/SIMD worth; LDS still admits ~4): the registers it leaves free on
+// every SIMD are what lets the binning pre-pass of the NEXT call run beside it (with the full-size
+// variant the register file is 100 % allocated and the other queue starves until the grid drains).
+// Costs ~4 % of the tile kernel (cold-path spills), wins ~7 % on pipelined calls.
+template <int K, int ECAP>
+__attribute__((amdgpu_waves_per_eu(5, 8))) MK_KERNEL(64) void k_voxelize_tiles_lean(GridDesc g, const unsigned* __restrict__ cell_start,
                                     const float4* __restrict__ rec_pos,
                                     const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
                                     const unsigned* __restrict__ cls_table, float* __restrict__ out,

@@ -171,12 +171,20 @@ inline int choose_tier(int forced, const volatile unsigned* feedback)
 }
 
 template <int K, int T, class BE>
-int launch_tiles_tier(BE& be, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+int launch_tiles_tier(BE& be, bool lean, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
                       void* ctab, float* out, unsigned* dcount, void* dlist)
 {
     constexpr int E = ECAP_TIER[T];
-    int st = be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
+    int st;
+    if constexpr (T == 0) {           // the bigger tiers are LDS-bound to fewer waves anyway: no lean instance of them
+        st = lean ? be.launch(k_voxelize_tiles_lean<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
+                              (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist)
+                  : be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
+                              (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
+    } else {
+        st = be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                        (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
+    }
     if (!st && !g.force_general)      // the tiles left behind (usually none) + the statistics for the next call
         st = be.launch(k_voxelize_dense_tiles<K, E>, dim3(dense_wgs), dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos,
                        (const unsigned*)rcls, (const unsigned*)ctab, out, (const unsigned*)dcount, (const unsigned*)dlist,
@@ -185,13 +193,13 @@ int launch_tiles_tier(BE& be, dim3 tgrid, unsigned dense_wgs, const GridDesc& g,
 }
 
 template <int K, class BE>
-int launch_tiles(BE& be, int tier, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+int launch_tiles(BE& be, int tier, bool lean, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
                  void* ctab, float* out, unsigned* dcount, void* dlist)
 {
     switch (tier) {
-    case 0: return launch_tiles_tier<K, 0>(be, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
-    case 1: return launch_tiles_tier<K, 1>(be, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
-    default: return launch_tiles_tier<K, 2>(be, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    case 0: return launch_tiles_tier<K, 0>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    case 1: return launch_tiles_tier<K, 1>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    default: return launch_tiles_tier<K, 2>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
     }
 }
 
@@ -264,9 +272,10 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     unsigned* dcount = (unsigned*)count + ncells;
     const unsigned dense_wgs = total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u;
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
+    const bool lean = be.set_is_pipelined(set);        // leave registers for the next call's pre-pass
     be.hot_begin();
-    st = g.K == 8 ? launch_tiles<8>(be, tier, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist)
-                  : launch_tiles<4>(be, tier, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist);
+    st = g.K == 8 ? launch_tiles<8>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist)
+                  : launch_tiles<4>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist);
     be.hot_end();
     be.tile_done(set);
     return st;
