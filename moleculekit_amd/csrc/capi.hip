@@ -43,6 +43,9 @@ struct mkamd_ctx {
     hipEvent_t ev_inputs = nullptr;        // main -> side: the call's inputs are ready
     hipEvent_t ev_pre_done[2] = {};        // side -> main: workspace set s is filled
     hipEvent_t ev_tile_done[2] = {};       // main -> side: the tile kernel that read set s has finished
+    hipEvent_t inputs_marker = nullptr;    // the event the next pipelined pre-pass waits for (ev_inputs or a timing event)
+    hipEvent_t tile_marker[2] = {};        // ditto per workspace set (ev_tile_done[s] or a timing event)
+    hipEvent_t last_hot_end = nullptr;
     bool tile_pending[2] = {false, false};
     int next_set = 0;
     bool in_pipelined_prepass = false;
@@ -109,9 +112,9 @@ struct mkamd_ctx {
         next_set ^= 1;
         // Inputs must not depend on work enqueued after the PREVIOUS call's tile kernel (the opt-in contract of
         // mkamd_ctx_set_pipelining): the side stream is ordered after everything before that launch only.
-        if (!have_pre_tile_event) (void)hipEventRecord(ev_inputs, main_stream);
-        (void)hipStreamWaitEvent(side_stream, ev_inputs, 0);
-        if (tile_pending[set]) (void)hipStreamWaitEvent(side_stream, ev_tile_done[set], 0);
+        if (!have_pre_tile_event) { (void)hipEventRecord(ev_inputs, main_stream); inputs_marker = ev_inputs; }
+        (void)hipStreamWaitEvent(side_stream, inputs_marker, 0);
+        if (tile_pending[set]) (void)hipStreamWaitEvent(side_stream, tile_marker[set], 0);
         stream = side_stream;
         in_pipelined_prepass = true;
         return set;
@@ -123,32 +126,42 @@ struct mkamd_ctx {
         (void)hipEventRecord(ev_pre_done[set], side_stream);
         stream = main_stream;
         (void)hipStreamWaitEvent(main_stream, ev_pre_done[set], 0);
-        (void)hipEventRecord(ev_inputs, main_stream);                 // "everything before this call's tile kernel"
-        have_pre_tile_event = true;
+        have_pre_tile_event = true;                                   // hot_begin() records the marker
     }
     void tile_done(int set)
     {
         if (!side_stream) return;
-        (void)hipEventRecord(ev_tile_done[set], main_stream);
+        if (last_hot_end) tile_marker[set] = last_hot_end;            // the timing event sits at the same place
+        else { (void)hipEventRecord(ev_tile_done[set], main_stream); tile_marker[set] = ev_tile_done[set]; }
+        last_hot_end = nullptr;
         tile_pending[set] = true;
         in_pipelined_prepass = false;
     }
+    // Events are barrier packets the command processor takes ~5 us each to retire, and they sit between one
+    // call's tile kernel and the next one's: the timing events double as the pipeline's markers when both exist.
     void hot_begin()
     {
-        if (!timing) return;
-        std::pair<hipEvent_t, hipEvent_t> ev;
-        if (!ev_free.empty()) { ev = ev_free.back(); ev_free.pop_back(); }
-        else {
-            if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return;
+        last_hot_end = nullptr;
+        if (timing) {
+            std::pair<hipEvent_t, hipEvent_t> ev;
+            bool ok = true;
+            if (!ev_free.empty()) { ev = ev_free.back(); ev_free.pop_back(); }
+            else ok = hipEventCreate(&ev.first) == hipSuccess && hipEventCreate(&ev.second) == hipSuccess;
+            if (ok) {
+                cur0 = ev.first; cur1 = ev.second;
+                (void)hipEventRecord(cur0, stream);
+                if (in_pipelined_prepass) inputs_marker = cur0;       // "everything before this call's tile kernel"
+                return;
+            }
         }
-        cur0 = ev.first; cur1 = ev.second;
-        (void)hipEventRecord(cur0, stream);
+        if (in_pipelined_prepass) { (void)hipEventRecord(ev_inputs, main_stream); inputs_marker = ev_inputs; }
     }
     void hot_end()
     {
         if (!timing || !cur0) return;
         (void)hipEventRecord(cur1, stream);
         ev_used.emplace_back(cur0, cur1);
+        last_hot_end = cur1;
         cur0 = cur1 = nullptr;
     }
 };

@@ -89,6 +89,33 @@ MK_DEV float sigma_to_w(SigT sigma, double w_scale)
     return (s != 0.0 && t == t) ? fminf(t, MK_W_MAX) : mk_inf();
 }
 
+// w of the (up to) CHG channels [c0, c0+CHG) of one atom.  An atom almost always carries ONE radius in
+// all the channels it has (sigma = radius x mask), so the double-precision division is done once for the
+// lane's first usable sigma and only atoms with several distinct sigmas take the per-channel path.
+// Values are exactly sigma_to_w's.
+template <typename SigT>
+MK_DEV void atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w_scale, float (&w)[CHG])
+{
+    SigT s[CHG];
+#pragma unroll
+    for (int j = 0; j < CHG; ++j) s[j] = (c0 + j < C) ? row[c0 + j] : (SigT)0;
+    SigT s0 = (SigT)0;
+#pragma unroll
+    for (int j = CHG - 1; j >= 0; --j) s0 = (s[j] != (SigT)0) ? s[j] : s0;
+    const float w0 = sigma_to_w(s0, w_scale);                    // +inf when the atom has no channel here
+    bool other = false;
+#pragma unroll
+    for (int j = 0; j < CHG; ++j) {
+        w[j] = (s[j] == s0) ? w0 : mk_inf();
+        other |= (s[j] != s0) && (s[j] != (SigT)0);
+    }
+    if (other) {                                                 // rare: several distinct sigmas (or NaN)
+#pragma unroll
+        for (int j = 0; j < CHG; ++j)
+            if ((s[j] != s0) && (s[j] != (SigT)0)) w[j] = sigma_to_w(s[j], w_scale);
+    }
+}
+
 // Class table: NCLS slots of w bit patterns (CLS_EMPTY = unused), word NCLS = overflow marker.
 // ------------------------------------------------------------------------------------------------
 // Class discovery: the distinct w values of the batch -> cls_table (<= NCLS, else the overflow word
@@ -164,6 +191,7 @@ MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned 
                                     unsigned rows_per_block, unsigned* __restrict__ out_sets,
                                     unsigned* __restrict__ cls_table /* non-null: final level */)
 {
+    mk_wave_priority_high();
     __shared__ unsigned s_set[MERGE_SET];
     __shared__ unsigned s_over;
     if (threadIdx.x < MERGE_SET) s_set[threadIdx.x] = CLS_EMPTY;
@@ -226,6 +254,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
                                 unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
 {
+    mk_wave_priority_high();
     __shared__ unsigned s_set[CLS_BLOCK_SET];
     __shared__ unsigned s_full;
     const bool classes = !g.force_general;
@@ -242,13 +271,14 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     bool any = false;
     for (int c0 = 0; c0 < g.C; c0 += CHG) {
         unsigned wb[CHG];
+        float w[CHG];
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) w[j] = mk_inf();
+        if (act) atom_channel_w(sigmas + (size_t)a * g.C, c0, g.C, g.w_scale, w);
 #pragma unroll
         for (int j = 0; j < CHG; ++j) {
             wb[j] = CLS_EMPTY;
-            if (act && c0 + j < g.C) {
-                const float w = sigma_to_w(sigmas[(size_t)a * g.C + c0 + j], g.w_scale);
-                if (w < mk_inf()) { wb[j] = mk_float_bits(w); any = true; }
-            }
+            if (w[j] < mk_inf()) { wb[j] = mk_float_bits(w[j]); any = true; }
         }
         if (classes) wave_register_classes(wb, s_set, &s_full);
     }
@@ -341,6 +371,7 @@ MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
                                float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                                unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
 {
+    mk_wave_priority_high();
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)g.M) return;
     const uint2 ix = tmp_idx[t];
@@ -356,11 +387,7 @@ MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
     for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
     for (int gq = 0; gq < g.G; ++gq) {
         float w[CHG];
-#pragma unroll
-        for (int c = 0; c < CHG; ++c) {
-            const int ch = gq * CHG + c;
-            w[c] = ch < g.C ? sigma_to_w(sg[ch], g.w_scale) : mk_inf();
-        }
+        atom_channel_w(sg, gq * CHG, g.C, g.w_scale, w);
         if (general) {
             rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
             rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
@@ -423,6 +450,7 @@ MK_DEV unsigned block_scan_exclusive(unsigned v, unsigned* total, unsigned* lds 
 MK_KERNEL(SCAN_THREADS) void k_scan_chunk_sums(const unsigned* __restrict__ in, size_t n,
                                                unsigned* __restrict__ chunk_sums)
 {
+    mk_wave_priority_high();
     __shared__ unsigned lds[8];
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
     unsigned s = 0;
@@ -438,6 +466,7 @@ MK_KERNEL(SCAN_THREADS) void k_scan_chunk_sums(const unsigned* __restrict__ in, 
 
 MK_KERNEL(SCAN_THREADS) void k_scan_sums_inplace(unsigned* __restrict__ chunk_sums, unsigned nchunks)
 {
+    mk_wave_priority_high();
     __shared__ unsigned lds[8];
     unsigned carry = 0;
     for (unsigned base = 0; base < nchunks; base += SCAN_THREADS) {
@@ -454,6 +483,7 @@ MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size
                                            const unsigned* __restrict__ chunk_offsets,
                                            unsigned* __restrict__ out /* n+1 */)
 {
+    mk_wave_priority_high();
     __shared__ unsigned lds[8];
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     unsigned v[SCAN_PER_THREAD];

@@ -69,6 +69,10 @@ MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { return 
 MK_DEV float mk_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }                        // v_fma_f32, never split
 // LDS atomic add, returns the old value (ds_add_rtn_u32)
 MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+// instruction-issue priority of this wave on its SIMD (s_setprio 0..3): the small latency-bound pre-pass
+// kernels raise it so that they are not starved of issue slots by the VALU-saturating tile kernel of the
+// previous call when the two overlap
+MK_DEV void mk_wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
 // value of `v` in lane `lane` (wave-uniform index) -> SGPR (v_readlane_b32)
 MK_DEV unsigned mk_readlane(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
 

@@ -105,6 +105,19 @@ def case_ragged_batch():
     return _case(np.concatenate(coords), offs, sig, origins, [13, 9, 21], 1.0)
 
 
+def case_tiny_items():
+    """Hundreds of tiny (and empty) items: one binning block spans far more cells than its LDS
+    counters hold (-> it ranks with global atomics), the next ones straddle item boundaries;
+    the last items are bigger, so that later blocks span few items (-> LDS ranking)."""
+    rng = np.random.default_rng(27)
+    ns = list(rng.integers(0, 13, size=420)) + [700, 900, 1500]
+    coords = [rng.normal(0, 3.0, size=(n, 3)).astype(np.float32) for n in ns]
+    sig = np.concatenate([synth_sigmas(rng, n) for n in ns])
+    offs = np.concatenate([[0], np.cumsum(ns)])
+    origins = rng.uniform(-7, -5, size=(len(ns), 3))
+    return _case(np.concatenate(coords), offs, sig, origins, [12, 10, 9], 1.0)
+
+
 def case_voxel07():
     """Non-dyadic voxel size (0.7 A) and a grid smaller than one tile."""
     rng = np.random.default_rng(22)
@@ -187,6 +200,7 @@ LATTICE_CASES = {
     "pbc_small": case_pbc_small,
     "celecoxib_bbox": case_celecoxib_bbox,
     "ragged_batch": case_ragged_batch,
+    "tiny_items": case_tiny_items,
     "voxel07": case_voxel07,
     "voxel025": case_voxel025,
     "channels1": lambda: case_channels(1),

@@ -189,6 +189,7 @@ MK_DEV unsigned mk_load_relaxed(unsigned* p) { return *p; }
 MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
 MK_DEV float mk_fma(float a, float b, float c) { return fmaf(a, b, c); }
 MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+MK_DEV void mk_wave_priority_high() {}
 MK_DEV unsigned mk_readlane(unsigned v, int lane)
 {
     const int wv = (int)threadIdx.x >> 6;
