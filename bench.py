@@ -70,6 +70,24 @@ def make_workload(name, batch, seed):
     return p, origins, nv
 
 
+def pmc_traffic(workload, batch, tile_k):
+    """HBM bytes per launch of the tile kernel from the committed PMC passes (rocprofv3 cannot run inside
+    the bench): profiles/r*_<workload>_pmc_counters.json, WRITE_SIZE + 2 x FETCH_SIZE KiB (the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md, HBM section). None when no pass exists for this
+    workload / batch (the passes are taken at the default batch)."""
+    import glob
+    if batch != DEFAULT_BATCH[workload] or tile_k not in (0, 8):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_counters.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    for k, v in d.items():
+        if "k_voxelize_tiles<8" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024), os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def algorithmic_bytes(p, nv, C=8):
     """per grid V*C*4 (one float32 write per voxel-channel) + N*(12 + 4*C)
     (coords + per-channel sigmas read once); summed over the batch."""
@@ -235,6 +253,7 @@ def main():
         k_avg_ms = k_ms / max(k_n, 1)
         achieved = alg / (k_avg_ms * 1e-3) / 1e9 if k_n else None
         info = ctx.device_info()
+        traffic, traffic_src = pmc_traffic(args.workload, B, args.tile_k)
         line = {
             "metric": "Mvoxel-channels/s (64^3 grid, 8 ch)" if args.workload == "cfg2" else f"Mvoxel-channels/s ({args.workload})",
             "value": round(total_vc / elapsed / 1e6, 2),
@@ -250,7 +269,7 @@ def main():
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                         "traffic": None, "kernel": "k_voxelize_tiles", "kernel_avg_ms": round(k_avg_ms, 5),
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_voxelize_tiles (+ dense pass)", "kernel_avg_ms": round(k_avg_ms, 5),
                          "kernel_launches": int(k_n), "algorithmic_bytes_per_launch": int(alg)},
             "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if k_n else None,
             "single_grid_latency_us": round(single_us, 2) if single_us else None,
