@@ -633,10 +633,13 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
     // (measured: 1.25 -> 2 -> 2.75 -> 3.25 waves/SIMD = 0.69 -> 0.48 -> 0.43 -> 0.40 ms on cfg2), hence
     // the lean ~9.3 KiB budget.
-    __shared__ __attribute__((aligned(16))) float sx[ECAP + 2];
-    __shared__ __attribute__((aligned(16))) float sy[ECAP + 2];
-    __shared__ __attribute__((aligned(16))) float sz[ECAP + 2];
-    float4* const ebuf = reinterpret_cast<float4*>(sx);   // general path: one chunk's entries of one channel (x,y,z,w)
+    // One object, so that the pair loop addresses x, y and z from ONE register with constant offsets.
+    constexpr int ESTRIDE = (ECAP + 2 + 3) & ~3;          // floats per coordinate array (16-byte multiple)
+    __shared__ __attribute__((aligned(16))) float sxyz[3 * ESTRIDE];
+    float* const sx = sxyz;
+    float* const sy = sxyz + ESTRIDE;
+    float* const sz = sxyz + 2 * ESTRIDE;
+    float4* const ebuf = reinterpret_cast<float4*>(sxyz);   // general path: one chunk's entries of one channel (x,y,z,w)
 #ifdef MK_LDS_PAD                                  // occupancy experiment knob (tools/): waste LDS on purpose
     __shared__ unsigned lds_pad[MK_LDS_PAD / 4];
     if (g.nx < 0) lds_pad[threadIdx.x] = 1u, out[0] = (float)lds_pad[(threadIdx.x + 1) & 63];
@@ -657,6 +660,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     }
     const int ly = lane >> 3, lz = lane & 7;
     const float Y = (float)ly - 3.5f, Z = (float)lz - 3.5f;
+    const mk_f2 Y2 = mk_f2_splat(Y), Z2 = mk_f2_splat(Z);
     constexpr float HX = 0.5f * (float)(K - 1);
     const float R2 = g.R2, INF = mk_inf();
     constexpr unsigned INF_BITS = 0x7f800000u;
@@ -756,7 +760,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 const int cls = __builtin_ctz(bits);
                 bits &= bits - 1u;
                 const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
-                const uint4 bg = make_uint4(bgp[0], bgp[1], bgp[2], bgp[3]);
+                const uint4 bg = make_uint4(mk_uniform(bgp[0]), mk_uniform(bgp[1]), mk_uniform(bgp[2]), mk_uniform(bgp[3]));
                 const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
                 unsigned m[K];
 #pragma unroll
@@ -766,17 +770,18 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
                     //  have to be merged after every one of these short runs -- measured 7 % slower)
+                    const float* e = sxyz + s0;
 #pragma clang loop vectorize(disable) interleave(disable)
-                    for (unsigned i = s0; i < e0; i += 2) {
-                        const float2 px = *reinterpret_cast<const float2*>(&sx[i]);   // i is even: 8-byte aligned
-                        const float2 py = *reinterpret_cast<const float2*>(&sy[i]);
-                        const float2 pz = *reinterpret_cast<const float2*>(&sz[i]);
-                        const float dya = Y - py.x, dza = Z - pz.x, dyb = Y - py.y, dzb = Z - pz.y;
-                        const float ra = mk_fma(dya, dya, dza * dza), rb = mk_fma(dyb, dyb, dzb * dzb);
+                    for (unsigned n = (e0 - s0) >> 1; n != 0u; --n, e += 2) {
+                        // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
+                        const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
+                        const mk_f2 dy = Y2 - py, dz = Z2 - pz;
+                        const mk_f2 r = mk_f2_fma(dy, dy, dz * dz);
 #pragma unroll
                         for (int k = K0; k < K1; ++k) {
-                            const float dxa = ((float)k - HX) - px.x, dxb = ((float)k - HX) - px.y;
-                            m[k] = mk_min3_bits(m[k], mk_fma(dxa, dxa, ra), mk_fma(dxb, dxb, rb));
+                            const mk_f2 dx = mk_f2_splat((float)k - HX) - px;
+                            const mk_f2 d2 = mk_f2_fma(dx, dx, r);
+                            m[k] = mk_min3_bits(m[k], d2[0], d2[1]);
                         }
                     }
                 };

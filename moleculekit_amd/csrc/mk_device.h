@@ -46,6 +46,15 @@ MK_DEV unsigned mk_min_bits(unsigned q, float t)
 }
 MK_DEV float mk_uint_as_float(unsigned u) { return __uint_as_float(u); }
 MK_DEV unsigned mk_float_bits(float f) { return __float_as_uint(f); }
+// v is the same in every lane (e.g. loaded from a wave-uniform LDS address): move it to a scalar register so
+// that loop counters / branches on it are scalar
+MK_DEV unsigned mk_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+// two floats processed by one packed instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: IEEE results,
+// identical to the scalar ops)
+typedef float mk_f2 __attribute__((ext_vector_type(2)));
+MK_DEV mk_f2 mk_f2_splat(float v) { return mk_f2{v, v}; }
+MK_DEV mk_f2 mk_f2_fma(mk_f2 a, mk_f2 b, mk_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+MK_DEV mk_f2 mk_f2_load(const float* p8) { return *reinterpret_cast<const mk_f2*>(p8); }   // 8-byte aligned
 // running bit-pattern minimum with TWO non-negative floats (v_min3_u32)
 MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
 {

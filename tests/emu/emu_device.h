@@ -171,6 +171,11 @@ MK_DEV float mk_rcp(float x) { return 1.0f / x; }
 MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+MK_DEV unsigned mk_uniform(unsigned v) { return v; }
+typedef float mk_f2 __attribute__((vector_size(8)));
+MK_DEV mk_f2 mk_f2_splat(float v) { return mk_f2{v, v}; }
+MK_DEV mk_f2 mk_f2_fma(mk_f2 a, mk_f2 b, mk_f2 c) { return mk_f2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
+MK_DEV mk_f2 mk_f2_load(const float* p8) { mk_f2 v; memcpy(&v, p8, 8); return v; }
 MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
 {
     const unsigned ua = mk_float_bits(a), ub = mk_float_bits(b);
