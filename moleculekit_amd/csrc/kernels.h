@@ -983,12 +983,12 @@ MK_KERNEL(64) void k_voxelize_tiles(GridDesc g, const unsigned* __restrict__ cel
     voxelize_tile<K, false, ECAP>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
 }
 
-// Same kernel held to 96 VGPRs (5 waves/SIMD worth; LDS still admits ~4): the registers it leaves free on
-// every SIMD are what lets the binning pre-pass of the NEXT call run beside it (with the full-size
-// variant the register file is 100 % allocated and the other queue starves until the grid drains).
-// Costs ~4 % of the tile kernel (cold-path spills), wins ~7 % on pipelined calls.
+// Same kernel held to 104 VGPRs (amdgpu_num_vgpr counts register PAIRS on gfx90a+: 52 -> 104): the ~100
+// registers it leaves free on every SIMD are what lets the binning pre-pass of the NEXT call run beside it
+// (at 122 -> 128 allocated x 4 waves the register file is 100 % taken and the other queue starves until the
+// grid drains).  Costs ~3 % of the tile kernel (a dozen cold-path spills), wins 5-13 % on pipelined calls.
 template <int K, int ECAP>
-__attribute__((amdgpu_waves_per_eu(5, 8))) MK_KERNEL(64) void k_voxelize_tiles_lean(GridDesc g, const unsigned* __restrict__ cell_start,
+__attribute__((amdgpu_num_vgpr(52))) MK_KERNEL(64) void k_voxelize_tiles_lean(GridDesc g, const unsigned* __restrict__ cell_start,
                                     const float4* __restrict__ rec_pos,
                                     const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
                                     const unsigned* __restrict__ cls_table, float* __restrict__ out,

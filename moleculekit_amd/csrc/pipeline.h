@@ -176,7 +176,7 @@ int launch_tiles_tier(BE& be, bool lean, dim3 tgrid, unsigned dense_wgs, const G
 {
     constexpr int E = ECAP_TIER[T];
     int st;
-    if constexpr (T == 0) {           // the bigger tiers are LDS-bound to fewer waves anyway: no lean instance of them
+    if constexpr (T <= 1) {           // the biggest tier is LDS-bound to < 3 waves/SIMD anyway: no lean instance of it
         st = lean ? be.launch(k_voxelize_tiles_lean<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                               (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist)
                   : be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
