@@ -11,9 +11,10 @@ Return order is the reference's: ``(features, centers)`` with ``usercenters`` el
 ``(features, centers, nvoxels)``; features float64 ``[V, C]`` (float32-accurate values, <= 1e-5
 from the reference's float64), V flattened x slowest / z fastest, channel order ``_order``.
 
-Out of scope here: automatic atom typing (``getChannels``), which the
-reference builds on RDKit/OpenBabel -- pass ``userchannels`` (bool masks or float sigmas), or have
-moleculekit installed, in which case its own ``getChannels`` is used to produce them.
+Channels: pass ``userchannels`` (bool masks or float sigmas); without them the
+reference's own ``getChannels`` is used when moleculekit is importable, else the table-driven typing of
+``moleculekit_amd.channels`` (molecules that already carry PDBQT atom types).  Assigning atom types
+(OpenBabel) and SmallMol typing (RDKit) are outside this package.
 """
 from __future__ import annotations
 
@@ -90,15 +91,20 @@ def getCenters(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
     return centers, nvoxels
 
 
-def _channels_from_moleculekit(mol, aromaticNitrogen, version, validitychecks):
+def getChannels(mol, aromaticNitrogen=False, version=2, validitychecks=True):
+    """Property channels of a molecule (voxeldescriptors.py:135-194): the reference's own implementation
+    when moleculekit is importable (it can re-type with OpenBabel / RDKit), else the table-driven typing
+    of ``moleculekit_amd.channels`` for molecules that already carry PDBQT atom types."""
     try:
-        from moleculekit.tools.voxeldescriptors import getChannels
-    except Exception as e:  # pragma: no cover - depends on the user's environment
-        raise NotImplementedError(
-            "Automatic channel assignment (getChannels: RDKit/OpenBabel atom typing) is outside this "
-            "package's scope; pass `userchannels` (bool masks or float sigmas), or install moleculekit "
-            "so its getChannels can be used.") from e
-    return getChannels(mol, aromaticNitrogen, version, validitychecks)
+        from moleculekit.tools.voxeldescriptors import getChannels as ref_getChannels
+    except Exception:  # depends on the user's environment
+        from .channels import getChannels as table_getChannels
+
+        return table_getChannels(mol, aromaticNitrogen, version, validitychecks)
+    return ref_getChannels(mol, aromaticNitrogen, version, validitychecks)
+
+
+_channels_from_moleculekit = getChannels
 
 
 def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, usercenters=None,

@@ -1,6 +1,8 @@
 """GPU tier (-m gpu): the reference-shaped Python API on top of the C ABI -- written to read like the
 reference's own tests (tests/test_voxeldescriptors.py): compute, load the stored reference result,
 np.allclose / np.array_equal."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,3 +138,25 @@ def test_fused_rotation_augmentation_on_device():
     exp = oracle_lattice(rc, case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
     assert np.abs(got - exp).max() <= TOL
     assert np.abs(got - case["expected"]).max() > 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", [1, 2])
+def test_getvoxeldescriptors_types_channels_itself_for_pdbqt_molecules(version):
+    """No `userchannels`: the channels come from the molecule's PDBQT atom types (moleculekit_amd.channels; the
+    real moleculekit's getChannels would be used if it were importable).  Expected = oracle on the sigma
+    channels the REFERENCE's typing produced for the same molecule (tests/golden/channels_3ptb.npz)."""
+    import copy
+
+    from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "channels_3ptb.npz"))
+    mol = Mol(g["coords"], element=g["element"])
+    mol.atomtype, mol.name, mol.resname, mol.charge, mol.bonds = g["atomtype"], g["name"], g["resname"], g["charge"], g["bonds"]
+    mol.copy = lambda: copy.copy(mol)
+    center = g["coords"].mean(0).astype(np.float64)
+    feats, centers, nvox = getVoxelDescriptors(mol, boxsize=[16, 16, 16], center=center, voxelsize=1, version=version)
+    sig = g["channels_v1"] if version == 1 else g["radii"][:, None] * g["feats_v2"].astype(float)
+    from oracle import oracle
+    want = oracle.calculate_occupancy(centers, g["coords"], sig)
+    assert feats.shape == want.shape == (16 ** 3, 8)
+    assert np.abs(feats - want).max() <= 1e-5
