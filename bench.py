@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector FP32 peak (secondary roofline: cfg2/cfg4 are VALU-bound)
 
-DEFAULT_BATCH = {"cfg1": 1024, "cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096}
+DEFAULT_BATCH = {"cfg1": 1024, "cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096, "dist": 2048}
 
 
 def real_protein_config(batch, seed):
@@ -125,6 +125,66 @@ def cpu_baseline(name):
             "host_cores_available": os.cpu_count()}
 
 
+def bench_distances(args):
+    """Secondary workload (`--workload dist`): `dist_trajectory` on an HBM-resident
+    trajectory, 30 000 atoms x F frames (reference layout [N,3,F]), 200 x 500 atom pairs, periodic by chain.
+    Output-bound: algorithmic bytes = 4 B per (frame, pair) written + the selected atoms' coordinates read once.
+    The cpu_baseline leg times the oracle on the first 64 frames and doubles as a bit-exactness check."""
+    import torch
+    from moleculekit_amd import _lib
+    N, F, n1, n2 = 30000, args.batch or DEFAULT_BATCH["dist"], 200, 500
+    rng = np.random.default_rng(4)
+    dev = torch.device("cuda", 0)
+    coords = torch.rand((N, 3, F), device=dev, dtype=torch.float32) * 66.9
+    box = torch.full((3, F), 66.9, device=dev, dtype=torch.float32)
+    chains_h = (np.arange(N) // 1000).astype(np.uint32)
+    chains = torch.as_tensor(chains_h.astype(np.int32), device=dev)
+    s1 = np.sort(rng.choice(N, n1, replace=False)).astype(np.uint32)
+    s2 = np.sort(rng.choice(N, n2, replace=False)).astype(np.uint32)
+    d1, d2 = torch.as_tensor(s1.astype(np.int32), device=dev), torch.as_tensor(s2.astype(np.int32), device=dev)
+    out = torch.empty((F, n1 * n2), device=dev, dtype=torch.float32)
+    ctx = _lib.default_context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2,
+                                chains.data_ptr(), False, True, False, out.data_ptr())
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the kernel
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    k_ms = e0.elapsed_time(e1) / args.steps
+    ndist = F * n1 * n2
+    alg = ndist * 4 + (n1 + n2) * 3 * F * 4 + 3 * F * 4
+    line = {"metric": "Mdist/s (dist_trajectory, periodic by chain)", "value": round(ndist * args.steps / elapsed / 1e6, 1),
+            "unit": "Mdist/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"},
+            "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_dist_pairs",
+                         "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        Fs = min(64, F)
+        csub, bsub = coords[:, :, :Fs].contiguous().cpu().numpy(), box[:, :Fs].contiguous().cpu().numpy()
+        t0 = time.perf_counter()
+        ref = oracle.dist_trajectory(csub, bsub, s1, s2, chains_h, False, True)
+        cpu_s = time.perf_counter() - t0
+        if not np.array_equal(out[:Fs].cpu().numpy(), ref):
+            raise SystemExit("dist_trajectory on the GPU is not bit-exact with the oracle")
+        line["cpu_baseline"] = {"value": round(Fs * n1 * n2 / cpu_s / 1e6, 2), "unit": "Mdist/s", "cores": 1, "kind": "port",
+                                "sample": f"first {Fs} frames of the same workload (also checked bit-exact)"}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +199,11 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap step n+1's binning pre-pass with step n's tile kernel")
     args = ap.parse_args()
+
+    if args.workload == "dist":
+        if args.gpus != 1:
+            raise SystemExit("--workload dist is a single-GPU secondary bench")
+        return bench_distances(args)
 
     import torch
     import torch.distributed as dist

@@ -19,7 +19,7 @@ for v in prof_cfg2 prof_cfg2_nopipe; do
   f=$(find gpurun_out/$v -name "*kernel_trace.csv" | head -1)
   python tools/timeline.py $f 12 2 > gpurun_out/timeline_$v.txt 2>&1
 done
-(timeout 300 python tools/bench_distance.py > gpurun_out/bench_distance.log 2>&1; echo "rc=$?" >> gpurun_out/bench_distance.log)
+(timeout 300 python bench.py --workload dist > gpurun_out/bench_distance.log 2>&1; echo "rc=$?" >> gpurun_out/bench_distance.log)
 (./.variants/ubench_mem > gpurun_out/ubench_mem.txt 2>&1)
 tail -3 gpurun_out/smoke.log; tail -4 gpurun_out/pytest_gpu.log
 python tools/summarize.py
