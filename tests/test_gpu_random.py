@@ -1,0 +1,73 @@
+"""GPU tier: seeded random configurations through every execution variant of the lattice path.
+
+For each configuration (batch size, ragged atom counts incl. empty items, density from sparse to far denser
+than any LDS tier, voxel size, odd grid shapes, 1..12 channels, few / many sigma classes, optional periodic
+boxes) the result must (a) stay within TOL of the oracle and (b) for a given tile depth K be BIT-IDENTICAL
+whatever the LDS tier and the class-sorted / general / dense path -- those variants only change how the same
+minima are scheduled.  (K itself moves the tile centre the coordinates are made relative to, i.e. the
+rounding of the last bit: K = 4 and K = 8 agree to ~1e-7, not bitwise.)"""
+import numpy as np
+import pytest
+
+from tests.cases import TOL, oracle_lattice
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(seed):
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 9))
+    vs = float(rng.choice([0.5, 0.7, 1.0, 1.0, 1.5, 2.0]))
+    nv = rng.integers(3, 21, size=3)
+    C = int(rng.choice([1, 3, 8, 8, 8, 12]))
+    extent = nv * vs
+    density = float(rng.choice([0.002, 0.02, 0.1, 0.1, 0.4]))            # atoms / A^3 (0.4: tiles over every tier)
+    span = extent + 12.0
+    nmean = min(int(density * np.prod(span)), 6000)
+    ns = [int(n) for n in rng.integers(0, 2 * nmean + 2, size=B)]
+    if seed % 3 == 0:
+        ns[int(rng.integers(0, B))] = 0
+    pbc = seed % 4 == 1
+    origins = rng.uniform(-5, 5, size=(B, 3))
+    coords, box = [], None
+    if pbc:
+        box = np.maximum(rng.uniform(0.6, 1.4, size=(B, 3)) * span, 10.5).astype(np.float32)
+    for b, n in enumerate(ns):
+        lo = origins[b] - 6.0
+        c = lo + rng.random((n, 3)) * span
+        if pbc:
+            c += rng.integers(-2, 3, size=(n, 3)) * box[b]                # unwrapped coordinates
+        coords.append(c.astype(np.float32))
+    n_classes = int(rng.choice([1, 3, 5, 40]))                            # 40 > 15: general path for the whole call
+    radii = rng.uniform(0.9, 2.3, size=n_classes)
+    N = sum(ns)
+    sig = radii[rng.integers(0, n_classes, size=(N, 1))] * (rng.random((N, C)) < rng.uniform(0.1, 0.9))
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    cc = np.concatenate(coords) if N else np.zeros((0, 3), np.float32)
+    return dict(coords=cc, atom_offsets=offs, sigmas=sig, origins=origins, nvoxels=nv.astype(np.int64), voxelsize=vs, box=box)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_all_variants(hip_ctx, seed):
+    from moleculekit_amd import batch
+    k = _config(seed)
+    args = (k["coords"], k["atom_offsets"], k["sigmas"], k["origins"], k["nvoxels"], k["voxelsize"])
+    base = batch.voxelize_lattice(*args, box=k["box"], ctx=hip_ctx)
+    want = oracle_lattice(k["coords"], k["atom_offsets"], k["sigmas"].astype(np.float64), k["origins"], k["nvoxels"],
+                          k["voxelsize"], k["box"])
+    assert base.shape == want.shape
+    assert np.abs(base - want).max(initial=0.0) <= TOL
+    try:
+        for tile_k in (4, 8):
+            ref = None
+            for tier, general in [(0, False), (1, False), (2, False), (-1, False), (-1, True)]:
+                hip_ctx.set_tile_k(tile_k); hip_ctx.set_lds_tier(tier); hip_ctx.set_force_general(general)
+                got = batch.voxelize_lattice(*args, box=k["box"], ctx=hip_ctx)
+                if ref is None:
+                    ref = got
+                    assert np.abs(got - want).max(initial=0.0) <= TOL
+                    assert np.abs(got - base).max(initial=0.0) <= 2e-6
+                else:
+                    assert np.array_equal(got, ref), (tile_k, tier, general)
+    finally:
+        hip_ctx.set_tile_k(0); hip_ctx.set_lds_tier(-1); hip_ctx.set_force_general(False)
