@@ -187,17 +187,16 @@ constexpr int MERGE_SET = 64;                      // capacity of the merge kern
 // Merge `rows_per_block` sets of `row_words` words each into one 64-word set per block.
 // Level 1: grid = ceil(nrows / rows_per_block) blocks over the per-block sets of k_bin_count;
 // level 2: one block over level 1's output, which also writes the final class table.
-MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned nrows, unsigned row_words,
-                                    unsigned rows_per_block, unsigned* __restrict__ out_sets,
-                                    unsigned* __restrict__ cls_table /* non-null: final level */)
+MK_DEV void merge_classes_block(const unsigned* __restrict__ rows, unsigned nrows, unsigned row_words,
+                                unsigned rows_per_block, unsigned* __restrict__ out_sets,
+                                unsigned* __restrict__ cls_table /* non-null: final level */, unsigned block)
 {
-    mk_wave_priority_high();
     __shared__ unsigned s_set[MERGE_SET];
     __shared__ unsigned s_over;
     if (threadIdx.x < MERGE_SET) s_set[threadIdx.x] = CLS_EMPTY;
     if (threadIdx.x == 0) s_over = 0u;
     mk_block_sync();
-    const unsigned r0 = blockIdx.x * rows_per_block;
+    const unsigned r0 = block * rows_per_block;
     const unsigned r1 = r0 + rows_per_block < nrows ? r0 + rows_per_block : nrows;
     const unsigned w0 = r0 * row_words, w1 = r1 * row_words;               // multiples of 4 words
     const uint4* __restrict__ v4 = reinterpret_cast<const uint4*>(rows);
@@ -214,7 +213,7 @@ MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned 
     mk_block_sync();
     if (cls_table == nullptr) {
         if (threadIdx.x < MERGE_SET)
-            out_sets[(size_t)blockIdx.x * MERGE_SET + threadIdx.x] = s_over ? CLS_TOO_MANY : s_set[threadIdx.x];
+            out_sets[(size_t)block * MERGE_SET + threadIdx.x] = s_over ? CLS_TOO_MANY : s_set[threadIdx.x];
     } else if (threadIdx.x == 0) {
         unsigned n = 0;
         bool over = s_over != 0u;
@@ -228,6 +227,14 @@ MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned 
         for (unsigned i = n; i < (unsigned)NCLS; ++i) cls_table[i] = CLS_EMPTY;
         cls_table[CLS_OVERFLOW] = over ? 0u : CLS_EMPTY;
     }
+}
+
+MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned nrows, unsigned row_words,
+                                    unsigned rows_per_block, unsigned* __restrict__ out_sets,
+                                    unsigned* __restrict__ cls_table /* non-null: final level */)
+{
+    mk_wave_priority_high();
+    merge_classes_block(rows, nrows, row_words, rows_per_block, out_sets, cls_table, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -447,12 +454,10 @@ MK_DEV unsigned block_scan_exclusive(unsigned v, unsigned* total, unsigned* lds 
     return woff + incl - v;
 }
 
-MK_KERNEL(SCAN_THREADS) void k_scan_chunk_sums(const unsigned* __restrict__ in, size_t n,
-                                               unsigned* __restrict__ chunk_sums)
+MK_DEV void scan_chunk_sums_block(const unsigned* __restrict__ in, size_t n, unsigned* __restrict__ chunk_sums, unsigned block)
 {
-    mk_wave_priority_high();
     __shared__ unsigned lds[8];
-    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+    const size_t base = (size_t)block * SCAN_CHUNK;
     unsigned s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_PER_THREAD; ++j) {
@@ -461,12 +466,11 @@ MK_KERNEL(SCAN_THREADS) void k_scan_chunk_sums(const unsigned* __restrict__ in, 
     }
     unsigned tot;
     (void)block_scan_exclusive(s, &tot, lds);
-    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = tot;
+    if (threadIdx.x == 0) chunk_sums[block] = tot;
 }
 
-MK_KERNEL(SCAN_THREADS) void k_scan_sums_inplace(unsigned* __restrict__ chunk_sums, unsigned nchunks)
+MK_DEV void scan_sums_inplace_block(unsigned* __restrict__ chunk_sums, unsigned nchunks)
 {
-    mk_wave_priority_high();
     __shared__ unsigned lds[8];
     unsigned carry = 0;
     for (unsigned base = 0; base < nchunks; base += SCAN_THREADS) {
@@ -477,6 +481,46 @@ MK_KERNEL(SCAN_THREADS) void k_scan_sums_inplace(unsigned* __restrict__ chunk_su
         if (i < nchunks) chunk_sums[i] = carry + ex;
         carry += tot;
     }
+}
+
+MK_KERNEL(SCAN_THREADS) void k_scan_chunk_sums(const unsigned* __restrict__ in, size_t n,
+                                               unsigned* __restrict__ chunk_sums)
+{
+    mk_wave_priority_high();
+    scan_chunk_sums_block(in, n, chunk_sums, blockIdx.x);
+}
+
+MK_KERNEL(SCAN_THREADS) void k_scan_sums_inplace(unsigned* __restrict__ chunk_sums, unsigned nchunks)
+{
+    mk_wave_priority_high();
+    scan_sums_inplace_block(chunk_sums, nchunks);
+}
+
+// The lattice pre-pass runs the two independent reductions that follow the binning -- sigma classes (two
+// merge levels) and the cell-count scan (chunk sums, scan of the sums) -- side by side in two launches
+// instead of five: each launch boundary is ~5 us of dependent latency on a chain that is latency-bound.
+//   stage 1: blocks [0, nl1) merge groups of per-block sigma sets, blocks [nl1, nl1+nchunks) sum count chunks
+//   stage 2: block 0 merges the level-1 sets into the class table, the other block scans the chunk sums
+static_assert(SCAN_THREADS == 256, "the fused pre-pass kernels run both jobs with 256 threads");
+MK_KERNEL(256) void k_prepass_reduce1(const unsigned* __restrict__ block_sets, unsigned nblk, unsigned rows_per_block,
+                                      unsigned nl1, unsigned* __restrict__ l1sets,
+                                      const unsigned* __restrict__ counts, size_t n, unsigned* __restrict__ chunk_sums)
+{
+    mk_wave_priority_high();
+    if (blockIdx.x < nl1)                                              // block-uniform
+        merge_classes_block(block_sets, nblk, (unsigned)CLS_BLOCK_SET, rows_per_block, l1sets, nullptr, blockIdx.x);
+    else
+        scan_chunk_sums_block(counts, n, chunk_sums, blockIdx.x - nl1);
+}
+
+MK_KERNEL(256) void k_prepass_reduce2(const unsigned* __restrict__ l1sets, unsigned nl1, unsigned* __restrict__ cls_table,
+                                      unsigned* __restrict__ chunk_sums, unsigned nchunks)
+{
+    mk_wave_priority_high();
+    if (nl1 != 0u && blockIdx.x == 0)                                  // block-uniform
+        merge_classes_block(l1sets, nl1, (unsigned)MERGE_SET, nl1, nullptr, cls_table, 0u);
+    else
+        scan_sums_inplace_block(chunk_sums, nchunks);
 }
 
 MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size_t n,

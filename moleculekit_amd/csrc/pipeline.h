@@ -246,15 +246,21 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                                       P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
         if (st) return st;
     }
-    if (P.total_atoms > 0 && !g.force_general) {                      // per-block sigma sets -> class table
-        if ((st = be.launch(k_merge_classes, dim3(nl1), dim3(256), (const unsigned*)bsets, nblk, (unsigned)CLS_BLOCK_SET,
-                            rows_per_block, (unsigned*)l1sets, (unsigned*)nullptr))) return st;
-        if ((st = be.launch(k_merge_classes, dim3(1), dim3(256), (const unsigned*)l1sets, nl1, (unsigned)MERGE_SET,
-                            nl1, (unsigned*)nullptr, (unsigned*)ctab))) return st;
-    } else {
-        if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
+    // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
+    const bool do_classes = P.total_atoms > 0 && !g.force_general;
+    if (!do_classes && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
+    {
+        const size_t nchunks = (ncells + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        void* chunks = nullptr;
+        if ((st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set))) return st;
+        const unsigned nl1_eff = do_classes ? nl1 : 0u;
+        if ((st = be.launch(k_prepass_reduce1, dim3(nl1_eff + (unsigned)nchunks), dim3(256), (const unsigned*)bsets, nblk, rows_per_block,
+                            nl1_eff, (unsigned*)l1sets, (const unsigned*)count, ncells, (unsigned*)chunks))) return st;
+        if ((st = be.launch(k_prepass_reduce2, dim3(do_classes ? 2u : 1u), dim3(256), (const unsigned*)l1sets, nl1_eff, (unsigned*)ctab,
+                            (unsigned*)chunks, (unsigned)nchunks))) return st;
+        if ((st = be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (const unsigned*)count, ncells,
+                            (const unsigned*)chunks, (unsigned*)start))) return st;
     }
-    if ((st = run_scan(be, (const unsigned*)count, ncells, (unsigned*)start, set))) return st;
     if (P.total_atoms > 0) {
         st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
                                       (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
