@@ -809,14 +809,16 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 unsigned m[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) m[k] = INF_BITS;
-                // planes [K0, K1) against the (even-length) entry range [s, e)
-                auto run = [&](auto k0_, auto k1_, unsigned s0, unsigned e0) {
+                // planes [K0, K1) against the entries of one sub-bucket: start words b0 (this) and b1 (next); the
+                // slots are padded to an even count, bit 0 of b0 says that the last slot is padding
+                auto run = [&](auto k0_, auto k1_, unsigned b0, unsigned b1) {
                     constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+                    const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
+                    const float* e = sxyz + s0;
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
                     //  have to be merged after every one of these short runs -- measured 7 % slower)
-                    const float* e = sxyz + s0;
 #pragma clang loop vectorize(disable) interleave(disable)
-                    for (unsigned n = (e0 - s0) >> 1; n != 0u; --n, e += 2) {
+                    for (unsigned n = (((b1 & ~1u) - s0) >> 1) - odd; n != 0u; --n, e += 2) {
                         // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
                         const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
                         const mk_f2 dy = Y2 - py, dz = Z2 - pz;
@@ -826,6 +828,15 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                             const mk_f2 dx = mk_f2_splat((float)k - HX) - px;
                             const mk_f2 d2 = mk_f2_fma(dx, dx, r);
                             m[k] = mk_min3_bits(m[k], d2[0], d2[1]);
+                        }
+                    }
+                    if (odd) {                                            // wave-uniform: the unpaired last entry
+                        const float px = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
+                        const float r = mk_fma(dy, dy, dz * dz);
+#pragma unroll
+                        for (int k = K0; k < K1; ++k) {
+                            const float dx = ((float)k - HX) - px;
+                            m[k] = mk_min_bits(m[k], mk_fma(dx, dx, r));
                         }
                     }
                 };
@@ -859,12 +870,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             mk_block_sync();                                                 // counts read; previous round done
             if (in_round) {
 #pragma unroll
-                for (int i = 0; i < 2 * NXR; ++i) {
-                    const unsigned s0 = start[i] - base;
-                    bucket[2 * NXR * lane + i] = s0;                             // placement cursors
-                    // odd sub-buckets get one far-away sentinel entry
-                    if (cnt[i] & 1u) { sx[s0 + cnt[i]] = 1.0e18f; sy[s0 + cnt[i]] = 0.f; sz[s0 + cnt[i]] = 0.f; }
-                }
+                for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i] - base;     // placement cursors
             }
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
@@ -878,12 +884,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     });
                 });
             mk_block_sync();
-            // cursors are dead now: the array becomes the table of sub-bucket starts (sub-buckets are
-            // contiguous, so a group's three ranges are four consecutive words; the word after the
+            // cursors are dead now: the array becomes the table of sub-bucket starts (even; bit 0 = "odd count, the
+            // last slot is padding"; sub-buckets are contiguous, so a group's three ranges are four consecutive words; the word after the
             // last group placed belongs to a channel outside the round, whose counts live in registers)
             if (in_round) {
 #pragma unroll
-                for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i] - base;
+                for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = (start[i] - base) | (cnt[i] & 1u);
             }
             if (lane == 0) bucket[c1 * NSLOT * NXR] = count;
             mk_block_sync();
