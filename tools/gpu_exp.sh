@@ -1,12 +1,13 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for rep in 1 2; do
-for v in base e704; do
-  for wl in cfg2 cfg1 cfg4; do
-    if [ $v = base ]; then L=""; else L="MKAMD_LIB=$R/.variants/libmkamd_$v.so"; fi
-    env $L timeout 300 python bench.py --no-cpu-baseline --workload $wl 2>/dev/null | python -c "
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+for wl in cfg1 cfg2 cfg3 cfg4 cfg5; do
+  timeout 300 python bench.py --no-cpu-baseline --workload $wl > gpurun_out/x_${wl}.log 2>&1
+  timeout 300 python bench.py --no-cpu-baseline --workload $wl --no-pipeline > gpurun_out/x_${wl}_nopipe.log 2>&1
+done
+for f in gpurun_out/x_cfg?.log gpurun_out/x_cfg?_nopipe.log; do echo "== $f"; tail -1 $f | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v $wl', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'])"
-  done
-done
-done
+try:
+    d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'])
+except Exception as e: print('ERR', e)
+"; done

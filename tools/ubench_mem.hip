@@ -80,8 +80,11 @@ static float time_ms(F&& launch, int reps = 20)
     return ms / reps;
 }
 
+void write_bench();
+
 int main()
 {
+    write_bench();
     const int n = 1600000;
     unsigned *idx_r, *idx_s, *cnt, *out, *perm;
     float *rows, *fout;
@@ -116,4 +119,50 @@ int main()
     printf("16-B scatter (random permutation)       %8.1f us\n", 1e3f * time_ms([&] { k_scatter16<<<nb, 256>>>(perm, src, dst, n); }));
     printf("16-B gather  (random permutation)       %8.1f us\n", 1e3f * time_ms([&] { k_gather16<<<nb, 256>>>(perm, src, dst, n); }));
     return 0;
+}
+
+// ---- write-bandwidth ceiling of the feature tensor: plain streaming float4 stores vs the tile kernel's
+//      pattern (lane = (y,z) of an 8x8 face, two float4 = 8 channels per voxel, K x-planes per wave) ----
+__global__ __launch_bounds__(256) void k_write_linear(float4* dst, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) dst[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+}
+__global__ __launch_bounds__(64) void k_write_tiles(float* out, int B, int nx, int ny, int nz, int tnx, int tny, int tnz)
+{
+    const int ntiles = tnx * tny * tnz;
+    const unsigned lt = blockIdx.x;
+    const int b = lt / ntiles;
+    int t = lt - b * ntiles;
+    const int tz = t % tnz; t /= tnz;
+    const int ty = t % tny, tx = t / tny;
+    const int ly = threadIdx.x >> 3, lz = threadIdx.x & 7;
+    const int y = ty * 8 + ly, z = tz * 8 + lz;
+    const size_t V = (size_t)nx * ny * nz;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = tx * 8 + k;
+        if (y < ny && z < nz && x < nx) {
+            float4* o = reinterpret_cast<float4*>(out + ((size_t)b * V + ((size_t)x * ny + y) * nz + z) * 8);
+            o[0] = make_float4(1.f, 2.f, 3.f, (float)k);
+            o[1] = make_float4(5.f, 6.f, 7.f, (float)x);
+        }
+    }
+}
+
+void write_bench()
+{
+    {
+        for (int cfg = 0; cfg < 2; ++cfg) {
+            const int B = cfg == 0 ? 1024 : 32, n = cfg == 0 ? 24 : 64;
+            const size_t bytes = (size_t)B * n * n * n * 32;
+            float* buf; CHECK(hipMalloc(&buf, bytes));
+            const int tn = (n + 7) / 8;
+            const float lin = time_ms([&] { k_write_linear<<<(unsigned)((bytes / 16 + 255) / 256), 256>>>((float4*)buf, bytes / 16); });
+            const float til = time_ms([&] { k_write_tiles<<<B * tn * tn * tn, 64>>>(buf, B, n, n, n, tn, tn, tn); });
+            printf("--- feature tensor %d x %d^3 x 8 ch (%.0f MB): linear float4 stores %.1f us = %.0f GB/s ; tile pattern %.1f us = %.0f GB/s\n",
+                   B, n, bytes / 1e6, lin * 1e3, bytes / lin / 1e6, til * 1e3, bytes / til / 1e6);
+            CHECK(hipFree(buf));
+        }
+    }
 }
