@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector FP32 peak (secondary roofline: cfg2/cfg4 are VALU-bound)
 
-DEFAULT_BATCH = {"cfg1": 1024, "cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096, "dist": 2048}
+DEFAULT_BATCH = {"cfg1": 1024, "cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096, "dist": 2048, "dropin": 1}
 
 
 def real_protein_config(batch, seed):
@@ -185,6 +185,36 @@ def bench_distances(args):
     print(json.dumps(line), flush=True)
 
 
+def bench_dropin(args):
+    """Secondary workload (`--workload dropin`): the drop-in call itself on BASELINE.json configs[0] (3PTB, 24^3
+    grid @ 1 A, 8 channels) -- host numpy arrays in, float64 [V, C] out, every call synchronous, PCIe both ways --
+    i.e. what a user who only swaps the import sees; next to the CPU port of the reference loop on the same grid."""
+    from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_3ptb.npz"))
+    kw = dict(boxsize=[24, 24, 24], center=g["center"], voxelsize=1, usercoords=g["coords"], userchannels=g["sigmas"])
+    for _ in range(max(args.warmup, 1)):
+        f, c, n = getVoxelDescriptors(None, **kw)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        f, c, n = getVoxelDescriptors(None, **kw)
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    V, C = f.shape
+    line = {"metric": "Mvoxel-channels/s (drop-in getVoxelDescriptors call, host arrays in/out)",
+            "value": round(V * C / ms / 1e3, 2), "unit": "Mvoxel-channels/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "reference fixture (3PTB)",
+            "config": {"workload": "dropin: BASELINE.json configs[0], one synchronous call per step, PCIe included"},
+            "max_abs_err_vs_reference": float(np.abs(f - g["features"]).max())}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        t0 = time.perf_counter()
+        oracle.calculate_occupancy(c, g["coords"], g["sigmas"])
+        cpu_s = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": round(V * C / cpu_s / 1e6, 4), "unit": "Mvoxel-channels/s", "cores": 1, "kind": "port",
+                                "sample": "the same grid, once", "ms": round(cpu_s * 1e3, 2)}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +230,8 @@ def main():
                     help="do not overlap step n+1's binning pre-pass with step n's tile kernel")
     args = ap.parse_args()
 
+    if args.workload == "dropin":
+        return bench_dropin(args)
     if args.workload == "dist":
         if args.gpus != 1:
             raise SystemExit("--workload dist is a single-GPU secondary bench")

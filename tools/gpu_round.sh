@@ -20,6 +20,7 @@ for v in prof_cfg2 prof_cfg2_nopipe; do
   python tools/timeline.py $f 12 2 > gpurun_out/timeline_$v.txt 2>&1
 done
 (timeout 300 python bench.py --workload dist > gpurun_out/bench_distance.log 2>&1; echo "rc=$?" >> gpurun_out/bench_distance.log)
+(timeout 300 python bench.py --workload dropin --steps 50 > gpurun_out/bench_dropin.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dropin.log)
 (./.variants/ubench_mem > gpurun_out/ubench_mem.txt 2>&1)
 tail -3 gpurun_out/smoke.log; tail -4 gpurun_out/pytest_gpu.log
 python tools/summarize.py
