@@ -58,6 +58,9 @@ struct mkamd_ctx {
     int lds_tier = -1;                     // -1 = adaptive
     unsigned* fb_host = nullptr;           // pinned, device-visible: tier statistics of the last finished call
     unsigned* fb_dev = nullptr;
+    bool err_mirrored = false;             // fb_host[NTIER+1] holds the error flag as of the last lattice call
+    void* stage_host = nullptr;            // pinned staging for the inputs of small _host calls (one H2D copy)
+    size_t stage_cap = 0;
     // tile-kernel timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
@@ -67,6 +70,7 @@ struct mkamd_ctx {
     // ---- backend concept (pipeline.h) ----
     const volatile unsigned* feedback_host() const { return fb_host; }
     unsigned* feedback_dev() const { return fb_dev; }
+    void note_error_flag_mirrored(bool yes) { err_mirrored = yes; }
     int ensure(int slot, size_t bytes, void** ptr, int set = 0)
     {
         slot += set * WS_NSLOTS;
@@ -178,6 +182,8 @@ static int check_ctx(mkamd_ctx* ctx)
 static int collect_async_errors(mkamd_ctx* ctx)
 {
     if (!ctx->bufs[WS_ERR]) return 0;
+    // the last lattice call's dense kernel mirrored the flag into pinned host memory: no copy on the clean path
+    if (ctx->err_mirrored && ctx->fb_host && ((volatile unsigned*)ctx->fb_host)[NTIER + 1] == 0u) return 0;
     int flag = 0;
     HIP_TRY(hipMemcpy(&flag, ctx->bufs[WS_ERR], sizeof(int), hipMemcpyDeviceToHost));
     if (flag == 0) return 0;
@@ -240,8 +246,8 @@ int mkamd_ctx_create(int device, mkamd_ctx** out)
              hipEventCreateWithFlags(&c->ev_tile_done[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) c->side_stream = nullptr;          // fall back to a single in-order stream
     // tier statistics come back through pinned host memory the dense kernel writes directly (no copy, no sync)
-    if (hipHostMalloc((void**)&c->fb_host, (NTIER + 1) * sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
-        for (int i = 0; i <= NTIER; ++i) c->fb_host[i] = 0u;
+    if (hipHostMalloc((void**)&c->fb_host, FEEDBACK_WORDS * sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+        for (int i = 0; i < FEEDBACK_WORDS; ++i) c->fb_host[i] = 0u;
         if (hipHostGetDevicePointer((void**)&c->fb_dev, c->fb_host, 0) != hipSuccess) c->fb_dev = nullptr;
     } else {
         c->fb_host = nullptr;                   // no feedback: the leanest tier is always used
@@ -269,6 +275,7 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx)
     }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->fb_host) (void)hipHostFree(ctx->fb_host);
+    if (ctx->stage_host) (void)hipHostFree(ctx->stage_host);
     delete ctx;
     return MKAMD_OK;
 }
@@ -499,19 +506,44 @@ int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, 
     const size_t sz = sigmas_are_f64 ? 8 : 4;
     const size_t out_bytes = (size_t)B * (size_t)V * (size_t)C * 4;
     void *dx = nullptr, *ds = nullptr, *doff = nullptr, *dorg = nullptr, *dbox = nullptr, *dout = nullptr;
-    if ((st = ctx->ensure(WS_H_COORDS, (size_t)N * 12, &dx))) return st;
-    if ((st = ctx->ensure(WS_H_SIGMAS, (size_t)N * C * sz, &ds))) return st;
-    if ((st = ctx->ensure(WS_H_OFFSETS, (size_t)(B + 1) * 8, &doff))) return st;
-    if ((st = ctx->ensure(WS_H_ORIGINS, (size_t)B * 24, &dorg))) return st;
-    if (box && (st = ctx->ensure(WS_H_BOX, (size_t)B * 12, &dbox))) return st;
     if ((st = ctx->ensure(WS_H_OUT, out_bytes, &dout))) return st;
-    if (N > 0) {
-        HIP_TRY(hipMemcpyAsync(dx, coords, (size_t)N * 12, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ds, sigmas, (size_t)N * C * sz, hipMemcpyHostToDevice, ctx->stream));
+    // small calls (the drop-in path: one molecule per call) are latency-bound: pack the inputs into one pinned
+    // buffer and ship them with ONE asynchronous copy instead of five staged pageable ones
+    const size_t a16 = 15;
+    const size_t o_x = 0, o_s = (o_x + (size_t)N * 12 + a16) & ~a16, o_off = (o_s + (size_t)N * C * sz + a16) & ~a16,
+                 o_org = (o_off + (size_t)(B + 1) * 8 + a16) & ~a16, o_box = (o_org + (size_t)B * 24 + a16) & ~a16,
+                 packed_bytes = o_box + (box ? (size_t)B * 12 : 0);
+    constexpr size_t STAGE_BYTES = (size_t)1 << 20;
+    bool packed = packed_bytes <= STAGE_BYTES;
+    if (packed && !ctx->stage_host) {
+        if (hipHostMalloc(&ctx->stage_host, STAGE_BYTES, hipHostMallocDefault) == hipSuccess) ctx->stage_cap = STAGE_BYTES;
+        else { ctx->stage_host = nullptr; packed = false; }
     }
-    HIP_TRY(hipMemcpyAsync(doff, atom_offsets, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(dorg, origins, (size_t)B * 24, hipMemcpyHostToDevice, ctx->stream));
-    if (box) HIP_TRY(hipMemcpyAsync(dbox, box, (size_t)B * 12, hipMemcpyHostToDevice, ctx->stream));
+    if (packed) {
+        void* dstage = nullptr;
+        if ((st = ctx->ensure(WS_H_STAGE, packed_bytes, &dstage))) return st;
+        char* h = (char*)ctx->stage_host;       // free again: every _host call ends with a stream synchronize
+        if (N > 0) { memcpy(h + o_x, coords, (size_t)N * 12); memcpy(h + o_s, sigmas, (size_t)N * C * sz); }
+        memcpy(h + o_off, atom_offsets, (size_t)(B + 1) * 8);
+        memcpy(h + o_org, origins, (size_t)B * 24);
+        if (box) memcpy(h + o_box, box, (size_t)B * 12);
+        HIP_TRY(hipMemcpyAsync(dstage, h, packed_bytes, hipMemcpyHostToDevice, ctx->stream));
+        dx = (char*)dstage + o_x; ds = (char*)dstage + o_s; doff = (char*)dstage + o_off; dorg = (char*)dstage + o_org;
+        dbox = (char*)dstage + o_box;
+    } else {
+        if ((st = ctx->ensure(WS_H_COORDS, (size_t)N * 12, &dx))) return st;
+        if ((st = ctx->ensure(WS_H_SIGMAS, (size_t)N * C * sz, &ds))) return st;
+        if ((st = ctx->ensure(WS_H_OFFSETS, (size_t)(B + 1) * 8, &doff))) return st;
+        if ((st = ctx->ensure(WS_H_ORIGINS, (size_t)B * 24, &dorg))) return st;
+        if (box && (st = ctx->ensure(WS_H_BOX, (size_t)B * 12, &dbox))) return st;
+        if (N > 0) {
+            HIP_TRY(hipMemcpyAsync(dx, coords, (size_t)N * 12, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(ds, sigmas, (size_t)N * C * sz, hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(doff, atom_offsets, (size_t)(B + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dorg, origins, (size_t)B * 24, hipMemcpyHostToDevice, ctx->stream));
+        if (box) HIP_TRY(hipMemcpyAsync(dbox, box, (size_t)B * 12, hipMemcpyHostToDevice, ctx->stream));
+    }
     st = mkamd_voxelize_lattice_dev(ctx, B, (const float*)dx, (const int64_t*)doff, N, ds, sigmas_are_f64, C,
                                     (const double*)dorg, nvoxels, voxelsize, box ? (const float*)dbox : nullptr,
                                     max_images, (float*)dout);

@@ -42,6 +42,7 @@ constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
 constexpr int NTIER = 3;
 constexpr int ECAP_TIER[NTIER] = {640, 768, 1024};
 constexpr int DENSE_WORDS = 1 + NTIER;   // [0] dense-list length, [1+t] tiles with more entries than tier t holds
+constexpr int FEEDBACK_WORDS = NTIER + 2; // host-visible: [t] tiles over tier t, [NTIER] tiles, [NTIER+1] the error flag
 constexpr int TRAV_BATCH = MK_TRAV_BATCH;   // candidate chunks whose loads are in flight together
 constexpr int NXR = 3;               // x-reach sub-buckets: 0 = all K planes, 1 = low half only, 2 = high half only
 constexpr int NBUCKET3 = NBUCKET * NXR;
@@ -1058,13 +1059,14 @@ MK_KERNEL(64) void k_voxelize_dense_tiles(GridDesc g, const unsigned* __restrict
                                           const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls,
                                           const unsigned* __restrict__ cls_table, float* __restrict__ out,
                                           const unsigned* __restrict__ dense_count, const unsigned* __restrict__ dense_list,
-                                          unsigned* __restrict__ feedback)
+                                          unsigned* __restrict__ feedback, const int* __restrict__ err_flag)
 {
     const unsigned n = *dense_count, total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     if (feedback && blockIdx.x == 0 && threadIdx.x == 0) {               // host-visible: drives the next calls' tier
 #pragma unroll
         for (int t = 0; t < NTIER; ++t) feedback[t] = dense_count[1 + t];
         feedback[NTIER] = total_tiles * (unsigned)g.G;
+        feedback[NTIER + 1] = (unsigned)*err_flag;      // mirror of the device-side error flag (set by the binning, long done)
     }
     for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {               // wave-uniform
         const unsigned e = dense_list[i];

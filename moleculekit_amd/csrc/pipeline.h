@@ -31,7 +31,7 @@ enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW
 enum WsSlot {
     WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
-    WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS,
+    WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS, WS_H_STAGE,
     // distance_utils row (dist_pipeline.h)
     WS_D_PA, WS_D_PB, WS_D_WRAP, WS_D_COM1, WS_D_COM2, WS_D_SEL1, WS_D_SEL2, WS_D_CHAINS, WS_D_CHAINS2, WS_D_G1A, WS_D_G1O,
     WS_D_G2A, WS_D_G2O, WS_D_MASS,
@@ -172,7 +172,7 @@ inline int choose_tier(int forced, const volatile unsigned* feedback)
 
 template <int K, int T, class BE>
 int launch_tiles_tier(BE& be, bool lean, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
-                      void* ctab, float* out, unsigned* dcount, void* dlist)
+                      void* ctab, float* out, unsigned* dcount, void* dlist, void* eflag)
 {
     constexpr int E = ECAP_TIER[T];
     int st;
@@ -188,18 +188,18 @@ int launch_tiles_tier(BE& be, bool lean, dim3 tgrid, unsigned dense_wgs, const G
     if (!st && !g.force_general)      // the tiles left behind (usually none) + the statistics for the next call
         st = be.launch(k_voxelize_dense_tiles<K, E>, dim3(dense_wgs), dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos,
                        (const unsigned*)rcls, (const unsigned*)ctab, out, (const unsigned*)dcount, (const unsigned*)dlist,
-                       be.feedback_dev());
+                       be.feedback_dev(), (const int*)eflag);
     return st;
 }
 
 template <int K, class BE>
 int launch_tiles(BE& be, int tier, bool lean, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
-                 void* ctab, float* out, unsigned* dcount, void* dlist)
+                 void* ctab, float* out, unsigned* dcount, void* dlist, void* eflag)
 {
     switch (tier) {
-    case 0: return launch_tiles_tier<K, 0>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
-    case 1: return launch_tiles_tier<K, 1>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
-    default: return launch_tiles_tier<K, 2>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist);
+    case 0: return launch_tiles_tier<K, 0>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    case 1: return launch_tiles_tier<K, 1>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    default: return launch_tiles_tier<K, 2>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
     }
 }
 
@@ -280,9 +280,10 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
     const bool lean = be.set_is_pipelined(set);        // leave registers for the next call's pre-pass
     be.hot_begin();
-    st = g.K == 8 ? launch_tiles<8>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist)
-                  : launch_tiles<4>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist);
+    st = g.K == 8 ? launch_tiles<8>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
+                  : launch_tiles<4>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
     be.hot_end();
+    be.note_error_flag_mirrored(!st && !g.force_general && be.feedback_dev() != nullptr);
     be.tile_done(set);
     return st;
 }

@@ -15,7 +15,8 @@ namespace {
 struct EmuBackend {
     void* bufs[WS_NSLOTS] = {};
     size_t caps[WS_NSLOTS] = {};
-    unsigned feedback[NTIER + 1] = {};
+    unsigned feedback[FEEDBACK_WORDS] = {};
+    void note_error_flag_mirrored(bool) {}
     const volatile unsigned* feedback_host() const { return feedback; }
     unsigned* feedback_dev() { return feedback; }
     ~EmuBackend() { for (void* p : bufs) free(p); }
