@@ -68,6 +68,11 @@ int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on);
  * kernel).  -1 (default) = adaptive: the leanest tier that at most 5 % of the tiles of the previous calls
  * on this context overflowed.  Results are bit-identical whatever the tier. */
 int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier);
+/* Binning pre-pass of the lattice path: 0 = the multi-kernel chain (any batch), 1 = one launch with one
+ * workgroup per item (cell grid of an item must fit 8191 LDS counters; meant for items of up to a few thousand
+ * atoms: ligand poses, pockets), -1 (default) = per-item when it fits and the batch averages <= 4096 atoms per
+ * item.  Results are bit-identical either way. */
+int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode);
 /* Opt-in software pipelining ACROSS calls of mkamd_voxelize_lattice_dev (off by default): the binning
  * pre-pass of a call (latency / atomic bound) runs on an internal stream beside the tile kernel (VALU bound)
  * of the previous call, on a second workspace set.  Results still appear in order on the context's stream.

@@ -56,6 +56,7 @@ struct mkamd_ctx {
     int tile_k = 0;
     int force_general = 0;
     int lds_tier = -1;                     // -1 = adaptive
+    int prepass_mode = -1;                 // -1 = automatic
     unsigned* fb_host = nullptr;           // pinned, device-visible: tier statistics of the last finished call
     unsigned* fb_dev = nullptr;
     bool err_mirrored = false;             // fb_host[NTIER+1] holds the error flag as of the last lattice call
@@ -334,6 +335,14 @@ int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier)
     return MKAMD_OK;
 }
 
+int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode)
+{
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (mode < -1 || mode > 1) return fail(MKAMD_EINVAL, "pre-pass mode must be -1 (automatic), 0 (kernel chain) or 1 (per-item)");
+    ctx->prepass_mode = mode;
+    return MKAMD_OK;
+}
+
 int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on)
 {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
@@ -470,7 +479,7 @@ int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coo
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
     P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
-    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier;
+    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;

@@ -58,6 +58,8 @@ struct GridDesc {
     int cs_log2, cs;            // cell edge in voxels (power of two >= cutoff radius)
     int h;                      // halo cells on each side of the grid
     int ncx, ncy, ncz, ncell;   // padded cell grid per item
+    int cstride;                // cell-array stride per item = ncell + 1 (the extra word is the item's end marker)
+    int cls_per_item;           // 1: one sigma-class table per item (k_prepass_items), 0: one for the call
     int rint;                   // integer upper bound of the cutoff radius in voxels
     int C, G;                   // channels, channel groups = ceil(C/8)
     int B;                      // items (molecules / poses / frames)
@@ -253,27 +255,16 @@ MK_KERNEL(256) void k_merge_classes(const unsigned* __restrict__ rows, unsigned 
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned TMP_UNUSED = 0xffffffffu;
 
-template <typename SigT>
-MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
-                                const long long* __restrict__ atom_offsets, long long total_atoms,
-                                const SigT* __restrict__ sigmas, const double* __restrict__ origins,
-                                const float* __restrict__ box, const double* __restrict__ affine,
-                                unsigned* __restrict__ cell_count,
-                                float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
-                                unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
+// One atom of the binning: its channels' w (drop test + class discovery), its position decomposed in double, one
+// temp record per (periodic) image inside grid+halo with the rank `rank_in_cell(cell)` hands out.  Called by all
+// lanes of a wave together (`act` = this lane holds an atom): the class registration is wave-cooperative.
+template <typename SigT, class RankFn>
+MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, const float* __restrict__ coords,
+                     const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
+                     const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
+                     float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, int* __restrict__ err_flag,
+                     bool classes, unsigned* s_set, unsigned* s_full, RankFn&& rank_in_cell)
 {
-    mk_wave_priority_high();
-    __shared__ unsigned s_set[CLS_BLOCK_SET];
-    __shared__ unsigned s_full;
-    const bool classes = !g.force_general;
-    if (classes) {
-        if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
-        if (threadIdx.x == 0) s_full = 0u;
-        mk_block_sync();
-    }
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = a < total_atoms;
-
     // ---- the atom's channels: w bit patterns (one pass over the sigmas serves the drop test AND the class
     //      discovery); registration is wave-cooperative, so every lane takes part ----
     bool any = false;
@@ -288,7 +279,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
             wb[j] = CLS_EMPTY;
             if (w[j] < mk_inf()) { wb[j] = mk_float_bits(w[j]); any = true; }
         }
-        if (classes) wave_register_classes(wb, s_set, &s_full);
+        if (classes) wave_register_classes(wb, s_set, s_full);
     }
 
     if (act) {
@@ -300,13 +291,15 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
         int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
         int b = 0;
         if (!drop) {
-            // item of this atom: largest b with atom_offsets[b] <= a
-            int lo = 0, hi = g.B;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+            b = b_known;
+            if (b < 0) {                                             // item of this atom: largest b with atom_offsets[b] <= a
+                int lo = 0, hi = g.B;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+                }
+                b = lo;
             }
-            b = lo;
             const int nvox[3] = {g.nx, g.ny, g.nz};
             // fused augmentation (tools/voxeldescriptors.py:78-114 rotateCoordinates, then the astype(float32) of
             // _getOccupancyC :519): x' = M x + t in double, rounded to float32 like the reference pipeline does
@@ -354,8 +347,8 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                         }
                         if (!inside) continue;
                         if (used >= g.img_cap) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
-                        const size_t cell = (size_t)b * g.ncell + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2];
-                        const unsigned rank = mk_atomic_add(&cell_count[cell], 1u);
+                        const size_t cell = (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2];
+                        const unsigned rank = rank_in_cell(cell);
                         tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2],
                                                          mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
                         tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
@@ -365,6 +358,29 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
         for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
     }
 
+}
+
+template <typename SigT>
+MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
+                                const long long* __restrict__ atom_offsets, long long total_atoms,
+                                const SigT* __restrict__ sigmas, const double* __restrict__ origins,
+                                const float* __restrict__ box, const double* __restrict__ affine,
+                                unsigned* __restrict__ cell_count,
+                                float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
+                                unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
+{
+    mk_wave_priority_high();
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_full;
+    const bool classes = !g.force_general;
+    if (classes) {
+        if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
+        if (threadIdx.x == 0) s_full = 0u;
+        mk_block_sync();
+    }
+    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    bin_atom<SigT>(g, a, a < total_atoms, -1, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, err_flag,
+                   classes, s_set, &s_full, [&](size_t cell) { return mk_atomic_add(&cell_count[cell], 1u); });
     if (classes) {
         mk_block_sync();
         if (threadIdx.x < CLS_BLOCK_SET)
@@ -372,27 +388,16 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     }
 }
 
+// One cell-sorted record: the parked position + the atom's per-channel class ids (or w values on the general path).
+// `tab` = the class table in registers (wave-uniform), so that a lookup is NCLS register compares.
 template <typename SigT>
-MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
-                               const unsigned* __restrict__ cell_start,
-                               const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_idx,
-                               float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
-                               unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
+MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* __restrict__ sigmas,
+                        const float4* __restrict__ tmp_pos, float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
+                        unsigned* __restrict__ rec_cls, const unsigned (&tab)[NCLS], bool general)
 {
-    mk_wave_priority_high();
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)g.M) return;
-    const uint2 ix = tmp_idx[t];
-    if (ix.x == TMP_UNUSED) return;
-    const unsigned slot = cell_start[ix.x] + ix.y;
     rec_pos[slot] = tmp_pos[t];
     const size_t a = t / (size_t)g.img_cap;
     const SigT* sg = sigmas + a * (size_t)g.C;
-    // class table -> registers (wave-uniform loads), so that a lookup is NCLS register compares
-    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
-    unsigned tab[NCLS];
-#pragma unroll
-    for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
     for (int gq = 0; gq < g.G; ++gq) {
         float w[CHG];
         atom_channel_w(sg, gq * CHG, g.C, g.w_scale, w);
@@ -413,6 +418,141 @@ MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
             }
             rec_cls[(size_t)gq * g.M + slot] = ids;
         }
+    }
+}
+
+template <typename SigT>
+MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
+                               const unsigned* __restrict__ cell_start,
+                               const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_idx,
+                               float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
+                               unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
+{
+    mk_wave_priority_high();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)g.M) return;
+    const uint2 ix = tmp_idx[t];
+    if (ix.x == TMP_UNUSED) return;
+    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+    unsigned tab[NCLS];
+#pragma unroll
+    for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
+    fill_record<SigT>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, rec_pos, rec_w, rec_cls, tab, general);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The whole pre-pass in ONE launch for batches of small items (ligand poses, pockets: up to a few thousand
+// atoms per item): one block per item counts its atoms into LDS cell counters (the rank inside the cell comes
+// from the LDS atomic -- no global atomics), collects the item's sigma classes in an LDS set, scans the counters
+// in place and permutes the temp records into the item's slice [atom_offsets[b] * img_cap, ...) of the record
+// arrays.  Replaces memset + k_bin_count + 2 reductions + k_scan_finish + k_bin_fill: for such batches those
+// are launch-latency-bound (~5 us per dependent launch).  Class tables are per item here (cls_table[B][16]): an
+// item with more than 15 distinct sigmas takes the general tile path on its own.
+// ------------------------------------------------------------------------------------------------
+constexpr int ITEM_HIST = 8192;                    // most LDS cell counters per item (cells + end marker): 32 KiB;
+                                                   // instantiated for 512 / 2048 / 8192 so that small grids stay small
+
+// exclusive scan helper for up to 1024 threads (16 waves)
+MK_DEV unsigned block_scan_exclusive16(unsigned v, unsigned* total, unsigned* lds /* >= 16 */)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned t = mk_shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == WAVE - 1) lds[wv] = incl;
+    mk_block_sync();
+    unsigned woff = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) {
+        const unsigned sv = lds[i];
+        if (i < wv) woff += sv;
+        tot += sv;
+    }
+    mk_block_sync();
+    *total = tot;
+    return woff + incl - v;
+}
+
+template <typename SigT, int HIST>
+MK_KERNEL(1024) void k_prepass_items(GridDesc g, const float* __restrict__ coords,
+                                     const long long* __restrict__ atom_offsets,
+                                     const void* __restrict__ sigmas_v, const double* __restrict__ origins,
+                                     const float* __restrict__ box, const double* __restrict__ affine,
+                                     unsigned* __restrict__ cell_start,
+                                     float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
+                                     float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
+                                     unsigned* __restrict__ rec_cls, unsigned* __restrict__ cls_table,
+                                     unsigned* __restrict__ dense_words, int* __restrict__ err_flag)
+{
+    mk_wave_priority_high();
+    const SigT* __restrict__ sigmas = static_cast<const SigT*>(sigmas_v);
+    __shared__ unsigned s_hist[HIST];
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_tab[CLS_TABLE_WORDS];
+    __shared__ unsigned s_scan[16];
+    __shared__ unsigned s_full;
+    const int b = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+    const int ncell = g.ncell;                                           // <= HIST - 1 (host checks)
+    if (b == 0 && tid < DENSE_WORDS) dense_words[tid] = 0u;              // dense-list length + tier statistics
+    for (int i = tid; i <= ncell; i += nth) s_hist[i] = 0u;
+    if (tid < CLS_BLOCK_SET) s_set[tid] = CLS_EMPTY;
+    if (tid == 0) s_full = 0u;
+    mk_block_sync();
+    const long long a0 = atom_offsets[b], a1 = atom_offsets[b + 1];
+    const size_t cell_base = (size_t)b * g.cstride;
+    const bool classes = !g.force_general;
+
+    // ---- phase 1: temp records with the rank inside the cell, LDS counts, the item's sigma classes ----
+    for (long long base = a0; base < a1; base += nth) {                  // block-uniform trip count
+        const long long a = base + tid;
+        bin_atom<SigT>(g, a, a < a1, b, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, err_flag,
+                       classes, s_set, &s_full, [&](size_t cell) { return mk_lds_add(&s_hist[cell - cell_base], 1u); });
+    }
+    mk_block_sync();
+
+    // ---- phase 2: the item's class table; counts -> starts (in place), published as this item's cell_start ----
+    if (tid == 0) {
+        unsigned n = 0;
+        bool over = !classes || s_full != 0u;
+        for (int i = 0; i < CLS_BLOCK_SET; ++i) {
+            const unsigned v = s_set[i];
+            if (v == CLS_EMPTY) continue;
+            if (n < (unsigned)NCLS) s_tab[n] = v;
+            ++n;
+        }
+        if (n > (unsigned)NCLS) over = true;
+        for (unsigned i = n; i < (unsigned)NCLS; ++i) s_tab[i] = CLS_EMPTY;
+        s_tab[CLS_OVERFLOW] = over ? 0u : CLS_EMPTY;
+    }
+    const unsigned rbase = (unsigned)((unsigned long long)a0 * (unsigned long long)g.img_cap);
+    unsigned carry = 0;
+    for (int base = 0; base <= ncell; base += nth) {                     // block-uniform
+        const int i = base + tid;
+        const unsigned v = (i <= ncell) ? s_hist[i] : 0u;
+        unsigned tot;
+        const unsigned ex = block_scan_exclusive16(v, &tot, s_scan);
+        if (i <= ncell) {
+            s_hist[i] = carry + ex;
+            cell_start[cell_base + i] = rbase + carry + ex;              // [ncell] = the item's end marker
+        }
+        carry += tot;
+    }
+    mk_block_sync();
+    if (tid < CLS_TABLE_WORDS) cls_table[(size_t)b * CLS_TABLE_WORDS + tid] = s_tab[tid];
+
+    // ---- phase 3: permute the temp records into cell order ----
+    const bool general = g.force_general || s_tab[CLS_OVERFLOW] != CLS_EMPTY;
+    unsigned tab[NCLS];
+#pragma unroll
+    for (int i = 0; i < NCLS; ++i) tab[i] = s_tab[i];
+    const size_t t0 = (size_t)a0 * (size_t)g.img_cap, t1 = (size_t)a1 * (size_t)g.img_cap;
+    for (size_t t = t0 + tid; t < t1; t += nth) {
+        const uint2 ix = tmp_idx[t];
+        if (ix.x == TMP_UNUSED) continue;
+        fill_record<SigT>(g, t, rbase + s_hist[ix.x - (unsigned)cell_base] + ix.y, sigmas, tmp_pos, rec_pos, rec_w, rec_cls, tab, general);
     }
 }
 
@@ -603,7 +743,7 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const unsi
     unsigned my_r0 = 0, my_r1 = 0;
     if (lane < ncols) {
         const int pcx = tg.cx_lo + lane / nyc, pcy = tg.cy_lo + lane % nyc;
-        const size_t cbase = (size_t)tg.b * g.ncell + ((size_t)pcx * g.ncy + pcy) * g.ncz;
+        const size_t cbase = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz;
         my_r0 = cell_start[cbase + tg.cz_lo];
         my_r1 = cell_start[cbase + tg.cz_hi + 1];                 // z-run of cells is contiguous
     }
@@ -696,6 +836,10 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 
     TileGeom tg;
     tg.b = (int)(lt / (unsigned)g.ntiles);
+    // the sigma classes of the call, or of this tile's item (k_prepass_items builds one table per item): one 64-byte
+    // load issued before the geometry arithmetic below, words 0..14 = w bits of the classes, word 15 = overflow marker
+    const unsigned* __restrict__ table = cls_table + (g.cls_per_item ? (size_t)tg.b * CLS_TABLE_WORDS : (size_t)0);
+    const unsigned table_word = (lane < CLS_TABLE_WORDS) ? table[lane] : CLS_EMPTY;
     {
         int t = (int)(lt - (unsigned)tg.b * (unsigned)g.ntiles);
         const int tz = t % g.tnz; t /= g.tnz;
@@ -736,12 +880,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
         for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
 
-    const bool general = !DENSE && (g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY);
+    const bool general = !DENSE && (g.force_general || mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY);
     const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
     const float4* __restrict__ w0p = rec_w + (size_t)(gq * 2 + 0) * g.M;
     const float4* __restrict__ w1p = rec_w + (size_t)(gq * 2 + 1) * g.M;
     // lane s < NCLS holds the w bits of class s (read back with a uniform-lane register read)
-    const unsigned my_class_w = (!general && lane < NCLS) ? cls_table[lane] : INF_BITS;
+    const unsigned my_class_w = (!general && lane < NCLS) ? table_word : INF_BITS;
 
     if (!general) {
         // ---- traversal 1: cull and histogram the buckets (traversal 2 places; the records are L2-hot then) ----
@@ -919,7 +1063,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     for_each_candidate<K, true, 1>(g, tg, cell_start, rec_pos, clsp,
                         [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
                             const unsigned id = surv ? (ids >> (4 * c0)) & 0xfu : 0u;
-                            const float wc = id ? mk_uint_as_float(cls_table[id - 1u]) : INF;
+                            const float wc = id ? mk_uint_as_float(table[id - 1u]) : INF;
                             const bool has = wc < INF;                       // false for +inf and NaN
                             const unsigned long long mask = mk_ballot(has);
                             if (mask == 0ull) return;                        // wave-uniform

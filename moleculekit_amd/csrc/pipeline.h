@@ -52,6 +52,7 @@ struct LatticeProblem {
     int tile_k = 0;                         // 0 = auto
     int force_general = 0;                  // 1 = never use the class-sorted path
     int lds_tier = -1;                      // -1 = adaptive (choose_tier), else the ECAP_TIER index to use
+    int prepass_mode = -1;                  // -1 = automatic, 0 = multi-kernel chain, 1 = one-launch per-item pre-pass (if it fits)
     // device pointers
     const float* coords = nullptr;
     const long long* atom_offsets = nullptr;
@@ -94,11 +95,13 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     g.ncz = ceil_div(g.nz, g.cs) + 2 * g.h;
     if (g.ncx > 1023 || g.ncy > 1023 || g.ncz > 1023) { err = "grid too large (more than 1023 cells per axis)"; return ST_EINVAL; }
     const long long ncell = (long long)g.ncx * g.ncy * g.ncz;
-    if (ncell * (long long)(P.B > 0 ? P.B : 1) > 0xFFFF0000LL) {
+    if ((ncell + 1) * (long long)(P.B > 0 ? P.B : 1) > 0xFFFF0000LL) {
         snprintf(buf, sizeof buf, "batch too large: %lld cells x %d items exceeds 2^32; split the batch", ncell, P.B);
         err = buf; return ST_EINVAL;
     }
     g.ncell = (int)ncell;
+    g.cstride = (int)ncell + 1;
+    g.cls_per_item = 0;
 
     // tile depth: K=8 unless the x extent pads badly or the launch would be too small to fill 256 CUs
     int K = P.tile_k;
@@ -215,8 +218,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     // Big batches are software-pipelined across calls: the pre-pass (latency / atomic bound) of this call
     // runs on an internal stream beside the tile kernel (VALU bound) of the previous call, on the other
     // workspace set.  Small calls stay in order on the caller's stream (the hand-over costs ~20 us).
-    const int set = be.acquire_set(P.total_atoms >= 200000);
-    const size_t ncells = (size_t)g.B * (size_t)g.ncell;
+    // small items (up to a few thousand atoms, cell grid within the LDS counters): the one-launch per-item pre-pass
+    // (short enough that overlapping it with the previous call's tile kernel does not pay: in order, set 0)
+    const bool per_item = (g.ncell + 1 <= ITEM_HIST) && P.prepass_mode != 0 &&
+                          (P.prepass_mode == 1 || P.total_atoms <= 4096LL * (long long)g.B);
+    g.cls_per_item = per_item ? 1 : 0;
+    const int set = be.acquire_set(P.total_atoms >= 200000 && !per_item);
+    const size_t ncells = (size_t)g.B * (size_t)g.cstride;
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
     void *tpos = nullptr, *tidx = nullptr;
     // count[ncells ...] = length of the dense-tile list + tier statistics (zeroed with the counters)
@@ -225,48 +233,63 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos, set))) return st;
     if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw, set))) return st;
     if ((st = be.ensure(WS_REC_CLS, (size_t)g.M * sizeof(unsigned) * g.G, &rcls, set))) return st;
-    if ((st = be.ensure(WS_CLS_TABLE, CLS_TABLE_WORDS * sizeof(unsigned), &ctab, set))) return st;
+    if ((st = be.ensure(WS_CLS_TABLE, (per_item ? (size_t)g.B : (size_t)1) * CLS_TABLE_WORDS * sizeof(unsigned), &ctab, set))) return st;
     if ((st = be.ensure(WS_ERR, sizeof(int), &eflag, 0))) return st;
     if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos, set))) return st;
     if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
 
-    if ((st = be.fill(count, 0, (ncells + DENSE_WORDS) * sizeof(unsigned)))) return st;
-    const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
-    const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
-    const unsigned nblk = agrid.x;
-    const unsigned rows_per_block = 128;
-    const unsigned nl1 = (nblk + rows_per_block - 1) / rows_per_block;
-    void *bsets = nullptr, *l1sets = nullptr;
-    if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nblk * CLS_BLOCK_SET * sizeof(unsigned), &bsets, set))) return st;
-    if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
-    if (P.total_atoms > 0) {
-        st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
-                                      P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag)
-                          : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
-                                      P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
+    if (per_item) {
+        unsigned* dwords = (unsigned*)count + ncells;
+        auto go = [&](auto kern) {
+            // few items: big blocks (latency of the one item matters); many items: small blocks (they fill the chip)
+            const unsigned threads = (g.B < 512 && P.total_atoms > 256LL * (long long)g.B) ? 1024u : 256u;
+            return be.launch(kern, dim3((unsigned)g.B), dim3(threads), g, P.coords, P.atom_offsets, P.sigmas, P.origins, P.box, P.affine,
+                             (unsigned*)start, (float4*)tpos, (uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls,
+                             (unsigned*)ctab, dwords, (int*)eflag);
+        };
+        const int need = g.ncell + 1;
+        if (P.sigmas_f64) st = need <= 512 ? go(k_prepass_items<double, 512>) : need <= 2048 ? go(k_prepass_items<double, 2048>) : go(k_prepass_items<double, ITEM_HIST>);
+        else              st = need <= 512 ? go(k_prepass_items<float, 512>) : need <= 2048 ? go(k_prepass_items<float, 2048>) : go(k_prepass_items<float, ITEM_HIST>);
         if (st) return st;
-    }
-    // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
-    const bool do_classes = P.total_atoms > 0 && !g.force_general;
-    if (!do_classes && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
-    {
-        const size_t nchunks = (ncells + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
-        void* chunks = nullptr;
-        if ((st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set))) return st;
-        const unsigned nl1_eff = do_classes ? nl1 : 0u;
-        if ((st = be.launch(k_prepass_reduce1, dim3(nl1_eff + (unsigned)nchunks), dim3(256), (const unsigned*)bsets, nblk, rows_per_block,
-                            nl1_eff, (unsigned*)l1sets, (const unsigned*)count, ncells, (unsigned*)chunks))) return st;
-        if ((st = be.launch(k_prepass_reduce2, dim3(do_classes ? 2u : 1u), dim3(256), (const unsigned*)l1sets, nl1_eff, (unsigned*)ctab,
-                            (unsigned*)chunks, (unsigned)nchunks))) return st;
-        if ((st = be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (const unsigned*)count, ncells,
-                            (const unsigned*)chunks, (unsigned*)start))) return st;
-    }
-    if (P.total_atoms > 0) {
-        st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
-                                      (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
-                          : be.launch(k_bin_fill<float>, fgrid, ablk, g, (const float*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
-                                      (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
-        if (st) return st;
+    } else {
+        if ((st = be.fill(count, 0, (ncells + DENSE_WORDS) * sizeof(unsigned)))) return st;
+        const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
+        const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
+        const unsigned nblk = agrid.x;
+        const unsigned rows_per_block = 128;
+        const unsigned nl1 = (nblk + rows_per_block - 1) / rows_per_block;
+        void *bsets = nullptr, *l1sets = nullptr;
+        if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nblk * CLS_BLOCK_SET * sizeof(unsigned), &bsets, set))) return st;
+        if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
+        if (P.total_atoms > 0) {
+            st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
+                                          P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag)
+                              : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
+                                          P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
+            if (st) return st;
+        }
+        // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
+        const bool do_classes = P.total_atoms > 0 && !g.force_general;
+        if (!do_classes && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
+        {
+            const size_t nchunks = (ncells + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
+            void* chunks = nullptr;
+            if ((st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set))) return st;
+            const unsigned nl1_eff = do_classes ? nl1 : 0u;
+            if ((st = be.launch(k_prepass_reduce1, dim3(nl1_eff + (unsigned)nchunks), dim3(256), (const unsigned*)bsets, nblk, rows_per_block,
+                                nl1_eff, (unsigned*)l1sets, (const unsigned*)count, ncells, (unsigned*)chunks))) return st;
+            if ((st = be.launch(k_prepass_reduce2, dim3(do_classes ? 2u : 1u), dim3(256), (const unsigned*)l1sets, nl1_eff, (unsigned*)ctab,
+                                (unsigned*)chunks, (unsigned)nchunks))) return st;
+            if ((st = be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (const unsigned*)count, ncells,
+                                (const unsigned*)chunks, (unsigned*)start))) return st;
+        }
+        if (P.total_atoms > 0) {
+            st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
+                                          (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
+                              : be.launch(k_bin_fill<float>, fgrid, ablk, g, (const float*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
+                                          (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
+            if (st) return st;
+        }
     }
     be.prepass_done(set);
 

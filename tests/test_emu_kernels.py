@@ -14,13 +14,50 @@ from tests.cases import LATTICE_CASES, TOL, check, golden
 @pytest.mark.parametrize("name", sorted(LATTICE_CASES))
 @pytest.mark.parametrize("tile_k", [8, 4])
 def test_lattice_case(name, tile_k):
+    """tile_k = 8 runs the one-launch per-item pre-pass (what small items get by default), tile_k = 4 the
+    multi-kernel chain (what big items get): both pre-passes see every case."""
     if tile_k == 4 and name in ("cfg5_small", "pbc_small", "cfg4_small", "dense_mixed"):
         pytest.skip("covered with K=8 (emulation time)")
     case = LATTICE_CASES[name]()
     got, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"],
-                                  case["nvoxels"], case["voxelsize"], box=case["box"], tile_k=tile_k)
+                                  case["nvoxels"], case["voxelsize"], box=case["box"], tile_k=tile_k,
+                                  prepass_mode=1 if tile_k == 8 else 0)
     assert err == 0
     check(case, got)
+
+
+@pytest.mark.parametrize("name", ["ragged_batch", "tiny_items", "special_sigmas", "pbc_batch", "channels11", "cfg1_3ptb"])
+def test_per_item_and_chain_prepass_are_bit_identical(name):
+    """The pre-pass only decides the ORDER of the records inside a cell and, per item instead of per call, the
+    numbering of the sigma classes -- neither may change a single bit of the result (minima are order-free)."""
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    a, ea = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=0)
+    b, eb = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=1)
+    assert ea == 0 and eb == 0
+    assert np.array_equal(a, b)
+
+
+def test_per_item_class_tables_keep_mixed_batches_on_the_sorted_path():
+    """40 distinct sigmas across the batch but <= 5 per item: the call-wide class table overflows (general path),
+    per-item tables do not; one item with 20 distinct sigmas overflows on its own. Same values either way."""
+    rng = np.random.default_rng(41)
+    ns = [50, 60, 70, 80, 90, 100, 110, 120]
+    coords = [rng.normal(0, 3.0, size=(n, 3)).astype(np.float32) for n in ns]
+    radii = rng.uniform(0.9, 2.4, size=40)
+    sig = []
+    for i, n in enumerate(ns):
+        pool = radii[5 * i:5 * i + 5] if i != 3 else radii[:20]
+        sig.append(pool[rng.integers(0, len(pool), size=(n, 1))] * (rng.random((n, 8)) < 0.4))
+    offs = np.concatenate([[0], np.cumsum(ns)])
+    origins = np.tile(np.array([[-6.0, -6.0, -6.0]]), (len(ns), 1))
+    args = (np.concatenate(coords), offs, np.concatenate(sig), origins, np.array([12, 12, 12]), 1.0)
+    from tests.cases import oracle_lattice
+    want = oracle_lattice(*args)
+    a, _ = E.voxelize_lattice(*args, tile_k=8, prepass_mode=0)
+    b, _ = E.voxelize_lattice(*args, tile_k=8, prepass_mode=1)
+    assert np.abs(a - want).max() <= TOL
+    assert np.array_equal(a, b)
 
 
 def test_scan_kernels():

@@ -3,7 +3,8 @@
 For each configuration (batch size, ragged atom counts incl. empty items, density from sparse to far denser
 than any LDS tier, voxel size, odd grid shapes, 1..12 channels, few / many sigma classes, optional periodic
 boxes) the result must (a) stay within TOL of the oracle and (b) for a given tile depth K be BIT-IDENTICAL
-whatever the LDS tier and the class-sorted / general / dense path -- those variants only change how the same
+whatever the LDS tier, the class-sorted / general / dense path and the pre-pass (kernel chain / one launch per
+item) -- those variants only change how the same
 minima are scheduled.  (K itself moves the tile centre the coordinates are made relative to, i.e. the
 rounding of the last bit: K = 4 and K = 8 agree to ~1e-7, not bitwise.)"""
 import numpy as np
@@ -60,14 +61,15 @@ def test_random_configuration_all_variants(hip_ctx, seed):
     try:
         for tile_k in (4, 8):
             ref = None
-            for tier, general in [(0, False), (1, False), (2, False), (-1, False), (-1, True)]:
+            for tier, general, prepass in [(0, False, 0), (1, False, 1), (2, False, 0), (-1, False, 1), (-1, True, 0), (-1, True, 1)]:
                 hip_ctx.set_tile_k(tile_k); hip_ctx.set_lds_tier(tier); hip_ctx.set_force_general(general)
+                hip_ctx.set_prepass_mode(prepass)
                 got = batch.voxelize_lattice(*args, box=k["box"], ctx=hip_ctx)
                 if ref is None:
                     ref = got
                     assert np.abs(got - want).max(initial=0.0) <= TOL
                     assert np.abs(got - base).max(initial=0.0) <= 2e-6
                 else:
-                    assert np.array_equal(got, ref), (tile_k, tier, general)
+                    assert np.array_equal(got, ref), (tile_k, tier, general, prepass)
     finally:
-        hip_ctx.set_tile_k(0); hip_ctx.set_lds_tier(-1); hip_ctx.set_force_general(False)
+        hip_ctx.set_tile_k(0); hip_ctx.set_lds_tier(-1); hip_ctx.set_force_general(False); hip_ctx.set_prepass_mode(-1)
