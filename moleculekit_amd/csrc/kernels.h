@@ -880,12 +880,14 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
         for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
 
-    const bool general = !DENSE && (g.force_general || mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY);
+    // "more sigma classes than the table holds": for a call-wide table (one hot line) this is checked up front; a
+    // per-item table is a fresh line per item, so the check waits until the first traversal has hidden the load
+    bool general = !DENSE && (g.force_general || (!g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY));
     const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
     const float4* __restrict__ w0p = rec_w + (size_t)(gq * 2 + 0) * g.M;
     const float4* __restrict__ w1p = rec_w + (size_t)(gq * 2 + 1) * g.M;
     // lane s < NCLS holds the w bits of class s (read back with a uniform-lane register read)
-    const unsigned my_class_w = (!general && lane < NCLS) ? table_word : INF_BITS;
+    const unsigned my_class_w = (lane < NCLS) ? table_word : INF_BITS;
 
     if (!general) {
         // ---- traversal 1: cull and histogram the buckets (traversal 2 places; the records are L2-hot then) ----
@@ -904,6 +906,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 });
             });
         mk_block_sync();
+        if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
+            general = true;                      // this item alone has too many classes (its records carry w, not ids)
+        } else {
         // ---- bucket starts: lane owns groups 2*lane, 2*lane+1 (3 sub-buckets each); every sub-bucket
         //      is padded to an even count so the pair loop never straddles two of them ----
         unsigned cnt[2 * NXR], pad[2 * NXR], start[2 * NXR];
@@ -1101,6 +1106,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             }
             return;                                                          // every channel stored
         }
+        }                                                                    // (item not general)
     }
 
     if (general) {
