@@ -7,6 +7,7 @@
 #include "pipeline.h"
 #include "dist_pipeline.h"
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -553,9 +554,16 @@ int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, 
         HIP_TRY(hipMemcpyAsync(dorg, origins, (size_t)B * 24, hipMemcpyHostToDevice, ctx->stream));
         if (box) HIP_TRY(hipMemcpyAsync(dbox, box, (size_t)B * 12, hipMemcpyHostToDevice, ctx->stream));
     }
+    // the per-item pre-pass gives every item ONE workgroup: here the offsets are visible, so a ragged batch whose
+    // average is small but which holds a huge item is kept on the kernel chain (automatic mode only)
+    long long biggest = 0;
+    for (int b = 0; b < B; ++b) biggest = std::max<long long>(biggest, atom_offsets[b + 1] - atom_offsets[b]);
+    const int saved_mode = ctx->prepass_mode;
+    if (saved_mode < 0 && biggest > 16384) ctx->prepass_mode = 0;
     st = mkamd_voxelize_lattice_dev(ctx, B, (const float*)dx, (const int64_t*)doff, N, ds, sigmas_are_f64, C,
                                     (const double*)dorg, nvoxels, voxelsize, box ? (const float*)dbox : nullptr,
                                     max_images, (float*)dout);
+    ctx->prepass_mode = saved_mode;
     if (st) return st;
     HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
