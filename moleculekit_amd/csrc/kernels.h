@@ -13,11 +13,17 @@
 //   Entries (atom x channel) that share the same sigma form a CLASS; inside a class
 //                min_a d2*w == w * min_a d2   and   "some in-range atom" == (min_a d2 < 25),
 //   bit for bit (w > 0, float rounding is monotone), so the cutoff test and the multiply by w also
-//   leave the inner loop: per (voxel, entry) it is  sub, fma, half a v_min3_u32.
+//   leave the inner loop: per (voxel, entry) it is  half a v_pk_add, half a v_pk_fma, half a v_min3_u32.
 //   It is a GATHER: one wave owns a K x 8 x 8 voxel tile, lane = (y,z), K x-planes in registers;
 //   candidate atoms come from a uniform cell list, are culled against the tile box, counting-sorted
 //   by (channel, class) in LDS and broadcast-read by all 64 lanes.  No atomics on the grid, no
 //   zero-fill pass, one 32-byte store per voxel.  MFMA unused (a neighbourhood min-reduction).
+//
+// Kernels, in launch order (pipeline.h):
+//   big items  : memset, k_bin_count, k_prepass_reduce1/2, k_scan_finish, k_bin_fill      (cell lists)
+//   small items: k_prepass_items                                  (the same, one workgroup per item)
+//   then       : k_voxelize_tiles[_lean]<K,ECAP>, k_voxelize_dense_tiles<K,ECAP>          (the grid)
+//   explicit centres: k_sigma_to_w, k_occupancy_centers;   lattice centres: k_grid_centers.
 //
 // Coordinates: everything is in VOXEL units relative to the grid origin (voxel i's centre sits at
 // integer coordinate i).  Atoms are decomposed IN DOUBLE into (cell index, cell-centre-relative
@@ -30,7 +36,7 @@
 namespace mkamd {
 
 constexpr int CHG = 8;               // channels per channel-group (one group = one pass of the tile kernel)
-constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per call (4-bit ids)
+constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per class table (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
 #ifndef MK_TRAV_BATCH
