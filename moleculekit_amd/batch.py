@@ -136,7 +136,9 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     ``max_images_per_atom`` when the box is smaller than grid + 10 A).
     ``affine``: optional float64 [B,12] CUDA tensor of per-item rigid transforms (``rotation_affines``) fused into
     the binning stage -- on-device augmentation, nothing leaves HBM.
-    Returns float32 [B,V,C] on the same device (or [B,C,nx,ny,nz] when ``channel_first``).
+    Returns float32 [B,V,C] on the same device, or with ``channel_first`` the logical [B,C,nx,ny,nz] tensor a
+    ``nn.Conv3d`` takes -- as a zero-copy view: voxel-major / channel-minor storage is exactly PyTorch's
+    ``torch.channels_last_3d`` (NDHWC) memory format.
     """
     import torch
 

@@ -106,6 +106,8 @@ def test_torch_device_resident_path_matches_host_path():
             box=None if case["box"] is None else t(case["box"], np.float32), max_images=mi, channel_first=True)
         nx, ny, nz = [int(v) for v in case["nvoxels"]]
         assert cf.shape == (out.shape[0], out.shape[2], nx, ny, nz)
+        # no copy was made: the [B,V,C] buffer IS the channels-last-3d (NDHWC) layout of the logical [B,C,nx,ny,nz] tensor
+        assert cf.is_contiguous(memory_format=torch.channels_last_3d)
         assert torch.equal(cf.permute(0, 2, 3, 4, 1).reshape(out.shape), out)
 
 
