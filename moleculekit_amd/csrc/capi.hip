@@ -733,3 +733,13 @@ int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float
 }
 
 }  // extern "C"
+
+#ifdef MK_PHASE_TIMERS
+// profiling build only (tools/gpu_phase_timers.sh): read and clear the per-phase cycle sums of the tile kernel
+extern "C" int mkamd_debug_phase_cycles(unsigned long long* out8)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mkamd::g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[8] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mkamd::g_phase_cycles), z, sizeof z) == hipSuccess ? 0 : 1;
+}
+#endif

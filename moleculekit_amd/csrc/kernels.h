@@ -35,6 +35,16 @@
 
 namespace mkamd {
 
+#ifdef MK_PHASE_TIMERS   // tools/phase_timers build only: wall-clock cycles a tile wave spends in each phase
+__device__ unsigned long long g_phase_cycles[8];
+#define MK_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        if (!DENSE && threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], now_ - phase_t_); phase_t_ = now_; } while (0)
+#define MK_PHASE_BEGIN() unsigned long long phase_t_ = __builtin_readcyclecounter()
+#else
+#define MK_PHASE_MARK(i) do {} while (0)
+#define MK_PHASE_BEGIN() do {} while (0)
+#endif
+
 constexpr int CHG = 8;               // channels per channel-group (one group = one pass of the tile kernel)
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per class table (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
@@ -738,25 +748,39 @@ struct CandChunk {                    // one chunk of 64 candidate records (one 
     bool valid;
 };
 
+// The candidate runs of a tile: lane j < ncols holds the record range of column j (one load round trip), plus the
+// chunk numbering.  Found once per tile and shared by every traversal.
+struct CandRuns {
+    unsigned r0, r1, nch, cb, T;
+};
+
+MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start)
+{
+    const int lane = threadIdx.x;
+    const int nyc = tg.cy_hi - tg.cy_lo + 1;
+    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 16 (cell edge >= cutoff radius)
+    CandRuns cr;
+    cr.r0 = 0; cr.r1 = 0;
+    if (lane < ncols) {
+        const int pcx = tg.cx_lo + lane / nyc, pcy = tg.cy_lo + lane % nyc;
+        const size_t cbase = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz;
+        cr.r0 = cell_start[cbase + tg.cz_lo];
+        cr.r1 = cell_start[cbase + tg.cz_hi + 1];                 // z-run of cells is contiguous
+    }
+    cr.nch = (cr.r1 - cr.r0 + (WAVE - 1)) >> 6;
+    const unsigned incl = wave_scan_inclusive(cr.nch);
+    cr.cb = incl - cr.nch;
+    cr.T = mk_readlane(incl, WAVE - 1);
+    return cr;
+}
+
 template <int K, bool LOAD_CLS, int BATCH, class F>
-MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start,
+MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const CandRuns& cr,
                                const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f)
 {
     constexpr float HX = 0.5f * (float)(K - 1);
     const int lane = threadIdx.x;
-    const int nyc = tg.cy_hi - tg.cy_lo + 1;
-    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 16 (cell edge >= cutoff radius)
-    unsigned my_r0 = 0, my_r1 = 0;
-    if (lane < ncols) {
-        const int pcx = tg.cx_lo + lane / nyc, pcy = tg.cy_lo + lane % nyc;
-        const size_t cbase = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz;
-        my_r0 = cell_start[cbase + tg.cz_lo];
-        my_r1 = cell_start[cbase + tg.cz_hi + 1];                 // z-run of cells is contiguous
-    }
-    const unsigned my_nch = (my_r1 - my_r0 + (WAVE - 1)) >> 6;
-    const unsigned incl = wave_scan_inclusive(my_nch);
-    const unsigned my_cb = incl - my_nch;
-    const unsigned T = mk_readlane(incl, WAVE - 1);
+    const unsigned my_r0 = cr.r0, my_r1 = cr.r1, my_nch = cr.nch, my_cb = cr.cb, T = cr.T;
 
     auto issue = [&](unsigned t, CandChunk& ch) {                    // start the loads of chunk t
         ch.r = 0u; ch.valid = false; ch.ids = 0u;
@@ -820,6 +844,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                           unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
 {
     static_assert(K == 4 || K == 8, "K");
+    MK_PHASE_BEGIN();
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
     // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
     // (measured: 1.25 -> 2 -> 2.75 -> 3.25 waves/SIMD = 0.69 -> 0.48 -> 0.43 -> 0.40 ms on cfg2), hence
@@ -877,6 +902,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         tg.fcs = (float)g.cs;
     }
 
+    const CandRuns runs = find_candidate_runs(g, tg, cell_start);   // issued early: the loads fly during the set-up below
+
     // running minima kept as BIT PATTERNS: every candidate value is a non-negative float (or +inf /
     // NaN), for which unsigned-integer order == float order and NaN (0x7fc00000) sorts above +inf,
     // so v_min_u32 / v_min3_u32 are exact NaN-ignoring float minima with no canonicalisation op.
@@ -896,6 +923,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     const unsigned my_class_w = (lane < NCLS) ? table_word : INF_BITS;
 
     if (!general) {
+        MK_PHASE_MARK(0);                                   // prologue
         // ---- traversal 1: cull and histogram the buckets (traversal 2 places; the records are L2-hot then) ----
         // bucket = (channel, class, x-reach): an entry whose x lies more than the cutoff below the
         // middle of the tile cannot reach the upper K/2 planes (those pairs would fail d^2 < 25 on
@@ -904,7 +932,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
         for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
         mk_block_sync();
-        for_each_candidate<K, true, TRAV_BATCH>(g, tg, cell_start, rec_pos, clsp,
+        for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp,
             [&](bool surv, unsigned, float ex, float, float, unsigned ids) {
                 const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
                 for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
@@ -915,6 +943,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
             general = true;                      // this item alone has too many classes (its records carry w, not ids)
         } else {
+        MK_PHASE_MARK(1);                                   // traversal 1 (histogram)
         // ---- bucket starts: lane owns groups 2*lane, 2*lane+1 (3 sub-buckets each); every sub-bucket
         //      is padded to an even count so the pair loop never straddles two of them ----
         unsigned cnt[2 * NXR], pad[2 * NXR], start[2 * NXR];
@@ -1031,7 +1060,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
-            for_each_candidate<K, true, TRAV_BATCH>(g, tg, cell_start, rec_pos, clsp,
+            for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp,
                 [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
                     const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
                     for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
@@ -1053,9 +1082,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 
         if (!DENSE) {
             // ---- the normal case: one round takes all eight channels; minima stay in q for the epilogue ----
+            MK_PHASE_MARK(2);                               // counts -> starts
             place(0, CHG, 0u, total);
+            MK_PHASE_MARK(3);                               // traversal 2 (placement)
 #pragma unroll
             for (int c = 0; c < CHG; ++c) process_classes(c, class_bits(c), q[c]);
+            MK_PHASE_MARK(4);                               // pair loops + class flushes
         } else {
             // ---- dense tile: consecutive channels whose padded entries fit the LDS arrays together are
             //      placed and processed in one round; a channel that does not fit on its own goes chunk
@@ -1071,7 +1103,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
                     for (int k = 0; k < K; ++k) m[k] = INF_BITS;
                     mk_block_sync();
-                    for_each_candidate<K, true, 1>(g, tg, cell_start, rec_pos, clsp,
+                    for_each_candidate<K, true, 1>(g, tg, runs, rec_pos, clsp,
                         [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
                             const unsigned id = surv ? (ids >> (4 * c0)) & 0xfu : 0u;
                             const float wc = id ? mk_uint_as_float(table[id - 1u]) : INF;
@@ -1147,7 +1179,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 mk_block_sync();                                     // ebuf is rewritten next
             }
         };
-        for_each_candidate<K, false, 1>(g, tg, cell_start, rec_pos, clsp, body);
+        for_each_candidate<K, false, 1>(g, tg, runs, rec_pos, clsp, body);
     }
 
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
@@ -1173,6 +1205,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             }
         }
     }
+    MK_PHASE_MARK(5);                                       // epilogue
 }
 
 template <int K, int ECAP>
