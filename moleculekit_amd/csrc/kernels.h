@@ -752,6 +752,9 @@ struct CandChunk {                    // one chunk of 64 candidate records (one 
 // chunk numbering.  Found once per tile and shared by every traversal.
 struct CandRuns {
     unsigned r0, r1, nch, cb, T;
+#ifdef MK_PHASE_TIMERS
+    mutable unsigned long long wait_ = 0, proc_ = 0;
+#endif
 };
 
 MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start)
@@ -813,11 +816,22 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
     // the L2 / fabric round trip once per batch instead of once per chunk
     CandChunk ch[BATCH];
     for (unsigned t = 0; t < T; t += BATCH) {
+#ifdef MK_PHASE_TIMERS
+        const unsigned long long ta_ = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) issue(t + (unsigned)k, ch[k]);
+#ifdef MK_PHASE_TIMERS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tb_ = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
             if (t + (unsigned)k < T) consume(ch[k]);                 // wave-uniform
+#ifdef MK_PHASE_TIMERS
+        const unsigned long long tc_ = __builtin_readcyclecounter();
+        cr.wait_ += tb_ - ta_; cr.proc_ += tc_ - tb_;                 // flushed at the end of the tile
+#endif
     }
 }
 
@@ -1206,6 +1220,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         }
     }
     MK_PHASE_MARK(5);                                       // epilogue
+#ifdef MK_PHASE_TIMERS
+    if (!DENSE && threadIdx.x == 0) { atomicAdd(&g_phase_cycles[6], runs.wait_); atomicAdd(&g_phase_cycles[7], runs.proc_); }
+#endif
 }
 
 template <int K, int ECAP>
