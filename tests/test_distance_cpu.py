@@ -91,3 +91,31 @@ def test_emu_larger_random_case_matches_oracle():
         exp = oracle.dist_trajectory(c, b, a, bb, ch, selfd, True)
         assert np.array_equal(got, exp, equal_nan=True)
         assert np.isnan(exp[5]).any()
+
+
+def _half_box_case():
+    """Separations sitting on, and one ulp either side of, half the box edge (the rounding boundary of the image
+    shift `round(d / box)`, distance_utils.pyx:49-52), for boxes whose reciprocal is inexact: only the correctly
+    rounded quotient rounds all of them like the reference."""
+    boxes = np.array([10.0, 33.3, 66.9, 7.123456, 100.0, 1e-3, 3.0e4], np.float32)
+    F = len(boxes)
+    seps = []
+    for k in (0.5, 1.5, 2.5):
+        h = (boxes * np.float32(k)).astype(np.float32)
+        seps += [h, np.nextafter(h, np.float32(0)), np.nextafter(h, np.float32(np.inf)),
+                 np.nextafter(np.nextafter(h, np.float32(0)), np.float32(0))]
+    n = 1 + 2 * len(seps)
+    c = np.zeros((n, 3, F), np.float32)
+    for i, s in enumerate(seps):
+        c[1 + 2 * i, 0] = s            # +x
+        c[2 + 2 * i, 1] = -s           # -y
+        c[2 + 2 * i, 2] = s * np.float32(0.75)
+    b = np.tile(boxes[None, :], (3, 1)).astype(np.float32)
+    ch = np.arange(n, dtype=np.uint32)          # every atom its own chain: always wrapped
+    return c, b, ch, np.array([0], np.uint32), np.arange(1, n, dtype=np.uint32)
+
+
+def test_image_shift_at_the_half_box_boundary_is_bit_exact():
+    c, b, ch, s1, s2 = _half_box_case()
+    got = E.dist_trajectory(c, b, s1, s2, ch, False, True)
+    assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))

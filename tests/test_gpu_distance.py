@@ -122,3 +122,14 @@ def test_metricdistance_style_drivers():
     with pytest.raises(RuntimeError):
         m.box = np.zeros((3, 2), np.float32)
         pp_calcDistances(m, s1, s2, "chains")
+
+
+def test_image_shift_at_the_half_box_boundary_is_bit_exact():
+    """Separations on / one ulp either side of half a box edge: the image shift round(d / box) must see the
+    correctly rounded quotient (a reciprocal-multiply shortcut would flip some of these)."""
+    from moleculekit_amd.distance_utils import dist_trajectory
+    from tests.test_distance_cpu import _half_box_case
+    c, b, ch, s1, s2 = _half_box_case()
+    r = np.zeros((c.shape[2], len(s2)), np.float32)
+    dist_trajectory(c, b, s1, s2, ch, False, True, r)
+    assert np.array_equal(r, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
