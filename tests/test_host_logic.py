@@ -151,3 +151,26 @@ def test_shard_bounds():
     b = distributed.shard_bounds(1000, 8, weights=w)
     loads = [w[b[i]:b[i + 1]].sum() for i in range(8)]
     assert max(loads) - min(loads) <= 100 and np.all(np.diff(b) > 0)
+
+
+def test_cube_export_is_byte_identical_to_the_reference(tmp_path):
+    """`.cube` export of voxel grids (util.py:415-458); expected text written by the real reference."""
+    from moleculekit_amd.util import readCube, writeCube, writeVoxelFeatures
+    g = golden("cube_case.npz")
+    fn = tmp_path / "a.cube"
+    writeCube(g["arr"], str(fn), g["vecMin"], g["vecRes"])
+    assert fn.read_text() == str(g["text"])
+    back, meta = readCube(str(fn))
+    assert np.array_equal(back, g["readback"]) and np.allclose(meta["org"], g["org"])
+    # a grid whose value count is a multiple of six ends with a newline (like the reference's loop)
+    writeCube(np.zeros((2, 3, 2)), str(fn), [0, 0, 0], [1, 1, 1])
+    assert fn.read_text().endswith("0\n") and fn.read_text().count("\n") == 7 + 2
+    # per-channel export of a getVoxelDescriptors-shaped result
+    nv = np.array([3, 2, 4]); V = int(np.prod(nv))
+    centers = (np.stack(np.meshgrid(np.arange(3), np.arange(2), np.arange(4), indexing="ij"), -1).reshape(V, 3) * 0.5 + [1.0, 2.0, 3.0])
+    feats = np.random.default_rng(0).random((V, 8))
+    files = writeVoxelFeatures(feats, centers, nv, str(tmp_path / "vox"))
+    assert len(files) == 8 and files[7].endswith("vox_occupancies.cube")
+    data, meta = readCube(files[2])
+    assert np.allclose(data, feats[:, 2].reshape(3, 2, 4), rtol=1e-4) and data.shape == (3, 2, 4)
+    assert np.allclose(meta["org"], (np.array([1.0, 2.0, 3.0]) - 0.25 + 0.25) / 0.52917725, atol=1e-5)
