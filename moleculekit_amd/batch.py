@@ -217,3 +217,119 @@ def voxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None,
     feats = voxelize_lattice(packed, offs, sig_all, np.broadcast_to(origin, (F, 3)), nvoxels, voxelsize,
                              box=bx, ctx=ctx)
     return feats, origin, nvoxels.astype(np.int64)
+
+
+_PINNED = {}
+_COPY_THREADS = 8
+_POOL = None
+
+
+def _copy_pool():
+    """A few host threads for the strided trajectory-slab copy (numpy releases the GIL while copying)."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=_COPY_THREADS)
+    return _POOL
+
+
+def _pinned(key, shape):
+    """Pinned float32 staging tensor, cached per (key, shape) for the life of the process."""
+    import torch
+    k = (key, tuple(shape))
+    t = _PINNED.get(k)
+    if t is None:
+        for old in [q for q in _PINNED if q[0] == key]:
+            del _PINNED[old]
+        t = _PINNED[k] = torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
+    return t
+
+
+def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None, frames=None, chunk=512,
+                           device=None, channel_first=False, ctx=None):
+    """Stream a host-resident trajectory through the GPU chunk by chunk ("trajectory
+    feeding"): yields ``(frame_indices, features)`` with ``features`` a float32 CUDA tensor ``[n, V, C]`` (or
+    ``[n, C, nx, ny, nz]`` with ``channel_first``) for ``n <= chunk`` frames at a time.
+
+    ``coords`` is ``Molecule.coords`` (float32 ``[N, 3, F]``, frame fastest), ``box`` ``Molecule.box`` (``[3, F]``)
+    or None.  Per chunk the host only copies the ``[N, 3, n]`` slab into one of two pinned staging buffers (runs of
+    ``n`` contiguous floats); the transpose to frame-major happens on the device.  A copy stream uploads chunk k+1
+    while the current stream voxelizes chunk k, so the consumer (a model, a reduction) sees a steady feed whose
+    rate is the slower of PCIe and the voxelizer.  The tensors are yours to keep: each chunk gets fresh memory.
+    """
+    import torch
+
+    coords = np.asarray(coords)
+    if coords.dtype != np.float32:
+        coords = coords.astype(np.float32)
+    if coords.ndim != 3 or coords.shape[1] != 3:
+        raise ValueError("coords must be (natoms, 3, nframes)")
+    N = coords.shape[0]
+    fr = np.arange(coords.shape[2]) if frames is None else np.asarray(frames, dtype=np.int64)
+    contiguous = frames is None or (len(fr) > 0 and np.array_equal(fr, np.arange(fr[0], fr[0] + len(fr))))
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    chunk = int(max(1, min(chunk, max(len(fr), 1))))
+    sig = np.ascontiguousarray(channels)
+    sig = sig.astype(np.float64 if sig.dtype == np.float64 else np.float32, copy=False)
+    C = sig.shape[1]
+    boxsize = np.array(boxsize, dtype=np.float64)
+    nvoxels = np.ceil(boxsize / voxelsize).astype(int)
+    origin = np.asarray(center, dtype=np.float64) - boxsize / 2
+    max_images = 1
+    if box is not None:
+        box = np.asarray(box, dtype=np.float32)
+        max_images = max_images_per_atom(np.ascontiguousarray(box[:, fr].T), nvoxels, voxelsize)
+
+    main = torch.cuda.current_stream(dev)
+    copy = torch.cuda.Stream(device=dev)
+    with torch.cuda.device(dev):
+        d_sig = torch.as_tensor(sig, device=dev).repeat(chunk, 1).contiguous()            # [chunk*N, C], shared by the frames
+        d_offs = torch.arange(chunk + 1, dtype=torch.int64, device=dev) * N
+        d_org = torch.as_tensor(np.broadcast_to(origin, (chunk, 3)).copy(), device=dev)
+        stage = [_pinned(("traj", i), (N, 3, chunk)) for i in range(2)]              # cached: pinning costs milliseconds
+        stage_box = [_pinned(("trajbox", i), (3, chunk)) for i in range(2)]
+        free = [torch.cuda.Event(), torch.cuda.Event()]          # staging buffer i may be overwritten
+        ready = [torch.cuda.Event(), torch.cuda.Event()]         # device copy of chunk in slot i has landed
+        dslab = [None, None]
+        dbox = [None, None]
+
+        def upload(k, slot):
+            idx = fr[k * chunk:(k + 1) * chunk]
+            n = len(idx)
+            free[slot].synchronize()                              # the previous H2D out of this buffer is done
+            dst = stage[slot].numpy()[:, :, :n]
+            if contiguous:                                        # strided slab -> pinned, split over a few host threads
+                f0 = int(idx[0])
+                parts = np.linspace(0, N, _COPY_THREADS + 1).astype(int)
+                list(_copy_pool().map(lambda ab: np.copyto(dst[ab[0]:ab[1]], coords[ab[0]:ab[1], :, f0:f0 + n]),
+                                      zip(parts[:-1], parts[1:])))
+            else:
+                np.copyto(dst, coords[:, :, idx])
+            if box is not None:
+                stage_box[slot][:, :n].copy_(torch.from_numpy(box[:, idx[0]:idx[0] + n] if contiguous else box[:, idx]))
+            with torch.cuda.stream(copy):
+                dslab[slot] = stage[slot][:, :, :n].to(dev, non_blocking=True)
+                dbox[slot] = stage_box[slot][:, :n].to(dev, non_blocking=True) if box is not None else None
+                free[slot].record(copy)
+                ready[slot].record(copy)
+            return idx
+
+        nchunks = (len(fr) + chunk - 1) // chunk
+        pending = upload(0, 0) if nchunks else None
+        for k in range(nchunks):
+            slot = k & 1
+            idx = pending
+            if k + 1 < nchunks:
+                pending = upload(k + 1, slot ^ 1)
+            n = len(idx)
+            main.wait_event(ready[slot])
+            slab, bx = dslab[slot], dbox[slot]
+            slab.record_stream(main)
+            xyz = slab.permute(2, 0, 1).contiguous().view(n * N, 3)                       # frame-major, on the device
+            d_b = None
+            if bx is not None:
+                bx.record_stream(main)
+                d_b = bx.t().contiguous()
+            feats = voxelize_lattice_torch(xyz, d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize, box=d_b,
+                                           max_images=max_images, ctx=ctx, channel_first=channel_first)
+            yield idx, feats
