@@ -32,6 +32,8 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_ctx_set_tile_k": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_force_general": (_c_int, [_vp, _c_int]),
+    "mkamd_xtc_info": (_c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "mkamd_xtc_read": (_c_int, [ctypes.c_char_p, _vp, ctypes.c_int64, ctypes.c_int64, _vp, _vp, _vp, _vp, ctypes.c_int32]),
     "mkamd_ctx_set_lds_tier": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_prepass_mode": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),

@@ -245,49 +245,30 @@ def _pinned(key, shape):
     return t
 
 
-def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None, frames=None, chunk=512,
-                           device=None, channel_first=False, ctx=None):
-    """Stream a host-resident trajectory through the GPU chunk by chunk (SURVEY.md section 8f-4, "trajectory
-    feeding"): yields ``(frame_indices, features)`` with ``features`` a float32 CUDA tensor ``[n, V, C]`` (or
-    ``[n, C, nx, ny, nz]`` with ``channel_first``) for ``n <= chunk`` frames at a time.
-
-    ``coords`` is ``Molecule.coords`` (float32 ``[N, 3, F]``, frame fastest), ``box`` ``Molecule.box`` (``[3, F]``)
-    or None.  Per chunk the host only copies the ``[N, 3, n]`` slab into one of two pinned staging buffers (runs of
-    ``n`` contiguous floats); the transpose to frame-major happens on the device.  A copy stream uploads chunk k+1
-    while the current stream voxelizes chunk k, so the consumer (a model, a reduction) sees a steady feed whose
-    rate is the slower of PCIe and the voxelizer.  The tensors are yours to keep: each chunk gets fresh memory.
-    """
+def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first, ctx,
+                     max_images):
+    """Core of the streamed voxelizers: ``fill(coords_np [N,3,n], box_np [3,n] | None, idx)`` produces chunk ``idx``
+    (frame indices) straight into pinned staging; a copy stream uploads chunk k+1 while the current stream
+    voxelizes chunk k; ``scale`` converts the coordinates to Angstrom on the device (XTC stores nm)."""
     import torch
 
-    coords = np.asarray(coords)
-    if coords.dtype != np.float32:
-        coords = coords.astype(np.float32)
-    if coords.ndim != 3 or coords.shape[1] != 3:
-        raise ValueError("coords must be (natoms, 3, nframes)")
-    N = coords.shape[0]
-    fr = np.arange(coords.shape[2]) if frames is None else np.asarray(frames, dtype=np.int64)
-    contiguous = frames is None or (len(fr) > 0 and np.array_equal(fr, np.arange(fr[0], fr[0] + len(fr))))
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     chunk = int(max(1, min(chunk, max(len(fr), 1))))
     sig = np.ascontiguousarray(channels)
     sig = sig.astype(np.float64 if sig.dtype == np.float64 else np.float32, copy=False)
-    C = sig.shape[1]
+    if sig.shape[0] != N:
+        raise ValueError(f"channels has {sig.shape[0]} rows, the trajectory {N} atoms")
     boxsize = np.array(boxsize, dtype=np.float64)
     nvoxels = np.ceil(boxsize / voxelsize).astype(int)
     origin = np.asarray(center, dtype=np.float64) - boxsize / 2
-    max_images = 1
-    if box is not None:
-        box = np.asarray(box, dtype=np.float32)
-        max_images = max_images_per_atom(np.ascontiguousarray(box[:, fr].T), nvoxels, voxelsize)
-
     main = torch.cuda.current_stream(dev)
     copy = torch.cuda.Stream(device=dev)
     with torch.cuda.device(dev):
         d_sig = torch.as_tensor(sig, device=dev).repeat(chunk, 1).contiguous()            # [chunk*N, C], shared by the frames
         d_offs = torch.arange(chunk + 1, dtype=torch.int64, device=dev) * N
         d_org = torch.as_tensor(np.broadcast_to(origin, (chunk, 3)).copy(), device=dev)
-        stage = [_pinned(("traj", i), (N, 3, chunk)) for i in range(2)]              # cached: pinning costs milliseconds
-        stage_box = [_pinned(("trajbox", i), (3, chunk)) for i in range(2)]
+        stage = [_pinned(("traj", i), (N * 3 * chunk,)) for i in range(2)]               # cached: pinning costs milliseconds
+        stage_box = [_pinned(("trajbox", i), (3 * chunk,)) for i in range(2)]
         free = [torch.cuda.Event(), torch.cuda.Event()]          # staging buffer i may be overwritten
         ready = [torch.cuda.Event(), torch.cuda.Event()]         # device copy of chunk in slot i has landed
         dslab = [None, None]
@@ -297,19 +278,12 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
             idx = fr[k * chunk:(k + 1) * chunk]
             n = len(idx)
             free[slot].synchronize()                              # the previous H2D out of this buffer is done
-            dst = stage[slot].numpy()[:, :, :n]
-            if contiguous:                                        # strided slab -> pinned, split over a few host threads
-                f0 = int(idx[0])
-                parts = np.linspace(0, N, _COPY_THREADS + 1).astype(int)
-                list(_copy_pool().map(lambda ab: np.copyto(dst[ab[0]:ab[1]], coords[ab[0]:ab[1], :, f0:f0 + n]),
-                                      zip(parts[:-1], parts[1:])))
-            else:
-                np.copyto(dst, coords[:, :, idx])
-            if box is not None:
-                stage_box[slot][:, :n].copy_(torch.from_numpy(box[:, idx[0]:idx[0] + n] if contiguous else box[:, idx]))
+            hc = stage[slot][:N * 3 * n].view(N, 3, n)            # tight [N,3,n]: one contiguous H2D
+            hb = stage_box[slot][:3 * n].view(3, n) if has_box else None
+            fill(hc.numpy(), hb.numpy() if has_box else None, idx)
             with torch.cuda.stream(copy):
-                dslab[slot] = stage[slot][:, :, :n].to(dev, non_blocking=True)
-                dbox[slot] = stage_box[slot][:, :n].to(dev, non_blocking=True) if box is not None else None
+                dslab[slot] = hc.to(dev, non_blocking=True)
+                dbox[slot] = hb.to(dev, non_blocking=True) if has_box else None
                 free[slot].record(copy)
                 ready[slot].record(copy)
             return idx
@@ -326,6 +300,8 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
             slab, bx = dslab[slot], dbox[slot]
             slab.record_stream(main)
             xyz = slab.permute(2, 0, 1).contiguous().view(n * N, 3)                       # frame-major, on the device
+            if scale != 1.0:
+                xyz.mul_(scale)
             d_b = None
             if bx is not None:
                 bx.record_stream(main)
@@ -333,3 +309,85 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
             feats = voxelize_lattice_torch(xyz, d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize, box=d_b,
                                            max_images=max_images, ctx=ctx, channel_first=channel_first)
             yield idx, feats
+
+
+def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None, frames=None, chunk=512,
+                           device=None, channel_first=False, ctx=None):
+    """Stream a host-resident trajectory through the GPU chunk by chunk (SURVEY.md section 8f-4, "trajectory
+    feeding"): yields ``(frame_indices, features)`` with ``features`` a float32 CUDA tensor ``[n, V, C]`` (or
+    ``[n, C, nx, ny, nz]`` with ``channel_first``) for ``n <= chunk`` frames at a time.
+
+    ``coords`` is ``Molecule.coords`` (float32 ``[N, 3, F]``, frame fastest), ``box`` ``Molecule.box`` (``[3, F]``)
+    or None.  Per chunk the host only copies the ``[N, 3, n]`` slab into one of two pinned staging buffers (a few
+    host threads; runs of ``n`` contiguous floats); the transpose to frame-major happens on the device.  A copy
+    stream uploads chunk k+1 while the current stream voxelizes chunk k, so the consumer (a model, a reduction) sees
+    a steady feed whose rate is the slower of PCIe and the voxelizer.  The tensors are yours to keep: each chunk
+    gets fresh memory.
+    """
+    coords = np.asarray(coords)
+    if coords.dtype != np.float32:
+        coords = coords.astype(np.float32)
+    if coords.ndim != 3 or coords.shape[1] != 3:
+        raise ValueError("coords must be (natoms, 3, nframes)")
+    N = coords.shape[0]
+    fr = np.arange(coords.shape[2]) if frames is None else np.asarray(frames, dtype=np.int64)
+    contiguous = frames is None or (len(fr) > 0 and np.array_equal(fr, np.arange(fr[0], fr[0] + len(fr))))
+    max_images = 1
+    if box is not None:
+        box = np.asarray(box, dtype=np.float32)
+        nvoxels = np.ceil(np.array(boxsize, dtype=np.float64) / voxelsize).astype(int)
+        max_images = max_images_per_atom(np.ascontiguousarray(box[:, fr].T), nvoxels, voxelsize)
+
+    def fill(dst, dst_box, idx):
+        n = len(idx)
+        if contiguous:                                            # strided slab -> pinned, split over a few host threads
+            f0 = int(idx[0])
+            parts = np.linspace(0, N, _COPY_THREADS + 1).astype(int)
+            list(_copy_pool().map(lambda ab: np.copyto(dst[ab[0]:ab[1]], coords[ab[0]:ab[1], :, f0:f0 + n]),
+                                  zip(parts[:-1], parts[1:])))
+            if dst_box is not None:
+                np.copyto(dst_box, box[:, f0:f0 + n])
+        else:
+            np.copyto(dst, coords[:, :, idx])
+            if dst_box is not None:
+                np.copyto(dst_box, box[:, idx])
+
+    yield from _stream_voxelize(N, fr, fill, 1.0, box is not None, channels, center, boxsize, voxelsize, chunk, device,
+                                channel_first, ctx, max_images)
+
+
+def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, frames=None, chunk=512, device=None,
+                    channel_first=False, ctx=None, nthreads=0):
+    """``iterVoxelizeTrajectory`` fed straight from an XTC file: chunk k+1 is decoded by host threads (libmkamd.so's
+    decoder, ``moleculekit_amd.xtc``) directly into pinned staging and uploaded while chunk k is voxelized.
+    ``pbc``: use the frames' box (orthorhombic lengths of the box vectors) for the minimum image.  Coordinates are
+    converted from the file's nm to Angstrom on the device, like ``readers.XTCread`` does on the host."""
+    import ctypes
+
+    from . import xtc as _xtc
+    natoms, nframes = _xtc.get_xtc_natoms(filename), _xtc.get_xtc_nframes(filename)
+    fr = np.arange(nframes, dtype=np.int64) if frames is None else np.asarray(frames, dtype=np.int64)
+    lib, path = _lib.load(), _xtc._path(filename)
+    max_images = 1
+    if pbc and len(fr):
+        _, bv, _, _ = _xtc.read_xtc_frames(filename, fr[:1])     # image bound from the first frame's box (+ checked per call)
+        lengths = np.sqrt((bv[:, :, 0].astype(np.float64) ** 2).sum(axis=1)) * 10.0
+        if not np.all(lengths > 0):
+            raise ValueError("pbc=True but the XTC frames carry no box")
+        nvoxels = np.ceil(np.array(boxsize, dtype=np.float64) / voxelsize).astype(int)
+        max_images = max_images_per_atom(lengths[None, :] * 0.98, nvoxels, voxelsize)    # 2 % slack for box fluctuations
+
+    def fill(dst, dst_box, idx):
+        n = len(idx)
+        sel = np.ascontiguousarray(idx, dtype=np.int64)
+        bv = np.empty((3, 3, n), dtype=np.float32)
+        t = np.empty(n, dtype=np.float32)
+        st = np.empty(n, dtype=np.int32)
+        _lib._check(lib.mkamd_xtc_read(path, _lib._ptr(sel), n, natoms, _lib._ptr(dst), _lib._ptr(bv), _lib._ptr(t),
+                                       _lib._ptr(st), int(nthreads)))
+        if dst_box is not None:                                   # box lengths in Angstrom (readers.py:1848-1859)
+            bv *= np.float32(10.0)                                # float32 like the reference's conversion
+            np.copyto(dst_box, np.sqrt(np.sum(bv * bv, axis=1)))
+
+    yield from _stream_voxelize(natoms, fr, fill, 10.0, bool(pbc), channels, center, boxsize, voxelsize, chunk, device,
+                                channel_first, ctx, max_images)

@@ -4,6 +4,8 @@
 // point fails with MKAMD_ENODEV / MKAMD_EHIP.
 #include "../../include/mkamd_voxel.h"
 #include "../../include/mkamd_distance.h"
+#include "../../include/mkamd_xtc.h"
+#include "xtc_reader.h"
 #include "pipeline.h"
 #include "dist_pipeline.h"
 
@@ -733,6 +735,33 @@ int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// XTC decoding (host side, include/mkamd_xtc.h)
+// ---------------------------------------------------------------------------------------------
+extern "C" int mkamd_xtc_info(const char* path, int64_t* n_atoms, int64_t* n_frames)
+{
+    if (!path || !n_atoms || !n_frames) return fail(MKAMD_EINVAL, "path/n_atoms/n_frames pointer is NULL");
+    std::string err;
+    int64_t na = 0, nf = 0;
+    const int st = mkamd::xtc::info(path, na, nf, err);
+    if (st) return fail(MKAMD_EINVAL, err);
+    *n_atoms = na; *n_frames = nf;
+    return MKAMD_OK;
+}
+
+extern "C" int mkamd_xtc_read(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, float* coords, float* box,
+                              float* time, int32_t* step, int32_t n_threads)
+{
+    if (!path) return fail(MKAMD_EINVAL, "path is NULL");
+    if (n_sel < 0 || n_atoms < 0) return fail(MKAMD_EINVAL, "n_sel and n_atoms must be >= 0");
+    if (n_sel == 0) return MKAMD_OK;
+    if (!coords || !box || !time || !step) return fail(MKAMD_EINVAL, "coords/box/time/step pointer is NULL");
+    std::string err;
+    const int st = mkamd::xtc::read(path, frames, n_sel, n_atoms, coords, box, time, step, (int)n_threads, err);
+    if (st) return fail(MKAMD_EINVAL, err);
+    return MKAMD_OK;
+}
 
 #ifdef MK_PHASE_TIMERS
 // profiling build only (tools/gpu_phase_timers.sh): read and clear the per-phase cycle sums of the tile kernel

@@ -1,0 +1,321 @@
+// xtc_reader.h -- host-side decoder for GROMACS XTC trajectories ("trajectory feeding").
+//
+// Replaces, for reading, moleculekit/fileformats/xtc/src/{xdrfile.cpp: xdrfile_decompress_coord_float :749-983,
+// xdrfile_xtc.cpp: xtc_header/xtc_coord :17-72, xtc_src.cpp: the frame index + xtc_read_new / xtc_read_frame}:
+// same files in, the same float32 bits out (coords [natoms, 3, nframes] frame-fastest in nm, box vectors
+// [3, 3, nframes], time, step).  The format is the published xdrfile / libxdrfile "xdr3dfcoord" scheme:
+//
+//   frame  := magic(1995) natoms step time(f32) box(9 f32) natoms                    -- big-endian XDR words
+//             natoms <= 9 ?  3*natoms f32
+//                         :  precision(f32) minint[3] maxint[3] smallidx nbytes  bitstream(nbytes, padded to 4)
+//   bitstream, MSB first.  Per atom a triple of non-negative ints relative to minint, packed either as three bit
+//   fields (when a range needs more than 24 bits) or as ONE mixed-radix number x0*(s1*s2) + x1*s2 + x2 whose bytes
+//   are stored least-significant first; then a flag bit and, if set, 5 bits that change the run length (number
+//   of following atoms coded as small offsets from their predecessor, radix MAGIC[smallidx] per axis) and move
+//   smallidx one step down / up.  The first small atom of a run is swapped with its predecessor on output
+//   (water oxygens behind their hydrogens).  A run length persists until a flag changes it.
+//
+// Own structure: memory-mapped file, frame index from the record lengths, a 64-bit accumulator bit reader, the
+// mixed-radix number held in an unsigned __int128 (at most 72 bits) instead of a byte-array long division, and
+// frames decoded in parallel on host threads (they are independent records).  No HIP in here.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace mkamd {
+namespace xtc {
+
+// radix table of the format ("magicints" of the xdrfile specification); entries below FIRST are unused zeros
+constexpr int MAGIC[] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406,
+                         512, 645, 812, 1024, 1290, 1625, 2048, 2580, 3250, 4096, 5060, 6501, 8192, 10321, 13003, 16384, 20642,
+                         26007, 32768, 41285, 52015, 65536, 82570, 104031, 131072, 165140, 208063, 262144, 330280, 416127,
+                         524287, 660561, 832255, 1048576, 1321122, 1664510, 2097152, 2642245, 3329021, 4194304, 5284491,
+                         6658042, 8388607, 10568983, 13316085, 16777216};
+constexpr int FIRST = 9;
+constexpr int NMAGIC = (int)(sizeof(MAGIC) / sizeof(MAGIC[0]));
+constexpr int32_t FRAME_MAGIC = 1995;
+
+enum Status { OK = 0, E_OPEN = 1, E_FORMAT = 2, E_RANGE = 3 };
+
+struct Mapped {
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    ~Mapped()
+    {
+        if (p) munmap(const_cast<uint8_t*>(p), n);
+        if (fd >= 0) close(fd);
+    }
+    bool open_file(const char* path)
+    {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) return true;
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { p = nullptr; return false; }
+        p = (const uint8_t*)m;
+        return true;
+    }
+};
+
+inline uint32_t be32(const uint8_t* q) { return ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3]; }
+inline int32_t be_i32(const uint8_t* q) { return (int32_t)be32(q); }
+inline float be_f32(const uint8_t* q)
+{
+    const uint32_t u = be32(q);
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// byte offsets of the frames; natoms of the first frame.  A truncated last record ends the list.
+inline int index_frames(const Mapped& m, std::vector<size_t>& offs, int64_t& natoms)
+{
+    offs.clear();
+    natoms = 0;
+    size_t p = 0;
+    while (p + 16 + 36 + 4 <= m.n) {
+        if (be_i32(m.p + p) != FRAME_MAGIC) return offs.empty() ? E_FORMAT : OK;
+        const int32_t na = be_i32(m.p + p + 4);
+        if (na < 0) return E_FORMAT;
+        if (offs.empty()) natoms = na;
+        size_t q = p + 16 + 36 + 4;
+        if (na <= 9) {
+            q += (size_t)12 * (size_t)na;
+        } else {
+            if (q + 36 > m.n) break;
+            const int32_t nbytes = be_i32(m.p + q + 32);
+            if (nbytes < 0) return E_FORMAT;
+            q += 36 + (((size_t)nbytes + 3) / 4) * 4;
+        }
+        if (q > m.n) break;
+        offs.push_back(p);
+        p = q;
+    }
+    return OK;
+}
+
+struct BitReader {                       // MSB-first bit stream over [p, end)
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc = 0;
+    int nacc = 0;
+    bool overrun = false;
+    uint32_t get(int nbits)              // 0 <= nbits <= 32
+    {
+        if (nbits == 0) return 0;
+        while (nacc < nbits) {
+            uint8_t b = 0;
+            if (p < end) b = *p++; else overrun = true;
+            acc = (acc << 8) | b;
+            nacc += 8;
+        }
+        nacc -= nbits;
+        return (uint32_t)((acc >> nacc) & ((nbits == 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
+    }
+    // three values packed as one mixed-radix number of `nbits` bits whose bytes come least-significant first
+    void get_triple(int nbits, const uint32_t (&radix)[3], int32_t (&out)[3])
+    {
+        unsigned __int128 x = 0;
+        int shift = 0;
+        while (nbits > 8) { x |= (unsigned __int128)get(8) << shift; shift += 8; nbits -= 8; }
+        if (nbits > 0) x |= (unsigned __int128)get(nbits) << shift;
+        out[2] = (int32_t)(uint32_t)(x % radix[2]); x /= radix[2];
+        out[1] = (int32_t)(uint32_t)(x % radix[1]); x /= radix[1];
+        out[0] = (int32_t)(uint32_t)(x & 0xffffffffu);
+    }
+};
+
+inline int bits_for(uint32_t size)       // bits needed for values 0 .. size (as the format counts them)
+{
+    int nb = 0;
+    uint64_t lim = 1;
+    while ((uint64_t)size >= lim && nb < 32) { ++nb; lim <<= 1; }
+    return nb;
+}
+
+inline int bits_for_product(const uint32_t (&s)[3])   // bits of (s0 * s1 * s2), the way the format rounds it
+{
+    // the product as little-endian bytes; bits = 8 * (bytes - 1) + bits of the top byte
+    unsigned __int128 prod = (unsigned __int128)s[0] * s[1] * s[2];
+    int nbytes = 1;
+    unsigned __int128 t = prod;
+    while ((t >> 8) != 0) { t >>= 8; ++nbytes; }
+    const uint32_t top = (uint32_t)t;
+    int nb = 0;
+    uint32_t lim = 1;
+    while (top >= lim) { ++nb; lim *= 2; }
+    return nb + (nbytes - 1) * 8;
+}
+
+// Decode the frame at `rec` into column `col` of the frame-fastest outputs (F columns).
+// `coords` is addressed as coords[(atom * 3 + axis) * cstride + ccol] (cstride = F, ccol = col writes the final
+// array directly; the threaded reader passes a small per-thread block instead and transposes it afterwards).
+inline int decode_frame(const Mapped& m, size_t rec, int64_t natoms, int64_t F, int64_t col, float* coords, int64_t cstride,
+                        int64_t ccol, float* box, float* time, int32_t* step)
+{
+    const uint8_t* q = m.p + rec;
+    if (be_i32(q) != FRAME_MAGIC) return E_FORMAT;
+    if ((int64_t)be_i32(q + 4) != natoms) return E_FORMAT;
+    step[col] = be_i32(q + 8);
+    time[col] = be_f32(q + 12);
+    for (int i = 0; i < 9; ++i) box[(size_t)i * F + col] = be_f32(q + 16 + 4 * i);
+    if ((int64_t)be_i32(q + 52) != natoms) return E_FORMAT;
+    q += 56;
+    auto put = [&](int64_t atom, int axis, float v) { coords[((size_t)atom * 3 + axis) * (size_t)cstride + (size_t)ccol] = v; };
+    if (natoms <= 9) {
+        for (int64_t a = 0; a < natoms; ++a)
+            for (int d = 0; d < 3; ++d) put(a, d, be_f32(q + 4 * (3 * a + d)));
+        return OK;
+    }
+    const float precision = be_f32(q);
+    int32_t lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) { lo[d] = be_i32(q + 4 + 4 * d); hi[d] = be_i32(q + 16 + 4 * d); }
+    int smallidx = be_i32(q + 28);
+    const int32_t nbytes = be_i32(q + 32);
+    q += 36;
+    if (nbytes < 0 || q + nbytes > m.p + m.n) return E_FORMAT;
+    uint32_t range[3];
+    for (int d = 0; d < 3; ++d) range[d] = (uint32_t)hi[d] - (uint32_t)lo[d] + 1u;
+    if (!range[0] || !range[1] || !range[2]) return E_FORMAT;
+    int field_bits[3] = {0, 0, 0}, triple_bits = 0;
+    const bool wide = (range[0] | range[1] | range[2]) > 0xffffffu;
+    if (wide) for (int d = 0; d < 3; ++d) field_bits[d] = bits_for(range[d]);
+    else triple_bits = bits_for_product(range);
+    if (smallidx < FIRST || smallidx >= NMAGIC) return E_FORMAT;
+    int smaller = MAGIC[std::max(FIRST, smallidx - 1)] / 2;
+    int smallnum = MAGIC[smallidx] / 2;
+    uint32_t small_radix[3] = {(uint32_t)MAGIC[smallidx], (uint32_t)MAGIC[smallidx], (uint32_t)MAGIC[smallidx]};
+
+    const float inv_precision = (float)(1.0 / (double)precision);
+    BitReader br{q, q + nbytes};
+    int64_t i = 0;          // atoms read
+    int64_t w = 0;          // atoms written
+    int run = 0;
+    auto emit = [&](const int32_t (&c)[3]) -> bool {
+        if (w >= natoms) return false;
+        for (int d = 0; d < 3; ++d) put(w, d, (float)c[d] * inv_precision);
+        ++w;
+        return true;
+    };
+    while (i < natoms) {
+        int32_t cur[3];
+        if (wide) { for (int d = 0; d < 3; ++d) cur[d] = (int32_t)br.get(field_bits[d]); }
+        else br.get_triple(triple_bits, range, cur);
+        ++i;
+        for (int d = 0; d < 3; ++d) cur[d] = (int32_t)((uint32_t)cur[d] + (uint32_t)lo[d]);
+        int32_t prev[3] = {cur[0], cur[1], cur[2]};
+        int step_idx = 0;
+        if (br.get(1) == 1u) {
+            run = (int)br.get(5);
+            step_idx = run % 3;
+            run -= step_idx;
+            --step_idx;                                     // -1 / 0 / +1
+        }
+        if (run > 0) {
+            for (int k = 0; k < run; k += 3) {
+                int32_t nxt[3];
+                br.get_triple(smallidx, small_radix, nxt);
+                ++i;
+                for (int d = 0; d < 3; ++d) nxt[d] = (int32_t)((uint32_t)nxt[d] + (uint32_t)prev[d] - (uint32_t)smallnum);
+                if (k == 0) {
+                    // the first small atom goes out BEFORE the full-precision one it was coded against ...
+                    if (!emit(nxt)) return E_FORMAT;
+                    if (!emit(prev)) return E_FORMAT;
+                } else {
+                    if (!emit(nxt)) return E_FORMAT;
+                }
+                for (int d = 0; d < 3; ++d) prev[d] = nxt[d];   // ... and every small atom is the reference of the next
+            }
+        } else {
+            if (!emit(cur)) return E_FORMAT;
+        }
+        smallidx += step_idx;
+        if (smallidx < FIRST || smallidx >= NMAGIC) return E_FORMAT;
+        if (step_idx < 0) {
+            smallnum = smaller;
+            smaller = smallidx > FIRST ? MAGIC[smallidx - 1] / 2 : 0;
+        } else if (step_idx > 0) {
+            smaller = smallnum;
+            smallnum = MAGIC[smallidx] / 2;
+        }
+        small_radix[0] = small_radix[1] = small_radix[2] = (uint32_t)MAGIC[smallidx];
+        if (small_radix[0] == 0u || br.overrun) return E_FORMAT;
+    }
+    return (w == natoms) ? OK : E_FORMAT;
+}
+
+// natoms / nframes of a file
+inline int info(const char* path, int64_t& natoms, int64_t& nframes, std::string& err)
+{
+    Mapped m;
+    if (!m.open_file(path)) { err = std::string("cannot open ") + path; return E_OPEN; }
+    std::vector<size_t> offs;
+    const int st = index_frames(m, offs, natoms);
+    if (st != OK) { err = "not an XTC file (bad magic number)"; return st; }
+    nframes = (int64_t)offs.size();
+    return OK;
+}
+
+// Decode `nsel` frames (indices `sel`, or 0..nsel-1 when sel == nullptr) into frame-fastest arrays of width nsel.
+inline int read(const char* path, const int64_t* sel, int64_t nsel, int64_t natoms_expected, float* coords, float* box,
+                float* time, int32_t* step, int nthreads, std::string& err)
+{
+    Mapped m;
+    if (!m.open_file(path)) { err = std::string("cannot open ") + path; return E_OPEN; }
+    std::vector<size_t> offs;
+    int64_t natoms = 0;
+    int st = index_frames(m, offs, natoms);
+    if (st != OK) { err = "not an XTC file (bad magic number)"; return st; }
+    if (natoms != natoms_expected) { err = "atom count of the file differs from the buffers'"; return E_RANGE; }
+    for (int64_t j = 0; j < nsel; ++j) {
+        const int64_t f = sel ? sel[j] : j;
+        if (f < 0 || f >= (int64_t)offs.size()) { err = "frame index out of range"; return E_RANGE; }
+    }
+    if (nthreads <= 0) nthreads = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+    nthreads = (int)std::min<int64_t>(nthreads, std::max<int64_t>(nsel, 1));
+    std::vector<int> status((size_t)nthreads, OK);
+    // The output is frame-fastest ([natoms, 3, nsel]): one frame is a column with a stride of nsel floats.  Each thread
+    // therefore decodes FB consecutive columns into a [3*natoms][FB] block of its own (FB floats = one cache line per
+    // row) and copies the block row by row into place, instead of scattering single floats a page apart.
+    constexpr int64_t FB = 16;
+    const int64_t nblocks = (nsel + FB - 1) / FB;
+    auto work = [&](int t) {
+        std::vector<float> blk((size_t)natoms * 3 * FB);
+        for (int64_t bidx = t; bidx < nblocks; bidx += nthreads) {
+            const int64_t j0 = bidx * FB, nb = std::min<int64_t>(FB, nsel - j0);
+            for (int64_t k = 0; k < nb; ++k) {
+                const int64_t f = sel ? sel[j0 + k] : j0 + k;
+                const int s = decode_frame(m, offs[(size_t)f], natoms, nsel, j0 + k, blk.data(), FB, k, box, time, step);
+                if (s != OK) { status[(size_t)t] = s; return; }
+            }
+            for (int64_t r = 0; r < natoms * 3; ++r)
+                std::memcpy(coords + (size_t)r * (size_t)nsel + (size_t)j0, blk.data() + (size_t)r * FB, (size_t)nb * sizeof(float));
+        }
+    };
+    nthreads = (int)std::min<int64_t>(nthreads, std::max<int64_t>(nblocks, 1));
+    if (nthreads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
+        for (auto& th : pool) th.join();
+    }
+    for (int s : status)
+        if (s != OK) { err = "corrupt XTC frame"; return s; }
+    return OK;
+}
+
+}  // namespace xtc
+}  // namespace mkamd

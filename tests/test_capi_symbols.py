@@ -12,7 +12,7 @@ HEADER = os.path.join(ROOT, "include", "mkamd_voxel.h")
 
 
 def declared_symbols():
-    text = open(HEADER).read() + open(os.path.join(ROOT, "include", "mkamd_distance.h")).read()
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("mkamd_voxel.h", "mkamd_distance.h", "mkamd_xtc.h"))
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mkamd_[a-z0-9_]+)\s*\(", text)))
 

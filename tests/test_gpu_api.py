@@ -188,3 +188,26 @@ def test_streamed_trajectory_matches_the_all_at_once_call():
             assert np.array_equal(got, want)
     cf = next(batch.iterVoxelizeTrajectory(xyz, sig, [L / 2] * 3, [16, 16, 16], 1.0, chunk=4, channel_first=True))[1]
     assert cf.shape == (4, 8, 16, 16, 16)
+
+
+def test_xtc_fed_stream_matches_decode_then_voxelize():
+    """XTC file -> host-thread decode straight into pinned staging -> copy stream -> voxelizer, against
+    XTCread (host decode + unit conversion) followed by voxelizeTrajectory; periodic (the file's box) and not."""
+    import torch
+    from moleculekit_amd import batch, xtc
+    fn = os.path.join(os.path.dirname(__file__), "golden", "xtc", "aladipep.xtc")
+    tr = xtc.XTCread(fn)
+    N, F = tr.coords.shape[0], tr.coords.shape[2]
+    rng = np.random.default_rng(12)
+    sig = np.where(rng.random((N, 8)) < 0.4, rng.choice([1.1, 1.52, 1.7], size=(N, 1)), 0.0)
+    center = tr.coords[:, :, 0].mean(0).astype(np.float64)
+    for pbc in (False, True):
+        want, _, _ = batch.voxelizeTrajectory(tr.coords, sig, center, [14, 14, 14], 1.0, box=tr.box.astype(np.float32) if pbc else None)
+        for chunk in (7, 64):
+            outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=pbc, chunk=chunk)]
+            torch.cuda.synchronize()
+            assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
+    sel = np.array([5, 0, 19])
+    outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=False, frames=sel, chunk=2)]
+    want, _, _ = batch.voxelizeTrajectory(tr.coords, sig, center, [14, 14, 14], 1.0, frames=sel)
+    assert np.array_equal(torch.cat(outs).cpu().numpy(), want)

@@ -1,0 +1,84 @@
+"""CPU tier: the XTC decoder in libmkamd.so (host code, no GPU) against what the REAL reference reader decodes from
+the same files (tests/golden/xtc/*, made by tests/golden/make_golden_xtc.py).  Integer/bit work: the bar is
+bit-exact float32 coordinates, box vectors, times and steps."""
+import os
+
+import numpy as np
+import pytest
+
+os.environ.setdefault("MKAMD_NO_TORCH_PRELOAD", "1")
+from moleculekit_amd import xtc  # noqa: E402
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xtc")
+FILES = ["mol", "aladipep", "3ptb_traj_head", "4rws_head"]
+
+
+def _fn(name):
+    return os.path.join(HERE, name + ".xtc")
+
+
+@pytest.mark.parametrize("name", FILES)
+@pytest.mark.parametrize("nthreads", [1, 0])
+def test_read_xtc_bit_exact(name, nthreads):
+    g = np.load(os.path.join(HERE, name + "_decoded.npz"))
+    coords, box, time, step = xtc.read_xtc(_fn(name), nthreads=nthreads)
+    st = int(g["stride"])
+    assert coords.dtype == np.float32 and coords.shape[0] == int(g["natoms"]) and coords.flags["C_CONTIGUOUS"]
+    assert np.array_equal(coords[::st].view(np.uint32), g["coords"].view(np.uint32))
+    assert int(coords.view(np.uint32).astype(np.uint64).sum()) == int(g["bitsum"])      # every atom, not just the stored ones
+    assert np.array_equal(box, g["box"]) and np.array_equal(time, g["time"]) and np.array_equal(step, g["step"])
+    assert xtc.get_xtc_natoms(_fn(name)) == coords.shape[0] and xtc.get_xtc_nframes(_fn(name)) == coords.shape[2]
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_read_xtc_frames_selection(name):
+    g = np.load(os.path.join(HERE, name + "_decoded.npz"))
+    c, b, t, s = xtc.read_xtc_frames(_fn(name), g["sel"])
+    st = int(g["stride"])
+    assert np.array_equal(c[::st], g["sel_coords"]) and np.array_equal(b, g["sel_box"])
+    assert np.array_equal(t, g["sel_time"]) and np.array_equal(s, g["sel_step"])
+    # repeats and arbitrary order are columns of the full read
+    full = xtc.read_xtc(_fn(name))[0]
+    F = full.shape[2]
+    sel = np.array([F - 1, 0, F - 1, F // 2])
+    assert np.array_equal(xtc.read_xtc_frames(_fn(name), sel)[0], full[:, :, sel])
+
+
+def test_xtcread_units_and_box():
+    """readers.XTCread (readers.py:1846-1860): nm -> A, ps -> fs, box vectors -> lengths / angles."""
+    raw_c, raw_b, raw_t, raw_s = xtc.read_xtc(_fn("aladipep"))
+    tr = xtc.XTCread(_fn("aladipep"))
+    assert np.array_equal(tr.coords, raw_c * np.float32(10.0)) and tr.coords.dtype == np.float32
+    assert np.allclose(tr.time, raw_t.astype(np.float64) * 1e3) and np.array_equal(tr.step, raw_s)
+    assert tr.box.shape == (3, raw_c.shape[2]) and np.allclose(tr.box[0], raw_b[0, 0] * 10.0, rtol=1e-6)
+    assert np.allclose(tr.boxangles, 90.0)
+    one = xtc.XTCread(_fn("aladipep"), frame=3)
+    assert one.coords.shape[2] == 1 and np.array_equal(one.coords[:, :, 0], tr.coords[:, :, 3])
+    la, lb, lc, al, be, ga = xtc.box_vectors_to_lengths_and_angles(np.array([2.0, 0, 0]), np.array([0, 1.0, 0]), np.array([0, 1.0, 1.0]))
+    assert la == 2.0 and lb == 1.0 and np.isclose(lc, np.sqrt(2)) and np.isclose(al, 45) and np.isclose(be, 90) and np.isclose(ga, 90)
+
+
+def test_truncated_and_bad_files(tmp_path):
+    buf = open(_fn("aladipep"), "rb").read()
+    cut = tmp_path / "cut.xtc"
+    cut.write_bytes(buf[:len(buf) - 1000])                       # last record incomplete: it is not a frame
+    nf = xtc.get_xtc_nframes(str(cut))
+    assert nf == 19
+    assert np.array_equal(xtc.read_xtc(str(cut))[0], xtc.read_xtc(_fn("aladipep"))[0][:, :, :19])
+    with pytest.raises(ValueError, match="out of range"):
+        xtc.read_xtc_frames(str(cut), [19])
+    bad = tmp_path / "bad.xtc"
+    bad.write_bytes(b"not an xtc file at all, just some text that is long enough to hold a header" * 2)
+    with pytest.raises(ValueError, match="XTC"):
+        xtc.read_xtc(str(bad))
+    with pytest.raises(ValueError, match="cannot open"):
+        xtc.get_xtc_natoms(str(tmp_path / "missing.xtc"))
+    corrupt = bytearray(buf)
+    corrupt[200:260] = b"\\xff" * 60                              # garbage inside the first frame's bit stream
+    cf = tmp_path / "corrupt.xtc"
+    cf.write_bytes(bytes(corrupt))
+    try:                                                         # must not crash; either an error or finite garbage
+        c = xtc.read_xtc(str(cf))[0]
+        assert c.shape[0] == 688
+    except ValueError:
+        pass
