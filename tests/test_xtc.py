@@ -6,8 +6,7 @@ import os
 import numpy as np
 import pytest
 
-os.environ.setdefault("MKAMD_NO_TORCH_PRELOAD", "1")
-from moleculekit_amd import xtc  # noqa: E402
+from moleculekit_amd import xtc
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "xtc")
 FILES = ["mol", "aladipep", "3ptb_traj_head", "4rws_head"]
