@@ -233,16 +233,18 @@ def _copy_pool():
     return _POOL
 
 
-def _pinned(key, shape):
-    """Pinned float32 staging tensor, cached per (key, shape) for the life of the process."""
+def _pinned_take(key, shape):
+    """Pinned float32 staging tensor of `shape`: taken OUT of a small process-wide cache (pinning costs milliseconds)
+    so that two streams running at once never share one; give it back with ``_pinned_give``."""
     import torch
-    k = (key, tuple(shape))
-    t = _PINNED.get(k)
-    if t is None:
-        for old in [q for q in _PINNED if q[0] == key]:
-            del _PINNED[old]
-        t = _PINNED[k] = torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
-    return t
+    t = _PINNED.pop((key, tuple(shape)), None)
+    return t if t is not None else torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
+
+
+def _pinned_give(key, t):
+    for old in [q for q in _PINNED if q[0] == key]:          # one buffer per role is enough to keep
+        del _PINNED[old]
+    _PINNED[(key, tuple(t.shape))] = t
 
 
 def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first, ctx,
@@ -267,8 +269,8 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
         d_sig = torch.as_tensor(sig, device=dev).repeat(chunk, 1).contiguous()            # [chunk*N, C], shared by the frames
         d_offs = torch.arange(chunk + 1, dtype=torch.int64, device=dev) * N
         d_org = torch.as_tensor(np.broadcast_to(origin, (chunk, 3)).copy(), device=dev)
-        stage = [_pinned(("traj", i), (N * 3 * chunk,)) for i in range(2)]               # cached: pinning costs milliseconds
-        stage_box = [_pinned(("trajbox", i), (3 * chunk,)) for i in range(2)]
+        stage = [_pinned_take(("traj", i), (N * 3 * chunk,)) for i in range(2)]
+        stage_box = [_pinned_take(("trajbox", i), (3 * chunk,)) for i in range(2)]
         free = [torch.cuda.Event(), torch.cuda.Event()]          # staging buffer i may be overwritten
         ready = [torch.cuda.Event(), torch.cuda.Event()]         # device copy of chunk in slot i has landed
         dslab = [None, None]
@@ -288,27 +290,33 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
                 ready[slot].record(copy)
             return idx
 
-        nchunks = (len(fr) + chunk - 1) // chunk
-        pending = upload(0, 0) if nchunks else None
-        for k in range(nchunks):
-            slot = k & 1
-            idx = pending
-            if k + 1 < nchunks:
-                pending = upload(k + 1, slot ^ 1)
-            n = len(idx)
-            main.wait_event(ready[slot])
-            slab, bx = dslab[slot], dbox[slot]
-            slab.record_stream(main)
-            xyz = slab.permute(2, 0, 1).contiguous().view(n * N, 3)                       # frame-major, on the device
-            if scale != 1.0:
-                xyz.mul_(scale)
-            d_b = None
-            if bx is not None:
-                bx.record_stream(main)
-                d_b = bx.t().contiguous()
-            feats = voxelize_lattice_torch(xyz, d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize, box=d_b,
-                                           max_images=max_images, ctx=ctx, channel_first=channel_first)
-            yield idx, feats
+        try:
+            nchunks = (len(fr) + chunk - 1) // chunk
+            pending = upload(0, 0) if nchunks else None
+            for k in range(nchunks):
+                slot = k & 1
+                idx = pending
+                if k + 1 < nchunks:
+                    pending = upload(k + 1, slot ^ 1)
+                n = len(idx)
+                main.wait_event(ready[slot])
+                slab, bx = dslab[slot], dbox[slot]
+                slab.record_stream(main)
+                xyz = slab.permute(2, 0, 1).contiguous().view(n * N, 3)                   # frame-major, on the device
+                if scale != 1.0:
+                    xyz.mul_(scale)
+                d_b = None
+                if bx is not None:
+                    bx.record_stream(main)
+                    d_b = bx.t().contiguous()
+                feats = voxelize_lattice_torch(xyz, d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize, box=d_b,
+                                               max_images=max_images, ctx=ctx, channel_first=channel_first)
+                yield idx, feats
+        finally:                                                  # also when the consumer stops early
+            copy.synchronize()                                    # no H2D still reading the staging buffers
+            for i in range(2):
+                _pinned_give(("traj", i), stage[i])
+                _pinned_give(("trajbox", i), stage_box[i])
 
 
 def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None, frames=None, chunk=512,
