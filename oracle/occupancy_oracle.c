@@ -140,3 +140,46 @@ float oracle_min_image_dist2(const float *c1, const float *c2, const float *box,
     }
     return dx * dx + dy * dy + dz * dz;
 }
+
+/*
+ * The same loop split over host threads (contiguous slices of the centres: no two threads touch the same result row).
+ * Only bench.py's cpu_baseline leg uses it, for the "what would all host cores do" figure next to the serial number --
+ * the reference itself is serial (no nogil, OpenMP commented out: setup.py:48).
+ */
+#include <pthread.h>
+
+typedef struct {
+    const double *centers; int64_t c0, c1;
+    const float *coords; int64_t n_atoms;
+    const double *sigmas; int32_t n_channels;
+    double *results;
+} oracle_slice_t;
+
+static void *oracle_slice_run(void *arg)
+{
+    const oracle_slice_t *s = (const oracle_slice_t *)arg;
+    oracle_calculate_occupancy(s->centers + 3 * s->c0, s->c1 - s->c0, s->coords, s->n_atoms, s->sigmas, s->n_channels,
+                               s->results + (size_t)s->c0 * s->n_channels);
+    return NULL;
+}
+
+int oracle_calculate_occupancy_threads(const double *centers, int64_t n_centers, const float *coords, int64_t n_atoms,
+                                       const double *sigmas, int32_t n_channels, double *results, int32_t n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    if ((int64_t)n_threads > n_centers) n_threads = (int32_t)(n_centers > 0 ? n_centers : 1);
+    pthread_t th[1024];
+    oracle_slice_t sl[1024];
+    int started = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        sl[t].centers = centers; sl[t].coords = coords; sl[t].n_atoms = n_atoms; sl[t].sigmas = sigmas;
+        sl[t].n_channels = n_channels; sl[t].results = results;
+        sl[t].c0 = n_centers * t / n_threads; sl[t].c1 = n_centers * (t + 1) / n_threads;
+        if (pthread_create(&th[t], NULL, oracle_slice_run, &sl[t]) != 0) break;
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    for (int t = started; t < n_threads; ++t) oracle_slice_run(&sl[t]);     /* could not spawn: run inline */
+    return started;
+}
