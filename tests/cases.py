@@ -118,6 +118,20 @@ def case_tiny_items():
     return _case(np.concatenate(coords), offs, sig, origins, [12, 10, 9], 1.0)
 
 
+def case_nonfinite_coords():
+    """NaN / +-inf / huge coordinates: the reference's `dist2 < 25` is false for them, i.e. such atoms contribute
+    nothing (and nothing may be indexed out of range on the way)."""
+    rng = np.random.default_rng(29)
+    n = 60
+    c = rng.normal(0, 3.0, size=(n, 3)).astype(np.float32)
+    c[3] = [np.nan, 0.0, 0.0]
+    c[7] = [0.0, np.inf, 0.0]
+    c[11] = [-np.inf, np.nan, 1.0]
+    c[13] = [3.0e38, -3.0e38, 1.0e30]
+    c[17] = [1.0e9, 0.0, 0.0]
+    return _case(c, [0, n], synth_sigmas(rng, n), [[-6.0, -6.0, -6.0]], [12, 12, 12], 1.0)
+
+
 def case_voxel07():
     """Non-dyadic voxel size (0.7 A) and a grid smaller than one tile."""
     rng = np.random.default_rng(22)
@@ -201,6 +215,7 @@ LATTICE_CASES = {
     "celecoxib_bbox": case_celecoxib_bbox,
     "ragged_batch": case_ragged_batch,
     "tiny_items": case_tiny_items,
+    "nonfinite_coords": case_nonfinite_coords,
     "voxel07": case_voxel07,
     "voxel025": case_voxel025,
     "channels1": lambda: case_channels(1),
