@@ -65,6 +65,16 @@ def make_config(name, batch, seed=None):
 def make_workload(name, batch, seed):
     from tests.synth import grid_origin
     p = make_config(name, batch, seed)
+    if os.environ.get("MKAMD_SPATIAL_ORDER", "0") == "1":
+        # experiment knob: atoms of every item in spatially coherent order (8 A blocks), like residues / waters in a
+        # real topology, instead of the synthetic generator's random order
+        co, sg, offs = p["coords"].copy(), p["sigmas"].copy(), p["atom_offsets"]
+        for b in range(len(offs) - 1):
+            s0, e0 = int(offs[b]), int(offs[b + 1])
+            key = np.floor(co[s0:e0] / 8.0).astype(np.int64)
+            order = np.lexsort((key[:, 2], key[:, 1], key[:, 0]))
+            co[s0:e0], sg[s0:e0] = co[s0:e0][order], sg[s0:e0][order]
+        p["coords"], p["sigmas"] = co, sg
     origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
     nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
     return p, origins, nv

@@ -32,6 +32,8 @@ MK_DEV int mk_rank_in_mask(unsigned long long mask)
 }
 
 MK_DEV int mk_popc64(unsigned long long m) { return __popcll(m); }
+MK_DEV int mk_clz64(unsigned long long m) { return __builtin_clzll(m); }      // m != 0
+MK_DEV int mk_ctz64(unsigned long long m) { return __builtin_ctzll(m); }      // m != 0
 
 MK_DEV float mk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_f32 (1 ulp); rcp(inf)=0, rcp(0)=inf
 
@@ -87,6 +89,8 @@ MK_DEV unsigned mk_readlane(unsigned v, int lane) { return (unsigned)__builtin_a
 
 MK_DEV unsigned mk_shfl_up(unsigned v, int delta) { return __shfl_up(v, delta, WAVE); }
 MK_DEV unsigned mk_shfl_down(unsigned v, int delta) { return __shfl_down(v, delta, WAVE); }
+// value of v in lane `src` (per-lane source: ds_bpermute_b32)
+MK_DEV unsigned mk_shfl(unsigned v, int src) { return (unsigned)__shfl((int)v, src, WAVE); }
 
 // separately rounded double multiply / add (never contracted into an FMA)
 MK_DEV double mk_dmul_rn(double a, double b)

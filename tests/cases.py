@@ -118,6 +118,24 @@ def case_tiny_items():
     return _case(np.concatenate(coords), offs, sig, origins, [12, 10, 9], 1.0)
 
 
+def case_sorted_atoms():
+    """Atom lists in spatially coherent order (runs of consecutive atoms in one cell, like residues / waters), with
+    channel-less and out-of-grid atoms breaking the runs: the binning ranks such runs with one atomic each."""
+    rng = np.random.default_rng(30)
+    ns = [900, 5, 700]
+    coords, sig = [], []
+    for n in ns:
+        c = rng.uniform(-9.0, 9.0, size=(n, 3)).astype(np.float32)
+        key = np.floor((c + 16.0) / 8.0).astype(np.int64)
+        c = c[np.lexsort((key[:, 2], key[:, 1], key[:, 0]))]
+        sg = synth_sigmas(rng, n)
+        sg[rng.random(n) < 0.15] = 0.0                       # dropped atoms inside the runs
+        c[rng.random(n) < 0.05] += 80.0                      # atoms far outside the grid inside the runs
+        coords.append(c); sig.append(sg)
+    offs = np.concatenate([[0], np.cumsum(ns)])
+    return _case(np.concatenate(coords), offs, np.concatenate(sig), np.tile([[-8.0, -8.0, -8.0]], (3, 1)), [16, 16, 16], 1.0)
+
+
 def case_nonfinite_coords():
     """NaN / +-inf / huge coordinates: the reference's `dist2 < 25` is false for them, i.e. such atoms contribute
     nothing (and nothing may be indexed out of range on the way)."""
@@ -216,6 +234,7 @@ LATTICE_CASES = {
     "ragged_batch": case_ragged_batch,
     "tiny_items": case_tiny_items,
     "nonfinite_coords": case_nonfinite_coords,
+    "sorted_atoms": case_sorted_atoms,
     "voxel07": case_voxel07,
     "voxel025": case_voxel025,
     "channels1": lambda: case_channels(1),

@@ -167,6 +167,8 @@ MK_DEV int mk_rank_in_mask(unsigned long long mask)
     return __builtin_popcountll(mask & ((1ull << lane) - 1ull));
 }
 MK_DEV int mk_popc64(unsigned long long m) { return __builtin_popcountll(m); }
+MK_DEV int mk_clz64(unsigned long long m) { return __builtin_clzll(m); }
+MK_DEV int mk_ctz64(unsigned long long m) { return __builtin_ctzll(m); }
 MK_DEV float mk_rcp(float x) { return 1.0f / x; }
 MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
@@ -210,6 +212,15 @@ MK_DEV unsigned mk_shfl_up(unsigned v, int delta)
     emu::g_blk.xchg[threadIdx.x] = v;
     emu::rendezvous(wv, WAVE);
     const unsigned r = lane >= delta ? emu::g_blk.xchg[threadIdx.x - delta] : v;
+    emu::rendezvous(wv, WAVE);
+    return r;
+}
+MK_DEV unsigned mk_shfl(unsigned v, int src)
+{
+    const int wv = (int)threadIdx.x >> 6;
+    emu::g_blk.xchg[threadIdx.x] = v;
+    emu::rendezvous(wv, WAVE);
+    const unsigned r = emu::g_blk.xchg[(wv << 6) + (src & 63)];
     emu::rendezvous(wv, WAVE);
     return r;
 }
