@@ -18,8 +18,9 @@ for f in sorted(glob.glob("gpurun_out/bench_*.log")):
             json.dump(json.loads(line), open(f"profiles/{tag}_bench_{name}.json", "w"), indent=1)
             break
 for d, suffix in (("prof_cfg2", ""), ("prof_cfg2_nopipe", "_nopipe")):
-    for f in glob.glob(f"gpurun_out/{d}/*/*_kernel_stats.csv"):
-        shutil.copy(f, f"profiles/{tag}_cfg2{suffix}_rocprofv3_kernel_stats.csv")
+    stats = sorted(glob.glob(f"gpurun_out/{d}/*/*_kernel_stats.csv"), key=os.path.getmtime)    # gpurun merges: keep the newest
+    if stats:
+        shutil.copy(stats[-1], f"profiles/{tag}_cfg2{suffix}_rocprofv3_kernel_stats.csv")
     t = f"gpurun_out/timeline_{d}.txt"
     if os.path.exists(t):
         shutil.copy(t, f"profiles/{tag}_cfg2{suffix}_timeline.txt")
