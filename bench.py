@@ -31,7 +31,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector FP32 peak (secondary roofline: cfg2/cfg4 are VALU-bound)
 
-DEFAULT_BATCH = {"cfg1": 1024, "cfg2": 32, "cfg3": 1024, "cfg4": 32, "cfg5": 4096, "dist": 2048, "dropin": 1}
+# items per GPU per step: big enough that the tile grid is many waves deep (a 32-grid step of cfg2 is only four:
+# its tail costs ~15 %) and that the fixed per-step costs (launch gaps, the barrier of the timed region) amortise
+DEFAULT_BATCH = {"cfg1": 4096, "cfg2": 256, "cfg3": 8192, "cfg4": 256, "cfg5": 16384, "dist": 2048, "dropin": 1}
 
 
 def real_protein_config(batch, seed):
@@ -92,8 +94,10 @@ def pmc_traffic(workload, batch, tile_k):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
+    if d.get("_items_per_launch") != batch:
+        return None, None
     for k, v in d.items():
-        if "k_voxelize_tiles<8" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if isinstance(v, dict) and "k_voxelize_tiles<8" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024), os.path.relpath(files[-1], ROOT)
     return None, None
 

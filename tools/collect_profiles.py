@@ -30,7 +30,10 @@ for f in glob.glob("gpurun_out/pmc_*/*/*counter_collection.csv"):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if acc:
-    out = {"_note": "mean per launch over the launches of `python bench.py --steps 4 --warmup 1 --no-pipeline` "
+    sys.path.insert(0, os.getcwd())
+    import bench
+    out = {"_items_per_launch": bench.DEFAULT_BATCH["cfg2"],
+           "_note": "mean per launch over the launches of `python bench.py --steps 4 --warmup 1 --no-pipeline` "
                     "(one rocprofv3 --pmc pass per counter group, tools/gpu_pmc.sh); FETCH_SIZE / WRITE_SIZE in KiB "
                     "(FETCH_SIZE counts 64 B per 128-B request on gfx950: double it, MI355X_MICROARCH.md HBM section)"}
     for k in sorted(acc):
