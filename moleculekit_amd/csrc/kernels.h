@@ -112,8 +112,15 @@ MK_DEV float sigma_to_w(SigT sigma, double w_scale)
 // all the channels it has (sigma = radius x mask), so the double-precision division is done once for the
 // lane's first usable sigma and only atoms with several distinct sigmas take the per-channel path.
 // Values are exactly sigma_to_w's.
+// Besides the CHG values it returns the atom's COMPACT channel description, which the binning parks per (atom, group)
+// so that the fill pass needs neither the sigmas nor the division again:
+//   cw.x = bit pattern of w0 (the lane's first usable sigma; CLS_EMPTY when there is none)
+//   cw.y = nibble mask, nibble j = 1 when channel c0+j carries w0; ATOM_MULTI_SIGMA when the atom has several distinct
+//          sigmas (rare), which sends the fill pass back to the sigma row.
+constexpr unsigned ATOM_MULTI_SIGMA = 0xffffffffu;
+
 template <typename SigT>
-MK_DEV void atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w_scale, float (&w)[CHG])
+MK_DEV uint2 atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w_scale, float (&w)[CHG])
 {
     SigT s[CHG];
 #pragma unroll
@@ -123,9 +130,11 @@ MK_DEV void atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w
     for (int j = CHG - 1; j >= 0; --j) s0 = (s[j] != (SigT)0) ? s[j] : s0;
     const float w0 = sigma_to_w(s0, w_scale);                    // +inf when the atom has no channel here
     bool other = false;
+    unsigned nib = 0u;
 #pragma unroll
     for (int j = 0; j < CHG; ++j) {
         w[j] = (s[j] == s0) ? w0 : mk_inf();
+        nib |= (s[j] == s0) ? (1u << (4 * j)) : 0u;
         other |= (s[j] != s0) && (s[j] != (SigT)0);
     }
     if (other) {                                                 // rare: several distinct sigmas (or NaN)
@@ -133,6 +142,8 @@ MK_DEV void atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w
         for (int j = 0; j < CHG; ++j)
             if ((s[j] != s0) && (s[j] != (SigT)0)) w[j] = sigma_to_w(s[j], w_scale);
     }
+    const bool none = !(w0 < mk_inf());
+    return make_uint2(none ? CLS_EMPTY : mk_float_bits(w0), other ? ATOM_MULTI_SIGMA : (none ? 0u : nib));
 }
 
 // Class table: NCLS slots of w bit patterns (CLS_EMPTY = unused), word NCLS = overflow marker.
@@ -177,26 +188,16 @@ MK_DEV void wave_register_value(unsigned bits, unsigned* s_set, unsigned* s_full
     }
 }
 
-MK_DEV void wave_register_classes(unsigned (&wb)[CHG], unsigned* s_set, unsigned* s_full)
+// `first` = the lane's w0 bits (most atoms carry ONE radius in all their channels: that is their only value),
+// `multi` = the lane's atom has several distinct sigmas, its other values are in wb[].
+MK_DEV void wave_register_classes(unsigned first, bool multi, const unsigned (&wb)[CHG], unsigned* s_set, unsigned* s_full)
 {
-    // most atoms carry ONE radius in all their channels: collapse equal values inside the lane first
-#pragma unroll
-    for (int j = 1; j < CHG; ++j)
-#pragma unroll
-        for (int i = 0; i < j; ++i)
-            if (wb[j] == wb[i]) wb[j] = CLS_EMPTY;
     // the lane's first value goes through one election loop (a handful of trips per wave) ...
-    unsigned first = CLS_EMPTY;
-#pragma unroll
-    for (int j = CHG - 1; j >= 0; --j) first = (wb[j] != CLS_EMPTY) ? wb[j] : first;
     wave_register_value(first, s_set, s_full);
     // ... and only waves holding atoms with SEVERAL distinct sigmas pay for the remaining slots
-    bool more = false;
+    if (mk_ballot(multi) != 0ull) {
 #pragma unroll
-    for (int j = 0; j < CHG; ++j) more |= (wb[j] != CLS_EMPTY) && (wb[j] != first);
-    if (mk_ballot(more) != 0ull) {
-#pragma unroll
-        for (int j = 0; j < CHG; ++j) wave_register_value((wb[j] != first) ? wb[j] : CLS_EMPTY, s_set, s_full);
+        for (int j = 0; j < CHG; ++j) wave_register_value((multi && wb[j] != first) ? wb[j] : CLS_EMPTY, s_set, s_full);
     }
 }
 
@@ -310,13 +311,28 @@ MK_DEV unsigned wave_rank_in_cell(bool want, unsigned cell, unsigned* __restrict
     return base + offset;
 }
 
-template <typename SigT, class RankOne, class RankWave>
-MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, const float* __restrict__ coords,
+// largest b in [lo, B) with atom_offsets[b] <= a
+MK_DEV int item_of_atom(const long long* __restrict__ atom_offsets, int B, long long a, int lo)
+{
+    int hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// PBC: 0 = open boundaries, 1 = periodic, -1 = decided at run time (g.pbc).  The periodic image loop costs ~20 VGPRs;
+// k_bin_count is compiled for both so that the common open-boundary kernel stays small enough to run beside the tile kernel.
+template <typename SigT, int PBC, class RankOne, class RankWave>
+MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_hi, const float* __restrict__ coords,
                      const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
                      const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
-                     float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, int* __restrict__ err_flag,
+                     float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, uint2* __restrict__ tmp_cls,
+                     int* __restrict__ err_flag,
                      bool classes, unsigned* s_set, unsigned* s_full, RankOne&& rank_one, RankWave&& rank_wave)
 {
+    const bool pbc = PBC < 0 ? (g.pbc != 0) : (PBC != 0);
     // ---- the atom's channels: w bit patterns (one pass over the sigmas serves the drop test AND the class
     //      discovery); registration is wave-cooperative, so every lane takes part ----
     bool any = false;
@@ -325,13 +341,20 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, cons
         float w[CHG];
 #pragma unroll
         for (int j = 0; j < CHG; ++j) w[j] = mk_inf();
-        if (act) atom_channel_w(sigmas + (size_t)a * g.C, c0, g.C, g.w_scale, w);
-#pragma unroll
-        for (int j = 0; j < CHG; ++j) {
-            wb[j] = CLS_EMPTY;
-            if (w[j] < mk_inf()) { wb[j] = mk_float_bits(w[j]); any = true; }
+        uint2 cw = make_uint2(CLS_EMPTY, 0u);
+        if (act) {
+            cw = atom_channel_w(sigmas + (size_t)a * g.C, c0, g.C, g.w_scale, w);
+            tmp_cls[(size_t)a * g.G + (c0 / CHG)] = cw;              // parked for the fill pass
         }
-        if (classes) wave_register_classes(wb, s_set, s_full);
+        const bool multi = cw.y == ATOM_MULTI_SIGMA;
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) wb[j] = (w[j] < mk_inf()) ? mk_float_bits(w[j]) : CLS_EMPTY;
+        any |= cw.x != CLS_EMPTY;
+        if (multi) {
+#pragma unroll
+            for (int j = 0; j < CHG; ++j) any |= wb[j] != CLS_EMPTY;
+        }
+        if (classes) wave_register_classes(cw.x, multi, wb, s_set, s_full);
     }
 
     const size_t t0 = (size_t)(act ? a : 0) * (size_t)g.img_cap;     // this atom's temp slots
@@ -342,15 +365,14 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, cons
     int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
     int b = 0;
     if (!drop) {
-        b = b_known;
-        if (b < 0) {                                                 // item of this atom: largest b with atom_offsets[b] <= a
-            int lo = 0, hi = g.B;
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
-            }
-            b = lo;
+        // item of this atom: the largest b in [b_lo, b_hi] with atom_offsets[b] <= a (the caller narrows the range
+        // with wave-uniform look-ups: nearly always b_lo == b_hi and nothing is searched per lane)
+        int lo = b_lo, hi = b_hi + 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
         }
+        b = lo;
         const int nvox[3] = {g.nx, g.ny, g.nz};
         // fused augmentation (tools/voxeldescriptors.py:78-114 rotateCoordinates, then the astype(float32) of
         // _getOccupancyC :519): x' = M x + t in double, rounded to float32 like the reference pipeline does
@@ -365,7 +387,7 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, cons
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             p[ax] = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
-            if (g.pbc) {
+            if (pbc) {
                 const double L = (double)box[3 * (size_t)b + ax] * g.inv_res;
                 if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); drop = true; }
                 Lv[ax] = L;
@@ -398,7 +420,7 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, cons
         tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
         ++used;
     };
-    if (!g.pbc) {
+    if (!pbc) {
         // one position per atom: every lane takes part in the ranking (consecutive atoms of one cell share an atomic)
         int pc[3] = {0, 0, 0};
         float rel[3] = {0.f, 0.f, 0.f};
@@ -438,13 +460,13 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_known, cons
         for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
 }
 
-template <typename SigT>
+template <typename SigT, int PBC>
 MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 const long long* __restrict__ atom_offsets, long long total_atoms,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                 const float* __restrict__ box, const double* __restrict__ affine,
                                 unsigned* __restrict__ cell_count,
-                                float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
+                                float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, uint2* __restrict__ tmp_cls,
                                 unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
 {
     mk_wave_priority_high();
@@ -456,8 +478,13 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
         if (threadIdx.x == 0) s_full = 0u;
         mk_block_sync();
     }
-    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bin_atom<SigT>(g, a, a < total_atoms, -1, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, err_flag,
+    // the items of the block's first and last atom (block-uniform: scalar loads); one block rarely spans several
+    const long long a_first = (long long)blockIdx.x * blockDim.x;
+    const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
+    const int b_lo = item_of_atom(atom_offsets, g.B, a_first, 0);
+    const int b_hi = item_of_atom(atom_offsets, g.B, a_last, b_lo);
+    const long long a = a_first + threadIdx.x;
+    bin_atom<SigT, PBC>(g, a, a < total_atoms, b_lo, b_hi, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, tmp_cls, err_flag,
                    classes, s_set, &s_full, [&](size_t cell) { return mk_atomic_add(&cell_count[cell], 1u); },
                    [&](bool want, size_t cell) { return wave_rank_in_cell(want, (unsigned)cell, cell_count); });
     if (classes) {
@@ -469,41 +496,55 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
 
 // One cell-sorted record: the parked position + the atom's per-channel class ids (or w values on the general path).
 // `tab` = the class table in registers (wave-uniform), so that a lookup is NCLS register compares.
+// The atom's channels come from the compact description the binning parked (w0 bits + nibble mask): one table look-up
+// and one multiply give the 8 class ids; only atoms with several distinct sigmas go back to their sigma row.
 template <typename SigT>
 MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* __restrict__ sigmas,
-                        const float4* __restrict__ tmp_pos, float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
+                        const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_cls,
+                        float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                         unsigned* __restrict__ rec_cls, const unsigned (&tab)[NCLS], bool general)
 {
     rec_pos[slot] = tmp_pos[t];
-    const size_t a = t / (size_t)g.img_cap;
-    const SigT* sg = sigmas + a * (size_t)g.C;
+    const size_t a = g.img_cap == 1 ? t : t / (size_t)g.img_cap;
+    auto class_of = [&](unsigned bits) {
+        unsigned id = 0;
+#pragma unroll
+        for (int i = 0; i < NCLS; ++i) id = (tab[i] == bits) ? (unsigned)(i + 1) : id;
+        return id;
+    };
     for (int gq = 0; gq < g.G; ++gq) {
+        const uint2 cw = tmp_cls[a * (size_t)g.G + gq];
+        if (cw.y != ATOM_MULTI_SIGMA) {
+            if (general) {
+                float w[CHG];
+#pragma unroll
+                for (int c = 0; c < CHG; ++c) w[c] = ((cw.y >> (4 * c)) & 1u) ? mk_int_as_float((int)cw.x) : mk_inf();
+                rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
+                rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
+            } else {
+                rec_cls[(size_t)gq * g.M + slot] = class_of(cw.x) * cw.y;      // ids <= 15: no carry between nibbles
+            }
+            continue;
+        }
         float w[CHG];
-        atom_channel_w(sg, gq * CHG, g.C, g.w_scale, w);
+        atom_channel_w(sigmas + a * (size_t)g.C, gq * CHG, g.C, g.w_scale, w);
         if (general) {
             rec_w[(size_t)(gq * 2 + 0) * g.M + slot] = make_float4(w[0], w[1], w[2], w[3]);
             rec_w[(size_t)(gq * 2 + 1) * g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
         } else {
             unsigned ids = 0;
-#pragma unroll
-            for (int c = 0; c < CHG; ++c) {
-                unsigned id = 0;
-                if (w[c] < mk_inf()) {
-                    const unsigned bits = mk_float_bits(w[c]);
-#pragma unroll
-                    for (int i = 0; i < NCLS; ++i) id = (tab[i] == bits) ? (unsigned)(i + 1) : id;
-                }
-                ids |= id << (4 * c);
-            }
+            for (int c = 0; c < CHG; ++c)
+                if (w[c] < mk_inf()) ids |= class_of(mk_float_bits(w[c])) << (4 * c);
             rec_cls[(size_t)gq * g.M + slot] = ids;
         }
     }
 }
 
 template <typename SigT>
-MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
+__attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
                                const unsigned* __restrict__ cell_start,
                                const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_idx,
+                               const uint2* __restrict__ tmp_cls,
                                float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                                unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
 {
@@ -516,7 +557,7 @@ MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
     unsigned tab[NCLS];
 #pragma unroll
     for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
-    fill_record<SigT>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, rec_pos, rec_w, rec_cls, tab, general);
+    fill_record<SigT>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, tmp_cls, rec_pos, rec_w, rec_cls, tab, general);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -561,7 +602,7 @@ MK_KERNEL(1024) void k_prepass_items(GridDesc g, const float* __restrict__ coord
                                      const void* __restrict__ sigmas_v, const double* __restrict__ origins,
                                      const float* __restrict__ box, const double* __restrict__ affine,
                                      unsigned* __restrict__ cell_start,
-                                     float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx,
+                                     float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, uint2* __restrict__ tmp_cls,
                                      float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                                      unsigned* __restrict__ rec_cls, unsigned* __restrict__ cls_table,
                                      unsigned* __restrict__ dense_words, int* __restrict__ err_flag)
@@ -587,7 +628,7 @@ MK_KERNEL(1024) void k_prepass_items(GridDesc g, const float* __restrict__ coord
     // ---- phase 1: temp records with the rank inside the cell, LDS counts, the item's sigma classes ----
     for (long long base = a0; base < a1; base += nth) {                  // block-uniform trip count
         const long long a = base + tid;
-        bin_atom<SigT>(g, a, a < a1, b, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, err_flag,
+        bin_atom<SigT, -1>(g, a, a < a1, b, b, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, tmp_cls, err_flag,
                        classes, s_set, &s_full, [&](size_t cell) { return mk_lds_add(&s_hist[cell - cell_base], 1u); },
                        [&](bool want, size_t cell) { return want ? mk_lds_add(&s_hist[cell - cell_base], 1u) : 0u; });
     }
@@ -632,7 +673,7 @@ MK_KERNEL(1024) void k_prepass_items(GridDesc g, const float* __restrict__ coord
     for (size_t t = t0 + tid; t < t1; t += nth) {
         const uint2 ix = tmp_idx[t];
         if (ix.x == TMP_UNUSED) continue;
-        fill_record<SigT>(g, t, rbase + s_hist[ix.x - (unsigned)cell_base] + ix.y, sigmas, tmp_pos, rec_pos, rec_w, rec_cls, tab, general);
+        fill_record<SigT>(g, t, rbase + s_hist[ix.x - (unsigned)cell_base] + ix.y, sigmas, tmp_pos, tmp_cls, rec_pos, rec_w, rec_cls, tab, general);
     }
 }
 

@@ -29,7 +29,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS, WS_H_STAGE,
     // distance_utils row (dist_pipeline.h)
@@ -226,7 +226,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     const int set = be.acquire_set(P.total_atoms >= 200000 && !per_item);
     const size_t ncells = (size_t)g.B * (size_t)g.cstride;
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
-    void *tpos = nullptr, *tidx = nullptr;
+    void *tpos = nullptr, *tidx = nullptr, *tcls = nullptr;
     // count[ncells ...] = length of the dense-tile list + tier statistics (zeroed with the counters)
     if ((st = be.ensure(WS_CELL_COUNT, (ncells + DENSE_WORDS) * sizeof(unsigned), &count, set))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
@@ -237,6 +237,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_ERR, sizeof(int), &eflag, 0))) return st;
     if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos, set))) return st;
     if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
+    if ((st = be.ensure(WS_TMP_CLS, (size_t)(P.total_atoms > 0 ? P.total_atoms : 1) * g.G * sizeof(uint2), &tcls, set))) return st;
 
     if (per_item) {
         unsigned* dwords = (unsigned*)count + ncells;
@@ -244,7 +245,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
             // few items: big blocks (latency of the one item matters); many items: small blocks (they fill the chip)
             const unsigned threads = (g.B < 512 && P.total_atoms > 256LL * (long long)g.B) ? 1024u : 256u;
             return be.launch(kern, dim3((unsigned)g.B), dim3(threads), g, P.coords, P.atom_offsets, P.sigmas, P.origins, P.box, P.affine,
-                             (unsigned*)start, (float4*)tpos, (uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls,
+                             (unsigned*)start, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls,
                              (unsigned*)ctab, dwords, (int*)eflag);
         };
         const int need = g.ncell + 1;
@@ -262,10 +263,12 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nblk * CLS_BLOCK_SET * sizeof(unsigned), &bsets, set))) return st;
         if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
         if (P.total_atoms > 0) {
-            st = P.sigmas_f64 ? be.launch(k_bin_count<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas,
-                                          P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag)
-                              : be.launch(k_bin_count<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas,
-                                          P.origins, P.box, P.affine, (unsigned*)count, (float4*)tpos, (uint2*)tidx, (unsigned*)bsets, (int*)eflag);
+            auto bin = [&](auto kern, auto* sig) {
+                return be.launch(kern, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine,
+                                 (unsigned*)count, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (unsigned*)bsets, (int*)eflag);
+            };
+            if (P.sigmas_f64) st = g.pbc ? bin(k_bin_count<double, 1>, (const double*)P.sigmas) : bin(k_bin_count<double, 0>, (const double*)P.sigmas);
+            else              st = g.pbc ? bin(k_bin_count<float, 1>, (const float*)P.sigmas) : bin(k_bin_count<float, 0>, (const float*)P.sigmas);
             if (st) return st;
         }
         // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
@@ -285,9 +288,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         }
         if (P.total_atoms > 0) {
             st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
-                                          (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
+                                          (const uint2*)tidx, (const uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
                               : be.launch(k_bin_fill<float>, fgrid, ablk, g, (const float*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
-                                          (const uint2*)tidx, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
+                                          (const uint2*)tidx, (const uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
             if (st) return st;
         }
     }
