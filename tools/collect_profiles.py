@@ -25,8 +25,12 @@ for d, suffix in (("prof_cfg2", ""), ("prof_cfg2_nopipe", "_nopipe")):
     if os.path.exists(t):
         shutil.copy(t, f"profiles/{tag}_cfg2{suffix}_timeline.txt")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("gpurun_out/pmc_*/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
+for d in sorted(glob.glob("gpurun_out/pmc_*/")):
+    # gpurun merges every call's output into the same directories: keep the newest pass only
+    fs = sorted(glob.glob(d + "*/*counter_collection.csv"), key=os.path.getmtime)
+    if not fs:
+        continue
+    for r in csv.DictReader(open(fs[-1])):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if acc:

@@ -4,7 +4,7 @@ for f in sorted(glob.glob('gpurun_out/bench_*.log')):
     for l in open(f):
         if l.startswith('{'):
             d = json.loads(l); r = d.get('roofline', {'frac': None})
-            print(f"{f.split('/')[-1]:28s} value={d['value']:>10} ms/step={d['ms_per_step']:<7} tile_ms={r.get('kernel_avg_ms')!s:<8} frac={r['frac']:<8} single_us={d.get('single_grid_latency_us')}")
+            print(f"{f.split('/')[-1]:28s} value={d['value']:>10} ms/step={d['ms_per_step']:<7} tile_ms={r.get('kernel_avg_ms')!s:<8} frac={r.get('frac')!s:<8} single_us={d.get('single_grid_latency_us')}")
 for f in sorted(glob.glob('gpurun_out/prof_*/*/*_kernel_stats.csv')):
     print(f)
     for r in csv.DictReader(open(f)):
