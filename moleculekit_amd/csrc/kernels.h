@@ -955,6 +955,39 @@ MK_DEV void for_each_present_channel(unsigned ids, F&& f)
 // is only appended to dense_list (dense_count = its length) and left to the DENSE = true instance,
 // which runs afterwards over that list: keeping the rare multi-round code out of this kernel keeps
 // its register footprint at 4 waves/SIMD (one kernel holding both needed ~2x the VGPRs).
+// x of plane k relative to the tile centre is c_k = k - (K-1)/2.  d^2 of (voxel in plane k, entry) is
+//   exact form:  (c_k - ex)^2 + dy^2 + dz^2                                  two instructions per (voxel, entry)
+//   fast form :  g_k + c_k^2,  g_k = fma(-2 c_k, ex, D0),  D0 = ex^2 + dy^2 + dz^2   ONE (D0 is shared by the K planes)
+// The fast form expands only the x term and only about the tile centre, but D0 is rounded at magnitude ~c_k^2 while the
+// pairs that matter have d^2 ~ rho^2 (rho = sigma / voxelsize, where the occupancy is steepest: slope 2.2 in relative
+// d^2): value error <= 2.2 * 2^-24 * (c_max^2 / rho^2 + 1).  It is therefore used per sigma CLASS only while
+// w = 1/rho^2 <= FAST_W_MAX = 22 / c_max^2 (error budget 3e-6; K = 8: sigma >= 0.75 voxels -- every vdW radius on a
+// 1 A grid), other classes take the exact form.  Every path (sorted, dense, general) makes the same choice from the
+// same w, so their results stay identical bit for bit.
+template <int K> MK_DEV constexpr float plane_x(int k) { return (float)k - 0.5f * (float)(K - 1); }
+template <int K> MK_DEV constexpr float plane_slope(int k) { return -2.f * plane_x<K>(k); }
+template <int K> MK_DEV constexpr float fast_w_max() { return 22.f / (plane_x<K>(K - 1) * plane_x<K>(K - 1)); }
+template <int K> MK_DEV float plane_d2(int k, float gk)
+{
+    // rounding may leave -1e-7 for a pair at distance 0: callers scale |d2| (a free source modifier), NaN stays NaN
+    return gk + plane_x<K>(k) * plane_x<K>(k);
+}
+// d^2 of one entry against the K planes, per-pair paths (general / dense chunks): the class rule above per entry
+template <int K> MK_DEV void entry_d2(float ex, float dyz2, float w, float (&d2)[K])
+{
+    if (w <= fast_w_max<K>()) {                          // wave-uniform (the entry is broadcast)
+        const float d0 = mk_fma(ex, ex, dyz2);
+#pragma unroll
+        for (int k = 0; k < K; ++k) d2[k] = plane_d2<K>(k, mk_fma(plane_slope<K>(k), ex, d0));
+    } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float dx = plane_x<K>(k) - ex;
+            d2[k] = mk_fma(dx, dx, dyz2);
+        }
+    }
+}
+
 template <int K, bool DENSE, int ECAP>
 MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, const unsigned* __restrict__ cell_start,
                           const float4* __restrict__ rec_pos,
@@ -1110,9 +1143,13 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
                 const uint4 bg = make_uint4(mk_uniform(bgp[0]), mk_uniform(bgp[1]), mk_uniform(bgp[2]), mk_uniform(bgp[3]));
                 const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
-                unsigned m[K];
+                // m[k] = min over the class's entries of g_k = d^2 - c_k^2 (c_k = x of plane k relative to the tile centre):
+                // with D0 = ex^2 + dy^2 + dz^2 per (lane, entry), g_k = D0 - 2 c_k ex is ONE fma per (voxel, entry); the
+                // plane constant c_k^2 is added to the class minimum at the flush (rounding is monotone: the same bits as
+                // adding it per entry).  g_k may be negative (>= -c_k^2), so these minima are float minima (v_min3_f32).
+                float m[K];
 #pragma unroll
-                for (int k = 0; k < K; ++k) m[k] = INF_BITS;
+                for (int k = 0; k < K; ++k) m[k] = INF;
                 // planes [K0, K1) against the entries of one sub-bucket: start words b0 (this) and b1 (next); the
                 // slots are padded to an even count, bit 0 of b0 says that the last slot is padding
                 auto run = [&](auto k0_, auto k1_, unsigned b0, unsigned b1) {
@@ -1124,34 +1161,55 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma clang loop vectorize(disable) interleave(disable)
                     for (unsigned n = (((b1 & ~1u) - s0) >> 1) - odd; n != 0u; --n, e += 2) {
                         // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
+                        // (fetching the next pair one trip ahead was measured: 2-4 % slower, the copies cost more)
                         const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
                         const mk_f2 dy = Y2 - py, dz = Z2 - pz;
-                        const mk_f2 r = mk_f2_fma(dy, dy, dz * dz);
+                        const mk_f2 d0 = mk_f2_fma(px, px, mk_f2_fma(dy, dy, dz * dz));
 #pragma unroll
                         for (int k = K0; k < K1; ++k) {
-                            const mk_f2 dx = mk_f2_splat((float)k - HX) - px;
-                            const mk_f2 d2 = mk_f2_fma(dx, dx, r);
-                            m[k] = mk_min3_bits(m[k], d2[0], d2[1]);
+                            const mk_f2 gk = mk_f2_fma(mk_f2_splat(plane_slope<K>(k)), px, d0);
+                            m[k] = mk_min3(m[k], gk[0], gk[1]);
                         }
                     }
                     if (odd) {                                            // wave-uniform: the unpaired last entry
+                        const float ex = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
+                        const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
+#pragma unroll
+                        for (int k = K0; k < K1; ++k) m[k] = mk_min(m[k], mk_fma(plane_slope<K>(k), ex, d0));
+                    }
+                };
+                // exact form for a class of small sigmas (w > FAST_W_MAX, rare): one compact loop, every plane against
+                // every entry of the three sub-buckets (the planes an entry cannot reach fail the cutoff anyway)
+                auto run_exact = [&](unsigned b0, unsigned b1) {
+                    const unsigned s0 = b0 & ~1u;
+                    const unsigned n = ((b1 & ~1u) - s0) - (b0 & 1u);
+                    const float* e = sxyz + s0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                    for (unsigned i = 0; i < n; ++i, ++e) {
                         const float px = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
                         const float r = mk_fma(dy, dy, dz * dz);
 #pragma unroll
-                        for (int k = K0; k < K1; ++k) {
-                            const float dx = ((float)k - HX) - px;
-                            m[k] = mk_min_bits(m[k], mk_fma(dx, dx, r));
+                        for (int k = 0; k < K; ++k) {
+                            const float dx = plane_x<K>(k) - px;
+                            m[k] = mk_min(m[k], mk_fma(dx, dx, r));
                         }
                     }
                 };
-                run(IntC<0>{}, IntC<K>{}, bg.x, bg.y);
-                run(IntC<0>{}, IntC<K / 2>{}, bg.y, bg.z);
-                run(IntC<K / 2>{}, IntC<K>{}, bg.z, bg.w);
+                const bool fast = wcls <= fast_w_max<K>();                // wave-uniform
+                if (fast) {
+                    run(IntC<0>{}, IntC<K>{}, bg.x, bg.y);
+                    run(IntC<0>{}, IntC<K / 2>{}, bg.y, bg.z);
+                    run(IntC<K / 2>{}, IntC<K>{}, bg.z, bg.w);
+                } else {
+                    run_exact(bg.x, bg.y);
+                    run_exact(bg.y, bg.z);
+                    run_exact(bg.z, bg.w);
+                }
                 // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const float d2 = mk_uint_as_float(m[k]);
-                    acc[k] = mk_min_bits(acc[k], d2 < R2 ? d2 * wcls : INF);
+                    const float d2 = fast ? plane_d2<K>(k, m[k]) : m[k];
+                    acc[k] = mk_min_bits(acc[k], d2 < R2 ? mk_abs(d2) * wcls : INF);
                 }
             }
         };
@@ -1236,13 +1294,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                             for (int i = 0; i < n; ++i) {
                                 const float4 e = ebuf[i];
                                 const float dy = Y - e.y, dz = Z - e.z;
-                                const float dyz2 = mk_fma(dy, dy, dz * dz);
+                                float d2[K];
+                                entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);
 #pragma unroll
-                                for (int k = 0; k < K; ++k) {
-                                    const float dx = ((float)k - HX) - e.x;
-                                    const float d2 = mk_fma(dx, dx, dyz2);
-                                    m[k] = mk_min_bits(m[k], d2 < R2 ? d2 * e.w : INF);   // occupancy_utils.pyx:53
-                                }
+                                for (int k = 0; k < K; ++k)
+                                    m[k] = mk_min_bits(m[k], d2[k] < R2 ? mk_abs(d2[k]) * e.w : INF);   // occupancy_utils.pyx:53
                             }
                             mk_block_sync();                                 // ebuf is rewritten next
                         });
@@ -1287,13 +1343,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 for (int i = 0; i < n; ++i) {
                     const float4 e = ebuf[i];
                     const float dy = Y - e.y, dz = Z - e.z;
-                    const float dyz2 = mk_fma(dy, dy, dz * dz);
+                    float d2[K];
+                    entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);                  // same fma tree as the sorted path
 #pragma unroll
-                    for (int k = 0; k < K; ++k) {
-                        const float dx = ((float)k - HX) - e.x;
-                        const float d2 = mk_fma(dx, dx, dyz2);               // same fma tree as the sorted path
-                        q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? d2 * e.w : INF);   // occupancy_utils.pyx:53
-                    }
+                    for (int k = 0; k < K; ++k)
+                        q[c][k] = mk_min_bits(q[c][k], d2[k] < R2 ? mk_abs(d2[k]) * e.w : INF);   // occupancy_utils.pyx:53
                 }
                 mk_block_sync();                                     // ebuf is rewritten next
             }

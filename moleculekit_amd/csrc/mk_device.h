@@ -40,6 +40,9 @@ MK_DEV float mk_rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // v_rcp_
 MK_DEV float mk_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 
 MK_DEV float mk_min(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32: NaN-ignoring
+MK_DEV float mk_abs(float a) { return __builtin_fabsf(a); }             // |x| source modifier
+MK_DEV float mk_max(float a, float b) { return __builtin_fmaxf(a, b); }  // v_max_f32: NaN-ignoring
+MK_DEV float mk_min3(float m, float a, float b) { return __builtin_fminf(__builtin_fminf(a, b), m); }   // v_min3_f32
 // min of a running bit pattern with a non-negative float (v_min_u32; see k_voxelize_tiles)
 MK_DEV unsigned mk_min_bits(unsigned q, float t)
 {

@@ -166,6 +166,15 @@ def case_voxel025():
     return _case(c, [0, n], synth_sigmas(rng, n), [[-3.0, -3.0, -3.0]], [24, 24, 24], 0.25)
 
 
+def case_voxel2():
+    """Coarse grid: 2 A voxels.  Radii below 0.75 voxels (hydrogens: 1.1 A) take the exact form of the pair loop,
+    the larger ones the one-fma form -- both in one call, dense enough that most voxels see both kinds."""
+    rng = np.random.default_rng(28)
+    n = 1500
+    c = rng.uniform(-16.0, 16.0, size=(n, 3)).astype(np.float32)
+    return _case(c, [0, n], synth_sigmas(rng, n), [[-15.0, -17.0, -16.0]], [16, 18, 17], 2.0)
+
+
 def case_channels(C):
     """Channel counts other than 8 (channel groups: 1 -> padded group, 11 -> two groups)."""
     rng = np.random.default_rng(24 + C)
@@ -237,6 +246,7 @@ LATTICE_CASES = {
     "sorted_atoms": case_sorted_atoms,
     "voxel07": case_voxel07,
     "voxel025": case_voxel025,
+    "voxel2": case_voxel2,
     "channels1": lambda: case_channels(1),
     "channels3": lambda: case_channels(3),
     "channels11": lambda: case_channels(11),

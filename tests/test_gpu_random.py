@@ -68,7 +68,7 @@ def test_random_configuration_all_variants(hip_ctx, seed):
                 if ref is None:
                     ref = got
                     assert np.abs(got - want).max(initial=0.0) <= TOL
-                    assert np.abs(got - base).max(initial=0.0) <= 2e-6
+                    assert np.abs(got - base).max(initial=0.0) <= 6e-6   # another K = other plane constants (and another fast/exact split of the classes)
                 else:
                     assert np.array_equal(got, ref), (tile_k, tier, general, prepass)
     finally:
