@@ -975,7 +975,7 @@ template <int K> MK_DEV float plane_d2(int k, float gk)
 // d^2 of one entry against the K planes, per-pair paths (general / dense chunks): the class rule above per entry
 template <int K> MK_DEV void entry_d2(float ex, float dyz2, float w, float (&d2)[K])
 {
-    if (w <= fast_w_max<K>()) {                          // wave-uniform (the entry is broadcast)
+    if (mk_uint_as_float(mk_uniform(mk_float_bits(w))) <= fast_w_max<K>()) {   // the entry is broadcast: a scalar branch
         const float d0 = mk_fma(ex, ex, dyz2);
 #pragma unroll
         for (int k = 0; k < K; ++k) d2[k] = plane_d2<K>(k, mk_fma(plane_slope<K>(k), ex, d0));

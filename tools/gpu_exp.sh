@@ -5,13 +5,8 @@ run() { name=$1; shift; env "$@" python bench.py --no-cpu-baseline --steps 10 --
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'])"; }
 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-for wl in cfg1 cfg3 cfg5; do
-for rep in 1 2; do
-EXTRA_ARGS="--workload $wl" run ${wl}_pipe_new A=1
-EXTRA_ARGS="--workload $wl" run ${wl}_pipe_head MKAMD_LIB=$R/.variants/lib_head.so
-done
-done
-EXTRA_ARGS="--workload cfg3 --batch 1024" run cfg3_b1024_new A=1
-EXTRA_ARGS="--workload cfg3 --batch 1024" run cfg3_b1024_head MKAMD_LIB=$R/.variants/lib_head.so
-EXTRA_ARGS="--workload cfg1 --batch 256" run cfg1_b256_new A=1
-EXTRA_ARGS="--workload cfg1 --batch 256" run cfg1_b256_head MKAMD_LIB=$R/.variants/lib_head.so
+EXTRA_ARGS="--no-pipeline" run cfg2_general_new MKAMD_FORCE_GENERAL=1
+EXTRA_ARGS="--no-pipeline" run cfg2_general_head MKAMD_FORCE_GENERAL=1 MKAMD_LIB=$R/.variants/lib_head.so
+EXTRA_ARGS="--no-pipeline" run cfg2_general_old MKAMD_FORCE_GENERAL=1 MKAMD_LIB=$R/.variants/lib_old.so
+EXTRA_ARGS="--no-pipeline" run cfg2_new A=1
+EXTRA_ARGS="--no-pipeline" run cfg2_head MKAMD_LIB=$R/.variants/lib_head.so
