@@ -175,6 +175,26 @@ def case_voxel2():
     return _case(c, [0, n], synth_sigmas(rng, n), [[-15.0, -17.0, -16.0]], [16, 18, 17], 2.0)
 
 
+def case_cutoff_exact(vs):
+    """The strict cutoff d^2 < 25 on exactly representable geometry, with sigmas large enough that a wrongly included
+    pair would show (sigma = 3 A at d = 5 A: 2.2e-3 against the tolerance of 1e-5): atoms ON voxel centres in every
+    part of a tile (the one-fma form expands d^2 about the tile centre), so that voxels sit at exactly 5 A along the
+    axes and on 3-4-0 triangles.  vs = 1 A, or 0.5 A (dyadic; distances in voxel units double)."""
+    atoms = np.array([[0, 0, 0], [7, 7, 7], [3, 4, 4], [-8, 0, 7], [8, -8, -1]], np.float32)
+    s = np.zeros((5, 8))
+    s[:, 7] = 3.0
+    s[0, 0] = 2.5
+    s[2, 3] = 3.0
+    s[3, 7] = 0.7 * vs                  # a class below 0.75 voxels: the exact form of the pair loop
+    case = _case(atoms, [0, 5], s, [[-12.0, -12.0, -12.0]], [int(24 / vs) + 1] * 3, vs)
+    # the oracle excludes the d = 5 voxels of the lone corner atom (channel 7: nothing else reaches them)
+    n = int(24 / vs) + 1
+    exp = case["expected"].reshape(n, n, n, 8)
+    at = lambda x, y, z: exp[int((x + 12) / vs), int((y + 12) / vs), int((z + 12) / vs), 7]
+    assert at(8, -8, 4) == 0.0 and at(8, -3, -1) == 0.0 and at(4, -5, -1) == 0.0 and at(8, -8, 3.0) > 1e-3
+    return case
+
+
 def case_channels(C):
     """Channel counts other than 8 (channel groups: 1 -> padded group, 11 -> two groups)."""
     rng = np.random.default_rng(24 + C)
@@ -247,6 +267,8 @@ LATTICE_CASES = {
     "voxel07": case_voxel07,
     "voxel025": case_voxel025,
     "voxel2": case_voxel2,
+    "cutoff_exact_1A": lambda: case_cutoff_exact(1.0),
+    "cutoff_exact_05A": lambda: case_cutoff_exact(0.5),
     "channels1": lambda: case_channels(1),
     "channels3": lambda: case_channels(3),
     "channels11": lambda: case_channels(11),
