@@ -13,7 +13,8 @@
 //   Entries (atom x channel) that share the same sigma form a CLASS; inside a class
 //                min_a d2*w == w * min_a d2   and   "some in-range atom" == (min_a d2 < 25),
 //   bit for bit (w > 0, float rounding is monotone), so the cutoff test and the multiply by w also
-//   leave the inner loop: per (voxel, entry) it is  half a v_pk_add, half a v_pk_fma, half a v_min3_u32.
+//   leave the inner loop; with d^2 expanded in x about the tile centre (plane_slope / plane_d2 below) what is left
+//   per (voxel, entry) is  half a v_pk_fma and half a v_min3_f32.
 //   It is a GATHER: one wave owns a K x 8 x 8 voxel tile, lane = (y,z), K x-planes in registers;
 //   candidate atoms come from a uniform cell list, are culled against the tile box, counting-sorted
 //   by (channel, class) in LDS and broadcast-read by all 64 lanes.  No atomics on the grid, no
