@@ -82,13 +82,20 @@ def _gridSpec(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
     return bb_min, nvoxels
 
 
+def _centersFromSpec(bb_min, nvoxels, voxelsize):
+    """``(lattice + bb_min).reshape(V, 3).copy()`` of the reference (:245-247) in one pass over the array: the sum
+    is written straight into the [V, 3] result (same values, float64, C-contiguous, owns its data)."""
+    nx, ny, nz = (int(v) for v in nvoxels)
+    centers = np.empty((nx * ny * nz, 3), dtype=np.float64)
+    np.add(_getGridCenters(nx, ny, nz, voxelsize), bb_min, out=centers.reshape(nx, ny, nz, 3))
+    return centers
+
+
 def getCenters(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
     """Voxel centres for voxelization: (centers float64 [V,3], nvoxels int (3,)) -- same arguments
     and results as the reference (voxeldescriptors.py:197-248)."""
     bb_min, nvoxels = _gridSpec(mol, buffer, boxsize, center, voxelsize)
-    centers = _getGridCenters(*list(nvoxels), voxelsize) + bb_min
-    centers = centers.reshape(np.prod(nvoxels), 3).copy()
-    return centers, nvoxels
+    return _centersFromSpec(bb_min, nvoxels, voxelsize), nvoxels
 
 
 def getChannels(mol, aromaticNitrogen=False, version=2, validitychecks=True):
@@ -130,8 +137,7 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
     centers = usercenters
     if centers is None:
         bb_min, nvoxels = _gridSpec(mol, buffer, boxsize, center, voxelsize)
-        centers = _getGridCenters(*list(nvoxels), voxelsize) + bb_min
-        centers = centers.reshape(np.prod(nvoxels), 3).copy()
+        centers = _centersFromSpec(bb_min, nvoxels, voxelsize)
         lattice = (np.asarray(bb_min, dtype=np.float64), nvoxels, voxelsize)
 
     coords = usercoords
