@@ -1,19 +1,13 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-cd /tmp
-rm -rf $R/gpurun_out/prof_dropin
-timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $R/gpurun_out/prof_dropin -- python $R/bench.py --workload dropin --steps 30 --no-cpu-baseline > $R/gpurun_out/rocprof_dropin.log 2>&1
 cd $R
-ls gpurun_out/prof_dropin/*/
-python - <<'PY'
-import csv,glob
-rows=[]
-for f in glob.glob("gpurun_out/prof_dropin/*/*kernel_trace.csv"):
-    for r in csv.DictReader(open(f)): rows.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),"K "+r["Kernel_Name"].split("(")[0][-40:]))
-for f in glob.glob("gpurun_out/prof_dropin/*/*memory_copy_trace.csv"):
-    for r in csv.DictReader(open(f)): rows.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),"M "+r.get("Direction","")+" "+r.get("Bytes","")))
-rows.sort()
-t0=rows[-40][0]
-for a,b,n in rows[-40:]: print(f"{(a-t0)/1e3:9.1f} {(b-t0)/1e3:9.1f} {(b-a)/1e3:7.1f}  {n}")
-PY
-tail -2 gpurun_out/rocprof_dropin.log | cut -c1-300
+run() { name=$1; shift; env "$@" python bench.py --no-cpu-baseline --steps 10 --warmup 3 $EXTRA_ARGS 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'])"; }
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
+for rep in 1 2; do
+EXTRA_ARGS="--workload $wl --no-pipeline" run ${wl}_nopipe_new A=1
+EXTRA_ARGS="--workload $wl --no-pipeline" run ${wl}_nopipe_head MKAMD_LIB=$R/.variants/lib_head.so
+done
+done
