@@ -826,7 +826,7 @@ MK_DEV float occupancy_from_q(float q)
     const float big = 1.0f - mk_exp2(-1.4426950408889634f * x);
     // x - x^2/2 + x^3/6 for x < 1/64 (truncation x^3/24 < 1.6e-7 relative); above that 1-exp(-x) is
     // relatively accurate to 6e-8/x <= 4e-6
-    const float small = x * (1.0f - x * (0.5f - x * 0.16666667f));
+    const float small = x * mk_fma(-x, mk_fma(-x, 0.16666667f, 0.5f), 1.0f);   // (the fmas hipcc contracts to anyway)
     return x < 0.015625f ? small : big;
 }
 
