@@ -4,10 +4,9 @@ cd $R
 run() { name=$1; shift; env "$@" python bench.py --no-cpu-baseline --steps 10 --warmup 3 $EXTRA_ARGS 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$name', d['value'], d['ms_per_step'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'])"; }
-python -m pytest tests -x -q -m gpu 2>&1 | tail -2
-for wl in cfg3 cfg5 cfg2 cfg1; do
-for rep in 1 2; do
-EXTRA_ARGS="--workload $wl --no-pipeline" run ${wl}_nopipe_new A=1
-EXTRA_ARGS="--workload $wl --no-pipeline" run ${wl}_nopipe_head MKAMD_LIB=$R/.variants/lib_head.so
+for wl in cfg2 cfg4 cfg3 cfg5 cfg1; do
+EXTRA_ARGS="--workload $wl --no-pipeline" run ${wl}_head A=1
+for v in 512_48 512_0 640_48 576_48; do
+EXTRA_ARGS="--workload $wl --no-pipeline" run ${wl}_occ_$v MKAMD_LIB=$R/.variants/lib_occ_$v.so
 done
 done
