@@ -962,12 +962,12 @@ MK_DEV void for_each_present_channel(unsigned ids, F&& f)
 // The fast form expands only the x term and only about the tile centre, but D0 is rounded at magnitude ~c_k^2 while the
 // pairs that matter have d^2 ~ rho^2 (rho = sigma / voxelsize, where the occupancy is steepest: slope 2.2 in relative
 // d^2): value error <= 2.2 * 2^-24 * (c_max^2 / rho^2 + 1).  It is therefore used per sigma CLASS only while
-// w = 1/rho^2 <= FAST_W_MAX = 22 / c_max^2 (error budget 3e-6; K = 8: sigma >= 0.75 voxels -- every vdW radius on a
+// w = 1/rho^2 <= FAST_W_MAX = 14 / c_max^2 (error budget 2e-6; K = 8: sigma >= 0.94 voxels -- every vdW radius on a
 // 1 A grid), other classes take the exact form.  Every path (sorted, dense, general) makes the same choice from the
 // same w, so their results stay identical bit for bit.
 template <int K> MK_DEV constexpr float plane_x(int k) { return (float)k - 0.5f * (float)(K - 1); }
 template <int K> MK_DEV constexpr float plane_slope(int k) { return -2.f * plane_x<K>(k); }
-template <int K> MK_DEV constexpr float fast_w_max() { return 22.f / (plane_x<K>(K - 1) * plane_x<K>(K - 1)); }
+template <int K> MK_DEV constexpr float fast_w_max() { return 14.f / (plane_x<K>(K - 1) * plane_x<K>(K - 1)); }
 template <int K> MK_DEV float plane_d2(int k, float gk)
 {
     // rounding may leave -1e-7 for a pair at distance 0: callers scale |d2| (a free source modifier), NaN stays NaN

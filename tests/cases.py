@@ -167,12 +167,21 @@ def case_voxel025():
 
 
 def case_voxel2():
-    """Coarse grid: 2 A voxels.  Radii below 0.75 voxels (hydrogens: 1.1 A) take the exact form of the pair loop,
-    the larger ones the one-fma form -- both in one call, dense enough that most voxels see both kinds."""
+    """Coarse grid: 2 A voxels: every radius is below 0.94 voxels, i.e. all classes take the exact form of the pair
+    loop (kernels.h, fast_w_max)."""
     rng = np.random.default_rng(28)
     n = 1500
     c = rng.uniform(-16.0, 16.0, size=(n, 3)).astype(np.float32)
     return _case(c, [0, n], synth_sigmas(rng, n), [[-15.0, -17.0, -16.0]], [16, 18, 17], 2.0)
+
+
+def case_voxel15():
+    """1.5 A voxels: hydrogens (1.1 A = 0.73 voxels) take the exact form, the larger radii (>= 1.0 voxels) the one-fma
+    form -- both in one call, dense enough that most voxels see both kinds."""
+    rng = np.random.default_rng(29)
+    n = 1200
+    c = rng.uniform(-13.0, 13.0, size=(n, 3)).astype(np.float32)
+    return _case(c, [0, n], synth_sigmas(rng, n), [[-12.0, -13.5, -12.75]], [17, 19, 18], 1.5)
 
 
 def case_cutoff_exact(vs):
@@ -185,7 +194,7 @@ def case_cutoff_exact(vs):
     s[:, 7] = 3.0
     s[0, 0] = 2.5
     s[2, 3] = 3.0
-    s[3, 7] = 0.7 * vs                  # a class below 0.75 voxels: the exact form of the pair loop
+    s[3, 7] = 0.7 * vs                  # a class below 0.94 voxels: the exact form of the pair loop
     case = _case(atoms, [0, 5], s, [[-12.0, -12.0, -12.0]], [int(24 / vs) + 1] * 3, vs)
     # the oracle excludes the d = 5 voxels of the lone corner atom (channel 7: nothing else reaches them)
     n = int(24 / vs) + 1
@@ -267,6 +276,7 @@ LATTICE_CASES = {
     "voxel07": case_voxel07,
     "voxel025": case_voxel025,
     "voxel2": case_voxel2,
+    "voxel15": case_voxel15,
     "cutoff_exact_1A": lambda: case_cutoff_exact(1.0),
     "cutoff_exact_05A": lambda: case_cutoff_exact(0.5),
     "channels1": lambda: case_channels(1),

@@ -128,7 +128,7 @@ def test_record_overflow_is_flagged():
     assert err & 1
 
 
-@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "special_sigmas", "pbc_batch", "channels11", "nonfinite_coords", "voxel2"])
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "special_sigmas", "pbc_batch", "channels11", "nonfinite_coords", "voxel2", "voxel15"])
 def test_sorted_and_general_paths_are_bit_identical(name):
     """The class-sorted tile path (cutoff, w and the plane constant c_k^2 hoisted out of the inner loop) must reproduce
     the general per-pair path bit for bit: min commutes exactly with monotone maps (adding a constant, clamping at 0,
