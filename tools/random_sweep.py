@@ -11,7 +11,7 @@ from moleculekit_amd import batch, _lib
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = _lib.default_context(0)
-worst = 0.0
+worst, where = 0.0, None
 for seed in range(first, first + count):
     k = _config(seed)
     for multi in (False, True):
@@ -24,7 +24,8 @@ for seed in range(first, first + count):
         want = oracle_lattice(k["coords"], k["atom_offsets"], sig.astype(np.float64), k["origins"], k["nvoxels"],
                               k["voxelsize"], k["box"])
         err = float(np.abs(got - want).max(initial=0.0))
-        worst = max(worst, err)
+        if err > worst:
+            worst, where = err, (seed, multi, k["voxelsize"], tuple(int(v) for v in k["nvoxels"]), k["box"] is not None)
         if err > TOL:
             print("FAIL seed", seed, "multi", multi, "err", err, "vs", k["voxelsize"])
-print("seeds", first, "..", first + count - 1, "worst abs err", worst, "(tolerance", TOL, ")")
+print("seeds", first, "..", first + count - 1, "worst abs err", worst, "(tolerance", TOL, ") at (seed, multi, voxelsize, nvoxels, pbc) =", where)
