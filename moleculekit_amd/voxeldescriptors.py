@@ -206,9 +206,13 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
 
     Lattice centres (known from getCenters, or recognised in the array) take the tiled lattice
     kernel; arbitrary centres take the explicit-centre kernel."""
-    coords = np.ascontiguousarray(np.asarray(coords).astype(np.float32))
-    centers = np.ascontiguousarray(np.asarray(centers).astype(np.float64))
-    channelsigmas = np.ascontiguousarray(np.asarray(channelsigmas).astype(np.float64))
+    # (the reference copies with astype, :519-521; nothing here writes to the inputs, so arrays that already have the
+    #  dtype and layout are used as they are -- the float64 centres of a 64^3 grid alone are 6 MB)
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    centers = np.asarray(centers)
+    if _lattice is None:
+        centers = np.ascontiguousarray(centers, dtype=np.float64)
+    channelsigmas = np.ascontiguousarray(channelsigmas, dtype=np.float64)
     if coords.ndim != 2 or coords.shape[1] != 3 or centers.ndim != 2 or centers.shape[1] != 3:
         raise ValueError("coords and centers must be (n, 3) arrays")
     if channelsigmas.ndim != 2 or channelsigmas.shape[0] != coords.shape[0]:
