@@ -1,6 +1,6 @@
-"""One-off wider sweep of tests/test_gpu_random.py's generator (GPU box): seeds beyond the 40 of the test tier, plus a
-variant whose atoms carry a DIFFERENT sigma per channel (the binning's multi-sigma path).  Prints the worst
-absolute error against the oracle.   python tools/random_sweep.py [first_seed] [count]"""
+"""One-off wider sweep of tests/test_gpu_random.py's generator (GPU box; not collected by pytest): seeds beyond the
+40 of the test tier, plus a variant whose atoms carry a DIFFERENT sigma per channel (the binning's multi-sigma path).
+Prints the worst absolute error against the oracle.   python tests/sweep_gpu_random.py [first_seed] [count]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
