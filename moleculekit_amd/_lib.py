@@ -116,8 +116,9 @@ def _ptr(a):
     if a is None:
         return None
     if isinstance(a, np.ndarray):
-        return a.ctypes.data_as(_vp)
-    return _vp(int(a))
+        return a.ctypes.data          # plain address: every pointer parameter is declared c_void_p (SIGNATURES); the
+                                      # caller's frame keeps the array alive for the duration of the call
+    return int(a)
 
 
 class Context:
