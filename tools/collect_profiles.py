@@ -24,6 +24,10 @@ for d, suffix in (("prof_cfg2", ""), ("prof_cfg2_nopipe", "_nopipe")):
     t = f"gpurun_out/timeline_{d}.txt"
     if os.path.exists(t):
         shutil.copy(t, f"profiles/{tag}_cfg2{suffix}_timeline.txt")
+for wl in ("cfg1", "cfg3", "cfg4", "cfg5"):                 # rocprofv3 --kernel-trace --stats of the other workloads, when taken
+    stats = sorted(glob.glob(f"gpurun_out/prof_{wl}/*/*_kernel_stats.csv"), key=os.path.getmtime)
+    if stats:
+        shutil.copy(stats[-1], f"profiles/{tag}_{wl}_rocprofv3_kernel_stats.csv")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob("gpurun_out/pmc_*/")):
     # gpurun merges every call's output into the same directories: keep the newest pass only
