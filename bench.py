@@ -33,7 +33,9 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # vector FP32 peak (secondary roofline: cfg2/cfg4
 
 # items per GPU per step: big enough that the tile grid is many waves deep (a 32-grid step of cfg2 is only four:
 # its tail costs ~15 %) and that the fixed per-step costs (launch gaps, the barrier of the timed region) amortise
-DEFAULT_BATCH = {"cfg1": 4096, "cfg2": 256, "cfg3": 8192, "cfg4": 256, "cfg5": 16384, "dist": 2048, "dropin": 1}
+# (cfg5's nominal batch is 100 000 items, BASELINE.json configs[4]; the small-molecule workloads keep gaining up to
+#  ~32 k grids per step: DESIGN.md section 5)
+DEFAULT_BATCH = {"cfg1": 4096, "cfg2": 256, "cfg3": 32768, "cfg4": 256, "cfg5": 65536, "dist": 2048, "dropin": 1}
 
 
 def real_protein_config(batch, seed):
