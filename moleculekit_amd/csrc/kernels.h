@@ -90,6 +90,7 @@ struct GridDesc {
     long long V;                // nx*ny*nz
     unsigned M;                 // capacity of the record arrays (= total atoms x img_cap)
     int img_cap;                // temp / record slots reserved per atom (1 unless periodic)
+    int prepass_hurry;          // 1: binning / fill waves raise their issue priority (pipeline.h, run_lattice)
 };
 
 // w of a present channel is clamped to a finite value (+inf is the "channel absent" marker): a
@@ -470,7 +471,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, uint2* __restrict__ tmp_cls,
                                 unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
 {
-    mk_wave_priority_high();
+    if (g.prepass_hurry) mk_wave_priority_high();
     __shared__ unsigned s_set[CLS_BLOCK_SET];
     __shared__ unsigned s_full;
     const bool classes = !g.force_general;
@@ -549,7 +550,7 @@ __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, 
                                float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                                unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
 {
-    mk_wave_priority_high();
+    if (g.prepass_hurry) mk_wave_priority_high();
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)g.M) return;
     const uint2 ix = tmp_idx[t];

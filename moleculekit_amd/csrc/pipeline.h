@@ -102,6 +102,7 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     g.ncell = (int)ncell;
     g.cstride = (int)ncell + 1;
     g.cls_per_item = 0;
+    g.prepass_hurry = 1;
 
     // tile depth: K=8 unless the x extent pads badly or the launch would be too small to fill 256 CUs
     int K = P.tile_k;
@@ -224,6 +225,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                           (P.prepass_mode == 1 || P.total_atoms <= 4096LL * (long long)g.B);
     g.cls_per_item = per_item ? 1 : 0;
     const int set = be.acquire_set(P.total_atoms >= 200000 && !per_item);
+    // Issue priority of the binning / fill waves that run beside the previous call's tile kernel.  Raised (s_setprio 3)
+    // they take issue slots from the tile waves whenever they are ready; left at 0 they live on the slots the tile
+    // kernel leaves idle, which is cheaper (cfg2 +2..4 % at 16..512 grids per step) as long as the chain still
+    // finishes inside the tile kernel.  It does when the tile kernel has enough work per atom: measured on cfg2's atoms
+    // over smaller grids, the chain is late (-8 %) at 2.2 voxels per atom, in time from 2.8 on; the periodic binning
+    // (one wave per SIMD beside the tile kernel, not two) needs the raised priority up to cfg4's 3.7 at least.
+    g.prepass_hurry = !(be.set_is_pipelined(set) && !g.pbc && (double)g.B * (double)g.V >= 4.0 * (double)P.total_atoms) ? 1 : 0;
     const size_t ncells = (size_t)g.B * (size_t)g.cstride;
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
     void *tpos = nullptr, *tidx = nullptr, *tcls = nullptr;
