@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- Mvoxel-channels/s of the voxel-descriptor hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1..cfg5|dist|dropin] [--batch B]
 
 A "step" is one pass of the hot path (bin -> scan -> fill -> tile kernel, all on the GPU) over one
 batch of synthetic items that is ALREADY resident in HBM; features stay resident in HBM (float32
 [B,V,C]).  Default workload = BASELINE.json configs[1] ("cfg2"): independent 50k-atom solvated-protein
 systems, 64^3 grid @ 1 A, 8 channels, B systems per GPU per step (SURVEY.md section 8d generators).
-N > 1: one process per GPU (torchrun), every rank owns its own B items (weak scaling), no collective
-inside the timed region (the trivial gather of feature tensors is timed separately as `gather_ms`).
+
+N > 1: one process per GPU over RCCL.  Started by the driver under torch.distributed.run, or -- when
+invoked as plain `python bench.py --gpus N` -- this file starts the N ranks itself (launch_ranks) and
+fails loudly when the node has fewer devices.  The batch of N x B items is sharded with
+moleculekit_amd.distributed.ShardedVoxelizer: every rank generates, stages (pinned memory) and keeps only
+its own B items (weak scaling), and the timed region holds no collective.  The trivial gather of the
+feature tensors is timed separately: `gather_ms` (one padded all-gather after the compute) and
+`gather_overlapped_extra_ms` (chunks gathered on a communication stream while the next chunk is computed).
+The headline workload is the same at every N (the driver divides the per-N values); north_star's "batched
+molecules" case (cfg3) runs through the same sharded path as a secondary leg (`batched_molecules`).
+`--dry-run` exercises the launch / rendezvous / shard / gather plumbing on CPU (gloo, stand-in compute).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded around the tile
-kernel on the stream it runs on; `cpu_baseline` times the oracle (oracle/liboracle.so, a port of the
-reference's serial Cython kernel) on a bounded sample of the same workload on 1 host core.
+kernel on the stream it runs on; at N = 1 `other_workloads` carries the same measurement for the other
+BASELINE configs; `cpu_baseline` times the oracle (oracle/liboracle.so, a port of the reference's serial
+Cython kernel) on a bounded sample of the same workload on 1 host core.
 """
 from __future__ import annotations
 
@@ -247,6 +257,181 @@ def bench_dropin(args):
     print(json.dumps(line), flush=True)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves -- one process per
+    GPU under torch.distributed.run on this node (rendezvous on 127.0.0.1) -- and let rank 0 print the line."""
+    import subprocess
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """CPU-only check of the N>1 plumbing (tests/test_bench_launch.py): ranks rendezvous over gloo, shard a tiny
+    batch with moleculekit_amd.distributed exactly as the timed path does, and gather it; the per-rank compute is a
+    stand-in that stamps every item with its global index (there is no CPU voxelizer in the product)."""
+    import torch
+    import torch.distributed as dist
+    from moleculekit_amd.distributed import ShardedVoxelizer
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, nv = args.batch or 5, np.array([4, 3, 2])
+    seen = []
+
+    def loader(lo, hi):                                       # this rank's items only; origin x = global item index
+        seen.append((lo, hi))
+        n = hi - lo
+        org = np.zeros((n, 3)); org[:, 0] = np.arange(lo, hi)
+        return (np.zeros((2 * n, 3), np.float32), np.arange(n + 1, dtype=np.int64) * 2, np.ones((2 * n, 8), np.float32), org, None)
+
+    def compute(c, offs, s, o, nvox, vs, bx):
+        return torch.from_numpy(np.broadcast_to(o[:, :1, None], (len(o), int(np.prod(nvox)), 8)).astype(np.float32).copy())
+
+    sv = ShardedVoxelizer.from_loader(world * B, loader, nv, 1.0, compute=compute)
+    t0 = time.perf_counter()
+    local = sv.voxelize()
+    full = sv.voxelize_gather(nchunks=3)
+    plain = sv.gather(local)
+    dist.barrier()
+    ok = (len(seen) == 1 and seen[0] == (rank * B, (rank + 1) * B) and tuple(full.shape) == (world * B, 24, 8)
+          and bool((full[:, 0, 0] == torch.arange(world * B, dtype=torch.float32)).all()) and torch.equal(full, plain))
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(ok))
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run (gloo, stand-in compute)", "dry_run": True, "n_gpus": world, "ranks_joined": world,
+                          "items_per_rank": B, "ok": all(flags), "seconds": round(time.perf_counter() - t0, 3)}), flush=True)
+    dist.destroy_process_group()
+    if not all(flags):
+        raise SystemExit("dry run: sharding / gather mismatch")
+
+
+def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, want_gather=False, want_single=False):
+    """Time `steps` passes of the hot path over this rank's resident shard of a batch of world x B items of workload
+    `name` (weak scaling).  The shard lives in a moleculekit_amd.distributed.ShardedVoxelizer: loaded by this rank
+    alone, staged through pinned memory, resident in HBM before the timed region; no collective inside it."""
+    import torch
+    from moleculekit_amd.distributed import ShardedVoxelizer
+    cfgno = int(name[3:])
+    cache = {}
+
+    def loader(lo, hi):                                       # this rank's B items (their own seed): nobody builds the whole batch
+        assert (lo, hi) == (rank * B, (rank + 1) * B)
+        p, origins, nv = make_workload(name, B, seed=1000 * cfgno + rank)
+        cache.update(p=p, origins=origins, nv=nv)
+        sig = np.ascontiguousarray(p["sigmas"], dtype=np.float32)
+        return p["coords"], p["atom_offsets"], sig, origins, p["box"]
+
+    from tests.synth import grid_origin
+    p0 = make_config(name, 1)
+    nv = grid_origin(p0["centers"][0], p0["boxsize"], p0["voxelsize"])[1]
+    sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx)
+    p = cache["p"]
+    V, C = int(np.prod(nv)), 8
+    out = torch.empty((B, V, C), dtype=torch.float32, device=dev)
+    step = lambda: sv.voxelize(out=out)
+    # set-up, not a step: size both workspace sets of the context (device allocations happen on the
+    # first call that uses a set) so that even --warmup 0 times no hipMalloc
+    for _ in range(2):
+        step()
+    ctx.synchronize()
+    for _ in range(warmup):
+        step()
+    ctx.synchronize()                     # also surfaces asynchronous errors of the warm-up
+    ctx.enable_kernel_timing(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.enable_kernel_timing(False)
+    k_ms, k_n = ctx.read_kernel_timing()
+    ctx.synchronize()
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # sanity of what was produced inside the timed region (never a cached / skipped result)
+    chk = out[0].double().sum().item()
+    assert np.isfinite(chk) and chk > 0, "bench produced an empty grid"
+    res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C))
+
+    if want_gather:
+        # the trivial gather of the feature tensors, timed on its own: (a) one padded all-gather after the compute,
+        # (b) chunk-overlapped with the compute (what a consumer that needs everything everywhere would run)
+        fence()
+        g0 = time.perf_counter()
+        full = sv.gather(out)
+        fence()
+        res["gather_ms"] = (time.perf_counter() - g0) * 1e3
+        assert full.shape[0] == world * B
+        del full
+        fence()
+        g0 = time.perf_counter()
+        full = sv.voxelize_gather(nchunks=4)
+        fence()
+        both = (time.perf_counter() - g0) * 1e3
+        res["compute_plus_overlapped_gather_ms"] = both
+        res["gather_overlapped_extra_ms"] = both - elapsed / steps * 1e3
+        assert full.shape[0] == world * B and torch.equal(full[rank * B:(rank + 1) * B], out)
+        del full
+
+    if want_single:
+        # latency of ONE grid (SURVEY.md section 7 H2: a single 64^3 grid cannot fill 256 CUs for long)
+        from moleculekit_amd import batch
+        ctx.set_pipelining(False)
+        d = sv._d
+        o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
+        n1 = int(p["atom_offsets"][1])
+        offs1 = d["offs"][:2].contiguous()
+        args1 = (d["coords"][:n1], offs1, d["sigmas"][:n1], d["origins"][:1], nv, p["voxelsize"])
+        kw1 = dict(box=None if d["box"] is None else d["box"][:1], max_images=sv.max_images, out=o1, ctx=ctx)
+        for _ in range(3):
+            batch.voxelize_lattice_torch(*args1, **kw1)
+        torch.cuda.synchronize(dev)
+        s0 = time.perf_counter()
+        for _ in range(20):
+            batch.voxelize_lattice_torch(*args1, **kw1)
+        torch.cuda.synchronize(dev)
+        res["single_us"] = (time.perf_counter() - s0) / 20 * 1e6
+        ctx.set_pipelining(not args.no_pipeline)
+    del out, sv
+    torch.cuda.empty_cache()
+    return res
+
+
+def roofline_of(res, workload, B, tile_k):
+    k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
+    achieved = res["alg"] / (k_avg_ms * 1e-3) / 1e9 if res["k_n"] else None
+    traffic, traffic_src = pmc_traffic(workload, B, tile_k)
+    return {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_voxelize_tiles (+ dense pass)",
+            "kernel_avg_ms": round(k_avg_ms, 5), "kernel_launches": int(res["k_n"]),
+            "algorithmic_bytes_per_launch": int(res["alg"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,10 +443,21 @@ def main():
     ap.add_argument("--lds-tier", type=int, default=-1, help="-1 adaptive (default), 0/1/2 = 640/768/1024 LDS entries per tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary workloads (cfg1/cfg3/cfg4/cfg5 at N=1, the cfg3 batched-molecule leg at N>1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap step n+1's binning pre-pass with step n's tile kernel")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU-only: rendezvous (gloo), shard and gather a tiny batch with a stand-in compute; no timing")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under torchrun: become the launcher (one rank per GPU, RCCL), the line comes from rank 0 of the children
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    if args.dry_run:
+        return dry_run(args)
     if args.workload == "dropin":
         return bench_dropin(args)
     if args.workload == "dist":
@@ -272,15 +468,17 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from moleculekit_amd import _lib, batch
+    from moleculekit_amd import _lib
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun: RCCL even for one rank (exercises the path)
@@ -290,8 +488,6 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B = args.batch or DEFAULT_BATCH[args.workload]
-    p, origins, nv = make_workload(args.workload, B, seed=1000 * int(args.workload[3:]) + rank)
-    V, C = int(np.prod(nv)), 8
     ctx = _lib.default_context(local)
     ctx.set_tile_k(args.tile_k)
     ctx.set_lds_tier(args.lds_tier)
@@ -300,18 +496,6 @@ def main():
     # steps are independent batches whose inputs are resident before the loop: the library may overlap the
     # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)
     ctx.set_pipelining(not args.no_pipeline)
-    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
-    d_coords, d_offs = t(p["coords"], np.float32), t(p["atom_offsets"], np.int64)
-    d_sig, d_org = t(p["sigmas"], np.float32), t(origins, np.float64)
-    d_box, max_images = None, 1
-    if p["box"] is not None:
-        d_box = t(p["box"], np.float32)
-        max_images = batch.max_images_per_atom(p["box"], nv, p["voxelsize"])
-    out = torch.empty((B, V, C), dtype=torch.float32, device=dev)
-
-    def step():
-        batch.voxelize_lattice_torch(d_coords, d_offs, d_sig, d_org, nv, p["voxelsize"], box=d_box,
-                                     max_images=max_images, out=out, ctx=ctx)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -319,71 +503,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # set-up, not a step: size both workspace sets of the context (device allocations happen on the
-    # first call that uses a set) so that even --warmup 0 times no hipMalloc
-    for _ in range(2):
-        step()
-    ctx.synchronize()
-    for _ in range(args.warmup):
-        step()
-    ctx.synchronize()                     # also surfaces asynchronous errors of the warm-up
-    ctx.enable_kernel_timing(True)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ctx.enable_kernel_timing(False)
-    k_ms, k_n = ctx.read_kernel_timing()
-    ctx.synchronize()
+    res = run_workload(args.workload, B, args.steps, args.warmup, ctx, dev, rank, world, args, fence,
+                       want_gather=use_dist and not args.no_gather, want_single=rank == 0)
+    p, nv, V, C, elapsed = res["p"], res["nv"], res["V"], res["C"], res["elapsed"]
 
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # sanity of what was produced inside the timed region (never a cached / skipped result)
-    chk = out[0].double().sum().item()
-    assert np.isfinite(chk) and chk > 0, "bench produced an empty grid"
-
-    gather_ms = None
-    if use_dist and not args.no_gather:
-        from moleculekit_amd.distributed import gather_features
-        bounds = np.arange(world + 1) * B
-        fence()
-        g0 = time.perf_counter()
-        full = gather_features(out, bounds)
-        fence()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        assert full.shape[0] == world * B
-        del full
-
-    single_us = None
-    if rank == 0:
-        # latency of ONE grid (a single 64^3 grid cannot fill 256 CUs for long)
-        ctx.set_pipelining(False)
-        o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
-        n1 = int(p["atom_offsets"][1])
-        offs1 = t(p["atom_offsets"][:2], np.int64)
-        args1 = (d_coords[:n1], offs1, d_sig[:n1], d_org[:1], nv, p["voxelsize"])
-        kw1 = dict(box=None if d_box is None else d_box[:1], max_images=max_images, out=o1, ctx=ctx)
-        for _ in range(3):
-            batch.voxelize_lattice_torch(*args1, **kw1)
-        torch.cuda.synchronize(dev)
-        s0 = time.perf_counter()
-        for _ in range(20):
-            batch.voxelize_lattice_torch(*args1, **kw1)
-        torch.cuda.synchronize(dev)
-        single_us = (time.perf_counter() - s0) / 20 * 1e6
+    # secondary legs (every rank takes part; only rank 0 reports).  N = 1: the other BASELINE configs, so that their
+    # roofline fractions are timed by whoever runs this file; N > 1: the batched-molecule workload (cfg3) through the
+    # same sharded path -- north_star's "batched molecules" -- next to the headline 64^3 workload.
+    extra = {}
+    if not args.no_extra and args.workload == "cfg2" and not args.batch:
+        names = ["cfg1", "cfg3", "cfg4", "cfg5"] if world == 1 else ["cfg3"]
+        for nm in names:
+            ctx.set_lds_tier(args.lds_tier)
+            r2 = run_workload(nm, DEFAULT_BATCH[nm], max(3, args.steps // 4), 2, ctx, dev, rank, world, args, fence)
+            steps2 = max(3, args.steps // 4)
+            extra[nm] = {"value": round(world * DEFAULT_BATCH[nm] * r2["V"] * r2["C"] * steps2 / r2["elapsed"] / 1e6, 2),
+                         "unit": "Mvoxel-channels/s", "items_per_gpu_per_step": DEFAULT_BATCH[nm], "steps": steps2,
+                         "ms_per_step": round(r2["elapsed"] / steps2 * 1e3, 4), "grid": [int(v) for v in r2["nv"]],
+                         "roofline": roofline_of(r2, nm, DEFAULT_BATCH[nm], args.tile_k)}
 
     if rank == 0:
         total_vc = world * B * V * C * args.steps
-        alg = algorithmic_bytes(p, nv, C)
-        k_avg_ms = k_ms / max(k_n, 1)
-        achieved = alg / (k_avg_ms * 1e-3) / 1e9 if k_n else None
+        k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
         info = ctx.device_info()
-        traffic, traffic_src = pmc_traffic(args.workload, B, args.tile_k)
         line = {
             "metric": "Mvoxel-channels/s (64^3 grid, 8 ch)" if args.workload == "cfg2" else f"Mvoxel-channels/s ({args.workload})",
             "value": round(total_vc / elapsed / 1e6, 2),
@@ -395,16 +537,17 @@ def main():
             "config": {"workload": f"{args.workload}: BASELINE.json configs[{int(args.workload[3:]) - 1}]",
                        "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
                        "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
-                       "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline, "parallelism": f"dp{world} (items sharded, no collective in the timed region)",
+                       "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
+                       "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region)",
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_voxelize_tiles (+ dense pass)", "kernel_avg_ms": round(k_avg_ms, 5),
-                         "kernel_launches": int(k_n), "algorithmic_bytes_per_launch": int(alg)},
-            "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if k_n else None,
-            "single_grid_latency_us": round(single_us, 2) if single_us else None,
-            "gather_ms": round(gather_ms, 3) if gather_ms is not None else None,
+            "roofline": roofline_of(res, args.workload, B, args.tile_k),
+            "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if res["k_n"] else None,
+            "single_grid_latency_us": round(res["single_us"], 2) if "single_us" in res else None,
+            "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
+            "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
         }
+        if extra:
+            line["other_workloads" if world == 1 else "batched_molecules"] = extra
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)

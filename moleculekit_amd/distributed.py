@@ -3,8 +3,18 @@
 Every molecule / pose / frame is an independent unit, so the batch is partitioned contiguously
 across ranks (one process per GPU, ``torch.distributed``; backend ``nccl`` is RCCL over xGMI on
 ROCm) with NO collective on the compute path.  The only exchange is the optional, trivial gather
-of the per-rank feature tensors at the end (``gather_features``): an RCCL all-gather of equally
-sized (padded) shards, or gather-to-root.
+of the per-rank feature tensors: gathering *all* features is xGMI-link
+bound, so it is offered
+  * not at all          -- ``ShardedVoxelizer.voxelize``: features stay sharded (what a data-parallel
+                           consumer wants; this is what ``bench.py --gpus N`` times),
+  * after the compute   -- ``gather_features``: one padded RCCL all-gather (or gather-to-root),
+  * overlapped          -- ``ShardedVoxelizer.voxelize_gather``: the shard is voxelized in chunks and
+                           chunk k travels on a communication stream while chunk k+1 is computed.
+
+Data path of one rank: it holds ONLY its own shard -- host arrays are sliced (or produced by a
+``loader(lo, hi)`` callback, so no rank ever materialises the whole batch), staged through pinned
+memory, uploaded once on a copy stream and kept resident in HBM; every later call works on the
+resident shard.
 
 The reference has no distributed code at all (no NCCL/MPI call sites); this
 module is new, not a translation.
@@ -16,13 +26,13 @@ import os
 import numpy as np
 
 
-def world():
+def world(group=None):
     """(rank, world_size) from torch.distributed if initialised, else from the torchrun env."""
     try:
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized():
-            return dist.get_rank(), dist.get_world_size()
+            return dist.get_rank(group), dist.get_world_size(group)
     except Exception:
         pass
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -53,10 +63,16 @@ def shard_bounds(n_items: int, world_size: int, weights=None):
 
 
 def shard_packed(coords, atom_offsets, sigmas, origins, box, lo, hi):
-    """Slice packed batch arrays down to items [lo, hi)."""
+    """Slice packed batch arrays down to items [lo, hi) (views; the offsets are rebased)."""
     a0, a1 = int(atom_offsets[lo]), int(atom_offsets[hi])
     offs = np.asarray(atom_offsets[lo:hi + 1], dtype=np.int64) - a0
     return (coords[a0:a1], offs, sigmas[a0:a1], origins[lo:hi], None if box is None else box[lo:hi])
+
+
+def chunk_bounds(n_local: int, nchunks: int):
+    """Split a shard of ``n_local`` items into ``nchunks`` contiguous chunks (sizes differ by at most one;
+    trailing chunks may be empty).  Every rank uses the same ``nchunks`` so that the per-chunk collectives match."""
+    return shard_bounds(n_local, max(int(nchunks), 1))
 
 
 def gather_features(local, bounds, group=None, dst=None):
@@ -93,42 +109,219 @@ def gather_features(local, bounds, group=None, dst=None):
     return torch.cat([recv[r][: int(sizes[r])] for r in range(ws)], dim=0)
 
 
-def voxelize_sharded(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None, gather=True,
-                     compute=None, device=None, balance_by_atoms=True):
-    """Voxelize a (host-resident, packed) batch across all ranks of the default process group.
+class ShardedVoxelizer:
+    """This rank's device-resident shard of a batch of lattice-grid items, and the ways to get features out of it.
 
-    Every rank passes the SAME full batch description; rank r computes only its contiguous shard on
-    its own GPU and -- when ``gather`` -- every rank returns the full float32 [B, V, C] tensor,
-    otherwise its local shard (what a data-parallel trainer wants).
-
-    ``compute(coords, offs, sigmas, origins, nvoxels, voxelsize, box) -> torch.Tensor`` defaults to
-    the HIP path (``batch.voxelize_lattice_torch`` on this rank's device); the CPU test-suite injects
-    the oracle here to exercise the sharding / gather logic under ``gloo``.
-    Returns (features, bounds).
+    Build with ``from_host`` (every rank passes the same packed host arrays; only views of this rank's shard are
+    touched) or ``from_loader`` (``loader(lo, hi)`` produces items [lo, hi) -- no rank holds the whole batch).
+    ``compute(coords, offs, sigmas, origins, nvoxels, voxelsize, box) -> torch.Tensor`` defaults to the HIP path
+    (``batch.voxelize_lattice_torch`` on this rank's GPU); the CPU test-suite injects a stand-in to exercise the
+    sharding / staging / gather logic under ``gloo`` -- the product never does.
     """
-    import torch
 
-    rank, ws = world()
-    B = len(atom_offsets) - 1
-    weights = np.diff(np.asarray(atom_offsets)) + 1.0 if balance_by_atoms else None
-    bounds = shard_bounds(B, ws, weights)
-    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-    c, offs, s, o, bx = shard_packed(np.asarray(coords), np.asarray(atom_offsets), np.asarray(sigmas),
-                                     np.asarray(origins, dtype=np.float64).reshape(-1, 3),
-                                     None if box is None else np.asarray(box), lo, hi)
-    if compute is None:
+    def __init__(self, n_items, bounds, shard, nvoxels, voxelsize, device=None, compute=None, group=None, ctx=None):
+        import torch
+
+        self.group = group
+        self.rank, self.world = world(group)
+        self.n_items = int(n_items)
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.nvoxels = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
+        self.V = int(np.prod(self.nvoxels.astype(np.int64)))
+        self.voxelsize = float(voxelsize)
+        self._compute = compute
+        self._ctx = ctx
+        coords, offs, sigmas, origins, box = shard
+        self.n_local = int(len(offs) - 1)
+        assert self.n_local == self.hi - self.lo, "the shard does not match this rank's bounds"
+        self.C = int(np.asarray(sigmas).shape[1]) if np.asarray(sigmas).ndim == 2 else 0
+        self._offs_host = np.ascontiguousarray(offs, dtype=np.int64)
+        self.max_images = 1
+        if compute is None:
+            if device is None:
+                device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", self.rank)) % max(torch.cuda.device_count(), 1))
+            self.device = torch.device(device)
+            if self.device.type != "cuda":
+                raise RuntimeError("ShardedVoxelizer needs a HIP device (there is no CPU path); tests inject `compute`")
+            if box is not None and len(box):
+                from . import batch
+                self.max_images = batch.max_images_per_atom(box, self.nvoxels, self.voxelsize)
+        else:
+            self.device = torch.device("cpu" if device is None else device)
+        sig = np.asarray(sigmas)
+        sig_dt = np.float64 if sig.dtype == np.float64 else np.float32
+        self._d = self._upload(dict(coords=(coords, np.float32), offs=(self._offs_host, np.int64), sigmas=(sig, sig_dt),
+                                    origins=(np.asarray(origins, dtype=np.float64).reshape(-1, 3), np.float64),
+                                    box=(box, np.float32)))
+        self._chunk_offs = {}
+
+    # ---- construction -------------------------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None, balance_by_atoms=True, **kw):
+        rank, ws = world(kw.get("group"))
+        atom_offsets = np.asarray(atom_offsets)
+        B = len(atom_offsets) - 1
+        weights = np.diff(atom_offsets) + 1.0 if balance_by_atoms else None
+        bounds = shard_bounds(B, ws, weights)
+        shard = shard_packed(np.asarray(coords), atom_offsets, np.asarray(sigmas),
+                             np.asarray(origins, dtype=np.float64).reshape(-1, 3),
+                             None if box is None else np.asarray(box), int(bounds[rank]), int(bounds[rank + 1]))
+        return cls(B, bounds, shard, nvoxels, voxelsize, **kw)
+
+    @classmethod
+    def from_loader(cls, n_items, loader, nvoxels, voxelsize, weights=None, **kw):
+        """``loader(lo, hi) -> (coords [n,3], atom_offsets [hi-lo+1] starting at 0, sigmas [n,C], origins [hi-lo,3],
+        box [hi-lo,3] | None)`` for items [lo, hi); ``weights`` (e.g. atoms per item) balance the partition."""
+        rank, ws = world(kw.get("group"))
+        bounds = shard_bounds(int(n_items), ws, weights)
+        return cls(n_items, bounds, tuple(loader(int(bounds[rank]), int(bounds[rank + 1]))), nvoxels, voxelsize, **kw)
+
+    def _upload(self, arrays):
+        """Host arrays -> device tensors through pinned staging on a copy stream (one H2D per array, asynchronous;
+        the compute stream waits for the copies' event).  On the CPU test path: plain tensors."""
+        import torch
+
+        out = {}
+        if self.device.type != "cuda":
+            for k, (a, dt) in arrays.items():
+                out[k] = None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=dt))
+            return out
+        copy = torch.cuda.Stream(device=self.device)
+        keep = []
+        with torch.cuda.stream(copy):
+            for k, (a, dt) in arrays.items():
+                if a is None:
+                    out[k] = None
+                    continue
+                a = np.asarray(a)
+                pinned = torch.empty(a.shape, dtype=getattr(torch, np.dtype(dt).name), pin_memory=True)
+                np.copyto(pinned.numpy(), a, casting="same_kind")        # the only host-side pass over the shard
+                out[k] = pinned.to(self.device, non_blocking=True)
+                keep.append(pinned)
+        ev = torch.cuda.Event()
+        ev.record(copy)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+        for t in out.values():
+            if t is not None:
+                t.record_stream(torch.cuda.current_stream(self.device))
+        copy.synchronize()              # the pinned staging buffers are released here (set-up, not the hot path)
+        return out
+
+    # ---- compute ------------------------------------------------------------------------------------------
+    def _run(self, coords, offs, sigmas, origins, box, out=None):
+        if self._compute is not None:
+            t = lambda x: None if x is None else x.numpy()
+            res = self._compute(t(coords), t(offs), t(sigmas), t(origins), self.nvoxels, self.voxelsize, t(box))
+            if out is not None:
+                out.copy_(res)
+                return out
+            return res
         from . import batch
 
-        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)) if device is None else device)
+        return batch.voxelize_lattice_torch(coords, offs, sigmas, origins, self.nvoxels, self.voxelsize, box=box,
+                                            max_images=self.max_images, out=out, ctx=self._ctx)
 
-        def compute(c, offs, s, o, nv, vs, bx):
-            mi = 1 if bx is None else batch.max_images_per_atom(bx, nv, vs)
-            t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
-            return batch.voxelize_lattice_torch(
-                t(c, np.float32).reshape(-1, 3), t(offs, np.int64), t(s, np.float32), t(o, np.float64), nv, vs,
-                box=None if bx is None else t(bx, np.float32), max_images=mi)
+    def _items(self, lo, hi):
+        """Views of the resident shard for local items [lo, hi) (the rebased offsets are built once per range)."""
+        import torch
 
-    local = compute(c, offs, s, o, nvoxels, voxelsize, bx)
-    if gather and ws > 1:
-        return gather_features(local, bounds), bounds
-    return local, bounds
+        d = self._d
+        a0, a1 = int(self._offs_host[lo]), int(self._offs_host[hi])
+        if (lo, hi) == (0, self.n_local):
+            offs = d["offs"]
+        else:
+            offs = self._chunk_offs.get((lo, hi))
+            if offs is None:
+                offs = torch.as_tensor(self._offs_host[lo:hi + 1] - a0, device=self.device)
+                self._chunk_offs[(lo, hi)] = offs
+        return d["coords"][a0:a1], offs, d["sigmas"][a0:a1], d["origins"][lo:hi], None if d["box"] is None else d["box"][lo:hi]
+
+    def voxelize(self, out=None):
+        """This rank's shard -> float32 [B_local, V, C] on its device; asynchronous, no collective."""
+        return self._run(*self._items(0, self.n_local), out=out)
+
+    def gather(self, local, dst=None):
+        return gather_features(local, self.bounds, group=self.group, dst=dst) if self.world > 1 else local
+
+    def voxelize_gather(self, nchunks=4, dst=None, timings=None):
+        """Voxelize the shard chunk by chunk and gather every finished chunk on a communication stream while the next
+        one is computed.  Returns the full float32 [B, V, C] tensor on every rank (``dst=None``: all-gather) or on
+        ``dst`` only (others get None).  Chunks are padded to the largest chunk of any rank so that each step is one
+        equal-sized collective; the rows land at their final position in the result."""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return self.voxelize()
+        ws, rank = self.world, self.rank
+        sizes = np.diff(self.bounds)
+        cb = [chunk_bounds(int(s), nchunks) for s in sizes]               # per rank: its chunk boundaries (same count)
+        tail = (self.V, self.C)
+        cuda = self.device.type == "cuda"
+        want = dst is None or rank == dst
+        full = torch.empty((self.n_items,) + tail, dtype=torch.float32, device=self.device) if want else None
+        local = torch.empty((self.n_local,) + tail, dtype=torch.float32, device=self.device)
+        comm = torch.cuda.Stream(device=self.device) if cuda else None
+        main = torch.cuda.current_stream(self.device) if cuda else None
+        for c in range(len(cb[rank]) - 1):
+            lo, hi = int(cb[rank][c]), int(cb[rank][c + 1])
+            cmax = max(int(cb[r][c + 1] - cb[r][c]) for r in range(ws))
+            if cmax == 0:
+                continue
+            if hi > lo:
+                self._run(*self._items(lo, hi), out=local[lo:hi])
+            ev = None
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record(main)
+            with (torch.cuda.stream(comm) if cuda else _null()):
+                if cuda:
+                    comm.wait_event(ev)
+                send = local[lo:hi]
+                if hi - lo != cmax:
+                    send = torch.zeros((cmax,) + tail, dtype=torch.float32, device=self.device)
+                    send[: hi - lo] = local[lo:hi]
+                if dst is None:
+                    recv = torch.empty((ws * cmax,) + tail, dtype=torch.float32, device=self.device)
+                    dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
+                    parts = [recv[r * cmax:(r + 1) * cmax] for r in range(ws)]
+                else:
+                    parts = [torch.empty((cmax,) + tail, dtype=torch.float32, device=self.device) for _ in range(ws)] if want else None
+                    dist.gather(send.contiguous(), parts, dst=dst, group=self.group)
+                if want:
+                    for r in range(ws):
+                        g0 = int(self.bounds[r] + cb[r][c])
+                        n = int(cb[r][c + 1] - cb[r][c])
+                        if n:
+                            full[g0:g0 + n].copy_(parts[r][:n])
+        if cuda:
+            main.wait_stream(comm)
+            local.record_stream(comm)
+        return full
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def voxelize_sharded(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None, gather=True,
+                     compute=None, device=None, balance_by_atoms=True, nchunks=0, dst=None):
+    """One-call form: voxelize a packed batch across all ranks of the default process group.
+
+    Every rank passes the same batch description (host arrays; only views of the rank's own shard are read);
+    rank r computes its contiguous shard on its own GPU and -- when ``gather`` -- every rank (or only ``dst``)
+    returns the full float32 [B, V, C] tensor, otherwise its local shard.  ``nchunks`` > 0 overlaps the gather
+    with the compute chunk by chunk (``ShardedVoxelizer.voxelize_gather``).  Returns (features, bounds).
+    """
+    sv = ShardedVoxelizer.from_host(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=box,
+                                    balance_by_atoms=balance_by_atoms, compute=compute, device=device)
+    if not gather or sv.world == 1:
+        return sv.voxelize(), sv.bounds
+    if nchunks > 0:
+        return sv.voxelize_gather(nchunks=nchunks, dst=dst), sv.bounds
+    return sv.gather(sv.voxelize(), dst=dst), sv.bounds

@@ -1,0 +1,34 @@
+"""CPU tier: `python bench.py --gpus 2` must start two ranks by itself (the driver's command shape) -- checked with
+`--dry-run`: gloo rendezvous on 127.0.0.1, the sharded data path of moleculekit_amd.distributed with a stand-in
+compute, both gathers.  Also: the launcher refuses to pretend when the node has fewer devices than asked for."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv, timeout=300):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus2_dry_run_spawns_two_ranks():
+    r = _run("--gpus", "2", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["ok"] is True
+
+
+def test_bench_refuses_more_gpus_than_devices():
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run("--gpus", str(have + 2), "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "HIP device(s) visible" in (r.stderr + r.stdout)

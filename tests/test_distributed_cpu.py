@@ -49,6 +49,24 @@ def _worker(rank, world, port, B, q):
               and local.shape[0] == bounds[rank + 1] - bounds[rank]
               and np.array_equal(local.numpy(), ref[bounds[rank]:bounds[rank + 1]])
               and ((root is None) if rank != 0 else np.array_equal(root.numpy(), ref)))
+        # the chunk-overlapped gather (all ranks / root only), on ragged shards balanced by atoms, more chunks than items
+        for nchunks in (1, 3, 16):
+            ch, b2 = D.voxelize_sharded(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0, gather=True,
+                                        compute=compute, nchunks=nchunks)
+            ok = ok and np.array_equal(b2, bounds) and np.array_equal(ch.numpy(), ref)
+            ch0, _ = D.voxelize_sharded(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0, gather=True,
+                                        compute=compute, nchunks=nchunks, dst=0)
+            ok = ok and ((ch0 is None) if rank != 0 else np.array_equal(ch0.numpy(), ref))
+        # a rank that only ever sees its own shard (loader), partition balanced by atoms per item
+        seen = []
+
+        def loader(lo, hi):
+            seen.append((lo, hi))
+            return D.shard_packed(p["coords"], p["atom_offsets"], p["sigmas"], origins, None, lo, hi)
+
+        sv = D.ShardedVoxelizer.from_loader(B, loader, nv, 1.0, weights=np.diff(p["atom_offsets"]) + 1.0, compute=compute)
+        ok = ok and seen == [(int(sv.bounds[rank]), int(sv.bounds[rank + 1]))] and np.array_equal(sv.bounds, bounds)
+        ok = ok and np.array_equal(sv.voxelize_gather(nchunks=2).numpy(), ref)
         q.put((rank, bool(ok), [int(b) for b in bounds]))
     finally:
         dist.destroy_process_group()
