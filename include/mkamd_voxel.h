@@ -9,7 +9,7 @@
  *   and, for periodic frames, the orthorhombic minimum image  (distance_utils/distance_utils.pyx:49-52).
  *
  * Plain pointers and sizes only (no torch / numpy types).  Every function returns an int status
- * (MKAMD_OK == 0) and never throws; mkamd_last_error() gives the message for the calling thread.
+ * (MKAMD_OK == 0) and never throws (every entry point is a function-try-block); mkamd_last_error() gives the message for the calling thread.
  * All device work is enqueued on the context's HIP stream.  "_host" entry points take host
  * pointers, copy in/out and synchronise; "_dev" entry points take device pointers, are
  * asynchronous and leave results resident in HBM.
@@ -38,6 +38,7 @@ extern "C" {
 #define MKAMD_ENODEV 3    /* no usable GPU */
 #define MKAMD_EOVERFLOW 4 /* more periodic images than max_images_per_atom allowed */
 #define MKAMD_EBOX 5      /* periodic box edge <= 2 x cutoff (10 A) or too many images */
+#define MKAMD_ENOMEM 6    /* host allocation failed inside the library (nothing C++ ever crosses this boundary) */
 
 typedef struct mkamd_ctx mkamd_ctx;
 
@@ -55,6 +56,10 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx);
 int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream);
 /* Wait for the stream and report asynchronous errors of "_dev" calls (MKAMD_EOVERFLOW/EBOX). */
 int mkamd_ctx_synchronize(mkamd_ctx* ctx);
+/* Non-blocking form for streaming callers: reports (and clears) an asynchronous error of a "_dev" lattice call that
+ * has ALREADY finished -- the device-side flag is mirrored into pinned host memory by every call, so the clean path is
+ * one host read.  An error still in flight is reported by a later poll or by mkamd_ctx_synchronize. */
+int mkamd_ctx_poll_errors(mkamd_ctx* ctx);
 /* name (<= len bytes), compute units, HBM bytes, gcn arch string e.g. "gfx950..." */
 int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_units,
                           uint64_t* hbm_bytes, char* arch, size_t arch_len);

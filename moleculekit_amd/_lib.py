@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MKAMD_LIB", os.path.join(_HERE, "csrc", "libmkamd.so"))
 
-MKAMD_OK, MKAMD_EINVAL, MKAMD_EHIP, MKAMD_ENODEV, MKAMD_EOVERFLOW, MKAMD_EBOX = range(6)
+MKAMD_OK, MKAMD_EINVAL, MKAMD_EHIP, MKAMD_ENODEV, MKAMD_EOVERFLOW, MKAMD_EBOX, MKAMD_ENOMEM = range(7)
 
 _c_int, _c_i32, _c_i64, _c_dbl, _vp = ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
@@ -28,6 +28,7 @@ SIGNATURES = {
     "mkamd_ctx_destroy": (_c_int, [_vp]),
     "mkamd_ctx_set_stream": (_c_int, [_vp, _vp]),
     "mkamd_ctx_synchronize": (_c_int, [_vp]),
+    "mkamd_ctx_poll_errors": (_c_int, [_vp]),
     "mkamd_ctx_device_info": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_c_int),
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_ctx_set_tile_k": (_c_int, [_vp, _c_int]),
@@ -102,6 +103,8 @@ def _check(st):
         msg = load().mkamd_last_error().decode(errors="replace")
         if st == MKAMD_EINVAL:
             raise ValueError(f"libmkamd: {msg}")
+        if st == MKAMD_ENOMEM:
+            raise MemoryError(f"libmkamd: {msg}")
         raise MkamdError(st, msg)
 
 
@@ -151,6 +154,11 @@ class Context:
 
     def synchronize(self):
         _check(load().mkamd_ctx_synchronize(self._h))
+
+    def poll_errors(self):
+        """Non-blocking: raise if an already finished asynchronous lattice call flagged an error (bad / too small
+        periodic box, more images than reserved)."""
+        _check(load().mkamd_ctx_poll_errors(self._h))
 
     def set_tile_k(self, k: int):
         _check(load().mkamd_ctx_set_tile_k(self._h, int(k)))
@@ -244,18 +252,31 @@ class Context:
 
 
 _contexts = {}
+_contexts_lock = threading.Lock()
 
 
 def default_context(device: int | None = None) -> Context:
-    """Per-(process, device) shared context. ``device=None`` -> LOCAL_RANK env or 0."""
+    """The calling THREAD's context on ``device`` (``None`` -> MKAMD_DEVICE / LOCAL_RANK env or 0).
+
+    A context owns one stream, one grow-only workspace and pinned staging buffers, and ctypes releases the GIL
+    during every call, so two host threads must never drive the same context at once (include/mkamd_voxel.h: "one
+    context per device and per host thread").  The reference's Cython kernel runs under the GIL and is thread-safe
+    by construction; keying the shared default by (process, thread, device) gives the drop-in API the same
+    guarantee.  Contexts of threads that have ended are closed the next time a new one is created."""
     if device is None:
         device = int(os.environ.get("MKAMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         n = device_count()
         if n > 0:
             device %= n
-    key = (os.getpid(), int(device))
+    key = (os.getpid(), threading.get_ident(), int(device))
     ctx = _contexts.get(key)
     if ctx is None:
-        ctx = Context(device)
-        _contexts[key] = ctx
+        with _contexts_lock:
+            alive = {t.ident for t in threading.enumerate()}
+            for k in [k for k in _contexts if k[0] != os.getpid() or k[1] not in alive]:
+                dead = _contexts.pop(k)
+                if k[0] == os.getpid():            # (a forked child must not free the parent's device handles)
+                    dead.close()
+            ctx = Context(device)
+            _contexts[key] = ctx
     return ctx

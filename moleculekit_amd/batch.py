@@ -219,6 +219,11 @@ def voxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None,
     return feats, origin, nvoxels.astype(np.int64)
 
 
+def _chunk_images(box3n, nvoxels, voxelsize) -> int:
+    """Images per atom for one chunk's boxes ([3, n], Angstrom); raises for edges <= 10 A (zero boxes included)."""
+    return max_images_per_atom(np.ascontiguousarray(np.asarray(box3n).T), nvoxels, voxelsize)
+
+
 _PINNED = {}
 _COPY_THREADS = 8
 _POOL = None
@@ -251,7 +256,12 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
                      max_images):
     """Core of the streamed voxelizers: ``fill(coords_np [N,3,n], box_np [3,n] | None, idx)`` produces chunk ``idx``
     (frame indices) straight into pinned staging; a copy stream uploads chunk k+1 while the current stream
-    voxelizes chunk k; ``scale`` converts the coordinates to Angstrom on the device (XTC stores nm)."""
+    voxelizes chunk k; ``scale`` converts the coordinates to Angstrom on the device (XTC stores nm).
+
+    Periodic boxes are checked per chunk on the host, where they are already at hand (``_chunk_images``: every edge
+    > 10 A, images per atom recomputed from THIS chunk's boxes -- an NPT trajectory may shrink after its first frame);
+    what only the device can see is polled without blocking after every chunk (``ctx.poll_errors``) and collected for
+    good when the generator ends, so a bad frame raises instead of yielding silently incomplete features."""
     import torch
 
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -275,6 +285,8 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
         ready = [torch.cuda.Event(), torch.cuda.Event()]         # device copy of chunk in slot i has landed
         dslab = [None, None]
         dbox = [None, None]
+        images = [max_images, max_images]
+        run_ctx = ctx or _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
 
         def upload(k, slot):
             idx = fr[k * chunk:(k + 1) * chunk]
@@ -283,6 +295,7 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
             hc = stage[slot][:N * 3 * n].view(N, 3, n)            # tight [N,3,n]: one contiguous H2D
             hb = stage_box[slot][:3 * n].view(3, n) if has_box else None
             fill(hc.numpy(), hb.numpy() if has_box else None, idx)
+            images[slot] = max(max_images, _chunk_images(hb.numpy(), nvoxels, voxelsize)) if has_box else 1
             with torch.cuda.stream(copy):
                 dslab[slot] = hc.to(dev, non_blocking=True)
                 dbox[slot] = hb.to(dev, non_blocking=True) if has_box else None
@@ -310,8 +323,10 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
                     bx.record_stream(main)
                     d_b = bx.t().contiguous()
                 feats = voxelize_lattice_torch(xyz, d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize, box=d_b,
-                                               max_images=max_images, ctx=ctx, channel_first=channel_first)
+                                               max_images=images[slot], ctx=run_ctx, channel_first=channel_first)
+                run_ctx.poll_errors()                             # non-blocking: errors of the chunks already finished
                 yield idx, feats
+            run_ctx.synchronize()                                 # the last chunks' asynchronous errors, if any
         finally:                                                  # also when the consumer stops early
             copy.synchronize()                                    # no H2D still reading the staging buffers
             for i in range(2):
@@ -378,7 +393,8 @@ def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, 
     lib, path = _lib.load(), _xtc._path(filename)
     max_images = 1
     if pbc and len(fr):
-        _, bv, _, _ = _xtc.read_xtc_frames(filename, fr[:1])     # image bound from the first frame's box (+ checked per call)
+        _, bv, _, _ = _xtc.read_xtc_frames(filename, fr[:1])     # first guess from the first frame's box; every chunk
+                                                                 # recomputes it from its own boxes (_stream_voxelize)
         lengths = np.sqrt((bv[:, :, 0].astype(np.float64) ** 2).sum(axis=1)) * 10.0
         if not np.all(lengths > 0):
             raise ValueError("pbc=True but the XTC frames carry no box")

@@ -11,8 +11,9 @@ Mirrors, array in / array out and vectorised (the reference loops over hydrogens
 * ``getChannels``                = ``moleculekit/tools/voxeldescriptors.py:135-194`` for ``Molecule``-like objects
 
 Not here: assigning the atom types themselves (``getPDBQTAtomTypesAndCharges`` needs OpenBabel) and the
-``SmallMol`` branch (RDKit); neither toolkit is part of this package's environment.  When the real
-``moleculekit`` is importable, ``moleculekit_amd.voxeldescriptors`` still prefers its ``getChannels``.
+``SmallMol`` branch (RDKit); neither toolkit is part of this package's environment.
+``moleculekit_amd.voxeldescriptors.getChannels`` uses this module by default and delegates to an installed
+moleculekit only when asked to (``backend="moleculekit"``).
 
 Host-side numpy only: typing is a few table look-ups per atom, it is not on the GPU path.
 """

@@ -17,19 +17,29 @@
 
 using namespace mkamd;
 
-static thread_local std::string g_last_error;
+// The message of the calling thread's last failure: a fixed buffer, so that reporting an error can never throw
+// (an std::string here could raise bad_alloc on the way out of an extern "C" function).
+static thread_local char g_last_error[512] = "";
 
-static int fail(int code, const std::string& msg)
+static int fail(int code, const char* msg) noexcept
 {
-    g_last_error = msg;
+    snprintf(g_last_error, sizeof g_last_error, "%s", msg ? msg : "");
     return code;
 }
+static int fail(int code, const std::string& msg) noexcept { return fail(code, msg.c_str()); }
 
-static int hip_fail(hipError_t e, const char* what)
+static int hip_fail(hipError_t e, const char* what) noexcept
 {
-    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MKAMD_ENODEV : MKAMD_EHIP,
-                std::string(what) + ": " + hipGetErrorString(e));
+    snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? MKAMD_ENODEV : MKAMD_EHIP;
 }
+
+// Every extern "C" entry point is a function-try-block closed by this: nothing C++ (bad_alloc from a vector / string,
+// anything a dependency throws) crosses the C boundary; it comes back as a status + message like every other failure.
+#define MK_API_CATCH                                                                              \
+    catch (const std::bad_alloc&) { return fail(MKAMD_ENOMEM, "out of host memory"); }            \
+    catch (const std::exception& e) { return fail(MKAMD_EHIP, e.what()); }                        \
+    catch (...) { return fail(MKAMD_EHIP, "unexpected C++ exception"); }
 
 #define HIP_TRY(expr)                                   \
     do {                                                \
@@ -110,22 +120,40 @@ struct mkamd_ctx {
         return 0;
     }
     // ---- cross-call software pipeline (pipeline.h: acquire_set / prepass_done / tile_done) ----
+    // Every event record / stream wait below is checked: a failed one would silently remove the ordering the results
+    // depend on, so on failure the context drains both streams (which restores a trivially correct order), turns
+    // pipelining off for good (`pipeline_broken`) and the call carries on in order on the caller's stream.
+    bool pipeline_broken = false;
+    bool sync_ok(hipError_t e)
+    {
+        if (e == hipSuccess) return true;
+        (void)hipGetLastError();
+        pipeline_broken = true;
+        if (side_stream) (void)hipStreamSynchronize(side_stream);
+        (void)hipStreamSynchronize(main_stream);
+        tile_pending[0] = tile_pending[1] = false;
+        have_pre_tile_event = false;
+        return false;
+    }
     int acquire_set(bool big_enough)
     {
         in_pipelined_prepass = false;
-        if (!big_enough || !pipelining || !side_stream) {
+        if (!big_enough || !pipelining || !side_stream || pipeline_broken) {
             // in-order call on the caller's stream, set 0 (any earlier pipelined call has already made the
             // main stream wait for its pre-pass; its tile kernel is ahead of us on the same stream)
             have_pre_tile_event = false;
             return 0;
         }
         const int set = next_set;
-        next_set ^= 1;
         // Inputs must not depend on work enqueued after the PREVIOUS call's tile kernel (the opt-in contract of
         // mkamd_ctx_set_pipelining): the side stream is ordered after everything before that launch only.
-        if (!have_pre_tile_event) { (void)hipEventRecord(ev_inputs, main_stream); inputs_marker = ev_inputs; }
-        (void)hipStreamWaitEvent(side_stream, inputs_marker, 0);
-        if (tile_pending[set]) (void)hipStreamWaitEvent(side_stream, tile_marker[set], 0);
+        if (!have_pre_tile_event) {
+            if (!sync_ok(hipEventRecord(ev_inputs, main_stream))) return 0;
+            inputs_marker = ev_inputs;
+        }
+        if (!sync_ok(hipStreamWaitEvent(side_stream, inputs_marker, 0))) return 0;
+        if (tile_pending[set] && !sync_ok(hipStreamWaitEvent(side_stream, tile_marker[set], 0))) return 0;
+        next_set ^= 1;
         stream = side_stream;
         in_pipelined_prepass = true;
         return set;
@@ -134,19 +162,19 @@ struct mkamd_ctx {
     void prepass_done(int set)
     {
         if (!in_pipelined_prepass) return;
-        (void)hipEventRecord(ev_pre_done[set], side_stream);
         stream = main_stream;
-        (void)hipStreamWaitEvent(main_stream, ev_pre_done[set], 0);
-        have_pre_tile_event = true;                                   // hot_begin() records the marker
+        // on failure sync_ok() has drained the side stream: the pre-pass is complete, the tile kernel may follow
+        if (sync_ok(hipEventRecord(ev_pre_done[set], side_stream)) && sync_ok(hipStreamWaitEvent(main_stream, ev_pre_done[set], 0)))
+            have_pre_tile_event = true;                               // hot_begin() records the marker
     }
     void tile_done(int set)
     {
         if (!side_stream) return;
-        if (last_hot_end) tile_marker[set] = last_hot_end;            // the timing event sits at the same place
-        else { (void)hipEventRecord(ev_tile_done[set], main_stream); tile_marker[set] = ev_tile_done[set]; }
-        last_hot_end = nullptr;
-        tile_pending[set] = true;
         in_pipelined_prepass = false;
+        if (pipeline_broken) { last_hot_end = nullptr; return; }
+        if (last_hot_end) { tile_marker[set] = last_hot_end; tile_pending[set] = true; }   // the timing event sits at the same place
+        else if (sync_ok(hipEventRecord(ev_tile_done[set], main_stream))) { tile_marker[set] = ev_tile_done[set]; tile_pending[set] = true; }
+        last_hot_end = nullptr;
     }
     // Events are barrier packets the command processor takes ~5 us each to retire, and they sit between one
     // call's tile kernel and the next one's: the timing events double as the pipeline's markers when both exist.
@@ -158,21 +186,27 @@ struct mkamd_ctx {
             bool ok = true;
             if (!ev_free.empty()) { ev = ev_free.back(); ev_free.pop_back(); }
             else ok = hipEventCreate(&ev.first) == hipSuccess && hipEventCreate(&ev.second) == hipSuccess;
-            if (ok) {
+            if (ok && hipEventRecord(ev.first, stream) == hipSuccess) {
                 cur0 = ev.first; cur1 = ev.second;
-                (void)hipEventRecord(cur0, stream);
                 if (in_pipelined_prepass) inputs_marker = cur0;       // "everything before this call's tile kernel"
                 return;
             }
+            (void)hipGetLastError();                                  // no timing for this launch; the marker below still goes in
         }
-        if (in_pipelined_prepass) { (void)hipEventRecord(ev_inputs, main_stream); inputs_marker = ev_inputs; }
+        if (in_pipelined_prepass) {
+            if (sync_ok(hipEventRecord(ev_inputs, main_stream))) inputs_marker = ev_inputs;
+        }
     }
     void hot_end()
     {
         if (!timing || !cur0) return;
-        (void)hipEventRecord(cur1, stream);
-        ev_used.emplace_back(cur0, cur1);
-        last_hot_end = cur1;
+        if (hipEventRecord(cur1, stream) == hipSuccess) {
+            ev_used.emplace_back(cur0, cur1);
+            last_hot_end = cur1;
+        } else {
+            (void)hipGetLastError();
+            ev_free.emplace_back(cur0, cur1);
+        }
         cur0 = cur1 = nullptr;
     }
 };
@@ -214,10 +248,10 @@ extern "C" {
 
 const char* mkamd_version(void) { return "moleculekit_amd 0.1.0 (gfx950, HIP)"; }
 
-const char* mkamd_last_error(void) { return g_last_error.c_str(); }
+const char* mkamd_last_error(void) { return g_last_error; }
 
 int mkamd_device_count(int* count)
-{
+try {
     if (!count) return fail(MKAMD_EINVAL, "count is NULL");
     *count = 0;
     int n = 0;
@@ -225,10 +259,10 @@ int mkamd_device_count(int* count)
     if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
     *count = n;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_create(int device, mkamd_ctx** out)
-{
+try {
     if (!out) return fail(MKAMD_EINVAL, "ctx out-pointer is NULL");
     *out = nullptr;
     int n = 0;
@@ -262,10 +296,10 @@ int mkamd_ctx_create(int device, mkamd_ctx** out)
     if (!c->fb_dev && c->fb_host) { (void)hipHostFree(c->fb_host); c->fb_host = nullptr; }
     *out = c;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_destroy(mkamd_ctx* ctx)
-{
+try {
     if (!ctx) return MKAMD_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -286,10 +320,10 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx)
     if (ctx->out_host) (void)hipHostFree(ctx->out_host);
     delete ctx;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     // NULL is a real stream (the legacy default stream, which is what torch.cuda.current_stream() usually is);
@@ -301,20 +335,35 @@ int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream)
     ctx->tile_pending[0] = ctx->tile_pending[1] = false;
     ctx->stream = ctx->main_stream = next;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_synchronize(mkamd_ctx* ctx)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     HIP_TRY(hipStreamSynchronize(ctx->main_stream));
     return collect_async_errors(ctx);
-}
+} MK_API_CATCH
+
+int mkamd_ctx_poll_errors(mkamd_ctx* ctx)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    // the dense pass of every lattice call mirrors the device-side flag into pinned host memory: reading it costs
+    // nothing and needs no synchronisation; only a raised flag pays for the drain + the precise report
+    if (!ctx->fb_host || ((volatile unsigned*)ctx->fb_host)[NTIER + 1] == 0u) return MKAMD_OK;
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->main_stream));
+    ctx->err_mirrored = false;
+    st = collect_async_errors(ctx);
+    ((volatile unsigned*)ctx->fb_host)[NTIER + 1] = 0u;
+    return st;
+} MK_API_CATCH
 
 int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_units,
                           uint64_t* hbm_bytes, char* arch, size_t arch_len)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     hipDeviceProp_t p;
@@ -324,59 +373,60 @@ int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_u
     if (compute_units) *compute_units = p.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_set_tile_k(mkamd_ctx* ctx, int k)
-{
+try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     if (k != 0 && k != 4 && k != 8) return fail(MKAMD_EINVAL, "tile K must be 0 (auto), 4 or 8");
     ctx->tile_k = k;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier)
-{
+try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     if (tier < -1 || tier >= NTIER) return fail(MKAMD_EINVAL, "LDS tier must be -1 (adaptive), 0, 1 or 2");
     ctx->lds_tier = tier;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode)
-{
+try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     if (mode < -1 || mode > 1) return fail(MKAMD_EINVAL, "pre-pass mode must be -1 (automatic), 0 (kernel chain) or 1 (per-item)");
     ctx->prepass_mode = mode;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_set_force_general(mkamd_ctx* ctx, int on)
-{
+try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     ctx->force_general = on != 0;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_set_pipelining(mkamd_ctx* ctx, int on)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(ctx->main_stream));
     if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     ctx->pipelining = on != 0;
+    ctx->pipeline_broken = false;             // both streams are drained: a fresh start
     ctx->have_pre_tile_event = false;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable)
-{
+try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     ctx->timing = enable != 0;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* launches)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -391,7 +441,7 @@ int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* laun
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // explicit centres
@@ -400,7 +450,7 @@ int mkamd_occupancy_centers_dev(mkamd_ctx* ctx, const double* d_centers, int64_t
                                 const float* d_coords, int64_t n_atoms, const void* d_sigmas,
                                 int sigmas_are_f64, int32_t n_channels, const double* box_host,
                                 float* d_features)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (n_centers > 0 && (!d_centers || !d_features)) return fail(MKAMD_EINVAL, "centers/features pointer is NULL");
@@ -410,12 +460,12 @@ int mkamd_occupancy_centers_dev(mkamd_ctx* ctx, const double* d_centers, int64_t
                      box_host, d_features, err);
     if (st && !err.empty()) return fail(st, err);
     return st;
-}
+} MK_API_CATCH
 
 int mkamd_occupancy_centers_host(mkamd_ctx* ctx, const double* centers, int64_t V, const float* coords,
                                  int64_t N, const void* sigmas, int sigmas_are_f64, int32_t C,
                                  const double* box, float* features)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
@@ -438,11 +488,11 @@ int mkamd_occupancy_centers_host(mkamd_ctx* ctx, const double* centers, int64_t 
     HIP_TRY(hipMemcpyAsync(features, dout, (size_t)V * C * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t V, const float* coords,
                               int64_t N, const double* sigmas, int32_t C, double* results)
-{
+try {
     if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
     if (V == 0 || N == 0) return ctx ? MKAMD_OK : fail(MKAMD_EINVAL, "ctx is NULL");
     if (!results) return fail(MKAMD_EINVAL, "results pointer is NULL");
@@ -455,7 +505,7 @@ int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t V, 
         if (v > results[i]) results[i] = v;
     }
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // lattice grids (the hot path)
@@ -465,17 +515,17 @@ int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
                                int sigmas_are_f64, int32_t C, const double* d_origins,
                                const int32_t* nvoxels, double voxelsize, const float* d_box,
                                int32_t max_images, float* d_features)
-{
+try {
     return mkamd_voxelize_lattice_aug_dev(ctx, B, d_coords, d_atom_offsets, total_atoms, d_sigmas, sigmas_are_f64, C,
                                           d_origins, nvoxels, voxelsize, d_box, max_images, nullptr, d_features);
-}
+} MK_API_CATCH
 
 int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
                                    const int64_t* d_atom_offsets, int64_t total_atoms, const void* d_sigmas,
                                    int sigmas_are_f64, int32_t C, const double* d_origins,
                                    const int32_t* nvoxels, double voxelsize, const float* d_box,
                                    int32_t max_images, const double* d_affine, float* d_features)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (!nvoxels) return fail(MKAMD_EINVAL, "nvoxels pointer is NULL");
@@ -493,13 +543,13 @@ int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coo
     st = run_lattice(*ctx, P, err);
     if (st && !err.empty()) return fail(st, err);
     return st;
-}
+} MK_API_CATCH
 
 int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
                                 const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
                                 const int32_t* nvoxels, double voxelsize, const float* box,
                                 int32_t max_images, float* features)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (B < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_items must be >= 0 and n_channels > 0");
@@ -595,14 +645,14 @@ int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (mapped_out) memcpy(features, ctx->out_host, out_bytes);
     return collect_async_errors(ctx);
-}
+} MK_API_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // lattice centres
 // ---------------------------------------------------------------------------------------------
 int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels, double voxelsize,
                            double* d_centers)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (!bb_min || !nvoxels) return fail(MKAMD_EINVAL, "bb_min/nvoxels pointer is NULL");
@@ -611,11 +661,11 @@ int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* 
     st = run_grid_centers(*ctx, bb_min, nv, voxelsize, d_centers, err);
     if (st && !err.empty()) return fail(st, err);
     return st;
-}
+} MK_API_CATCH
 
 int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels, double voxelsize,
                             double* centers)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (!bb_min || !nvoxels) return fail(MKAMD_EINVAL, "bb_min/nvoxels pointer is NULL");
@@ -629,37 +679,37 @@ int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t*
     HIP_TRY(hipMemcpyAsync(centers, dc, (size_t)V * 24, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 // ---------------------------------------------------------------------------------------------
 // distance_utils row (include/mkamd_distance.h)
 // ---------------------------------------------------------------------------------------------
 static int upload(mkamd_ctx* ctx, int slot, const void* src, size_t bytes, void** dst)
-{
+try {
     int st = ctx->ensure(slot, bytes, dst, 0);
     if (st) return st;
     if (bytes) HIP_TRY(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     return 0;
-}
+} MK_API_CATCH
 
 int64_t mkamd_dist_count_pairs(int64_t n1, int64_t n2, int selfdist) { return count_pairs(n1, n2, selfdist); }
 
 int mkamd_dist_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t F, const float* d_box,
                               const uint32_t* d_sel1, int64_t n1, const uint32_t* d_sel2, int64_t n2,
                               const uint32_t* d_chains, int selfdist, int pbc, int squared, float* d_results)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     std::string err;
     st = run_dist_trajectory(*ctx, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_results, err);
     if (st && !err.empty()) return fail(st, err);
     return st;
-}
+} MK_API_CATCH
 
 int mkamd_dist_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t N, int64_t F, const float* box,
                                const uint32_t* sel1, int64_t n1, const uint32_t* sel2, int64_t n2,
                                const uint32_t* chains, int selfdist, int pbc, int squared, float* results)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (N < 0 || F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
@@ -681,14 +731,14 @@ int mkamd_dist_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t N, i
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t N, int64_t F, const float* box,
                               const int32_t* g1_atoms, const int64_t* g1_off, int64_t ng1, const int32_t* g2_atoms,
                               const int64_t* g2_off, int64_t ng2, const uint32_t* chains1, const uint32_t* chains2,
                               int selfdist, int pairs, int pbc, const float* masses, int reduction1, int reduction2,
                               float* results)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (N < 0 || F < 0 || ng1 < 0 || ng2 < 0) return fail(MKAMD_EINVAL, "negative size");
@@ -720,10 +770,10 @@ int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t N, in
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_cdist_host(mkamd_ctx* ctx, const float* c1, int64_t n1, const float* c2, int64_t n2, int32_t D, float* results)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (n1 < 0 || n2 < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
@@ -739,10 +789,10 @@ int mkamd_cdist_host(mkamd_ctx* ctx, const float* c1, int64_t n1, const float* c
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float* results)
-{
+try {
     int st = check_ctx(ctx);
     if (st) return st;
     if (n < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
@@ -757,7 +807,7 @@ int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)n * (n - 1) / 2 * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 }  // extern "C"
 
@@ -765,7 +815,7 @@ int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float
 // XTC decoding (host side, include/mkamd_xtc.h)
 // ---------------------------------------------------------------------------------------------
 extern "C" int mkamd_xtc_info(const char* path, int64_t* n_atoms, int64_t* n_frames)
-{
+try {
     if (!path || !n_atoms || !n_frames) return fail(MKAMD_EINVAL, "path/n_atoms/n_frames pointer is NULL");
     std::string err;
     int64_t na = 0, nf = 0;
@@ -773,11 +823,11 @@ extern "C" int mkamd_xtc_info(const char* path, int64_t* n_atoms, int64_t* n_fra
     if (st) return fail(MKAMD_EINVAL, err);
     *n_atoms = na; *n_frames = nf;
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 extern "C" int mkamd_xtc_read(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, float* coords, float* box,
                               float* time, int32_t* step, int32_t n_threads)
-{
+try {
     if (!path) return fail(MKAMD_EINVAL, "path is NULL");
     if (n_sel < 0 || n_atoms < 0) return fail(MKAMD_EINVAL, "n_sel and n_atoms must be >= 0");
     if (n_sel == 0) return MKAMD_OK;
@@ -786,7 +836,7 @@ extern "C" int mkamd_xtc_read(const char* path, const int64_t* frames, int64_t n
     const int st = mkamd::xtc::read(path, frames, n_sel, n_atoms, coords, box, time, step, (int)n_threads, err);
     if (st) return fail(MKAMD_EINVAL, err);
     return MKAMD_OK;
-}
+} MK_API_CATCH
 
 #ifdef MK_PHASE_TIMERS
 // profiling build only (tools/gpu_phase_timers.sh): read and clear the per-phase cycle sums of the tile kernel

@@ -12,9 +12,10 @@ Return order is the reference's: ``(features, centers)`` with ``usercenters`` el
 from the reference's float64), V flattened x slowest / z fastest, channel order ``_order``.
 
 Channels: pass ``userchannels`` (bool masks or float sigmas); without them the
-reference's own ``getChannels`` is used when moleculekit is importable, else the table-driven typing of
-``moleculekit_amd.channels`` (molecules that already carry PDBQT atom types).  Assigning atom types
-(OpenBabel) and SmallMol typing (RDKit) are outside this package.
+table-driven typing of ``moleculekit_amd.channels`` is used (molecules that already carry PDBQT atom types) --
+always, whatever else is installed; ``getChannels(..., backend="moleculekit")`` / ``CHANNELS_BACKEND`` delegate to
+an installed moleculekit explicitly.  Assigning atom types (OpenBabel) and SmallMol typing (RDKit) are outside
+this package.
 """
 from __future__ import annotations
 
@@ -98,20 +99,26 @@ def getCenters(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
     return _centersFromSpec(bb_min, nvoxels, voxelsize), nvoxels
 
 
-def getChannels(mol, aromaticNitrogen=False, version=2, validitychecks=True):
-    """Property channels of a molecule (voxeldescriptors.py:135-194): the reference's own implementation
-    when moleculekit is importable (it can re-type with OpenBabel / RDKit), else the table-driven typing
-    of ``moleculekit_amd.channels`` for molecules that already carry PDBQT atom types."""
-    try:
-        from moleculekit.tools.voxeldescriptors import getChannels as ref_getChannels
-    except Exception:  # depends on the user's environment
+CHANNELS_BACKEND = "table"   # what getVoxelDescriptors(mol) without `userchannels` uses; see getChannels
+
+
+def getChannels(mol, aromaticNitrogen=False, version=2, validitychecks=True, backend=None):
+    """Property channels of a molecule (voxeldescriptors.py:135-194).
+
+    ``backend="table"`` (the default, ``CHANNELS_BACKEND``): this package's table-driven typing
+    (``moleculekit_amd.channels``) for molecules that already carry PDBQT atom types -- the same code whatever
+    is installed next to it.  ``backend="moleculekit"``: delegate, explicitly, to an installed moleculekit
+    (which can re-type with OpenBabel / RDKit); raises ImportError when it is not importable."""
+    backend = CHANNELS_BACKEND if backend is None else backend
+    if backend == "table":
         from .channels import getChannels as table_getChannels
 
         return table_getChannels(mol, aromaticNitrogen, version, validitychecks)
-    return ref_getChannels(mol, aromaticNitrogen, version, validitychecks)
+    if backend == "moleculekit":
+        from moleculekit.tools.voxeldescriptors import getChannels as ref_getChannels
 
-
-_channels_from_moleculekit = getChannels
+        return ref_getChannels(mol, aromaticNitrogen, version, validitychecks)
+    raise ValueError(f"unknown channels backend {backend!r} (expected 'table' or 'moleculekit')")
 
 
 def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, usercenters=None,
@@ -125,7 +132,7 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
     """
     channels = userchannels
     if channels is None:
-        channels, mol = _channels_from_moleculekit(mol, aromaticNitrogen, version, validitychecks)
+        channels, mol = getChannels(mol, aromaticNitrogen, version, validitychecks)
     channels = np.asarray(channels)
 
     if channels.dtype == bool:   # bool masks -> per-channel sigma = vdW radius of the atom (:332-335)
@@ -231,10 +238,22 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
 def install():
     """Make an installed moleculekit use the MI355X kernels: swaps
     ``moleculekit.tools.voxeldescriptors._getOccupancyC`` (the sole caller of the Cython kernel,
-    voxeldescriptors.py:356) for this module's.  Returns the original function."""
+    voxeldescriptors.py:356) for this module's.  Returns the original function; ``uninstall()`` puts it back."""
     import moleculekit.tools.voxeldescriptors as ref
 
+    if getattr(ref, "_getOccupancyC_reference", None) is not None:      # already installed
+        return ref._getOccupancyC_reference
     original = ref._getOccupancyC
     ref._getOccupancyC = lambda coords, centers, channelsigmas: _getOccupancyC(coords, centers, channelsigmas)
     ref._getOccupancyC_reference = original
     return original
+
+
+def uninstall():
+    """Undo ``install()``."""
+    import moleculekit.tools.voxeldescriptors as ref
+
+    original = getattr(ref, "_getOccupancyC_reference", None)
+    if original is not None:
+        ref._getOccupancyC = original
+        ref._getOccupancyC_reference = None
