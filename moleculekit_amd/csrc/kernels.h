@@ -91,12 +91,17 @@ struct GridDesc {
     unsigned M;                 // capacity of the record arrays (= total atoms x img_cap)
     int img_cap;                // temp / record slots reserved per atom (1 unless periodic)
     int prepass_hurry;          // 1: binning / fill waves raise their issue priority (pipeline.h, run_lattice)
+    // exact cut-off decisions for wide sigmas (k_exact_fixup)
+    double res;                 // voxelsize
+    float w_exact_max;          // an entry with w below this has a value step > 5e-6 at the cutoff (sigma > 1.81 A)
 };
 
 // w of a present channel is clamped to a finite value (+inf is the "channel absent" marker): a
 // vanishing sigma then still yields 1 exactly on a voxel centre (d = 0) and 0 elsewhere, as
 // occupancy_utils.pyx:57-60 does.
 constexpr float MK_W_MAX = 3.0e38f;
+constexpr double CUTOFF2_A = 25.0;   // occupancy_utils.pyx:53, in A^2
+constexpr double CUTOFF_A_KERNEL = 5.0;
 
 enum { MK_ERR_RECORD_OVERFLOW = 1, MK_ERR_BAD_BOX = 2, MK_ERR_TOO_MANY_IMAGES = 4 };
 
@@ -1439,6 +1444,191 @@ MK_KERNEL(64) void k_voxelize_dense_tiles(GridDesc g, const unsigned* __restrict
         const unsigned e = dense_list[i];
         voxelize_tile<K, true, ECAP>(g, e % total_tiles, (int)(e / total_tiles), cell_start, rec_pos, nullptr, rec_cls, cls_table, out, nullptr, nullptr);
         mk_block_sync();                                                 // LDS arrays are reused by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact cut-off decisions.  occupancy_utils.pyx:53 tests d^2 < 25 in DOUBLE; the tile kernels test float32 distances
+// that carry ~3e-6 A^2 of error, so a pair within that of the cutoff can land on the wrong side.  What is then at stake is
+// the value AT the cutoff, 1 - exp(-(sigma^2/25)^6): below 5e-6 for sigma <= 1.81 A (every H C N O F P S Cl -- inside
+// the 1e-5 parity bound together with the 2-3e-6 of float32 noise), but 7.7e-5 for Na, 2e-3 for a user sigma of 3 A.
+// So for the WIDE sigmas only (w < g.w_exact_max) every (voxel, channel) with an atom on the cutoff shell is re-evaluated
+// after the tile kernels with the reference's own arithmetic in double:
+//   * driven by the atoms, not by the voxels: the hot kernels are untouched.  A wave looks at the summary the pre-pass
+//     already built for its 256 atoms (the block's sigma set) or its item (the item's class table): no wide sigma, the
+//     common case, and it is done;
+//   * a wide atom's shell is walked analytically: for every (x, y) voxel column within reach the two z where the sphere
+//     |v - atom| = 5 A crosses it, the voxels next to them tested in double against a band of +-2e-4 A^2 (60 x the float32
+//     error); 0.006 voxels per atom on average at 1 A, a few dozen when atoms and voxels share a lattice;
+//   * each hit is recomputed over ALL atoms of the item: centre = fl64(index * res) + bb_min
+//     (voxeldescriptors.py:125-132,245-247), d = float32 coordinate - centre (min-imaged for periodic items,
+//     distance_utils.pyx:49-52), strict d^2 < 25, x = sigma / sqrt(d^2), 1 - exp(-x^12), max over atoms
+//     (occupancy_utils.pyx:46-61), stored as float32.
+// ------------------------------------------------------------------------------------------------
+constexpr double EXACT_BAND_REL = 8e-6;      // band = R^2 x this (2e-4 A^2)
+
+// the occupancy of (voxel ix,iy,iz of item b, channel c) exactly as the reference computes it; all 64 lanes take part
+template <typename SigT>
+MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, int c, const float* __restrict__ coords,
+                            const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
+                            const double* __restrict__ origins, const float* __restrict__ box,
+                            const double* __restrict__ affine, float* __restrict__ out, double* s_best)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const double cx = mk_dadd_rn(mk_dmul_rn((double)ix, g.res), origins[3 * (size_t)b + 0]);
+    const double cy = mk_dadd_rn(mk_dmul_rn((double)iy, g.res), origins[3 * (size_t)b + 1]);
+    const double cz = mk_dadd_rn(mk_dmul_rn((double)iz, g.res), origins[3 * (size_t)b + 2]);
+    double L[3] = {1.0, 1.0, 1.0};
+    if (g.pbc) { L[0] = (double)box[3 * (size_t)b]; L[1] = (double)box[3 * (size_t)b + 1]; L[2] = (double)box[3 * (size_t)b + 2]; }
+    double best = 0.0;
+    for (long long a = atom_offsets[b] + lane; a < atom_offsets[b + 1]; a += WAVE) {
+        const double sg = (double)sigmas[(size_t)a * g.C + c];
+        if (!(sg != 0.0) || sg != sg) continue;                            // occupancy_utils.pyx:55-56 (a NaN is never stored)
+        float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
+        if (affine != nullptr) {                                           // rounded to float32 like the binning (bin_atom)
+            const double* A = affine + 12 * (size_t)b;
+            const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+            xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+            xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+            xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+        }
+        double dx = (double)xyz[0] - cx, dy = (double)xyz[1] - cy, dz = (double)xyz[2] - cz;
+        if (g.pbc) {
+            dx -= L[0] * round(dx / L[0]);
+            dy -= L[1] * round(dy / L[1]);
+            dz -= L[2] * round(dz / L[2]);
+        }
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        if (d2 < CUTOFF2_A) {
+            const double x = sg / sqrt(d2);
+            const double x3 = x * x * x;
+            const double val = 1.0 - exp(-(x3 * x3 * x3 * x3));
+            if (val > best) best = val;
+        }
+    }
+    s_best[lane] = best;
+    mk_block_sync();
+    if (lane == 0) {
+        double m = s_best[0];
+        for (int j = 1; j < WAVE; ++j) m = s_best[j] > m ? s_best[j] : m;
+        const size_t vox = (size_t)b * (size_t)g.V + ((size_t)ix * g.ny + iy) * g.nz + iz;
+        out[vox * (size_t)g.C + (size_t)c] = (float)m;
+    }
+    mk_block_sync();
+}
+
+// One wave per 256 atoms of the binning (per_item == 0: `summary` = the blocks' sigma sets, CLS_BLOCK_SET words each;
+// nullptr = no summary, look at every atom) or per item (per_item == 1: `summary` = the items' class tables).
+template <typename SigT>
+MK_KERNEL(64) void k_exact_fixup(GridDesc g, int per_item, const unsigned* __restrict__ summary,
+                                 const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
+                                 long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
+                                 const float* __restrict__ box, const double* __restrict__ affine,
+                                 const uint2* __restrict__ tmp_cls, float* __restrict__ out)
+{
+    __shared__ double s_best[WAVE];
+    const int lane = threadIdx.x;
+    const float wmax = g.w_exact_max;
+    auto wide_bits = [&](unsigned bits) { return bits != CLS_EMPTY && mk_uint_as_float(bits) < wmax; };   // NaN: false
+    // ---- the summary: is there anything wide among this wave's atoms at all? ----
+    long long a_lo, a_hi;
+    if (per_item) {
+        const int b = (int)blockIdx.x;
+        a_lo = atom_offsets[b]; a_hi = atom_offsets[b + 1];
+        if (summary != nullptr) {
+            const unsigned t = lane < CLS_TABLE_WORDS ? summary[(size_t)b * CLS_TABLE_WORDS + lane] : CLS_EMPTY;
+            const bool maybe = lane == CLS_OVERFLOW ? t != CLS_EMPTY : wide_bits(t);   // overflowed table: look at the atoms
+            if (mk_ballot(maybe) == 0ull) return;
+        }
+    } else {
+        a_lo = (long long)blockIdx.x * 256;
+        a_hi = a_lo + 256 < total_atoms ? a_lo + 256 : total_atoms;
+        if (summary != nullptr) {
+            const unsigned t = lane < CLS_BLOCK_SET ? summary[(size_t)blockIdx.x * CLS_BLOCK_SET + lane] : CLS_EMPTY;
+            if (mk_ballot(t == CLS_TOO_MANY || wide_bits(t)) == 0ull) return;
+        }
+    }
+    const double R = CUTOFF_A_KERNEL / g.res, R2 = R * R, band = R2 * EXACT_BAND_REL, Rb = sqrt(R2 + band);
+    const int nvox[3] = {g.nx, g.ny, g.nz};
+    int b_hint = per_item ? (int)blockIdx.x : item_of_atom(atom_offsets, g.B, a_lo, 0);
+    for (long long base = a_lo; base < a_hi; base += WAVE) {               // wave-uniform
+        const long long a_mine = base + lane;
+        bool wide = false;
+        if (a_mine < a_hi) {
+            for (int gq = 0; gq < g.G; ++gq) {
+                const uint2 cw = tmp_cls[(size_t)a_mine * g.G + gq];
+                if (cw.y == ATOM_MULTI_SIGMA) {
+                    for (int c = gq * CHG; c < g.C && c < gq * CHG + CHG; ++c)
+                        wide |= sigma_to_w(sigmas[(size_t)a_mine * g.C + c], g.w_scale) < wmax;
+                } else wide |= wide_bits(cw.x);
+            }
+        }
+        unsigned long long todo = mk_ballot(wide);
+        while (todo) {                                                     // wave-uniform: one wide atom at a time
+            const int l = mk_ctz64(todo);
+            todo &= todo - 1ull;
+            const long long a = base + l;
+            const int b = per_item ? (int)blockIdx.x : item_of_atom(atom_offsets, g.B, a, b_hint);
+            b_hint = b;
+            // position in voxel units, as the binning sees it
+            float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
+            if (affine != nullptr) {
+                const double* A = affine + 12 * (size_t)b;
+                const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+                xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+                xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+                xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+            }
+            double p[3], Lv[3] = {0.0, 0.0, 0.0};
+            int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
+            bool skip = false;
+            for (int ax = 0; ax < 3; ++ax) {
+                p[ax] = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+                if (g.pbc) {
+                    const double Lx = (double)box[3 * (size_t)b + ax] * g.inv_res;
+                    if (!(Lx > 2.0 * (g.Rp - 1e-3))) skip = true;          // bad box: the binning has raised the error flag
+                    Lv[ax] = Lx;
+                    const double i0 = ceil((-Rb - p[ax]) / Lx), i1 = floor(((double)(nvox[ax] - 1) + Rb - p[ax]) / Lx);
+                    if (!(i1 - i0 <= 64.0)) skip = true;
+                    k0[ax] = (int)i0; k1[ax] = (int)i1;
+                }
+                if (!(p[ax] == p[ax])) skip = true;                        // NaN coordinate
+            }
+            if (skip) continue;
+            for (int kx = k0[0]; kx <= k1[0]; ++kx)
+            for (int ky = k0[1]; ky <= k1[1]; ++ky)
+            for (int kz = k0[2]; kz <= k1[2]; ++kz) {                      // wave-uniform: the periodic images
+                const double qx = p[0] + kx * Lv[0], qy = p[1] + ky * Lv[1], qz = p[2] + kz * Lv[2];
+                const double fx0 = ceil(qx - Rb), fx1 = floor(qx + Rb), fy0 = ceil(qy - Rb), fy1 = floor(qy + Rb);
+                const int x_lo = fx0 > 0.0 ? (int)fx0 : 0, x_hi = fx1 < (double)(g.nx - 1) ? (int)fx1 : g.nx - 1;
+                const int y_lo = fy0 > 0.0 ? (int)fy0 : 0, y_hi = fy1 < (double)(g.ny - 1) ? (int)fy1 : g.ny - 1;
+                if (x_hi < x_lo || y_hi < y_lo) continue;
+                const int nyr = y_hi - y_lo + 1, ncol = (x_hi - x_lo + 1) * nyr;
+                for (int cb = 0; cb < ncol; cb += WAVE) {                  // wave-uniform: 64 voxel columns at a time
+                    const int col = cb + lane;
+                    const int ix = x_lo + (col < ncol ? col / nyr : 0), iy = y_lo + (col < ncol ? col % nyr : 0);
+                    const double dx = (double)ix - qx, dy = (double)iy - qy, r2 = R2 - dx * dx - dy * dy;
+                    const double zr = sqrt(r2 > 0.0 ? r2 : 0.0);
+                    const long long ia = (long long)floor(qz - zr + 0.5), ib = (long long)floor(qz + zr + 0.5);
+                    for (int s = 0; s < 6; ++s) {                          // the voxels next to the two crossings
+                        const long long iz = s < 3 ? ia - 1 + s : ib - 1 + (s - 3);
+                        const double dz = (double)iz - qz, d2 = dx * dx + dy * dy + dz * dz;
+                        const bool hit = col < ncol && r2 >= -band && iz >= 0 && iz < (long long)g.nz && (s < 3 || iz > ia + 1) &&
+                                         fabs(d2 - R2) <= band;
+                        unsigned long long hits = mk_ballot(hit);
+                        while (hits) {                                     // wave-uniform: rare
+                            const int hl = mk_ctz64(hits);
+                            hits &= hits - 1ull;
+                            const int vx = (int)mk_readlane((unsigned)ix, hl), vy = (int)mk_readlane((unsigned)iy, hl);
+                            const int vz = (int)mk_readlane((unsigned)(int)iz, hl);
+                            for (int c = 0; c < g.C; ++c)                  // the atom's wide channels
+                                if (sigma_to_w(sigmas[(size_t)a * g.C + c], g.w_scale) < wmax)
+                                    exact_recompute<SigT>(g, b, vx, vy, vz, c, coords, atom_offsets, sigmas, origins, box, affine, out, s_best);
+                        }
+                    }
+                }
+            }
+        }
     }
 }
 

@@ -83,6 +83,9 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     const double R = CUTOFF_A / P.voxelsize;                 // cutoff in voxel units
     g.R2 = (float)(R * R);
     g.R2cull = (float)(R * R * 1.0002 + 1e-3);
+    g.res = P.voxelsize;
+    // value step at the cutoff = 1-exp(-(1/(R2 w))^6) > 5e-6  <=>  R2 w < (5e-6)^(-1/6) = 7.647  (sigma > 1.81 A)
+    g.w_exact_max = (float)(7.647 / (R * R));
     g.Rp = R + 1e-3;
     g.rint = (int)std::ceil(R);
     if (g.rint > 512) { err = "voxelsize too small (cutoff spans > 512 voxels)"; return ST_EINVAL; }
@@ -247,7 +250,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
     if ((st = be.ensure(WS_TMP_CLS, (size_t)(P.total_atoms > 0 ? P.total_atoms : 1) * g.G * sizeof(uint2), &tcls, set))) return st;
 
+    const unsigned* fix_summary = nullptr;         // what k_exact_fixup looks at first (see there)
+    unsigned fix_waves = 0;
     if (per_item) {
+        fix_summary = g.force_general ? nullptr : (const unsigned*)ctab;
+        fix_waves = (unsigned)g.B;
         unsigned* dwords = (unsigned*)count + ncells;
         auto go = [&](auto kern) {
             // few items: big blocks (latency of the one item matters); many items: small blocks (they fill the chip)
@@ -270,6 +277,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         void *bsets = nullptr, *l1sets = nullptr;
         if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nblk * CLS_BLOCK_SET * sizeof(unsigned), &bsets, set))) return st;
         if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
+        fix_summary = g.force_general ? nullptr : (const unsigned*)bsets;
+        fix_waves = P.total_atoms > 0 ? nblk : 0u;
         if (P.total_atoms > 0) {
             auto bin = [&](auto kern, auto* sig) {
                 return be.launch(kern, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine,
@@ -316,6 +325,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     be.hot_begin();
     st = g.K == 8 ? launch_tiles<8>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
                   : launch_tiles<4>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
+    if (!st && fix_waves != 0u) {
+        // exact cut-off decisions for wide sigmas (the waves whose atoms have none -- normally all -- leave at once)
+        st = P.sigmas_f64 ? be.launch(k_exact_fixup<double>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,
+                                      P.total_atoms, (const double*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out)
+                          : be.launch(k_exact_fixup<float>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,
+                                      P.total_atoms, (const float*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out);
+    }
     be.hot_end();
     be.note_error_flag_mirrored(!st && !g.force_general && be.feedback_dev() != nullptr);
     be.tile_done(set);

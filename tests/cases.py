@@ -204,6 +204,72 @@ def case_cutoff_exact(vs):
     return case
 
 
+def _place_on_shell(rng, centre, delta_d2):
+    """A float32 position whose squared distance to `centre` (double) is 25 + delta_d2 A^2 to within ~1e-9: a point on
+    the 5 A sphere whose direction has one SMALL component (so that one float32 ulp along that axis moves d^2 by only
+    ~1e-8), then an exhaustive search over the nearby float32 lattice points."""
+    centre = np.asarray(centre, np.float64)
+    k = int(rng.integers(0, 3))
+    u = rng.normal(size=3)
+    u[k] = 0.0
+    u *= np.sqrt(1.0 - 0.003 ** 2) / np.linalg.norm(u)
+    u[k] = 0.003 * rng.choice([-1.0, 1.0])
+    base = (centre + np.sqrt(25.0 + delta_d2) * u).astype(np.float32)
+    ulp = np.maximum(np.spacing(np.abs(base)).astype(np.float64), 1.2e-7)   # (a coordinate near 0 has tiny ulps: step coarser)
+    steps = [np.arange(-3, 4), np.arange(-3, 4), np.arange(-3, 4)]
+    steps[k] = np.arange(-3000, 3001)
+    g = np.stack(np.meshgrid(*steps, indexing="ij"), axis=-1).reshape(-1, 3)
+    cand = (base.astype(np.float64)[None, :] + g * ulp[None, :]).astype(np.float32)
+    d = cand.astype(np.float64) - centre[None, :]
+    err = np.abs((d * d).sum(axis=1) - 25.0 - delta_d2)
+    i = int(err.argmin())
+    return cand[i].copy(), float(err[i])
+
+
+def case_cutoff_adversarial(vs, periodic=False):
+    """The cut-off decision where float32 cannot make it: atoms with WIDE sigmas (Na 2.27 A, K 2.75 A, a user 3.0 A:
+    the value at the cutoff is 7.7e-5 .. 2.2e-3 against the tolerance of 1e-5) placed so that one voxel centre of a
+    NON-dyadic grid sits at d^2 = 25 + {0, +-1e-6, +-1e-5, +-1e-4} A^2 (d = 5 A +- 0, 1e-7, 1e-6, 1e-5) in double, the
+    reference's arithmetic (occupancy_utils.pyx:53).  One item per (sigma, offset); every item also holds ordinary atoms
+    in the same channel, so the exact re-evaluation has to see all of them.  `periodic`: the same through a box whose
+    image, not the atom itself, carries the borderline distance."""
+    rng = np.random.default_rng(77 + int(vs * 100) + (1000 if periodic else 0))
+    n = int(round(16 / vs)) + 1
+    origin = np.array([-8.13, -7.91, -8.37])
+    coords, sig, offs, targets = [], [], [0], []
+    for sigma in (2.27, 2.75, 3.0):
+        for delta in (0.0, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4):
+            iv = rng.integers(n // 2 - 2, n // 2 + 3, size=3)
+            centre = oracle.grid_centers(origin, [n, n, n], vs).reshape(n, n, n, 3)[iv[0], iv[1], iv[2]]
+            pos, err = _place_on_shell(rng, centre, delta)
+            assert err < 5e-8, err
+            others = (centre[None, :] + rng.normal(0, 1.0, size=(6, 3)) * 6.0).astype(np.float32)
+            others = others[np.linalg.norm(others.astype(np.float64) - centre, axis=1) > 5.5]   # the target sees only the wide atom
+            c = np.concatenate([pos[None, :], others])
+            s = np.zeros((len(c), 8))
+            s[0, 7] = sigma
+            s[0, 2] = sigma
+            s[1:, 7] = 1.7
+            s[1:, 0] = 1.52
+            if periodic:
+                c[0] += np.array([20.0, -20.0, 40.0], np.float32) * 1.0      # only its image is in range
+            coords.append(c); sig.append(s); offs.append(offs[-1] + len(c))
+            targets.append(tuple(int(v) for v in iv))
+    B = len(offs) - 1
+    box = np.tile(np.array([[20.0, 20.0, 20.0]], np.float32), (B, 1)) if periodic else None
+    case = _case(np.concatenate(coords), offs, np.concatenate(sig), np.tile(origin, (B, 1)), [n, n, n], vs, box=box)
+    # the construction really straddles the cutoff: target voxels of the "inside" items are non-zero, "outside" ones zero
+    exp = case["expected"].reshape(B, n, n, n, 8)
+    k = 0
+    for sigma in (2.27, 2.75, 3.0):
+        for delta in (0.0, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4):
+            v = exp[k][targets[k]][2]
+            if not periodic and delta != 0.0:       # (delta = 0 lands within 1e-10 of the cutoff, on either side)
+                assert (v > 5e-5) == (delta < 0), (sigma, delta, v)
+            k += 1
+    return case
+
+
 def case_channels(C):
     """Channel counts other than 8 (channel groups: 1 -> padded group, 11 -> two groups)."""
     rng = np.random.default_rng(24 + C)
@@ -279,6 +345,9 @@ LATTICE_CASES = {
     "voxel15": case_voxel15,
     "cutoff_exact_1A": lambda: case_cutoff_exact(1.0),
     "cutoff_exact_05A": lambda: case_cutoff_exact(0.5),
+    "cutoff_adversarial_1A": lambda: case_cutoff_adversarial(1.0),
+    "cutoff_adversarial_07A": lambda: case_cutoff_adversarial(0.7),
+    "cutoff_adversarial_pbc": lambda: case_cutoff_adversarial(1.0, periodic=True),
     "channels1": lambda: case_channels(1),
     "channels3": lambda: case_channels(3),
     "channels11": lambda: case_channels(11),
