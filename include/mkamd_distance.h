@@ -3,10 +3,11 @@
  *
  * GPU replacements for moleculekit/distance_utils/distance_utils.pyx:
  *   dist_trajectory                  :126-155     -> mkamd_dist_trajectory_host
- *   contacts_trajectory              :59-93       -> mkamd_dist_trajectory_host(squared = 1) + threshold on the host
+ *   contacts_trajectory              :59-93  }    -> mkamd_contacts_trajectory_host (thresholded and compacted on the GPU,
+ *   get_collisions                   :98-121 }       the reference's (frame, i, j) order; no [frames x pairs] matrix anywhere)
  *   dist_trajectory_reduction        :211-281 }   -> mkamd_dist_reduction_host (pairs = 0 / 1)
  *   dist_trajectory_reduction_pairs  :286-350 }
- *   cdist / get_collisions           :355-383, :98-121 -> mkamd_cdist_host
+ *   cdist                            :355-383     -> mkamd_cdist_host
  *   pdist                            :388-416     -> mkamd_pdist_host
  * All float32, BIT-EXACT with the reference (same operation order, one rounding per operation).
  *
@@ -38,6 +39,19 @@ int mkamd_dist_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t n_f
                               const uint32_t* d_sel1, int64_t n1, const uint32_t* d_sel2, int64_t n2,
                               const uint32_t* d_digitized_chains, int selfdist, int pbc, int squared,
                               float* d_results);
+
+/* contacts_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, dist_threshold): per frame the atom
+ * pairs (a, b) = (sel1[i], sel2[j]) with dist2 <= threshold^2 (float32 compare, distance_utils.pyx:73,82), in the
+ * reference's (i, j) loop order.  Counted, prefix-summed and written on the device, chunk of frames by chunk of frames
+ * (memory stays bounded whatever n_frames x n_pairs is).
+ *   frame_offsets int64 [n_frames + 1] (out): frame f owns pairs [frame_offsets[f], frame_offsets[f+1])
+ *   *pairs (out): 2 * frame_offsets[n_frames] uint32 (a0, b0, a1, b1, ...) in memory OWNED BY THE CONTEXT, valid until
+ *   the next contacts call on it (NULL when there is no contact).
+ * get_collisions (:98-121) is the one-frame, non-periodic case on the concatenation of the two coordinate sets. */
+int mkamd_contacts_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t n_atoms, int64_t n_frames,
+                                   const float* box, const uint32_t* sel1, int64_t n1, const uint32_t* sel2,
+                                   int64_t n2, const uint32_t* digitized_chains, int selfdist, int pbc,
+                                   float dist_threshold, int64_t* frame_offsets, const uint32_t** pairs);
 
 /* dist_trajectory_reduction / dist_trajectory_reduction_pairs.  The reference's vector<vector<int>> groups
  * are passed as CSR: atoms int32 [sum of group sizes], offsets int64 [n_groups + 1].  reduction: 0 closest,

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mkamd_dist_trajectory_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int,
                                             _c_int, _vp]),
     "mkamd_dist_trajectory_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int, _c_int, _vp]),
+    "mkamd_contacts_trajectory_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int,
+                                                ctypes.c_float, _vp, ctypes.POINTER(_vp)]),
     "mkamd_dist_reduction_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _vp,
                                            _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp]),
     "mkamd_cdist_host": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _c_i32, _vp]),
@@ -234,6 +236,20 @@ class Context:
     def dist_trajectory_dev(self, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_out):
         _check(load().mkamd_dist_trajectory_dev(self._h, _ptr(d_coords), F, _ptr(d_box), _ptr(d_sel1), n1, _ptr(d_sel2), n2,
                                                 _ptr(d_chains), int(selfdist), int(pbc), int(squared), _ptr(d_out)))
+
+    def contacts_trajectory_host(self, coords, box, sel1, sel2, chains, selfdist, pbc, threshold):
+        """-> (frame_offsets int64 [F+1], pairs uint32 [n_contacts, 2]) -- thresholded and compacted on the GPU."""
+        N, _, F = coords.shape
+        offs = np.zeros(F + 1, dtype=np.int64)
+        ptr = _vp(None)
+        _check(load().mkamd_contacts_trajectory_host(self._h, _ptr(coords), N, F, _ptr(box), _ptr(sel1), sel1.shape[0], _ptr(sel2),
+                                                     sel2.shape[0], _ptr(chains), int(selfdist), int(pbc), float(threshold),
+                                                     _ptr(offs), ctypes.byref(ptr)))
+        n = int(offs[-1])
+        if n == 0 or not ptr.value:
+            return offs, np.zeros((0, 2), dtype=np.uint32)
+        buf = (ctypes.c_uint32 * (2 * n)).from_address(ptr.value)          # context-owned: copy before the next call
+        return offs, np.frombuffer(buf, dtype=np.uint32).reshape(n, 2).copy()
 
     def dist_reduction_host(self, coords, box, g1a, g1o, g2a, g2o, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out):
         N, _, F = coords.shape

@@ -76,6 +76,7 @@ struct mkamd_ctx {
     void* stage_host = nullptr;            // pinned staging for the inputs of small _host calls (one H2D copy)
     void* stage_host_dev = nullptr;        // device-side address of the same memory (mapped): tiny inputs are read in place
     size_t stage_cap = 0;
+    std::vector<uint32_t> contacts_host;   // result of the last mkamd_contacts_trajectory_host call (owned here)
     void* out_host = nullptr;              // pinned, device-mapped result buffer of small _host calls (no D2H copy)
     void* out_host_dev = nullptr;          // its device-side address
     // tile-kernel timing
@@ -730,6 +731,74 @@ try {
     if (st) return st;
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+} MK_API_CATCH
+
+// contacts_trajectory / get_collisions on the device (dist_kernels.h: count -> scan -> fill per chunk of frames)
+int mkamd_contacts_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t N, int64_t F, const float* box,
+                                   const uint32_t* sel1, int64_t n1, const uint32_t* sel2, int64_t n2,
+                                   const uint32_t* chains, int selfdist, int pbc, float dist_threshold,
+                                   int64_t* frame_offsets, const uint32_t** pairs)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (N < 0 || F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (!frame_offsets || !pairs) return fail(MKAMD_EINVAL, "frame_offsets/pairs pointer is NULL");
+    ctx->contacts_host.clear();
+    *pairs = nullptr;
+    for (int64_t f = 0; f <= F; ++f) frame_offsets[f] = 0;
+    const int64_t P = count_pairs(n1, n2, selfdist);
+    if (F == 0 || P == 0) return MKAMD_OK;
+    if (P >= 0xffffffffLL) return fail(MKAMD_EINVAL, "too many atom pairs (>= 2^32); split the selections");
+    if (!coords || !box || !sel1 || !sel2 || !chains) return fail(MKAMD_EINVAL, "NULL pointer");
+    for (int64_t i = 0; i < n1; ++i) if (sel1[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel1 index out of range");
+    for (int64_t i = 0; i < n2; ++i) if (sel2[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel2 index out of range");
+    void *dc, *db, *d1, *d2, *dch, *pa, *pb, *wr, *cnt, *tot, *base, *dout = nullptr;
+    if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+    if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
+    if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
+    if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
+    if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
+    if ((st = ctx->ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
+    if ((st = ctx->ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
+    if ((st = ctx->ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
+    if ((st = ctx->launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256),
+                          (const unsigned*)d1, (long long)n1, (const unsigned*)d2, (long long)n2, (const unsigned*)dch, selfdist, pbc,
+                          (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
+    // frames per chunk: the per-(tile, frame) counters stay within ~256 MiB whatever the number of pairs
+    const long long tiles = ceil_div(P, DT);
+    long long chunk = ((long long)(256u << 20) / (tiles * 4)) / DT * DT;
+    chunk = std::max<long long>(DT, std::min<long long>(chunk, ((long long)F + DT - 1) / DT * DT));
+    chunk = std::min<long long>(chunk, 65535LL * DT);
+    const float thr2 = dist_threshold * dist_threshold;              // `float dist_threshold` squared in float (:73)
+    if ((st = ctx->ensure(WS_D_CNT, (size_t)tiles * chunk * 4, &cnt, 0))) return st;
+    if ((st = ctx->ensure(WS_D_TOT, (size_t)chunk * 8, &tot, 0))) return st;
+    if ((st = ctx->ensure(WS_D_BASE, (size_t)chunk * 8, &base, 0))) return st;
+    std::vector<unsigned long long> totals((size_t)chunk), bases((size_t)chunk);
+    for (long long f0 = 0; f0 < F; f0 += chunk) {
+        const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
+        const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
+        if ((st = ctx->launch(k_contacts_count, grid, dim3(DT_THREADS), (const float*)dc, (long long)F, f0, fc, fc_pad, (const float*)db,
+                              (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, (long long)P, thr2, (unsigned*)cnt))) return st;
+        if ((st = ctx->launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(DT_THREADS), (unsigned*)cnt, tiles, fc_pad,
+                              (unsigned long long*)tot))) return st;
+        HIP_TRY(hipMemcpyAsync(totals.data(), tot, (size_t)fc_pad * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long run = 0;
+        for (long long i = 0; i < fc_pad; ++i) { bases[(size_t)i] = run; run += i < fc ? totals[(size_t)i] : 0ull; }
+        for (long long i = 0; i < fc; ++i) frame_offsets[f0 + i + 1] = frame_offsets[f0 + i] + (int64_t)totals[(size_t)i];
+        if (run == 0) continue;
+        if ((st = ctx->ensure(WS_H_OUT, (size_t)run * 8, &dout, 0))) return st;
+        HIP_TRY(hipMemcpyAsync(base, bases.data(), (size_t)fc_pad * 8, hipMemcpyHostToDevice, ctx->stream));
+        if ((st = ctx->launch(k_contacts_fill, grid, dim3(DT_THREADS), (const float*)dc, (long long)F, f0, fc, fc_pad, (const float*)db,
+                              (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, (long long)P, thr2, (const unsigned*)cnt,
+                              (const unsigned long long*)base, (uint2*)dout))) return st;
+        const size_t old = ctx->contacts_host.size();
+        ctx->contacts_host.resize(old + (size_t)run * 2);
+        HIP_TRY(hipMemcpyAsync(ctx->contacts_host.data() + old, dout, (size_t)run * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    *pairs = ctx->contacts_host.data();
     return MKAMD_OK;
 } MK_API_CATCH
 

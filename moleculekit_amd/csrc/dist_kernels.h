@@ -68,20 +68,21 @@ MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long l
                                        unsigned* __restrict__ wrap)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long i = blockIdx.y;
-    if (i >= n1 || j >= n2) return;
-    long long idx;
-    if (selfdist) {
-        if (j <= i) return;
-        // rows 0..i-1 hold max(n2-1-k, 0) entries each
-        const long long full = i < n2 ? i : n2;                     // rows with a positive count
-        idx = full * (n2 - 1) - full * (full - 1) / 2 + (j - i - 1);
-    } else {
-        idx = i * n2 + j;
+    if (j >= n2) return;
+    for (long long i = blockIdx.y; i < n1; i += gridDim.y) {        // rows beyond the 65535 y-blocks: grid stride
+        long long idx;
+        if (selfdist) {
+            if (j <= i) continue;
+            // rows 0..i-1 hold max(n2-1-k, 0) entries each
+            const long long full = i < n2 ? i : n2;                 // rows with a positive count
+            idx = full * (n2 - 1) - full * (full - 1) / 2 + (j - i - 1);
+        } else {
+            idx = i * n2 + j;
+        }
+        const unsigned a = sel1[i], b = sel2[j];
+        pa[idx] = a; pb[idx] = b;
+        wrap[idx] = (pbc && chains[a] != chains[b]) ? 1u : 0u;
     }
-    const unsigned a = sel1[i], b = sel2[j];
-    pa[idx] = a; pb[idx] = b;
-    wrap[idx] = (pbc && chains[a] != chains[b]) ? 1u : 0u;
 }
 
 // dist_trajectory (distance_utils.pyx:126-155): results[f, p] = sqrt(_dist(...)) (or the square).
@@ -130,6 +131,115 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// contacts_trajectory / get_collisions (distance_utils.pyx:59-93, :98-121) entirely on the device: the reference
+// appends (a, b) inside its (frame, i, j) loops whenever dist2 <= threshold^2 (float32); here the same pairs come out
+// in the same order without ever materialising the [frames x pairs] distance matrix:
+//   k_contacts_count : the 64-frame x 64-pair tiles of k_dist_pairs; every lane (= frame) tests its wave's 16
+//                      consecutive pairs and the block stores ONE count per (tile, frame)
+//   k_contacts_scan  : per frame, exclusive prefix of the counts over the pair tiles (+ the frame's total)
+//   k_contacts_fill  : the same tiles again; a lane keeps its 16 hits as a bit mask, ranks them behind the tile's
+//                      prefix and the lower waves of its block, and writes (a, b) at frame_base + rank: (i, j) order
+// Frames are processed in chunks (host loop, capi.hip) so that the counters stay within a fixed memory budget.
+// ------------------------------------------------------------------------------------------------
+constexpr int CT_RUN = DT / (DT_THREADS / DT);        // consecutive pairs per wave of a tile (16)
+
+// bit k set: pair (p_first + k) of frame f is a contact.  Same traversal as k_dist_pairs (first atom cached).
+MK_DEV unsigned contact_mask(const float* __restrict__ coords, long long F, long long f, bool fin, float bx, float by, float bz,
+                             const unsigned* __restrict__ pa, const unsigned* __restrict__ pb,
+                             const unsigned* __restrict__ wrap, long long P, long long p_first, float thr2)
+{
+    unsigned mask = 0u, cur_a = 0xffffffffu;
+    float xa = 0.f, ya = 0.f, za = 0.f;
+    for (int k = 0; k < CT_RUN; ++k) {
+        const long long p = p_first + k;
+        if (p >= P) break;                                         // wave-uniform
+        const unsigned a = pa[p], b = pb[p];
+        if (a != cur_a) {                                          // wave-uniform
+            cur_a = a;
+            if (fin) { xa = coords[((size_t)a * 3 + 0) * F + f]; ya = coords[((size_t)a * 3 + 1) * F + f]; za = coords[((size_t)a * 3 + 2) * F + f]; }
+        }
+        if (fin) {
+            const float d2 = dist2_min_image_f32(xa, ya, za, coords[((size_t)b * 3 + 0) * F + f], coords[((size_t)b * 3 + 1) * F + f],
+                                                 coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, wrap[p] != 0u);
+            mask |= (d2 <= thr2) ? (1u << k) : 0u;                 // distance_utils.pyx:82 / :111 (NaN: no contact)
+        }
+    }
+    return mask;
+}
+
+// blockIdx.x = pair tile, blockIdx.y = 64-frame slab of the chunk [f_begin, f_begin + fc); cnt is [tiles][fc_pad]
+MK_KERNEL(DT_THREADS) void k_contacts_count(const float* __restrict__ coords, long long F, long long f_begin, long long fc,
+                                            long long fc_pad, const float* __restrict__ box, const unsigned* __restrict__ pa,
+                                            const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap, long long P,
+                                            float thr2, unsigned* __restrict__ cnt)
+{
+    __shared__ unsigned s_c[DT_THREADS / DT][DT];
+    const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
+    const long long lf = (long long)blockIdx.y * DT + fl, f = f_begin + lf;
+    const bool fin = lf < fc;
+    const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
+    const unsigned m = contact_mask(coords, F, f, fin, bx, by, bz, pa, pb, wrap, P, (long long)blockIdx.x * DT + pq * CT_RUN, thr2);
+    s_c[pq][fl] = (unsigned)__builtin_popcount(m);
+    mk_block_sync();
+    if (pq == 0) {
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < DT_THREADS / DT; ++w) t += s_c[w][fl];
+        cnt[(size_t)blockIdx.x * fc_pad + lf] = t;                 // padded frames count 0
+    }
+}
+
+// one block per 64-frame slab: lanes = frames, the 4 waves split the tile range; in-place exclusive prefix over the
+// tiles of every frame, totals[frame] = its number of contacts
+MK_KERNEL(DT_THREADS) void k_contacts_scan(unsigned* __restrict__ cnt, long long tiles, long long fc_pad,
+                                           unsigned long long* __restrict__ totals)
+{
+    __shared__ unsigned long long s_seg[DT_THREADS / DT][DT];
+    const int fl = threadIdx.x & (DT - 1), w = threadIdx.x >> 6;
+    constexpr int NW = DT_THREADS / DT;
+    const long long lf = (long long)blockIdx.x * DT + fl;
+    const long long per = (tiles + NW - 1) / NW, t0 = w * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    unsigned long long sum = 0;
+    for (long long t = t0; t < t1; ++t) sum += cnt[(size_t)t * fc_pad + lf];
+    s_seg[w][fl] = sum;
+    mk_block_sync();
+    unsigned long long run = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { if (i < w) run += s_seg[i][fl]; total += s_seg[i][fl]; }
+    for (long long t = t0; t < t1; ++t) {
+        const unsigned c = cnt[(size_t)t * fc_pad + lf];
+        cnt[(size_t)t * fc_pad + lf] = (unsigned)run;              // per-frame prefix: < 2^32 pairs per frame (host checks P)
+        run += c;
+    }
+    if (w == 0) totals[lf] = total;
+}
+
+MK_KERNEL(DT_THREADS) void k_contacts_fill(const float* __restrict__ coords, long long F, long long f_begin, long long fc,
+                                           long long fc_pad, const float* __restrict__ box, const unsigned* __restrict__ pa,
+                                           const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap, long long P,
+                                           float thr2, const unsigned* __restrict__ prefix,
+                                           const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
+{
+    __shared__ unsigned s_c[DT_THREADS / DT][DT];
+    const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
+    const long long lf = (long long)blockIdx.y * DT + fl, f = f_begin + lf;
+    const bool fin = lf < fc;
+    const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
+    const long long p_first = (long long)blockIdx.x * DT + pq * CT_RUN;
+    unsigned m = contact_mask(coords, F, f, fin, bx, by, bz, pa, pb, wrap, P, p_first, thr2);
+    s_c[pq][fl] = (unsigned)__builtin_popcount(m);
+    mk_block_sync();
+    if (!fin || m == 0u) return;
+    unsigned long long pos = frame_base[lf] + prefix[(size_t)blockIdx.x * fc_pad + lf];
+    for (int w = 0; w < pq; ++w) pos += s_c[w][fl];
+    while (m) {                                                    // ascending pair index = the reference's (i, j) order
+        const int k = __builtin_ctz(m);
+        m &= m - 1u;
+        out[pos++] = make_uint2(pa[p_first + k], pb[p_first + k]);
+    }
+}
+
 // Centre of mass of every group in every frame (distance_utils.pyx:160-183): sequential float32
 // accumulation in group order.  com has the coords layout [n_groups, 3, F]; lanes along frames.
 MK_KERNEL(256) void k_group_com(const float* __restrict__ coords, long long F,
@@ -137,20 +247,21 @@ MK_KERNEL(256) void k_group_com(const float* __restrict__ coords, long long F,
                                 long long ng, const float* __restrict__ masses, float* __restrict__ com)
 {
     const long long f = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long g = blockIdx.y;
-    if (f >= F || g >= ng) return;
-    float total = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-    for (long long k = g_off[g]; k < g_off[g + 1]; ++k) {
-        const size_t a = (size_t)g_atoms[k];
-        const float m = masses[a];
-        cx = mk_fadd_rn(cx, mk_fmul_rn(coords[(a * 3 + 0) * F + f], m));
-        cy = mk_fadd_rn(cy, mk_fmul_rn(coords[(a * 3 + 1) * F + f], m));
-        cz = mk_fadd_rn(cz, mk_fmul_rn(coords[(a * 3 + 2) * F + f], m));
-        total = mk_fadd_rn(total, m);
+    if (f >= F) return;
+    for (long long g = blockIdx.y; g < ng; g += gridDim.y) {        // grid stride over the groups
+        float total = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
+        for (long long k = g_off[g]; k < g_off[g + 1]; ++k) {
+            const size_t a = (size_t)g_atoms[k];
+            const float m = masses[a];
+            cx = mk_fadd_rn(cx, mk_fmul_rn(coords[(a * 3 + 0) * F + f], m));
+            cy = mk_fadd_rn(cy, mk_fmul_rn(coords[(a * 3 + 1) * F + f], m));
+            cz = mk_fadd_rn(cz, mk_fmul_rn(coords[(a * 3 + 2) * F + f], m));
+            total = mk_fadd_rn(total, m);
+        }
+        com[((size_t)g * 3 + 0) * F + f] = mk_fdiv_rn(cx, total);
+        com[((size_t)g * 3 + 1) * F + f] = mk_fdiv_rn(cy, total);
+        com[((size_t)g * 3 + 2) * F + f] = mk_fdiv_rn(cz, total);
     }
-    com[((size_t)g * 3 + 0) * F + f] = mk_fdiv_rn(cx, total);
-    com[((size_t)g * 3 + 1) * F + f] = mk_fdiv_rn(cy, total);
-    com[((size_t)g * 3 + 2) * F + f] = mk_fdiv_rn(cz, total);
 }
 
 // Group-pair table of dist_trajectory_reduction (:240-281) / _pairs (:312-350).
@@ -160,21 +271,22 @@ MK_KERNEL(256) void k_build_group_pairs(long long ng1, long long ng2, const unsi
                                         unsigned* __restrict__ wrap)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long i = blockIdx.y;
-    if (i >= ng1 || j >= ng2) return;
-    long long idx;
-    if (pairs) {
-        if (j != i) return;
-        idx = i;
-    } else if (selfdist) {
-        if (j <= i) return;
-        const long long full = i < ng2 ? i : ng2;
-        idx = full * (ng2 - 1) - full * (full - 1) / 2 + (j - i - 1);
-    } else {
-        idx = i * ng2 + j;
+    if (j >= ng2) return;
+    for (long long i = blockIdx.y; i < ng1; i += gridDim.y) {       // grid stride over the first groups
+        long long idx;
+        if (pairs) {
+            if (j != i) continue;
+            idx = i;
+        } else if (selfdist) {
+            if (j <= i) continue;
+            const long long full = i < ng2 ? i : ng2;
+            idx = full * (ng2 - 1) - full * (full - 1) / 2 + (j - i - 1);
+        } else {
+            idx = i * ng2 + j;
+        }
+        ga[idx] = (unsigned)i; gb[idx] = (unsigned)j;
+        wrap[idx] = (pbc && chains1[i] != chains2[j]) ? 1u : 0u;
     }
-    ga[idx] = (unsigned)i; gb[idx] = (unsigned)j;
-    wrap[idx] = (pbc && chains1[i] != chains2[j]) ? 1u : 0u;
 }
 
 // dist_trajectory_reduction[_pairs]: per (frame, group pair) the minimum squared distance over the atom
@@ -215,28 +327,30 @@ MK_KERNEL(256) void k_cdist(const float* __restrict__ c1, long long n1, const fl
                             long long n2, int D, float* __restrict__ out)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long i = blockIdx.y;
-    if (i >= n1 || j >= n2) return;
-    float d2 = 0.f;
-    for (int k = 0; k < D; ++k) {
-        const float diff = mk_fsub_rn(c1[i * D + k], c2[j * D + k]);
-        d2 = mk_fadd_rn(d2, mk_fmul_rn(diff, diff));
+    if (j >= n2) return;
+    for (long long i = blockIdx.y; i < n1; i += gridDim.y) {        // grid stride over the rows
+        float d2 = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float diff = mk_fsub_rn(c1[i * D + k], c2[j * D + k]);
+            d2 = mk_fadd_rn(d2, mk_fmul_rn(diff, diff));
+        }
+        out[i * n2 + j] = mk_fsqrt_rn(d2);
     }
-    out[i * n2 + j] = mk_fsqrt_rn(d2);
 }
 
 // pdist (distance_utils.pyx:388-416): condensed upper triangle, row i holds n-1-i entries.
 MK_KERNEL(256) void k_pdist(const float* __restrict__ c, long long n, int D, float* __restrict__ out)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long i = blockIdx.y;
-    if (i >= n || j >= n || j <= i) return;
-    float d2 = 0.f;
-    for (int k = 0; k < D; ++k) {
-        const float diff = mk_fsub_rn(c[i * D + k], c[j * D + k]);
-        d2 = mk_fadd_rn(d2, mk_fmul_rn(diff, diff));
+    if (j >= n) return;
+    for (long long i = blockIdx.y; i < n && i < j; i += gridDim.y) { // grid stride over the rows (upper triangle: i < j)
+        float d2 = 0.f;
+        for (int k = 0; k < D; ++k) {
+            const float diff = mk_fsub_rn(c[i * D + k], c[j * D + k]);
+            d2 = mk_fadd_rn(d2, mk_fmul_rn(diff, diff));
+        }
+        out[i * (n - 1) - i * (i - 1) / 2 + (j - i - 1)] = mk_fsqrt_rn(d2);
     }
-    out[i * (n - 1) - i * (i - 1) / 2 + (j - i - 1)] = mk_fsqrt_rn(d2);
 }
 
 }  // namespace mkamd

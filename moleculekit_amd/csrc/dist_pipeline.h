@@ -28,7 +28,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
     if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
     if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
-    if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)n1), dim3(256), sel1, n1, sel2, n2,
+    if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
                         chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
     return be.launch(k_dist_pairs, dim3((unsigned)ceil_div(P, DT), (unsigned)ceil_div(F, DT)), dim3(DT_THREADS), coords, F, box,
                      (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
@@ -51,18 +51,18 @@ int run_dist_reduction(BE& be, const float* coords, long long F, const float* bo
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &ga, 0))) return st;
     if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &gb, 0))) return st;
     if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
-    if ((st = be.launch(k_build_group_pairs, dim3((unsigned)ceil_div(ng2, 256), (unsigned)ng1), dim3(256), ng1, ng2, chains1,
+    if ((st = be.launch(k_build_group_pairs, dim3((unsigned)ceil_div(ng2, 256), (unsigned)std::min<long long>(ng1, 65535)), dim3(256), ng1, ng2, chains1,
                         chains2, selfdist, pairs, pbc, (unsigned*)ga, (unsigned*)gb, (unsigned*)wr))) return st;
     const float *c1 = coords, *c2 = coords;
     if (reduction1 == 1) {
         if ((st = be.ensure(WS_D_COM1, (size_t)ng1 * 3 * F * 4, &com1, 0))) return st;
-        if ((st = be.launch(k_group_com, dim3((unsigned)ceil_div(F, 256), (unsigned)ng1), dim3(256), coords, F, g1_atoms, g1_off,
+        if ((st = be.launch(k_group_com, dim3((unsigned)ceil_div(F, 256), (unsigned)std::min<long long>(ng1, 65535)), dim3(256), coords, F, g1_atoms, g1_off,
                             ng1, masses, (float*)com1))) return st;
         c1 = (const float*)com1;
     }
     if (reduction2 == 1) {
         if ((st = be.ensure(WS_D_COM2, (size_t)ng2 * 3 * F * 4, &com2, 0))) return st;
-        if ((st = be.launch(k_group_com, dim3((unsigned)ceil_div(F, 256), (unsigned)ng2), dim3(256), coords, F, g2_atoms, g2_off,
+        if ((st = be.launch(k_group_com, dim3((unsigned)ceil_div(F, 256), (unsigned)std::min<long long>(ng2, 65535)), dim3(256), coords, F, g2_atoms, g2_off,
                             ng2, masses, (float*)com2))) return st;
         c2 = (const float*)com2;
     }
@@ -76,8 +76,7 @@ int run_cdist(BE& be, const float* c1, long long n1, const float* c2, long long 
 {
     if (n1 < 0 || n2 < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
     if (n1 == 0 || n2 == 0) return ST_OK;
-    if (n1 > 0x7fffffffLL) { err = "too many rows"; return ST_EINVAL; }
-    return be.launch(k_cdist, dim3((unsigned)ceil_div(n2, 256), (unsigned)n1), dim3(256), c1, n1, c2, n2, D, out);
+    return be.launch(k_cdist, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), c1, n1, c2, n2, D, out);
 }
 
 template <class BE>
@@ -85,7 +84,7 @@ int run_pdist(BE& be, const float* c, long long n, int D, float* out, std::strin
 {
     if (n < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
     if (n < 2) return ST_OK;
-    return be.launch(k_pdist, dim3((unsigned)ceil_div(n, 256), (unsigned)n), dim3(256), c, n, D, out);
+    return be.launch(k_pdist, dim3((unsigned)ceil_div(n, 256), (unsigned)std::min<long long>(n, 65535)), dim3(256), c, n, D, out);
 }
 
 }  // namespace mkamd

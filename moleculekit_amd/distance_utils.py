@@ -3,9 +3,9 @@
 Same names, argument order, dtypes and in-place ``results`` semantics as the reference's typed-memoryview
 functions; float32 results are BIT-EXACT with the reference (the kernels reproduce its float32 operation
 order with un-contracted round-to-nearest ops, see csrc/dist_kernels.h).  The all-pairs distance work runs
-in HIP kernels; the variable-length index lists of ``contacts_trajectory`` / ``get_collisions`` are
-extracted on the host from GPU-computed squared distances (``dist2 <= threshold^2`` in float32, as
-:82-90 and :111-120 do).
+in HIP kernels; the variable-length index lists of ``contacts_trajectory`` / ``get_collisions`` are thresholded
+(``dist2 <= threshold^2`` in float32, as :82-90 and :111-120 do) and compacted on the GPU as well, in the
+reference's loop order and in chunks of frames, so that no [frames x pairs] matrix ever exists on either side.
 """
 from __future__ import annotations
 
@@ -56,15 +56,6 @@ def dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, re
     _store(results, tmp)
 
 
-def _pair_atoms(sel1, sel2, selfdist):
-    n1, n2 = len(sel1), len(sel2)
-    if selfdist:
-        i, j = np.nonzero(np.arange(n2)[None, :] > np.arange(n1)[:, None])
-    else:
-        i, j = np.divmod(np.arange(n1 * n2), n2)
-    return sel1[i], sel2[j]
-
-
 def contacts_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, dist_threshold=5, ctx=None):
     """distance_utils.pyx:59-93: per frame the flat list ``[a0, b0, a1, b1, ...]`` of atom pairs with
     ``dist2 <= threshold^2`` (float32), in the reference's (i, j) loop order."""
@@ -73,36 +64,23 @@ def contacts_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc
     sel1 = _req("sel1", sel1, np.uint32, 1); sel2 = _req("sel2", sel2, np.uint32, 1)
     chains = _req("digitized_chains", digitized_chains, np.uint32, 1)
     ctx = ctx or _lib.default_context()
-    F = coords.shape[2]
-    npairs = int(_lib.load().mkamd_dist_count_pairs(len(sel1), len(sel2), int(bool(selfdist))))
-    d2 = np.zeros((F, npairs), dtype=np.float32)
-    ctx.dist_trajectory_host(coords, box, sel1, sel2, chains, bool(selfdist), bool(pbc), True, d2)
-    thr = np.float32(dist_threshold) * np.float32(dist_threshold)        # `float dist_threshold` squared in float
-    pa, pb = _pair_atoms(sel1, sel2, bool(selfdist))
-    out = []
-    for f in range(F):
-        hit = np.nonzero(d2[f] <= thr)[0]
-        flat = np.empty(2 * len(hit), dtype=np.int64)
-        flat[0::2] = pa[hit]; flat[1::2] = pb[hit]
-        out.append(flat.tolist())
-    return out
+    offs, pairs = ctx.contacts_trajectory_host(coords, box, sel1, sel2, chains, bool(selfdist), bool(pbc), dist_threshold)
+    flat = pairs.astype(np.int64).ravel()
+    return [flat[2 * offs[f]:2 * offs[f + 1]].tolist() for f in range(coords.shape[2])]
 
 
 def get_collisions(coords1, coords2, dist_threshold, ctx=None):
     """distance_utils.pyx:98-121: flat ``[i0, j0, i1, j1, ...]`` (row indices) with dist2 <= threshold^2."""
     c1 = _req("coords1", coords1, np.float32, 2); c2 = _req("coords2", coords2, np.float32, 2)
-    # squared distances in the reference's float32 order: reuse dist_trajectory on a one-frame pseudo trajectory
+    # the one-frame, non-periodic case of the contact kernels on the concatenation of the two sets
     n1, n2 = c1.shape[0], c2.shape[0]
     both = np.ascontiguousarray(np.concatenate([c1[:, :3], c2[:, :3]])[:, :, None])
     sel1 = np.arange(n1, dtype=np.uint32); sel2 = np.arange(n1, n1 + n2, dtype=np.uint32)
-    d2 = np.zeros((1, n1 * n2), dtype=np.float32)
-    (ctx or _lib.default_context()).dist_trajectory_host(both, np.zeros((3, 1), np.float32), sel1, sel2,
-                                                         np.zeros(n1 + n2, np.uint32), False, False, True, d2)
-    thr = np.float32(dist_threshold) * np.float32(dist_threshold)
-    hit = np.nonzero(d2[0] <= thr)[0]
-    flat = np.empty(2 * len(hit), dtype=np.int64)
-    flat[0::2], flat[1::2] = np.divmod(hit, n2)
-    return flat.tolist()
+    _, pairs = (ctx or _lib.default_context()).contacts_trajectory_host(
+        both, np.zeros((3, 1), np.float32), sel1, sel2, np.zeros(n1 + n2, np.uint32), False, False, dist_threshold)
+    flat = pairs.astype(np.int64)
+    flat[:, 1] -= n1
+    return flat.ravel().tolist()
 
 
 def _reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, results, ctx):

@@ -133,3 +133,41 @@ def test_image_shift_at_the_half_box_boundary_is_bit_exact():
     r = np.zeros((c.shape[2], len(s2)), np.float32)
     dist_trajectory(c, b, s1, s2, ch, False, True, r)
     assert np.array_equal(r, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
+
+
+def test_more_than_65535_rows_and_groups():
+    """Launch geometry: the row / group dimension is a grid-stride loop, not gridDim.y (capped at 65535).  cdist with
+    70 000 rows, dist_trajectory with a 70 000-atom first selection, contact lists over the same, centres of mass of
+    70 000 one-atom groups -- each against numpy / the oracle, bit for bit."""
+    from moleculekit_amd.distance_utils import cdist, contacts_trajectory, dist_trajectory, dist_trajectory_reduction
+    rng = np.random.default_rng(65)
+    n1, n2, F = 70000, 3, 2
+    xyz = rng.uniform(-20, 20, size=(n1 + n2, 3, F)).astype(np.float32)
+    box = np.full((3, F), 31.0, np.float32)
+    chains = (np.arange(n1 + n2) % 7).astype(np.uint32)
+    sel1, sel2 = np.arange(n1, dtype=np.uint32), np.arange(n1, n1 + n2, dtype=np.uint32)
+    # cdist: rows beyond 65535 are reached
+    a, b = np.ascontiguousarray(xyz[:n1, :, 0]), np.ascontiguousarray(xyz[n1:, :, 0])
+    got = np.zeros((n1, n2), np.float32)
+    cdist(a, b, got)
+    d = a[:, None, :] - b[None, :, :]
+    want = np.sqrt(((d[..., 0] * d[..., 0]) + (d[..., 1] * d[..., 1])) + (d[..., 2] * d[..., 2]))   # float32, the reference's order
+    assert np.array_equal(got, want.astype(np.float32))
+    # dist_trajectory + contacts on the same selections vs the oracle
+    got = np.zeros((F, n1 * n2), np.float32)
+    dist_trajectory(xyz, box, sel1, sel2, chains, False, True, got)
+    want = oracle.dist_trajectory(xyz, box, sel1, sel2, chains, False, True)
+    assert np.array_equal(got, want)
+    res = contacts_trajectory(xyz, box, sel1, sel2, chains, False, True, 6.0)
+    d2 = oracle.dist_trajectory(xyz, box, sel1, sel2, chains, False, True, squared=True)
+    thr = np.float32(6.0) * np.float32(6.0)
+    for f in range(F):
+        flat = np.asarray(res[f], np.int64).reshape(-1, 2)
+        assert flat[:, 0].max() > 65535
+        assert np.array_equal(flat[:, 0] * n2 + (flat[:, 1] - n1), np.nonzero(d2[f] <= thr)[0])   # same pairs, the (i, j) order
+    # 70 000 one-atom groups through the centre-of-mass reduction: com == the atom, distances == dist_trajectory
+    m = rng.uniform(1, 16, size=n1 + n2).astype(np.float32)
+    got = np.zeros((F, n1 * n2), np.float32)
+    dist_trajectory_reduction(xyz, box, [[i] for i in range(n1)], [[n1 + j] for j in range(n2)], chains[:n1].copy(),
+                              chains[n1:].copy(), False, True, np.ones_like(m), 1, 1, got)
+    assert np.array_equal(got, want)

@@ -149,6 +149,29 @@ def test_cfg2_full_size_against_reference_samples(hip_ctx):
         assert np.abs(got.max(0) - g["channel_max"]).max() <= TOL
 
 
+def test_cfg4_full_size_against_reference_samples(hip_ctx):
+    """BASELINE.json configs[3] at its REAL shape (30 000 atoms per frame, 66.9 A periodic box, 48^3 x 8): two frames in
+    one call; 16384 sampled voxels per frame + per-channel checksums of the real reference's 27-image composition
+    (tests/golden/cfg4_full_sampled.npz, made by tests/golden/make_golden_cfg4.py)."""
+    from moleculekit_amd import batch
+    g = golden("cfg4_full_sampled.npz")
+    p = synth_config(4, 2)
+    origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    assert np.array_equal(nv, g["nvoxels"])
+    for k in (8, 4):
+        hip_ctx.set_tile_k(k)
+        got = batch.voxelize_lattice(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, p["voxelsize"], box=p["box"],
+                                     ctx=hip_ctx).astype(np.float64)
+        hip_ctx.set_tile_k(0)
+        for frame in (0, 1):
+            f = got[frame]
+            assert np.abs(f[g[f"f{frame}_sample_idx"]] - g[f"f{frame}_sample_features"]).max() <= TOL
+            assert np.all(np.abs(f.sum(0) - g[f"f{frame}_channel_sums"]) <= 1e-6 * f.shape[0])   # mean |err| << 1e-6
+            assert np.array_equal(np.count_nonzero(f > 1e-6, axis=0) > 0, g[f"f{frame}_nonzero"] > 0)
+            assert np.abs(f.max(0) - g[f"f{frame}_channel_max"]).max() <= TOL
+
+
 def test_3ptb_bbox_buffer8_against_reference_samples(hip_ctx):
     """The reference test's own call shape (test_voxeldescriptors.py:77-79: buffer=8 -> 60x55x65 grid)."""
     from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
