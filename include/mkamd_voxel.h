@@ -78,6 +78,10 @@ int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier);
  * atoms: ligand poses, pockets), -1 (default) = per-item when it fits and the batch averages <= 4096 atoms per
  * item.  Results are bit-identical either way. */
 int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode);
+/* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team of four that shares the tile's
+ * candidate traversal and splits its x-planes (latency: one grid per call, the reference's own usage), -1 (default) =
+ * a team when the whole launch has fewer tiles than the chip has SIMDs.  Results are bit-identical either way. */
+int mkamd_ctx_set_tile_team(mkamd_ctx* ctx, int mode);
 /* Opt-in software pipelining ACROSS calls of mkamd_voxelize_lattice_dev (off by default): the binning
  * pre-pass of a call (latency / atomic bound) runs on an internal stream beside the tile kernel (VALU bound)
  * of the previous call, on a second workspace set.  Results still appear in order on the context's stream.

@@ -38,6 +38,7 @@ SIGNATURES = {
     "mkamd_ctx_set_lds_tier": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_prepass_mode": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
@@ -172,6 +173,10 @@ class Context:
     def set_prepass_mode(self, mode: int):
         """-1 automatic (default), 0 multi-kernel chain, 1 one-launch per-item pre-pass (include/mkamd_voxel.h)."""
         _check(load().mkamd_ctx_set_prepass_mode(self._h, int(mode)))
+
+    def set_tile_team(self, mode: int):
+        """-1 automatic (default), 0 one wave per tile, 1 a team of four waves per tile (include/mkamd_voxel.h)."""
+        _check(load().mkamd_ctx_set_tile_team(self._h, int(mode)))
 
     def set_force_general(self, on: bool):
         _check(load().mkamd_ctx_set_force_general(self._h, int(bool(on))))

@@ -871,7 +871,7 @@ struct CandRuns {
 
 MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const int nyc = tg.cy_hi - tg.cy_lo + 1;
     const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 16 (cell edge >= cutoff radius)
     CandRuns cr;
@@ -891,10 +891,11 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
 
 template <int K, bool LOAD_CLS, int BATCH, class F>
 MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const CandRuns& cr,
-                               const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f)
+                               const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f,
+                               unsigned first_batch = 0u, unsigned batch_stride = 1u)
 {
     constexpr float HX = 0.5f * (float)(K - 1);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
     const unsigned my_r0 = cr.r0, my_r1 = cr.r1, my_nch = cr.nch, my_cb = cr.cb, T = cr.T;
 
     auto issue = [&](unsigned t, CandChunk& ch) {                    // start the loads of chunk t
@@ -926,8 +927,9 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
     };
     // BATCH chunks' loads are issued back to back, then the BATCH chunks are processed: the wave pays
     // the L2 / fabric round trip once per batch instead of once per chunk
+    // (a team of waves shares one tile: wave w takes the batches w, w + team, ... -- first_batch / batch_stride)
     CandChunk ch[BATCH];
-    for (unsigned t = 0; t < T; t += BATCH) {
+    for (unsigned t = first_batch * BATCH; t < T; t += BATCH * batch_stride) {
 #ifdef MK_PHASE_TIMERS
         const unsigned long long ta_ = __builtin_readcyclecounter();
 #endif
@@ -995,7 +997,11 @@ template <int K> MK_DEV void entry_d2(float ex, float dyz2, float w, float (&d2)
     }
 }
 
-template <int K, bool DENSE, int ECAP>
+// TEAM > 1 (launches too small to fill the chip: one grid per call, the reference's usage): TEAM waves share one tile --
+// each takes every TEAM-th batch of candidate chunks in the two traversals (histogram and placement go through the
+// same LDS counters) and K / TEAM of the tile's x-planes in the pair loops and the epilogue.  The arithmetic per
+// (voxel, entry) is the one-wave kernel's, bit for bit; what changes is the latency of a tile (~1/3).
+template <int K, bool DENSE, int ECAP, int TEAM = 1>
 MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, const unsigned* __restrict__ cell_start,
                           const float4* __restrict__ rec_pos,
                           const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
@@ -1003,6 +1009,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                           unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
 {
     static_assert(K == 4 || K == 8, "K");
+    static_assert(TEAM == 1 || (!DENSE && (K / 2) % (K / TEAM) == 0 && K / TEAM >= 1), "a team splits the planes evenly inside each half");
+    constexpr int KL = K / TEAM;                          // planes this wave owns: [kb, kb + KL)
     MK_PHASE_BEGIN();
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
     // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
@@ -1022,7 +1030,13 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     // per-tile histogram -> placement cursors -> (after placement) sub-bucket starts again; [NBUCKET3] = end
     __shared__ unsigned bucket[NBUCKET3 + 1];
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int kb = wv * KL;
+    const bool lead = lane == 0 && wv == 0;               // the one thread of the tile's team that reports to global memory
+    // x of this wave's plane j relative to the tile centre (compile-time constants for the one-wave kernel)
+    auto pl_x = [&](int j) { return TEAM == 1 ? plane_x<K>(j) : (float)(kb + j) - 0.5f * (float)(K - 1); };
+    auto pl_slope = [&](int j) { return -2.f * pl_x(j); };
 
     TileGeom tg;
     tg.b = (int)(lt / (unsigned)g.ntiles);
@@ -1066,11 +1080,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     // running minima kept as BIT PATTERNS: every candidate value is a non-negative float (or +inf /
     // NaN), for which unsigned-integer order == float order and NaN (0x7fc00000) sorts above +inf,
     // so v_min_u32 / v_min3_u32 are exact NaN-ignoring float minima with no canonicalisation op.
-    unsigned q[CHG][K];
+    unsigned q[CHG][KL];
 #pragma unroll
     for (int c = 0; c < CHG; ++c)
 #pragma unroll
-        for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
+        for (int k = 0; k < KL; ++k) q[c][k] = INF_BITS;
 
     // "more sigma classes than the table holds": for a call-wide table (one hot line) this is checked up front; a
     // per-item table is a fresh line per item, so the check waits until the first traversal has hidden the load
@@ -1097,7 +1111,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
                     (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                 });
-            });
+            }, (unsigned)wv, (unsigned)TEAM);
         mk_block_sync();
         if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
             general = true;                      // this item alone has too many classes (its records carry w, not ids)
@@ -1121,7 +1135,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             for (int i = 0; i < 2 * NXR; ++i) { start[i] = run; run += pad[i]; }
         }
         if (!DENSE && total > (unsigned)ECAP_TIER[0]) {                      // wave-uniform; statistics for the tier choice
-            if (lane == 0) {
+            if (lead) {
 #pragma unroll
                 for (int t = 0; t < NTIER; ++t)
                     if (total > (unsigned)ECAP_TIER[t]) (void)mk_atomic_add(&dense_count[1 + t], 1u);
@@ -1129,8 +1143,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         }
         if (!DENSE && total > (unsigned)ECAP) {                              // wave-uniform
             // too dense for one round: hand the tile to the dense instance of this kernel
-            if (lane == 0) dense_list[mk_atomic_add(dense_count, 1u)] = lt + (unsigned)gq * ((unsigned)g.B * (unsigned)g.ntiles);
-            return;
+            if (lead) dense_list[mk_atomic_add(dense_count, 1u)] = lt + (unsigned)gq * ((unsigned)g.B * (unsigned)g.ntiles);
+            return;                                                          // (the whole team: `total` is the same in every wave)
         }
         const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
         const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u);
@@ -1143,7 +1157,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         };
         // ---- one channel, class by class: inner loop = sub, fma, half a min3 per (voxel, entry); the
         //      class flush applies the cutoff to the class minimum and scales by w ----
-        auto process_classes = [&](int c, unsigned bits, unsigned (&acc)[K]) {
+        auto process_classes = [&](int c, unsigned bits, unsigned (&acc)[KL]) {
             while (bits) {                                                // wave-uniform
                 const int cls = __builtin_ctz(bits);
                 bits &= bits - 1u;
@@ -1154,13 +1168,15 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 // with D0 = ex^2 + dy^2 + dz^2 per (lane, entry), g_k = D0 - 2 c_k ex is ONE fma per (voxel, entry); the
                 // plane constant c_k^2 is added to the class minimum at the flush (rounding is monotone: the same bits as
                 // adding it per entry).  g_k may be negative (>= -c_k^2), so these minima are float minima (v_min3_f32).
-                float m[K];
+                float m[KL];
 #pragma unroll
-                for (int k = 0; k < K; ++k) m[k] = INF;
+                for (int k = 0; k < KL; ++k) m[k] = INF;
                 // planes [K0, K1) against the entries of one sub-bucket: start words b0 (this) and b1 (next); the
                 // slots are padded to an even count, bit 0 of b0 says that the last slot is padding
                 auto run = [&](auto k0_, auto k1_, unsigned b0, unsigned b1) {
                     constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+                    if (TEAM > 1 && (kb < K0 || kb >= K1)) return;            // wave-uniform: none of this wave's planes
+                    constexpr int J0 = TEAM == 1 ? K0 : 0, J1 = TEAM == 1 ? K1 : KL;   // this wave's planes of [K0, K1)
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
                     const float* e = sxyz + s0;
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
@@ -1173,8 +1189,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                         const mk_f2 dy = Y2 - py, dz = Z2 - pz;
                         const mk_f2 d0 = mk_f2_fma(px, px, mk_f2_fma(dy, dy, dz * dz));
 #pragma unroll
-                        for (int k = K0; k < K1; ++k) {
-                            const mk_f2 gk = mk_f2_fma(mk_f2_splat(plane_slope<K>(k)), px, d0);
+                        for (int k = J0; k < J1; ++k) {
+                            const mk_f2 gk = mk_f2_fma(mk_f2_splat(pl_slope(k)), px, d0);
                             m[k] = mk_min3(m[k], gk[0], gk[1]);
                         }
                     }
@@ -1182,7 +1198,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                         const float ex = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
                         const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
 #pragma unroll
-                        for (int k = K0; k < K1; ++k) m[k] = mk_min(m[k], mk_fma(plane_slope<K>(k), ex, d0));
+                        for (int k = J0; k < J1; ++k) m[k] = mk_min(m[k], mk_fma(pl_slope(k), ex, d0));
                     }
                 };
                 // exact form for a class of small sigmas (w > FAST_W_MAX, rare): one compact loop, every plane against
@@ -1196,8 +1212,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                         const float px = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
                         const float r = mk_fma(dy, dy, dz * dz);
 #pragma unroll
-                        for (int k = 0; k < K; ++k) {
-                            const float dx = plane_x<K>(k) - px;
+                        for (int k = 0; k < KL; ++k) {
+                            const float dx = pl_x(k) - px;
                             m[k] = mk_min(m[k], mk_fma(dx, dx, r));
                         }
                     }
@@ -1214,14 +1230,14 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 }
                 // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
 #pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float d2 = fast ? plane_d2<K>(k, m[k]) : m[k];
+                for (int k = 0; k < KL; ++k) {
+                    const float d2 = fast ? m[k] + pl_x(k) * pl_x(k) : m[k];         // (plane_d2: g_k + c_k^2)
                     acc[k] = mk_min_bits(acc[k], d2 < R2 ? mk_abs(d2) * wcls : INF);
                 }
             }
         };
         // dense tiles only: a finished channel goes straight to memory (4-byte stores, 32-byte stride)
-        auto store_channel = [&](int c, const unsigned (&acc)[K]) {
+        auto store_channel = [&](int c, const unsigned (&acc)[KL]) {
             const int y = tg.y0 + ly, z = tg.z0 + lz;
             if (y < g.ny && z < g.nz && gq * CHG + c < g.C) {
 #pragma unroll
@@ -1251,7 +1267,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                         const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                         sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
                     });
-                });
+                }, (unsigned)wv, (unsigned)TEAM);
             mk_block_sync();
             // cursors are dead now: the array becomes the table of sub-bucket starts (even; bit 0 = "odd count, the
             // last slot is padding"; sub-buckets are contiguous, so a group's three ranges are four consecutive words; the word after the
@@ -1264,7 +1280,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             mk_block_sync();
         };
 
-        if (!DENSE) {
+        if constexpr (!DENSE) {
             // ---- the normal case: one round takes all eight channels; minima stay in q for the epilogue ----
             MK_PHASE_MARK(2);                               // counts -> starts
             place(0, CHG, 0u, total);
@@ -1350,10 +1366,22 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 for (int i = 0; i < n; ++i) {
                     const float4 e = ebuf[i];
                     const float dy = Y - e.y, dz = Z - e.z;
-                    float d2[K];
-                    entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);                  // same fma tree as the sorted path
+                    float d2[KL];
+                    if constexpr (TEAM == 1) {
+                        entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);              // same fma tree as the sorted path
+                    } else {                                                             // this wave's planes, the same two forms
+                        const float dyz2 = mk_fma(dy, dy, dz * dz);
+                        if (mk_uint_as_float(mk_uniform(mk_float_bits(e.w))) <= fast_w_max<K>()) {
+                            const float d0 = mk_fma(e.x, e.x, dyz2);
 #pragma unroll
-                    for (int k = 0; k < K; ++k)
+                            for (int k = 0; k < KL; ++k) d2[k] = mk_fma(pl_slope(k), e.x, d0) + pl_x(k) * pl_x(k);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < KL; ++k) { const float dx = pl_x(k) - e.x; d2[k] = mk_fma(dx, dx, dyz2); }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KL; ++k)
                         q[c][k] = mk_min_bits(q[c][k], d2[k] < R2 ? mk_abs(d2[k]) * e.w : INF);   // occupancy_utils.pyx:53
                 }
                 mk_block_sync();                                     // ebuf is rewritten next
@@ -1366,8 +1394,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     const int y = tg.y0 + ly, z = tg.z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int x = tg.x0 + k;
+    for (int k = 0; k < KL; ++k) {
+        const int x = tg.x0 + kb + k;
         float f[CHG];
 #pragma unroll
         for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
@@ -1423,6 +1451,22 @@ __attribute__((amdgpu_num_vgpr(52))) MK_KERNEL(64) void k_voxelize_tiles_lean(Gr
     const unsigned lt = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (lt >= (unsigned)g.B * (unsigned)g.ntiles) return;                // whole wave leaves together
     voxelize_tile<K, false, ECAP>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
+}
+
+// TEAM waves per tile (voxelize_tile): for launches of fewer tiles than the chip has SIMDs, where the latency of one
+// tile is the latency of the call.
+constexpr int TILE_TEAM = 4;
+template <int K, int ECAP>
+MK_KERNEL(TILE_TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned* __restrict__ cell_start,
+                                    const float4* __restrict__ rec_pos,
+                                    const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
+                                    const unsigned* __restrict__ cls_table, float* __restrict__ out,
+                                    unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
+{
+    const unsigned per_xcd = gridDim.x >> 3;      // gridDim.x is a multiple of 8 (host pads)
+    const unsigned lt = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (lt >= (unsigned)g.B * (unsigned)g.ntiles) return;                // the whole team leaves together
+    voxelize_tile<K, false, ECAP, TILE_TEAM>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
 }
 
 // The tiles k_voxelize_tiles left behind (usually none: the launch then costs ~2 us).

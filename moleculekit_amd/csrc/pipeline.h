@@ -53,6 +53,7 @@ struct LatticeProblem {
     int force_general = 0;                  // 1 = never use the class-sorted path
     int lds_tier = -1;                      // -1 = adaptive (choose_tier), else the ECAP_TIER index to use
     int prepass_mode = -1;                  // -1 = automatic, 0 = multi-kernel chain, 1 = one-launch per-item pre-pass (if it fits)
+    int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
     // device pointers
     const float* coords = nullptr;
     const long long* atom_offsets = nullptr;
@@ -177,13 +178,19 @@ inline int choose_tier(int forced, const volatile unsigned* feedback)
     return tier;
 }
 
+enum TileFlavour { TILES_PLAIN = 0, TILES_LEAN = 1, TILES_TEAM = 2 };
+
 template <int K, int T, class BE>
-int launch_tiles_tier(BE& be, bool lean, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
                       void* ctab, float* out, unsigned* dcount, void* dlist, void* eflag)
 {
     constexpr int E = ECAP_TIER[T];
     int st;
-    if constexpr (T <= 1) {           // the biggest tier is LDS-bound to < 3 waves/SIMD anyway: no lean instance of it
+    const bool lean = flavour == TILES_LEAN;
+    if (flavour == TILES_TEAM) {      // a handful of tiles (one grid per call): TILE_TEAM waves per tile
+        st = be.launch(k_voxelize_tiles_team<K, E>, tgrid, dim3(WAVE * TILE_TEAM), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
+                       (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
+    } else if constexpr (T <= 1) {    // the biggest tier is LDS-bound to < 3 waves/SIMD anyway: no lean instance of it
         st = lean ? be.launch(k_voxelize_tiles_lean<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                               (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist)
                   : be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
@@ -200,13 +207,13 @@ int launch_tiles_tier(BE& be, bool lean, dim3 tgrid, unsigned dense_wgs, const G
 }
 
 template <int K, class BE>
-int launch_tiles(BE& be, int tier, bool lean, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+int launch_tiles(BE& be, int tier, int flavour, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
                  void* ctab, float* out, unsigned* dcount, void* dlist, void* eflag)
 {
     switch (tier) {
-    case 0: return launch_tiles_tier<K, 0>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
-    case 1: return launch_tiles_tier<K, 1>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
-    default: return launch_tiles_tier<K, 2>(be, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    case 0: return launch_tiles_tier<K, 0>(be, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    case 1: return launch_tiles_tier<K, 1>(be, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    default: return launch_tiles_tier<K, 2>(be, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
     }
 }
 
@@ -321,10 +328,12 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     unsigned* dcount = (unsigned*)count + ncells;
     const unsigned dense_wgs = total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u;
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
-    const bool lean = be.set_is_pipelined(set);        // leave registers for the next call's pre-pass
+    // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
+    const bool team = P.tile_team > 0 || (P.tile_team < 0 && (unsigned long long)total_tiles * (unsigned)g.G <= 1024ull);
+    const int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
     be.hot_begin();
-    st = g.K == 8 ? launch_tiles<8>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
-                  : launch_tiles<4>(be, tier, lean, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
+    st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
+                  : launch_tiles<4>(be, tier, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
     if (!st && fix_waves != 0u) {
         // exact cut-off decisions for wide sigmas (the waves whose atoms have none -- normally all -- leave at once)
         st = P.sigmas_f64 ? be.launch(k_exact_fixup<double>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,

@@ -240,3 +240,23 @@ def test_fused_rotation_matches_rotate_then_voxelize():
     exp = oracle_lattice(rc, case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
     assert np.abs(fused - exp).max() <= TOL
     assert np.abs(fused - case["expected"]).max() > 0.1          # the rotation really changed the grids
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "pbc_batch", "channels11", "cutoff_exact_1A", "voxel15", "special_sigmas"])
+@pytest.mark.parametrize("tile_k", [8, 4])
+def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
+    """One grid per call (the reference's usage) runs a team of four waves per tile: shared candidate traversal, the
+    x-planes split among the waves.  Same arithmetic per (voxel, entry), so not a bit may differ from the one-wave
+    kernel -- on the class-sorted path and, forced, on the general path."""
+    if tile_k == 4 and name in ("pbc_batch", "voxel15"):
+        pytest.skip("covered with K=8 (emulation time)")
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    one, e1 = E.voxelize_lattice(*args, box=case["box"], tile_k=tile_k, tile_team=0)
+    team, e2 = E.voxelize_lattice(*args, box=case["box"], tile_k=tile_k, tile_team=1)
+    assert e1 == 0 and e2 == 0
+    assert np.array_equal(one, team)
+    check(case, team)
+    if name in ("ragged_batch", "channels11"):
+        gen, e3 = E.voxelize_lattice(*args, box=case["box"], tile_k=tile_k, tile_team=1, force_general=True)
+        assert e3 == 0 and np.array_equal(gen, one)

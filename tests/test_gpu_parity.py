@@ -131,6 +131,29 @@ def test_grid_centers_bit_exact(hip_ctx):
         assert np.array_equal(got, g[f"box{i}_centers"])
 
 
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "pbc_batch", "channels11", "cutoff_adversarial_1A", "voxel15", "special_sigmas"])
+def test_team_of_waves_per_tile_is_bit_identical(hip_ctx, name):
+    """One grid per call runs four waves per tile (mkamd_ctx_set_tile_team): not a bit may differ from one wave per tile."""
+    from moleculekit_amd import batch
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    try:
+        for k in (8, 4):
+            hip_ctx.set_tile_k(k)
+            hip_ctx.set_tile_team(0)
+            one = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+            hip_ctx.set_tile_team(1)
+            team = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+            assert np.array_equal(one, team)
+            check(case, team)
+            hip_ctx.set_force_general(True)
+            gen = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+            hip_ctx.set_force_general(False)
+            assert np.array_equal(gen, one)
+    finally:
+        hip_ctx.set_tile_k(0); hip_ctx.set_tile_team(-1); hip_ctx.set_force_general(False)
+
+
 def test_cfg2_full_size_against_reference_samples(hip_ctx):
     """BASELINE.json configs[1] at FULL size (50k atoms, 64^3 x 8): 16384 sampled voxels + per-channel
     checksums of the real reference's output (tests/golden/cfg2_sampled.npz)."""
