@@ -792,6 +792,30 @@ MK_KERNEL(256) void k_prepass_reduce2(const unsigned* __restrict__ l1sets, unsig
         scan_sums_inplace_block(chunk_sums, nchunks);
 }
 
+// Both reductions after the binning -- sigma classes -> class table, cell counts -> cell starts -- by ONE workgroup, for
+// calls small enough that three dependent launches (~5 us each) cost more than the work: one grid per call.
+constexpr int SMALL_PREPASS_THREADS = 1024;
+constexpr unsigned SMALL_PREPASS_MAX_CELLS = 1u << 13;     // counts one block scans in a few microseconds (8 rounds)
+constexpr unsigned SMALL_PREPASS_MAX_BLOCKS = 4096;        // per-block sigma sets one block merges likewise
+
+MK_KERNEL(SMALL_PREPASS_THREADS) void k_prepass_small(const unsigned* __restrict__ block_sets, unsigned nblk,
+                                                      unsigned* __restrict__ cls_table, const unsigned* __restrict__ counts,
+                                                      unsigned n, unsigned* __restrict__ starts /* n+1 */)
+{
+    mk_wave_priority_high();
+    __shared__ unsigned s_scan[16];
+    if (nblk != 0u) merge_classes_block(block_sets, nblk, (unsigned)CLS_BLOCK_SET, nblk, nullptr, cls_table, 0u);
+    unsigned carry = 0;
+    for (unsigned base = 0; base <= n; base += SMALL_PREPASS_THREADS) {    // block-uniform
+        const unsigned i = base + threadIdx.x;
+        const unsigned v = i < n ? counts[i] : 0u;
+        unsigned tot;
+        const unsigned ex = block_scan_exclusive16(v, &tot, s_scan);
+        if (i <= n) starts[i] = carry + ex;                                // starts[n] = grand total
+        carry += tot;
+    }
+}
+
 MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size_t n,
                                            const unsigned* __restrict__ chunk_offsets,
                                            unsigned* __restrict__ out /* n+1 */)
@@ -889,22 +913,30 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
     return cr;
 }
 
-template <int K, bool LOAD_CLS, int BATCH, class F>
-MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const CandRuns& cr,
-                               const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f,
-                               unsigned first_batch = 0u, unsigned batch_stride = 1u)
-{
-    constexpr float HX = 0.5f * (float)(K - 1);
-    const int lane = threadIdx.x & (WAVE - 1);
-    const unsigned my_r0 = cr.r0, my_r1 = cr.r1, my_nch = cr.nch, my_cb = cr.cb, T = cr.T;
+// issue(t, ch) starts the loads of candidate chunk t; consume(ch, f) makes its records tile-relative, culls them
+// against the tile box and calls f(survives, record index, x, y, z, class ids) -- by ALL lanes
+struct CandLoader {
+    const GridDesc& g;
+    const TileGeom& tg;
+    const CandRuns& cr;
+    const float4* __restrict__ rec_pos;
+    const unsigned* __restrict__ rec_cls;
+};
 
-    auto issue = [&](unsigned t, CandChunk& ch) {                    // start the loads of chunk t
+template <bool LOAD_CLS>
+MK_DEV void cand_issue(const CandLoader& L, unsigned t, CandChunk& ch)
+{
+    const CandRuns& cr = L.cr;
+    const float4* __restrict__ rec_pos = L.rec_pos;
+    const unsigned* __restrict__ rec_cls = L.rec_cls;
+    {
+        const int lane = threadIdx.x & (WAVE - 1);
         ch.r = 0u; ch.valid = false; ch.ids = 0u;
         ch.P = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t < T) {                                                 // wave-uniform
-            const unsigned long long own = mk_ballot(my_cb <= t && t < my_cb + my_nch);
+        if (t < cr.T) {                                              // wave-uniform
+            const unsigned long long own = mk_ballot(cr.cb <= t && t < cr.cb + cr.nch);
             const int j = __builtin_ctzll(own);
-            const unsigned r0 = mk_readlane(my_r0, j), r1 = mk_readlane(my_r1, j), cb = mk_readlane(my_cb, j);
+            const unsigned r0 = mk_readlane(cr.r0, j), r1 = mk_readlane(cr.r1, j), cb = mk_readlane(cr.cb, j);
             ch.r = r0 + ((t - cb) << 6) + (unsigned)lane;
             ch.valid = ch.r < r1;
             if (ch.valid) {
@@ -912,8 +944,16 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
                 if (LOAD_CLS) ch.ids = rec_cls[ch.r];
             }
         }
-    };
-    auto consume = [&](const CandChunk& ch) {
+    }
+}
+
+template <int K, class F>
+MK_DEV void cand_consume(const CandLoader& L, const CandChunk& ch, F&& f)
+{
+    const GridDesc& g = L.g;
+    const TileGeom& tg = L.tg;
+    {
+        constexpr float HX = 0.5f * (float)(K - 1);
         const int pk = mk_float_as_int(ch.P.w);
         // (cell centre - tile centre) is an exact small half-integer; ONE rounding per axis
         const float ex = ch.P.x + ((float)(pk & 1023) * tg.fcs + tg.offx);
@@ -924,7 +964,16 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
         const float gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
         const bool surv = ch.valid && (gx * gx + gy * gy + gz * gz < g.R2cull);
         f(surv, ch.r, ex, ey, ez, ch.ids);
-    };
+    }
+}
+
+template <int K, bool LOAD_CLS, int BATCH, class F>
+MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const CandRuns& cr,
+                               const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f,
+                               unsigned first_batch = 0u, unsigned batch_stride = 1u)
+{
+    const CandLoader ld{g, tg, cr, rec_pos, rec_cls};
+    const unsigned T = cr.T;
     // BATCH chunks' loads are issued back to back, then the BATCH chunks are processed: the wave pays
     // the L2 / fabric round trip once per batch instead of once per chunk
     // (a team of waves shares one tile: wave w takes the batches w, w + team, ... -- first_batch / batch_stride)
@@ -934,14 +983,14 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
         const unsigned long long ta_ = __builtin_readcyclecounter();
 #endif
 #pragma unroll
-        for (int k = 0; k < BATCH; ++k) issue(t + (unsigned)k, ch[k]);
+        for (int k = 0; k < BATCH; ++k) cand_issue<LOAD_CLS>(ld, t + (unsigned)k, ch[k]);
 #ifdef MK_PHASE_TIMERS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long tb_ = __builtin_readcyclecounter();
 #endif
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
-            if (t + (unsigned)k < T) consume(ch[k]);                 // wave-uniform
+            if (t + (unsigned)k < T) cand_consume<K>(ld, ch[k], f);      // wave-uniform
 #ifdef MK_PHASE_TIMERS
         const unsigned long long tc_ = __builtin_readcyclecounter();
         cr.wait_ += tb_ - ta_; cr.proc_ += tc_ - tb_;                 // flushed at the end of the tile
@@ -1105,13 +1154,28 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
         for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
         mk_block_sync();
-        for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp,
-            [&](bool surv, unsigned, float ex, float, float, unsigned ids) {
-                const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
-                for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
-                    (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
-                });
-            }, (unsigned)wv, (unsigned)TEAM);
+        auto count_entry = [&](bool surv, unsigned, float ex, float, float, unsigned ids) {
+            const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+            for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
+                (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+            });
+        };
+        // A team's wave sees only every TEAM-th chunk: when that is at most TEAM_KEEP of them (it nearly always is) they
+        // are loaded ONCE, all at the same time, and stay in registers for the placement pass -- the tile's latency is
+        // a chain of dependent memory round trips, and this removes all but one of the traversals'.
+        constexpr int TEAM_KEEP = TEAM > 1 ? 6 : 1;
+        CandChunk kept[TEAM_KEEP];
+        const bool keep = TEAM > 1 && runs.T <= (unsigned)(TEAM_KEEP * TEAM);                 // the same in every wave
+        const CandLoader loader{g, tg, runs, rec_pos, clsp};
+        if (keep) {
+#pragma unroll
+            for (int i = 0; i < TEAM_KEEP; ++i) cand_issue<true>(loader, (unsigned)(wv + i * TEAM), kept[i]);
+#pragma unroll
+            for (int i = 0; i < TEAM_KEEP; ++i)
+                if ((unsigned)(wv + i * TEAM) < runs.T) cand_consume<K>(loader, kept[i], count_entry);
+        } else {
+            for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp, count_entry, (unsigned)wv, (unsigned)TEAM);
+        }
         mk_block_sync();
         if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
             general = true;                      // this item alone has too many classes (its records carry w, not ids)
@@ -1260,14 +1324,20 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
-            for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp,
-                [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
-                    const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
-                    for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
-                        const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
-                        sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
-                    });
-                }, (unsigned)wv, (unsigned)TEAM);
+            auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
+                const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+                for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
+                    const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+                    sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
+                });
+            };
+            if (keep) {
+#pragma unroll
+                for (int i = 0; i < TEAM_KEEP; ++i)
+                    if ((unsigned)(wv + i * TEAM) < runs.T) cand_consume<K>(loader, kept[i], place_entry);
+            } else {
+                for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp, place_entry, (unsigned)wv, (unsigned)TEAM);
+            }
             mk_block_sync();
             // cursors are dead now: the array becomes the table of sub-bucket starts (even; bit 0 = "odd count, the
             // last slot is padding"; sub-buckets are contiguous, so a group's three ranges are four consecutive words; the word after the

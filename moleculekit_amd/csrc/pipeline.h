@@ -246,7 +246,10 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
     void *tpos = nullptr, *tidx = nullptr, *tcls = nullptr;
     // count[ncells ...] = length of the dense-tile list + tier statistics (zeroed with the counters)
-    if ((st = be.ensure(WS_CELL_COUNT, (ncells + DENSE_WORDS) * sizeof(unsigned), &count, set))) return st;
+    // (the counters are cleared with one memset per call: its size is kept a multiple of 256 bytes -- an odd tail costs
+    //  the runtime a second fill kernel, ~4 us on the latency path of a single-grid call)
+    const size_t count_bytes = ((ncells + DENSE_WORDS) * sizeof(unsigned) + 255) & ~(size_t)255;
+    if ((st = be.ensure(WS_CELL_COUNT, count_bytes, &count, set))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
     if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos, set))) return st;
     if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw, set))) return st;
@@ -275,7 +278,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         else              st = need <= 512 ? go(k_prepass_items<float, 512>) : need <= 2048 ? go(k_prepass_items<float, 2048>) : go(k_prepass_items<float, ITEM_HIST>);
         if (st) return st;
     } else {
-        if ((st = be.fill(count, 0, (ncells + DENSE_WORDS) * sizeof(unsigned)))) return st;
+        if ((st = be.fill(count, 0, count_bytes))) return st;
         const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
         const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
         const unsigned nblk = agrid.x;
@@ -298,7 +301,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
         const bool do_classes = P.total_atoms > 0 && !g.force_general;
         if (!do_classes && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
-        {
+        if (ncells <= SMALL_PREPASS_MAX_CELLS && nblk <= SMALL_PREPASS_MAX_BLOCKS) {
+            // a small call (one grid): one launch instead of three dependent ones
+            if ((st = be.launch(k_prepass_small, dim3(1), dim3(SMALL_PREPASS_THREADS), (const unsigned*)bsets, do_classes ? nblk : 0u,
+                                (unsigned*)ctab, (const unsigned*)count, (unsigned)ncells, (unsigned*)start))) return st;
+        } else {
             const size_t nchunks = (ncells + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
             void* chunks = nullptr;
             if ((st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set))) return st;
