@@ -12,7 +12,7 @@ import torch
 from moleculekit_amd import _lib, batch
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
-B = bench.DEFAULT_BATCH[wl]
+B = int(sys.argv[2]) if len(sys.argv) > 2 else bench.DEFAULT_BATCH[wl]
 p, origins, nv = bench.make_workload(wl, B, seed=7)
 dev = torch.device("cuda", 0)
 t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
