@@ -493,6 +493,7 @@ def main():
     ctx.set_lds_tier(args.lds_tier)
     ctx.set_prepass_mode(int(os.environ.get("MKAMD_PREPASS", "-1")))
     ctx.set_force_general(os.environ.get("MKAMD_FORCE_GENERAL", "0") == "1")
+    ctx.set_coarse_cells(os.environ.get("MKAMD_COARSE_CELLS", "0") == "1")         # A-B knob: the round-1 cell size
     # steps are independent batches whose inputs are resident before the loop: the library may overlap the
     # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)
     ctx.set_pipelining(not args.no_pipeline)

@@ -884,32 +884,51 @@ struct CandChunk {                    // one chunk of 64 candidate records (one 
     bool valid;
 };
 
-// The candidate runs of a tile: lane j < ncols holds the record range of column j (one load round trip), plus the
-// chunk numbering.  Found once per tile and shared by every traversal.
+// The candidate runs of a tile: lane j < ncols holds the record range of cell column j (one load round trip) -- the
+// z-cells of a column are adjacent in memory -- trimmed to the cells that can hold an atom within the cutoff of the tile
+// box (columns out of reach altogether are dropped).  The candidates are numbered 0..N-1 across the runs (`pre` = a
+// run's first number) and visited in chunks of 64 consecutive numbers, so that a chunk is full whatever the runs'
+// lengths are.  Found once per tile and shared by every traversal.
 struct CandRuns {
-    unsigned r0, r1, nch, cb, T;
+    unsigned r0, len, pre, N, T;
 #ifdef MK_PHASE_TIMERS
     mutable unsigned long long wait_ = 0, proc_ = 0;
 #endif
 };
 
+template <int K>
 MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const int nyc = tg.cy_hi - tg.cy_lo + 1;
-    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 16 (cell edge >= cutoff radius)
+    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 49 (cell edge > half the cutoff radius, plan_lattice)
     CandRuns cr;
-    cr.r0 = 0; cr.r1 = 0;
+    cr.r0 = 0; cr.len = 0;
     if (lane < ncols) {
         const int pcx = tg.cx_lo + lane / nyc, pcy = tg.cy_lo + lane % nyc;
-        const size_t cbase = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz;
-        cr.r0 = cell_start[cbase + tg.cz_lo];
-        cr.r1 = cell_start[cbase + tg.cz_hi + 1];                 // z-run of cells is contiguous
+        // a cell holds positions in [c0 - 0.5, c0 + cs - 0.5), c0 = (pc - h) * cs (bin_atom: locate); its gap to the tile's voxel box
+        const float fcs = (float)g.cs;
+        const float cx0 = (float)((pcx - g.h) * g.cs) - 0.5f, cy0 = (float)((pcy - g.h) * g.cs) - 0.5f;
+        const float gx = fmaxf(fmaxf((float)tg.x0 - (cx0 + fcs), cx0 - (float)(tg.x0 + K - 1)), 0.f);
+        const float gy = fmaxf(fmaxf((float)tg.y0 - (cy0 + fcs), cy0 - (float)(tg.y0 + 7)), 0.f);
+        const float rest = g.R2cull - (gx * gx + gy * gy);
+        if (rest > 0.f) {
+            const float zg = sqrtf(rest) * 1.0001f + 1e-3f;      // reach along z left for this column (generous)
+            const float inv = 1.0f / fcs;
+            int ca = (int)floorf(((float)tg.z0 - zg + 0.5f) * inv) + g.h, cb = (int)floorf(((float)(tg.z0 + 7) + zg + 0.5f) * inv) + g.h;
+            ca = ca < tg.cz_lo ? tg.cz_lo : ca;
+            cb = cb > tg.cz_hi ? tg.cz_hi : cb;
+            if (ca <= cb) {
+                const size_t cbase = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz;
+                cr.r0 = cell_start[cbase + ca];
+                cr.len = cell_start[cbase + cb + 1] - cr.r0;      // z-run of cells is contiguous
+            }
+        }
     }
-    cr.nch = (cr.r1 - cr.r0 + (WAVE - 1)) >> 6;
-    const unsigned incl = wave_scan_inclusive(cr.nch);
-    cr.cb = incl - cr.nch;
-    cr.T = mk_readlane(incl, WAVE - 1);
+    const unsigned incl = wave_scan_inclusive(cr.len);
+    cr.pre = incl - cr.len;
+    cr.N = mk_readlane(incl, WAVE - 1);
+    cr.T = (cr.N + (WAVE - 1)) >> 6;
     return cr;
 }
 
@@ -934,11 +953,15 @@ MK_DEV void cand_issue(const CandLoader& L, unsigned t, CandChunk& ch)
         ch.r = 0u; ch.valid = false; ch.ids = 0u;
         ch.P = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < cr.T) {                                              // wave-uniform
-            const unsigned long long own = mk_ballot(cr.cb <= t && t < cr.cb + cr.nch);
-            const int j = __builtin_ctzll(own);
-            const unsigned r0 = mk_readlane(cr.r0, j), r1 = mk_readlane(cr.r1, j), cb = mk_readlane(cr.cb, j);
-            ch.r = r0 + ((t - cb) << 6) + (unsigned)lane;
-            ch.valid = ch.r < r1;
+            // candidate numbers [64 t, 64 t + 64): the runs that overlap them (a handful), each claimed by its lanes
+            const unsigned n0 = t << 6, n = n0 + (unsigned)lane;
+            unsigned long long over = mk_ballot(cr.len != 0u && cr.pre < n0 + (unsigned)WAVE && cr.pre + cr.len > n0);
+            while (over) {                                           // wave-uniform
+                const int j = mk_ctz64(over);
+                over &= over - 1ull;
+                const unsigned pj = mk_readlane(cr.pre, j), lj = mk_readlane(cr.len, j), rj = mk_readlane(cr.r0, j);
+                if (n - pj < lj) { ch.r = rj + (n - pj); ch.valid = true; }      // unsigned: pj <= n < pj + lj
+            }
             if (ch.valid) {
                 ch.P = rec_pos[ch.r];
                 if (LOAD_CLS) ch.ids = rec_cls[ch.r];
@@ -1124,7 +1147,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         tg.fcs = (float)g.cs;
     }
 
-    const CandRuns runs = find_candidate_runs(g, tg, cell_start);   // issued early: the loads fly during the set-up below
+    const CandRuns runs = find_candidate_runs<K>(g, tg, cell_start);   // issued early: the loads fly during the set-up below
 
     // running minima kept as BIT PATTERNS: every candidate value is a non-negative float (or +inf /
     // NaN), for which unsigned-integer order == float order and NaN (0x7fc00000) sorts above +inf,
