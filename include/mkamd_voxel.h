@@ -78,10 +78,11 @@ int mkamd_ctx_set_lds_tier(mkamd_ctx* ctx, int tier);
  * atoms: ligand poses, pockets), -1 (default) = per-item when it fits and the batch averages <= 4096 atoms per
  * item.  Results are bit-identical either way. */
 int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode);
-/* Cell edge of the binning: 0 (default) = a power of two in (cutoff/2, cutoff] voxels, 1 = cutoff-sized cells (twice
- * as coarse: more candidates per tile to cull; kept for A-B benchmarking).  Values agree to float32 noise (the
- * cell-relative offsets are rounded at a different magnitude), both within the 1e-5 parity bound. */
-int mkamd_ctx_set_coarse_cells(mkamd_ctx* ctx, int on);
+/* Cell edge of the binning: 0 (default) = the power of two >= the cutoff radius in voxels, 1 = half of that (fewer
+ * candidates per tile to cull, eight times the cell counters; measured slightly slower -- kept for A-B benchmarking).
+ * Values agree to float32 noise (the cell-relative offsets are rounded at a different magnitude), both within the
+ * 1e-5 parity bound. */
+int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on);
 /* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team of four that shares the tile's
  * candidate traversal and splits its x-planes (latency: one grid per call, the reference's own usage), -1 (default) =
  * a team when the whole launch has fewer tiles than the chip has SIMDs.  Results are bit-identical either way. */

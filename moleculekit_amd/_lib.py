@@ -39,7 +39,7 @@ SIGNATURES = {
     "mkamd_ctx_set_prepass_mode": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
-    "mkamd_ctx_set_coarse_cells": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
@@ -179,9 +179,9 @@ class Context:
         """-1 automatic (default), 0 one wave per tile, 1 a team of four waves per tile (include/mkamd_voxel.h)."""
         _check(load().mkamd_ctx_set_tile_team(self._h, int(mode)))
 
-    def set_coarse_cells(self, on: bool):
-        """Cutoff-sized cells instead of half-cutoff ones (A-B benchmarking; same values to float32 noise)."""
-        _check(load().mkamd_ctx_set_coarse_cells(self._h, int(bool(on))))
+    def set_fine_cells(self, on: bool):
+        """Half-cutoff cells instead of cutoff-sized ones (A-B benchmarking; same values to float32 noise)."""
+        _check(load().mkamd_ctx_set_fine_cells(self._h, int(bool(on))))
 
     def set_force_general(self, on: bool):
         _check(load().mkamd_ctx_set_force_general(self._h, int(bool(on))))

@@ -50,6 +50,9 @@ constexpr int CHG = 8;               // channels per channel-group (one group = 
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per class table (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
+#ifndef MK_DIAG           // tools/gpu_diag.sh builds only: compile parts of the tile kernel out to count what they cost
+#define MK_DIAG 0         // 1 pair loops, 2 class flushes, 4 epilogue arithmetic, 8 placement + all class work, 16 histogram traversal
+#endif
 #ifndef MK_TRAV_BATCH
 #define MK_TRAV_BATCH 4
 #endif
@@ -1190,7 +1193,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         CandChunk kept[TEAM_KEEP];
         const bool keep = TEAM > 1 && runs.T <= (unsigned)(TEAM_KEEP * TEAM);                 // the same in every wave
         const CandLoader loader{g, tg, runs, rec_pos, clsp};
-        if (keep) {
+        if (MK_DIAG & 16) {
+        } else if (keep) {
 #pragma unroll
             for (int i = 0; i < TEAM_KEEP; ++i) cand_issue<true>(loader, (unsigned)(wv + i * TEAM), kept[i]);
 #pragma unroll
@@ -1263,6 +1267,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 auto run = [&](auto k0_, auto k1_, unsigned b0, unsigned b1) {
                     constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
                     if (TEAM > 1 && (kb < K0 || kb >= K1)) return;            // wave-uniform: none of this wave's planes
+                    if (MK_DIAG & 1) return;
                     constexpr int J0 = TEAM == 1 ? K0 : 0, J1 = TEAM == 1 ? K1 : KL;   // this wave's planes of [K0, K1)
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
                     const float* e = sxyz + s0;
@@ -1291,6 +1296,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 // exact form for a class of small sigmas (w > FAST_W_MAX, rare): one compact loop, every plane against
                 // every entry of the three sub-buckets (the planes an entry cannot reach fail the cutoff anyway)
                 auto run_exact = [&](unsigned b0, unsigned b1) {
+                    if (MK_DIAG & 1) return;
                     const unsigned s0 = b0 & ~1u;
                     const unsigned n = ((b1 & ~1u) - s0) - (b0 & 1u);
                     const float* e = sxyz + s0;
@@ -1316,6 +1322,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     run_exact(bg.z, bg.w);
                 }
                 // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
+                if (!(MK_DIAG & 2))
 #pragma unroll
                 for (int k = 0; k < KL; ++k) {
                     const float d2 = fast ? m[k] + pl_x(k) * pl_x(k) : m[k];         // (plane_d2: g_k + c_k^2)
@@ -1376,8 +1383,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         if constexpr (!DENSE) {
             // ---- the normal case: one round takes all eight channels; minima stay in q for the epilogue ----
             MK_PHASE_MARK(2);                               // counts -> starts
-            place(0, CHG, 0u, total);
+            if (!(MK_DIAG & 8)) place(0, CHG, 0u, total);
             MK_PHASE_MARK(3);                               // traversal 2 (placement)
+            if (!(MK_DIAG & 8))
 #pragma unroll
             for (int c = 0; c < CHG; ++c) process_classes(c, class_bits(c), q[c]);
             MK_PHASE_MARK(4);                               // pair loops + class flushes
@@ -1491,7 +1499,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         const int x = tg.x0 + kb + k;
         float f[CHG];
 #pragma unroll
-        for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
+        for (int c = 0; c < CHG; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
         if (yz_in && x < g.nx) {
             const size_t vox = (size_t)tg.b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
             if (g.C == CHG) {

@@ -53,7 +53,7 @@ struct LatticeProblem {
     int force_general = 0;                  // 1 = never use the class-sorted path
     int lds_tier = -1;                      // -1 = adaptive (choose_tier), else the ECAP_TIER index to use
     int prepass_mode = -1;                  // -1 = automatic, 0 = multi-kernel chain, 1 = one-launch per-item pre-pass (if it fits)
-    int coarse_cells = 0;                   // 1 = cutoff-sized cells (the round-1 layout; A-B benchmarking)
+    int fine_cells = 0;                     // 1 = half-cutoff cells (A-B benchmarking, see plan_lattice)
     int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
     // device pointers
     const float* coords = nullptr;
@@ -91,12 +91,14 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     g.Rp = R + 1e-3;
     g.rint = (int)std::ceil(R);
     if (g.rint > 512) { err = "voxelsize too small (cutoff spans > 512 voxels)"; return ST_EINVAL; }
-    // cell edge: a power of two in (R/2, R] voxels, at least 4 (1 A grid: 4).  A tile then looks at up to 7 x 7 cell
-    // columns (<= 64: one per lane) whose cells hug its rounded box far better than cutoff-sized cells would: at 1 A the
-    // candidates of a tile drop from 27 x 8^3 = 13 824 A^3 to ~7 200 A^3, against the 3 986 A^3 that survive the exact cull
+    // cell edge: the power of two >= the cutoff radius in voxels (1 A grid: 8), so that a tile looks at <= 3 x 3 x 3 cells.
+    // `fine_cells` halves it (<= 7 x 7 cell columns, one per lane): the candidates of a tile then hug its rounded box
+    // better (at 1 A 7 200 A^3 instead of 27 x 8^3 = 13 824 A^3, against the 3 986 A^3 that survive the exact cull) --
+    // measured round 2: VALU instructions of the tile kernel -2.4 %, scalar ones +10 %, time +1.5 % on cfg2 and +5 % on
+    // cfg3 (eight times the cell counters), so it is not the default
     g.cs_log2 = 3;
     while ((1 << g.cs_log2) < g.rint && g.cs_log2 < 9) ++g.cs_log2;
-    if (g.cs_log2 > 2 && !P.coarse_cells) --g.cs_log2;
+    if (g.cs_log2 > 2 && P.fine_cells) --g.cs_log2;
     g.cs = 1 << g.cs_log2;
     g.h = ceil_div((long long)g.rint + 1, g.cs);
     g.ncx = ceil_div(g.nx, g.cs) + 2 * g.h;

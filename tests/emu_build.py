@@ -46,7 +46,7 @@ def _p(a):
 
 
 def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box=None, max_images=0,
-                     tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None, prepass_mode=-1, tile_team=-1, coarse_cells=False):
+                     tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None, prepass_mode=-1, tile_team=-1, fine_cells=False):
     """feedback: optional uint32[4] array, in = tier statistics of the 'previous call', out = this call's."""
     coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
     atom_offsets = np.ascontiguousarray(atom_offsets, np.int64)
@@ -64,7 +64,7 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
         _p(origins), _p(nvox), ctypes.c_double(voxelsize), _p(bx), ctypes.c_int(max_images),
         ctypes.c_int(tile_k), ctypes.c_int(int(force_general)),
         _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out), ctypes.byref(err),
-        ctypes.c_int(lds_tier), _p(feedback), ctypes.c_int(prepass_mode), ctypes.c_int(tile_team), ctypes.c_int(int(coarse_cells)))
+        ctypes.c_int(lds_tier), _p(feedback), ctypes.c_int(prepass_mode), ctypes.c_int(tile_team), ctypes.c_int(int(fine_cells)))
     if st != 0:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return out, err.value

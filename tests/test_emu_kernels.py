@@ -96,11 +96,11 @@ def test_grid_centers_bit_exact():
 
 def test_plan_choices():
     p = E.plan(1, 50000, 8, [64, 64, 64], 1.0)
-    assert p["K"] == 4 and p["cs"] == 4 and p["h"] == 2 and p["ncx"] == 20      # single grid: more waves; half-cutoff cells
+    assert p["K"] == 4 and p["cs"] == 8 and p["h"] == 1 and p["ncx"] == 10      # single grid: more waves
     p = E.plan(64, 64 * 50000, 8, [64, 64, 64], 1.0)
     assert p["K"] == 8 and p["ntiles"] == 512
     p = E.plan(1000, 35000, 8, [24, 24, 24], 0.5)
-    assert p["cs"] == 8 and p["rint"] == 10 and p["G"] == 1
+    assert p["cs"] == 16 and p["rint"] == 10 and p["G"] == 1
     p = E.plan(4, 100, 11, [12, 24, 24], 1.0)
     assert p["K"] == 4 and p["G"] == 2                                          # x extent pads badly with K=8
     with pytest.raises(RuntimeError):
@@ -264,13 +264,13 @@ def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
 
 @pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "pbc_batch", "voxel07", "voxel025", "voxel2", "tiny_items", "sorted_atoms"])
 def test_cell_size_only_moves_the_last_bits(name):
-    """Half-cutoff cells (the default: fewer candidates per tile) against cutoff-sized ones: the cells decide which
+    """Half-cutoff cells (an A-B knob: fewer candidates per tile) against the cutoff-sized default: the cells decide which
     records a tile looks at before the exact cull, and the magnitude at which the cell-relative float32 offsets are
     rounded (smaller cells round finer) -- values agree to float32 noise, both within the parity bound."""
     case = LATTICE_CASES[name]()
     args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
-    fine, e1 = E.voxelize_lattice(*args, box=case["box"], tile_k=8)
-    coarse, e2 = E.voxelize_lattice(*args, box=case["box"], tile_k=8, coarse_cells=True)
+    fine, e1 = E.voxelize_lattice(*args, box=case["box"], tile_k=8, fine_cells=True)
+    coarse, e2 = E.voxelize_lattice(*args, box=case["box"], tile_k=8)
     assert e1 == 0 and e2 == 0
     assert np.abs(fine.astype(np.float64) - coarse).max() <= 5e-6
     check(case, fine)
