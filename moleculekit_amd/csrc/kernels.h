@@ -884,8 +884,14 @@ struct TileGeom {                     // wave-uniform description of the tile be
 struct CandChunk {                    // one chunk of 64 candidate records (one per lane), loads in flight
     float4 P;
     unsigned r, ids;
+    unsigned code;                    // (run << SURV_OFF_BITS) | offset inside the run: what the survivor list keeps of a record
     bool valid;
 };
+// Survivor list of the tile kernel: the records that pass the cull, as 16-bit (run, offset) codes in the ~1 KB of LDS the
+// tile has to spare.  The cull is then evaluated ONCE, and the histogram and placement passes walk ~290 survivors
+// (5 chunks) instead of ~1000 candidates (18 chunks) each; their per-record channel loops run over dense lanes.
+constexpr int SURV_CAP = 480;
+constexpr int SURV_OFF_BITS = 10;
 
 // The candidate runs of a tile: lane j < ncols holds the record range of cell column j (one load round trip) -- the
 // z-cells of a column are adjacent in memory -- trimmed to the cells that can hold an atom within the cutoff of the tile
@@ -894,6 +900,7 @@ struct CandChunk {                    // one chunk of 64 candidate records (one 
 // lengths are.  Found once per tile and shared by every traversal.
 struct CandRuns {
     unsigned r0, len, pre, N, T;
+    bool codable;                     // every run is short enough for the 16-bit survivor codes
 #ifdef MK_PHASE_TIMERS
     mutable unsigned long long wait_ = 0, proc_ = 0;
 #endif
@@ -932,6 +939,7 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
     cr.pre = incl - cr.len;
     cr.N = mk_readlane(incl, WAVE - 1);
     cr.T = (cr.N + (WAVE - 1)) >> 6;
+    cr.codable = mk_ballot(cr.len > (1u << SURV_OFF_BITS)) == 0ull;      // (run index < 64: 6 bits)
     return cr;
 }
 
@@ -953,7 +961,7 @@ MK_DEV void cand_issue(const CandLoader& L, unsigned t, CandChunk& ch)
     const unsigned* __restrict__ rec_cls = L.rec_cls;
     {
         const int lane = threadIdx.x & (WAVE - 1);
-        ch.r = 0u; ch.valid = false; ch.ids = 0u;
+        ch.r = 0u; ch.valid = false; ch.ids = 0u; ch.code = 0u;
         ch.P = make_float4(0.f, 0.f, 0.f, 0.f);
         if (t < cr.T) {                                              // wave-uniform
             // candidate numbers [64 t, 64 t + 64): the runs that overlap them (a handful), each claimed by its lanes
@@ -963,7 +971,7 @@ MK_DEV void cand_issue(const CandLoader& L, unsigned t, CandChunk& ch)
                 const int j = mk_ctz64(over);
                 over &= over - 1ull;
                 const unsigned pj = mk_readlane(cr.pre, j), lj = mk_readlane(cr.len, j), rj = mk_readlane(cr.r0, j);
-                if (n - pj < lj) { ch.r = rj + (n - pj); ch.valid = true; }      // unsigned: pj <= n < pj + lj
+                if (n - pj < lj) { ch.r = rj + (n - pj); ch.code = ((unsigned)j << SURV_OFF_BITS) | (n - pj); ch.valid = true; }   // unsigned: pj <= n < pj + lj
             }
             if (ch.valid) {
                 ch.P = rec_pos[ch.r];
@@ -973,7 +981,7 @@ MK_DEV void cand_issue(const CandLoader& L, unsigned t, CandChunk& ch)
     }
 }
 
-template <int K, class F>
+template <int K, class F, bool LOAD_CODE = false>
 MK_DEV void cand_consume(const CandLoader& L, const CandChunk& ch, F&& f)
 {
     const GridDesc& g = L.g;
@@ -989,11 +997,11 @@ MK_DEV void cand_consume(const CandLoader& L, const CandChunk& ch, F&& f)
         const float gy = fmaxf(fabsf(ey) - 3.5f, 0.f);
         const float gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
         const bool surv = ch.valid && (gx * gx + gy * gy + gz * gz < g.R2cull);
-        f(surv, ch.r, ex, ey, ez, ch.ids);
+        f(surv, LOAD_CODE ? ch.code : ch.r, ex, ey, ez, ch.ids);
     }
 }
 
-template <int K, bool LOAD_CLS, int BATCH, class F>
+template <int K, bool LOAD_CLS, int BATCH, class F, bool LOAD_CODE = false>
 MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const CandRuns& cr,
                                const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls, F&& f,
                                unsigned first_batch = 0u, unsigned batch_stride = 1u)
@@ -1016,7 +1024,7 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
 #endif
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
-            if (t + (unsigned)k < T) cand_consume<K>(ld, ch[k], f);      // wave-uniform
+            if (t + (unsigned)k < T) cand_consume<K, F&, LOAD_CODE>(ld, ch[k], f);      // wave-uniform
 #ifdef MK_PHASE_TIMERS
         const unsigned long long tc_ = __builtin_readcyclecounter();
         cr.wait_ += tb_ - ta_; cr.proc_ += tc_ - tb_;                 // flushed at the end of the tile
@@ -1104,6 +1112,14 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #endif
     // per-tile histogram -> placement cursors -> (after placement) sub-bucket starts again; [NBUCKET3] = end
     __shared__ unsigned bucket[NBUCKET3 + 1];
+#ifdef MK_NO_SURV_LIST                                 // A-B builds (tools/gpu_ab.sh): the two-traversal kernel of round 1
+    constexpr bool SURV_LIST = false;
+#else
+    // the hot kernel culls once and keeps the survivors (see SURV_CAP) -- on the leanest LDS tier only: the list's 960 bytes
+    // fit the 10 KiB a tile may take at 4 waves per SIMD there, on the bigger tiers they would cost a wave per CU or two
+    constexpr bool SURV_LIST = TEAM == 1 && !DENSE && ECAP == ECAP_TIER[0];
+#endif
+    __shared__ unsigned short s_surv[SURV_LIST ? SURV_CAP : 2];
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
@@ -1193,7 +1209,51 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         CandChunk kept[TEAM_KEEP];
         const bool keep = TEAM > 1 && runs.T <= (unsigned)(TEAM_KEEP * TEAM);                 // the same in every wave
         const CandLoader loader{g, tg, runs, rec_pos, clsp};
+        // ---- the hot kernel: ONE pass over the candidates (cull + compaction of the survivors' codes), then the
+        //      histogram over the survivors only ----
+        unsigned nsurv = 0u;                                  // wave-uniform
+        bool use_list = false;
+        // survivor i of the list: its record again (an L2-hot gather), tile-relative; f(valid, ., x, y, z, class ids)
+        auto for_each_survivor = [&](auto&& f) {
+            for (unsigned i0 = 0; i0 < nsurv; i0 += 2 * WAVE) {          // two chunks' loads in flight
+                float4 P[2]; unsigned ids[2]; bool ok[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned i = i0 + (unsigned)(u * WAVE + lane);
+                    ok[u] = i < nsurv;
+                    const unsigned code = ok[u] ? (unsigned)s_surv[i] : 0u;
+                    const unsigned r = mk_shfl(runs.r0, (int)(code >> SURV_OFF_BITS)) + (code & ((1u << SURV_OFF_BITS) - 1u));
+                    P[u] = make_float4(0.f, 0.f, 0.f, 0.f); ids[u] = 0u;
+                    if (ok[u]) { P[u] = rec_pos[r]; ids[u] = clsp[r]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (i0 + (unsigned)(u * WAVE) >= nsurv) break;        // wave-uniform
+                    const int pk = mk_float_as_int(P[u].w);
+                    const float ex = P[u].x + ((float)(pk & 1023) * tg.fcs + tg.offx);
+                    const float ey = P[u].y + ((float)((pk >> 10) & 1023) * tg.fcs + tg.offy);
+                    const float ez = P[u].z + ((float)((pk >> 20) & 1023) * tg.fcs + tg.offz);
+                    f(ok[u], 0u, ex, ey, ez, ids[u]);
+                }
+            }
+        };
+        if constexpr (SURV_LIST) {
+            // (worth it when most candidates are rejected, i.e. when there are many: a sparse tile's few chunks go the old way)
+            if (!(MK_DIAG & 16) && runs.codable && runs.N > 4u * WAVE) {
+                auto keep_survivor = [&](bool surv, unsigned code, float, float, float, unsigned) {
+                    const unsigned long long m = mk_ballot(surv);
+                    const unsigned pos = nsurv + (unsigned)mk_rank_in_mask(m);
+                    if (surv && pos < (unsigned)SURV_CAP) s_surv[pos] = (unsigned short)code;
+                    nsurv += (unsigned)mk_popc64(m);
+                };
+                for_each_candidate<K, false, TRAV_BATCH, decltype(keep_survivor)&, true>(g, tg, runs, rec_pos, clsp, keep_survivor);
+                use_list = nsurv <= (unsigned)SURV_CAP;
+                mk_block_sync();                              // the list is read by other lanes than wrote it
+                if (use_list) for_each_survivor(count_entry);
+            }
+        }
         if (MK_DIAG & 16) {
+        } else if (use_list) {
         } else if (keep) {
 #pragma unroll
             for (int i = 0; i < TEAM_KEEP; ++i) cand_issue<true>(loader, (unsigned)(wv + i * TEAM), kept[i]);
@@ -1361,7 +1421,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
                 });
             };
-            if (keep) {
+            if (use_list) {
+                for_each_survivor(place_entry);
+            } else if (keep) {
 #pragma unroll
                 for (int i = 0; i < TEAM_KEEP; ++i)
                     if ((unsigned)(wv + i * TEAM) < runs.T) cand_consume<K>(loader, kept[i], place_entry);
