@@ -139,6 +139,13 @@ int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t n_items, const float* co
                                 int sigmas_are_f64, int32_t n_channels, const double* origins,
                                 const int32_t* nvoxels, double voxelsize, const float* box,
                                 int32_t max_images_per_atom, float* features);
+/* the same with float64 features [B,V,C] -- the dtype the reference's _getOccupancyC returns (voxeldescriptors.py:531);
+ * values are the float32 results widened (in the pass that takes them out of the pinned result buffer) */
+int mkamd_voxelize_lattice_host_f64(mkamd_ctx* ctx, int32_t n_items, const float* coords,
+                                    const int64_t* atom_offsets, const void* sigmas,
+                                    int sigmas_are_f64, int32_t n_channels, const double* origins,
+                                    const int32_t* nvoxels, double voxelsize, const float* box,
+                                    int32_t max_images_per_atom, double* features);
 int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_coords,
                                const int64_t* d_atom_offsets, int64_t total_atoms,
                                const void* d_sigmas, int sigmas_are_f64, int32_t n_channels,

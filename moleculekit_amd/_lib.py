@@ -47,6 +47,8 @@ SIGNATURES = {
     "mkamd_occupancy_centers_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp]),
     "mkamd_voxelize_lattice_host": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl,
                                              _vp, _c_i32, _vp]),
+    "mkamd_voxelize_lattice_host_f64": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl,
+                                                 _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
                                             _c_dbl, _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_aug_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
@@ -223,7 +225,8 @@ class Context:
 
     def voxelize_lattice_host(self, B, coords, offsets, sigmas, sig_f64, C, origins, nvox, voxelsize, box,
                               max_images, out):
-        _check(load().mkamd_voxelize_lattice_host(self._h, B, _ptr(coords), _ptr(offsets), _ptr(sigmas),
+        fn = load().mkamd_voxelize_lattice_host_f64 if out.dtype == np.float64 else load().mkamd_voxelize_lattice_host
+        _check(fn(self._h, B, _ptr(coords), _ptr(offsets), _ptr(sigmas),
                                                   int(sig_f64), C, _ptr(origins), _ptr(nvox), float(voxelsize),
                                                   _ptr(box), int(max_images), _ptr(out)))
 

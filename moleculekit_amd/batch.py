@@ -77,8 +77,8 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, 
         bx = np.ascontiguousarray(box, dtype=np.float32).reshape(B, 3)
     if out is None:
         out = np.empty((B, V, C), dtype=np.float32)
-    elif out.dtype != np.float32 or not out.flags["C_CONTIGUOUS"] or out.size != B * V * C:
-        raise ValueError("out must be a C-contiguous float32 array of B*V*C elements")
+    elif out.dtype not in (np.float32, np.float64) or not out.flags["C_CONTIGUOUS"] or out.size != B * V * C:
+        raise ValueError("out must be a C-contiguous float32 (or float64: widened by the library) array of B*V*C elements")
     ctx.voxelize_lattice_host(B, coords, atom_offsets, sigmas, sig64, C, origins, nv, float(voxelsize), bx, 0, out)
     return out.reshape(B, V, C)
 

@@ -79,6 +79,7 @@ struct mkamd_ctx {
     void* stage_host_dev = nullptr;        // device-side address of the same memory (mapped): tiny inputs are read in place
     size_t stage_cap = 0;
     std::vector<uint32_t> contacts_host;   // result of the last mkamd_contacts_trajectory_host call (owned here)
+    std::vector<float> f32_stage;          // host staging of big float64-out results
     void* out_host = nullptr;              // pinned, device-mapped result buffer of small _host calls (no D2H copy)
     void* out_host_dev = nullptr;          // its device-side address
     // tile-kernel timing
@@ -563,11 +564,13 @@ try {
     return st;
 } MK_API_CATCH
 
-int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
-                                const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
-                                const int32_t* nvoxels, double voxelsize, const float* box,
-                                int32_t max_images, float* features)
-try {
+// `features64` != NULL: the caller wants the reference's float64 [B,V,C] (voxeldescriptors.py:531); the widening is
+// done here, in the pass that takes the results out of the pinned buffer anyway, instead of in a second pass in numpy
+static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                      const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                      const int32_t* nvoxels, double voxelsize, const float* box,
+                                      int32_t max_images, float* features, double* features64)
+{
     int st = check_ctx(ctx);
     if (st) return st;
     if (B < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_items must be >= 0 and n_channels > 0");
@@ -575,7 +578,7 @@ try {
     if (nvoxels[0] < 0 || nvoxels[1] < 0 || nvoxels[2] < 0) return fail(MKAMD_EINVAL, "nvoxels must be >= 0");
     const long long V = (long long)nvoxels[0] * nvoxels[1] * nvoxels[2];
     if (B == 0 || V == 0) return MKAMD_OK;
-    if (!atom_offsets || !origins || !features) return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
+    if (!atom_offsets || !origins || (!features && !features64)) return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
     if (atom_offsets[0] != 0) return fail(MKAMD_EINVAL, "atom_offsets[0] must be 0");
     for (int b = 0; b < B; ++b)
         if (atom_offsets[b + 1] < atom_offsets[b]) return fail(MKAMD_EINVAL, "atom_offsets must be non-decreasing");
@@ -659,10 +662,40 @@ try {
                                     max_images, (float*)dout);
     ctx->prepass_mode = saved_mode;
     if (st) return st;
+    const size_t nvals = out_bytes / 4;
+    if (features64) {
+        const float* src = (const float*)ctx->out_host;
+        if (!mapped_out) {                                    // big result: through a host staging vector
+            ctx->f32_stage.resize(nvals);
+            HIP_TRY(hipMemcpyAsync(ctx->f32_stage.data(), dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            src = ctx->f32_stage.data();
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < nvals; ++i) features64[i] = (double)src[i];
+        return collect_async_errors(ctx);
+    }
     if (!mapped_out) HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (mapped_out) memcpy(features, ctx->out_host, out_bytes);
     return collect_async_errors(ctx);
+}
+
+int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                const int32_t* nvoxels, double voxelsize, const float* box,
+                                int32_t max_images, float* features)
+try {
+    return voxelize_lattice_host_impl(ctx, B, coords, atom_offsets, sigmas, sigmas_are_f64, C, origins, nvoxels, voxelsize, box,
+                                      max_images, features, nullptr);
+} MK_API_CATCH
+
+int mkamd_voxelize_lattice_host_f64(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                    const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                    const int32_t* nvoxels, double voxelsize, const float* box,
+                                    int32_t max_images, double* features)
+try {
+    return voxelize_lattice_host_impl(ctx, B, coords, atom_offsets, sigmas, sigmas_are_f64, C, origins, nvoxels, voxelsize, box,
+                                      max_images, nullptr, features);
 } MK_API_CATCH
 
 // ---------------------------------------------------------------------------------------------

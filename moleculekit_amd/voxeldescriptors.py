@@ -83,12 +83,26 @@ def _gridSpec(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
     return bb_min, nvoxels
 
 
+_CENTERS_CACHE = {}          # (bb_min bytes, nvoxels, voxelsize) -> centres; a handful of entries (one pocket, many poses)
+
+
 def _centersFromSpec(bb_min, nvoxels, voxelsize):
     """``(lattice + bb_min).reshape(V, 3).copy()`` of the reference (:245-247) in one pass over the array: the sum
-    is written straight into the [V, 3] result (same values, float64, C-contiguous, owns its data)."""
+    is written straight into the [V, 3] result (same values, float64, C-contiguous, owns its data).  Repeated calls on
+    the same grid (a screening loop voxelizes thousands of poses in one pocket box) get a copy of the cached array
+    -- a memcpy instead of the broadcast add; every caller still owns what it gets, like with the reference."""
     nx, ny, nz = (int(v) for v in nvoxels)
+    bb = np.asarray(bb_min)
+    key = (bb.dtype.str, bb.tobytes(), nx, ny, nz, float(voxelsize))
+    hit = _CENTERS_CACHE.get(key)
+    if hit is not None:
+        return hit.copy()
     centers = np.empty((nx * ny * nz, 3), dtype=np.float64)
     np.add(_getGridCenters(nx, ny, nz, voxelsize), bb_min, out=centers.reshape(nx, ny, nz, 3))
+    if len(_CENTERS_CACHE) >= 4:
+        _CENTERS_CACHE.pop(next(iter(_CENTERS_CACHE)))
+    if centers.nbytes <= (64 << 20):
+        _CENTERS_CACHE[key] = centers.copy()
     return centers
 
 
@@ -228,10 +242,11 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
     if lattice is not None:
         bb_min, nvoxels, voxelsize = lattice
         offs = np.array([0, coords.shape[0]], dtype=np.int64)
-        feats = _batch.voxelize_lattice(coords, offs, channelsigmas, np.asarray(bb_min, np.float64)[None, :],
-                                        nvoxels, voxelsize)[0]
-    else:
-        feats = _batch.occupancy_centers(centers, coords, channelsigmas)
+        V = int(np.prod(np.asarray(nvoxels, dtype=np.int64)))
+        out = np.empty((1, V, channelsigmas.shape[1]), dtype=np.float64)     # the library widens while copying out
+        return _batch.voxelize_lattice(coords, offs, channelsigmas, np.asarray(bb_min, np.float64)[None, :],
+                                       nvoxels, voxelsize, out=out)[0]
+    feats = _batch.occupancy_centers(centers, coords, channelsigmas)
     return feats.astype(np.float64)
 
 

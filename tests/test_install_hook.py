@@ -32,9 +32,11 @@ def test_install_swaps_and_uninstall_restores(stub_moleculekit, monkeypatch):
     import moleculekit_amd.voxeldescriptors as mine
     calls = []
 
-    def fake_lattice(coords, offs, sigmas, origins, nvoxels, voxelsize, **kw):
+    def fake_lattice(coords, offs, sigmas, origins, nvoxels, voxelsize, out=None, **kw):
         calls.append(("lattice", coords.dtype, sigmas.dtype, tuple(int(v) for v in nvoxels), float(voxelsize)))
-        return np.zeros((1, int(np.prod(nvoxels)), sigmas.shape[1]), np.float32)
+        assert out is not None and out.dtype == np.float64          # the library widens while copying out
+        out[...] = 0.0
+        return out
 
     def fake_centers(centers, coords, sigmas, **kw):
         calls.append(("centers", centers.shape))
