@@ -109,7 +109,7 @@ def pmc_traffic(workload, batch, tile_k):
     if d.get("_items_per_launch") != batch:
         return None, None
     for k, v in d.items():
-        if isinstance(v, dict) and "k_voxelize_tiles<8" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        if isinstance(v, dict) and ("k_voxelize_tiles<8" in k or "k_voxelize_tiles_lean<8" in k) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024), os.path.relpath(files[-1], ROOT)
     return None, None
 

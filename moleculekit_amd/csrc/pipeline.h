@@ -344,7 +344,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
     // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
     const bool team = P.tile_team > 0 || (P.tile_team < 0 && (unsigned long long)total_tiles * (unsigned)g.G <= 1024ull);
+#ifdef MK_NO_LEAN                                       // A-B builds: the plain kernel also beside the pre-pass
+    const int flavour = team ? TILES_TEAM : TILES_PLAIN;
+#else
     const int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
+#endif
     be.hot_begin();
     st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
                   : launch_tiles<4>(be, tier, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);

@@ -1,0 +1,12 @@
+# tools/gpu_r2_final.sh -- the round-2 evidence session: everything profiles/r2_* is made from
+bash tools/gpu_r2a.sh > gpurun_out/session_a.txt 2>&1
+bash tools/gpu_pmc.sh > gpurun_out/session_pmc.txt 2>&1
+bash tools/gpu_diag.sh > gpurun_out/diag_breakdown.txt 2>&1
+(timeout 600 python tools/latency_probe.py > gpurun_out/latency_probe.txt 2>&1)
+(timeout 300 python bench.py --workload dist > gpurun_out/bench_distance.log 2>&1; echo "rc=$?" >> gpurun_out/bench_distance.log)
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+rm -rf gpurun_out/prof_cfg2_nopipe
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py --no-cpu-baseline --no-extra --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
+f=$(find gpurun_out/prof_cfg2_nopipe -name "*kernel_trace.csv" | head -1); python tools/timeline.py $f 12 2 > gpurun_out/timeline_prof_cfg2_nopipe.txt 2>&1
+for wl in cfg3 cfg4; do rm -rf gpurun_out/prof_$wl; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py --no-cpu-baseline --no-extra --workload $wl --steps 5 > $R/gpurun_out/rocprof_$wl.log 2>&1); done
+tail -5 gpurun_out/session_a.txt | cut -c1-300; cat gpurun_out/diag_breakdown.txt | tail -7; tail -4 gpurun_out/latency_probe.txt
