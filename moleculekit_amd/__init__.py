@@ -7,8 +7,8 @@
 Hand-written HIP kernels (gfx950) behind a C ABI (include/mkamd_voxel.h, libmkamd.so); Python is
 the host side only.  See DESIGN.md / INTEGRATION.md.
 """
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 from .voxeldescriptors import (  # noqa: F401
-    getCenters, getVoxelDescriptors, rotateCoordinates, install,
+    getCenters, getVoxelDescriptors, rotateCoordinates, install, uninstall,
 )

@@ -250,7 +250,7 @@ static int ensure_err_flag(mkamd_ctx* ctx)
 
 extern "C" {
 
-const char* mkamd_version(void) { return "moleculekit_amd 0.1.0 (gfx950, HIP)"; }
+const char* mkamd_version(void) { return "moleculekit_amd 0.2.0 (gfx950, HIP)"; }
 
 const char* mkamd_last_error(void) { return g_last_error; }
 
