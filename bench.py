@@ -549,6 +549,19 @@ def main():
         }
         if extra:
             line["other_workloads" if world == 1 else "batched_molecules"] = extra
+        if world == 1 and not args.no_extra and args.workload == "cfg2":
+            # the reference's own call pattern: ONE molecule per synchronous call, host arrays in, float64 [V, C] out
+            # (BASELINE.json configs[0]: 3PTB, 24^3 @ 1 A) -- what a user who only swaps the import sees
+            from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
+            g3 = np.load(os.path.join(ROOT, "tests", "golden", "cfg1_3ptb.npz"))
+            kw = dict(boxsize=[24, 24, 24], center=g3["center"], voxelsize=1, usercoords=g3["coords"], userchannels=g3["sigmas"])
+            for _ in range(5):
+                f3, _, _ = getVoxelDescriptors(None, **kw)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                f3, _, _ = getVoxelDescriptors(None, **kw)
+            line["dropin_call_ms"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
+            line["dropin_max_abs_err_vs_reference"] = float(np.abs(f3 - g3["features"]).max())
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
