@@ -116,6 +116,17 @@ struct mkamd_ctx {
         HIP_TRY(hipMemsetAsync(p, byte, bytes, stream));
         return 0;
     }
+    int to_host(void* dst, const void* src_dev, size_t bytes)
+    {
+        HIP_TRY(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int to_device(void* dst_dev, const void* src, size_t bytes)
+    {
+        HIP_TRY(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, stream));
+        return 0;
+    }
     template <class... KA, class... A>
     int launch(void (*kernel)(KA...), dim3 grid, dim3 block, A... args)
     {
@@ -799,55 +810,22 @@ try {
     for (int64_t f = 0; f <= F; ++f) frame_offsets[f] = 0;
     const int64_t P = count_pairs(n1, n2, selfdist);
     if (F == 0 || P == 0) return MKAMD_OK;
-    if (P >= 0xffffffffLL) return fail(MKAMD_EINVAL, "too many atom pairs (>= 2^32); split the selections");
     if (!coords || !box || !sel1 || !sel2 || !chains) return fail(MKAMD_EINVAL, "NULL pointer");
     for (int64_t i = 0; i < n1; ++i) if (sel1[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel1 index out of range");
     for (int64_t i = 0; i < n2; ++i) if (sel2[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel2 index out of range");
-    void *dc, *db, *d1, *d2, *dch, *pa, *pb, *wr, *cnt, *tot, *base, *dout = nullptr;
+    void *dc, *db, *d1, *d2, *dch;
     if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
     if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
     if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
     if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
     if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
-    if ((st = ctx->ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
-    if ((st = ctx->ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
-    if ((st = ctx->ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
-    if ((st = ctx->launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256),
-                          (const unsigned*)d1, (long long)n1, (const unsigned*)d2, (long long)n2, (const unsigned*)dch, selfdist, pbc,
-                          (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
-    // frames per chunk: the per-(tile, frame) counters stay within ~256 MiB whatever the number of pairs
-    const long long tiles = ceil_div(P, DT);
-    long long chunk = ((long long)(256u << 20) / (tiles * 4)) / DT * DT;
-    chunk = std::max<long long>(DT, std::min<long long>(chunk, ((long long)F + DT - 1) / DT * DT));
-    chunk = std::min<long long>(chunk, 65535LL * DT);
-    const float thr2 = dist_threshold * dist_threshold;              // `float dist_threshold` squared in float (:73)
-    if ((st = ctx->ensure(WS_D_CNT, (size_t)tiles * chunk * 4, &cnt, 0))) return st;
-    if ((st = ctx->ensure(WS_D_TOT, (size_t)chunk * 8, &tot, 0))) return st;
-    if ((st = ctx->ensure(WS_D_BASE, (size_t)chunk * 8, &base, 0))) return st;
-    std::vector<unsigned long long> totals((size_t)chunk), bases((size_t)chunk);
-    for (long long f0 = 0; f0 < F; f0 += chunk) {
-        const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
-        const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
-        if ((st = ctx->launch(k_contacts_count, grid, dim3(DT_THREADS), (const float*)dc, (long long)F, f0, fc, fc_pad, (const float*)db,
-                              (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, (long long)P, thr2, (unsigned*)cnt))) return st;
-        if ((st = ctx->launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(DT_THREADS), (unsigned*)cnt, tiles, fc_pad,
-                              (unsigned long long*)tot))) return st;
-        HIP_TRY(hipMemcpyAsync(totals.data(), tot, (size_t)fc_pad * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        unsigned long long run = 0;
-        for (long long i = 0; i < fc_pad; ++i) { bases[(size_t)i] = run; run += i < fc ? totals[(size_t)i] : 0ull; }
-        for (long long i = 0; i < fc; ++i) frame_offsets[f0 + i + 1] = frame_offsets[f0 + i] + (int64_t)totals[(size_t)i];
-        if (run == 0) continue;
-        if ((st = ctx->ensure(WS_H_OUT, (size_t)run * 8, &dout, 0))) return st;
-        HIP_TRY(hipMemcpyAsync(base, bases.data(), (size_t)fc_pad * 8, hipMemcpyHostToDevice, ctx->stream));
-        if ((st = ctx->launch(k_contacts_fill, grid, dim3(DT_THREADS), (const float*)dc, (long long)F, f0, fc, fc_pad, (const float*)db,
-                              (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, (long long)P, thr2, (const unsigned*)cnt,
-                              (const unsigned long long*)base, (uint2*)dout))) return st;
-        const size_t old = ctx->contacts_host.size();
-        ctx->contacts_host.resize(old + (size_t)run * 2);
-        HIP_TRY(hipMemcpyAsync(ctx->contacts_host.data() + old, dout, (size_t)run * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-    }
+    std::string err;
+    static_assert(sizeof(long long) == sizeof(int64_t), "frame offsets are int64");
+    st = run_contacts(*ctx, (const float*)dc, (long long)F, (const float*)db, (const unsigned*)d1, (long long)n1, (const unsigned*)d2,
+                      (long long)n2, (const unsigned*)dch, selfdist, pbc, dist_threshold, (size_t)256 << 20,
+                      (long long*)frame_offsets, ctx->contacts_host, err);
+    if (st) return err.empty() ? st : fail(st, err);
+    if (ctx->contacts_host.empty()) return MKAMD_OK;
     *pairs = ctx->contacts_host.data();
     return MKAMD_OK;
 } MK_API_CATCH

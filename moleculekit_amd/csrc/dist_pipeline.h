@@ -3,6 +3,8 @@
 #include "dist_kernels.h"
 #include "pipeline.h"
 
+#include <vector>
+
 namespace mkamd {
 
 inline long long count_pairs(long long n1, long long n2, int selfdist)
@@ -69,6 +71,63 @@ int run_dist_reduction(BE& be, const float* coords, long long F, const float* bo
     return be.launch(k_dist_reduction, dim3((unsigned)ceil_div(P, DT), (unsigned)ceil_div(F, DT)), dim3(DT_THREADS), c1, c2, F, box,
                      g1_atoms, g1_off, g2_atoms, g2_off, reduction1, reduction2, (const unsigned*)ga, (const unsigned*)gb,
                      (const unsigned*)wr, P, out);
+}
+
+// contacts_trajectory / get_collisions on device pointers (dist_kernels.h: count -> scan -> fill per chunk of frames).
+// Besides the usual backend concept the backend provides
+//   int to_host(void* dst, const void* src_dev, size_t bytes)     copy out and wait for it (and for the kernels before it)
+//   int to_device(void* dst_dev, const void* src, size_t bytes)   copy in (stream-ordered)
+// `budget_bytes` bounds the per-(pair tile, frame) counters: it decides how many frames go in one chunk.
+// frame_offsets [F+1] and `pairs` (2 x uint32 per contact, frames concatenated) are host-side results.
+template <class BE>
+int run_contacts(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
+                 const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, float dist_threshold,
+                 size_t budget_bytes, long long* frame_offsets, std::vector<unsigned>& pairs, std::string& err)
+{
+    pairs.clear();
+    for (long long f = 0; f <= F; ++f) frame_offsets[f] = 0;
+    if (F < 0 || n1 < 0 || n2 < 0) { err = "negative size"; return ST_EINVAL; }
+    const long long P = count_pairs(n1, n2, selfdist);
+    if (F == 0 || P == 0) return ST_OK;
+    if (P >= 0xffffffffLL) { err = "too many atom pairs (>= 2^32); split the selections"; return ST_EINVAL; }
+    void *pa = nullptr, *pb = nullptr, *wr = nullptr, *cnt = nullptr, *tot = nullptr, *base = nullptr, *dout = nullptr;
+    int st;
+    if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
+    if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
+    if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
+    if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
+                        chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
+    // frames per chunk: the per-(tile, frame) counters stay within the budget whatever the number of pairs
+    const long long tiles = ceil_div(P, DT);
+    long long chunk = ((long long)budget_bytes / (tiles * 4)) / DT * DT;
+    chunk = std::max<long long>(DT, std::min<long long>(chunk, (F + DT - 1) / DT * DT));
+    chunk = std::min<long long>(chunk, 65535LL * DT);
+    const float thr2 = dist_threshold * dist_threshold;              // `float dist_threshold` squared in float (:73)
+    if ((st = be.ensure(WS_D_CNT, (size_t)tiles * chunk * 4, &cnt, 0))) return st;
+    if ((st = be.ensure(WS_D_TOT, (size_t)chunk * 8, &tot, 0))) return st;
+    if ((st = be.ensure(WS_D_BASE, (size_t)chunk * 8, &base, 0))) return st;
+    std::vector<unsigned long long> totals((size_t)chunk), bases((size_t)chunk);
+    for (long long f0 = 0; f0 < F; f0 += chunk) {
+        const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
+        const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
+        if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
+                            (const unsigned*)wr, P, thr2, (unsigned*)cnt))) return st;
+        if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(DT_THREADS), (unsigned*)cnt, tiles, fc_pad,
+                            (unsigned long long*)tot))) return st;
+        if ((st = be.to_host(totals.data(), tot, (size_t)fc_pad * 8))) return st;
+        unsigned long long run = 0;
+        for (long long i = 0; i < fc_pad; ++i) { bases[(size_t)i] = run; run += i < fc ? totals[(size_t)i] : 0ull; }
+        for (long long i = 0; i < fc; ++i) frame_offsets[f0 + i + 1] = frame_offsets[f0 + i] + (long long)totals[(size_t)i];
+        if (run == 0) continue;
+        if ((st = be.ensure(WS_H_OUT, (size_t)run * 8, &dout, 0))) return st;
+        if ((st = be.to_device(base, bases.data(), (size_t)fc_pad * 8))) return st;
+        if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
+                            (const unsigned*)wr, P, thr2, (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
+        const size_t old = pairs.size();
+        pairs.resize(old + (size_t)run * 2);
+        if ((st = be.to_host(pairs.data() + old, dout, (size_t)run * 8))) return st;
+    }
+    return ST_OK;
 }
 
 template <class BE>

@@ -33,6 +33,8 @@ struct EmuBackend {
         return 0;
     }
     int fill(void* p, int byte, size_t bytes) { memset(p, byte, bytes); return 0; }
+    int to_host(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
+    int to_device(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
     template <class... KA, class... A>
     int launch(void (*kernel)(KA...), dim3 grid, dim3 block, A... args)
     {
@@ -138,6 +140,20 @@ int emu_dist_reduction(const float* coords, long long F, const float* box, const
 {
     EmuBackend be;
     return run_dist_reduction(be, coords, F, box, g1a, g1o, ng1, g2a, g2o, ng2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out, g_err);
+}
+
+// contacts_trajectory: frame_offsets [F+1]; pairs_out (capacity 2*cap uint32) gets the (a, b) pairs; returns the count in *n_out
+int emu_contacts(const float* coords, long long F, const float* box, const unsigned* sel1, long long n1, const unsigned* sel2,
+                 long long n2, const unsigned* chains, int selfdist, int pbc, float threshold, long long budget_bytes,
+                 long long* frame_offsets, unsigned* pairs_out, long long cap, long long* n_out)
+{
+    EmuBackend be;
+    std::vector<unsigned> pairs;
+    const int st = run_contacts(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, threshold, (size_t)budget_bytes,
+                                frame_offsets, pairs, g_err);
+    *n_out = (long long)(pairs.size() / 2);
+    if (!st && (long long)(pairs.size() / 2) <= cap) memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(unsigned));
+    return st;
 }
 
 int emu_cdist(const float* c1, long long n1, const float* c2, long long n2, int D, float* out)

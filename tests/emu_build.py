@@ -157,6 +157,26 @@ def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masse
     return out
 
 
+def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshold, budget_bytes=256 << 20):
+    """-> per-frame list of flat [a0, b0, a1, b1, ...] lists (the reference's return shape), through the device-side
+    count / scan / fill kernels; a tiny `budget_bytes` forces several chunks of frames."""
+    coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
+    sel1 = np.ascontiguousarray(sel1, np.uint32); sel2 = np.ascontiguousarray(sel2, np.uint32)
+    chains = np.ascontiguousarray(chains, np.uint32)
+    F = coords.shape[2]
+    cap = F * _npairs(len(sel1), len(sel2), selfdist)
+    offs = np.zeros(F + 1, np.int64)
+    pairs = np.zeros(2 * max(cap, 1), np.uint32)
+    n = ctypes.c_longlong(0)
+    st = lib().emu_contacts(_p(coords), ctypes.c_longlong(F), _p(box), _p(sel1), ctypes.c_longlong(len(sel1)), _p(sel2),
+                            ctypes.c_longlong(len(sel2)), _p(chains), ctypes.c_int(int(selfdist)), ctypes.c_int(int(pbc)),
+                            ctypes.c_float(threshold), ctypes.c_longlong(budget_bytes), _p(offs), _p(pairs), ctypes.c_longlong(cap),
+                            ctypes.byref(n))
+    assert st == 0, lib().emu_last_error()
+    flat = pairs[:2 * n.value].astype(np.int64)
+    return [flat[2 * offs[f]:2 * offs[f + 1]].tolist() for f in range(F)]
+
+
 def cdist(c1, c2):
     c1 = np.ascontiguousarray(c1, np.float32); c2 = np.ascontiguousarray(c2, np.float32)
     out = np.full((c1.shape[0], c2.shape[0]), -7.0, np.float32)

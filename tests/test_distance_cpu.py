@@ -67,6 +67,33 @@ def test_contacts_from_squared_distances_match_reference_lists(g):
     assert np.array_equal(counts, g["contacts_counts"]) and np.array_equal(flat, g["contacts_flat"])
 
 
+def test_device_side_contact_lists_match_reference_lists(g):
+    """contacts_trajectory through the count / scan / fill kernels (emulated): the reference's lists, in its order,
+    also when a tiny counter budget cuts the frames into several chunks, and for self pairs."""
+    c, b, ch = g["coords"], g["box"], g["chains"]
+    for budget in (256 << 20, 1):
+        res = E.contacts_trajectory(c, b, g["sel1"], g["sel2"], ch, False, True, 12.0, budget_bytes=budget)
+        assert np.array_equal([len(x) // 2 for x in res], g["contacts_counts"])
+        assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_flat"])
+    res = E.contacts_trajectory(c, b, g["sel2"], g["sel2"], ch, True, False, 15.0)
+    assert np.array_equal([len(x) // 2 for x in res], g["contacts_self_counts"])
+    assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_self_flat"])
+    # more frames than one 64-frame slab, pairs not a multiple of the tile edge, a threshold nothing meets
+    rng = np.random.default_rng(9)
+    N, F = 40, 150
+    xyz = rng.uniform(-12, 12, size=(N, 3, F)).astype(np.float32)
+    box = np.full((3, F), 27.0, np.float32)
+    chains = (np.arange(N) % 3).astype(np.uint32)
+    s1, s2 = np.arange(0, 13, dtype=np.uint32), np.arange(9, 40, dtype=np.uint32)
+    for thr in (6.0, 0.01):
+        d2 = oracle.dist_trajectory(xyz, box, s1, s2, chains, False, True, squared=True)
+        res = E.contacts_trajectory(xyz, box, s1, s2, chains, False, True, thr, budget_bytes=4 * 7 * 64)
+        for f in range(F):
+            hit = np.nonzero(d2[f] <= np.float32(thr) * np.float32(thr))[0]
+            i, j = np.divmod(hit, len(s2))
+            assert res[f] == np.stack([s1[i], s2[j]], 1).astype(np.int64).ravel().tolist()
+
+
 def test_squareform_and_known_answers():
     """The reference's own known-answer tests (tests/test_distance.py:1-28) on the oracle + host squareform."""
     from moleculekit_amd.distance_utils import squareform
