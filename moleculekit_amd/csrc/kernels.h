@@ -53,6 +53,9 @@ constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
 #ifndef MK_DIAG           // tools/gpu_diag.sh builds only: compile parts of the tile kernel out to count what they cost
 #define MK_DIAG 0         // 1 pair loops, 2 class flushes, 4 epilogue arithmetic, 8 placement + all class work, 16 histogram traversal
 #endif
+#ifndef MK_SURV_BATCH
+#define MK_SURV_BATCH 2
+#endif
 #ifndef MK_TRAV_BATCH
 #define MK_TRAV_BATCH 4
 #endif
@@ -1215,10 +1218,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         bool use_list = false;
         // survivor i of the list: its record again (an L2-hot gather), tile-relative; f(valid, ., x, y, z, class ids)
         auto for_each_survivor = [&](auto&& f) {
-            for (unsigned i0 = 0; i0 < nsurv; i0 += 2 * WAVE) {          // two chunks' loads in flight
-                float4 P[2]; unsigned ids[2]; bool ok[2];
+            constexpr int SB = MK_SURV_BATCH;
+            for (unsigned i0 = 0; i0 < nsurv; i0 += SB * WAVE) {         // SB chunks' loads in flight
+                float4 P[SB]; unsigned ids[SB]; bool ok[SB];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < SB; ++u) {
                     const unsigned i = i0 + (unsigned)(u * WAVE + lane);
                     ok[u] = i < nsurv;
                     const unsigned code = ok[u] ? (unsigned)s_surv[i] : 0u;
@@ -1227,7 +1231,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     if (ok[u]) { P[u] = rec_pos[r]; ids[u] = clsp[r]; }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < SB; ++u) {
                     if (i0 + (unsigned)(u * WAVE) >= nsurv) break;        // wave-uniform
                     const int pk = mk_float_as_int(P[u].w);
                     const float ex = P[u].x + ((float)(pk & 1023) * tg.fcs + tg.offx);

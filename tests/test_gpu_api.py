@@ -211,3 +211,39 @@ def test_xtc_fed_stream_matches_decode_then_voxelize():
     outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=False, frames=sel, chunk=2)]
     want, _, _ = batch.voxelizeTrajectory(tr.coords, sig, center, [14, 14, 14], 1.0, frames=sel)
     assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
+
+
+def test_streaming_paths_raise_on_bad_frames_instead_of_yielding_incomplete_features():
+    """A trajectory whose box shrinks after the first frame (NPT) keeps its periodic images: every chunk recomputes the
+    images per atom from ITS boxes (same values as the all-at-once call, which sees all boxes); a frame with a box edge
+    <= 10 A -- or a zero box -- raises instead of silently dropping atoms; and what only the device can see (more images
+    than a caller of the raw torch entry point reserved) comes back through poll_errors / synchronize."""
+    import torch
+    from moleculekit_amd import _lib, batch
+    rng = np.random.default_rng(19)
+    N, F = 200, 24
+    xyz = rng.uniform(0, 30, size=(N, 3, F)).astype(np.float32)
+    sig = np.where(rng.random((N, 8)) < 0.4, rng.choice([1.2, 1.7], size=(N, 1)), 0.0)
+    box = np.full((3, F), 40.0, np.float32)
+    box[:, 8:] = 13.0                                         # smaller than grid + halo: several images per atom from frame 8 on
+    want, _, _ = batch.voxelizeTrajectory(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=box)
+    outs = [f for _, f in batch.iterVoxelizeTrajectory(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=box, chunk=4)]
+    torch.cuda.synchronize()
+    assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
+    bad = box.copy(); bad[1, 13] = 9.5
+    with pytest.raises(ValueError):
+        for _ in batch.iterVoxelizeTrajectory(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=bad, chunk=4):
+            pass
+    # the raw device entry point with too few reserved images: the flag is raised on the device, poll_errors reports it
+    ctx = _lib.default_context(0)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    fr = np.ascontiguousarray(np.transpose(xyz[:, :, 8:10], (2, 0, 1))).reshape(-1, 3)
+    out = batch.voxelize_lattice_torch(t(fr, np.float32), t(np.arange(3) * N, np.int64), t(np.tile(sig, (2, 1)), np.float32),
+                                       t(np.tile([[5.0, 5.0, 5.0]], (2, 1)), np.float64), [20, 20, 20], 1.0,
+                                       box=t(np.full((2, 3), 13.0), np.float32), max_images=1, ctx=ctx)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.MkamdError):
+        ctx.poll_errors()
+    ctx.poll_errors()                                         # reported once, then clean again
+    del out
