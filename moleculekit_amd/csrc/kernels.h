@@ -1118,11 +1118,15 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #ifdef MK_NO_SURV_LIST                                 // A-B builds (tools/gpu_ab.sh): the two-traversal kernel of round 1
     constexpr bool SURV_LIST = false;
 #else
-    // the hot kernel culls once and keeps the survivors (see SURV_CAP) -- on the leanest LDS tier only: the list's 960 bytes
-    // fit the 10 KiB a tile may take at 4 waves per SIMD there, on the bigger tiers they would cost a wave per CU or two
-    constexpr bool SURV_LIST = TEAM == 1 && !DENSE && ECAP == ECAP_TIER[0];
+    // the hot kernel culls once and keeps the survivors (see SURV_CAP).  The list BORROWS the z array of the entry buffer:
+    // it is written by the cull pass, read by the histogram pass, and moved into registers (eight 16-bit codes per lane)
+    // before the placement pass starts writing entries -- no LDS of its own, so every tier keeps its occupancy
+    constexpr bool SURV_LIST = TEAM == 1 && !DENSE;
 #endif
-    __shared__ unsigned short s_surv[SURV_LIST ? SURV_CAP : 2];
+    unsigned short* const s_surv = reinterpret_cast<unsigned short*>(sz);
+    static_assert(2 * ESTRIDE >= SURV_CAP, "the survivor codes fit the z array");
+    constexpr int SURV_REGS = (SURV_CAP + WAVE - 1) / WAVE;
+    unsigned surv_code[SURV_REGS];                          // this lane's codes (survivors lane, lane + 64, ...), for the placement pass
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
@@ -1217,15 +1221,20 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         unsigned nsurv = 0u;                                  // wave-uniform
         bool use_list = false;
         // survivor i of the list: its record again (an L2-hot gather), tile-relative; f(valid, ., x, y, z, class ids)
-        auto for_each_survivor = [&](auto&& f) {
+        auto for_each_survivor = [&](auto from_regs_, auto&& f) {
+            constexpr bool FROM_REGS = decltype(from_regs_)::value != 0;
             constexpr int SB = MK_SURV_BATCH;
-            for (unsigned i0 = 0; i0 < nsurv; i0 += SB * WAVE) {         // SB chunks' loads in flight
+            static_assert(SURV_REGS % SB == 0, "the batches tile the code registers");
+#pragma unroll
+            for (int cb = 0; cb < SURV_REGS; cb += SB) {                 // SB chunks' loads in flight
+                const unsigned i0 = (unsigned)(cb * WAVE);
+                if (i0 >= nsurv) break;                                  // wave-uniform
                 float4 P[SB]; unsigned ids[SB]; bool ok[SB];
 #pragma unroll
                 for (int u = 0; u < SB; ++u) {
                     const unsigned i = i0 + (unsigned)(u * WAVE + lane);
                     ok[u] = i < nsurv;
-                    const unsigned code = ok[u] ? (unsigned)s_surv[i] : 0u;
+                    const unsigned code = FROM_REGS ? surv_code[cb + u] : (ok[u] ? (unsigned)s_surv[i] : 0u);
                     const unsigned r = mk_shfl(runs.r0, (int)(code >> SURV_OFF_BITS)) + (code & ((1u << SURV_OFF_BITS) - 1u));
                     P[u] = make_float4(0.f, 0.f, 0.f, 0.f); ids[u] = 0u;
                     if (ok[u]) { P[u] = rec_pos[r]; ids[u] = clsp[r]; }
@@ -1253,7 +1262,14 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 for_each_candidate<K, false, TRAV_BATCH, decltype(keep_survivor)&, true>(g, tg, runs, rec_pos, clsp, keep_survivor);
                 use_list = nsurv <= (unsigned)SURV_CAP;
                 mk_block_sync();                              // the list is read by other lanes than wrote it
-                if (use_list) for_each_survivor(count_entry);
+                if (use_list) {
+                    for_each_survivor(IntC<0>{}, count_entry);
+#pragma unroll
+                    for (int cb = 0; cb < SURV_REGS; ++cb) {              // the codes leave the z array before entries go in
+                        const unsigned i = (unsigned)(cb * WAVE + lane);
+                        surv_code[cb] = i < nsurv ? (unsigned)s_surv[i] : 0u;
+                    }
+                }
             }
         }
         if (MK_DIAG & 16) {
@@ -1426,7 +1442,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 });
             };
             if (use_list) {
-                for_each_survivor(place_entry);
+                for_each_survivor(IntC<1>{}, place_entry);
             } else if (keep) {
 #pragma unroll
                 for (int i = 0; i < TEAM_KEEP; ++i)
