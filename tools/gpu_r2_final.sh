@@ -10,3 +10,5 @@ rm -rf gpurun_out/prof_cfg2_nopipe
 f=$(find gpurun_out/prof_cfg2_nopipe -name "*kernel_trace.csv" | head -1); python tools/timeline.py $f 12 2 > gpurun_out/timeline_prof_cfg2_nopipe.txt 2>&1
 for wl in cfg3 cfg4; do rm -rf gpurun_out/prof_$wl; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py --no-cpu-baseline --no-extra --workload $wl --steps 5 > $R/gpurun_out/rocprof_$wl.log 2>&1); done
 tail -5 gpurun_out/session_a.txt | cut -c1-300; cat gpurun_out/diag_breakdown.txt | tail -7; tail -4 gpurun_out/latency_probe.txt
+for wl in cfg1 cfg5; do rm -rf gpurun_out/prof_$wl; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py --no-cpu-baseline --no-extra --workload $wl --steps 5 > $R/gpurun_out/rocprof_$wl.log 2>&1); done
+(MKAMD_LIB=.variants/libmkamd_phase.so python tools/phase_timers.py cfg2 > gpurun_out/phase_timers.txt 2>&1; MKAMD_LIB=.variants/libmkamd_phase.so python tools/phase_timers.py cfg3 >> gpurun_out/phase_timers.txt 2>&1; MKAMD_LIB=.variants/libmkamd_phase.so python tools/phase_timers.py cfg2 1 >> gpurun_out/phase_timers.txt 2>&1)
