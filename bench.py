@@ -167,7 +167,7 @@ def cpu_baseline(name):
     return out
 
 
-def bench_distances(args):
+def bench_distances(args, emit=True):
     """Secondary workload (`--workload dist`): `dist_trajectory` on an HBM-resident
     trajectory, 30 000 atoms x F frames (reference layout [N,3,F]), 200 x 500 atom pairs, periodic by chain.
     Output-bound: algorithmic bytes = 4 B per (frame, pair) written + the selected atoms' coordinates read once.
@@ -224,7 +224,11 @@ def bench_distances(args):
             raise SystemExit("dist_trajectory on the GPU is not bit-exact with the oracle")
         line["cpu_baseline"] = {"value": round(Fs * n1 * n2 / cpu_s / 1e6, 2), "unit": "Mdist/s", "cores": 1, "kind": "port",
                                 "sample": f"first {Fs} frames of the same workload (also checked bit-exact)"}
-    print(json.dumps(line), flush=True)
+    del coords, out
+    torch.cuda.empty_cache()
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def bench_dropin(args):
@@ -562,6 +566,12 @@ def main():
                 f3, _, _ = getVoxelDescriptors(None, **kw)
             line["dropin_call_ms"] = round((time.perf_counter() - t0) / 100 * 1e3, 4)
             line["dropin_max_abs_err_vs_reference"] = float(np.abs(f3 - g3["features"]).max())
+            # the distance_utils row next to it: dist_trajectory, bit-exact float32
+            dargs = argparse.Namespace(batch=0, steps=max(3, args.steps // 4), warmup=2, no_cpu_baseline=True)
+            dl = bench_distances(dargs, emit=False)
+            line.setdefault("other_workloads", {})["dist_trajectory"] = {
+                "value": dl["value"], "unit": dl["unit"], "ms_per_step": dl["ms_per_step"], "config": dl["config"]["workload"],
+                "roofline": dl["roofline"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
