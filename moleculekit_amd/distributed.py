@@ -241,8 +241,17 @@ class ShardedVoxelizer:
         """This rank's shard -> float32 [B_local, V, C] on its device; asynchronous, no collective."""
         return self._run(*self._items(0, self.n_local), out=out)
 
+    def _collectives(self):
+        """True when a process group exists: the collectives then run even with ONE rank (a 1-GPU box exercises the
+        RCCL path that way); without a group (plain single-process use) everything is local."""
+        try:
+            import torch.distributed as dist
+            return dist.is_available() and dist.is_initialized()
+        except Exception:
+            return False
+
     def gather(self, local, dst=None):
-        return gather_features(local, self.bounds, group=self.group, dst=dst) if self.world > 1 else local
+        return gather_features(local, self.bounds, group=self.group, dst=dst) if self._collectives() else local
 
     def voxelize_gather(self, nchunks=4, dst=None, timings=None):
         """Voxelize the shard chunk by chunk and gather every finished chunk on a communication stream while the next
@@ -252,7 +261,7 @@ class ShardedVoxelizer:
         import torch
         import torch.distributed as dist
 
-        if self.world == 1:
+        if not self._collectives():
             return self.voxelize()
         ws, rank = self.world, self.rank
         sizes = np.diff(self.bounds)
@@ -320,7 +329,7 @@ def voxelize_sharded(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, 
     """
     sv = ShardedVoxelizer.from_host(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=box,
                                     balance_by_atoms=balance_by_atoms, compute=compute, device=device)
-    if not gather or sv.world == 1:
+    if not gather or not sv._collectives():
         return sv.voxelize(), sv.bounds
     if nchunks > 0:
         return sv.voxelize_gather(nchunks=nchunks, dst=dst), sv.bounds
