@@ -974,7 +974,11 @@ MK_DEV void cand_issue(const CandLoader& L, unsigned t, CandChunk& ch)
                 const int j = mk_ctz64(over);
                 over &= over - 1ull;
                 const unsigned pj = mk_readlane(cr.pre, j), lj = mk_readlane(cr.len, j), rj = mk_readlane(cr.r0, j);
-                if (n - pj < lj) { ch.r = rj + (n - pj); ch.code = ((unsigned)j << SURV_OFF_BITS) | (n - pj); ch.valid = true; }   // unsigned: pj <= n < pj + lj
+                const unsigned off = n - pj;
+                const bool mine = off < lj;                          // unsigned: pj <= n < pj + lj  (selects, not a branch:
+                ch.r = mine ? rj + off : ch.r;                       //  the masked-region form costs a dozen scalar ops per run)
+                ch.code = mine ? (((unsigned)j << SURV_OFF_BITS) | off) : ch.code;
+                ch.valid = ch.valid || mine;
             }
             if (ch.valid) {
                 ch.P = rec_pos[ch.r];
