@@ -205,12 +205,17 @@ MK_DEV void wave_register_value(unsigned bits, unsigned* s_set, unsigned* s_full
 // `multi` = the lane's atom has several distinct sigmas, its other values are in wb[].
 MK_DEV void wave_register_classes(unsigned first, bool multi, const unsigned (&wb)[CHG], unsigned* s_set, unsigned* s_full)
 {
+    // A value that already sits in its home slot of the block's set needs nothing: one LDS read per lane instead of an
+    // election trip per distinct value -- after the block's first wave that is nearly every lane (a value displaced by
+    // a collision, or one being inserted by another wave right now, simply takes the election as before).
+    const unsigned first0 = first;
+    if (first != CLS_EMPTY && s_set[class_hash(first) & (unsigned)(CLS_BLOCK_SET - 1)] == first) first = CLS_EMPTY;
     // the lane's first value goes through one election loop (a handful of trips per wave) ...
     wave_register_value(first, s_set, s_full);
     // ... and only waves holding atoms with SEVERAL distinct sigmas pay for the remaining slots
     if (mk_ballot(multi) != 0ull) {
 #pragma unroll
-        for (int j = 0; j < CHG; ++j) wave_register_value((multi && wb[j] != first) ? wb[j] : CLS_EMPTY, s_set, s_full);
+        for (int j = 0; j < CHG; ++j) wave_register_value((multi && wb[j] != first0) ? wb[j] : CLS_EMPTY, s_set, s_full);
     }
 }
 
@@ -333,6 +338,20 @@ MK_DEV int item_of_atom(const long long* __restrict__ atom_offsets, int B, long 
         if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// the same for the first and the last atom of a block, without the two chains of dependent loads in the common cases:
+// items of equal size (the guess a * B / total is right: two independent loads confirm it) and a block inside one item
+MK_DEV void items_of_block(const long long* __restrict__ atom_offsets, int B, long long total_atoms, long long a_first,
+                           long long a_last, int& b_lo, int& b_hi)
+{
+    int b = (int)((double)a_first * (double)B / (double)(total_atoms > 0 ? total_atoms : 1));
+    b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
+    const long long o0 = atom_offsets[b], o1 = atom_offsets[b + 1];
+    long long next = o1;
+    if (o0 <= a_first && a_first < o1) b_lo = b;
+    else { b_lo = item_of_atom(atom_offsets, B, a_first, 0); next = atom_offsets[b_lo + 1]; }
+    b_hi = a_last < next ? b_lo : item_of_atom(atom_offsets, B, a_last, b_lo);
 }
 
 // PBC: 0 = open boundaries, 1 = periodic, -1 = decided at run time (g.pbc).  The periodic image loop costs ~20 VGPRs;
@@ -494,8 +513,8 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     // the items of the block's first and last atom (block-uniform: scalar loads); one block rarely spans several
     const long long a_first = (long long)blockIdx.x * blockDim.x;
     const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
-    const int b_lo = item_of_atom(atom_offsets, g.B, a_first, 0);
-    const int b_hi = item_of_atom(atom_offsets, g.B, a_last, b_lo);
+    int b_lo, b_hi;
+    items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
     const long long a = a_first + threadIdx.x;
     bin_atom<SigT, PBC>(g, a, a < total_atoms, b_lo, b_hi, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, tmp_cls, err_flag,
                    classes, s_set, &s_full, [&](size_t cell) { return mk_atomic_add(&cell_count[cell], 1u); },
