@@ -65,6 +65,7 @@ struct mkamd_ctx {
     bool pipelining = false;               // opt-in (mkamd_ctx_set_pipelining)
     bool have_pre_tile_event = false;
     void* bufs[2 * WS_NSLOTS] = {};        // two workspace sets (set 1 only used by pipelined calls)
+    CounterState counters[2];              // what is known about each set's cell counters between calls
     size_t caps[2 * WS_NSLOTS] = {};
     int tile_k = 0;
     int force_general = 0;
@@ -89,6 +90,7 @@ struct mkamd_ctx {
     int launch_status = 0;
 
     // ---- backend concept (pipeline.h) ----
+    CounterState& counter_state(int set) { return counters[set & 1]; }
     const volatile unsigned* feedback_host() const { return fb_host; }
     unsigned* feedback_dev() const { return fb_dev; }
     void note_error_flag_mirrored(bool yes) { err_mirrored = yes; }

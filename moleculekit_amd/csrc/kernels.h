@@ -824,7 +824,7 @@ constexpr unsigned SMALL_PREPASS_MAX_CELLS = 1u << 13;     // counts one block s
 constexpr unsigned SMALL_PREPASS_MAX_BLOCKS = 4096;        // per-block sigma sets one block merges likewise
 
 MK_KERNEL(SMALL_PREPASS_THREADS) void k_prepass_small(const unsigned* __restrict__ block_sets, unsigned nblk,
-                                                      unsigned* __restrict__ cls_table, const unsigned* __restrict__ counts,
+                                                      unsigned* __restrict__ cls_table, unsigned* __restrict__ counts,
                                                       unsigned n, unsigned* __restrict__ starts /* n+1 */)
 {
     mk_wave_priority_high();
@@ -834,6 +834,7 @@ MK_KERNEL(SMALL_PREPASS_THREADS) void k_prepass_small(const unsigned* __restrict
     for (unsigned base = 0; base <= n; base += SMALL_PREPASS_THREADS) {    // block-uniform
         const unsigned i = base + threadIdx.x;
         const unsigned v = i < n ? counts[i] : 0u;
+        if (i < n) counts[i] = 0u;                                         // the counters leave every call as they entered it: zero
         unsigned tot;
         const unsigned ex = block_scan_exclusive16(v, &tot, s_scan);
         if (i <= n) starts[i] = carry + ex;                                // starts[n] = grand total
@@ -841,7 +842,7 @@ MK_KERNEL(SMALL_PREPASS_THREADS) void k_prepass_small(const unsigned* __restrict
     }
 }
 
-MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size_t n,
+MK_KERNEL(SCAN_THREADS) void k_scan_finish(unsigned* __restrict__ in /* zeroed once read: see run_lattice */, size_t n,
                                            const unsigned* __restrict__ chunk_offsets,
                                            unsigned* __restrict__ out /* n+1 */)
 {
@@ -854,6 +855,7 @@ MK_KERNEL(SCAN_THREADS) void k_scan_finish(const unsigned* __restrict__ in, size
     for (int j = 0; j < SCAN_PER_THREAD; ++j) {
         const size_t i = base + j;
         v[j] = (i < n) ? in[i] : 0u;
+        if (i < n) in[i] = 0u;
         s += v[j];
     }
     unsigned tot;
@@ -1777,10 +1779,13 @@ MK_KERNEL(64) void k_exact_fixup(GridDesc g, int per_item, const unsigned* __res
                                  const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
                                  long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                  const float* __restrict__ box, const double* __restrict__ affine,
-                                 const uint2* __restrict__ tmp_cls, float* __restrict__ out)
+                                 const uint2* __restrict__ tmp_cls, float* __restrict__ out, unsigned* __restrict__ dense_words)
 {
     __shared__ double s_best[WAVE];
     const int lane = threadIdx.x;
+    // the last kernel of a call: the dense-tile list's length and the tier statistics (read by the dense pass, which is
+    // done) go back to zero, like the cell counters did in the scan -- the next call needs no memset
+    if (blockIdx.x == 0 && lane < DENSE_WORDS) dense_words[lane] = 0u;
     const float wmax = g.w_exact_max;
     auto wide_bits = [&](unsigned bits) { return bits != CLS_EMPTY && mk_uint_as_float(bits) < wmax; };   // NaN: false
     // ---- the summary: is there anything wide among this wave's atoms at all? ----

@@ -159,13 +159,13 @@ inline int max_images_from_boxes(const float* box, int B, const int* nvox, doubl
 }
 
 template <class BE>
-int run_scan(BE& be, const unsigned* counts, size_t n, unsigned* starts /* n+1 */, int set = 0)
+int run_scan(BE& be, unsigned* counts /* cleared by the last kernel */, size_t n, unsigned* starts /* n+1 */, int set = 0)
 {
     const size_t nchunks = (n + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
     void* chunks = nullptr;
     int st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set);
     if (st) return st;
-    if ((st = be.launch(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (unsigned*)chunks))) return st;
+    if ((st = be.launch(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (const unsigned*)counts, n, (unsigned*)chunks))) return st;
     if ((st = be.launch(k_scan_sums_inplace, dim3(1), dim3(SCAN_THREADS), (unsigned*)chunks, (unsigned)nchunks))) return st;
     return be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (const unsigned*)chunks, starts);
 }
@@ -224,6 +224,10 @@ int launch_tiles(BE& be, int tier, int flavour, dim3 tgrid, unsigned dense_wgs, 
     }
 }
 
+// What a backend remembers about the cell-counter buffer of one workspace set (run_lattice): which allocation it is and
+// how many of its leading bytes are known to be zero between calls.
+struct CounterState { void* ptr = nullptr; size_t clean = 0; };
+
 // The lattice hot path: bin -> scan -> fill -> tile kernel.  All pointers in P are device pointers.
 template <class BE>
 int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
@@ -267,6 +271,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
     if ((st = be.ensure(WS_TMP_CLS, (size_t)(P.total_atoms > 0 ? P.total_atoms : 1) * g.G * sizeof(uint2), &tcls, set))) return st;
 
+    CounterState& cs = be.counter_state(set);
+    if (cs.ptr != count) { cs.ptr = count; cs.clean = 0; }
+    size_t clean_after = cs.clean;
+    cs.clean = 0;                                   // nothing is vouched for until this call has been enqueued in full
+
     const unsigned* fix_summary = nullptr;         // what k_exact_fixup looks at first (see there)
     unsigned fix_waves = 0;
     if (per_item) {
@@ -285,7 +294,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         else              st = need <= 512 ? go(k_prepass_items<float, 512>) : need <= 2048 ? go(k_prepass_items<float, 2048>) : go(k_prepass_items<float, ITEM_HIST>);
         if (st) return st;
     } else {
-        if ((st = be.fill(count, 0, count_bytes))) return st;
+        // The counters are zero when a call starts and every call leaves them zero (the scan kernels clear what they
+        // read, the fix-up kernel the dense words): the memset -- a launch of its own, 6 us of a one-grid call -- is only
+        // needed for bytes no call has vouched for yet (a new or grown buffer, a call that failed half-way).
+        if (clean_after < count_bytes) {
+            if ((st = be.fill(count, 0, count_bytes))) return st;
+            clean_after = count_bytes;
+        }
         const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
         const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
         const unsigned nblk = agrid.x;
@@ -311,7 +326,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (ncells <= SMALL_PREPASS_MAX_CELLS && nblk <= SMALL_PREPASS_MAX_BLOCKS) {
             // a small call (one grid): one launch instead of three dependent ones
             if ((st = be.launch(k_prepass_small, dim3(1), dim3(SMALL_PREPASS_THREADS), (const unsigned*)bsets, do_classes ? nblk : 0u,
-                                (unsigned*)ctab, (const unsigned*)count, (unsigned)ncells, (unsigned*)start))) return st;
+                                (unsigned*)ctab, (unsigned*)count, (unsigned)ncells, (unsigned*)start))) return st;
         } else {
             const size_t nchunks = (ncells + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
             void* chunks = nullptr;
@@ -321,7 +336,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                                 nl1_eff, (unsigned*)l1sets, (const unsigned*)count, ncells, (unsigned*)chunks))) return st;
             if ((st = be.launch(k_prepass_reduce2, dim3(do_classes ? 2u : 1u), dim3(256), (const unsigned*)l1sets, nl1_eff, (unsigned*)ctab,
                                 (unsigned*)chunks, (unsigned)nchunks))) return st;
-            if ((st = be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (const unsigned*)count, ncells,
+            if ((st = be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (unsigned*)count, ncells,
                                 (const unsigned*)chunks, (unsigned*)start))) return st;
         }
         if (P.total_atoms > 0) {
@@ -355,11 +370,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (!st && fix_waves != 0u) {
         // exact cut-off decisions for wide sigmas (the waves whose atoms have none -- normally all -- leave at once)
         st = P.sigmas_f64 ? be.launch(k_exact_fixup<double>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,
-                                      P.total_atoms, (const double*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out)
+                                      P.total_atoms, (const double*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out, dcount)
                           : be.launch(k_exact_fixup<float>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,
-                                      P.total_atoms, (const float*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out);
+                                      P.total_atoms, (const float*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out, dcount);
     }
     be.hot_end();
+    // (a call without atoms launches no fix-up, and nothing that could have touched a counter either)
+    if (!st) cs.clean = clean_after;
     be.note_error_flag_mirrored(!st && !g.force_general && be.feedback_dev() != nullptr);
     be.tile_done(set);
     return st;

@@ -16,6 +16,9 @@ struct EmuBackend {
     void* bufs[WS_NSLOTS] = {};
     size_t caps[WS_NSLOTS] = {};
     unsigned feedback[FEEDBACK_WORDS] = {};
+    CounterState counters[2];
+    int fills = 0;                      // memsets of the cell counters (the tests count them)
+    CounterState& counter_state(int set) { return counters[set & 1]; }
     void note_error_flag_mirrored(bool) {}
     const volatile unsigned* feedback_host() const { return feedback; }
     unsigned* feedback_dev() { return feedback; }
@@ -32,7 +35,7 @@ struct EmuBackend {
         *ptr = bufs[slot];
         return 0;
     }
-    int fill(void* p, int byte, size_t bytes) { memset(p, byte, bytes); return 0; }
+    int fill(void* p, int byte, size_t bytes) { memset(p, byte, bytes); ++fills; return 0; }
     int to_host(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
     int to_device(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
     template <class... KA, class... A>
@@ -62,7 +65,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
                          int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
                          const float* box, int max_images, int tile_k, int force_general, const double* affine, float* features,
                          int* err_flag_out, int lds_tier, unsigned* feedback_io /* NTIER+1: in = previous call's, out = this call's */,
-                         int prepass_mode, int tile_team, int fine_cells)
+                         int prepass_mode, int tile_team, int fine_cells, int repeat /* calls on ONE backend */, int* fills_out)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -81,8 +84,12 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     P.coords = coords; P.atom_offsets = atom_offsets; P.sigmas = sigmas; P.origins = origins;
     P.box = box; P.affine = affine; P.out = features;
     const size_t nout = (size_t)B * nvox[0] * nvox[1] * nvox[2] * C;
-    for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;
-    const int st = run_lattice(be, P, g_err);
+    int st = 0;
+    for (int r = 0; r < (repeat > 0 ? repeat : 1) && !st; ++r) {     // later rounds run on the counters the earlier ones left
+        for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;
+        st = run_lattice(be, P, g_err);
+    }
+    if (fills_out) *fills_out = be.fills;
     if (err_flag_out) *err_flag_out = *(int*)be.bufs[WS_ERR];
     if (feedback_io) for (int i = 0; i <= NTIER; ++i) feedback_io[i] = be.feedback[i];
     return st;
@@ -107,7 +114,9 @@ int emu_grid_centers(const double* bb_min, const int* nvox, double voxelsize, do
 int emu_exclusive_scan(const unsigned* in, long long n, unsigned* out /* n+1 */)
 {
     EmuBackend be;
-    return run_scan(be, in, (size_t)n, out);
+    std::vector<unsigned> counts(in, in + n);                // the scan clears its input (the counters are self-cleaning)
+    counts.push_back(0u);
+    return run_scan(be, counts.data(), (size_t)n, out);
 }
 
 // planning only: lets the tests inspect the GridDesc the product would use

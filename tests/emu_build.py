@@ -46,8 +46,11 @@ def _p(a):
 
 
 def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box=None, max_images=0,
-                     tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None, prepass_mode=-1, tile_team=-1, fine_cells=False):
-    """feedback: optional uint32[4] array, in = tier statistics of the 'previous call', out = this call's."""
+                     tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None, prepass_mode=-1, tile_team=-1, fine_cells=False,
+                     repeat=1, fills=None):
+    """feedback: optional uint32[4] array, in = tier statistics of the 'previous call', out = this call's.
+    repeat: run the call that many times on ONE backend (workspace kept) and return the last result; fills: optional
+    one-element list that receives the number of counter memsets those calls issued."""
     coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
     atom_offsets = np.ascontiguousarray(atom_offsets, np.int64)
     sig64 = sigmas.dtype == np.float64
@@ -59,12 +62,16 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
     out = np.empty((B, V, C), np.float32)
     bx = None if box is None else np.ascontiguousarray(box, np.float32).reshape(B, 3)
     err = ctypes.c_int(0)
+    nfills = ctypes.c_int(0)
     st = lib().emu_voxelize_lattice(
         ctypes.c_int(B), _p(coords), _p(atom_offsets), _p(sigmas), ctypes.c_int(int(sig64)), ctypes.c_int(C),
         _p(origins), _p(nvox), ctypes.c_double(voxelsize), _p(bx), ctypes.c_int(max_images),
         ctypes.c_int(tile_k), ctypes.c_int(int(force_general)),
         _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out), ctypes.byref(err),
-        ctypes.c_int(lds_tier), _p(feedback), ctypes.c_int(prepass_mode), ctypes.c_int(tile_team), ctypes.c_int(int(fine_cells)))
+        ctypes.c_int(lds_tier), _p(feedback), ctypes.c_int(prepass_mode), ctypes.c_int(tile_team), ctypes.c_int(int(fine_cells)),
+        ctypes.c_int(int(repeat)), ctypes.byref(nfills))
+    if fills is not None:
+        fills[:] = [nfills.value]
     if st != 0:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return out, err.value

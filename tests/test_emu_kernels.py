@@ -38,6 +38,22 @@ def test_per_item_and_chain_prepass_are_bit_identical(name):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("name,mode", [("ragged_batch", 0), ("cfg1_3ptb", 0), ("dense_mixed", 0), ("ragged_batch", 1), ("pbc_batch", 0)])
+def test_counters_leave_every_call_zeroed(name, mode):
+    """The cell counters and the dense-tile words are cleared by the kernels that read them last: a second and a third
+    call on the same workspace run WITHOUT the memset (the emulation poisons fresh workspace, so a counter that was not
+    put back would show) and return the first call's bits."""
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    fills1, fills3 = [0], [0]
+    a, ea = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=mode, fills=fills1)
+    b, eb = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=mode, repeat=3, fills=fills3)
+    assert ea == 0 and eb == 0
+    assert np.array_equal(a, b)
+    assert fills3[0] == fills1[0]                       # the two extra calls issued no memset of their own
+    check(case, b)
+
+
 def test_per_item_class_tables_keep_mixed_batches_on_the_sorted_path():
     """40 distinct sigmas across the batch but <= 5 per item: the call-wide class table overflows (general path),
     per-item tables do not; one item with 20 distinct sigmas overflows on its own. Same values either way."""
