@@ -1110,7 +1110,10 @@ template <int K> MK_DEV void entry_d2(float ex, float dyz2, float w, float (&d2)
 
 // TEAM > 1 (launches too small to fill the chip: one grid per call, the reference's usage): TEAM waves share one tile --
 // each takes every TEAM-th batch of candidate chunks in the two traversals (histogram and placement go through the
-// same LDS counters) and K / TEAM of the tile's x-planes in the pair loops and the epilogue.  The arithmetic per
+// same LDS counters), every TEAM-th PAIR of a sub-bucket's entries against all K planes in the pair loops (splitting the
+// planes instead left each wave the whole per-pair set-up for one or two planes' worth of tests: 73 % of the 3PTB call's
+// tile kernel), and, after one min-reduction of the waves' accumulators through LDS, K / TEAM planes of the epilogue.
+// Minima are order-free and the class flush is monotone, so the bits are the one-wave kernel's.  The arithmetic per
 // (voxel, entry) is the one-wave kernel's, bit for bit; what changes is the latency of a tile (~1/3).
 template <int K, bool DENSE, int ECAP, int TEAM = 1>
 MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, const unsigned* __restrict__ cell_start,
@@ -1120,8 +1123,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                           unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
 {
     static_assert(K == 4 || K == 8, "K");
-    static_assert(TEAM == 1 || (!DENSE && (K / 2) % (K / TEAM) == 0 && K / TEAM >= 1), "a team splits the planes evenly inside each half");
-    constexpr int KL = K / TEAM;                          // planes this wave owns: [kb, kb + KL)
+    static_assert(TEAM == 1 || (!DENSE && K % TEAM == 0), "a team splits the planes of the epilogue evenly");
+    constexpr int KL = K;                                 // planes in this wave's accumulators (all of them)
+    constexpr int KE = K / TEAM;                          // planes of the epilogue this wave owns: [kb, kb + KE)
     MK_PHASE_BEGIN();
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
     // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
@@ -1155,10 +1159,10 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const int kb = wv * KL;
+    const int kb = wv * KE;
     const bool lead = lane == 0 && wv == 0;               // the one thread of the tile's team that reports to global memory
     // x of this wave's plane j relative to the tile centre (compile-time constants for the one-wave kernel)
-    auto pl_x = [&](int j) { return TEAM == 1 ? plane_x<K>(j) : (float)(kb + j) - 0.5f * (float)(K - 1); };
+    auto pl_x = [&](int j) { return plane_x<K>(j); };
     auto pl_slope = [&](int j) { return -2.f * pl_x(j); };
 
     TileGeom tg;
@@ -1371,18 +1375,19 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 // slots are padded to an even count, bit 0 of b0 says that the last slot is padding
                 auto run = [&](auto k0_, auto k1_, unsigned b0, unsigned b1) {
                     constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
-                    if (TEAM > 1 && (kb < K0 || kb >= K1)) return;            // wave-uniform: none of this wave's planes
                     if (MK_DIAG & 1) return;
-                    constexpr int J0 = TEAM == 1 ? K0 : 0, J1 = TEAM == 1 ? K1 : KL;   // this wave's planes of [K0, K1)
+                    constexpr int J0 = K0, J1 = K1;
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
-                    const float* e = sxyz + s0;
+                    // a team's wave takes every TEAM-th pair; the unpaired last entry goes to the wave whose turn it would be
+                    const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
+                    const float* e = sxyz + s0 + (TEAM > 1 ? 2u * (unsigned)wv : 0u);
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
                     //  have to be merged after every one of these short runs -- measured 7 % slower)
                     // (the LDS address is the only induction variable: a trip counter ends up in a VGPR with a carry-out
                     //  compare -- one VALU instruction per trip more, PMC: 8 970 -> 8 739 per tile)
-                    const float* const e_end = e + 2u * ((((b1 & ~1u) - s0) >> 1) - odd);
+                    const float* const e_end = sxyz + s0 + 2u * npairs;
 #pragma clang loop vectorize(disable) interleave(disable)
-                    for (; e != e_end; e += 2) {
+                    for (; TEAM > 1 ? e < e_end : e != e_end; e += 2 * TEAM) {
                         // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
                         // (fetching the next pair one trip ahead was measured: 2-4 % slower, the copies cost more)
                         const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
@@ -1394,8 +1399,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                             m[k] = mk_min3(m[k], gk[0], gk[1]);
                         }
                     }
-                    if (odd) {                                            // wave-uniform: the unpaired last entry
-                        const float ex = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
+                    if (odd && (TEAM == 1 || (unsigned)wv == (npairs & (unsigned)(TEAM - 1)))) {   // wave-uniform: the unpaired last entry
+                        const float* t = sxyz + s0 + 2u * npairs;
+                        const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
                         const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
 #pragma unroll
                         for (int k = J0; k < J1; ++k) m[k] = mk_min(m[k], mk_fma(pl_slope(k), ex, d0));
@@ -1409,8 +1415,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     const unsigned n = ((b1 & ~1u) - s0) - (b0 & 1u);
                     const float* e = sxyz + s0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                    for (unsigned i = 0; i < n; ++i, ++e) {
-                        const float px = e[0], dy = Y - e[ESTRIDE], dz = Z - e[2 * ESTRIDE];
+                    for (unsigned i = (TEAM > 1 ? (unsigned)wv : 0u); i < n; i += TEAM) {   // (a team's wave: every TEAM-th entry)
+                        const float* ee = e + i;
+                        const float px = ee[0], dy = Y - ee[ESTRIDE], dz = Z - ee[2 * ESTRIDE];
                         const float r = mk_fma(dy, dy, dz * dz);
 #pragma unroll
                         for (int k = 0; k < KL; ++k) {
@@ -1563,10 +1570,10 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         auto body = [&](bool surv, unsigned r, float ex, float ey, float ez, unsigned) {
             float4 W0 = make_float4(INF, INF, INF, INF), W1 = W0;
             if (surv) { W0 = w0p[r]; W1 = w1p[r]; }
-            const float wv[CHG] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
+            const float wch[CHG] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
 #pragma unroll
             for (int c = 0; c < CHG; ++c) {
-                const float wc = wv[c];
+                const float wc = wch[c];
                 const bool has = surv && (wc < INF);                // false for +inf and NaN
                 const unsigned long long mask = mk_ballot(has);
                 if (mask == 0ull) continue;                          // wave-uniform
@@ -1574,23 +1581,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
                 mk_block_sync();
 #pragma clang loop vectorize(disable) interleave(disable)
-                for (int i = 0; i < n; ++i) {
+                for (int i = (TEAM > 1 ? wv : 0); i < n; i += TEAM) {        // (a team's wave: every TEAM-th entry, all planes)
                     const float4 e = ebuf[i];
                     const float dy = Y - e.y, dz = Z - e.z;
                     float d2[KL];
-                    if constexpr (TEAM == 1) {
-                        entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);              // same fma tree as the sorted path
-                    } else {                                                             // this wave's planes, the same two forms
-                        const float dyz2 = mk_fma(dy, dy, dz * dz);
-                        if (mk_uint_as_float(mk_uniform(mk_float_bits(e.w))) <= fast_w_max<K>()) {
-                            const float d0 = mk_fma(e.x, e.x, dyz2);
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) d2[k] = mk_fma(pl_slope(k), e.x, d0) + pl_x(k) * pl_x(k);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < KL; ++k) { const float dx = pl_x(k) - e.x; d2[k] = mk_fma(dx, dx, dyz2); }
-                        }
-                    }
+                    entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);                  // same fma tree as the sorted path
 #pragma unroll
                     for (int k = 0; k < KL; ++k)
                         q[c][k] = mk_min_bits(q[c][k], d2[k] < R2 ? mk_abs(d2[k]) * e.w : INF);   // occupancy_utils.pyx:53
@@ -1601,11 +1596,29 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         for_each_candidate<K, false, 1>(g, tg, runs, rec_pos, clsp, body);
     }
 
+    // ---- a team: the waves' accumulators (each saw a quarter of the entries) meet in LDS -- unsigned minima of bit
+    //      patterns, as everywhere -- and every wave takes K / TEAM planes of the result through the epilogue ----
+    if constexpr (TEAM > 1) {
+        __shared__ unsigned s_red[CHG * K * WAVE];
+#pragma unroll
+        for (int i = wv; i < CHG * K; i += TEAM) s_red[i * WAVE + lane] = INF_BITS;
+        mk_block_sync();
+#pragma unroll
+        for (int c = 0; c < CHG; ++c)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (q[c][k] != INF_BITS) mk_lds_min(&s_red[(c * K + k) * WAVE + lane], q[c][k]);
+        mk_block_sync();
+#pragma unroll
+        for (int c = 0; c < CHG; ++c)
+#pragma unroll
+            for (int k = 0; k < KE; ++k) q[c][k] = s_red[(c * K + kb + k) * WAVE + lane];    // (planes [kb, kb + KE) move to the front)
+    }
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
     const int y = tg.y0 + ly, z = tg.z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
 #pragma unroll
-    for (int k = 0; k < KL; ++k) {
+    for (int k = 0; k < KE; ++k) {
         const int x = tg.x0 + kb + k;
         float f[CHG];
 #pragma unroll

@@ -83,6 +83,7 @@ MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { return 
 MK_DEV float mk_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }                        // v_fma_f32, never split
 // LDS atomic add, returns the old value (ds_add_rtn_u32)
 MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+MK_DEV void mk_lds_min(unsigned* p, unsigned v) { (void)atomicMin(p, v); }                                   // ds_min_u32
 // instruction-issue priority of this wave on its SIMD (s_setprio 0..3): the small latency-bound pre-pass
 // kernels raise it so that they are not starved of issue slots by the VALU-saturating tile kernel of the
 // previous call when the two overlap

@@ -199,6 +199,7 @@ MK_DEV unsigned mk_load_relaxed(unsigned* p) { return *p; }
 MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
 MK_DEV float mk_fma(float a, float b, float c) { return fmaf(a, b, c); }
 MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+MK_DEV void mk_lds_min(unsigned* p, unsigned v) { if (v < *p) *p = v; }
 MK_DEV void mk_wave_priority_high() {}
 MK_DEV unsigned mk_readlane(unsigned v, int lane)
 {

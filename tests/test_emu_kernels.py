@@ -261,9 +261,10 @@ def test_fused_rotation_matches_rotate_then_voxelize():
 @pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "pbc_batch", "channels11", "cutoff_exact_1A", "voxel15", "special_sigmas"])
 @pytest.mark.parametrize("tile_k", [8, 4])
 def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
-    """One grid per call (the reference's usage) runs a team of four waves per tile: shared candidate traversal, the
-    x-planes split among the waves.  Same arithmetic per (voxel, entry), so not a bit may differ from the one-wave
-    kernel -- on the class-sorted path and, forced, on the general path."""
+    """One grid per call (the reference's usage) runs a team of four waves per tile: shared candidate traversal, every
+    fourth pair of a sub-bucket's entries per wave, the waves' minima merged through LDS before the epilogue.  Same
+    arithmetic per (voxel, entry), minima are order-free and the class flush is monotone, so not a bit may differ from
+    the one-wave kernel -- on the class-sorted path and, forced, on the general path."""
     if tile_k == 4 and name in ("pbc_batch", "voxel15"):
         pytest.skip("covered with K=8 (emulation time)")
     case = LATTICE_CASES[name]()
