@@ -1693,28 +1693,6 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned*
     voxelize_tile<K, false, ECAP, TILE_TEAM>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
 }
 
-// The tiles k_voxelize_tiles left behind (usually none: the launch then costs ~2 us).
-template <int K, int ECAP>
-MK_KERNEL(64) void k_voxelize_dense_tiles(GridDesc g, const unsigned* __restrict__ cell_start,
-                                          const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls,
-                                          const unsigned* __restrict__ cls_table, float* __restrict__ out,
-                                          const unsigned* __restrict__ dense_count, const unsigned* __restrict__ dense_list,
-                                          unsigned* __restrict__ feedback, const int* __restrict__ err_flag)
-{
-    const unsigned n = *dense_count, total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
-    if (feedback && blockIdx.x == 0 && threadIdx.x == 0) {               // host-visible: drives the next calls' tier
-#pragma unroll
-        for (int t = 0; t < NTIER; ++t) feedback[t] = dense_count[1 + t];
-        feedback[NTIER] = total_tiles * (unsigned)g.G;
-        feedback[NTIER + 1] = (unsigned)*err_flag;      // mirror of the device-side error flag (set by the binning, long done)
-    }
-    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {               // wave-uniform
-        const unsigned e = dense_list[i];
-        voxelize_tile<K, true, ECAP>(g, e % total_tiles, (int)(e / total_tiles), cell_start, rec_pos, nullptr, rec_cls, cls_table, out, nullptr, nullptr);
-        mk_block_sync();                                                 // LDS arrays are reused by the next tile
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Exact cut-off decisions.  occupancy_utils.pyx:53 tests d^2 < 25 in DOUBLE; the tile kernels test float32 distances
 // that carry ~3e-6 A^2 of error, so a pair within that of the cutoff can land on the wrong side.  What is then at stake is
@@ -1788,23 +1766,19 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, in
 // One wave per 256 atoms of the binning (per_item == 0: `summary` = the blocks' sigma sets, CLS_BLOCK_SET words each;
 // nullptr = no summary, look at every atom) or per item (per_item == 1: `summary` = the items' class tables).
 template <typename SigT>
-MK_KERNEL(64) void k_exact_fixup(GridDesc g, int per_item, const unsigned* __restrict__ summary,
-                                 const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
-                                 long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
-                                 const float* __restrict__ box, const double* __restrict__ affine,
-                                 const uint2* __restrict__ tmp_cls, float* __restrict__ out, unsigned* __restrict__ dense_words)
+MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_item, const unsigned* __restrict__ summary,
+                              const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
+                              long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
+                              const float* __restrict__ box, const double* __restrict__ affine,
+                              const uint2* __restrict__ tmp_cls, float* __restrict__ out, double* s_best)
 {
-    __shared__ double s_best[WAVE];
     const int lane = threadIdx.x;
-    // the last kernel of a call: the dense-tile list's length and the tier statistics (read by the dense pass, which is
-    // done) go back to zero, like the cell counters did in the scan -- the next call needs no memset
-    if (blockIdx.x == 0 && lane < DENSE_WORDS) dense_words[lane] = 0u;
     const float wmax = g.w_exact_max;
     auto wide_bits = [&](unsigned bits) { return bits != CLS_EMPTY && mk_uint_as_float(bits) < wmax; };   // NaN: false
     // ---- the summary: is there anything wide among this wave's atoms at all? ----
     long long a_lo, a_hi;
     if (per_item) {
-        const int b = (int)blockIdx.x;
+        const int b = (int)blk;
         a_lo = atom_offsets[b]; a_hi = atom_offsets[b + 1];
         if (summary != nullptr) {
             const unsigned t = lane < CLS_TABLE_WORDS ? summary[(size_t)b * CLS_TABLE_WORDS + lane] : CLS_EMPTY;
@@ -1812,16 +1786,16 @@ MK_KERNEL(64) void k_exact_fixup(GridDesc g, int per_item, const unsigned* __res
             if (mk_ballot(maybe) == 0ull) return;
         }
     } else {
-        a_lo = (long long)blockIdx.x * 256;
+        a_lo = (long long)blk * 256;
         a_hi = a_lo + 256 < total_atoms ? a_lo + 256 : total_atoms;
         if (summary != nullptr) {
-            const unsigned t = lane < CLS_BLOCK_SET ? summary[(size_t)blockIdx.x * CLS_BLOCK_SET + lane] : CLS_EMPTY;
+            const unsigned t = lane < CLS_BLOCK_SET ? summary[(size_t)blk * CLS_BLOCK_SET + lane] : CLS_EMPTY;
             if (mk_ballot(t == CLS_TOO_MANY || wide_bits(t)) == 0ull) return;
         }
     }
     const double R = CUTOFF_A_KERNEL / g.res, R2 = R * R, band = R2 * EXACT_BAND_REL, Rb = sqrt(R2 + band);
     const int nvox[3] = {g.nx, g.ny, g.nz};
-    int b_hint = per_item ? (int)blockIdx.x : item_of_atom(atom_offsets, g.B, a_lo, 0);
+    int b_hint = per_item ? (int)blk : item_of_atom(atom_offsets, g.B, a_lo, 0);
     for (long long base = a_lo; base < a_hi; base += WAVE) {               // wave-uniform
         const long long a_mine = base + lane;
         bool wide = false;
@@ -1839,7 +1813,7 @@ MK_KERNEL(64) void k_exact_fixup(GridDesc g, int per_item, const unsigned* __res
             const int l = mk_ctz64(todo);
             todo &= todo - 1ull;
             const long long a = base + l;
-            const int b = per_item ? (int)blockIdx.x : item_of_atom(atom_offsets, g.B, a, b_hint);
+            const int b = per_item ? (int)blk : item_of_atom(atom_offsets, g.B, a, b_hint);
             b_hint = b;
             // position in voxel units, as the binning sees it
             float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
@@ -1901,6 +1875,58 @@ MK_KERNEL(64) void k_exact_fixup(GridDesc g, int per_item, const unsigned* __res
             }
         }
     }
+}
+
+// The last launch of a call: (a) the tiles the tile kernel left for the dense instance (usually none), (b) the
+// exact cut-off fix-up, which must see a tile's final values -- in ONE launch instead of two (5 us of every small
+// call).  Blocks [0, dense_wgs) take dense tiles; the rest are fix-up waves, and only when there WERE dense tiles do
+// they wait for the dense blocks to finish: those have lower block indices, so they were all dispatched -- running or
+// done -- before the first fix-up wave started, and the wait cannot starve them.
+// Block 0 also mirrors the tier statistics and the error flag to host-visible memory and clears the OTHER copy of the
+// dense words (two copies alternate from call to call, so that nothing still reads what is being cleared).
+template <int K, int ECAP, typename SigT>
+MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __restrict__ cell_start,
+                          const float4* __restrict__ rec_pos, const unsigned* __restrict__ rec_cls,
+                          const unsigned* __restrict__ cls_table, float* __restrict__ out,
+                          unsigned* __restrict__ dense_words, unsigned* __restrict__ other_words,
+                          const unsigned* __restrict__ dense_list, unsigned* __restrict__ feedback, const int* __restrict__ err_flag,
+                          int per_item, const unsigned* __restrict__ summary, const float* __restrict__ coords,
+                          const long long* __restrict__ atom_offsets, long long total_atoms, const SigT* __restrict__ sigmas,
+                          const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
+                          const uint2* __restrict__ tmp_cls)
+{
+    __shared__ double s_best[WAVE];
+    const unsigned n = dense_words[0], total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x <= (unsigned)DENSE_WORDS) other_words[threadIdx.x] = 0u;       // (word DENSE_WORDS = the done counter)
+        if (feedback && threadIdx.x == 0) {                                // host-visible: drives the next calls' tier
+#pragma unroll
+            for (int t = 0; t < NTIER; ++t) feedback[t] = dense_words[1 + t];
+            feedback[NTIER] = total_tiles * (unsigned)g.G;
+            feedback[NTIER + 1] = (unsigned)*err_flag;  // mirror of the device-side error flag (set by the binning, long done)
+        }
+    }
+    if (blockIdx.x < dense_wgs) {
+        for (unsigned i = blockIdx.x; i < n; i += dense_wgs) {             // wave-uniform
+            const unsigned e = dense_list[i];
+            voxelize_tile<K, true, ECAP>(g, e % total_tiles, (int)(e / total_tiles), cell_start, rec_pos, nullptr, rec_cls, cls_table, out, nullptr, nullptr);
+            mk_block_sync();                                               // LDS arrays are reused by the next tile
+        }
+        if (n != 0u) {                                                     // somebody may be waiting for these stores
+            mk_threadfence();
+            mk_block_sync();
+            if (threadIdx.x == 0) (void)mk_atomic_add(&dense_words[DENSE_WORDS], 1u);
+        }
+        return;
+    }
+    if (n != 0u) {                                                         // wave-uniform, rare
+        if (threadIdx.x == 0)
+            while (mk_load_relaxed(&dense_words[DENSE_WORDS]) < dense_wgs) mk_sleep();
+        mk_block_sync();
+        mk_threadfence();
+    }
+    exact_fixup_block<SigT>(g, blockIdx.x - dense_wgs, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
+                            tmp_cls, out, s_best);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -68,6 +68,10 @@ MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
     return t < m ? t : m;
 }
 
+// device-scope fence: this thread's earlier writes are visible to every CU before its later ones (and vice versa for reads)
+MK_DEV void mk_threadfence() { __threadfence(); }
+MK_DEV void mk_sleep() { __builtin_amdgcn_s_sleep(8); }
+
 // workgroup barrier (for the 64-thread tile kernel this is a single-wave s_barrier).
 MK_DEV void mk_block_sync() { __syncthreads(); }
 

@@ -29,7 +29,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT, WS_DENSE_WORDS,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS, WS_H_STAGE,
     // distance_utils row (dist_pipeline.h)
@@ -187,8 +187,18 @@ inline int choose_tier(int forced, const volatile unsigned* feedback)
 
 enum TileFlavour { TILES_PLAIN = 0, TILES_LEAN = 1, TILES_TEAM = 2 };
 
+// what the call's last launch (k_tail: dense tiles + exact cut-off fix-up) needs besides the tile kernel's arguments
+struct TailArgs {
+    unsigned dense_wgs = 0, fix_waves = 0;
+    unsigned* other_words = nullptr;
+    int per_item = 0;
+    const unsigned* summary = nullptr;
+    const LatticeProblem* P = nullptr;
+    const void* tcls = nullptr;
+};
+
 template <int K, int T, class BE>
-int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
                       void* ctab, float* out, unsigned* dcount, void* dlist, void* eflag)
 {
     constexpr int E = ECAP_TIER[T];
@@ -206,27 +216,37 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, unsigned dense_wgs, const
         st = be.launch(k_voxelize_tiles<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                        (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
     }
-    if (!st && !g.force_general)      // the tiles left behind (usually none) + the statistics for the next call
-        st = be.launch(k_voxelize_dense_tiles<K, E>, dim3(dense_wgs), dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos,
-                       (const unsigned*)rcls, (const unsigned*)ctab, out, (const unsigned*)dcount, (const unsigned*)dlist,
-                       be.feedback_dev(), (const int*)eflag);
+    // the tiles left behind (usually none), the statistics for the next call and the exact cut-off fix-up: one launch
+    if (!st && ta.dense_wgs + ta.fix_waves != 0u) {
+        const LatticeProblem& P = *ta.P;
+        auto tail = [&](auto kern, auto* sig) {
+            return be.launch(kern, dim3(ta.dense_wgs + ta.fix_waves), dim3(WAVE), g, ta.dense_wgs, (const unsigned*)start, (const float4*)rpos,
+                             (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, ta.other_words, (const unsigned*)dlist,
+                             g.force_general ? (unsigned*)nullptr : be.feedback_dev(), (const int*)eflag, ta.per_item, ta.summary, P.coords,
+                             P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls);
+        };
+        st = P.sigmas_f64 ? tail(k_tail<K, E, double>, (const double*)P.sigmas) : tail(k_tail<K, E, float>, (const float*)P.sigmas);
+    }
     return st;
 }
 
 template <int K, class BE>
-int launch_tiles(BE& be, int tier, int flavour, dim3 tgrid, unsigned dense_wgs, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
+int launch_tiles(BE& be, int tier, int flavour, dim3 tgrid, const TailArgs& ta, const GridDesc& g, void* start, void* rpos, void* rw, void* rcls,
                  void* ctab, float* out, unsigned* dcount, void* dlist, void* eflag)
 {
     switch (tier) {
-    case 0: return launch_tiles_tier<K, 0>(be, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
-    case 1: return launch_tiles_tier<K, 1>(be, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
-    default: return launch_tiles_tier<K, 2>(be, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    case 0: return launch_tiles_tier<K, 0>(be, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    case 1: return launch_tiles_tier<K, 1>(be, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
+    default: return launch_tiles_tier<K, 2>(be, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, out, dcount, dlist, eflag);
     }
 }
 
 // What a backend remembers about the cell-counter buffer of one workspace set (run_lattice): which allocation it is and
 // how many of its leading bytes are known to be zero between calls.
-struct CounterState { void* ptr = nullptr; size_t clean = 0; };
+// The dense words (dense-tile list length, tier statistics, k_tail's done counter) live in a buffer of their own, in TWO
+// copies that alternate from call to call: a call's last launch clears the copy the NEXT call will use.
+struct CounterState { void* ptr = nullptr; size_t clean = 0; void* wptr = nullptr; bool wclean = false; unsigned parity = 0; };
+constexpr int DENSE_SET_WORDS = DENSE_WORDS + 1;     // + the done counter of k_tail's dense blocks
 
 // The lattice hot path: bin -> scan -> fill -> tile kernel.  All pointers in P are device pointers.
 template <class BE>
@@ -256,10 +276,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     const size_t ncells = (size_t)g.B * (size_t)g.cstride;
     void *count = nullptr, *start = nullptr, *rpos = nullptr, *rw = nullptr, *rcls = nullptr, *ctab = nullptr, *eflag = nullptr;
     void *tpos = nullptr, *tidx = nullptr, *tcls = nullptr;
-    // count[ncells ...] = length of the dense-tile list + tier statistics (zeroed with the counters)
-    // (the counters are cleared with one memset per call: its size is kept a multiple of 256 bytes -- an odd tail costs
-    //  the runtime a second fill kernel, ~4 us on the latency path of a single-grid call)
-    const size_t count_bytes = ((ncells + DENSE_WORDS) * sizeof(unsigned) + 255) & ~(size_t)255;
+    // (when the counters do need a memset its size is a multiple of 256 bytes: an odd tail costs the runtime a second
+    //  fill kernel)
+    const size_t count_bytes = (ncells * sizeof(unsigned) + 255) & ~(size_t)255;
+    void* dwords_all = nullptr;
+    if ((st = be.ensure(WS_DENSE_WORDS, 2 * DENSE_SET_WORDS * sizeof(unsigned), &dwords_all, set))) return st;
     if ((st = be.ensure(WS_CELL_COUNT, count_bytes, &count, set))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
     if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos, set))) return st;
@@ -275,13 +296,20 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (cs.ptr != count) { cs.ptr = count; cs.clean = 0; }
     size_t clean_after = cs.clean;
     cs.clean = 0;                                   // nothing is vouched for until this call has been enqueued in full
+    if (cs.wptr != dwords_all || !cs.wclean) {      // new buffer, or a call that failed half-way: both copies from scratch
+        if ((st = be.fill(dwords_all, 0, 2 * DENSE_SET_WORDS * sizeof(unsigned)))) return st;
+        cs.wptr = dwords_all;
+    }
+    cs.wclean = false;
+    unsigned* const dcount = (unsigned*)dwords_all + cs.parity * DENSE_SET_WORDS;
+    unsigned* const dother = (unsigned*)dwords_all + (cs.parity ^ 1u) * DENSE_SET_WORDS;
 
     const unsigned* fix_summary = nullptr;         // what k_exact_fixup looks at first (see there)
     unsigned fix_waves = 0;
     if (per_item) {
         fix_summary = g.force_general ? nullptr : (const unsigned*)ctab;
         fix_waves = (unsigned)g.B;
-        unsigned* dwords = (unsigned*)count + ncells;
+        unsigned* dwords = dcount;
         auto go = [&](auto kern) {
             // few items: big blocks (latency of the one item matters); many items: small blocks (they fill the chip)
             const unsigned threads = (g.B < 512 && P.total_atoms > 256LL * (long long)g.B) ? 1024u : 256u;
@@ -295,7 +323,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (st) return st;
     } else {
         // The counters are zero when a call starts and every call leaves them zero (the scan kernels clear what they
-        // read, the fix-up kernel the dense words): the memset -- a launch of its own, 6 us of a one-grid call -- is only
+        // read): the memset -- a launch of its own, 6 us of a one-grid call -- is only
         // needed for bytes no call has vouched for yet (a new or grown buffer, a call that failed half-way).
         if (clean_after < count_bytes) {
             if ((st = be.fill(count, 0, count_bytes))) return st;
@@ -354,8 +382,6 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((unsigned long long)total_tiles * (unsigned)g.G > 0xFFFF0000ull) { err = "batch too large: more than 2^32 tiles x channel groups; split the batch"; return ST_EINVAL; }
     void* dlist = nullptr;
     if ((st = be.ensure(WS_DENSE_LIST, (size_t)total_tiles * g.G * sizeof(unsigned), &dlist, set))) return st;
-    unsigned* dcount = (unsigned*)count + ncells;
-    const unsigned dense_wgs = total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u;
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
     // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
     const bool team = P.tile_team > 0 || (P.tile_team < 0 && (unsigned long long)total_tiles * (unsigned)g.G <= 1024ull);
@@ -364,20 +390,20 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
 #else
     const int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
 #endif
+    TailArgs ta;
+    // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)
+    ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
+    ta.fix_waves = fix_waves; ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
     be.hot_begin();
-    st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
-                  : launch_tiles<4>(be, tier, flavour, tgrid, dense_wgs, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
-    if (!st && fix_waves != 0u) {
-        // exact cut-off decisions for wide sigmas (the waves whose atoms have none -- normally all -- leave at once)
-        st = P.sigmas_f64 ? be.launch(k_exact_fixup<double>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,
-                                      P.total_atoms, (const double*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out, dcount)
-                          : be.launch(k_exact_fixup<float>, dim3(fix_waves), dim3(WAVE), g, per_item ? 1 : 0, fix_summary, P.coords, P.atom_offsets,
-                                      P.total_atoms, (const float*)P.sigmas, P.origins, P.box, P.affine, (const uint2*)tcls, P.out, dcount);
-    }
+    st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
+                  : launch_tiles<4>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
     be.hot_end();
-    // (a call without atoms launches no fix-up, and nothing that could have touched a counter either)
-    if (!st) cs.clean = clean_after;
-    be.note_error_flag_mirrored(!st && !g.force_general && be.feedback_dev() != nullptr);
+    if (!st) {
+        cs.clean = clean_after;
+        cs.wclean = true;
+        if (ta.dense_wgs + ta.fix_waves != 0u) cs.parity ^= 1u;       // k_tail has cleared the other copy: the next call's
+    }
+    be.note_error_flag_mirrored(!st && !g.force_general && ta.dense_wgs != 0u && be.feedback_dev() != nullptr);
     be.tile_done(set);
     return st;
 }

@@ -270,6 +270,23 @@ def case_cutoff_adversarial(vs, periodic=False):
     return case
 
 
+def case_dense_with_wide_sigmas():
+    """Dense tiles (900 atoms in a 7 A cube: more entries than any LDS tier holds, several rounds of the dense instance)
+    AND wide sigmas on exactly representable geometry (atoms on voxel centres, sigma = 3 A in channel 7: voxels at exactly
+    5 A along the axes and on 3-4-0 triangles, value at the cut-off 2.2e-3): the exact cut-off fix-up has to run AFTER
+    the dense tiles of the same call -- one launch does both (k_tail), and its fix-up waves wait for its dense blocks."""
+    rng = np.random.default_rng(77)
+    n = 900
+    c = rng.uniform(0, 7, size=(n, 3)).astype(np.float32)
+    s = np.tile(rng.choice([1.1, 1.7, 1.52], size=(n, 1)), (1, 8)).astype(np.float64)
+    s = np.where(rng.random((n, 8)) < np.asarray([1.0, 0.1, 0.1, 0.3, 1.0, 0.05, 0.0, 0.2])[None, :], s, 0.0)
+    s[:, 7] = 0.0
+    lattice = np.array([[0, 0, 0], [7, 7, 7], [3, 4, 4], [12, 3, 8], [-2, 9, 1]], np.float32)
+    sl = np.zeros((len(lattice), 8))
+    sl[:, 7] = 3.0
+    return _case(np.concatenate([c, lattice]), [0, n + len(lattice)], np.concatenate([s, sl]), [[-4.0, -4.0, -4.0]], [24, 16, 16], 1.0)
+
+
 def case_channels(C):
     """Channel counts other than 8 (channel groups: 1 -> padded group, 11 -> two groups)."""
     rng = np.random.default_rng(24 + C)
@@ -352,6 +369,7 @@ LATTICE_CASES = {
     "channels3": lambda: case_channels(3),
     "channels11": lambda: case_channels(11),
     "special_sigmas": case_special_sigmas,
+    "dense_with_wide_sigmas": case_dense_with_wide_sigmas,
     "pbc_batch": case_pbc_batch,
     "cfg4_small": case_cfg4_small,
 }
