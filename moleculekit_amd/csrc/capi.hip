@@ -577,6 +577,31 @@ try {
     return st;
 } MK_API_CATCH
 
+// End of a small synchronous call (tens of microseconds of GPU work): poll the stream instead of blocking on it -- the
+// blocking wait's wake-up costs more than the polls; a call that is still running after ~2 000 polls blocks after all.
+static hipError_t wait_for_small_call(hipStream_t s)
+{
+    for (int i = 0; i < 2000; ++i) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+    }
+    (void)hipGetLastError();
+    return hipStreamSynchronize(s);
+}
+
+// float32 -> float64 over the result of a call (the drop-in path returns the reference's float64 [V, C]): the baseline
+// x86-64 build converts two values per instruction; where the host has AVX2 (checked at run time) eight
+__attribute__((target("avx2"))) static void widen_avx2(const float* __restrict__ src, double* __restrict__ dst, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+static void widen(const float* __restrict__ src, double* __restrict__ dst, size_t n)
+{
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { widen_avx2(src, dst, n); return; }
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+
 // `features64` != NULL: the caller wants the reference's float64 [B,V,C] (voxeldescriptors.py:531); the widening is
 // done here, in the pass that takes the results out of the pinned buffer anyway, instead of in a second pass in numpy
 static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
@@ -683,12 +708,12 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
             HIP_TRY(hipMemcpyAsync(ctx->f32_stage.data(), dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
             src = ctx->f32_stage.data();
         }
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < nvals; ++i) features64[i] = (double)src[i];
+        HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
+        widen(src, features64, nvals);
         return collect_async_errors(ctx);
     }
     if (!mapped_out) HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
     if (mapped_out) memcpy(features, ctx->out_host, out_bytes);
     return collect_async_errors(ctx);
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""tools/dropin_profile.py -- where the drop-in getVoxelDescriptors(3PTB) call spends its time on the host:
+cProfile over 300 calls (cumulative per function), and the bare C call (mkamd_voxelize_lattice_host_f64) timed alone."""
+import cProfile, os, pstats, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
+from moleculekit_amd import _lib
+
+g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "cfg1_3ptb.npz"))
+kw = dict(boxsize=[24, 24, 24], center=g["center"], voxelsize=1, usercoords=g["coords"], userchannels=g["sigmas"])
+for _ in range(20):
+    getVoxelDescriptors(None, **kw)
+n = 300
+t0 = time.perf_counter()
+for _ in range(n):
+    getVoxelDescriptors(None, **kw)
+print(f"getVoxelDescriptors: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call")
+# the C call alone, same arrays as _getOccupancyC hands over
+ctx = _lib.default_context()
+from tests.synth import grid_origin
+o, nv = grid_origin(g["center"], g["boxsize"], 1.0)
+coords = np.ascontiguousarray(g["coords"], np.float32)
+sig = np.ascontiguousarray(g["sigmas"], np.float64)
+offs = np.array([0, len(coords)], np.int64)
+out = np.empty((1, int(np.prod(nv)), 8), np.float64)
+org = np.ascontiguousarray(o[None], np.float64)
+nv32 = np.ascontiguousarray(nv, np.int32)
+for _ in range(20):
+    ctx.voxelize_lattice_host(1, coords, offs, sig, True, 8, org, nv32, 1.0, None, 1, out)
+t0 = time.perf_counter()
+for _ in range(n):
+    ctx.voxelize_lattice_host(1, coords, offs, sig, True, 8, org, nv32, 1.0, None, 1, out)
+print(f"mkamd_voxelize_lattice_host_f64 through ctypes: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call")
+out32 = np.empty((1, int(np.prod(nv)), 8), np.float32)
+sig32 = sig.astype(np.float32)
+t0 = time.perf_counter()
+for _ in range(n):
+    ctx.voxelize_lattice_host(1, coords, offs, sig32, False, 8, org, nv32, 1.0, None, 1, out32)
+print(f"  float32 sigmas in, float32 features out: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(n):
+    getVoxelDescriptors(None, **kw)
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
