@@ -21,9 +21,10 @@
 //   zero-fill pass, one 32-byte store per voxel.  MFMA unused (a neighbourhood min-reduction).
 //
 // Kernels, in launch order (pipeline.h):
-//   big items  : memset, k_bin_count, k_prepass_reduce1/2, k_scan_finish, k_bin_fill      (cell lists)
+//   big items  : k_bin_count, k_prepass_reduce1/2, k_scan_finish, k_bin_fill              (cell lists; the counters
+//                clear themselves, pipeline.h)
 //   small items: k_prepass_items                                  (the same, one workgroup per item)
-//   then       : k_voxelize_tiles[_lean]<K,ECAP>, k_voxelize_dense_tiles<K,ECAP>          (the grid)
+//   then       : k_voxelize_tiles[_lean|_team]<K,ECAP>, k_tail<K,ECAP,SigT>                 (the grid; dense tiles + fix-up)
 //   explicit centres: k_sigma_to_w, k_occupancy_centers;   lattice centres: k_grid_centers.
 //
 // Coordinates: everything is in VOXEL units relative to the grid origin (voxel i's centre sits at
@@ -97,7 +98,7 @@ struct GridDesc {
     unsigned M;                 // capacity of the record arrays (= total atoms x img_cap)
     int img_cap;                // temp / record slots reserved per atom (1 unless periodic)
     int prepass_hurry;          // 1: binning / fill waves raise their issue priority (pipeline.h, run_lattice)
-    // exact cut-off decisions for wide sigmas (k_exact_fixup)
+    // exact cut-off decisions for wide sigmas (k_tail's fix-up waves)
     double res;                 // voxelsize
     float w_exact_max;          // an entry with w below this has a value step > 5e-6 at the cutoff (sigma > 1.81 A)
 };

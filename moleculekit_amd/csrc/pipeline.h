@@ -304,7 +304,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     unsigned* const dcount = (unsigned*)dwords_all + cs.parity * DENSE_SET_WORDS;
     unsigned* const dother = (unsigned*)dwords_all + (cs.parity ^ 1u) * DENSE_SET_WORDS;
 
-    const unsigned* fix_summary = nullptr;         // what k_exact_fixup looks at first (see there)
+    const unsigned* fix_summary = nullptr;         // what a fix-up wave of k_tail looks at first (see exact_fixup_block)
     unsigned fix_waves = 0;
     if (per_item) {
         fix_summary = g.force_general ? nullptr : (const unsigned*)ctab;
