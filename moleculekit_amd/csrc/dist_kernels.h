@@ -17,15 +17,35 @@
 
 namespace mkamd {
 
+// d - b * round(d / b) (distance_utils.pyx:49-51) without the division where that is provably the same: what is needed of
+// fl(d / b) is only WHICH integer it rounds to.  q = fl(d * fl(1 / b)) is within 3 x 2^-24 |q| of fl(d / b); unless q sits
+// that close to a half-integer (where round() changes its value) both round to the same integer.  Lanes that do -- and
+// everything that is not an ordinary number: zero boxes, overflow, NaN fail the comparison -- take the correctly rounded
+// division.  `ib` = fl(1 / b), computed once per (lane, frame) instead of three IEEE divisions per pair.
+MK_DEV float wrap_axis_f32(float d, float b, float ib)
+{
+    const float q = mk_fmul_rn(d, ib);
+    const float t = fabsf(q);
+    const float fr = t - floorf(t);                                   // exact
+    float r;
+    if (fabsf(fr - 0.5f) > 3e-7f * t + 1e-30f) {
+        r = roundf(q);
+    } else {
+        asm volatile("" ::: "memory");                               // a real branch: the division must not be computed "just in case"
+        r = roundf(mk_fdiv_rn(d, b));
+    }
+    return mk_fsub_rn(d, mk_fmul_rn(b, r));
+}
+
 // distance_utils.pyx:34-54 (_dist) / :188-206 (_dist2)
 MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y2, float z2,
-                                 float bx, float by, float bz, bool wrap)
+                                 float bx, float by, float bz, float ibx, float iby, float ibz, bool wrap)
 {
     float dx = mk_fsub_rn(x1, x2), dy = mk_fsub_rn(y1, y2), dz = mk_fsub_rn(z1, z2);
     if (wrap) {
-        dx = mk_fsub_rn(dx, mk_fmul_rn(bx, roundf(mk_fdiv_rn(dx, bx))));
-        dy = mk_fsub_rn(dy, mk_fmul_rn(by, roundf(mk_fdiv_rn(dy, by))));
-        dz = mk_fsub_rn(dz, mk_fmul_rn(bz, roundf(mk_fdiv_rn(dz, bz))));
+        dx = wrap_axis_f32(dx, bx, ibx);
+        dy = wrap_axis_f32(dy, by, iby);
+        dz = wrap_axis_f32(dz, bz, ibz);
     }
     return mk_fadd_rn(mk_fadd_rn(mk_fmul_rn(dx, dx), mk_fmul_rn(dy, dy)), mk_fmul_rn(dz, dz));
 }
@@ -101,6 +121,7 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
         const long long f = f0 + fl;
         const bool fin = f < F;
         const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
+        const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
         unsigned cur_a = 0xffffffffu;
         float xa = 0.f, ya = 0.f, za = 0.f;
         // this wave takes 16 CONSECUTIVE pairs of the tile (they mostly share the first atom)
@@ -115,7 +136,7 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
             }
             if (fin) {
                 const float d2 = dist2_min_image_f32(xa, ya, za, coords[((size_t)b * 3 + 0) * F + f], coords[((size_t)b * 3 + 1) * F + f],
-                                                     coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, wrap[p] != 0u);
+                                                     coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, ibx, iby, ibz, wrap[p] != 0u);
                 tile[pp][fl] = squared ? d2 : mk_fsqrt_rn(d2);
             }
         }
@@ -151,6 +172,7 @@ MK_DEV unsigned contact_mask(const float* __restrict__ coords, long long F, long
 {
     unsigned mask = 0u, cur_a = 0xffffffffu;
     float xa = 0.f, ya = 0.f, za = 0.f;
+    const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
     for (int k = 0; k < CT_RUN; ++k) {
         const long long p = p_first + k;
         if (p >= P) break;                                         // wave-uniform
@@ -161,7 +183,7 @@ MK_DEV unsigned contact_mask(const float* __restrict__ coords, long long F, long
         }
         if (fin) {
             const float d2 = dist2_min_image_f32(xa, ya, za, coords[((size_t)b * 3 + 0) * F + f], coords[((size_t)b * 3 + 1) * F + f],
-                                                 coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, wrap[p] != 0u);
+                                                 coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, ibx, iby, ibz, wrap[p] != 0u);
             mask |= (d2 <= thr2) ? (1u << k) : 0u;                 // distance_utils.pyx:82 / :111 (NaN: no contact)
         }
     }
@@ -305,6 +327,7 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
         const long long a = ga[p], b = gb[p];
         const bool w = wrap[p] != 0u;
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
+        const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
         const long long i0 = com1 ? a : g1_off[a], i1 = com1 ? a + 1 : g1_off[a + 1];
         const long long j0 = com2 ? b : g2_off[b], j1 = com2 ? b + 1 : g2_off[b + 1];
         float mindist = -1.f;
@@ -314,7 +337,7 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
             for (long long j = j0; j < j1; ++j) {
                 const size_t at2 = com2 ? (size_t)j : (size_t)g2_atoms[j];
                 const float d2 = dist2_min_image_f32(x1, y1, z1, c2[(at2 * 3 + 0) * F + f], c2[(at2 * 3 + 1) * F + f],
-                                                     c2[(at2 * 3 + 2) * F + f], bx, by, bz, w);
+                                                     c2[(at2 * 3 + 2) * F + f], bx, by, bz, ibx, iby, ibz, w);
                 if (d2 < mindist || mindist < 0.f) mindist = d2;
             }
         }
