@@ -1124,7 +1124,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                           unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
 {
     static_assert(K == 4 || K == 8, "K");
-    static_assert(TEAM == 1 || (!DENSE && K % TEAM == 0), "a team splits the planes of the epilogue evenly");
+    static_assert(TEAM == 1 || (!DENSE && K % TEAM == 0 && (TEAM & (TEAM - 1)) == 0), "a team (a power of two of waves) splits the planes of the epilogue evenly");
     constexpr int KL = K;                                 // planes in this wave's accumulators (all of them)
     constexpr int KE = K / TEAM;                          // planes of the epilogue this wave owns: [kb, kb + KE)
     MK_PHASE_BEGIN();
@@ -1358,6 +1358,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         };
         // ---- one channel, class by class: inner loop = sub, fma, half a min3 per (voxel, entry); the
         //      class flush applies the cutoff to the class minimum and scales by w ----
+        unsigned deal = 0u;                                  // team: the wave the next pair goes to (wave-uniform)
         auto process_classes = [&](int c, unsigned bits, unsigned (&acc)[KL]) {
             while (bits) {                                                // wave-uniform
                 const int cls = __builtin_ctz(bits);
@@ -1379,9 +1380,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     if (MK_DIAG & 1) return;
                     constexpr int J0 = K0, J1 = K1;
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
-                    // a team's wave takes every TEAM-th pair; the unpaired last entry goes to the wave whose turn it would be
+                    // a team's wave takes every TEAM-th pair, dealt round-robin ACROSS the sub-buckets (`deal` = whose turn it
+                    // is: the same in every wave) -- most sub-buckets hold one to three pairs, and starting each of them at
+                    // wave 0 gave that wave 60 pairs of a cfg2 tile and the last one 20; the unpaired last entry is dealt too
                     const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
-                    const float* e = sxyz + s0 + (TEAM > 1 ? 2u * (unsigned)wv : 0u);
+                    const unsigned first = TEAM > 1 ? (((unsigned)wv + (unsigned)TEAM - deal) & (unsigned)(TEAM - 1)) : 0u;
+                    const float* e = sxyz + s0 + 2u * first;
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
                     //  have to be merged after every one of these short runs -- measured 7 % slower)
                     // (the LDS address is the only induction variable: a trip counter ends up in a VGPR with a carry-out
@@ -1400,7 +1404,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                             m[k] = mk_min3(m[k], gk[0], gk[1]);
                         }
                     }
-                    if (odd && (TEAM == 1 || (unsigned)wv == (npairs & (unsigned)(TEAM - 1)))) {   // wave-uniform: the unpaired last entry
+                    const bool tail_mine = TEAM == 1 || (unsigned)wv == ((deal + npairs) & (unsigned)(TEAM - 1));
+                    if (TEAM > 1) deal = (deal + npairs + odd) & (unsigned)(TEAM - 1);
+                    if (odd && tail_mine) {                               // wave-uniform: the unpaired last entry
                         const float* t = sxyz + s0 + 2u * npairs;
                         const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
                         const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
