@@ -12,3 +12,6 @@ for wl in cfg3 cfg4; do rm -rf gpurun_out/prof_$wl; (cd /tmp && timeout 300 rocp
 tail -5 gpurun_out/session_a.txt | cut -c1-300; cat gpurun_out/diag_breakdown.txt | tail -7; tail -4 gpurun_out/latency_probe.txt
 for wl in cfg1 cfg5; do rm -rf gpurun_out/prof_$wl; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py --no-cpu-baseline --no-extra --workload $wl --steps 5 > $R/gpurun_out/rocprof_$wl.log 2>&1); done
 (MKAMD_LIB=.variants/libmkamd_phase.so python tools/phase_timers.py cfg2 > gpurun_out/phase_timers.txt 2>&1; MKAMD_LIB=.variants/libmkamd_phase.so python tools/phase_timers.py cfg3 >> gpurun_out/phase_timers.txt 2>&1; MKAMD_LIB=.variants/libmkamd_phase.so python tools/phase_timers.py cfg2 1 >> gpurun_out/phase_timers.txt 2>&1)
+for w in cfg2 3ptb; do rm -rf gpurun_out/st_$w; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/st_$w -- python $R/tools/single_timeline.py $w > $R/gpurun_out/st_$w.log 2>&1); python tools/single_timeline_report.py gpurun_out/st_$w > gpurun_out/single_timeline_$w.txt 2>&1; done
+(timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
+(bash tools/gpu_pmc_bin.sh > gpurun_out/pmc_bin.txt 2>&1)
