@@ -328,3 +328,36 @@ def test_pipelined_calls_match_in_order_calls(hip_ctx):
     for a, b in zip(ref, got):
         assert np.array_equal(a, b)
     assert ref[0].max() > 0.5
+
+
+def test_many_dense_tiles_with_fixups_in_one_tail_launch(hip_ctx):
+    """k_tail at scale: 400 copies of the dense + wide-sigma item (4 800 tiles, most of them dense: more than the 4 096
+    dense blocks of the launch, so the blocks loop) -- every fix-up wave has to wait for the dense blocks, and every
+    copy must come out with the same bits, within tolerance of the oracle.  In order and with the
+    steps software-pipelined (the next call's pre-pass beside this call's tail)."""
+    from moleculekit_amd import batch
+    from tests.cases import case_dense_with_wide_sigmas, check
+    case = case_dense_with_wide_sigmas()
+    n = len(case["coords"])
+    B = 400
+    one = batch.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                 case["voxelsize"], ctx=hip_ctx)
+    check(case, one)
+    coords = np.tile(case["coords"], (B, 1))
+    sig = np.tile(case["sigmas"], (B, 1))
+    offs = np.arange(B + 1, dtype=np.int64) * n
+    origins = np.tile(case["origins"], (B, 1))
+    try:
+        for pipelined, prepass in ((False, -1), (True, -1), (False, 0), (True, 0)):   # per-item pre-pass / kernel chain
+            hip_ctx.set_pipelining(pipelined)
+            hip_ctx.set_prepass_mode(prepass)
+            for _ in range(3):
+                got = batch.voxelize_lattice(coords, offs, sig, origins, case["nvoxels"], case["voxelsize"], ctx=hip_ctx)
+                assert got.shape[0] == B
+                check(case, got[:1])
+                assert np.abs(got[0] - one[0]).max() <= 6e-6      # (the one-item call runs K = 4 tiles, the batch K = 8)
+                bad = [b for b in range(B) if not np.array_equal(got[b], got[0])]
+                assert not bad, (pipelined, prepass, len(bad), bad[:5], float(np.abs(got[bad[0]] - got[0]).max()))
+    finally:
+        hip_ctx.set_pipelining(False)
+        hip_ctx.set_prepass_mode(-1)
