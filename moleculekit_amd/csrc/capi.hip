@@ -583,7 +583,10 @@ static hipError_t wait_for_small_call(hipStream_t s)
 {
     for (int i = 0; i < 2000; ++i) {
         const hipError_t e = hipStreamQuery(s);
-        if (e != hipErrorNotReady) return e;
+        if (e != hipErrorNotReady) {
+            if (i != 0 && e == hipSuccess) (void)hipGetLastError();    // "not ready" is an answer, not an error to find later
+            return e;
+        }
     }
     (void)hipGetLastError();
     return hipStreamSynchronize(s);
