@@ -311,8 +311,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         fix_waves = (unsigned)g.B;
         unsigned* dwords = dcount;
         auto go = [&](auto kern) {
-            // few items: big blocks (latency of the one item matters); many items: small blocks (they fill the chip)
-            const unsigned threads = (g.B < 512 && P.total_atoms > 256LL * (long long)g.B) ? 1024u : 256u;
+            // few items: big blocks (latency of the one item matters); many items: small blocks (they fill the chip) --
+            // down to ONE wave per item for ligand-sized items (a block's time is a chain of latencies whatever its
+            // size, and four times as many blocks are resident: cfg3's 32 768 items 343 -> ~90 us)
+            const long long avg = P.total_atoms / (long long)g.B;
+            const unsigned threads = (g.B < 512 && avg > 256) ? 1024u : (g.B >= 2048 && avg <= 64) ? 64u : (g.B >= 2048 && avg <= 128) ? 128u : 256u;
             return be.launch(kern, dim3((unsigned)g.B), dim3(threads), g, P.coords, P.atom_offsets, P.sigmas, P.origins, P.box, P.affine,
                              (unsigned*)start, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls,
                              (unsigned*)ctab, dwords, (int*)eflag);
