@@ -176,6 +176,7 @@ struct mkamd_ctx {
         return set;
     }
     bool set_is_pipelined(int) const { return in_pipelined_prepass; }
+    bool pipelining_possible() const { return pipelining && side_stream && !pipeline_broken; }
     void prepass_done(int set)
     {
         if (!in_pipelined_prepass) return;

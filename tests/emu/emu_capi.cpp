@@ -48,6 +48,7 @@ struct EmuBackend {
     void hot_end() {}
     int acquire_set(bool) { return 0; }
     bool set_is_pipelined(int) const { return false; }
+    bool pipelining_possible() const { return false; }
     void prepass_done(int) {}
     void tile_done(int) {}
 };
