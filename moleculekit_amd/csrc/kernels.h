@@ -465,25 +465,25 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         // periodic: the images p + k L inside grid + halo.  Nearly every atom has exactly one, so the FIRST image of
         // every lane is ranked together (one atomic per distinct cell of the wave, like above) and only further images
         // (grids wider than the box) fall back to one atomic each.
-        const int nkx = drop ? 0 : (k1[0] >= k0[0] ? k1[0] - k0[0] + 1 : 0);
-        const int nky = drop ? 0 : (k1[1] >= k0[1] ? k1[1] - k0[1] + 1 : 0);
-        const int nkz = drop ? 0 : (k1[2] >= k0[2] ? k1[2] - k0[2] + 1 : 0);
-        const int nimg = nkx * nky * nkz;
-        auto image = [&](int i, int (&pc)[3], float (&rel)[3]) {      // i-th image, x slowest (the order of the old loops)
-            const int kz = k0[2] + i % nkz, ky = k0[1] + (i / nkz) % nky, kx = k0[0] + i / (nkz * nky);
+        // (the images are walked with three counters, z fastest -- x slowest, the order of the old loops; an index that
+        //  is divided back into (kx, ky, kz) costs three integer divisions per image and a dozen registers)
+        const bool none = drop || k1[0] < k0[0] || k1[1] < k0[1] || k1[2] < k0[2];
+        int kx = k0[0], ky = k0[1], kz = k0[2];
+        bool more = !none;                                           // (kx, ky, kz) is an image not looked at yet
+        auto image = [&](int (&pc)[3], float (&rel)[3]) {            // look at the current image, step to the next
             const double q[3] = {p[0] + kx * Lv[0], p[1] + ky * Lv[1], p[2] + kz * Lv[2]};
+            if (++kz > k1[2]) { kz = k0[2]; if (++ky > k1[1]) { ky = k0[1]; if (++kx > k1[0]) more = false; } }
             return locate(q, pc, rel);
         };
-        int i = 0;
         int pc[3] = {0, 0, 0};
         float rel[3] = {0.f, 0.f, 0.f};
         bool want = false;
-        for (; i < nimg && !want; ++i) want = image(i, pc, rel);     // per-lane trip count, no cross-lane work inside
+        while (more && !want) want = image(pc, rel);                 // per-lane trip count, no cross-lane work inside
         const size_t cell0 = want ? (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2] : (size_t)0;
         const unsigned rank0 = rank_wave(want, cell0);                // all lanes
         if (want) park(pc, rel, cell0, rank0);
-        for (; i < nimg; ++i) {
-            if (!image(i, pc, rel)) continue;
+        while (more) {
+            if (!image(pc, rel)) continue;
             if (used >= g.img_cap) { mk_atomic_or(err_flag, MK_ERR_RECORD_OVERFLOW); continue; }
             const size_t cell = (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2];
             park(pc, rel, cell, rank_one(cell));
