@@ -1229,12 +1229,20 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         // bucket = (channel, class, x-reach): an entry whose x lies more than the cutoff below the
         // middle of the tile cannot reach the upper K/2 planes (those pairs would fail d^2 < 25 on
         // dx^2 alone) and vice versa, so such entries are only run against their half of the planes.
-        const float reach = sqrtf(R2) * 1.000001f;
+        // (how far along x an entry reaches depends on how far OUTSIDE the tile's y-z square it sits: rx^2 = R^2 - dyz^2;
+        //  with the plain cutoff as reach 330 pair tests per voxel, tools/tile_model.py)
+        const float R2m = R2 * 1.000002f;
+        auto x_reach = [&](float ex, float ey, float ez) {
+            const float dy = mk_max(mk_abs(ey) - 3.5f, 0.f), dz = mk_max(mk_abs(ez) - 3.5f, 0.f);
+            const float rx2 = R2m - mk_fma(dy, dy, dz * dz);
+            const float lo = 0.5f - ex, hi = ex + 0.5f;               // distance to the nearest plane of the upper / lower half
+            return (lo > 0.f && lo * lo > rx2) ? 1 : ((hi > 0.f && hi * hi > rx2) ? 2 : 0);
+        };
 #pragma unroll
         for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
         mk_block_sync();
-        auto count_entry = [&](bool surv, unsigned, float ex, float, float, unsigned ids) {
-            const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+        auto count_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
+            const int xr = x_reach(ex, ey, ez);
             for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
                 (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
             });
@@ -1477,7 +1485,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
             auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids) {
-                const int xr = (0.5f - ex > reach) ? 1 : ((ex + 0.5f > reach) ? 2 : 0);
+                const int xr = x_reach(ex, ey, ez);
                 for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
                     const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                     sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
