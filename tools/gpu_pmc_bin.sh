@@ -6,7 +6,7 @@ cd /tmp
 for lib in moleculekit_amd/csrc/libmkamd.so "$@"; do
   tag=$(basename $lib .so)
   rm -rf $R/gpurun_out/pb_$tag
-  (MKAMD_DIAG=1 MKAMD_LIB=$R/$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pb_$tag -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-pipeline > $R/gpurun_out/pb_$tag.log 2>&1)
+  (MKAMD_DIAG=1 MKAMD_LIB=$R/$lib timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/pb_$tag -- python $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-pipeline ${PB_ARGS:-} > $R/gpurun_out/pb_$tag.log 2>&1)
 done
 cd $R
 python - "$@" <<'PY'
