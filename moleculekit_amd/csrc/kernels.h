@@ -346,6 +346,7 @@ MK_DEV int item_of_atom(const long long* __restrict__ atom_offsets, int B, long 
 MK_DEV void items_of_block(const long long* __restrict__ atom_offsets, int B, long long total_atoms, long long a_first,
                            long long a_last, int& b_lo, int& b_hi)
 {
+    if (B == 1) { b_lo = b_hi = 0; return; }                       // one item per call (the reference's usage): nothing to look up
     int b = (int)((double)a_first * (double)B / (double)(total_atoms > 0 ? total_atoms : 1));
     b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
     const long long o0 = atom_offsets[b], o1 = atom_offsets[b + 1];
