@@ -495,6 +495,7 @@ def main():
     ctx.set_prepass_mode(int(os.environ.get("MKAMD_PREPASS", "-1")))
     ctx.set_force_general(os.environ.get("MKAMD_FORCE_GENERAL", "0") == "1")
     ctx.set_fine_cells(os.environ.get("MKAMD_FINE_CELLS", "0") == "1")         # A-B knob: half-cutoff cells
+    ctx.set_tile_items(int(os.environ.get("MKAMD_TILE_ITEMS", "-1")))          # A-B knob: a workgroup per item (ligand-sized batches)
     # steps are independent batches whose inputs are resident before the loop: the library may overlap the
     # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)
     ctx.set_pipelining(not args.no_pipeline)

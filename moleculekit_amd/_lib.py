@@ -39,6 +39,7 @@ SIGNATURES = {
     "mkamd_ctx_set_prepass_mode": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
@@ -180,6 +181,11 @@ class Context:
     def set_tile_team(self, mode: int):
         """-1 automatic (default), 0 one wave per tile, 1 a team of four waves per tile (include/mkamd_voxel.h)."""
         _check(load().mkamd_ctx_set_tile_team(self._h, int(mode)))
+
+    def set_tile_items(self, mode: int):
+        """-1 automatic (default), 0 tiles on their own, 1 a workgroup per item that sorts the item's entries once
+        (batches of ligand-sized items; include/mkamd_voxel.h)."""
+        _check(load().mkamd_ctx_set_tile_items(self._h, int(mode)))
 
     def set_fine_cells(self, on: bool):
         """Half-cutoff cells instead of cutoff-sized ones (A-B benchmarking; same values to float32 noise)."""

@@ -1710,6 +1710,309 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned*
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batches of LIGAND-SIZED items (cfg3, cfg5: tens of atoms per item, a few dozen tiles per item).  A tile of such an
+// item holds a few dozen entries, and most of what its wave does in k_voxelize_tiles is fixed cost -- candidate runs,
+// cull, histogram, scan, placement: four chains of dependent loads / LDS atomics per tile -- spent on nearly the same
+// atoms 27 times over.  Here ONE workgroup of four waves takes an item: its entries are sorted by (channel, class) ONCE
+// into LDS, then every wave walks tiles of the item and only converts the entries to tile-relative coordinates (entries
+// out of the tile's reach become a far-away sentinel: the cull of the tile kernel, bit for bit), runs the pair loops
+// and the epilogue.  Same arithmetic per (voxel, entry) as voxelize_tile, so the bits are the same.
+// An item that does not fit (more than ITEM_ECAP padded entries, or more sigma classes than the table holds) is done by
+// the same waves without the sort: its records chunk by chunk, per-entry w and cutoff (the general path's arithmetic).
+// ------------------------------------------------------------------------------------------------
+constexpr int ITEM_ECAP = 256;                       // (atom, channel) entries of an item, groups padded to even
+constexpr int ITEM_STRIDE = (ITEM_ECAP + 2 + 3) & ~3;
+constexpr int ITEM_MAX_RECORDS = 4 * ITEM_ECAP;      // items with more records are not even counted
+
+template <int K>
+MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, const int gq, const float4* s_ent,
+                               const unsigned total, const unsigned* s_gstart /* [NBUCKET + 1]: start | odd */,
+                               const unsigned* s_cbits /* [CHG]: non-empty classes of a channel */,
+                               const unsigned my_class_w, float* stage, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    constexpr float HX = 0.5f * (float)(K - 1);
+    const int tz = t % g.tnz, ty = (t / g.tnz) % g.tny, tx = t / (g.tnz * g.tny);
+    const int x0 = tx * K, y0 = ty * 8, z0 = tz * 8;
+    const int ly = lane >> 3, lz = lane & 7;
+    const float Y = (float)ly - 3.5f, Z = (float)lz - 3.5f;
+    const mk_f2 Y2 = mk_f2_splat(Y), Z2 = mk_f2_splat(Z);
+    const float R2 = g.R2, INF = mk_inf();
+    constexpr unsigned INF_BITS = 0x7f800000u;
+    // cell centre (voxel coords) minus tile centre, per axis (as in voxelize_tile)
+    const float cmid = 0.5f * (float)(g.cs - 1), fcs = (float)g.cs;
+    const float offx = cmid - (float)(g.h * g.cs) - ((float)x0 + HX);
+    const float offy = cmid - (float)(g.h * g.cs) - ((float)y0 + 3.5f);
+    const float offz = cmid - (float)(g.h * g.cs) - ((float)z0 + 3.5f);
+    float* const sx = stage;
+    // ---- the item's entries relative to THIS tile (cand_consume's arithmetic and cull) ----
+    for (unsigned i = (unsigned)lane; i < total; i += WAVE) {
+        const float4 P = s_ent[i];
+        const int pk = mk_float_as_int(P.w);
+        float ex = P.x + ((float)(pk & 1023) * fcs + offx);
+        float ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
+        float ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
+        const float gx = fmaxf(fabsf(ex) - HX, 0.f), gy = fmaxf(fabsf(ey) - 3.5f, 0.f), gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
+        if (!(gx * gx + gy * gy + gz * gz < g.R2cull)) ex = ey = ez = 1.0e15f;     // out of reach (or padding): never a minimum
+        sx[i] = ex; sx[ITEM_STRIDE + i] = ey; sx[2 * ITEM_STRIDE + i] = ez;
+    }
+    mk_wave_sync();
+    unsigned q[CHG][K];
+#pragma unroll
+    for (int c = 0; c < CHG; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
+#pragma unroll
+    for (int c = 0; c < CHG; ++c) {
+        unsigned bits = mk_uniform(s_cbits[c]);
+        while (bits) {                                                    // wave-uniform
+            const int cls = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            const unsigned b0 = mk_uniform(s_gstart[c * NSLOT + cls]), b1 = mk_uniform(s_gstart[c * NSLOT + cls + 1]);
+            const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
+            float m[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) m[k] = INF;
+            const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
+            const bool fast = wcls <= fast_w_max<K>();                    // wave-uniform
+            if (fast) {                                                   // (the pair loop of voxelize_tile, all K planes)
+                const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
+                const float* e = sx + s0;
+                const float* const e_end = e + 2u * npairs;
+#pragma clang loop vectorize(disable) interleave(disable)
+                for (; e != e_end; e += 2) {
+                    const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ITEM_STRIDE), pz = mk_f2_load(e + 2 * ITEM_STRIDE);
+                    const mk_f2 dy = Y2 - py, dz = Z2 - pz;
+                    const mk_f2 d0 = mk_f2_fma(px, px, mk_f2_fma(dy, dy, dz * dz));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const mk_f2 gk = mk_f2_fma(mk_f2_splat(plane_slope<K>(k)), px, d0);
+                        m[k] = mk_min3(m[k], gk[0], gk[1]);
+                    }
+                }
+                if (odd) {                                                // wave-uniform: the unpaired last entry
+                    const float ex = e[0], dy = Y - e[ITEM_STRIDE], dz = Z - e[2 * ITEM_STRIDE];
+                    const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
+#pragma unroll
+                    for (int k = 0; k < K; ++k) m[k] = mk_min(m[k], mk_fma(plane_slope<K>(k), ex, d0));
+                }
+            } else {                                                      // exact form for a class of small sigmas
+                const unsigned n = ((b1 & ~1u) - s0) - odd;
+                const float* e = sx + s0;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                for (unsigned i = 0; i < n; ++i, ++e) {
+                    const float px = e[0], dy = Y - e[ITEM_STRIDE], dz = Z - e[2 * ITEM_STRIDE];
+                    const float r = mk_fma(dy, dy, dz * dz);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const float dx = plane_x<K>(k) - px;
+                        m[k] = mk_min(m[k], mk_fma(dx, dx, r));
+                    }
+                }
+            }
+            // class flush: cutoff on the class minimum (occupancy_utils.pyx:53), then scale by w
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float d2 = fast ? m[k] + plane_x<K>(k) * plane_x<K>(k) : m[k];
+                q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? mk_abs(d2) * wcls : INF);
+            }
+        }
+    }
+    // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
+    const int y = y0 + ly, z = z0 + lz;
+    const bool yz_in = (y < g.ny) && (z < g.nz);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int x = x0 + k;
+        float f[CHG];
+#pragma unroll
+        for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
+        if (yz_in && x < g.nx) {
+            const size_t vox = (size_t)b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+            if (g.C == CHG) {
+                float4* o = reinterpret_cast<float4*>(out + vox * CHG);
+                o[0] = make_float4(f[0], f[1], f[2], f[3]);
+                o[1] = make_float4(f[4], f[5], f[6], f[7]);
+            } else {
+                float* o = out + vox * (size_t)g.C + (size_t)gq * CHG;
+#pragma unroll
+                for (int c = 0; c < CHG; ++c)
+                    if (gq * CHG + c < g.C) o[c] = f[c];
+            }
+        }
+    }
+    mk_wave_sync();                                                       // the staging arrays are rewritten for the next tile
+}
+
+// One tile of an item whose entries were NOT sorted (see k_voxelize_items): the item's records in chunks of 64, a
+// channel's entries of the chunk compacted into the wave's staging area, per-entry w and cutoff -- voxelize_tile's
+// general path over the item's records instead of the tile's candidate cells.
+template <int K>
+MK_DEV void voxelize_item_tile_unsorted(const GridDesc& g, const int b, const int t, const int gq, const unsigned r0, const unsigned r1,
+                                        const float4* __restrict__ rec_pos, const unsigned* __restrict__ clsp,
+                                        const float4* __restrict__ w0p /* w1p = w0p + g.M */, const bool carries_w,
+                                        const unsigned* __restrict__ table, float* stage, float* __restrict__ out)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    constexpr float HX = 0.5f * (float)(K - 1);
+    const int tz = t % g.tnz, ty = (t / g.tnz) % g.tny, tx = t / (g.tnz * g.tny);
+    const int x0 = tx * K, y0 = ty * 8, z0 = tz * 8;
+    const int ly = lane >> 3, lz = lane & 7;
+    const float Y = (float)ly - 3.5f, Z = (float)lz - 3.5f;
+    const float R2 = g.R2, INF = mk_inf();
+    const float cmid = 0.5f * (float)(g.cs - 1), fcs = (float)g.cs;
+    const float offx = cmid - (float)(g.h * g.cs) - ((float)x0 + HX);
+    const float offy = cmid - (float)(g.h * g.cs) - ((float)y0 + 3.5f);
+    const float offz = cmid - (float)(g.h * g.cs) - ((float)z0 + 3.5f);
+    float4* const ebuf = reinterpret_cast<float4*>(stage);               // 64 entries of one channel (x, y, z, w)
+    static_assert(3 * ITEM_STRIDE * sizeof(float) >= WAVE * sizeof(float4), "the staging area holds one chunk");
+    unsigned q[CHG][K];
+#pragma unroll
+    for (int c = 0; c < CHG; ++c)
+#pragma unroll
+        for (int k = 0; k < K; ++k) q[c][k] = 0x7f800000u;
+    for (unsigned base = r0; base < r1; base += WAVE) {                  // wave-uniform
+        const unsigned r = base + (unsigned)lane;
+        bool surv = r < r1;
+        float ex = 0.f, ey = 0.f, ez = 0.f;
+        float wch[CHG];
+#pragma unroll
+        for (int c = 0; c < CHG; ++c) wch[c] = INF;
+        if (surv) {
+            const float4 P = rec_pos[r];
+            const int pk = mk_float_as_int(P.w);
+            ex = P.x + ((float)(pk & 1023) * fcs + offx);
+            ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
+            ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
+            const float gx = fmaxf(fabsf(ex) - HX, 0.f), gy = fmaxf(fabsf(ey) - 3.5f, 0.f), gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
+            surv = gx * gx + gy * gy + gz * gz < g.R2cull;
+            if (surv) {
+                if (carries_w) {
+                    const float4 W0 = w0p[r], W1 = w0p[(size_t)g.M + r];
+                    wch[0] = W0.x; wch[1] = W0.y; wch[2] = W0.z; wch[3] = W0.w; wch[4] = W1.x; wch[5] = W1.y; wch[6] = W1.z; wch[7] = W1.w;
+                } else {
+                    const unsigned ids = clsp[r];
+#pragma unroll
+                    for (int c = 0; c < CHG; ++c) {
+                        const unsigned id = (ids >> (4 * c)) & 0xfu;
+                        if (id) wch[c] = mk_uint_as_float(table[id - 1u]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CHG; ++c) {
+            const float wc = wch[c];
+            const bool has = surv && (wc < INF);                         // false for +inf and NaN
+            const unsigned long long mask = mk_ballot(has);
+            if (mask == 0ull) continue;                                  // wave-uniform
+            const int n = mk_popc64(mask);
+            if (has) ebuf[mk_rank_in_mask(mask)] = make_float4(ex, ey, ez, wc);
+            mk_wave_sync();
+#pragma clang loop vectorize(disable) interleave(disable)
+            for (int i = 0; i < n; ++i) {
+                const float4 e = ebuf[i];
+                const float dy = Y - e.y, dz = Z - e.z;
+                float d2[K];
+                entry_d2<K>(e.x, mk_fma(dy, dy, dz * dz), e.w, d2);      // same fma tree as the sorted path
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    q[c][k] = mk_min_bits(q[c][k], d2[k] < R2 ? mk_abs(d2[k]) * e.w : INF);   // occupancy_utils.pyx:53
+            }
+            mk_wave_sync();                                              // ebuf is rewritten next
+        }
+    }
+    const int y = y0 + ly, z = z0 + lz;
+    const bool yz_in = (y < g.ny) && (z < g.nz);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int x = x0 + k;
+        float f[CHG];
+#pragma unroll
+        for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
+        if (yz_in && x < g.nx) {
+            const size_t vox = (size_t)b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+            if (g.C == CHG) {
+                float4* o = reinterpret_cast<float4*>(out + vox * CHG);
+                o[0] = make_float4(f[0], f[1], f[2], f[3]);
+                o[1] = make_float4(f[4], f[5], f[6], f[7]);
+            } else {
+                float* o = out + vox * (size_t)g.C + (size_t)gq * CHG;
+#pragma unroll
+                for (int c = 0; c < CHG; ++c)
+                    if (gq * CHG + c < g.C) o[c] = f[c];
+            }
+        }
+    }
+}
+
+template <int K>
+MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __restrict__ cell_start,
+                                                const float4* __restrict__ rec_pos, const float4* __restrict__ rec_w,
+                                                const unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table,
+                                                float* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) float4 s_ent[ITEM_ECAP + 2];
+    __shared__ __attribute__((aligned(16))) float s_stage[TILE_TEAM][3 * ITEM_STRIDE];
+    __shared__ unsigned s_cnt[NBUCKET];                       // counts, then placement cursors
+    __shared__ unsigned s_gstart[NBUCKET + 1];
+    __shared__ unsigned s_cbits[CHG];
+    __shared__ unsigned s_total;
+    const int b = (int)blockIdx.x, gq = (int)blockIdx.y;
+    const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const unsigned* __restrict__ table = cls_table + (g.cls_per_item ? (size_t)b * CLS_TABLE_WORDS : (size_t)0);
+    const unsigned table_word = (lane < CLS_TABLE_WORDS) ? table[lane] : CLS_EMPTY;
+    const unsigned my_class_w = (lane < NCLS) ? table_word : 0x7f800000u;
+    const size_t cbase = (size_t)b * (size_t)g.cstride;
+    const unsigned r0 = cell_start[cbase], r1 = cell_start[cbase + (size_t)g.ncell];      // the item's records (cell-sorted, contiguous)
+    const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
+    bool fits = !g.force_general && mk_readlane(table_word, CLS_OVERFLOW) == CLS_EMPTY && (r1 - r0) <= (unsigned)ITEM_MAX_RECORDS;
+    if (fits) {
+        if (tid < NBUCKET) s_cnt[tid] = 0u;
+        mk_block_sync();
+        for (unsigned r = r0 + (unsigned)tid; r < r1; r += blockDim.x)
+            for_each_present_channel(clsp[r], [&](int c, unsigned id) { (void)mk_lds_add(&s_cnt[c * NSLOT + (int)id - 1], 1u); });
+        mk_block_sync();
+        if (wv == 0) {                                        // group starts: lane owns groups 2 lane, 2 lane + 1, padded to even
+            const unsigned c0 = s_cnt[2 * lane], c1 = s_cnt[2 * lane + 1];
+            const unsigned p0 = (c0 + 1u) & ~1u, p1 = (c1 + 1u) & ~1u;
+            const unsigned incl = wave_scan_inclusive(p0 + p1);
+            const unsigned st0 = incl - p0 - p1, st1 = st0 + p0;
+            s_gstart[2 * lane] = st0 | (c0 & 1u);
+            s_gstart[2 * lane + 1] = st1 | (c1 & 1u);
+            s_cnt[2 * lane] = st0; s_cnt[2 * lane + 1] = st1;                // placement cursors
+            if (lane == WAVE - 1) { s_gstart[NBUCKET] = incl; s_total = incl; }
+            // non-empty classes of channel c = groups 16 c .. 16 c + 15 = lanes 8 c .. 8 c + 7
+            const unsigned long long ne0 = mk_ballot(c0 != 0u), ne1 = mk_ballot(c1 != 0u);
+            if (lane < CHG) {
+                const unsigned e = (unsigned)(ne0 >> (8 * lane)) & 0xffu, o = (unsigned)(ne1 >> (8 * lane)) & 0xffu;
+                unsigned bits = 0;
+                for (int j = 0; j < 8; ++j) bits |= (((e >> j) & 1u) << (2 * j)) | (((o >> j) & 1u) << (2 * j + 1));
+                s_cbits[lane] = bits;
+            }
+        }
+        mk_block_sync();
+        fits = s_total <= (unsigned)ITEM_ECAP;                // block-uniform
+    }
+    if (fits) {
+        for (unsigned r = r0 + (unsigned)tid; r < r1; r += blockDim.x) {
+            const float4 P = rec_pos[r];
+            for_each_present_channel(clsp[r], [&](int c, unsigned id) { s_ent[mk_lds_add(&s_cnt[c * NSLOT + (int)id - 1], 1u)] = P; });
+        }
+        mk_block_sync();
+        const unsigned total = s_total;
+        for (int t = wv; t < g.ntiles; t += TILE_TEAM)
+            voxelize_item_tile<K>(g, b, t, gq, s_ent, total, s_gstart, s_cbits, my_class_w, s_stage[wv], out);
+        return;
+    }
+    // the item does not fit: every wave takes tiles as above, but walks the item's records chunk by chunk without sorting
+    // them (per-entry w and cutoff: the general path's arithmetic) -- slow, correct for any item, and rare here
+    const bool carries_w = g.force_general || mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY;
+    for (int t = wv; t < g.ntiles; t += TILE_TEAM)
+        voxelize_item_tile_unsorted<K>(g, b, t, gq, r0, r1, rec_pos, clsp, rec_w + (size_t)(gq * 2) * g.M, carries_w, table, s_stage[wv], out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exact cut-off decisions.  occupancy_utils.pyx:53 tests d^2 < 25 in DOUBLE; the tile kernels test float32 distances
 // that carry ~3e-6 A^2 of error, so a pair within that of the cutoff can land on the wrong side.  What is then at stake is
 // the value AT the cutoff, 1 - exp(-(sigma^2/25)^6): below 5e-6 for sigma <= 1.81 A (every H C N O F P S Cl -- inside

@@ -72,6 +72,15 @@ MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
 MK_DEV void mk_threadfence() { __threadfence(); }
 MK_DEV void mk_sleep() { __builtin_amdgcn_s_sleep(8); }
 
+// the lanes of ONE wave have all passed this point and see each other's LDS writes (a wave's LDS operations complete in
+// order: what is needed is that the compiler keeps them in order) -- for waves of a workgroup that run independently
+MK_DEV void mk_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // workgroup barrier (for the 64-thread tile kernel this is a single-wave s_barrier).
 MK_DEV void mk_block_sync() { __syncthreads(); }
 

@@ -56,6 +56,7 @@ struct LatticeProblem {
     int prepass_mode = -1;                  // -1 = automatic, 0 = multi-kernel chain, 1 = one-launch per-item pre-pass (if it fits)
     int fine_cells = 0;                     // 1 = half-cutoff cells (A-B benchmarking, see plan_lattice)
     int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
+    int tile_items = -1;                    // -1 = automatic (a workgroup per item for batches of ligand-sized items), 0 = never, 1 = always
     // device pointers
     const float* coords = nullptr;
     const long long* atom_offsets = nullptr;
@@ -186,7 +187,7 @@ inline int choose_tier(int forced, const volatile unsigned* feedback)
     return tier;
 }
 
-enum TileFlavour { TILES_PLAIN = 0, TILES_LEAN = 1, TILES_TEAM = 2 };
+enum TileFlavour { TILES_PLAIN = 0, TILES_LEAN = 1, TILES_TEAM = 2, TILES_ITEMS = 3 };
 
 // what the call's last launch (k_tail: dense tiles + exact cut-off fix-up) needs besides the tile kernel's arguments
 struct TailArgs {
@@ -205,7 +206,10 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
     constexpr int E = ECAP_TIER[T];
     int st;
     const bool lean = flavour == TILES_LEAN;
-    if (flavour == TILES_TEAM) {      // a handful of tiles (one grid per call): TILE_TEAM waves per tile
+    if (flavour == TILES_ITEMS) {     // batches of ligand-sized items: a workgroup per item, its entries sorted once
+        st = be.launch(k_voxelize_items<K>, dim3((unsigned)g.B, (unsigned)g.G), dim3(WAVE * TILE_TEAM), g, (const unsigned*)start, (const float4*)rpos,
+                       (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, out);
+    } else if (flavour == TILES_TEAM) {      // a handful of tiles (one grid per call): TILE_TEAM waves per tile
         st = be.launch(k_voxelize_tiles_team<K, E>, tgrid, dim3(WAVE * TILE_TEAM), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                        (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
     } else if constexpr (T <= 1) {    // the biggest tier is LDS-bound to < 3 waves/SIMD anyway: no lean instance of it
@@ -396,8 +400,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
 #ifdef MK_NO_LEAN                                       // A-B builds: the plain kernel also beside the pre-pass
     const int flavour = team ? TILES_TEAM : TILES_PLAIN;
 #else
-    const int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
+    int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
 #endif
+    // many ligand-sized items (cfg3, cfg5): a workgroup per item sorts its entries once for all its tiles
+    if (!team && P.tile_items != 0 && (P.tile_items > 0 || (per_item && g.B >= 1024 && P.total_atoms <= 96LL * (long long)g.B && g.ntiles <= 512)))
+        flavour = TILES_ITEMS;
     TailArgs ta;
     // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);

@@ -66,7 +66,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
                          int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
                          const float* box, int max_images, int tile_k, int force_general, const double* affine, float* features,
                          int* err_flag_out, int lds_tier, unsigned* feedback_io /* NTIER+1: in = previous call's, out = this call's */,
-                         int prepass_mode, int tile_team, int fine_cells, int repeat /* calls on ONE backend */, int* fills_out)
+                         int prepass_mode, int tile_team, int fine_cells, int repeat /* calls on ONE backend */, int* fills_out, int tile_items)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -75,7 +75,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     LatticeProblem P;
     P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
     P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
-    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier; P.prepass_mode = prepass_mode; P.tile_team = tile_team; P.fine_cells = fine_cells;
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier; P.prepass_mode = prepass_mode; P.tile_team = tile_team; P.fine_cells = fine_cells; P.tile_items = tile_items;
     if (feedback_io) for (int i = 0; i <= NTIER; ++i) be.feedback[i] = feedback_io[i];
     if (box && max_images <= 0) {
         max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);

@@ -192,6 +192,7 @@ MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
 MK_DEV unsigned mk_min_bits(unsigned q, float t) { const unsigned b = mk_float_bits(t); return b < q ? b : q; }
 MK_DEV float mk_uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 MK_DEV void mk_block_sync() { emu::rendezvous(16, emu::g_blk.nthreads); }
+MK_DEV void mk_wave_sync() { emu::rendezvous((int)threadIdx.x >> 6, 64); }
 MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
 MK_DEV void mk_atomic_or(int* p, int v) { *p |= v; }

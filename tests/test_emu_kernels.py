@@ -279,6 +279,31 @@ def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
         assert e3 == 0 and np.array_equal(gen, one)
 
 
+@pytest.mark.parametrize("name", ["cfg3_small", "cfg5_small", "tiny_items", "ragged_batch", "pbc_batch", "channels11", "special_sigmas",
+                                  "cutoff_exact_1A", "voxel15", "cutoff_adversarial_1A"])
+@pytest.mark.parametrize("prepass", [1, 0])
+def test_workgroup_per_item_is_bit_identical(name, prepass):
+    """Batches of ligand-sized items: one workgroup per item sorts the item's entries once for all its tiles
+    (k_voxelize_items).  Same arithmetic per (voxel, entry) and the tile kernel's cull, so not a bit may differ from the
+    wave-per-tile kernel -- small items on the sorted path, items of more than 256 entries (ragged_batch, cutoff cases
+    with few atoms but many channels ...) and the forced general path on the unsorted one, on either pre-pass."""
+    if prepass == 0 and name in ("cfg5_small", "pbc_batch", "voxel15", "cutoff_adversarial_1A"):
+        pytest.skip("covered with the per-item pre-pass (emulation time)")
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    one, e1 = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=prepass, tile_team=0, tile_items=0)
+    itm, e2 = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=prepass, tile_team=0, tile_items=1)
+    assert e1 == 0 and e2 == 0
+    assert np.array_equal(one, itm)
+    check(case, itm)
+    if name in ("tiny_items", "channels11"):
+        gen, e3 = E.voxelize_lattice(*args, box=case["box"], tile_k=8, prepass_mode=prepass, tile_team=0, tile_items=1, force_general=True)
+        assert e3 == 0 and np.array_equal(gen, one)
+        k4, e4 = E.voxelize_lattice(*args, box=case["box"], tile_k=4, prepass_mode=prepass, tile_team=0, tile_items=1)
+        k4r, _ = E.voxelize_lattice(*args, box=case["box"], tile_k=4, prepass_mode=prepass, tile_team=0, tile_items=0)
+        assert e4 == 0 and np.array_equal(k4, k4r)
+
+
 @pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "pbc_batch", "voxel07", "voxel025", "voxel2", "tiny_items", "sorted_atoms"])
 def test_cell_size_only_moves_the_last_bits(name):
     """Half-cutoff cells (an A-B knob: fewer candidates per tile) against the cutoff-sized default: the cells decide which

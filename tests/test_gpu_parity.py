@@ -361,3 +361,33 @@ def test_many_dense_tiles_with_fixups_in_one_tail_launch(hip_ctx):
     finally:
         hip_ctx.set_pipelining(False)
         hip_ctx.set_prepass_mode(-1)
+
+
+def test_batches_of_ligand_sized_items_take_the_workgroup_per_item_kernel(hip_ctx):
+    """2 000 items of 10 .. 70 atoms (the automatic choice: >= 1024 items, <= 96 atoms on average, per-item pre-pass):
+    k_voxelize_items against the wave-per-tile kernel, bit for bit, a sample of the items against the oracle; one item
+    of 900 atoms in the middle of the batch (more than 256 entries: the unsorted walk) and an empty one."""
+    from moleculekit_amd import batch
+    rng = np.random.default_rng(91)
+    ns = rng.integers(10, 71, size=2000)
+    ns[777] = 900
+    ns[778] = 0
+    coords = [rng.normal(0, 3.0 if n < 100 else 6.0, size=(n, 3)).astype(np.float32) for n in ns]
+    sig = [np.where(rng.random((n, 8)) < [0.5, 0.1, 0.2, 0.1, 0.05, 0.05, 0.01, 0.7], rng.choice([1.2, 1.52, 1.7, 1.9], size=(n, 1)), 0.0) for n in ns]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    origins = np.tile(np.array([[-10.0, -10.0, -10.0]]), (len(ns), 1)) + rng.uniform(-0.5, 0.5, size=(len(ns), 3))
+    nv = np.array([20, 20, 20])
+    args = (np.concatenate(coords), offs, np.concatenate(sig), origins, nv, 1.0)
+    try:
+        hip_ctx.set_tile_items(0)
+        ref = batch.voxelize_lattice(*args, ctx=hip_ctx)
+        hip_ctx.set_tile_items(-1)
+        got = batch.voxelize_lattice(*args, ctx=hip_ctx)
+    finally:
+        hip_ctx.set_tile_items(-1)
+    assert np.array_equal(got, ref)
+    assert np.all(got[778] == 0.0)
+    for b in (0, 1, 777, 1999):
+        s_, e_ = offs[b], offs[b + 1]
+        want = oracle_lattice(args[0][s_:e_], np.array([0, e_ - s_]), args[2][s_:e_], origins[b:b + 1], nv, 1.0)
+        assert np.abs(got[b] - want[0]).max() <= TOL

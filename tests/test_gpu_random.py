@@ -71,5 +71,14 @@ def test_random_configuration_all_variants(hip_ctx, seed):
                     assert np.abs(got - base).max(initial=0.0) <= 6e-6   # another K = other plane constants (and another fast/exact split of the classes)
                 else:
                     assert np.array_equal(got, ref), (tile_k, tier, general, prepass)
+            # a workgroup per item (what batches of ligand-sized items get): sorted once per item, or -- items of more
+            # than 256 entries, too many classes, the forced general path -- walked unsorted; the same bits
+            for general, prepass in ((False, 1), (False, 0), (True, 1)):
+                hip_ctx.set_tile_k(tile_k); hip_ctx.set_lds_tier(-1); hip_ctx.set_force_general(general)
+                hip_ctx.set_prepass_mode(prepass); hip_ctx.set_tile_team(0); hip_ctx.set_tile_items(1)
+                got = batch.voxelize_lattice(*args, box=k["box"], ctx=hip_ctx)
+                hip_ctx.set_tile_team(-1); hip_ctx.set_tile_items(-1)
+                assert np.array_equal(got, ref), (tile_k, "items", general, prepass)
     finally:
         hip_ctx.set_tile_k(0); hip_ctx.set_lds_tier(-1); hip_ctx.set_force_general(False); hip_ctx.set_prepass_mode(-1)
+        hip_ctx.set_tile_team(-1); hip_ctx.set_tile_items(-1)
