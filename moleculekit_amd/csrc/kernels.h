@@ -1728,6 +1728,7 @@ template <int K>
 MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, const int gq, const float4* s_ent,
                                const unsigned total, const unsigned* s_gstart /* [NBUCKET + 1]: start | odd */,
                                const unsigned* s_cbits /* [CHG]: non-empty classes of a channel */,
+                               const unsigned char* s_grp /* [total]: group of an entry, 0xff = padding */, unsigned* cur /* [NBUCKET], this wave's */,
                                const unsigned my_class_w, float* stage, float* __restrict__ out)
 {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1745,16 +1746,23 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
     const float offy = cmid - (float)(g.h * g.cs) - ((float)y0 + 3.5f);
     const float offz = cmid - (float)(g.h * g.cs) - ((float)z0 + 3.5f);
     float* const sx = stage;
-    // ---- the item's entries relative to THIS tile (cand_consume's arithmetic and cull) ----
+    // ---- the item's entries relative to THIS tile (cand_consume's arithmetic and cull); the ones within reach move to
+    //      the front of their group's slots (one LDS atomic each; their order inside a group is free: minima) ----
+    for (int gi = lane; gi < NBUCKET; gi += WAVE) cur[gi] = 0u;
+    mk_wave_sync();
     for (unsigned i = (unsigned)lane; i < total; i += WAVE) {
+        const unsigned gi = s_grp[i];
+        if (gi == 0xffu) continue;                                        // padding slot
         const float4 P = s_ent[i];
         const int pk = mk_float_as_int(P.w);
-        float ex = P.x + ((float)(pk & 1023) * fcs + offx);
-        float ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
-        float ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
+        const float ex = P.x + ((float)(pk & 1023) * fcs + offx);
+        const float ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
+        const float ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
         const float gx = fmaxf(fabsf(ex) - HX, 0.f), gy = fmaxf(fabsf(ey) - 3.5f, 0.f), gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
-        if (!(gx * gx + gy * gy + gz * gz < g.R2cull)) ex = ey = ez = 1.0e15f;     // out of reach (or padding): never a minimum
-        sx[i] = ex; sx[ITEM_STRIDE + i] = ey; sx[2 * ITEM_STRIDE + i] = ez;
+        if (gx * gx + gy * gy + gz * gz < g.R2cull) {
+            const unsigned slot = (s_gstart[gi] & ~1u) + mk_lds_add(&cur[gi], 1u);
+            sx[slot] = ex; sx[ITEM_STRIDE + slot] = ey; sx[2 * ITEM_STRIDE + slot] = ez;
+        }
     }
     mk_wave_sync();
     unsigned q[CHG][K];
@@ -1768,15 +1776,16 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
         while (bits) {                                                    // wave-uniform
             const int cls = __builtin_ctz(bits);
             bits &= bits - 1u;
-            const unsigned b0 = mk_uniform(s_gstart[c * NSLOT + cls]), b1 = mk_uniform(s_gstart[c * NSLOT + cls + 1]);
+            const unsigned n_in = mk_uniform(cur[c * NSLOT + cls]);            // entries of the group within reach of this tile
+            if (n_in == 0u) continue;
+            const unsigned s0 = mk_uniform(s_gstart[c * NSLOT + cls]) & ~1u, odd = n_in & 1u;
             const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
             float m[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) m[k] = INF;
-            const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
             const bool fast = wcls <= fast_w_max<K>();                    // wave-uniform
             if (fast) {                                                   // (the pair loop of voxelize_tile, all K planes)
-                const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
+                const unsigned npairs = n_in >> 1;
                 const float* e = sx + s0;
                 const float* const e_end = e + 2u * npairs;
 #pragma clang loop vectorize(disable) interleave(disable)
@@ -1797,7 +1806,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
                     for (int k = 0; k < K; ++k) m[k] = mk_min(m[k], mk_fma(plane_slope<K>(k), ex, d0));
                 }
             } else {                                                      // exact form for a class of small sigmas
-                const unsigned n = ((b1 & ~1u) - s0) - odd;
+                const unsigned n = n_in;
                 const float* e = sx + s0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
                 for (unsigned i = 0; i < n; ++i, ++e) {
@@ -1958,6 +1967,8 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __re
     __shared__ unsigned s_gstart[NBUCKET + 1];
     __shared__ unsigned s_cbits[CHG];
     __shared__ unsigned s_total;
+    __shared__ unsigned s_cur[TILE_TEAM][NBUCKET];            // per wave and tile: entries of a group within reach
+    __shared__ unsigned char s_grp[ITEM_ECAP + 2];
     const int b = (int)blockIdx.x, gq = (int)blockIdx.y;
     const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const unsigned* __restrict__ table = cls_table + (g.cls_per_item ? (size_t)b * CLS_TABLE_WORDS : (size_t)0);
@@ -1995,14 +2006,20 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __re
         fits = s_total <= (unsigned)ITEM_ECAP;                // block-uniform
     }
     if (fits) {
+        for (int i = tid; i < ITEM_ECAP + 2; i += (int)blockDim.x) s_grp[i] = 0xffu;
+        mk_block_sync();
         for (unsigned r = r0 + (unsigned)tid; r < r1; r += blockDim.x) {
             const float4 P = rec_pos[r];
-            for_each_present_channel(clsp[r], [&](int c, unsigned id) { s_ent[mk_lds_add(&s_cnt[c * NSLOT + (int)id - 1], 1u)] = P; });
+            for_each_present_channel(clsp[r], [&](int c, unsigned id) {
+                const unsigned pos = mk_lds_add(&s_cnt[c * NSLOT + (int)id - 1], 1u);
+                s_ent[pos] = P;
+                s_grp[pos] = (unsigned char)(c * NSLOT + (int)id - 1);
+            });
         }
         mk_block_sync();
         const unsigned total = s_total;
         for (int t = wv; t < g.ntiles; t += TILE_TEAM)
-            voxelize_item_tile<K>(g, b, t, gq, s_ent, total, s_gstart, s_cbits, my_class_w, s_stage[wv], out);
+            voxelize_item_tile<K>(g, b, t, gq, s_ent, total, s_gstart, s_cbits, s_grp, s_cur[wv], my_class_w, s_stage[wv], out);
         return;
     }
     // the item does not fit: every wave takes tiles as above, but walks the item's records chunk by chunk without sorting
