@@ -1770,6 +1770,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
     for (int c = 0; c < CHG; ++c)
 #pragma unroll
         for (int k = 0; k < K; ++k) q[c][k] = INF_BITS;
+    unsigned live = 0u;                                                   // channels with an entry within reach (wave-uniform)
 #pragma unroll
     for (int c = 0; c < CHG; ++c) {
         unsigned bits = mk_uniform(s_cbits[c]);
@@ -1778,6 +1779,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
             bits &= bits - 1u;
             const unsigned n_in = mk_uniform(cur[c * NSLOT + cls]);            // entries of the group within reach of this tile
             if (n_in == 0u) continue;
+            live |= 1u << c;
             const unsigned s0 = mk_uniform(s_gstart[c * NSLOT + cls]) & ~1u, odd = n_in & 1u;
             const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
             float m[K];
@@ -1827,7 +1829,18 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
             }
         }
     }
-    // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
+    // ---- epilogue: q -> occupancy in place (a channel without an entry in reach is all zeros: no rcp / exp for it --
+    //      for these sparse tiles the 64 evaluations are a third of the work), one 32-byte store per voxel ----
+#pragma unroll
+    for (int c = 0; c < CHG; ++c) {
+        if (live & (1u << c)) {                                           // wave-uniform
+#pragma unroll
+            for (int k = 0; k < K; ++k) q[c][k] = mk_float_bits(occupancy_from_q(mk_uint_as_float(q[c][k])));
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k) q[c][k] = 0u;
+        }
+    }
     const int y = y0 + ly, z = z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
 #pragma unroll
@@ -1835,7 +1848,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
         const int x = x0 + k;
         float f[CHG];
 #pragma unroll
-        for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
+        for (int c = 0; c < CHG; ++c) f[c] = mk_uint_as_float(q[c][k]);
         if (yz_in && x < g.nx) {
             const size_t vox = (size_t)b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
             if (g.C == CHG) {
