@@ -20,6 +20,7 @@ args = (t(p["coords"], np.float32), t(p["atom_offsets"], np.int64), t(p["sigmas"
 kw = dict(box=None if p["box"] is None else t(p["box"], np.float32),
           max_images=1 if p["box"] is None else batch.max_images_per_atom(p["box"], nv, p["voxelsize"]))
 ctx = _lib.default_context(0)
+ctx.set_tile_items(0)            # the timers live in the wave-per-tile kernel (voxelize_tile), not in k_voxelize_items
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 8)()
 for _ in range(3):
@@ -33,7 +34,7 @@ ctx.synchronize()
 lib.mkamd_debug_phase_cycles(buf)
 v = np.array(list(buf)[:6], dtype=np.float64)
 names = ["prologue", "traversal 1 (histogram)", "counts -> starts", "traversal 2 (placement)", "pair loops + flushes", "epilogue"]
-print(f"{wl}: share of a tile wave's wall-clock cycles per phase (sum over {n} launches)")
+print(f"{wl}: share of a tile wave's wall-clock cycles per phase, wave-per-tile kernel (sum over {n} launches)")
 for nm, x in zip(names, v):
     print(f"  {nm:28s} {100 * x / v.sum():5.1f} %")
 w = np.array(list(buf)[6:8], dtype=np.float64)
