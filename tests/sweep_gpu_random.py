@@ -11,6 +11,8 @@ from moleculekit_amd import batch, _lib
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = _lib.default_context(0)
+if os.environ.get("MKAMD_TILE_ITEMS") == "1":       # the workgroup-per-item kernel on every configuration
+    ctx.set_tile_team(0); ctx.set_tile_items(1)
 worst, where = 0.0, None
 for seed in range(first, first + count):
     k = _config(seed)
