@@ -428,7 +428,7 @@ def roofline_of(res, workload, B, tile_k):
     traffic, traffic_src = pmc_traffic(workload, B, tile_k)
     return {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_voxelize_tiles (+ dense pass)",
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_voxelize_tiles|_lean|_team|k_voxelize_items + k_tail (what runs between the timing events)",
             "kernel_avg_ms": round(k_avg_ms, 5), "kernel_launches": int(res["k_n"]),
             "algorithmic_bytes_per_launch": int(res["alg"])}
 
