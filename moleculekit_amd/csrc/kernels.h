@@ -1720,7 +1720,7 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned*
 // An item that does not fit (more than ITEM_ECAP padded entries, or more sigma classes than the table holds) is done by
 // the same waves without the sort: its records chunk by chunk, per-entry w and cutoff (the general path's arithmetic).
 // ------------------------------------------------------------------------------------------------
-constexpr int ITEM_ECAP = 256;                       // (atom, channel) entries of an item, groups padded to even
+constexpr int ITEM_ECAP = 384;                       // (atom, channel) entries of an item, groups padded to even
 constexpr int ITEM_STRIDE = (ITEM_ECAP + 2 + 3) & ~3;
 constexpr int ITEM_MAX_RECORDS = 4 * ITEM_ECAP;      // items with more records are not even counted
 

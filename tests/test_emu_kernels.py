@@ -285,7 +285,7 @@ def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
 def test_workgroup_per_item_is_bit_identical(name, prepass):
     """Batches of ligand-sized items: one workgroup per item sorts the item's entries once for all its tiles
     (k_voxelize_items).  Same arithmetic per (voxel, entry) and the tile kernel's cull, so not a bit may differ from the
-    wave-per-tile kernel -- small items on the sorted path, items of more than 256 entries (ragged_batch, cutoff cases
+    wave-per-tile kernel -- small items on the sorted path, items of more than 384 entries (ragged_batch, cutoff cases
     with few atoms but many channels ...) and the forced general path on the unsorted one, on either pre-pass."""
     if prepass == 0 and name in ("cfg5_small", "pbc_batch", "voxel15", "cutoff_adversarial_1A"):
         pytest.skip("covered with the per-item pre-pass (emulation time)")

@@ -366,7 +366,7 @@ def test_many_dense_tiles_with_fixups_in_one_tail_launch(hip_ctx):
 def test_batches_of_ligand_sized_items_take_the_workgroup_per_item_kernel(hip_ctx):
     """2 000 items of 10 .. 70 atoms (the automatic choice: >= 1024 items, <= 96 atoms on average, per-item pre-pass):
     k_voxelize_items against the wave-per-tile kernel, bit for bit, a sample of the items against the oracle; one item
-    of 900 atoms in the middle of the batch (more than 256 entries: the unsorted walk) and an empty one."""
+    of 900 atoms in the middle of the batch (more than 384 entries: the unsorted walk) and an empty one."""
     from moleculekit_amd import batch
     rng = np.random.default_rng(91)
     ns = rng.integers(10, 71, size=2000)

@@ -72,7 +72,7 @@ def test_random_configuration_all_variants(hip_ctx, seed):
                 else:
                     assert np.array_equal(got, ref), (tile_k, tier, general, prepass)
             # a workgroup per item (what batches of ligand-sized items get): sorted once per item, or -- items of more
-            # than 256 entries, too many classes, the forced general path -- walked unsorted; the same bits
+            # than 384 entries, too many classes, the forced general path -- walked unsorted; the same bits
             for general, prepass in ((False, 1), (False, 0), (True, 1)):
                 hip_ctx.set_tile_k(tile_k); hip_ctx.set_lds_tier(-1); hip_ctx.set_force_general(general)
                 hip_ctx.set_prepass_mode(prepass); hip_ctx.set_tile_team(0); hip_ctx.set_tile_items(1)
