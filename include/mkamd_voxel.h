@@ -88,8 +88,9 @@ int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on);
  * a team when the whole launch has fewer tiles than the chip has SIMDs.  Results are bit-identical either way. */
 int mkamd_ctx_set_tile_team(mkamd_ctx* ctx, int mode);
 /* A workgroup per ITEM instead of a wave per tile: 1 = always (when no team is used), 0 = never, -1 (default) = for
- * batches of >= 1024 ligand-sized items (<= 96 atoms on average) on the per-item pre-pass: the item's entries are sorted
- * once for all its tiles instead of once per tile.  Results are bit-identical either way. */
+ * ligand-sized items (<= 96 atoms on average) on the per-item pre-pass, any batch size: the item's entries are sorted
+ * once for all its tiles (once per chunk of its tiles while the batch is too small to fill the chip) instead of once
+ * per tile.  Results are bit-identical either way. */
 int mkamd_ctx_set_tile_items(mkamd_ctx* ctx, int mode);
 /* Opt-in software pipelining ACROSS calls of mkamd_voxelize_lattice_dev (off by default): the binning
  * pre-pass of a call (latency / atomic bound) runs on an internal stream beside the tile kernel (VALU bound)

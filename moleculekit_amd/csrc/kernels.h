@@ -1972,7 +1972,7 @@ template <int K>
 MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __restrict__ cell_start,
                                                 const float4* __restrict__ rec_pos, const float4* __restrict__ rec_w,
                                                 const unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table,
-                                                float* __restrict__ out)
+                                                float* __restrict__ out, int tiles_per_block /* a multiple of TILE_TEAM */)
 {
     __shared__ __attribute__((aligned(16))) float4 s_ent[ITEM_ECAP + 2];
     __shared__ __attribute__((aligned(16))) float s_stage[TILE_TEAM][3 * ITEM_STRIDE];
@@ -1982,7 +1982,12 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __re
     __shared__ unsigned s_total;
     __shared__ unsigned s_cur[TILE_TEAM][NBUCKET];            // per wave and tile: entries of a group within reach
     __shared__ unsigned char s_grp[ITEM_ECAP + 2];
-    const int b = (int)blockIdx.x, gq = (int)blockIdx.y;
+    // few items: several workgroups per item, each with a share of its tiles (the sort of a ligand's entries is cheap
+    // enough to repeat; a small batch then still fills the chip)
+    const int nchunk = (g.ntiles + tiles_per_block - 1) / tiles_per_block;
+    const int b = (int)blockIdx.x / nchunk, gq = (int)blockIdx.y;
+    const int t_begin = ((int)blockIdx.x - b * nchunk) * tiles_per_block;
+    const int t_end = t_begin + tiles_per_block < g.ntiles ? t_begin + tiles_per_block : g.ntiles;
     const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
     const unsigned* __restrict__ table = cls_table + (g.cls_per_item ? (size_t)b * CLS_TABLE_WORDS : (size_t)0);
     const unsigned table_word = (lane < CLS_TABLE_WORDS) ? table[lane] : CLS_EMPTY;
@@ -2031,14 +2036,14 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __re
         }
         mk_block_sync();
         const unsigned total = s_total;
-        for (int t = wv; t < g.ntiles; t += TILE_TEAM)
+        for (int t = t_begin + wv; t < t_end; t += TILE_TEAM)
             voxelize_item_tile<K>(g, b, t, gq, s_ent, total, s_gstart, s_cbits, s_grp, s_cur[wv], my_class_w, s_stage[wv], out);
         return;
     }
     // the item does not fit: every wave takes tiles as above, but walks the item's records chunk by chunk without sorting
     // them (per-entry w and cutoff: the general path's arithmetic) -- slow, correct for any item, and rare here
     const bool carries_w = g.force_general || mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY;
-    for (int t = wv; t < g.ntiles; t += TILE_TEAM)
+    for (int t = t_begin + wv; t < t_end; t += TILE_TEAM)
         voxelize_item_tile_unsorted<K>(g, b, t, gq, r0, r1, rec_pos, clsp, rec_w + (size_t)(gq * 2) * g.M, carries_w, table, s_stage[wv], out);
 }
 

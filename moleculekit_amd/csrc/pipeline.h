@@ -207,8 +207,16 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
     int st;
     const bool lean = flavour == TILES_LEAN;
     if (flavour == TILES_ITEMS) {     // batches of ligand-sized items: a workgroup per item, its entries sorted once
-        st = be.launch(k_voxelize_items<K>, dim3((unsigned)g.B, (unsigned)g.G), dim3(WAVE * TILE_TEAM), g, (const unsigned*)start, (const float4*)rpos,
-                       (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, out);
+        // one workgroup per item when there are enough items to fill the chip (4 096 waves), else several per item
+        const long long want_blocks = 1024;
+        long long nchunk = (want_blocks + g.B - 1) / g.B;
+        const long long max_chunk = (g.ntiles + TILE_TEAM - 1) / TILE_TEAM;
+        nchunk = nchunk < 1 ? 1 : (nchunk > max_chunk ? max_chunk : nchunk);
+        int tpb = (int)((g.ntiles + nchunk - 1) / nchunk);
+        tpb = ((tpb + TILE_TEAM - 1) / TILE_TEAM) * TILE_TEAM;
+        const unsigned blocks_per_item = (unsigned)((g.ntiles + tpb - 1) / tpb);
+        st = be.launch(k_voxelize_items<K>, dim3((unsigned)g.B * blocks_per_item, (unsigned)g.G), dim3(WAVE * TILE_TEAM), g, (const unsigned*)start,
+                       (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, out, tpb);
     } else if (flavour == TILES_TEAM) {      // a handful of tiles (one grid per call): TILE_TEAM waves per tile
         st = be.launch(k_voxelize_tiles_team<K, E>, tgrid, dim3(WAVE * TILE_TEAM), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                        (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
@@ -403,7 +411,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
 #endif
     // many ligand-sized items (cfg3, cfg5): a workgroup per item sorts its entries once for all its tiles
-    if (!team && P.tile_items != 0 && (P.tile_items > 0 || (per_item && g.B >= 1024 && P.total_atoms <= 96LL * (long long)g.B && g.ntiles <= 512)))
+    if (P.tile_items != 0 && ((P.tile_items > 0 && !team) || (P.tile_items < 0 && P.tile_team <= 0 && per_item && P.total_atoms <= 96LL * (long long)g.B && g.ntiles <= 512)))
         flavour = TILES_ITEMS;
     TailArgs ta;
     // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)

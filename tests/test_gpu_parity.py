@@ -364,7 +364,7 @@ def test_many_dense_tiles_with_fixups_in_one_tail_launch(hip_ctx):
 
 
 def test_batches_of_ligand_sized_items_take_the_workgroup_per_item_kernel(hip_ctx):
-    """2 000 items of 10 .. 70 atoms (the automatic choice: >= 1024 items, <= 96 atoms on average, per-item pre-pass):
+    """2 000 items of 10 .. 70 atoms (the automatic choice: <= 96 atoms on average, per-item pre-pass):
     k_voxelize_items against the wave-per-tile kernel, bit for bit, a sample of the items against the oracle; one item
     of 900 atoms in the middle of the batch (more than 384 entries: the unsorted walk) and an empty one."""
     from moleculekit_amd import batch
