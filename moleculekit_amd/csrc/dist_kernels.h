@@ -19,23 +19,20 @@ namespace mkamd {
 
 // d - b * round(d / b) (distance_utils.pyx:49-51) without the division where that is provably the same: what is needed of
 // fl(d / b) is only WHICH integer it rounds to.  q = fl(d * fl(1 / b)) is within 3 x 2^-24 |q| of fl(d / b); unless q sits
-// that close to a half-integer (where round() changes its value) both round to the same integer.  Lanes that do -- and
-// everything that is not an ordinary number: zero boxes, overflow, NaN fail the comparison -- take the correctly rounded
-// division.  `ib` = fl(1 / b), computed once per (lane, frame) instead of three IEEE divisions per pair.
-MK_DEV float wrap_axis_f32(float d, float b, float ib)
+// that close to a half-integer (where round() changes its value) both round to the same integer -- and away from the
+// half-integers round-half-away (C round) and round-half-even (ONE instruction, v_rndne_f32) agree as well.  With
+// r = rndne(q) the distance of q from the nearest half-integer is 0.5 - |q - r| (the subtraction is exact), so the
+// test costs a subtract, an fma and a compare.  Axes that fail it -- and everything that is not an ordinary number: zero
+// boxes, overflow, NaN fail the comparison -- take the correctly rounded division; one branch for the three axes.
+// `ib` = fl(1 / b), computed once per (lane, frame) instead of three IEEE divisions per pair.
+MK_DEV float round_quotient_fast(float d, float ib, bool& sure)
 {
     const float q = mk_fmul_rn(d, ib);
-    const float t = fabsf(q);
-    const float fr = t - floorf(t);                                   // exact
-    float r;
-    if (fabsf(fr - 0.5f) > 3e-7f * t + 1e-30f) {
-        r = roundf(q);
-    } else {
-        asm volatile("" ::: "memory");                               // a real branch: the division must not be computed "just in case"
-        r = roundf(mk_fdiv_rn(d, b));
-    }
-    return mk_fsub_rn(d, mk_fmul_rn(b, r));
+    const float r = mk_rint(q);
+    sure = fabsf(q - r) < mk_fma(-3e-7f, fabsf(q), 0.5f);
+    return r;
 }
+MK_DEV float round_quotient_exact(float d, float b) { return roundf(mk_fdiv_rn(d, b)); }
 
 // distance_utils.pyx:34-54 (_dist) / :188-206 (_dist2)
 MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y2, float z2,
@@ -43,9 +40,17 @@ MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y
 {
     float dx = mk_fsub_rn(x1, x2), dy = mk_fsub_rn(y1, y2), dz = mk_fsub_rn(z1, z2);
     if (wrap) {
-        dx = wrap_axis_f32(dx, bx, ibx);
-        dy = wrap_axis_f32(dy, by, iby);
-        dz = wrap_axis_f32(dz, bz, ibz);
+        bool sx, sy, sz;
+        float rx = round_quotient_fast(dx, ibx, sx), ry = round_quotient_fast(dy, iby, sy), rz = round_quotient_fast(dz, ibz, sz);
+        if (!(sx && sy && sz)) {
+            asm volatile("" ::: "memory");                           // a real branch: the divisions must not be computed "just in case"
+            if (!sx) rx = round_quotient_exact(dx, bx);
+            if (!sy) ry = round_quotient_exact(dy, by);
+            if (!sz) rz = round_quotient_exact(dz, bz);
+        }
+        dx = mk_fsub_rn(dx, mk_fmul_rn(bx, rx));
+        dy = mk_fsub_rn(dy, mk_fmul_rn(by, ry));
+        dz = mk_fsub_rn(dz, mk_fmul_rn(bz, rz));
     }
     return mk_fadd_rn(mk_fadd_rn(mk_fmul_rn(dx, dx), mk_fmul_rn(dy, dy)), mk_fmul_rn(dz, dz));
 }
@@ -108,7 +113,14 @@ MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long l
 // dist_trajectory (distance_utils.pyx:126-155): results[f, p] = sqrt(_dist(...)) (or the square).
 // Lanes run along frames, so the atom indices of a pair are wave-uniform: pairs are visited in the reference's
 // i-major order and the first atom's coordinates (and the frame's box) stay in registers while i does not
-// change -- 3 instead of 6 coordinate loads per distance, the loads being what bounds this kernel (L1/L2).
+// change -- 3 instead of 6 coordinate loads per distance.
+// A wave takes DP_RUN consecutive pairs of the tile.  Their (a, b, wrap) come from ONE load each (lane k holds pair
+// k, handed out with readlane), and the coordinates of DP_BATCH pairs are requested together before the first of them
+// is used: the first version looked its pair up, waited, loaded its three coordinates, waited -- 32 dependent round
+// trips to L2 per wave, which is what bounded it (0.56 ms for 100 000 pairs x 2 048 frames: 1.5 TB/s of stores).
+constexpr int DP_RUN = DT / (DT_THREADS / DT);   // 16
+constexpr int DP_BATCH = 4;
+
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
                                         const float* __restrict__ box, const unsigned* __restrict__ pa,
                                         const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
@@ -118,26 +130,49 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
     const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
     {
         const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
-        const long long f = f0 + fl;
-        const bool fin = f < F;
-        const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
+        // frames past the end compute on the last frame and pairs past the end on the last pair (valid addresses, no
+        // divergence); the store phase below never reads those tile entries
+        const long long f = f0 + fl < F ? f0 + fl : F - 1;
+        const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
         const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
-        unsigned cur_a = 0xffffffffu;
-        float xa = 0.f, ya = 0.f, za = 0.f;
-        // this wave takes 16 CONSECUTIVE pairs of the tile (they mostly share the first atom)
-        for (int k = 0; k < DT / (DT_THREADS / DT); ++k) {
-            const int pp = pq * (DT / (DT_THREADS / DT)) + k;
-            const long long p = p0 + pp;
-            if (p >= P) break;                                     // wave-uniform
-            const unsigned a = pa[p], b = pb[p];
-            if (a != cur_a) {                                      // wave-uniform
-                cur_a = a;
-                if (fin) { xa = coords[((size_t)a * 3 + 0) * F + f]; ya = coords[((size_t)a * 3 + 1) * F + f]; za = coords[((size_t)a * 3 + 2) * F + f]; }
-            }
-            if (fin) {
-                const float d2 = dist2_min_image_f32(xa, ya, za, coords[((size_t)b * 3 + 0) * F + f], coords[((size_t)b * 3 + 1) * F + f],
-                                                     coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, ibx, iby, ibz, wrap[p] != 0u);
-                tile[pp][fl] = squared ? d2 : mk_fsqrt_rn(d2);
+        const long long pw = p0 + pq * DP_RUN;                       // the wave's first pair
+        const long long left = P - pw;                               // wave-uniform
+        if (left > 0) {
+            const long long pi = pw + (fl & (DP_RUN - 1)) < P ? pw + (fl & (DP_RUN - 1)) : P - 1;
+            const unsigned va = pa[pi], vb = pb[pi], vw = wrap[pi];
+            const float* __restrict__ cf = coords + f;
+            auto at = [&](unsigned atom, int ax) { return cf[((size_t)atom * 3 + ax) * F]; };
+            unsigned cur_a = 0xffffffffu;
+            float xa = 0.f, ya = 0.f, za = 0.f;
+#pragma unroll
+            for (int k0 = 0; k0 < DP_RUN; k0 += DP_BATCH) {
+                if ((long long)k0 >= left) break;                    // wave-uniform
+                unsigned a[DP_BATCH], b[DP_BATCH], w[DP_BATCH];
+                bool same = true;                                    // wave-uniform: the batch stays with the cached first atom
+#pragma unroll
+                for (int u = 0; u < DP_BATCH; ++u) {
+                    a[u] = mk_readlane(va, k0 + u); b[u] = mk_readlane(vb, k0 + u); w[u] = mk_readlane(vw, k0 + u);
+                    same &= a[u] == cur_a;
+                }
+                float B3[DP_BATCH][3], d2[DP_BATCH];
+#pragma unroll
+                for (int u = 0; u < DP_BATCH; ++u) { B3[u][0] = at(b[u], 0); B3[u][1] = at(b[u], 1); B3[u][2] = at(b[u], 2); }
+                if (same) {
+#pragma unroll
+                    for (int u = 0; u < DP_BATCH; ++u)
+                        d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
+                } else {
+                    float A3[DP_BATCH][3];
+#pragma unroll
+                    for (int u = 0; u < DP_BATCH; ++u) { A3[u][0] = at(a[u], 0); A3[u][1] = at(a[u], 1); A3[u][2] = at(a[u], 2); }
+#pragma unroll
+                    for (int u = 0; u < DP_BATCH; ++u)
+                        d2[u] = dist2_min_image_f32(A3[u][0], A3[u][1], A3[u][2], B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
+                    cur_a = a[DP_BATCH - 1];
+                    xa = A3[DP_BATCH - 1][0]; ya = A3[DP_BATCH - 1][1]; za = A3[DP_BATCH - 1][2];
+                }
+#pragma unroll
+                for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = squared ? d2[u] : mk_fsqrt_rn(d2[u]);
             }
         }
     }

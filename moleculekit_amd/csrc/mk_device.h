@@ -138,6 +138,7 @@ MK_DEV float mk_fmul_rn(float a, float b)
     return a * b;
 }
 MK_DEV float mk_fdiv_rn(float a, float b) { return __fdiv_rn(a, b); }     // IEEE correctly rounded
+MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // round half to even: v_rndne_f32
 // IEEE correctly rounded sqrt.  (hipcc lowers __fsqrt_rn / sqrtf in this build to a bare v_sqrt_f32, which
 // is only accurate to 1 ulp -- measured: 15 % of results off in the last bit.)  v_sqrt_f32 is within 1 ulp, so
 // the correctly rounded value is s or one of its neighbours; the sign of the exactly computed (FMA)
