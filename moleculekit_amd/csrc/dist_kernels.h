@@ -58,6 +58,27 @@ MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y
 constexpr int DT = 64;                 // tile edge (frames and pairs)
 constexpr int DT_THREADS = 256;
 
+// The second half of every tile kernel here: tile[pair][frame] (lanes ran along frames) goes out with lanes along pairs.
+// A wave owns every fourth frame row; a full tile (the common case, block-uniform) reads its 16 values from LDS at
+// once and stores them behind one another, an edge tile checks every element.
+MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long long p0, long long F, long long P, float* __restrict__ out)
+{
+    constexpr int NW = DT_THREADS / DT, ROWS = DT / NW;
+    const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
+    float* __restrict__ o = out + (size_t)(f0 + fq) * (size_t)P + (size_t)(p0 + pl);
+    const size_t step = (size_t)NW * (size_t)P;
+    if (f0 + DT <= F && p0 + DT <= P) {
+        float v[ROWS];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) v[i] = tile[pl][fq + i * NW];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) o[(size_t)i * step] = v[i];
+    } else {
+        for (int i = 0; i < ROWS; ++i)
+            if (f0 + fq + i * NW < F && p0 + pl < P) o[(size_t)i * step] = tile[pl][fq + i * NW];
+    }
+}
+
 // Compute value(f, p) for a DT x DT tile with lanes along frames, store it with lanes along pairs.
 // blockIdx.x = pair tile, blockIdx.y = frame tile.
 template <class Fn>
@@ -74,14 +95,7 @@ MK_DEV void tile_frames_to_pairs(long long F, long long P, float* __restrict__ o
         }
     }
     mk_block_sync();
-    {
-        const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
-        const long long p = p0 + pl;
-        for (int ff = fq; ff < DT; ff += DT_THREADS / DT) {
-            const long long f = f0 + ff;
-            if (f < F && p < P) out[f * P + p] = tile[pl][ff];
-        }
-    }
+    store_tile_rows(tile, f0, p0, F, P, out);
 }
 
 // Pair table of dist_trajectory (distance_utils.pyx:144-155): loop order i over sel1, j over sel2 from
@@ -136,12 +150,21 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
         const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
         const long long pw = p0 + pq * DP_RUN;                       // the wave's first pair
+#ifdef MK_DIST_DIAG                                                  // store-only floor (tools): no loads, no arithmetic
+        const long long left = 0;
+        for (int k = 0; k < DP_RUN; ++k) tile[pq * DP_RUN + k][fl] = bx;
+#else
         const long long left = P - pw;                               // wave-uniform
+#endif
         if (left > 0) {
             const long long pi = pw + (fl & (DP_RUN - 1)) < P ? pw + (fl & (DP_RUN - 1)) : P - 1;
             const unsigned va = pa[pi], vb = pb[pi], vw = wrap[pi];
-            const float* __restrict__ cf = coords + f;
-            auto at = [&](unsigned atom, int ax) { return cf[((size_t)atom * 3 + ax) * F]; };
+            // a coordinate row is a wave-uniform base (the atom index sits in a scalar register) plus this lane's frame as
+            // a 32-bit byte offset (the host refuses F >= 2^30): the addresses cost no vector instructions
+            const unsigned fb = (unsigned)f * 4u;
+            auto at = [&](unsigned atom, int ax) {
+                return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
+            };
             unsigned cur_a = 0xffffffffu;
             float xa = 0.f, ya = 0.f, za = 0.f;
 #pragma unroll
@@ -177,14 +200,7 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
         }
     }
     mk_block_sync();
-    {
-        const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
-        const long long p = p0 + pl;
-        for (int ff = fq; ff < DT; ff += DT_THREADS / DT) {
-            const long long f = f0 + ff;
-            if (f < F && p < P) out[f * P + p] = tile[pl][ff];
-        }
-    }
+    store_tile_rows(tile, f0, p0, F, P, out);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -25,6 +25,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     const long long P = count_pairs(n1, n2, selfdist);
     if (F == 0 || P == 0) return ST_OK;
     if (P > 0x7fffffffLL * 32) { err = "too many pairs"; return ST_EINVAL; }
+    if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     void *pa = nullptr, *pb = nullptr, *wr = nullptr;
     int st;
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;

@@ -138,6 +138,18 @@ MK_DEV float mk_fmul_rn(float a, float b)
     return a * b;
 }
 MK_DEV float mk_fdiv_rn(float a, float b) { return __fdiv_rn(a, b); }     // IEEE correctly rounded
+// *(float*)((char*)base + byte_offset) for a WAVE-UNIFORM global base: the base is pinned to scalar registers and the
+// load keeps its global address space (global_load_dword v, v_offset, s[base:base+1]) -- left alone, the optimizer folds
+// the lane's offset into the 64-bit address arithmetic first and redoes it per lane, five vector instructions a load
+MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
+{
+    const unsigned long long b = (unsigned long long)reinterpret_cast<uintptr_t>(base);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    typedef const __attribute__((address_space(1))) char* gptr;
+    gptr p = (gptr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    return *(const __attribute__((address_space(1))) float*)(p + byte_offset);
+}
 MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // round half to even: v_rndne_f32
 // IEEE correctly rounded sqrt.  (hipcc lowers __fsqrt_rn / sqrtf in this build to a bare v_sqrt_f32, which
 // is only accurate to 1 ulp -- measured: 15 % of results off in the last bit.)  v_sqrt_f32 is within 1 ulp, so

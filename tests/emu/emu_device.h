@@ -247,6 +247,10 @@ MK_DEV float mk_fsub_rn(float a, float b) { volatile float r = a - b; return r; 
 MK_DEV float mk_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 MK_DEV float mk_fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 MK_DEV float mk_fsqrt_rn(float a) { return sqrtf(a); }
+MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_offset);
+}
 MK_DEV float mk_rint(float a) { return nearbyintf(a); }              // round half to even (default rounding mode)
 MK_DEV float mk_int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 MK_DEV int mk_float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
