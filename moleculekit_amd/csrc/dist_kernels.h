@@ -21,17 +21,12 @@ namespace mkamd {
 // fl(d / b) is only WHICH integer it rounds to.  q = fl(d * fl(1 / b)) is within 3 x 2^-24 |q| of fl(d / b); unless q sits
 // that close to a half-integer (where round() changes its value) both round to the same integer -- and away from the
 // half-integers round-half-away (C round) and round-half-even (ONE instruction, v_rndne_f32) agree as well.  With
-// r = rndne(q) the distance of q from the nearest half-integer is 0.5 - |q - r| (the subtraction is exact), so the
-// test costs a subtract, an fma and a compare.  Axes that fail it -- and everything that is not an ordinary number: zero
-// boxes, overflow, NaN fail the comparison -- take the correctly rounded division; one branch for the three axes.
+// r = rndne(q) the distance of q from the nearest half-integer is 0.5 - |q - r| (the subtraction is exact).  The three
+// axes share ONE test: the largest |q - r| against the bound of the largest |q| (two v_max3_f32, an fma, a compare).
+// Pairs that fail it -- and everything that is not an ordinary number: a zero box makes q infinite, the bound -inf and
+// the comparison false -- take the correctly rounded divisions.  (A NaN q is ignored by the maxima; then r is NaN and so
+// is the reference's result: 0 / 0, inf / inf or a NaN operand.)
 // `ib` = fl(1 / b), computed once per (lane, frame) instead of three IEEE divisions per pair.
-MK_DEV float round_quotient_fast(float d, float ib, bool& sure)
-{
-    const float q = mk_fmul_rn(d, ib);
-    const float r = mk_rint(q);
-    sure = fabsf(q - r) < mk_fma(-3e-7f, fabsf(q), 0.5f);
-    return r;
-}
 MK_DEV float round_quotient_exact(float d, float b) { return roundf(mk_fdiv_rn(d, b)); }
 
 // distance_utils.pyx:34-54 (_dist) / :188-206 (_dist2)
@@ -40,13 +35,13 @@ MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y
 {
     float dx = mk_fsub_rn(x1, x2), dy = mk_fsub_rn(y1, y2), dz = mk_fsub_rn(z1, z2);
     if (wrap) {
-        bool sx, sy, sz;
-        float rx = round_quotient_fast(dx, ibx, sx), ry = round_quotient_fast(dy, iby, sy), rz = round_quotient_fast(dz, ibz, sz);
-        if (!(sx && sy && sz)) {
+        const float qx = mk_fmul_rn(dx, ibx), qy = mk_fmul_rn(dy, iby), qz = mk_fmul_rn(dz, ibz);
+        float rx = mk_rint(qx), ry = mk_rint(qy), rz = mk_rint(qz);
+        const float tm = mk_max3(fabsf(qx - rx), fabsf(qy - ry), fabsf(qz - rz));
+        const float qm = mk_max3(fabsf(qx), fabsf(qy), fabsf(qz));
+        if (!(tm < mk_fma(-3e-7f, qm, 0.5f))) {
             asm volatile("" ::: "memory");                           // a real branch: the divisions must not be computed "just in case"
-            if (!sx) rx = round_quotient_exact(dx, bx);
-            if (!sy) ry = round_quotient_exact(dy, by);
-            if (!sz) rz = round_quotient_exact(dz, bz);
+            rx = round_quotient_exact(dx, bx); ry = round_quotient_exact(dy, by); rz = round_quotient_exact(dz, bz);
         }
         dx = mk_fsub_rn(dx, mk_fmul_rn(bx, rx));
         dy = mk_fsub_rn(dy, mk_fmul_rn(by, ry));
@@ -133,7 +128,10 @@ MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long l
 // is used: the first version looked its pair up, waited, loaded its three coordinates, waited -- 32 dependent round
 // trips to L2 per wave, which is what bounded it (0.56 ms for 100 000 pairs x 2 048 frames: 1.5 TB/s of stores).
 constexpr int DP_RUN = DT / (DT_THREADS / DT);   // 16
-constexpr int DP_BATCH = 4;
+#ifndef MK_DP_BATCH
+#define MK_DP_BATCH 4
+#endif
+constexpr int DP_BATCH = MK_DP_BATCH;           // (8 was measured too)
 
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
                                         const float* __restrict__ box, const unsigned* __restrict__ pa,
@@ -158,7 +156,10 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
 #endif
         if (left > 0) {
             const long long pi = pw + (fl & (DP_RUN - 1)) < P ? pw + (fl & (DP_RUN - 1)) : P - 1;
-            const unsigned va = pa[pi], vb = pb[pi], vw = wrap[pi];
+            // lane k: first atom of pair k, and its second atom with the wrap flag in bit 31 (atom indices are int32)
+            const unsigned va = pa[pi], vb = pb[pi] | (wrap[pi] != 0u ? 0x80000000u : 0u);
+            const unsigned a_first = mk_readlane(va, 0);
+            const bool one_a = mk_ballot(va != a_first) == 0ull;      // the usual case in i-major order: one first atom for the run
             // a coordinate row is a wave-uniform base (the atom index sits in a scalar register) plus this lane's frame as
             // a 32-bit byte offset (the host refuses F >= 2^30): the addresses cost no vector instructions
             const unsigned fb = (unsigned)f * 4u;
@@ -174,7 +175,9 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
                 bool same = true;                                    // wave-uniform: the batch stays with the cached first atom
 #pragma unroll
                 for (int u = 0; u < DP_BATCH; ++u) {
-                    a[u] = mk_readlane(va, k0 + u); b[u] = mk_readlane(vb, k0 + u); w[u] = mk_readlane(vw, k0 + u);
+                    a[u] = one_a ? a_first : mk_readlane(va, k0 + u);
+                    const unsigned bw = mk_readlane(vb, k0 + u);
+                    b[u] = bw & 0x7fffffffu; w[u] = bw >> 31;
                     same &= a[u] == cur_a;
                 }
                 float B3[DP_BATCH][3], d2[DP_BATCH];

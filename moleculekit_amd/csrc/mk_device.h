@@ -138,18 +138,21 @@ MK_DEV float mk_fmul_rn(float a, float b)
     return a * b;
 }
 MK_DEV float mk_fdiv_rn(float a, float b) { return __fdiv_rn(a, b); }     // IEEE correctly rounded
-// *(float*)((char*)base + byte_offset) for a WAVE-UNIFORM global base: the base is pinned to scalar registers and the
-// load keeps its global address space (global_load_dword v, v_offset, s[base:base+1]) -- left alone, the optimizer folds
-// the lane's offset into the 64-bit address arithmetic first and redoes it per lane, five vector instructions a load
+// *(float*)((char*)base + byte_offset) for a WAVE-UNIFORM global base: a raw buffer load whose descriptor holds the base
+// in scalar registers (buffer_load_dword v, v_offset, s[rsrc], 0 offen) -- the address costs NO vector instruction.
+// (Left alone, the optimizer folds the lane's offset into the 64-bit address arithmetic and redoes it per lane: five
+//  vector instructions a load; a global_load with the base pinned to scalar registers still pays one.)
 MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
 {
     const unsigned long long b = (unsigned long long)reinterpret_cast<uintptr_t>(base);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
-    typedef const __attribute__((address_space(1))) char* gptr;
-    gptr p = (gptr)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-    return *(const __attribute__((address_space(1))) float*)(p + byte_offset);
+    void* p = reinterpret_cast<void*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+    // gfx9 raw buffer: stride 0, num_records = 2^32 - 1 bytes (no range to enforce: the callers bound the offset), DATA_FORMAT 32
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)0xffffffffu, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_offset, 0, 0));
 }
+MK_DEV float mk_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32 (NaN operands are ignored)
 MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // round half to even: v_rndne_f32
 // IEEE correctly rounded sqrt.  (hipcc lowers __fsqrt_rn / sqrtf in this build to a bare v_sqrt_f32, which
 // is only accurate to 1 ulp -- measured: 15 % of results off in the last bit.)  v_sqrt_f32 is within 1 ulp, so
@@ -157,6 +160,14 @@ MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // rou
 // residuals x - s*s_down and x - s*s_up tells on which side of the two rounding midpoints x lies.
 MK_DEV float mk_fsqrt_rn(float x)
 {
+    // every lane of the wave holds an ordinary number in [2^-96, inf) -- practically always: the correction alone
+    if (__builtin_amdgcn_ballot_w64(!((__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u))) == 0ull) {
+        const float s = __builtin_amdgcn_sqrtf(x);
+        const float s_down = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+        const float r_down = __builtin_fmaf(-s_down, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+        const float y = (r_down <= 0.0f) ? s_down : s;
+        return (r_up > 0.0f) ? s_up : y;
+    }
     // keep v_sqrt_f32 away from denormal inputs / results: scale tiny x by 2^64 (exact), result by 2^-32
     const bool tiny = x < 0x1.0p-96f;
     const float xs = tiny ? x * 0x1.0p+64f : x;
