@@ -133,6 +133,63 @@ constexpr int DP_RUN = DT / (DT_THREADS / DT);   // 16
 #endif
 constexpr int DP_BATCH = MK_DP_BATCH;           // (8 was measured too)
 
+// d^2 of the DP_RUN consecutive pairs [pw, pw + DP_RUN) for this lane's frame (byte offset fb = 4 f into a coordinate
+// row; the host refuses F >= 2^30): emit(k, d2), k = 0 .. DP_RUN-1, called by all lanes.  Pairs past the end repeat
+// the last pair (valid addresses, no divergence) -- the caller drops what they emit.  Needs pw < P.
+template <class Emit>
+MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned fb, float bx, float by, float bz,
+                         const unsigned* __restrict__ pa, const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
+                         long long P, long long pw, Emit&& emit)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
+    const long long left = P - pw;                                   // wave-uniform, > 0
+    const long long pi = pw + (lane & (DP_RUN - 1)) < P ? pw + (lane & (DP_RUN - 1)) : P - 1;
+    // lane k: first atom of pair k, and its second atom with the wrap flag in bit 31 (atom indices are int32)
+    const unsigned va = pa[pi], vb = pb[pi] | (wrap[pi] != 0u ? 0x80000000u : 0u);
+    const unsigned a_first = mk_readlane(va, 0);
+    const bool one_a = mk_ballot(va != a_first) == 0ull;              // the usual case in i-major order: one first atom for the run
+    // a coordinate row is a wave-uniform base (the atom index sits in a scalar register) plus this lane's frame as a
+    // 32-bit byte offset: the addresses cost no vector instructions
+    auto at = [&](unsigned atom, int ax) {
+        return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
+    };
+    unsigned cur_a = 0xffffffffu;
+    float xa = 0.f, ya = 0.f, za = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < DP_RUN; k0 += DP_BATCH) {
+        if ((long long)k0 >= left) break;                            // wave-uniform
+        unsigned a[DP_BATCH], b[DP_BATCH], w[DP_BATCH];
+        bool same = true;                                            // wave-uniform: the batch stays with the cached first atom
+#pragma unroll
+        for (int u = 0; u < DP_BATCH; ++u) {
+            a[u] = one_a ? a_first : mk_readlane(va, k0 + u);
+            const unsigned bw = mk_readlane(vb, k0 + u);
+            b[u] = bw & 0x7fffffffu; w[u] = bw >> 31;
+            same &= a[u] == cur_a;
+        }
+        float B3[DP_BATCH][3], d2[DP_BATCH];
+#pragma unroll
+        for (int u = 0; u < DP_BATCH; ++u) { B3[u][0] = at(b[u], 0); B3[u][1] = at(b[u], 1); B3[u][2] = at(b[u], 2); }
+        if (same) {
+#pragma unroll
+            for (int u = 0; u < DP_BATCH; ++u)
+                d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
+        } else {
+            float A3[DP_BATCH][3];
+#pragma unroll
+            for (int u = 0; u < DP_BATCH; ++u) { A3[u][0] = at(a[u], 0); A3[u][1] = at(a[u], 1); A3[u][2] = at(a[u], 2); }
+#pragma unroll
+            for (int u = 0; u < DP_BATCH; ++u)
+                d2[u] = dist2_min_image_f32(A3[u][0], A3[u][1], A3[u][2], B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
+            cur_a = a[DP_BATCH - 1];
+            xa = A3[DP_BATCH - 1][0]; ya = A3[DP_BATCH - 1][1]; za = A3[DP_BATCH - 1][2];
+        }
+#pragma unroll
+        for (int u = 0; u < DP_BATCH; ++u) emit(k0 + u, d2[u]);
+    }
+}
+
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
                                         const float* __restrict__ box, const unsigned* __restrict__ pa,
                                         const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
@@ -142,65 +199,17 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
     const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
     {
         const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
-        // frames past the end compute on the last frame and pairs past the end on the last pair (valid addresses, no
-        // divergence); the store phase below never reads those tile entries
+        // frames past the end compute on the last frame (the store phase never reads those tile entries)
         const long long f = f0 + fl < F ? f0 + fl : F - 1;
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
-        const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
         const long long pw = p0 + pq * DP_RUN;                       // the wave's first pair
 #ifdef MK_DIST_DIAG                                                  // store-only floor (tools): no loads, no arithmetic
-        const long long left = 0;
         for (int k = 0; k < DP_RUN; ++k) tile[pq * DP_RUN + k][fl] = bx;
 #else
-        const long long left = P - pw;                               // wave-uniform
+        if (pw < P)
+            for_pair_run(coords, F, (unsigned)f * 4u, bx, by, bz, pa, pb, wrap, P, pw,
+                         [&](int k, float d2) { tile[pq * DP_RUN + k][fl] = squared ? d2 : mk_fsqrt_rn(d2); });
 #endif
-        if (left > 0) {
-            const long long pi = pw + (fl & (DP_RUN - 1)) < P ? pw + (fl & (DP_RUN - 1)) : P - 1;
-            // lane k: first atom of pair k, and its second atom with the wrap flag in bit 31 (atom indices are int32)
-            const unsigned va = pa[pi], vb = pb[pi] | (wrap[pi] != 0u ? 0x80000000u : 0u);
-            const unsigned a_first = mk_readlane(va, 0);
-            const bool one_a = mk_ballot(va != a_first) == 0ull;      // the usual case in i-major order: one first atom for the run
-            // a coordinate row is a wave-uniform base (the atom index sits in a scalar register) plus this lane's frame as
-            // a 32-bit byte offset (the host refuses F >= 2^30): the addresses cost no vector instructions
-            const unsigned fb = (unsigned)f * 4u;
-            auto at = [&](unsigned atom, int ax) {
-                return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
-            };
-            unsigned cur_a = 0xffffffffu;
-            float xa = 0.f, ya = 0.f, za = 0.f;
-#pragma unroll
-            for (int k0 = 0; k0 < DP_RUN; k0 += DP_BATCH) {
-                if ((long long)k0 >= left) break;                    // wave-uniform
-                unsigned a[DP_BATCH], b[DP_BATCH], w[DP_BATCH];
-                bool same = true;                                    // wave-uniform: the batch stays with the cached first atom
-#pragma unroll
-                for (int u = 0; u < DP_BATCH; ++u) {
-                    a[u] = one_a ? a_first : mk_readlane(va, k0 + u);
-                    const unsigned bw = mk_readlane(vb, k0 + u);
-                    b[u] = bw & 0x7fffffffu; w[u] = bw >> 31;
-                    same &= a[u] == cur_a;
-                }
-                float B3[DP_BATCH][3], d2[DP_BATCH];
-#pragma unroll
-                for (int u = 0; u < DP_BATCH; ++u) { B3[u][0] = at(b[u], 0); B3[u][1] = at(b[u], 1); B3[u][2] = at(b[u], 2); }
-                if (same) {
-#pragma unroll
-                    for (int u = 0; u < DP_BATCH; ++u)
-                        d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
-                } else {
-                    float A3[DP_BATCH][3];
-#pragma unroll
-                    for (int u = 0; u < DP_BATCH; ++u) { A3[u][0] = at(a[u], 0); A3[u][1] = at(a[u], 1); A3[u][2] = at(a[u], 2); }
-#pragma unroll
-                    for (int u = 0; u < DP_BATCH; ++u)
-                        d2[u] = dist2_min_image_f32(A3[u][0], A3[u][1], A3[u][2], B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
-                    cur_a = a[DP_BATCH - 1];
-                    xa = A3[DP_BATCH - 1][0]; ya = A3[DP_BATCH - 1][1]; za = A3[DP_BATCH - 1][2];
-                }
-#pragma unroll
-                for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = squared ? d2[u] : mk_fsqrt_rn(d2[u]);
-            }
-        }
     }
     mk_block_sync();
     store_tile_rows(tile, f0, p0, F, P, out);
@@ -219,29 +228,20 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_RUN = DT / (DT_THREADS / DT);        // consecutive pairs per wave of a tile (16)
 
-// bit k set: pair (p_first + k) of frame f is a contact.  Same traversal as k_dist_pairs (first atom cached).
+// bit k set: pair (p_first + k) of frame f is a contact.  Same traversal as k_dist_pairs (for_pair_run); a padded frame
+// (`fin` false) computes on frame 0 and reports nothing.
 MK_DEV unsigned contact_mask(const float* __restrict__ coords, long long F, long long f, bool fin, float bx, float by, float bz,
                              const unsigned* __restrict__ pa, const unsigned* __restrict__ pb,
                              const unsigned* __restrict__ wrap, long long P, long long p_first, float thr2)
 {
-    unsigned mask = 0u, cur_a = 0xffffffffu;
-    float xa = 0.f, ya = 0.f, za = 0.f;
-    const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
-    for (int k = 0; k < CT_RUN; ++k) {
-        const long long p = p_first + k;
-        if (p >= P) break;                                         // wave-uniform
-        const unsigned a = pa[p], b = pb[p];
-        if (a != cur_a) {                                          // wave-uniform
-            cur_a = a;
-            if (fin) { xa = coords[((size_t)a * 3 + 0) * F + f]; ya = coords[((size_t)a * 3 + 1) * F + f]; za = coords[((size_t)a * 3 + 2) * F + f]; }
-        }
-        if (fin) {
-            const float d2 = dist2_min_image_f32(xa, ya, za, coords[((size_t)b * 3 + 0) * F + f], coords[((size_t)b * 3 + 1) * F + f],
-                                                 coords[((size_t)b * 3 + 2) * F + f], bx, by, bz, ibx, iby, ibz, wrap[p] != 0u);
-            mask |= (d2 <= thr2) ? (1u << k) : 0u;                 // distance_utils.pyx:82 / :111 (NaN: no contact)
-        }
-    }
-    return mask;
+    static_assert(CT_RUN == DP_RUN, "one run per wave");
+    if (p_first >= P) return 0u;                                     // wave-uniform
+    unsigned mask = 0u;
+    for_pair_run(coords, F, fin ? (unsigned)f * 4u : 0u, bx, by, bz, pa, pb, wrap, P, p_first,
+                 [&](int k, float d2) { mask |= (d2 <= thr2) ? (1u << k) : 0u; });   // distance_utils.pyx:82 / :111 (NaN: no contact)
+    const long long left = P - p_first;
+    if (left < CT_RUN) mask &= (1u << (unsigned)left) - 1u;
+    return fin ? mask : 0u;
 }
 
 // blockIdx.x = pair tile, blockIdx.y = 64-frame slab of the chunk [f_begin, f_begin + fc); cnt is [tiles][fc_pad]

@@ -91,6 +91,7 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     const long long P = count_pairs(n1, n2, selfdist);
     if (F == 0 || P == 0) return ST_OK;
     if (P >= 0xffffffffLL) { err = "too many atom pairs (>= 2^32); split the selections"; return ST_EINVAL; }
+    if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     void *pa = nullptr, *pb = nullptr, *wr = nullptr, *cnt = nullptr, *tot = nullptr, *base = nullptr, *dout = nullptr;
     int st;
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
