@@ -137,8 +137,21 @@ template <typename SigT>
 MK_DEV uint2 atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w_scale, float (&w)[CHG])
 {
     SigT s[CHG];
+    // a full group of channels in a 16-byte aligned row (C = 8, the reference's channel set): 16-byte loads -- as eight
+    // separate dwords with the `c0 + j < C` branches between them the wave asked the L1 for four times the lines
+    struct alignas(16) Vec16 { SigT v[16 / sizeof(SigT)]; };
+    constexpr int PER = 16 / (int)sizeof(SigT);
+    if (c0 + CHG <= C && (reinterpret_cast<uintptr_t>(row + c0) & (uintptr_t)15) == 0) {
 #pragma unroll
-    for (int j = 0; j < CHG; ++j) s[j] = (c0 + j < C) ? row[c0 + j] : (SigT)0;
+        for (int i = 0; i < CHG / PER; ++i) {
+            const Vec16 v = reinterpret_cast<const Vec16*>(row + c0)[i];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) s[i * PER + j] = v.v[j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) s[j] = (c0 + j < C) ? row[c0 + j] : (SigT)0;
+    }
     SigT s0 = (SigT)0;
 #pragma unroll
     for (int j = CHG - 1; j >= 0; --j) s0 = (s[j] != (SigT)0) ? s[j] : s0;
@@ -410,6 +423,8 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         const int nvox[3] = {g.nx, g.ny, g.nz};
         // fused augmentation (tools/voxeldescriptors.py:78-114 rotateCoordinates, then the astype(float32) of
         // _getOccupancyC :519): x' = M x + t in double, rounded to float32 like the reference pipeline does
+        // (asking for the position up front, together with the sigmas, was measured: no gain -- the waves spend 10 % of
+        //  their cycles in s_waitcnt, the kernel is not waiting for memory)
         float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
         if (affine != nullptr) {
             const double* A = affine + 12 * (size_t)b;
