@@ -92,6 +92,38 @@ def test_trajectory_scale_against_oracle():
     assert np.array_equal(r2, oracle.dist_trajectory(c, b, s2, s2, ch, True, True))
 
 
+def test_ragged_runs_zero_box_and_contact_lists_against_oracle():
+    """What the pair-run traversal has to get right on the hardware: runs of 16 pairs whose first atom changes inside a
+    batch of four (n2 = 5, self pairs), pair and frame counts that are not multiples of 64 or 16, a frame with a zero box
+    (pbc -> NaN like the reference: the image-shift test must send it to the division), and the same traversal under the
+    contact lists (reference order: frame, i, j; distance_utils.pyx:59-93)."""
+    from moleculekit_amd.distance_utils import dist_trajectory, contacts_trajectory
+    rng = np.random.default_rng(3)
+    N, F = 150, 70
+    c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(15, 25, size=(3, F)).astype(np.float32)
+    b[:, 5] = 0.0
+    ch = rng.integers(0, 3, size=N).astype(np.uint32)
+    s1 = np.arange(0, 90, dtype=np.uint32); s2 = np.arange(40, 150, dtype=np.uint32)
+    thr = 12.0
+    for selfd, a, bb in ((False, s1, s2), (True, s2, s2), (True, s1[:7], s2[:20]), (False, s1[:9], s2[:5]), (False, s1[:1], s2[:3])):
+        exp = oracle.dist_trajectory(c, b, a, bb, ch, selfd, True)
+        got = np.zeros_like(exp)
+        dist_trajectory(c, b, a, bb, ch, selfd, True, got)
+        assert np.array_equal(got, exp, equal_nan=True)
+        assert np.isnan(exp[5]).any()
+        d2 = oracle.dist_trajectory(c, b, a, bb, ch, selfd, True, squared=True)
+        if selfd:
+            table = [(a[i], bb[j]) for i in range(len(a)) for j in range(i + 1, len(bb))]
+        else:
+            table = [(a[i], bb[j]) for i in range(len(a)) for j in range(len(bb))]
+        lists = contacts_trajectory(c, b, a, bb, ch, selfd, True, thr)
+        assert len(lists) == F
+        for f in range(F):
+            hits = np.nonzero(d2[f] <= np.float32(thr) * np.float32(thr))[0]          # NaN: no contact (:82)
+            assert lists[f] == [int(v) for k in hits for v in table[k]]
+
+
 def test_metricdistance_style_drivers():
     """pp_calcDistances / get_reduced_distances / calculate_contacts (projections/util.py, distance.py) on a duck-typed
     molecule, incl. the analytic 2 A-box case in the spirit of tests/test_metricdistance.py:99-135."""
