@@ -74,25 +74,6 @@ MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long 
     }
 }
 
-// Compute value(f, p) for a DT x DT tile with lanes along frames, store it with lanes along pairs.
-// blockIdx.x = pair tile, blockIdx.y = frame tile.
-template <class Fn>
-MK_DEV void tile_frames_to_pairs(long long F, long long P, float* __restrict__ out, Fn&& value)
-{
-    __shared__ float tile[DT][DT + 1];
-    const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
-    {
-        const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
-        const long long f = f0 + fl;
-        for (int pp = pq; pp < DT; pp += DT_THREADS / DT) {
-            const long long p = p0 + pp;
-            if (f < F && p < P) tile[pp][fl] = value(f, p);
-        }
-    }
-    mk_block_sync();
-    store_tile_rows(tile, f0, p0, F, P, out);
-}
-
 // Pair table of dist_trajectory (distance_utils.pyx:144-155): loop order i over sel1, j over sel2 from
 // (selfdist ? i+1 : 0).  One thread per (i, j); wrap = pbc && chains differ (:49).
 MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long long n1,
@@ -369,6 +350,13 @@ MK_KERNEL(256) void k_build_group_pairs(long long ng1, long long ng2, const unsi
 // pairs (reduction 0, "closest") or between centres of mass (reduction 1; c1/c2 then point at COM arrays
 // and every group counts as one pseudo-atom indexed by its group id).  The reference's update rule
 // `if dist2 < mindist or mindist < 0` (mindist starts at -1) is kept verbatim, NaN behaviour included.
+// Lanes run along frames; a wave takes every fourth group pair of the tile.  Everything about a group pair is
+// wave-uniform (group ids, atom lists: scalar loads), the coordinate rows are scalar bases + the lane's frame offset
+// (mk_load_f32_uniform_base), and the second group's atoms go four at a time: twelve loads in flight, then the four
+// distances, then the reference's update in ITS order.  (First version: one pair at a time, every load waited for, a
+// 64-bit multiply-add per lane and load for the address.)
+constexpr int DR_BATCH = 4;
+
 MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const float* __restrict__ c2,
                                             long long F, const float* __restrict__ box,
                                             const int* __restrict__ g1_atoms, const long long* __restrict__ g1_off,
@@ -377,26 +365,57 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
                                             const unsigned* __restrict__ gb, const unsigned* __restrict__ wrap,
                                             long long P, float* __restrict__ out)
 {
-    tile_frames_to_pairs(F, P, out, [&](long long f, long long p) {
-        const long long a = ga[p], b = gb[p];
-        const bool w = wrap[p] != 0u;
+    __shared__ float tile[DT][DT + 1];
+    const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
+    {
+        const int fl = threadIdx.x & (DT - 1);
+        const int pq = (int)mk_uniform(threadIdx.x >> 6);            // the wave's index, as a scalar
+        // frames past the end compute on the last frame (the store phase never reads those tile entries)
+        const long long f = f0 + fl < F ? f0 + fl : F - 1;
+        const unsigned fb = (unsigned)f * 4u;                        // the host refuses F >= 2^30
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
         const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
-        const long long i0 = com1 ? a : g1_off[a], i1 = com1 ? a + 1 : g1_off[a + 1];
-        const long long j0 = com2 ? b : g2_off[b], j1 = com2 ? b + 1 : g2_off[b + 1];
-        float mindist = -1.f;
-        for (long long i = i0; i < i1; ++i) {
-            const size_t at1 = com1 ? (size_t)i : (size_t)g1_atoms[i];
-            const float x1 = c1[(at1 * 3 + 0) * F + f], y1 = c1[(at1 * 3 + 1) * F + f], z1 = c1[(at1 * 3 + 2) * F + f];
-            for (long long j = j0; j < j1; ++j) {
-                const size_t at2 = com2 ? (size_t)j : (size_t)g2_atoms[j];
-                const float d2 = dist2_min_image_f32(x1, y1, z1, c2[(at2 * 3 + 0) * F + f], c2[(at2 * 3 + 1) * F + f],
-                                                     c2[(at2 * 3 + 2) * F + f], bx, by, bz, ibx, iby, ibz, w);
-                if (d2 < mindist || mindist < 0.f) mindist = d2;
+        auto at = [&](const float* __restrict__ c, size_t atom, int ax) {
+            return mk_load_f32_uniform_base(c + (atom * 3 + (size_t)ax) * (size_t)F, fb);
+        };
+        for (int pp = pq; pp < DT; pp += DT_THREADS / DT) {
+            const long long p = p0 + pp;
+            if (p >= P) break;                                       // wave-uniform
+            const long long a = ga[p], b = gb[p];
+            const bool w = wrap[p] != 0u;
+            const long long i0 = com1 ? a : g1_off[a], i1 = com1 ? a + 1 : g1_off[a + 1];
+            const long long j0 = com2 ? b : g2_off[b], j1 = com2 ? b + 1 : g2_off[b + 1];
+            float mindist = -1.f;
+            for (long long i = i0; i < i1; ++i) {
+                const size_t at1 = com1 ? (size_t)i : (size_t)g1_atoms[i];
+                const float x1 = at(c1, at1, 0), y1 = at(c1, at1, 1), z1 = at(c1, at1, 2);
+                long long j = j0;
+                for (; j + DR_BATCH <= j1; j += DR_BATCH) {
+                    float B3[DR_BATCH][3], d2[DR_BATCH];
+#pragma unroll
+                    for (int u = 0; u < DR_BATCH; ++u) {
+                        const size_t at2 = com2 ? (size_t)(j + u) : (size_t)g2_atoms[j + u];
+                        B3[u][0] = at(c2, at2, 0); B3[u][1] = at(c2, at2, 1); B3[u][2] = at(c2, at2, 2);
+                    }
+#pragma unroll
+                    for (int u = 0; u < DR_BATCH; ++u)
+                        d2[u] = dist2_min_image_f32(x1, y1, z1, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w);
+#pragma unroll
+                    for (int u = 0; u < DR_BATCH; ++u)
+                        if (d2[u] < mindist || mindist < 0.f) mindist = d2[u];
+                }
+                for (; j < j1; ++j) {
+                    const size_t at2 = com2 ? (size_t)j : (size_t)g2_atoms[j];
+                    const float d2 = dist2_min_image_f32(x1, y1, z1, at(c2, at2, 0), at(c2, at2, 1), at(c2, at2, 2),
+                                                         bx, by, bz, ibx, iby, ibz, w);
+                    if (d2 < mindist || mindist < 0.f) mindist = d2;
+                }
             }
+            tile[pp][fl] = mk_fsqrt_rn(mindist);
         }
-        return mk_fsqrt_rn(mindist);
-    });
+    }
+    mk_block_sync();
+    store_tile_rows(tile, f0, p0, F, P, out);
 }
 
 // cdist (distance_utils.pyx:355-383): results[i, j]; any dimension D; lanes along j.

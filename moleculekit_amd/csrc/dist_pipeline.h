@@ -49,6 +49,7 @@ int run_dist_reduction(BE& be, const float* coords, long long F, const float* bo
     if ((reduction1 | reduction2) & ~1) { err = "reduction must be 0 (closest) or 1 (com)"; return ST_EINVAL; }
     const long long P = pairs ? ng1 : count_pairs(ng1, ng2, selfdist);
     if (F == 0 || P == 0) return ST_OK;
+    if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     void *ga = nullptr, *gb = nullptr, *wr = nullptr, *com1 = nullptr, *com2 = nullptr;
     int st;
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &ga, 0))) return st;

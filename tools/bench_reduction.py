@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""tools/bench_reduction.py -- dist_trajectory_reduction ("closest" atom between residues, the MetricDistance contact-map
+projection: distance_utils.pyx:211-281) on a synthetic protein-like trajectory: 200 groups of 15 atoms, 512 frames, all
+19 900 group pairs, periodic.  Host arrays in / out (copies included in the wall clock); run it under
+`rocprofv3 --kernel-trace` (tools/gpu_kstats_reduction.sh) for the kernel's own duration.  MKAMD_LIB selects the build."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from moleculekit_amd import distance_utils as du
+
+rng = np.random.default_rng(5)
+G, A, F = 200, 15, 512
+N = G * A
+L = 60.0
+centres = rng.uniform(0, L, size=(G, 3))
+c0 = (np.repeat(centres, A, axis=0) + rng.normal(0, 1.5, size=(N, 3))).astype(np.float32)
+coords = np.ascontiguousarray((c0[:, :, None] + rng.normal(0, 0.3, size=(N, 3, F))).astype(np.float32))
+box = np.full((3, F), L, dtype=np.float32)
+groups = [np.arange(g * A, (g + 1) * A, dtype=np.int32) for g in range(G)]
+chains = (np.arange(G) // 50).astype(np.uint32)
+masses = np.ones(N, np.float32)
+P = G * (G - 1) // 2
+out = np.zeros((F, P), np.float32)
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter()
+    du.dist_trajectory_reduction(coords, box, groups, groups, chains, chains, True, True, masses, 0, 0, out)
+    ts.append(time.perf_counter() - t0)
+print(f"dist_trajectory_reduction: {min(ts) * 1e3:.1f} ms per call, {P * A * A * F / 1e9:.2f} G atom-pair distances per call, checksum {float(out.sum()):.6e}")
