@@ -1175,7 +1175,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     unsigned surv_code[SURV_REGS];                          // this lane's codes (survivors lane, lane + 64, ...), for the placement pass
 
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int wv = TEAM > 1 ? (int)mk_uniform((unsigned)(threadIdx.x >> 6)) : 0;   // (as a scalar: see k_voxelize_items)
     const int kb = wv * KE;
     const bool lead = lane == 0 && wv == 0;               // the one thread of the tile's team that reports to global memory
     // x of this wave's plane j relative to the tile centre (compile-time constants for the one-wave kernel)
@@ -2003,7 +2003,10 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __re
     const int b = (int)blockIdx.x / nchunk, gq = (int)blockIdx.y;
     const int t_begin = ((int)blockIdx.x - b * nchunk) * tiles_per_block;
     const int t_end = t_begin + tiles_per_block < g.ntiles ? t_begin + tiles_per_block : g.ntiles;
-    const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & (WAVE - 1);
+    // the wave's index as a SCALAR: the compiler cannot know that threadIdx.x >> 6 is the same in all lanes, and did a tile's
+    // geometry (three integer divisions by run-time sizes, the float offsets) per lane in vector instructions
+    const int wv = (int)mk_uniform((unsigned)(tid >> 6));
     const unsigned* __restrict__ table = cls_table + (g.cls_per_item ? (size_t)b * CLS_TABLE_WORDS : (size_t)0);
     const unsigned table_word = (lane < CLS_TABLE_WORDS) ? table[lane] : CLS_EMPTY;
     const unsigned my_class_w = (lane < NCLS) ? table_word : 0x7f800000u;
