@@ -15,3 +15,6 @@ for wl in cfg1 cfg5; do rm -rf gpurun_out/prof_$wl; (cd /tmp && timeout 300 rocp
 for w in cfg2 3ptb; do rm -rf gpurun_out/st_$w; (cd /tmp && timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/st_$w -- python $R/tools/single_timeline.py $w > $R/gpurun_out/st_$w.log 2>&1); python tools/single_timeline_report.py gpurun_out/st_$w > gpurun_out/single_timeline_$w.txt 2>&1; done
 (timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
 (bash tools/gpu_pmc_bin.sh > gpurun_out/pmc_bin.txt 2>&1)
+(bash tools/gpu_pmc_dist.sh > gpurun_out/pmc_dist.txt 2>&1)
+(bash tools/gpu_kstats_reduction.sh > gpurun_out/kstats_reduction.txt 2>&1)
+(MKAMD_LIB=$R/.variants/libmkamd_distdiag.so timeout 200 python bench.py --workload dist --no-cpu-baseline > gpurun_out/bench_distance_store_only.log 2>&1)
