@@ -1175,7 +1175,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     unsigned surv_code[SURV_REGS];                          // this lane's codes (survivors lane, lane + 64, ...), for the placement pass
 
     const int lane = threadIdx.x & (WAVE - 1);
-    const int wv = TEAM > 1 ? (int)mk_uniform((unsigned)(threadIdx.x >> 6)) : 0;   // (as a scalar: see k_voxelize_items)
+    const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int kb = wv * KE;
     const bool lead = lane == 0 && wv == 0;               // the one thread of the tile's team that reports to global memory
     // x of this wave's plane j relative to the tile centre (compile-time constants for the one-wave kernel)
@@ -2304,23 +2304,30 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
 // ------------------------------------------------------------------------------------------------
 // Explicit (non-lattice) centres: the exact calculate_occupancy contract for arbitrary `centers`
 // (usercenters / direct calls).  Distances in DOUBLE exactly as the reference (float32 coords
-// promoted, strict d^2 < 25), min-q reduction in float32.  Brute force O(N*V): thread per centre,
-// atoms staged through LDS in chunks of 256.  blockIdx.y = channel group.
+// promoted, strict d^2 < 25), min-q reduction in float32.  Brute force O(N*V).
+// A workgroup owns 64 centres (lane = centre) and its waves split the ATOMS: the atoms go through LDS in chunks of one
+// atom per thread, wave w tests the w-th 64 of a chunk, and the waves' running minima meet in LDS (ds_min_u32 on the
+// bit patterns: order-free, so the result does not depend on the split) before the epilogue.  The host picks 4, 8 or 16
+// waves so that a small centre list still fills the chip -- with a thread per centre and every thread walking all
+// atoms (round 1) a 24^3 grid ran on 54 of the 256 CUs for 100 us.  blockIdx.y = channel group.
 // w here is 1/sigma^2 in A^-2 (w_scale = 1).
 // ------------------------------------------------------------------------------------------------
-constexpr int EXPL_THREADS = 256;
+constexpr int EXPL_CENTERS = 64;                     // centres per workgroup
+constexpr int EXPL_MAX_WAVES = 16;
 
-MK_KERNEL(EXPL_THREADS) void k_occupancy_centers(const double* __restrict__ centers, long long V,
+MK_KERNEL(EXPL_MAX_WAVES * WAVE) void k_occupancy_centers(const double* __restrict__ centers, long long V,
                                                  const float* __restrict__ coords, long long N,
                                                  const float4* __restrict__ w /* [G][2][N] */,
                                                  int C, int use_box, double bx, double by, double bz,
                                                  float* __restrict__ out)
 {
-    __shared__ float4 s_pos[EXPL_THREADS];
-    __shared__ float4 s_w0[EXPL_THREADS];
-    __shared__ float4 s_w1[EXPL_THREADS];
+    __shared__ float4 s_pos[EXPL_MAX_WAVES * WAVE];
+    __shared__ float4 s_w0[EXPL_MAX_WAVES * WAVE];
+    __shared__ float4 s_w1[EXPL_MAX_WAVES * WAVE];
+    __shared__ unsigned s_q[CHG][EXPL_CENTERS];
     const int gq = blockIdx.y;
-    const long long v = (long long)blockIdx.x * EXPL_THREADS + threadIdx.x;
+    const int nth = (int)blockDim.x, tid = (int)threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    const long long v0 = (long long)blockIdx.x * EXPL_CENTERS, v = v0 + lane;
     const bool active = v < V;
     double cx = 0, cy = 0, cz = 0;
     if (active) { cx = centers[3 * v]; cy = centers[3 * v + 1]; cz = centers[3 * v + 2]; }
@@ -2328,17 +2335,20 @@ MK_KERNEL(EXPL_THREADS) void k_occupancy_centers(const double* __restrict__ cent
     unsigned q[CHG];
 #pragma unroll
     for (int c = 0; c < CHG; ++c) q[c] = 0x7f800000u;
+    for (int i = tid; i < CHG * EXPL_CENTERS; i += nth) s_q[i / EXPL_CENTERS][i % EXPL_CENTERS] = 0x7f800000u;
 
-    for (long long a0 = 0; a0 < N; a0 += EXPL_THREADS) {
-        const long long a = a0 + threadIdx.x;
+    for (long long a0 = 0; a0 < N; a0 += nth) {
+        const long long a = a0 + tid;
         if (a < N) {
-            s_pos[threadIdx.x] = make_float4(coords[3 * a], coords[3 * a + 1], coords[3 * a + 2], 0.f);
-            s_w0[threadIdx.x] = w[(size_t)(gq * 2 + 0) * N + a];
-            s_w1[threadIdx.x] = w[(size_t)(gq * 2 + 1) * N + a];
+            s_pos[tid] = make_float4(coords[3 * a], coords[3 * a + 1], coords[3 * a + 2], 0.f);
+            s_w0[tid] = w[(size_t)(gq * 2 + 0) * N + a];
+            s_w1[tid] = w[(size_t)(gq * 2 + 1) * N + a];
         }
         mk_block_sync();
-        const int cnt = (N - a0) < EXPL_THREADS ? (int)(N - a0) : EXPL_THREADS;
-        for (int i = 0; i < cnt; ++i) {
+        const long long left = N - a0 - (long long)wv * WAVE;             // this wave's atoms of the chunk
+        const int cnt = left < 0 ? 0 : (left < WAVE ? (int)left : WAVE);
+        for (int k = 0; k < cnt; ++k) {
+            const int i = wv * WAVE + k;
             const float4 p = s_pos[i];
             double dx = (double)p.x - cx, dy = (double)p.y - cy, dz = (double)p.z - cz;
             if (use_box) {                       // distance_utils.pyx:49-52, evaluated in double
@@ -2350,17 +2360,21 @@ MK_KERNEL(EXPL_THREADS) void k_occupancy_centers(const double* __restrict__ cent
             const bool in = d2 < 25.0;           // occupancy_utils.pyx:53
             const float d2f = (float)d2;
             const float4 w0 = s_w0[i], w1 = s_w1[i];
-            const float wv[CHG] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            const float wc[CHG] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int c = 0; c < CHG; ++c)
-                q[c] = mk_min_bits(q[c], in ? d2f * wv[c] : INF);     // 0*inf = NaN sorts above +inf
+                q[c] = mk_min_bits(q[c], in ? d2f * wc[c] : INF);     // 0*inf = NaN sorts above +inf
         }
         mk_block_sync();
     }
-    if (active) {
 #pragma unroll
-        for (int c = 0; c < CHG; ++c)
-            if (gq * CHG + c < C) out[(size_t)v * C + gq * CHG + c] = occupancy_from_q(mk_uint_as_float(q[c]));
+    for (int c = 0; c < CHG; ++c) mk_lds_min(&s_q[c][lane], q[c]);
+    mk_block_sync();
+    // epilogue: consecutive threads take consecutive channels of a centre (the output is centre-major)
+    for (int i = tid; i < CHG * EXPL_CENTERS; i += nth) {
+        const int c = i % CHG, l = i / CHG;
+        if (v0 + l < V && gq * CHG + c < C)
+            out[(size_t)(v0 + l) * C + gq * CHG + c] = occupancy_from_q(mk_uint_as_float(s_q[c][l]));
     }
 }
 

@@ -452,7 +452,11 @@ int run_centers(BE& be, const double* d_centers, long long V, const float* d_coo
                         : be.launch(k_sigma_to_w<float>, grid, blk, (const float*)d_sigmas, N, C, G, 1.0, (float4*)w);
         if (st) return st;
     }
-    const dim3 grid((unsigned)ceil_div(V, EXPL_THREADS), (unsigned)G), blk(EXPL_THREADS);
+    // 64 centres per workgroup; its waves split the atoms: as many (4, 8, 16) as it takes to put ~4 waves on every SIMD
+    const long long wgs = ceil_div(V, EXPL_CENTERS) * G;
+    int waves = 4;
+    while (waves < EXPL_MAX_WAVES && wgs * waves < 4096) waves *= 2;
+    const dim3 grid((unsigned)ceil_div(V, EXPL_CENTERS), (unsigned)G), blk((unsigned)(waves * WAVE));
     return be.launch(k_occupancy_centers, grid, blk, d_centers, V, d_coords, N, (const float4*)w, C,
                      box_host ? 1 : 0, box_host ? box_host[0] : 0.0, box_host ? box_host[1] : 0.0,
                      box_host ? box_host[2] : 0.0, d_out);

@@ -20,6 +20,7 @@ this package.
 from __future__ import annotations
 
 import logging
+import threading
 from functools import lru_cache
 
 import numpy as np
@@ -182,12 +183,37 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
     return features, centers, nvoxels
 
 
+_LATTICE_MEMO = []          # [(copy of the centres, verdict)], most recent first
+_LATTICE_MEMO_SIZE = 4
+_LATTICE_MEMO_LOCK = threading.Lock()
+
+
 def _lattice_from_centers(centers):
     """Recognise a getCenters-style lattice in an explicit (V,3) centre list.
 
     Returns (bb_min float64 (3,), nvoxels int (3,), voxelsize) when ``centers`` equals, to ~1e-9 A,
-    ``bb_min + index*voxelsize`` in x-slowest / z-fastest order; else None."""
+    ``bb_min + index*voxelsize`` in x-slowest / z-fastest order; else None.
+
+    Callers that pass ``usercenters`` pass the SAME centres call after call (computed once, the molecule rotated per
+    sample), so the last few verdicts are kept with a copy of the array they were made for: one exact comparison
+    (~10 us for a 24^3 grid) instead of the recognition's passes (~120 us)."""
     c = np.asarray(centers, dtype=np.float64)
+    if c.ndim != 2 or c.shape[1] != 3 or c.shape[0] < 2:
+        return None
+    with _LATTICE_MEMO_LOCK:
+        memo = list(_LATTICE_MEMO)
+    for known, verdict in memo:
+        if known.shape == c.shape and np.array_equal(known, c):
+            return None if verdict is None else (verdict[0].copy(), verdict[1].copy(), verdict[2])
+    verdict = _recognise_lattice(c)
+    if c.nbytes <= (32 << 20):
+        with _LATTICE_MEMO_LOCK:
+            _LATTICE_MEMO.insert(0, (c.copy(), verdict))
+            del _LATTICE_MEMO[_LATTICE_MEMO_SIZE:]
+    return None if verdict is None else (verdict[0].copy(), verdict[1].copy(), verdict[2])
+
+
+def _recognise_lattice(c):
     V = c.shape[0]
     if c.ndim != 2 or c.shape[1] != 3 or V < 2:
         return None

@@ -174,3 +174,21 @@ def test_cube_export_is_byte_identical_to_the_reference(tmp_path):
     data, meta = readCube(files[2])
     assert np.allclose(data, feats[:, 2].reshape(3, 2, 4), rtol=1e-4) and data.shape == (3, 2, 4)
     assert np.allclose(meta["org"], (np.array([1.0, 2.0, 3.0]) - 0.25 + 0.25) / 0.52917725, atol=1e-5)
+
+
+def test_lattice_verdicts_are_remembered_per_content_not_per_object():
+    """`usercenters` callers pass the same centres call after call; the recognition's verdict is kept with a copy of
+    the array, so an array CHANGED IN PLACE must be recognised afresh (and a non-lattice verdict is remembered too)."""
+    from moleculekit_amd.voxeldescriptors import _lattice_from_centers, getCenters
+    c, nv = getCenters(boxsize=[6, 5, 4], center=np.array([1.0, 2.0, 3.0]), voxelsize=0.5)
+    first = _lattice_from_centers(c)
+    again = _lattice_from_centers(c)
+    assert first is not None and np.array_equal(first[1], nv) and first[2] == 0.5
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1]) and first[2] == again[2]
+    again[0][:] = 99.0                                      # the caller may scribble on what it was handed
+    assert np.array_equal(_lattice_from_centers(c)[0], first[0])
+    c[7, 1] += 1e-3                                         # same object, different content
+    assert _lattice_from_centers(c) is None and _lattice_from_centers(c) is None
+    c[7, 1] -= 1e-3
+    assert _lattice_from_centers(c) is not None
+    assert _lattice_from_centers(c[:, :2]) is None and _lattice_from_centers(c[:1]) is None

@@ -59,3 +59,24 @@ for team in (0, -1):
         f, c, n = getVoxelDescriptors(None, **kw)
     print(f"drop-in getVoxelDescriptors(3PTB) team={team}: {(time.perf_counter() - t0) / 100 * 1e3:.4f} ms per call, max err {np.abs(f - g['features']).max():.2e}")
 ctx.set_tile_team(-1)
+
+
+def probe_usercenters():
+    """The drop-in call when the caller passes the centres (`usercenters`, the ML pipelines' usage: centres computed
+    once, coordinates rotated per sample): a lattice is recognised on the host, anything else goes to the pairwise kernel."""
+    from moleculekit_amd.voxeldescriptors import getCenters
+    coords, chans = g["coords"], g["sigmas"]
+    centers, nvox = getCenters(boxsize=[24, 24, 24], center=g["center"], voxelsize=1)
+    rng = np.random.default_rng(0)
+    jitter = centers + rng.normal(0, 1e-3, centers.shape)                     # not a lattice any more
+    for name, c in (("lattice usercenters", centers), ("arbitrary usercenters", jitter)):
+        for _ in range(20):
+            getVoxelDescriptors(None, usercenters=c, userchannels=chans, usercoords=coords)
+        t0 = time.perf_counter(); n = 200
+        for _ in range(n):
+            f, _c = getVoxelDescriptors(None, usercenters=c, userchannels=chans, usercoords=coords)
+        err = np.abs(f - g["features"]).max() if c is centers else float("nan")
+        print(f"drop-in getVoxelDescriptors(3PTB, {name}): {(time.perf_counter() - t0) / n * 1e3:.4f} ms per call, max err vs golden {err:.2e}")
+
+
+probe_usercenters()
