@@ -14,6 +14,8 @@
  * Layouts (C-contiguous, the reference's):  coords float32 [n_atoms, 3, n_frames] (Molecule.coords),
  * box float32 [3, n_frames] (Molecule.box), results float32 [n_frames, n_pairs].
  * Pair order: i over sel1, j over sel2 (from i+1 when selfdist) -- the reference's loop order.
+ * n_frames < 2^30 (MKAMD_EINVAL beyond: a frame's byte offset into a coordinate row is a 32-bit buffer offset in the
+ * kernels; the reference's own frame loops are C ints).
  * Host pointers in, host pointers out (copies + kernels + synchronise); status codes as mkamd_voxel.h.
  */
 #ifndef MKAMD_DISTANCE_H
