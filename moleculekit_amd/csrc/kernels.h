@@ -2336,6 +2336,7 @@ MK_KERNEL(EXPL_MAX_WAVES * WAVE) void k_occupancy_centers(const double* __restri
 #pragma unroll
     for (int c = 0; c < CHG; ++c) q[c] = 0x7f800000u;
     for (int i = tid; i < CHG * EXPL_CENTERS; i += nth) s_q[i / EXPL_CENTERS][i % EXPL_CENTERS] = 0x7f800000u;
+    mk_block_sync();
 
     for (long long a0 = 0; a0 < N; a0 += nth) {
         const long long a = a0 + tid;
