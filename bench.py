@@ -379,24 +379,34 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C))
 
     if want_gather:
-        # the trivial gather of the feature tensors, timed on its own: (a) one padded all-gather after the compute,
-        # (b) chunk-overlapped with the compute (what a consumer that needs everything everywhere would run)
-        fence()
-        g0 = time.perf_counter()
-        full = sv.gather(out)
-        fence()
-        res["gather_ms"] = (time.perf_counter() - g0) * 1e3
-        assert full.shape[0] == world * B
-        del full
-        fence()
-        g0 = time.perf_counter()
-        full = sv.voxelize_gather(nchunks=4)
-        fence()
-        both = (time.perf_counter() - g0) * 1e3
-        res["compute_plus_overlapped_gather_ms"] = both
-        res["gather_overlapped_extra_ms"] = both - elapsed / steps * 1e3
-        assert full.shape[0] == world * B and torch.equal(full[rank * B:(rank + 1) * B], out)
-        del full
+        # (a secondary measurement: a failure in it -- RCCL, memory for the world x B result -- is reported on the line,
+        #  it must not cost the primary one)
+        try:
+            # the trivial gather of the feature tensors, timed on its own: (a) one padded all-gather after the compute,
+            # (b) chunk-overlapped with the compute (what a consumer that needs everything everywhere would run)
+            fence()
+            g0 = time.perf_counter()
+            full = sv.gather(out)
+            fence()
+            res["gather_ms"] = (time.perf_counter() - g0) * 1e3
+            assert full.shape[0] == world * B
+            del full
+            fence()
+            g0 = time.perf_counter()
+            full = sv.voxelize_gather(nchunks=4)
+            fence()
+            both = (time.perf_counter() - g0) * 1e3
+            res["compute_plus_overlapped_gather_ms"] = both
+            res["gather_overlapped_extra_ms"] = both - elapsed / steps * 1e3
+            assert full.shape[0] == world * B and torch.equal(full[rank * B:(rank + 1) * B], out)
+            del full
+        except Exception as e:                                   # noqa: BLE001 -- reported, not swallowed
+            res["gather_error"] = f"{type(e).__name__}: {e}"[:300]
+            res.pop("gather_ms", None); res.pop("gather_overlapped_extra_ms", None)
+            try:
+                fence()
+            except Exception:                                    # noqa: BLE001
+                pass
 
     if want_single:
         # latency of ONE grid (a single 64^3 grid cannot fill 256 CUs for long)
@@ -548,6 +558,7 @@ def main():
             "single_grid_latency_us": round(res["single_us"], 2) if "single_us" in res else None,
             "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
             "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
+            **({"gather_error": res["gather_error"]} if "gather_error" in res else {}),
         }
         if extra:
             line["other_workloads" if world == 1 else "batched_molecules"] = extra
