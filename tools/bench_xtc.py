@@ -18,7 +18,7 @@ with tempfile.TemporaryDirectory() as d:
             f.write(src)
     N, F = xtc.get_xtc_natoms(fn), xtc.get_xtc_nframes(fn)
     out = {"atoms": N, "frames": F, "file_MB": round(len(src) * reps / 1e6, 1)}
-    for nt in (1, 16):
+    for nt in (1, 16, 0):                # 0 = the library's default (up to 64 host threads)
         xtc.read_xtc(fn, nthreads=nt)
         t0 = time.perf_counter(); xtc.read_xtc(fn, nthreads=nt); dt = time.perf_counter() - t0
         out[f"decode_frames_per_s_{nt}thr"] = round(F / dt, 1)
