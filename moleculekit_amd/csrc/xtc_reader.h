@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,6 +52,7 @@ struct Mapped {
     const uint8_t* p = nullptr;
     size_t n = 0;
     int fd = -1;
+    long long ident[7] = {0, 0, 0, 0, 0, 0, 0};   // device, inode, size, mtime and ctime (s, ns): what the frame index is remembered by
     ~Mapped()
     {
         if (p) munmap(const_cast<uint8_t*>(p), n);
@@ -62,6 +65,9 @@ struct Mapped {
         struct stat st;
         if (fstat(fd, &st) != 0) return false;
         n = (size_t)st.st_size;
+        ident[0] = (long long)st.st_dev; ident[1] = (long long)st.st_ino; ident[2] = (long long)st.st_size;
+        ident[3] = (long long)st.st_mtim.tv_sec; ident[4] = (long long)st.st_mtim.tv_nsec;
+        ident[5] = (long long)st.st_ctim.tv_sec; ident[6] = (long long)st.st_ctim.tv_nsec;
         if (n == 0) return true;
         void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
         if (m == MAP_FAILED) { p = nullptr; return false; }
@@ -104,6 +110,30 @@ inline int index_frames(const Mapped& m, std::vector<size_t>& offs, int64_t& nat
         offs.push_back(p);
         p = q;
     }
+    return OK;
+}
+
+// The frame index of the file last read, kept for the next call on the same file (same device, inode, size,
+// modification and status-change time): a streaming reader asks for a few hundred frames per call, and walking the record headers of the
+// WHOLE file each time -- a page of the mapping per frame -- made a long trajectory quadratic (10 000 frames: as long
+// as decoding the chunk itself).
+struct FrameIndex { long long ident[7]; std::vector<size_t> offs; int64_t natoms; };
+
+inline int index_frames_cached(const Mapped& m, std::shared_ptr<const FrameIndex>& out)
+{
+    static std::mutex mu;
+    static std::shared_ptr<const FrameIndex> last;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (last && std::memcmp(last->ident, m.ident, sizeof m.ident) == 0) { out = last; return OK; }
+    }
+    auto idx = std::make_shared<FrameIndex>();
+    std::memcpy(idx->ident, m.ident, sizeof m.ident);
+    const int st = index_frames(m, idx->offs, idx->natoms);
+    if (st != OK) return st;
+    out = idx;
+    std::lock_guard<std::mutex> lk(mu);
+    last = idx;
     return OK;
 }
 
@@ -262,10 +292,11 @@ inline int info(const char* path, int64_t& natoms, int64_t& nframes, std::string
 {
     Mapped m;
     if (!m.open_file(path)) { err = std::string("cannot open ") + path; return E_OPEN; }
-    std::vector<size_t> offs;
-    const int st = index_frames(m, offs, natoms);
+    std::shared_ptr<const FrameIndex> idx;
+    const int st = index_frames_cached(m, idx);
     if (st != OK) { err = "not an XTC file (bad magic number)"; return st; }
-    nframes = (int64_t)offs.size();
+    natoms = idx->natoms;
+    nframes = (int64_t)idx->offs.size();
     return OK;
 }
 
@@ -301,10 +332,11 @@ inline int read(const char* path, const int64_t* sel, int64_t nsel, int64_t nato
 {
     Mapped m;
     if (!m.open_file(path)) { err = std::string("cannot open ") + path; return E_OPEN; }
-    std::vector<size_t> offs;
-    int64_t natoms = 0;
-    int st = index_frames(m, offs, natoms);
+    std::shared_ptr<const FrameIndex> idx;
+    int st = index_frames_cached(m, idx);
     if (st != OK) { err = "not an XTC file (bad magic number)"; return st; }
+    const std::vector<size_t>& offs = idx->offs;
+    const int64_t natoms = idx->natoms;
     if (natoms != natoms_expected) { err = "atom count of the file differs from the buffers'"; return E_RANGE; }
     for (int64_t j = 0; j < nsel; ++j) {
         const int64_t f = sel ? sel[j] : j;

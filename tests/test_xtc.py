@@ -81,3 +81,19 @@ def test_truncated_and_bad_files(tmp_path):
         assert c.shape[0] == 688
     except ValueError:
         pass
+
+
+def test_frame_index_is_remembered_per_file_state_not_per_path(tmp_path):
+    """The reader keeps the frame index of the file it read last (a streaming caller asks chunk after chunk); a file
+    REPLACED under the same path -- other frame count, other atom count -- must be indexed afresh."""
+    import shutil
+    a, b = _fn("aladipep"), _fn("3ptb_traj_head")
+    p = str(tmp_path / "t.xtc")
+    shutil.copyfile(a, p)
+    ca1 = xtc.read_xtc(p)[0]
+    ca2 = xtc.read_xtc_frames(p, [0])[0]                     # second call on the same file: the remembered index
+    assert np.array_equal(ca1[:, :, :1], ca2)
+    shutil.copyfile(b, p)
+    cb = xtc.read_xtc(p)[0]
+    assert np.array_equal(cb, xtc.read_xtc(b)[0]) and np.array_equal(ca1, xtc.read_xtc(a)[0])
+    assert (xtc.get_xtc_natoms(p), xtc.get_xtc_nframes(p)) == (xtc.get_xtc_natoms(b), xtc.get_xtc_nframes(b))
