@@ -26,11 +26,14 @@ with tempfile.TemporaryDirectory() as d:
     sig = np.where(np.random.default_rng(0).random((N, 8)) < 0.4, 1.7, 0.0).astype(np.float32)
     c0 = xtc.XTCread(fn, frame=0).coords[:, :, 0].mean(0)
     acc = torch.zeros(8, device="cuda", dtype=torch.float64)
-    def run():
-        for _, feats in batch.iterVoxelizeXTC(fn, sig, c0, [24, 24, 24], 1.0, pbc=False, chunk=256):
+    def run(chunk):
+        for _, feats in batch.iterVoxelizeXTC(fn, sig, c0, [24, 24, 24], 1.0, pbc=False, chunk=chunk):
             acc.add_(feats.sum(dim=(0, 1), dtype=torch.float64))
         torch.cuda.synchronize()
-    run()
-    t0 = time.perf_counter(); run(); dt = time.perf_counter() - t0
-    out["xtc_to_voxels_frames_per_s"] = round(F / dt, 1)
+    # (a chunk is decoded in blocks of 16 frames, one block per host thread at a time: 256 frames keep 16 threads busy,
+    #  1024 frames 64)
+    for chunk in (256, 1024):
+        run(chunk)
+        t0 = time.perf_counter(); run(chunk); dt = time.perf_counter() - t0
+        out["xtc_to_voxels_frames_per_s" + ("" if chunk == 256 else f"_chunk{chunk}")] = round(F / dt, 1)
 print(json.dumps(out))
