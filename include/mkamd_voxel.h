@@ -175,6 +175,12 @@ int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t*
 int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels,
                            double voxelsize, double* d_centers);
 
+/* (5) the inverse, on the host (no context, no GPU): is `centers` float64 [V,3] a getCenters lattice -- bb_min +
+ * fl64(index * voxelsize), x slowest / z fastest (voxeldescriptors.py:125-132, :245-247) -- to 1e-9 A?  Returns 1 and
+ * fills bb_min[3], nvoxels[3], voxelsize, else 0 (also for NaNs and fewer than two centres).  What the drop-in
+ * `_getOccupancyC` asks of the `usercenters` it is handed, before it chooses between (2) and (3). */
+int mkamd_lattice_from_centers(const double* centers, int64_t n_centers, double* bb_min, int32_t* nvoxels, double* voxelsize);
+
 #ifdef __cplusplus
 }
 #endif

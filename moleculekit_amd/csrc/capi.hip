@@ -783,6 +783,54 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+// The lattice test of moleculekit_amd/voxeldescriptors.py::_recognise_lattice_numpy in two passes over the array instead
+// of a dozen numpy temporaries: axis lengths from the first place z (then y, at stride nz) stops increasing, one common
+// positive step, then every centre against fl64(index * step) + centre 0 with the tolerance 1e-9 * max(1, max |c|).
+extern "C" int mkamd_lattice_from_centers(const double* c, int64_t V, double* bb_min, int32_t* nvoxels, double* voxelsize)
+try {
+    if (!c || !bb_min || !nvoxels || !voxelsize || V < 2) return 0;
+    int64_t nz = V;
+    for (int64_t i = 1; i < V; ++i) if (c[3 * i + 2] <= c[3 * (i - 1) + 2]) { nz = i; break; }
+    if (V % nz) return 0;
+    const int64_t rows = V / nz;
+    int64_t ny = rows;
+    for (int64_t i = 1; i < rows; ++i) if (c[3 * (i * nz) + 1] <= c[3 * ((i - 1) * nz) + 1]) { ny = i; break; }
+    if (rows % ny) return 0;
+    const int64_t nx = rows / ny;
+    if (nx > 0x7fffffff || ny > 0x7fffffff || nz > 0x7fffffff) return 0;
+    double steps[3]; int ns = 0;
+    if (nz > 1) steps[ns++] = c[3 * 1 + 2] - c[2];
+    if (ny > 1) steps[ns++] = c[3 * nz + 1] - c[1];
+    if (nx > 1) steps[ns++] = c[3 * (nz * ny) + 0] - c[0];
+    if (ns == 0) return 0;
+    for (int i = 0; i < ns; ++i) if (!(steps[i] > 0.0)) return 0;
+    const double vs = steps[0];
+    const double stol = 1e-9 * std::max(1.0, std::fabs(vs));
+    for (int i = 0; i < ns; ++i) if (std::fabs(steps[i] - vs) > stol) return 0;
+    double maxabs = 0.0;
+    for (int64_t i = 0; i < 3 * V; ++i) {
+        const double a = std::fabs(c[i]);
+        if (!(a <= maxabs)) { if (a != a) return 0; maxabs = a; }           // a NaN centre is no lattice
+    }
+    const double tol = 1e-9 * std::max(1.0, maxabs);
+    const double o[3] = {c[0], c[1], c[2]};
+    const double* q = c;
+    for (int64_t ix = 0; ix < nx; ++ix) {
+        const double ex = (double)ix * vs + o[0];
+        for (int64_t iy = 0; iy < ny; ++iy) {
+            const double ey = (double)iy * vs + o[1];
+            for (int64_t iz = 0; iz < nz; ++iz, q += 3) {
+                const double ez = (double)iz * vs + o[2];
+                if (std::fabs(ex - q[0]) > tol || std::fabs(ey - q[1]) > tol || std::fabs(ez - q[2]) > tol) return 0;
+            }
+        }
+    }
+    bb_min[0] = o[0]; bb_min[1] = o[1]; bb_min[2] = o[2];
+    nvoxels[0] = (int32_t)nx; nvoxels[1] = (int32_t)ny; nvoxels[2] = (int32_t)nz;
+    *voxelsize = vs;
+    return 1;
+} catch (...) { return 0; }
+
 // ---------------------------------------------------------------------------------------------
 // distance_utils row (include/mkamd_distance.h)
 // ---------------------------------------------------------------------------------------------

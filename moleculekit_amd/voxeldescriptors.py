@@ -19,8 +19,8 @@ this package.
 """
 from __future__ import annotations
 
+import ctypes
 import logging
-import threading
 from functools import lru_cache
 
 import numpy as np
@@ -183,37 +183,34 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
     return features, centers, nvoxels
 
 
-_LATTICE_MEMO = []          # [(copy of the centres, verdict)], most recent first
-_LATTICE_MEMO_SIZE = 4
-_LATTICE_MEMO_LOCK = threading.Lock()
-
-
 def _lattice_from_centers(centers):
     """Recognise a getCenters-style lattice in an explicit (V,3) centre list.
 
     Returns (bb_min float64 (3,), nvoxels int (3,), voxelsize) when ``centers`` equals, to ~1e-9 A,
-    ``bb_min + index*voxelsize`` in x-slowest / z-fastest order; else None.
-
-    Callers that pass ``usercenters`` pass the SAME centres call after call (computed once, the molecule rotated per
-    sample), so the last few verdicts are kept with a copy of the array they were made for: one exact comparison
-    (~10 us for a 24^3 grid) instead of the recognition's passes (~120 us)."""
+    ``bb_min + index*voxelsize`` in x-slowest / z-fastest order; else None.  Asked on every call that brings its own
+    centres (``usercenters``, and every call through ``install()``: the reference computes the centres and hands over a
+    copy), so it is done in the library: ~10 us for a 24^3 grid.  (A memo of the last verdicts, keyed by an exact
+    comparison with a kept copy, was tried first: the comparison alone costs as much as the native recognition.)"""
     c = np.asarray(centers, dtype=np.float64)
     if c.ndim != 2 or c.shape[1] != 3 or c.shape[0] < 2:
         return None
-    with _LATTICE_MEMO_LOCK:
-        memo = list(_LATTICE_MEMO)
-    for known, verdict in memo:
-        if known.shape == c.shape and np.array_equal(known, c):
-            return None if verdict is None else (verdict[0].copy(), verdict[1].copy(), verdict[2])
-    verdict = _recognise_lattice(c)
-    if c.nbytes <= (32 << 20):
-        with _LATTICE_MEMO_LOCK:
-            _LATTICE_MEMO.insert(0, (c.copy(), verdict))
-            del _LATTICE_MEMO[_LATTICE_MEMO_SIZE:]
-    return None if verdict is None else (verdict[0].copy(), verdict[1].copy(), verdict[2])
+    return _recognise_lattice(c)
 
 
 def _recognise_lattice(c):
+    """The recognition itself, in the library (two passes over the array, ~10 us for a 24^3 grid; the numpy form below --
+    kept as the specification the tests compare it with -- takes a dozen temporaries and ~120 us)."""
+    from . import _lib
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    bb_min = np.zeros(3, dtype=np.float64)
+    nvox = np.zeros(3, dtype=np.int32)
+    vs = ctypes.c_double(0.0)
+    if not _lib.load().mkamd_lattice_from_centers(_lib._ptr(c), int(c.shape[0]), _lib._ptr(bb_min), _lib._ptr(nvox), ctypes.byref(vs)):
+        return None
+    return bb_min, nvox.astype(np.int64), float(vs.value)
+
+
+def _recognise_lattice_numpy(c):
     V = c.shape[0]
     if c.ndim != 2 or c.shape[1] != 3 or V < 2:
         return None

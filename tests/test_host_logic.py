@@ -176,19 +176,44 @@ def test_cube_export_is_byte_identical_to_the_reference(tmp_path):
     assert np.allclose(meta["org"], (np.array([1.0, 2.0, 3.0]) - 0.25 + 0.25) / 0.52917725, atol=1e-5)
 
 
-def test_lattice_verdicts_are_remembered_per_content_not_per_object():
-    """`usercenters` callers pass the same centres call after call; the recognition's verdict is kept with a copy of
-    the array, so an array CHANGED IN PLACE must be recognised afresh (and a non-lattice verdict is remembered too)."""
+def test_lattice_recognition_follows_the_content_of_the_array():
+    """`usercenters` callers pass the same array object call after call; what counts is what is IN it."""
     from moleculekit_amd.voxeldescriptors import _lattice_from_centers, getCenters
     c, nv = getCenters(boxsize=[6, 5, 4], center=np.array([1.0, 2.0, 3.0]), voxelsize=0.5)
     first = _lattice_from_centers(c)
-    again = _lattice_from_centers(c)
     assert first is not None and np.array_equal(first[1], nv) and first[2] == 0.5
-    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1]) and first[2] == again[2]
-    again[0][:] = 99.0                                      # the caller may scribble on what it was handed
-    assert np.array_equal(_lattice_from_centers(c)[0], first[0])
+    first[0][:] = 99.0                                      # the caller may scribble on what it was handed
+    assert np.array_equal(_lattice_from_centers(c)[0], c[0])
     c[7, 1] += 1e-3                                         # same object, different content
-    assert _lattice_from_centers(c) is None and _lattice_from_centers(c) is None
+    assert _lattice_from_centers(c) is None
     c[7, 1] -= 1e-3
     assert _lattice_from_centers(c) is not None
     assert _lattice_from_centers(c[:, :2]) is None and _lattice_from_centers(c[:1]) is None
+
+
+def test_native_lattice_recognition_agrees_with_its_numpy_specification():
+    """mkamd_lattice_from_centers (what the drop-in asks of `usercenters`) against the numpy form it replaces: lattices
+    of every shape class (one row, one plane, anisotropic counts, fractional voxel sizes, far origins), and non-lattices
+    (a nudged centre, reversed order, a missing centre, noise at the tolerance, a NaN)."""
+    from moleculekit_amd import voxeldescriptors as vd
+    rng = np.random.default_rng(1)
+    lattices = [vd.getCenters(boxsize=bs, center=np.array(ctr, float), voxelsize=vs)[0]
+                for bs, vs, ctr in (([24, 24, 24], 1.0, [0, 0, 0]), ([6, 5, 4], 0.5, [1, 2, 3]), ([10, 1, 1], 1.0, [5, 5, 5]),
+                                    ([1, 1, 7], 0.25, [0, 0, 0]), ([3, 4, 1], 1.0, [100, -50, 3]), ([2, 2, 2], 3.0, [1e4, 1e4, -1e4]))]
+    others = []
+    for c in lattices:
+        j = c.copy(); j[len(j) // 2, 1] += 1e-6
+        n = c.copy(); n[0, 0] = np.nan
+        others += [j, c[::-1].copy(), c[:-1].copy(), c + rng.normal(0, 1e-12, c.shape), c + rng.normal(0, 3e-9, c.shape), n]
+    n_lat = 0
+    for c in lattices + others:
+        a = vd._recognise_lattice(c)
+        b = vd._recognise_lattice_numpy(np.asarray(c, dtype=np.float64))
+        if np.isnan(c).any():
+            assert a is None                                  # (the numpy form lets a NaN through its max(): not a lattice here)
+            continue
+        assert (a is None) == (b is None)
+        if a is not None:
+            n_lat += 1
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], np.asarray(b[1])) and a[2] == b[2]
+    assert n_lat >= len(lattices)

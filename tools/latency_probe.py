@@ -69,12 +69,14 @@ def probe_usercenters():
     centers, nvox = getCenters(boxsize=[24, 24, 24], center=g["center"], voxelsize=1)
     rng = np.random.default_rng(0)
     jitter = centers + rng.normal(0, 1e-3, centers.shape)                     # not a lattice any more
-    for name, c in (("lattice usercenters", centers), ("arbitrary usercenters", jitter)):
-        for _ in range(20):
-            getVoxelDescriptors(None, usercenters=c, userchannels=chans, usercoords=coords)
+    shifted = [centers + np.array([0.01 * k, 0.0, 0.0]) for k in range(8)]   # a different lattice every call (translation augmentation)
+    for name, c in (("lattice usercenters", centers), ("lattice usercenters, shifted every call", shifted), ("arbitrary usercenters", jitter)):
+        pick = (lambda k: c[k % len(c)]) if isinstance(c, list) else (lambda k: c)
+        for k in range(20):
+            getVoxelDescriptors(None, usercenters=pick(k), userchannels=chans, usercoords=coords)
         t0 = time.perf_counter(); n = 200
-        for _ in range(n):
-            f, _c = getVoxelDescriptors(None, usercenters=c, userchannels=chans, usercoords=coords)
+        for k in range(n):
+            f, _c = getVoxelDescriptors(None, usercenters=pick(k), userchannels=chans, usercoords=coords)
         err = np.abs(f - g["features"]).max() if c is centers else float("nan")
         print(f"drop-in getVoxelDescriptors(3PTB, {name}): {(time.perf_counter() - t0) / n * 1e3:.4f} ms per call, max err vs golden {err:.2e}")
 
