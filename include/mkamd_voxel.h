@@ -85,7 +85,8 @@ int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode);
 int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on);
 /* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team of four that shares the tile's
  * candidate traversal and splits its entries (latency: one grid per call, the reference's own usage), -1 (default) =
- * a team when the whole launch has fewer tiles than the chip has SIMDs.  Results are bit-identical either way. */
+ * a team when the whole launch has fewer tiles than the chip has SIMDs (ligand-sized items take the workgroup-per-item
+ * kernel below instead, whatever the batch size).  Results are bit-identical either way. */
 int mkamd_ctx_set_tile_team(mkamd_ctx* ctx, int mode);
 /* A workgroup per ITEM instead of a wave per tile: 1 = always (when no team is used), 0 = never, -1 (default) = for
  * ligand-sized items (<= 96 atoms on average) on the per-item pre-pass, any batch size: the item's entries are sorted
