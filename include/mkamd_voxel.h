@@ -110,7 +110,9 @@ int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* laun
  *     results[v,c] = max(results[v,c], max_a{ 1-exp(-(sigmas[a,c]/|coords[a]-centers[v]|)^12) :
  *                                               |.|^2 < 25, sigmas[a,c] != 0 })
  * max-accumulating IN PLACE into the caller's float64 results (caller zero-fills, voxeldescriptors.py:531).
- * Distances are evaluated in double on the GPU; values are float32-accurate (<= 1e-6 abs). */
+ * Centres that form a getCenters lattice (what the reference's only caller passes, voxeldescriptors.py:356) are
+ * recognised and take the tiled lattice kernels of (2), values within 1e-5; any other centre list takes the pairwise
+ * kernel of (3): distances in double, values float32-accurate (<= 1e-6 abs). */
 int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t n_centers,
                               const float* coords, int64_t n_atoms, const double* sigmas,
                               int32_t n_channels, double* results);
