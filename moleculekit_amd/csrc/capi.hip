@@ -538,21 +538,25 @@ try {
     if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
     if (V == 0 || N == 0) return ctx ? MKAMD_OK : fail(MKAMD_EINVAL, "ctx is NULL");
     if (!results) return fail(MKAMD_EINVAL, "results pointer is NULL");
-    std::vector<float> tmp((size_t)V * C);
+    int st0 = check_ctx(ctx);
+    if (st0) return st0;
+    std::vector<float>& tmp = ctx->f32_stage;               // context-owned: no fresh pages to fault in on every call
+    tmp.resize((size_t)V * C);
     // The reference's only caller hands this function a getCenters LATTICE (voxeldescriptors.py:356 via _getOccupancyC):
     // recognised (two passes over the centres, host) it takes the tiled lattice kernels -- microseconds where the
     // pairwise kernel below tests N x V pairs in double; anything the lattice path refuses falls through to it.
     int st = MKAMD_EINVAL;
     double bb_min[3], vs = 0.0;
     int32_t nv[3];
-    if (check_ctx(ctx) == MKAMD_OK && mkamd_lattice_from_centers(centers, V, bb_min, nv, &vs)) {
+    if (mkamd_lattice_from_centers(centers, V, bb_min, nv, &vs)) {
         const int64_t offs[2] = {0, N};
         st = mkamd_voxelize_lattice_host(ctx, 1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, tmp.data());
     }
     if (st) st = mkamd_occupancy_centers_host(ctx, centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data());
     if (st) return st;
     // in-place max-accumulate, `value > old ? value : old` as occupancy_utils.pyx:61
-    for (size_t i = 0; i < tmp.size(); ++i) {
+    const size_t nvals = (size_t)V * C;
+    for (size_t i = 0; i < nvals; ++i) {
         const double v = (double)tmp[i];
         if (v > results[i]) results[i] = v;
     }
