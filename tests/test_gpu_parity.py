@@ -122,6 +122,34 @@ def test_calculate_occupancy_dropin_in_place_max(hip_ctx):
     assert np.abs(acc - ref).max() <= TOL
 
 
+def test_calculate_occupancy_recognises_the_lattice_its_caller_passes(hip_ctx):
+    """The literal C-level call (what the stub of INTEGRATION.md binds): a getCenters lattice -- the reference's only
+    usage, voxeldescriptors.py:356 -- must reach the tile kernels (seen through the context's tile-kernel launch
+    counter), the same centres jittered must not, and both must agree with the oracle."""
+    from moleculekit_amd.occupancy_utils import calculate_occupancy
+    from moleculekit_amd.voxeldescriptors import getCenters
+    g = golden("cfg1_3ptb.npz")
+    coords = np.ascontiguousarray(g["coords"], np.float32); sig = np.ascontiguousarray(g["sigmas"], np.float64)
+    centers, _ = getCenters(boxsize=[24, 24, 24], center=np.asarray(g["center"]), voxelsize=1)
+    jitter = centers + np.random.default_rng(0).normal(0, 1e-3, centers.shape)
+    hip_ctx.enable_kernel_timing(True)
+    try:
+        hip_ctx.read_kernel_timing()
+        res = np.zeros((centers.shape[0], sig.shape[1]))
+        calculate_occupancy(centers, coords, sig, res, ctx=hip_ctx)
+        assert hip_ctx.read_kernel_timing()[1] >= 1                      # tile-kernel launches
+        assert np.abs(res - g["features"]).max() <= TOL
+        arb = np.zeros_like(res)
+        calculate_occupancy(jitter, coords, sig, arb, ctx=hip_ctx)
+        assert hip_ctx.read_kernel_timing()[1] == 0
+    finally:
+        hip_ctx.enable_kernel_timing(False)
+    sub = np.random.default_rng(1).choice(centers.shape[0], 1500, replace=False)
+    want = np.zeros((len(sub), sig.shape[1]))
+    oracle.calculate_occupancy(np.ascontiguousarray(jitter[sub]), coords, sig, want)
+    assert np.abs(arb[sub] - want).max() <= TOL
+
+
 def test_grid_centers_bit_exact(hip_ctx):
     from moleculekit_amd import batch
     g = golden("getcenters_cases.npz")
