@@ -168,6 +168,20 @@ def cpu_baseline(name):
     return out
 
 
+def dist_traffic(F):
+    """HBM bytes per launch of k_dist_pairs from the committed PMC passes (profiles/r*_dist_pmc_counters.json, taken at
+    the default frame count): WRITE_SIZE + 2 x FETCH_SIZE KiB, as pmc_traffic."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dist_pmc_counters.json")))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    v = next((v for k, v in d.items() if isinstance(v, dict) and "k_dist_pairs" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v), None)
+    if v is None or d.get("_items_per_launch") != F:
+        return None
+    return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024)
+
+
 def bench_distances(args, emit=True):
     """Secondary workload (`--workload dist`): `dist_trajectory` on an HBM-resident
     trajectory, 30 000 atoms x F frames (reference layout [N,3,F]), 200 x 500 atom pairs, periodic by chain.
@@ -212,7 +226,7 @@ def bench_distances(args, emit=True):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"},
             "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_dist_pairs",
+                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F), "kernel": "k_dist_pairs",
                          "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg}}
     if not args.no_cpu_baseline:
         from oracle import oracle
