@@ -37,7 +37,18 @@ def _csr(groups):
 def _store(results, tmp):
     if results.shape != tmp.shape:
         raise ValueError(f"results must have shape {tmp.shape}, got {results.shape}")
-    results[...] = tmp
+    if tmp is not results:
+        results[...] = tmp
+
+
+def _target(results, shape):
+    """Where the library writes: the caller's array itself when it is a C-contiguous float32 array of the right shape
+    (no second pass over hundreds of megabytes), else a temporary that _store copies from."""
+    if results.shape != shape:
+        raise ValueError(f"results must have shape {shape}, got {results.shape}")
+    if results.dtype == np.float32 and results.flags["C_CONTIGUOUS"] and results.flags["WRITEABLE"]:
+        return results
+    return np.empty(shape, dtype=np.float32)
 
 
 def dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, results, ctx=None):
@@ -51,7 +62,7 @@ def dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, re
     ctx = ctx or _lib.default_context()
     F = coords.shape[2]
     npairs = int(_lib.load().mkamd_dist_count_pairs(len(sel1), len(sel2), int(bool(selfdist))))
-    tmp = np.zeros((F, npairs), dtype=np.float32)
+    tmp = _target(results, (F, npairs))
     ctx.dist_trajectory_host(coords, box, sel1, sel2, chains, bool(selfdist), bool(pbc), False, tmp)
     _store(results, tmp)
 
@@ -93,7 +104,7 @@ def _reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pairs, pbc, ma
     ctx = ctx or _lib.default_context()
     F = coords.shape[2]
     nout = len(groups1) if pairs else int(_lib.load().mkamd_dist_count_pairs(len(groups1), len(groups2), int(bool(selfdist))))
-    tmp = np.zeros((F, nout), dtype=np.float32)
+    tmp = _target(results, (F, nout))
     ctx.dist_reduction_host(coords, box, a1, o1, a2, o2, ch1, ch2, bool(selfdist), bool(pairs), bool(pbc), masses,
                             int(r1), int(r2), tmp)
     _store(results, tmp)
@@ -120,7 +131,7 @@ def cdist(coords1, coords2, results, ctx=None):
     _req("results", results, np.float32, 2)
     if c1.shape[1] != c2.shape[1]:
         raise ValueError("Second dimension of input arguments must match")
-    tmp = np.zeros((c1.shape[0], c2.shape[0]), dtype=np.float32)
+    tmp = _target(results, (c1.shape[0], c2.shape[0]))
     (ctx or _lib.default_context()).cdist_host(c1, c2, tmp)
     _store(results, tmp)
 
@@ -130,7 +141,7 @@ def pdist(coords, results, ctx=None):
     c = _req("coords", coords, np.float32, 2)
     _req("results", results, np.float32, 1)
     n = c.shape[0]
-    tmp = np.zeros(n * (n - 1) // 2, dtype=np.float32)
+    tmp = _target(results, (n * (n - 1) // 2,))
     (ctx or _lib.default_context()).pdist_host(c, tmp)
     _store(results, tmp)
 
