@@ -97,3 +97,22 @@ def test_frame_index_is_remembered_per_file_state_not_per_path(tmp_path):
     cb = xtc.read_xtc(p)[0]
     assert np.array_equal(cb, xtc.read_xtc(b)[0]) and np.array_equal(ca1, xtc.read_xtc(a)[0])
     assert (xtc.get_xtc_natoms(p), xtc.get_xtc_nframes(p)) == (xtc.get_xtc_natoms(b), xtc.get_xtc_nframes(b))
+
+
+def test_threaded_decode_into_a_fresh_big_array_equals_the_serial_one(tmp_path):
+    """Results of 8 MB and more are pre-touched by the decode threads (contiguous slices, zeros) before the frames are
+    written: a file long enough to take that path -- the 3PTB fixture's frames repeated, XTC frames are self-contained
+    records -- decoded by 1, 4 and the default number of threads, and an index list in shuffled order."""
+    src = open(_fn("3ptb_traj_head"), "rb").read()
+    p = str(tmp_path / "long.xtc")
+    with open(p, "wb") as f:
+        for _ in range(40):
+            f.write(src)
+    serial = xtc.read_xtc(p, nthreads=1)
+    assert serial[0].nbytes >= (8 << 20)
+    for nt in (4, 0):
+        got = xtc.read_xtc(p, nthreads=nt)
+        assert all(np.array_equal(a, b) for a, b in zip(got, serial))
+    order = np.random.default_rng(0).permutation(serial[0].shape[2])
+    picked = xtc.read_xtc_frames(p, order, nthreads=4)
+    assert np.array_equal(picked[0], serial[0][:, :, order]) and np.array_equal(picked[3], serial[3][order])
