@@ -178,6 +178,14 @@ int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t*
 int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels,
                            double voxelsize, double* d_centers);
 
+/* Host helper: touch `bytes` of a buffer the caller is about to have filled (zeros, one byte per page, by host threads in
+ * contiguous slices, after a transparent-huge-page hint) -- what the _host entry points do themselves for results of
+ * 32 MB and more; for callers that fill a fresh array chunk by chunk through the _dev entry points.  No-op below 8 MB. */
+int mkamd_prefault(void* buffer, uint64_t bytes);
+/* Synchronous device -> host copy on the context's stream (hipMemcpyAsync + wait): what the _host entry points use for
+ * their results, for callers of the _dev entry points that collect chunks into a host array. */
+int mkamd_copy_to_host(mkamd_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes);
+
 /* (5) the inverse, on the host (no context, no GPU): is `centers` float64 [V,3] a getCenters lattice -- bb_min +
  * fl64(index * voxelsize), x slowest / z fastest (voxeldescriptors.py:125-132, :245-247) -- to 1e-9 A?  Returns 1 and
  * fills bb_min[3], nvoxels[3], voxelsize, else 0 (also for NaNs and fewer than two centres).  What the drop-in

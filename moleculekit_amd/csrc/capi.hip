@@ -810,6 +810,25 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+extern "C" int mkamd_copy_to_host(mkamd_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (bytes == 0) return MKAMD_OK;
+    if (!host_dst || !device_src) return fail(MKAMD_EINVAL, "NULL pointer");
+    HIP_TRY(hipMemcpyAsync(host_dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+} MK_API_CATCH
+
+extern "C" int mkamd_prefault(void* buffer, uint64_t bytes)
+try {
+    if (!buffer) return MKAMD_OK;
+    const int nt = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+    mkamd::xtc::prefault_output(static_cast<float*>(buffer), (size_t)bytes / sizeof(float), nt);
+    return MKAMD_OK;
+} catch (...) { return MKAMD_OK; }
+
 // The lattice test of moleculekit_amd/voxeldescriptors.py::_recognise_lattice_numpy in two passes over the array instead
 // of a dozen numpy temporaries: axis lengths from the first place z (then y, at stride nz) stops increasing, one common
 // positive step, then every centre against fl64(index * step) + centre 0 with the tolerance 1e-9 * max(1, max |c|).

@@ -176,7 +176,9 @@ def test_streamed_trajectory_matches_the_all_at_once_call():
     sig = np.where(rng.random((N, 8)) < 0.4, rng.choice([1.2, 1.7, 1.55], size=(N, 1)), 0.0)
     box = np.full((3, F), L, np.float32)
     for bx, frames in ((None, None), (box, None), (box, np.array([3, 4, 5, 20, 7, 36]))):
-        want, origin, nv = batch.voxelizeTrajectory(xyz, sig, [L / 2] * 3, [16, 16, 16], 1.0, box=bx, frames=frames)
+        want, origin, nv = batch._voxelizeTrajectory_packed(xyz, sig, [L / 2] * 3, [16, 16, 16], 1.0, box=bx, frames=frames)
+        pub, origin2, nv2 = batch.voxelizeTrajectory(xyz, sig, [L / 2] * 3, [16, 16, 16], 1.0, box=bx, frames=frames)   # (streamed inside)
+        assert np.array_equal(pub, want) and np.array_equal(origin2, origin) and np.array_equal(nv2, nv) and pub.flags["C_CONTIGUOUS"]
         for chunk in (5, 16, 64):
             seen, outs = [], []
             for idx, feats in batch.iterVoxelizeTrajectory(xyz, sig, [L / 2] * 3, [16, 16, 16], 1.0, box=bx, frames=frames, chunk=chunk):
@@ -202,14 +204,14 @@ def test_xtc_fed_stream_matches_decode_then_voxelize():
     sig = np.where(rng.random((N, 8)) < 0.4, rng.choice([1.1, 1.52, 1.7], size=(N, 1)), 0.0)
     center = tr.coords[:, :, 0].mean(0).astype(np.float64)
     for pbc in (False, True):
-        want, _, _ = batch.voxelizeTrajectory(tr.coords, sig, center, [14, 14, 14], 1.0, box=tr.box.astype(np.float32) if pbc else None)
+        want, _, _ = batch._voxelizeTrajectory_packed(tr.coords, sig, center, [14, 14, 14], 1.0, box=tr.box.astype(np.float32) if pbc else None)
         for chunk in (7, 64):
             outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=pbc, chunk=chunk)]
             torch.cuda.synchronize()
             assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
     sel = np.array([5, 0, 19])
     outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=False, frames=sel, chunk=2)]
-    want, _, _ = batch.voxelizeTrajectory(tr.coords, sig, center, [14, 14, 14], 1.0, frames=sel)
+    want, _, _ = batch._voxelizeTrajectory_packed(tr.coords, sig, center, [14, 14, 14], 1.0, frames=sel)
     assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
 
 
@@ -226,7 +228,8 @@ def test_streaming_paths_raise_on_bad_frames_instead_of_yielding_incomplete_feat
     sig = np.where(rng.random((N, 8)) < 0.4, rng.choice([1.2, 1.7], size=(N, 1)), 0.0)
     box = np.full((3, F), 40.0, np.float32)
     box[:, 8:] = 13.0                                         # smaller than grid + halo: several images per atom from frame 8 on
-    want, _, _ = batch.voxelizeTrajectory(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=box)
+    want, _, _ = batch._voxelizeTrajectory_packed(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=box)
+    assert np.array_equal(batch.voxelizeTrajectory(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=box)[0], want)
     outs = [f for _, f in batch.iterVoxelizeTrajectory(xyz, sig, [15.0] * 3, [20, 20, 20], 1.0, box=box, chunk=4)]
     torch.cuda.synchronize()
     assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
