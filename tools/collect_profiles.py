@@ -51,4 +51,15 @@ if acc:
 for src, dst in (("ubench_mem.txt", f"{tag}_ubench_mem.txt"),):
     if os.path.exists("gpurun_out/" + src):
         shutil.copy("gpurun_out/" + src, "profiles/" + dst)
+for src, dst in (("bench_xtc.txt", f"{tag}_bench_xtc.txt"), ("host_paths.txt", f"{tag}_host_paths.txt"), ("pmc_dist.txt", f"{tag}_dist_pairs_pmc.txt"),
+                 ("kstats_reduction.txt", f"{tag}_dist_reduction_kernel_stats.txt"), ("diag_breakdown.txt", f"{tag}_cfg2_valu_breakdown.txt"),
+                 ("latency_probe.txt", f"{tag}_latency_probe.txt"), ("phase_timers.txt", f"{tag}_phase_timers.txt"),
+                 ("dropin_profile.txt", f"{tag}_dropin_host_profile.txt"), ("pmc_bin.txt", f"{tag}_prepass_instruction_counts.txt")):
+    if os.path.exists("gpurun_out/" + src):
+        shutil.copy("gpurun_out/" + src, "profiles/" + dst)
+for wl in ("cfg1", "cfg3", "cfg4", "cfg5", "dist"):
+    if os.path.exists(f"gpurun_out/{wl}_pmc_counters.json"):
+        shutil.copy(f"gpurun_out/{wl}_pmc_counters.json", f"profiles/{tag}_{wl}_pmc_counters.json")
+if os.path.exists("gpurun_out/single_timeline_cfg2.txt") and os.path.exists("gpurun_out/single_timeline_3ptb.txt"):
+    open(f"profiles/{tag}_single_call_timeline.txt", "w").write(open("gpurun_out/single_timeline_cfg2.txt").read() + open("gpurun_out/single_timeline_3ptb.txt").read())
 print("\n".join(sorted(os.listdir("profiles"))))

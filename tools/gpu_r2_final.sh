@@ -18,3 +18,6 @@ for w in cfg2 3ptb; do rm -rf gpurun_out/st_$w; (cd /tmp && timeout 200 rocprofv
 (bash tools/gpu_pmc_dist.sh > gpurun_out/pmc_dist.txt 2>&1)
 (bash tools/gpu_kstats_reduction.sh > gpurun_out/kstats_reduction.txt 2>&1)
 (MKAMD_LIB=$R/.variants/libmkamd_distdiag.so timeout 200 python bench.py --workload dist --no-cpu-baseline > gpurun_out/bench_distance_store_only.log 2>&1)
+(python tools/bench_xtc.py 2>/dev/null | tail -1 > gpurun_out/bench_xtc.txt)
+((python tools/bench_host_batch.py; python tools/bench_host_dist.py; python tools/bench_calculate_occupancy.py; python tools/bench_voxelize_trajectory.py) 2>/dev/null | grep -v amdgpu.ids > gpurun_out/host_paths.txt)
+(bash tools/gpu_pmc_traffic_wl.sh cfg1 cfg3 cfg4 cfg5 dist > gpurun_out/pmc_traffic_wl.txt 2>&1)
