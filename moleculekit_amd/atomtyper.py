@@ -1,0 +1,363 @@
+"""Atom-typing array logic beside the voxelizer -- the parts of the reference's
+``moleculekit/tools/atomtyper.py`` that are plain rules over arrays:
+
+* ``getPDBQTAtomType`` / ``pdbqt_atom_types``   ``tools/atomtyper.py:43-128`` -- OpenBabel (Sybyl-style) atom type ->
+  AutoDock PDBQT type, one atom (the reference's signature) or the whole molecule at once
+* ``atomtypingValidityChecks``                  ``:244-327`` -- is this molecule fit for typing / voxelization
+* ``getPDBQTAtomTypesAndCharges``               ``:330-373`` -- the driver; the typing proper is OpenBabel's
+  (third party, not in this package's environment): its per-atom properties come in through ``obabel_properties``
+* ``getFeatures``                               ``:523-554`` -- re-exported from ``channels.features_from_atomtypes``
+
+Everything works on ``Molecule``-like objects: anything with the arrays ``name, resname, resid, chain, segid, element,
+bonds`` (+ ``insertion``, ``bondtype``, ``coords [N,3]`` or ``[N,3,F]`` where a rule needs them).  Host-side numpy;
+none of it is on the GPU path.  Pinned by ``tests/golden/atomtyper_*.npz|json`` (outputs of the real reference on the
+metallo-protein fixture its own test holds, ``tests/test_voxeldescriptors.py:109-131``).
+
+Two rules of the reference go through machinery this package does not rebuild, and are restated at the array level:
+``mol.atomselect("protein")`` (VMD's rule: four bonded backbone-named atoms inside one residue make the residue's
+bonded atoms protein, ``atomselect_utils.pyx:107-254``) and ``autoSegment``'s count of protein segments (a new segment
+where the peptide C-N link of consecutive residues is longer than 2 A, ``tools/autosegment.py:291-326``).  The
+reference evaluates selections on file bonds PLUS bonds guessed from geometry; here the molecule's own bond table is
+used, joined with "all four backbone names present in the residue" (what guessed bonds add for a well-formed residue).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _residue_tables as _tab
+from .channels import _METAL_ATYPES, features_from_atomtypes
+
+metal_atypes = _METAL_ATYPES          # tools/atomtyper.py:16-40
+
+
+def _str(a):
+    return np.asarray(a).astype(str)
+
+
+def _bond_array(mol, n=None):
+    b = getattr(mol, "bonds", None)
+    b = np.zeros((0, 2), dtype=np.int64) if b is None else np.asarray(b, dtype=np.int64).reshape(-1, 2)
+    if n is not None and b.size and (b.min() < 0 or b.max() >= n):
+        raise ValueError("Bonds array contains atoms which are not in the molecule. "
+                         f"The maximum atom index in the bonds array is {b.max()} while the molecule contains {n} atoms.")
+    return b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OpenBabel type -> PDBQT type
+# ---------------------------------------------------------------------------------------------------------------------
+def pdbqt_atom_types(atypes, bonds, element, aromaticNitrogen: bool = False) -> np.ndarray:
+    """``getPDBQTAtomType`` for every atom at once: ``atypes [N]`` OpenBabel types -> PDBQT types (object array).
+
+    The rules, in the reference's order of precedence (``tools/atomtyper.py:71-128``): metals keep their type;
+    ``Car`` -> ``A``, other ``C*`` -> ``C``; ``N*`` -> ``N`` with the acceptor suffix decided by the type and the
+    number of bond entries of the atom; ``O*`` -> ``OA``; ``S*`` -> ``SA`` (``S`` for ``Sox`` / ``Sac``); ``H*`` -> ``H``,
+    ``HD`` when the partner of the atom's first bond is not a carbon; anything else -> its first letter."""
+    t = _str(atypes)
+    n = t.shape[0]
+    el = _str(element)
+    b = np.asarray(bonds, dtype=np.int64).reshape(-1, 2)
+    deg = np.bincount(b.ravel(), minlength=n) if b.size else np.zeros(n, dtype=np.int64)
+    first = np.array([s[:1] for s in t], dtype="U1")
+    last = np.array([s[-1:] for s in t], dtype="U1")
+    if np.any(first == ""):
+        raise IndexError("string index out of range")          # what atype[0] does to an empty type
+    out = first.astype(object)                                  # the fall-through: atype[0]
+    is_c, is_n, is_o, is_s, is_h = (first == c for c in "CNOSH")
+    out[is_c] = "C"
+    out[t == "Car"] = "A"
+    # nitrogens: N, NA, or the aromatic pair Na / Nn
+    two = deg == 2
+    amide = np.isin(t, ("Nam", "Npl", "Ng+"))
+    nar = t == "Nar"
+    other_n = is_n & ~amide & ~nar
+    out[is_n] = "N"
+    out[amide & two] = "NA"
+    out[nar & two] = "Na" if aromaticNitrogen else "NA"
+    out[nar & ~two] = "Nn" if aromaticNitrogen else "N"
+    out[other_n & (last != "+")] = "NA"
+    out[is_o] = "OA"
+    out[is_s] = "SA"
+    out[np.isin(t, ("Sox", "Sac"))] = "S"
+    # hydrogens: the partner in the FIRST bond row that mentions the atom
+    if np.any(is_h & ~np.isin(t, metal_atypes)):
+        first_row = np.full(n, -1, dtype=np.int64)
+        if b.size:
+            rows = np.repeat(np.arange(b.shape[0]), 2)
+            flat = b.ravel()
+            order = np.argsort(flat, kind="stable")             # stable: the earliest row of every atom comes first
+            atoms, start = np.unique(flat[order], return_index=True)
+            first_row[atoms] = rows[order][start]
+        hyd = np.where(is_h & ~np.isin(t, metal_atypes))[0]
+        lonely = hyd[first_row[hyd] < 0]
+        if lonely.size:
+            raise RuntimeError(f"Could not atomtype hydrogen atom with index {lonely[0]} due to no bonding partners.")
+        pair = b[first_row[hyd]]
+        partner = np.where(pair[:, 0] != hyd, pair[:, 0], pair[:, 1])
+        out[hyd] = np.where(np.isin(el[partner], ("C", "A")), "H", "HD")
+    metal = np.isin(t, metal_atypes)
+    out[metal] = t[metal]
+    return out
+
+
+def getPDBQTAtomType(atype: str, aidx: int, mol, aromaticNitrogen: bool = False) -> str:
+    """The reference's one-atom form (same signature, ``tools/atomtyper.py:43-46``): the PDBQT type of atom ``aidx``
+    of ``mol`` whose OpenBabel type is ``atype``.  ``RuntimeError`` for a hydrogen without bonds."""
+    el = _str(mol.element)
+    n = el.shape[0]
+    b = _bond_array(mol)
+    rows = b[np.any(b == aidx, axis=1)] if b.size else b        # only this atom's bond rows matter (order kept)
+    types = np.full(n, "X", dtype=object)
+    types[aidx] = atype
+    try:
+        return str(pdbqt_atom_types(types, rows, el, aromaticNitrogen)[aidx])
+    except RuntimeError:
+        raise RuntimeError(f"Could not atomtype hydrogen atom with index {aidx} due to no bonding partners.") from None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# validity checks
+# ---------------------------------------------------------------------------------------------------------------------
+def _group_ids(*fields):
+    """Integer id per atom of the tuple of field values (equal tuples -> equal ids)."""
+    key = np.zeros(len(fields[0]), dtype=np.int64)
+    for f in fields:
+        _, inv = np.unique(np.asarray(f), return_inverse=True)
+        key = key * (int(inv.max()) + 1 if inv.size else 1) + inv
+    return key
+
+
+def _components(n, edges):
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    if len(edges) == 0:
+        return np.arange(n)
+    g = coo_matrix((np.ones(len(edges), dtype=np.int8), (edges[:, 0], edges[:, 1])), shape=(n, n))
+    return connected_components(g, directed=False)[1]
+
+
+def protein_mask(mol) -> np.ndarray:
+    """Boolean [N]: what the reference's ``atomselect("protein")`` selects.  VMD's rule on the bond table (four bonded
+    backbone-named atoms inside one residue make everything bonded to them inside that residue protein), joined with
+    the residues that simply hold all four backbone names -- the reference adds bonds guessed from the geometry
+    before it applies the rule, so a well-formed residue is protein for it even when the table lacks its bonds."""
+    name = _str(mol.name)
+    n = name.shape[0]
+    b = _bond_array(mol, n)
+    out = np.zeros(n, dtype=bool)
+    for idx in _residue_runs(mol, np.ones(n, dtype=bool)):
+        if len(set(name[idx]) & _tab.PROTEIN_BACKBONE_NAMES) >= 4:
+            out[idx] = True
+    if b.size == 0:
+        return out
+    key = _group_ids(np.asarray(mol.resid), _str(mol.chain), _str(mol.segid))
+    bb = np.isin(name, list(_tab.PROTEIN_BACKBONE_NAMES))
+    term = np.isin(name, list(_tab.PROTEIN_TERMINAL_NAMES))
+    if term.any():                                              # a terminal oxygen counts when it hangs on a backbone atom
+        on_bb = np.zeros(n, dtype=bool)
+        on_bb[b[bb[b[:, 1]], 0]] = True
+        on_bb[b[bb[b[:, 0]], 1]] = True
+        bb = bb | (term & on_bb)
+    inside = b[key[b[:, 0]] == key[b[:, 1]]]
+    # clusters of bonded backbone atoms inside one residue: four of them make a protein residue ...
+    cl = _components(n, inside[bb[inside[:, 0]] & bb[inside[:, 1]]])
+    size = np.bincount(cl[bb], minlength=n)
+    seed = bb & (size[cl] >= 4)
+    # ... and everything bonded to them inside the residue belongs to it
+    comp = _components(n, inside)
+    good = np.zeros(n, dtype=bool)
+    good[comp[seed]] = True
+    return out | good[comp]
+
+
+def _residue_runs(mol, sel):
+    """Index arrays of the residues of the selected atoms, in file order: a new residue where resid, insertion or
+    chain changes from one selected atom to the next (``Molecule.getResidues``, ``molecule.py:372-421``)."""
+    idx = np.where(sel)[0]
+    if idx.size == 0:
+        return []
+    n = len(sel)
+    ins = _str(getattr(mol, "insertion", np.full(n, "")))
+    cols = (np.asarray(mol.resid)[idx], ins[idx], _str(mol.chain)[idx])
+    change = np.zeros(idx.size, dtype=bool)
+    for c in cols:
+        change[1:] |= c[1:] != c[:-1]
+    return np.split(idx, np.where(change)[0])
+
+
+def _frame_coords(mol):
+    c = np.asarray(mol.coords)
+    return c[:, :, int(getattr(mol, "frame", 0))] if c.ndim == 3 else c
+
+
+def predicted_segments(mol, sel, protein_cutoff: float = 2.0, ca_fallback_cutoff: float = 5.0) -> int:
+    """How many segments ``autoSegment`` would cut the selected residues into (``tools/autosegment.py:285-367``), for
+    selections of protein residues, caps, water, ions and lipids -- what ``atomtypingValidityChecks`` asks for.
+    Protein residues are walked in file order; a new segment starts where chain / segid change or the backbone is not
+    continuous: peptide link C(i)-N(i+1) within ``protein_cutoff`` (an isopeptide link only next to a non-canonical
+    residue), CA-CA within ``ca_fallback_cutoff`` when C or N is missing, or a bond of the table that joins the
+    backbone C / N of one residue to the other residue.  Water, ions and lipids are one segment each."""
+    name, resname, element = _str(mol.name), _str(mol.resname), _str(mol.element)
+    chain, segid = _str(mol.chain), _str(mol.segid)
+    xyz = _frame_coords(mol).astype(np.float64)
+    b = _bond_array(mol)
+    runs = _residue_runs(mol, sel)
+    metal_ion = {e.upper() for e in _tab.METAL_ELEMENTS}
+    cats = []
+    for idx in runs:
+        rn, names = resname[idx[0]], set(name[idx])
+        if rn in _tab.WATER_RESNAMES:
+            cats.append("water")
+        elif rn in _tab.ION_RESNAMES or (rn in metal_ion and len(idx) == 1):
+            cats.append("ion")
+        elif rn in _tab.LIPID_RESNAMES:
+            cats.append("lipid")
+        elif rn in _tab.CAP_RESNAMES or {"N", "CA", "C"} <= names:
+            cats.append("protein")
+        else:
+            cats.append("other")
+    if "other" in cats:
+        raise NotImplementedError("segments of non-polymer molecules (split by bonded components) are not predicted here")
+
+    def atom(idx, nm):
+        hit = idx[name[idx] == nm]
+        return hit[0] if hit.size else None
+
+    def linked(p, c):
+        d = np.linalg.norm(xyz[p][:, None, :] - xyz[c][None, :, :], axis=2)
+        noncanon = resname[p[0]] not in _tab.CANONICAL_RESNAMES or resname[c[0]] not in _tab.CANONICAL_RESNAMES
+        for r, s in zip(*np.where(d <= protein_cutoff)):
+            ia, ib = p[r], c[s]
+            na, ea, nb, eb = name[ia], element[ia], name[ib], element[ib]
+            kind = None                                          # tools/nonstandard_residues.py:341-351
+            if na == "N" and eb == "C":
+                kind = "peptide" if nb == "C" else "isopeptide"
+            elif nb == "N" and ea == "C":
+                kind = "peptide" if na == "C" else "isopeptide"
+            elif (na == "C" and eb == "N") or (nb == "C" and ea == "N"):
+                kind = "isopeptide"
+            if kind == "peptide" or (kind == "isopeptide" and noncanon):
+                return True
+        if atom(p, "C") is None or atom(c, "N") is None:
+            a0, a1 = atom(p, "CA"), atom(c, "CA")
+            if a0 is not None and a1 is not None and np.linalg.norm(xyz[a0] - xyz[a1]) <= ca_fallback_cutoff:
+                return True
+        if b.size:                                               # a deposited backbone bond the geometry missed
+            pc, cn = p[name[p] == "C"], c[name[c] == "N"]
+            in_p, in_c = np.isin(b, p), np.isin(b, c)
+            is_cn, is_pc = np.isin(b, cn), np.isin(b, pc)
+            if np.any((is_cn[:, 0] & in_p[:, 1]) | (is_cn[:, 1] & in_p[:, 0]) | (is_pc[:, 0] & in_c[:, 1]) | (is_pc[:, 1] & in_c[:, 0])):
+                return True
+        return False
+
+    nseg, prev = 0, None
+    for i, cat in enumerate(cats):
+        if cat != "protein":
+            continue
+        cur = runs[i]
+        if prev is None or chain[prev[0]] != chain[cur[0]] or segid[prev[0]] != segid[cur[0]] or not linked(prev, cur):
+            nseg += 1
+        prev = cur
+    return nseg + sum(1 for bucket in ("water", "ion", "lipid") if bucket in cats)
+
+
+def atomtypingValidityChecks(mol) -> None:
+    """``tools/atomtyper.py:244-327``: raises what the reference raises (same exception types and messages) when the
+    molecule is not fit for atom typing: no protein atoms, atoms that are neither protein nor metal, fewer bonds than
+    atoms - 1 (``ValueError``), duplicate bonds, blank segment / chain ids, a segment count that differs from the
+    predicted one, no hydrogens."""
+    name, resname, element = _str(mol.name), _str(mol.resname), _str(mol.element)
+    n = name.shape[0]
+    bonds = _bond_array(mol, n)
+    protsel = protein_mask(mol)
+    metals = np.isin(element, metal_atypes)
+    notallowed = ~(protsel | metals)
+    if not np.any(protsel):
+        raise RuntimeError("No protein atoms found in Molecule")
+    if np.any(notallowed):
+        raise RuntimeError(
+            "Found atoms with resnames {} in the Molecule which can cause issues with the voxelization. Please make sure to only pass protein atoms and metals.".format(
+                np.unique(resname[notallowed])))
+    if bonds.shape[0] < (n - 1):
+        raise ValueError(
+            "The protein has less bonds than (number of atoms - 1). This seems incorrect. You can assign bonds with `mol.bonds = mol._getBonds()`")
+    # unique bonds: rows as unordered pairs (with the bond type, when the types differ: molecule.py:3791-3810)
+    srt = np.sort(bonds, axis=1)
+    bt = getattr(mol, "bondtype", None)
+    if bt is not None and len(bt) and len(np.unique(_str(bt))) > 1:
+        nuq = len(set(zip(srt[:, 0].tolist(), srt[:, 1].tolist(), _str(bt).tolist())))
+    else:
+        nuq = len(np.unique(srt, axis=0))
+    if nuq != bonds.shape[0]:
+        raise RuntimeError(
+            "The protein has duplicate bond information. This will mess up atom typing. Please keep only unique bonds in the molecule. If you want you can use moleculekit.molecule.calculateUniqueBonds for this.")
+    segid, chain = _str(mol.segid), _str(mol.chain)
+    if np.all(segid == "") or np.all(chain == ""):
+        raise RuntimeError("Please assign segments to the segid and chain fields of the molecule using autoSegment")
+    # autoSegment on a copy with blank ids, over "protein or resname ACE NME"; atoms outside keep the blank id
+    blank = _Blank(mol, n)
+    sel = protsel | np.isin(resname, ("ACE", "NME"))
+    numsegsref = predicted_segments(blank, sel) + (1 if not np.all(sel) else 0)
+    numsegs = len(np.unique(segid))
+    if numsegs != numsegsref:
+        raise RuntimeError(
+            "The molecule contains {} segments while we predict {}. Make sure you used autoSegment on the protein".format(
+                numsegs, numsegsref))
+    if not np.any(element == "H"):
+        raise RuntimeError(
+            "No hydrogens found in the Molecule. Make sure to use systemPrepare before passing it to voxelization. Also you might need to recalculate the bonds after this.")
+
+
+class _Blank:
+    """A view of a molecule with blank chain / segid (what the reference hands to autoSegment, :310-312)."""
+
+    def __init__(self, mol, n):
+        self._mol = mol
+        self.chain = np.full(n, "")
+        self.segid = np.full(n, "")
+
+    def __getattr__(self, k):
+        return getattr(self._mol, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# drivers
+# ---------------------------------------------------------------------------------------------------------------------
+def getPDBQTAtomTypesAndCharges(mol, aromaticNitrogen: bool = False, validitychecks: bool = True, obabel_properties=None):
+    """``tools/atomtyper.py:330-373``: ``(atomtypes object [N], charges float32 [N])``.
+
+    The typing proper is OpenBabel's (``getOpenBabelProperties``: Sybyl-style types + Gasteiger charges) -- a third-party
+    toolkit that is not rebuilt here.  ``obabel_properties`` takes its output: rows ``(index, resname, resid, name,
+    type, charge)``; without it an importable ``moleculekit.tools.obabel_tools`` is used, and otherwise the call
+    raises.  What follows OpenBabel is this module's: the HIP ring carbons become ``Car`` (:361-364), charges are
+    rounded to three decimals, every atom goes through ``getPDBQTAtomType``."""
+    if validitychecks:
+        atomtypingValidityChecks(mol)
+    if obabel_properties is None:
+        try:
+            from moleculekit.tools.obabel_tools import getOpenBabelProperties
+        except ImportError as e:
+            raise RuntimeError("atom typing needs OpenBabel (through an installed moleculekit) or precomputed "
+                               "`obabel_properties`; moleculekit_amd does not rebuild that toolkit") from e
+        obabel_properties = getOpenBabelProperties(mol)
+    n = len(_str(mol.name))
+    sybyl = np.full(n, "", dtype=object)
+    charges = np.full(n, np.nan, dtype=np.float32)
+    seen = np.zeros(n, dtype=bool)
+    for idx, resname, _resid, name, attype, charge in obabel_properties:
+        nm = str(name).strip()
+        if resname == "HIP" and nm.startswith("C") and nm not in ("CA", "C", "CB"):
+            attype = "Car"
+        sybyl[int(idx)] = attype
+        charges[int(idx)] = np.float32(f"{float(charge):.3f}")
+        seen[int(idx)] = True
+    types = np.full(n, "", dtype=object)
+    if seen.any():
+        full = np.where(seen, sybyl, "X")
+        types[seen] = pdbqt_atom_types(full, _bond_array(mol, n), mol.element, aromaticNitrogen)[seen]
+    return types, charges
+
+
+def getFeatures(mol) -> np.ndarray:
+    """``tools/atomtyper.py:523-554`` on a typed ``Molecule``-like object: boolean ``[N, 8]``."""
+    return features_from_atomtypes(mol.atomtype, mol.resname, mol.name, mol.bonds)

@@ -10,8 +10,9 @@ Mirrors, array in / array out and vectorised (the reference loops over hydrogens
   the table stage of ``getChannels(version=2)``)
 * ``getChannels``                = ``moleculekit/tools/voxeldescriptors.py:135-194`` for ``Molecule``-like objects
 
-Not here: assigning the atom types themselves (``getPDBQTAtomTypesAndCharges`` needs OpenBabel) and the
-``SmallMol`` branch (RDKit); neither toolkit is part of this package's environment.
+The rules around the typing proper (OpenBabel type -> PDBQT type, the validity checks) are in
+``moleculekit_amd.atomtyper``.  Not here: OpenBabel's own typing / Gasteiger charges and the ``SmallMol`` branch
+(RDKit); neither toolkit is part of this package's environment.
 ``moleculekit_amd.voxeldescriptors.getChannels`` uses this module by default and delegates to an installed
 moleculekit only when asked to (``backend="moleculekit"``).
 
@@ -126,9 +127,10 @@ def getChannels(mol, aromaticNitrogen: bool = False, version: int = 2, validityc
     by the element's van-der-Waals radius (``:190-193``).
 
     ``version=1`` uses the PDBQT types/charges as they are; ``version=2`` in the reference first re-types the
-    molecule with OpenBabel (``getPDBQTAtomTypesAndCharges``) -- that step is not available here, so the
-    atom types on ``mol`` are taken as given (``aromaticNitrogen`` / ``validitychecks`` only affect that
-    step and are accepted for signature compatibility)."""
+    molecule with OpenBabel (``getPDBQTAtomTypesAndCharges``, ``tools/atomtyper.py:330-373``) -- a third-party step
+    that is not available here, so the atom types on ``mol`` are taken as given (``aromaticNitrogen`` only affects
+    that step).  ``validitychecks`` runs ``atomtyper.atomtypingValidityChecks`` like the reference does before
+    typing, when ``mol`` carries the fields the checks read (resid, chain, segid, coords)."""
     for field in ("atomtype", "element", "name"):
         if not hasattr(mol, field):
             raise TypeError(f"getChannels needs a Molecule-like object with a `{field}` array "
@@ -141,6 +143,10 @@ def getChannels(mol, aromaticNitrogen: bool = False, version: int = 2, validityc
     if version == 1:
         mask = atomtype_properties_pdbqt(atomtype, mol.element, mol.name, mol.charge, _mol_bonds(mol))
     elif version == 2:
+        if validitychecks and all(hasattr(mol, f) for f in ("resid", "chain", "segid", "coords", "resname", "bonds")):
+            from .atomtyper import atomtypingValidityChecks
+
+            atomtypingValidityChecks(mol)
         mask = features_from_atomtypes(atomtype, mol.resname, mol.name, getattr(mol, "bonds"))
     else:
         raise ValueError("version must be 1 or 2")

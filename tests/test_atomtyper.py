@@ -1,0 +1,99 @@
+"""The atom-typing row against vectors made by the REAL reference
+(tests/golden/make_golden_atomtyper.py): the metallo-protein fixture the reference's own test holds
+(tests/test_voxeldescriptors.py:109-131: 1ATL_atomtyped.psf/.pdb -> 1ATL_channels.npy), getPDBQTAtomType on
+Sybyl-style inputs (tools/atomtyper.py:43-128) and atomtypingValidityChecks (:244-327).  Exact equality."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+
+from moleculekit_amd import atomtyper, channels
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+G = np.load(os.path.join(GOLD, "atomtyper_1atl.npz"))
+FIELDS = ("name", "resname", "element", "resid", "insertion", "chain", "segid", "bonds", "bondtype", "coords")
+
+
+def mol_like(src, prefix="", **extra):
+    m = types.SimpleNamespace(**{f: src[prefix + f] for f in FIELDS}, **extra)
+    m.copy = lambda: types.SimpleNamespace(**{k: v for k, v in vars(m).items() if k != "copy"})
+    return m
+
+
+def test_1atl_channels_equal_the_reference_held_matrix():
+    """getChannels(version=2) on the typed 1ATL molecule == 1ATL_channels.npy, bit for bit (zinc and calcium in
+    channel 6); the validity checks run on the way, as in the reference."""
+    mol = mol_like(G, atomtype=G["atomtype"], charge=G["charge"])
+    chan, _ = channels.getChannels(mol, version=2, validitychecks=True)
+    assert chan.dtype == np.float64 and np.array_equal(chan, G["ref_channels"])
+    assert (chan[:, 6] != 0).sum() == 2 and set(G["element"][chan[:, 6] != 0]) == {"Zn", "Ca"}
+    assert np.array_equal(atomtyper.getFeatures(mol), G["feats_v2"])
+
+
+@pytest.mark.parametrize("arom", [False, True])
+def test_pdbqt_types_of_every_trial_match_the_reference(arom):
+    want = G["pdbqt_arom" if arom else "pdbqt_plain"]
+    for trial in range(G["sybyl"].shape[0]):
+        got = atomtyper.pdbqt_atom_types(G["sybyl"][trial], G["bonds"], G["element"], arom)
+        assert np.array_equal(got.astype("U4"), want[trial]), f"trial {trial}"
+    # trial 0 is the inverse image of the stored typing
+    assert np.array_equal(want[0], G["atomtype"]) or arom
+
+
+def test_one_atom_form_has_the_reference_signature():
+    mol = mol_like(G)
+    rng = np.random.default_rng(3)
+    for i in rng.choice(len(G["name"]), 200, replace=False):
+        for trial in (0, 2, 5):
+            assert atomtyper.getPDBQTAtomType(str(G["sybyl"][trial][i]), int(i), mol) == G["pdbqt_plain"][trial][i]
+            assert atomtyper.getPDBQTAtomType(str(G["sybyl"][trial][i]), int(i), mol, True) == G["pdbqt_arom"][trial][i]
+
+
+def test_hydrogen_without_a_bond_raises_like_the_reference():
+    mol = types.SimpleNamespace(element=np.array(["H", "C"]), bonds=np.zeros((0, 2), dtype=int))
+    with pytest.raises(RuntimeError, match="Could not atomtype hydrogen atom with index 0 due to no bonding partners"):
+        atomtyper.getPDBQTAtomType("H", 0, mol)
+    with pytest.raises(RuntimeError, match="index 0"):
+        atomtyper.pdbqt_atom_types(np.array(["H", "C3"]), mol.bonds, mol.element)
+    assert atomtyper.getPDBQTAtomType("Zn", 0, mol) == "Zn" and atomtyper.getPDBQTAtomType("HG", 0, mol) == "HG"
+
+
+def test_validity_checks_raise_what_the_reference_raises():
+    cases = json.load(open(os.path.join(GOLD, "atomtyper_validity.json")))
+    mols = np.load(os.path.join(GOLD, "atomtyper_validity_mols.npz"))
+    assert sum(v["raises"] is None for v in cases.values()) == 3
+    for tag, want in sorted(cases.items()):
+        mol = mol_like(G) if tag == "prepared_full" else mol_like(mols, tag + "__")
+        if want["raises"] is None:
+            atomtyper.atomtypingValidityChecks(mol)
+            continue
+        with pytest.raises({"RuntimeError": RuntimeError, "ValueError": ValueError}[want["raises"]]) as e:
+            atomtyper.atomtypingValidityChecks(mol)
+        assert str(e.value) == want["message"], tag
+
+
+def test_protein_mask_without_a_bond_table_falls_back_to_backbone_names():
+    mols = np.load(os.path.join(GOLD, "atomtyper_validity_mols.npz"))
+    full = mol_like(mols, "fragment_ok__")
+    bare = mol_like(mols, "fragment_ok__")
+    bare.bonds = np.zeros((0, 2), dtype=np.int64)
+    assert np.array_equal(atomtyper.protein_mask(full), atomtyper.protein_mask(bare))
+    assert atomtyper.protein_mask(full).sum() == (mols["fragment_ok__segid"] == "P0").sum()
+
+
+def test_driver_takes_openbabel_properties_and_applies_the_hip_rule():
+    mol = mol_like(G)
+    props = [(i, G["resname"][i], int(G["resid"][i]), G["name"][i], G["sybyl"][0][i], 0.12345) for i in range(len(G["name"]))]
+    # OpenBabel would call the HIP ring carbons C2/C3; the driver turns them into Car -> 'A'
+    for i in np.where(G["hip_ring_carbon"])[0]:
+        props[i] = props[i][:4] + ("C2", -0.5)
+    t, q = atomtyper.getPDBQTAtomTypesAndCharges(mol, validitychecks=True, obabel_properties=props)
+    assert np.array_equal(t.astype("U4"), G["atomtype"]) and q.dtype == np.float32
+    assert np.all(t[G["hip_ring_carbon"]] == "A") and q[0] == np.float32("0.123")
+    try:
+        import moleculekit  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="OpenBabel"):
+            atomtyper.getPDBQTAtomTypesAndCharges(mol, validitychecks=False)

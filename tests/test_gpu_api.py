@@ -164,6 +164,29 @@ def test_getvoxeldescriptors_types_channels_itself_for_pdbqt_molecules(version):
     assert np.abs(feats - want).max() <= 1e-5
 
 
+@pytest.mark.gpu
+def test_1atl_metalloprotein_from_its_typed_molecule():
+    """The fixture pair the reference's own test holds (tests/test_voxeldescriptors.py:109-131: 1ATL_atomtyped ->
+    1ATL_channels.npy, zinc and calcium in the metal channel): getVoxelDescriptors types the molecule itself
+    (version 2, validity checks on) and voxelizes it around the zinc site; expected = oracle on the channel matrix
+    the REFERENCE stored for that molecule."""
+    import copy
+
+    from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "atomtyper_1atl.npz"))
+    mol = Mol(g["coords"], element=g["element"])
+    for f in ("atomtype", "name", "resname", "resid", "insertion", "chain", "segid", "bonds", "bondtype", "charge"):
+        setattr(mol, f, g[f])
+    mol.copy = lambda: copy.copy(mol)
+    zn = g["coords"][g["element"] == "Zn"][0].astype(np.float64)
+    feats, centers, nvox = getVoxelDescriptors(mol, boxsize=[24, 24, 24], center=zn, voxelsize=1, version=2)
+    from oracle import oracle
+    want = oracle.calculate_occupancy(centers, g["coords"], g["ref_channels"])
+    assert feats.shape == want.shape == (24 ** 3, 8) and list(nvox) == [24, 24, 24]
+    assert np.abs(feats - want).max() <= TOL
+    assert feats[:, 6].max() > 0.99 and (feats[:, 6] > 0).sum() < 1500       # the metal channel: two spheres, nothing else
+
+
 def test_streamed_trajectory_matches_the_all_at_once_call():
     """SURVEY 8f-4 (trajectory feeding): chunks uploaded on a copy stream while the previous chunk is voxelized;
     same values as voxelizeTrajectory, whatever the chunking, with and without a periodic box / frame subsets."""
