@@ -556,15 +556,17 @@ try {
     tmp.resize((size_t)V * C);
     // The reference's only caller hands this function a getCenters LATTICE (voxeldescriptors.py:356 via _getOccupancyC):
     // recognised (two passes over the centres, host) it takes the tiled lattice kernels -- microseconds where the
-    // pairwise kernel below tests N x V pairs in double; anything the lattice path refuses falls through to it.
-    int st = MKAMD_EINVAL;
+    // pairwise kernel below tests N x V pairs in double.
+    // A status other than "this geometry is not for the tiled kernels" (MKAMD_EINVAL: every argument has been checked
+    // above, so what is left are the capacity limits of the lattice plan) goes back to the caller -- a HIP error or a
+    // failed allocation is not retried on a kernel a hundred times slower (route_calculate_occupancy, pipeline.h).
     double bb_min[3], vs = 0.0;
     int32_t nv[3];
-    if (mkamd_lattice_from_centers(centers, V, bb_min, nv, &vs)) {
-        const int64_t offs[2] = {0, N};
-        st = mkamd_voxelize_lattice_host(ctx, 1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, tmp.data());
-    }
-    if (st) st = mkamd_occupancy_centers_host(ctx, centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data());
+    const bool is_lattice = mkamd::lattice_from_centers(centers, (long long)V, bb_min, nv, &vs);
+    const int st = mkamd::route_calculate_occupancy(is_lattice,
+        [&] { const int64_t offs[2] = {0, N};
+              return mkamd_voxelize_lattice_host(ctx, 1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, tmp.data()); },
+        [&] { return mkamd_occupancy_centers_host(ctx, centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data()); });
     if (st) return st;
     // in-place max-accumulate, `value > old ? value : old` as occupancy_utils.pyx:61
     const size_t nvals = (size_t)V * C;
@@ -834,47 +836,7 @@ try {
 // positive step, then every centre against fl64(index * step) + centre 0 with the tolerance 1e-9 * max(1, max |c|).
 extern "C" int mkamd_lattice_from_centers(const double* c, int64_t V, double* bb_min, int32_t* nvoxels, double* voxelsize)
 try {
-    if (!c || !bb_min || !nvoxels || !voxelsize || V < 2) return 0;
-    int64_t nz = V;
-    for (int64_t i = 1; i < V; ++i) if (c[3 * i + 2] <= c[3 * (i - 1) + 2]) { nz = i; break; }
-    if (V % nz) return 0;
-    const int64_t rows = V / nz;
-    int64_t ny = rows;
-    for (int64_t i = 1; i < rows; ++i) if (c[3 * (i * nz) + 1] <= c[3 * ((i - 1) * nz) + 1]) { ny = i; break; }
-    if (rows % ny) return 0;
-    const int64_t nx = rows / ny;
-    if (nx > 0x7fffffff || ny > 0x7fffffff || nz > 0x7fffffff) return 0;
-    double steps[3]; int ns = 0;
-    if (nz > 1) steps[ns++] = c[3 * 1 + 2] - c[2];
-    if (ny > 1) steps[ns++] = c[3 * nz + 1] - c[1];
-    if (nx > 1) steps[ns++] = c[3 * (nz * ny) + 0] - c[0];
-    if (ns == 0) return 0;
-    for (int i = 0; i < ns; ++i) if (!(steps[i] > 0.0)) return 0;
-    const double vs = steps[0];
-    const double stol = 1e-9 * std::max(1.0, std::fabs(vs));
-    for (int i = 0; i < ns; ++i) if (std::fabs(steps[i] - vs) > stol) return 0;
-    double maxabs = 0.0;
-    for (int64_t i = 0; i < 3 * V; ++i) {
-        const double a = std::fabs(c[i]);
-        if (!(a <= maxabs)) { if (a != a) return 0; maxabs = a; }           // a NaN centre is no lattice
-    }
-    const double tol = 1e-9 * std::max(1.0, maxabs);
-    const double o[3] = {c[0], c[1], c[2]};
-    const double* q = c;
-    for (int64_t ix = 0; ix < nx; ++ix) {
-        const double ex = (double)ix * vs + o[0];
-        for (int64_t iy = 0; iy < ny; ++iy) {
-            const double ey = (double)iy * vs + o[1];
-            for (int64_t iz = 0; iz < nz; ++iz, q += 3) {
-                const double ez = (double)iz * vs + o[2];
-                if (std::fabs(ex - q[0]) > tol || std::fabs(ey - q[1]) > tol || std::fabs(ez - q[2]) > tol) return 0;
-            }
-        }
-    }
-    bb_min[0] = o[0]; bb_min[1] = o[1]; bb_min[2] = o[2];
-    nvoxels[0] = (int32_t)nx; nvoxels[1] = (int32_t)ny; nvoxels[2] = (int32_t)nz;
-    *voxelsize = vs;
-    return 1;
+    return mkamd::lattice_from_centers(c, (long long)V, bb_min, nvoxels, voxelsize) ? 1 : 0;
 } catch (...) { return 0; }
 
 // ---------------------------------------------------------------------------------------------

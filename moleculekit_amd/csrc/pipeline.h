@@ -473,4 +473,68 @@ int run_grid_centers(BE& be, const double* bb_min, const int* nvox, double voxel
                      bb_min[2], nvox[0], nvox[1], nvox[2], voxelsize, d_centers);
 }
 
+// Is this centre list a getCenters lattice (x slowest, z fastest, one positive step)?  The test of
+// moleculekit_amd/voxeldescriptors.py::_recognise_lattice_numpy in two passes over the array instead of a dozen numpy
+// temporaries: axis lengths from the first place z (then y, at stride nz) stops increasing, one common positive step,
+// then every centre against fl64(index * step) + centre 0 with the tolerance 1e-9 * max(1, max |c|).  Host code.
+inline bool lattice_from_centers(const double* c, long long V, double* bb_min, int* nvoxels, double* voxelsize)
+{
+    if (!c || !bb_min || !nvoxels || !voxelsize || V < 2) return false;
+    long long nz = V;
+    for (long long i = 1; i < V; ++i) if (c[3 * i + 2] <= c[3 * (i - 1) + 2]) { nz = i; break; }
+    if (V % nz) return false;
+    const long long rows = V / nz;
+    long long ny = rows;
+    for (long long i = 1; i < rows; ++i) if (c[3 * (i * nz) + 1] <= c[3 * ((i - 1) * nz) + 1]) { ny = i; break; }
+    if (rows % ny) return false;
+    const long long nx = rows / ny;
+    if (nx > 0x7fffffff || ny > 0x7fffffff || nz > 0x7fffffff) return false;
+    double steps[3]; int ns = 0;
+    if (nz > 1) steps[ns++] = c[3 * 1 + 2] - c[2];
+    if (ny > 1) steps[ns++] = c[3 * nz + 1] - c[1];
+    if (nx > 1) steps[ns++] = c[3 * (nz * ny) + 0] - c[0];
+    if (ns == 0) return false;
+    for (int i = 0; i < ns; ++i) if (!(steps[i] > 0.0)) return false;
+    const double vs = steps[0];
+    const double stol = 1e-9 * std::max(1.0, std::fabs(vs));
+    for (int i = 0; i < ns; ++i) if (std::fabs(steps[i] - vs) > stol) return false;
+    double maxabs = 0.0;
+    for (long long i = 0; i < 3 * V; ++i) {
+        const double a = std::fabs(c[i]);
+        if (!(a <= maxabs)) { if (a != a) return false; maxabs = a; }           // a NaN centre is no lattice
+    }
+    const double tol = 1e-9 * std::max(1.0, maxabs);
+    const double o[3] = {c[0], c[1], c[2]};
+    const double* q = c;
+    for (long long ix = 0; ix < nx; ++ix) {
+        const double ex = (double)ix * vs + o[0];
+        for (long long iy = 0; iy < ny; ++iy) {
+            const double ey = (double)iy * vs + o[1];
+            for (long long iz = 0; iz < nz; ++iz, q += 3) {
+                const double ez = (double)iz * vs + o[2];
+                if (std::fabs(ex - q[0]) > tol || std::fabs(ey - q[1]) > tol || std::fabs(ez - q[2]) > tol) return false;
+            }
+        }
+    }
+    bb_min[0] = o[0]; bb_min[1] = o[1]; bb_min[2] = o[2];
+    nvoxels[0] = (int)nx; nvoxels[1] = (int)ny; nvoxels[2] = (int)nz;
+    *voxelsize = vs;
+    return true;
+}
+
+// mkamd_calculate_occupancy's choice between the tiled lattice kernels and the pairwise double-precision kernel
+// (occupancy_utils.pyx:34-61 takes any centre list; its one caller passes a lattice).  Only "not a lattice" and the
+// lattice plan's own refusal of a geometry (ST_EINVAL: more than 1023 cells per axis, a cutoff of more than 512 voxels,
+// more than 2^31 tiles) reach the pairwise kernel; every other status of the lattice path -- a HIP error, a failed
+// allocation -- is the call's status.
+template <class Lattice, class Pairwise>
+inline int route_calculate_occupancy(bool is_lattice, Lattice&& lattice, Pairwise&& pairwise)
+{
+    if (is_lattice) {
+        const int st = lattice();
+        if (st != ST_EINVAL) return st;
+    }
+    return pairwise();
+}
+
 }  // namespace mkamd

@@ -7,6 +7,7 @@
 #include "../../moleculekit_amd/csrc/dist_pipeline.h"
 
 #include <string>
+#include <vector>
 
 using namespace mkamd;
 
@@ -102,6 +103,42 @@ int emu_occupancy_centers(const double* centers, long long V, const float* coord
     EmuBackend be;
     for (long long i = 0; i < V * C; ++i) features[i] = -123.0f;
     return run_centers(be, centers, V, coords, N, sigmas, sigmas_f64, C, box, features, g_err);
+}
+
+// mirrors mkamd_calculate_occupancy (capi.hip): the same lattice recogniser and the same routing rule (pipeline.h), the
+// emulated kernels behind them.  inject_lattice_status != 0 stands in for a failure inside the lattice path (a HIP error,
+// an allocation failure): the tests check that it comes back instead of being retried on the pairwise kernel.
+// *route_out: 1 = tiled lattice kernels served the call, 2 = pairwise kernel, 0 = neither (an error came back).
+int emu_calculate_occupancy(const double* centers, long long V, const float* coords, long long N, const double* sigmas,
+                            int C, double* results, int inject_lattice_status, int* route_out)
+{
+    if (V <= 0 || N <= 0) return ST_OK;
+    std::vector<float> tmp((size_t)V * C, -123.0f);
+    double bb_min[3], vs = 0.0;
+    int nv[3];
+    int route = 0;
+    const bool is_lattice = lattice_from_centers(centers, V, bb_min, nv, &vs);
+    const int st = route_calculate_occupancy(is_lattice,
+        [&] {
+            if (inject_lattice_status) return inject_lattice_status;
+            const long long offs[2] = {0, N};
+            const int r = emu_voxelize_lattice(1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, 0, 0, nullptr, tmp.data(),
+                                               nullptr, -1, nullptr, -1, -1, 0, 1, nullptr, -1);
+            if (!r) route = 1;
+            return r;
+        },
+        [&] {
+            const int r = emu_occupancy_centers(centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data());
+            if (!r) route = 2;
+            return r;
+        });
+    if (route_out) *route_out = st ? 0 : route;
+    if (st) return st;
+    for (size_t i = 0; i < tmp.size(); ++i) {
+        const double v = (double)tmp[i];
+        if (v > results[i]) results[i] = v;          // occupancy_utils.pyx:61
+    }
+    return ST_OK;
 }
 
 int emu_choose_tier(int forced, const unsigned* feedback) { return choose_tier(forced, feedback); }

@@ -197,3 +197,18 @@ def pdist(c):
     out = np.full(n * (n - 1) // 2, -7.0, np.float32)
     assert lib().emu_pdist(_p(c), ctypes.c_longlong(n), ctypes.c_int(c.shape[1]), _p(out)) == 0
     return out
+
+
+def calculate_occupancy(centers, coords, sigmas, results, inject_lattice_status=0):
+    """mkamd_calculate_occupancy's routing (lattice recogniser + route_calculate_occupancy of pipeline.h) on the emulated
+    kernels: max-accumulates into `results` (float64 [V, C]) and returns (status, route) with route 1 = tiled lattice
+    kernels, 2 = pairwise kernel, 0 = an error came back."""
+    centers = np.ascontiguousarray(centers, np.float64).reshape(-1, 3)
+    coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
+    sigmas = np.ascontiguousarray(sigmas, np.float64)
+    assert results.dtype == np.float64 and results.flags["C_CONTIGUOUS"]
+    route = ctypes.c_int(0)
+    st = lib().emu_calculate_occupancy(_p(centers), ctypes.c_longlong(centers.shape[0]), _p(coords),
+                                       ctypes.c_longlong(coords.shape[0]), _p(sigmas), ctypes.c_int(sigmas.shape[1]),
+                                       _p(results), ctypes.c_int(inject_lattice_status), ctypes.byref(route))
+    return st, route.value

@@ -317,3 +317,34 @@ def test_cell_size_only_moves_the_last_bits(name):
     assert np.abs(fine.astype(np.float64) - coarse).max() <= 5e-6
     check(case, fine)
     check(case, coarse)
+
+
+def test_calculate_occupancy_returns_errors_instead_of_retrying_on_the_pairwise_kernel():
+    """mkamd_calculate_occupancy (capi.hip) through the emulator: a getCenters lattice takes the tiled kernels, any other
+    centre list the pairwise kernel, a lattice the plan refuses (more than 1023 cells per axis) falls through to the
+    pairwise kernel -- and a FAILURE inside the lattice path (HIP error, allocation) comes back as the call's status
+    with `results` untouched (round 2 retried it silently on the 100x slower kernel)."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    coords = rng.uniform(0, 6, (40, 3)).astype(np.float32)
+    sig = np.where(rng.random((40, 8)) < 0.3, 1.7, 0.0)
+    centers = oracle.grid_centers(np.array([-1.0, -1.0, -1.0]), [8, 8, 8], 1.0)
+    want = oracle.calculate_occupancy(centers, coords, sig)
+    res = np.zeros_like(want)
+    st, route = E.calculate_occupancy(centers, coords, sig, res)
+    assert (st, route) == (0, 1) and np.abs(res - want).max() <= TOL
+    jit = centers + rng.normal(0, 1e-3, centers.shape)                       # not a lattice
+    res2 = np.full_like(want, 0.25)                                          # in-place max contract (occupancy_utils.pyx:61)
+    st, route = E.calculate_occupancy(jit, coords, sig, res2)
+    assert (st, route) == (0, 2) and np.abs(res2 - np.maximum(oracle.calculate_occupancy(jit, coords, sig), 0.25)).max() <= TOL
+    for injected in (2, 6):                                                  # ST_EHIP, MKAMD_ENOMEM
+        res3 = np.full_like(want, -7.0)
+        st, route = E.calculate_occupancy(centers, coords, sig, res3, inject_lattice_status=injected)
+        assert (st, route) == (injected, 0) and np.all(res3 == -7.0)
+    st, route = E.calculate_occupancy(centers, coords, sig, np.zeros_like(want), inject_lattice_status=1)
+    assert (st, route) == (0, 2)                                             # ST_EINVAL = the plan's refusal: pairwise serves it
+    # a lattice the plan really refuses: 0.009 A voxels put the cutoff beyond 512 voxels
+    tiny = oracle.grid_centers(np.array([2.0, 2.0, 2.0]), [4, 4, 4], 0.009)
+    res4 = np.zeros((64, 8))
+    st, route = E.calculate_occupancy(tiny, coords, sig, res4)
+    assert (st, route) == (0, 2) and np.abs(res4 - oracle.calculate_occupancy(tiny, coords, sig)).max() <= TOL
