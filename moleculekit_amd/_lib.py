@@ -289,8 +289,7 @@ class Context:
         _check(load().mkamd_grid_centers_dev(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(d_out)))
 
 
-_contexts = {}
-_contexts_lock = threading.Lock()
+_tls = threading.local()
 
 
 def default_context(device: int | None = None) -> Context:
@@ -299,22 +298,26 @@ def default_context(device: int | None = None) -> Context:
     A context owns one stream, one grow-only workspace and pinned staging buffers, and ctypes releases the GIL
     during every call, so two host threads must never drive the same context at once (include/mkamd_voxel.h: "one
     context per device and per host thread").  The reference's Cython kernel runs under the GIL and is thread-safe
-    by construction; keying the shared default by (process, thread, device) gives the drop-in API the same
-    guarantee.  Contexts of threads that have ended are closed the next time a new one is created."""
+    by construction; a default context per (process, thread, device) gives the drop-in API the same guarantee.
+
+    The contexts live in the thread's own ``threading.local`` storage: nobody but the owning thread ever looks one up,
+    and nothing closes it from outside -- it is released (``Context.__del__``) when the thread's storage dies AND no
+    one else holds a reference (a context handed to another object, e.g. ``ShardedVoxelizer``, outlives its thread).
+    A thread that Python did not start (a C++ callback thread) gets storage like any other.  After ``fork`` the child
+    makes its own contexts and leaves the parent's handles alone."""
     if device is None:
         device = int(os.environ.get("MKAMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         n = device_count()
         if n > 0:
             device %= n
-    key = (os.getpid(), threading.get_ident(), int(device))
-    ctx = _contexts.get(key)
+    held = getattr(_tls, "contexts", None)
+    if held is None or getattr(_tls, "pid", None) != os.getpid():
+        if held:                                   # forked child: the parent's device handles are not ours to free
+            for c in held.values():
+                c._h = _vp(None)
+        held = _tls.contexts = {}
+        _tls.pid = os.getpid()
+    ctx = held.get(int(device))
     if ctx is None:
-        with _contexts_lock:
-            alive = {t.ident for t in threading.enumerate()}
-            for k in [k for k in _contexts if k[0] != os.getpid() or k[1] not in alive]:
-                dead = _contexts.pop(k)
-                if k[0] == os.getpid():            # (a forked child must not free the parent's device handles)
-                    dead.close()
-            ctx = Context(device)
-            _contexts[key] = ctx
+        ctx = held[int(device)] = Context(device)
     return ctx

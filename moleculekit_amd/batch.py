@@ -145,7 +145,10 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     dev = coords.device
     if dev.type != "cuda":
         raise RuntimeError("voxelize_lattice_torch needs CUDA/HIP tensors (there is no CPU path)")
-    ctx = ctx or _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+    dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+    if ctx is not None and ctx.device != dev_index:
+        raise ValueError(f"ctx lives on GPU {ctx.device} but the tensors are on cuda:{dev_index} (kernels run on the context's device)")
+    ctx = ctx or _lib.default_context(dev_index)
     assert coords.dtype == torch.float32 and coords.is_contiguous()
     assert atom_offsets.dtype == torch.int64 and atom_offsets.is_contiguous()
     assert sigmas.dtype in (torch.float32, torch.float64) and sigmas.is_contiguous() and sigmas.dim() == 2
@@ -218,16 +221,21 @@ def voxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None,
     out = np.empty((F, V, C), dtype=np.float32)
     if F == 0 or V == 0:
         return out, origin, nvoxels.astype(np.int64)
-    import torch
+    try:
+        import torch
+    except ImportError:                            # torch only owns device memory here: without it, the packed host call
+        return _voxelizeTrajectory_packed(coords, channels, center, boxsize, voxelsize, box=box, frames=frames, ctx=ctx)
+    # the GPU is the CONTEXT's (the caller's, or this thread's default: MKAMD_DEVICE / LOCAL_RANK), never torch's current one
+    cctx = ctx or _lib.default_context()
     _lib._check(_lib.load().mkamd_prefault(_lib._ptr(out), out.nbytes))
     chunk = int(max(1, min(F, (256 << 20) // max(V * C * 4, 1))))      # ~256 MB of features per step
     pos = 0
     lib = _lib.load()
-    for idx, feats in iterVoxelizeTrajectory(coords, sig, center, boxsize, voxelsize, box=box, frames=frames, chunk=chunk, ctx=ctx):
+    for idx, feats in iterVoxelizeTrajectory(coords, sig, center, boxsize, voxelsize, box=box, frames=frames, chunk=chunk,
+                                             device=f"cuda:{cctx.device}", ctx=cctx):
         n = len(idx)
         feats = feats.contiguous()
         torch.cuda.current_stream(feats.device).synchronize()
-        cctx = ctx or _lib.default_context(feats.device.index)
         # (the runtime's own device -> host copy into the pre-touched pages: 40 GB/s; a torch copy_ into a pageable
         #  tensor stages through bounce buffers at a third of that)
         _lib._check(lib.mkamd_copy_to_host(cctx._h, out[pos:pos + n].ctypes.data, feats.data_ptr(), n * V * C * 4))
@@ -303,7 +311,17 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
     good when the generator ends, so a bad frame raises instead of yielding silently incomplete features."""
     import torch
 
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    # the device: the caller's, else the context's, else this thread's default context's (MKAMD_DEVICE / LOCAL_RANK) --
+    # torch's current device only names the index of a bare "cuda"
+    if device is None:
+        dev = torch.device("cuda", (ctx or _lib.default_context()).device)
+    else:
+        dev = torch.device(device)
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+    if ctx is not None and ctx.device != dev.index:
+        raise ValueError(f"ctx lives on GPU {ctx.device} but the tensors of this call would be allocated on {dev}: "
+                         "pass a context of that device (kernels run on the context's device)")
     chunk = int(max(1, min(chunk, max(len(fr), 1))))
     sig = np.ascontiguousarray(channels)
     sig = sig.astype(np.float64 if sig.dtype == np.float64 else np.float32, copy=False)
@@ -325,7 +343,7 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
         dslab = [None, None]
         dbox = [None, None]
         images = [max_images, max_images]
-        run_ctx = ctx or _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
+        run_ctx = ctx or _lib.default_context(dev.index)
 
         def upload(k, slot):
             idx = fr[k * chunk:(k + 1) * chunk]

@@ -51,6 +51,26 @@ def _target(results, shape):
     return np.empty(shape, dtype=np.float32)
 
 
+def _frame_inputs(coords, box, chains, pbc, used_atoms):
+    """What the library reads wholesale -- 3 x F box floats and one chain id per atom -- from what the reference reads
+    only where it needs it: the box only when ``pbc`` (distance_utils.pyx:49-52), a chain id only at the atoms the call
+    touches.  A box of another shape is fine without pbc (zeros stand in), an error with it; a short chain array is
+    padded once every touched atom has an entry."""
+    N, F = coords.shape[0], coords.shape[2]
+    if coords.shape[1] != 3:
+        raise ValueError(f"coords must be (natoms, 3, nframes), got {coords.shape}")
+    if box.shape != (3, F):
+        if pbc:
+            raise ValueError(f"box must have shape (3, {F}) for periodic distances, got {box.shape}")
+        box = np.zeros((3, F), dtype=np.float32)
+    if chains.shape[0] < N:
+        top = int(max((int(np.max(u)) for u in used_atoms if len(u)), default=-1))
+        if top >= chains.shape[0]:
+            raise ValueError(f"digitized_chains has {chains.shape[0]} entries but atom {top} is used")
+        chains = np.concatenate([chains, np.zeros(N - chains.shape[0], dtype=np.uint32)])
+    return box, chains
+
+
 def dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, results, ctx=None):
     """distance_utils.pyx:126-155: ``results[f, idx] = |coords[sel1[i],:,f] - coords[sel2[j],:,f]|`` with the
     orthorhombic minimum image across different chains when ``pbc``."""
@@ -59,6 +79,7 @@ def dist_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc, re
     sel1 = _req("sel1", sel1, np.uint32, 1); sel2 = _req("sel2", sel2, np.uint32, 1)
     chains = _req("digitized_chains", digitized_chains, np.uint32, 1)
     _req("results", results, np.float32, 2)
+    box, chains = _frame_inputs(coords, box, chains, pbc, (sel1, sel2))
     ctx = ctx or _lib.default_context()
     F = coords.shape[2]
     npairs = int(_lib.load().mkamd_dist_count_pairs(len(sel1), len(sel2), int(bool(selfdist))))
@@ -74,6 +95,7 @@ def contacts_trajectory(coords, box, sel1, sel2, digitized_chains, selfdist, pbc
     box = _req("box", box, np.float32, 2)
     sel1 = _req("sel1", sel1, np.uint32, 1); sel2 = _req("sel2", sel2, np.uint32, 1)
     chains = _req("digitized_chains", digitized_chains, np.uint32, 1)
+    box, chains = _frame_inputs(coords, box, chains, pbc, (sel1, sel2))
     ctx = ctx or _lib.default_context()
     offs, pairs = ctx.contacts_trajectory_host(coords, box, sel1, sel2, chains, bool(selfdist), bool(pbc), dist_threshold)
     flat = pairs.astype(np.int64).ravel()
@@ -101,6 +123,12 @@ def _reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pairs, pbc, ma
     masses = _req("masses", masses, np.float32, 1)
     _req("results", results, np.float32, 2)
     a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)
+    box, ch1 = _frame_inputs(coords, box, ch1, pbc, (a1,))
+    _, ch2 = _frame_inputs(coords, box, ch2, pbc, (a2,))
+    if masses.shape[0] < coords.shape[0]:            # read only by the centre-of-mass reduction (distance_utils.pyx:158-185)
+        if int(r1) == 1 or int(r2) == 1:
+            raise ValueError(f"masses has {masses.shape[0]} entries for {coords.shape[0]} atoms")
+        masses = np.concatenate([masses, np.zeros(coords.shape[0] - masses.shape[0], dtype=np.float32)])
     ctx = ctx or _lib.default_context()
     F = coords.shape[2]
     nout = len(groups1) if pairs else int(_lib.load().mkamd_dist_count_pairs(len(groups1), len(groups2), int(bool(selfdist))))

@@ -84,6 +84,7 @@ def _gridSpec(mol=None, buffer=0, boxsize=None, center=None, voxelsize=1):
     return bb_min, nvoxels
 
 
+_CENTERS_LOCK = __import__("threading").Lock()
 _CENTERS_CACHE = {}          # (bb_min bytes, nvoxels, voxelsize) -> centres; a handful of entries (one pocket, many poses)
 
 
@@ -95,15 +96,18 @@ def _centersFromSpec(bb_min, nvoxels, voxelsize):
     nx, ny, nz = (int(v) for v in nvoxels)
     bb = np.asarray(bb_min)
     key = (bb.dtype.str, bb.tobytes(), nx, ny, nz, float(voxelsize))
-    hit = _CENTERS_CACHE.get(key)
+    with _CENTERS_LOCK:                         # the drop-in API is per-thread safe: the cache is shared, so guarded
+        hit = _CENTERS_CACHE.get(key)
     if hit is not None:
         return hit.copy()
     centers = np.empty((nx * ny * nz, 3), dtype=np.float64)
     np.add(_getGridCenters(nx, ny, nz, voxelsize), bb_min, out=centers.reshape(nx, ny, nz, 3))
-    if len(_CENTERS_CACHE) >= 4:
-        _CENTERS_CACHE.pop(next(iter(_CENTERS_CACHE)))
     if centers.nbytes <= (64 << 20):
-        _CENTERS_CACHE[key] = centers.copy()
+        keep = centers.copy()
+        with _CENTERS_LOCK:
+            while len(_CENTERS_CACHE) >= 4:
+                _CENTERS_CACHE.pop(next(iter(_CENTERS_CACHE)), None)
+            _CENTERS_CACHE[key] = keep
     return centers
 
 

@@ -217,3 +217,35 @@ def test_native_lattice_recognition_agrees_with_its_numpy_specification():
             n_lat += 1
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], np.asarray(b[1])) and a[2] == b[2]
     assert n_lat >= len(lattices)
+
+
+def test_distance_wrappers_validate_what_the_library_reads_wholesale():
+    """the C side copies 3 x F box floats and one chain id per atom; the reference reads the box only with
+    pbc and a chain id only at the atoms it touches.  The wrappers reconcile the two BEFORE any pointer crosses."""
+    from moleculekit_amd import distance_utils as du
+    coords = np.zeros((6, 3, 4), np.float32)
+    chains = np.zeros(6, np.uint32)
+    box, ch = du._frame_inputs(coords, np.zeros((3, 1), np.float32), chains, False, (np.arange(6),))
+    assert box.shape == (3, 4) and not box.any() and ch is chains
+    with pytest.raises(ValueError, match=r"box must have shape \(3, 4\)"):
+        du._frame_inputs(coords, np.zeros((3, 1), np.float32), chains, True, (np.arange(6),))
+    _, ch = du._frame_inputs(coords, np.zeros((3, 4), np.float32), chains[:4], True, (np.array([0, 3], np.uint32),))
+    assert ch.shape == (6,) and ch.dtype == np.uint32
+    with pytest.raises(ValueError, match="atom 5 is used"):
+        du._frame_inputs(coords, np.zeros((3, 4), np.float32), chains[:4], True, (np.array([5], np.uint32),))
+
+
+def test_centres_cache_survives_concurrent_eviction():
+    import threading
+    errors = []
+
+    def churn(seed):
+        try:
+            for i in range(200):
+                vd._centersFromSpec(np.array([float(seed), float(i % 7), 0.0]), (3, 3, 3), 1.0)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ts = [threading.Thread(target=churn, args=(s,)) for s in range(8)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errors and len(vd._CENTERS_CACHE) <= 4

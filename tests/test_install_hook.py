@@ -4,7 +4,9 @@ moleculekit (tools/voxeldescriptors.py:515-533, called at :356) for this package
 call time by `getVoxelDescriptors`).  The HIP library is not needed: the library call under the hook is recorded.
 Also here: the default context is per host thread, and `getChannels` never silently changes backend."""
 import sys
+import gc
 import threading
+import weakref
 import types
 
 import numpy as np
@@ -91,15 +93,25 @@ def test_default_context_is_per_thread(monkeypatch):
             self.closed = True
 
     monkeypatch.setattr(_lib, "Context", FakeCtx)
-    monkeypatch.setattr(_lib, "_contexts", {})
+    monkeypatch.setattr(_lib, "_tls", threading.local())
     main = _lib.default_context(0)
     assert _lib.default_context(0) is main and FakeCtx.made == 1
-    other = []
-    t = threading.Thread(target=lambda: other.append(_lib.default_context(0)))
+    other, kept_alive = [], []
+
+    def worker(keep):
+        c = _lib.default_context(0)
+        assert _lib.default_context(0) is c
+        other.append(weakref.ref(c))
+        if keep:
+            kept_alive.append(c)                 # handed to someone who outlives the thread
+
+    t = threading.Thread(target=worker, args=(False,))
     t.start(); t.join()
-    assert other[0] is not main and FakeCtx.made == 2
-    assert _lib.default_context(0) is main
-    t2 = threading.Thread(target=lambda: other.append(_lib.default_context(0)))
+    assert FakeCtx.made == 2 and _lib.default_context(0) is main
+    t2 = threading.Thread(target=worker, args=(True,))
     t2.start(); t2.join()
-    # the ended thread's context was reclaimed (or, if the OS recycled the thread id, simply taken over)
-    assert other[0].closed or other[1] is other[0]
+    del t, t2
+    gc.collect()
+    # a context dies with its thread's storage -- unless someone else still holds it; nobody closes it from outside
+    assert other[0]() is None
+    assert other[1]() is kept_alive[0] and not kept_alive[0].closed and not main.closed
