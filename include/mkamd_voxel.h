@@ -83,6 +83,14 @@ int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode);
  * Values agree to float32 noise (the cell-relative offsets are rounded at a different magnitude), both within the
  * 1e-5 parity bound. */
 int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on);
+/* Tolerance-aware reach (opt-in; 0 = off, the default: the reference's hard 5 A cutoff for every atom,
+ * occupancy_utils.pyx:53).  An (atom, channel) entry is worth 1 - exp(-(sigma/r)^12) < eps beyond r = sigma * eps^(-1/12)
+ * (hydrogens, sigma 1.1 A: 3.48 A at eps = 1e-6), and the channel value is a maximum over entries, so dropping an
+ * entry wherever it is worth less than eps moves no value by more than eps.  With eps > 0 every atom is culled per
+ * TILE at min(5 A, that radius) (rounded up to one of four levels); voxels of a tile the atom still reaches see it at
+ * any distance below 5 A as before.  Results stay within eps (+ the float32 noise of the exact mode, <= 3.4e-6) of the
+ * reference; they are no longer bit-identical between tilings / kernels.  eps in [0, 1e-5]. */
+int mkamd_ctx_set_value_tolerance(mkamd_ctx* ctx, double eps);
 /* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team of four that shares the tile's
  * candidate traversal and splits its entries (latency: one grid per call, the reference's own usage), -1 (default) =
  * a team when the whole launch has fewer tiles than the chip has SIMDs (ligand-sized items take the workgroup-per-item

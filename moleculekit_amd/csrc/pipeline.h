@@ -55,6 +55,7 @@ struct LatticeProblem {
     int lds_tier = -1;                      // -1 = adaptive (choose_tier), else the ECAP_TIER index to use
     int prepass_mode = -1;                  // -1 = automatic, 0 = multi-kernel chain, 1 = one-launch per-item pre-pass (if it fits)
     int fine_cells = 0;                     // 1 = half-cutoff cells (A-B benchmarking, see plan_lattice)
+    double value_tol = 0.0;                 // > 0: entries may be dropped where they are worth less than this (tolerance-aware reach)
     int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
     int tile_items = -1;                    // -1 = automatic (a workgroup per item for batches of ligand-sized items), 0 = never, 1 = always
     // device pointers
@@ -90,6 +91,8 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     g.res = P.voxelsize;
     // value step at the cutoff = 1-exp(-(1/(R2 w))^6) > 5e-6  <=>  R2 w < (5e-6)^(-1/6) = 7.647  (sigma > 1.81 A)
     g.w_exact_max = (float)(7.647 / (R * R));
+    // 1 - exp(-t^-6) < eps beyond t = w d^2 = eps^(-1/6); off (0) unless the caller opted in.  Capped at 1e-5: the parity bound
+    g.reach_tau = (P.value_tol > 0.0) ? (float)std::pow(std::min(P.value_tol, 1e-5), -1.0 / 6.0) : 0.f;
     g.Rp = R + 1e-3;
     g.rint = (int)std::ceil(R);
     if (g.rint > 512) { err = "voxelsize too small (cutoff spans > 512 voxels)"; return ST_EINVAL; }

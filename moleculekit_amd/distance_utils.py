@@ -123,8 +123,12 @@ def _reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pairs, pbc, ma
     masses = _req("masses", masses, np.float32, 1)
     _req("results", results, np.float32, 2)
     a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)
-    box, ch1 = _frame_inputs(coords, box, ch1, pbc, (a1,))
-    _, ch2 = _frame_inputs(coords, box, ch2, pbc, (a2,))
+    box, _ = _frame_inputs(coords, box, np.zeros(coords.shape[0], np.uint32), pbc, ())
+    # (chain ids are per GROUP here, distance_utils.pyx:225-229: the library reads one per group)
+    if ch1.shape[0] < len(groups1) or ch2.shape[0] < len(groups2):
+        raise ValueError(f"digitized_chains1/2 have {ch1.shape[0]}/{ch2.shape[0]} entries for {len(groups1)}/{len(groups2)} groups")
+    if a1.size and (a1.min() < 0 or a1.max() >= coords.shape[0]) or a2.size and (a2.min() < 0 or a2.max() >= coords.shape[0]):
+        raise ValueError("group atom index out of range")
     if masses.shape[0] < coords.shape[0]:            # read only by the centre-of-mass reduction (distance_utils.pyx:158-185)
         if int(r1) == 1 or int(r2) == 1:
             raise ValueError(f"masses has {masses.shape[0]} entries for {coords.shape[0]} atoms")

@@ -67,7 +67,8 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
                          int sigmas_f64, int C, const double* origins, const int* nvox, double voxelsize,
                          const float* box, int max_images, int tile_k, int force_general, const double* affine, float* features,
                          int* err_flag_out, int lds_tier, unsigned* feedback_io /* NTIER+1: in = previous call's, out = this call's */,
-                         int prepass_mode, int tile_team, int fine_cells, int repeat /* calls on ONE backend */, int* fills_out, int tile_items)
+                         int prepass_mode, int tile_team, int fine_cells, int repeat /* calls on ONE backend */, int* fills_out, int tile_items,
+                         double value_tol)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -76,7 +77,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     LatticeProblem P;
     P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
     P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
-    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier; P.prepass_mode = prepass_mode; P.tile_team = tile_team; P.fine_cells = fine_cells; P.tile_items = tile_items;
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier; P.prepass_mode = prepass_mode; P.tile_team = tile_team; P.fine_cells = fine_cells; P.tile_items = tile_items; P.value_tol = value_tol;
     if (feedback_io) for (int i = 0; i <= NTIER; ++i) be.feedback[i] = feedback_io[i];
     if (box && max_images <= 0) {
         max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);
@@ -123,7 +124,7 @@ int emu_calculate_occupancy(const double* centers, long long V, const float* coo
             if (inject_lattice_status) return inject_lattice_status;
             const long long offs[2] = {0, N};
             const int r = emu_voxelize_lattice(1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, 0, 0, nullptr, tmp.data(),
-                                               nullptr, -1, nullptr, -1, -1, 0, 1, nullptr, -1);
+                                               nullptr, -1, nullptr, -1, -1, 0, 1, nullptr, -1, 0.0);
             if (!r) route = 1;
             return r;
         },

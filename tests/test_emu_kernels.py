@@ -348,3 +348,41 @@ def test_calculate_occupancy_returns_errors_instead_of_retrying_on_the_pairwise_
     res4 = np.zeros((64, 8))
     st, route = E.calculate_occupancy(tiny, coords, sig, res4)
     assert (st, route) == (0, 2) and np.abs(res4 - oracle.calculate_occupancy(tiny, coords, sig)).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "pbc_batch", "cutoff_adversarial_1A", "special_sigmas", "voxel15"])
+def test_tolerance_aware_reach_stays_inside_its_bound(name):
+    """mkamd_ctx_set_value_tolerance (opt-in): every atom is culled per tile where it is worth less than eps.  The
+    result may move by at most eps against the exact mode (a maximum over entries is 1-Lipschitz in each of them) and
+    stays inside the 1e-5 parity bound against the reference; with eps = 0 nothing changes, bit for bit."""
+    case = LATTICE_CASES[name]()
+    kw = dict(box=case["box"]) if case["box"] is not None else {}
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    exact, _ = E.voxelize_lattice(*args, **kw)
+    again, _ = E.voxelize_lattice(*args, value_tol=0.0, **kw)
+    assert np.array_equal(exact, again)
+    for eps in (1e-6, 5e-6):
+        tol, err = E.voxelize_lattice(*args, value_tol=eps, **kw)
+        assert err == 0
+        assert np.abs(tol - exact).max() <= eps * 1.001                   # moved by no more than the tolerance
+        assert np.all(tol <= exact)                                       # entries are only ever dropped
+        assert np.abs(tol - case["expected"]).max() <= TOL                # and still inside the parity bound
+    # the knob does something (3PTB has no hydrogens: only its N / O atoms drop to the 4.56 A level at eps = 5e-6)
+    if name == "cfg1_3ptb":
+        assert np.count_nonzero(tol != exact) > 0
+
+
+def test_reach_levels_cover_the_radius_an_atom_needs():
+    """Level l culls at reach^2 = (1 - 0.17 l) x 25 A^2; an atom gets the largest level whose reach still covers
+    sigma x eps^(-1/12).  One atom per sigma on a fine grid: the voxels it loses are exactly those beyond ITS reach."""
+    for sigma, eps in ((1.1, 1e-6), (1.52, 1e-6), (1.7, 1e-6), (0.8, 1e-6), (1.1, 5e-6)):
+        need = min(5.0, sigma * eps ** (-1.0 / 12.0))
+        coords = np.array([[12.03, 11.98, 12.01]], np.float32)
+        sig = np.zeros((1, 8)); sig[0, 0] = sigma
+        origin, nv = np.zeros((1, 3)), np.array([24, 24, 24])
+        exact, _ = E.voxelize_lattice(coords, np.array([0, 1]), sig, origin, nv, 1.0)
+        tol, _ = E.voxelize_lattice(coords, np.array([0, 1]), sig, origin, nv, 1.0, value_tol=eps)
+        d = np.linalg.norm(oracle.grid_centers(origin[0], nv, 1.0) - coords[0].astype(np.float64), axis=1)
+        lost = (tol[0, :, 0] == 0) & (exact[0, :, 0] > 0)
+        assert np.abs(tol - exact).max() <= eps
+        assert not lost[d < need - 1e-3].any()                            # nothing inside the radius the atom needs is lost

@@ -423,3 +423,47 @@ def test_batches_of_ligand_sized_items_take_the_workgroup_per_item_kernel(hip_ct
         s_, e_ = offs[b], offs[b + 1]
         want = oracle_lattice(args[0][s_:e_], np.array([0, e_ - s_]), args[2][s_:e_], origins[b:b + 1], nv, 1.0)
         assert np.abs(got[b] - want[0]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", sorted(LATTICE_CASES))
+def test_tolerance_aware_reach_is_opt_in_and_bounded(hip_ctx, name):
+    """mkamd_ctx_set_value_tolerance: off by default; with eps in (0, 1e-5] atoms are culled per tile
+    where they are worth less than eps -- no value moves by more than eps against the exact mode (and only downwards),
+    every case stays inside the 1e-5 parity bound, and switching it off again restores the exact bits."""
+    from moleculekit_amd import batch
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    exact = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+    try:
+        for eps in (1e-6, 5e-6):
+            hip_ctx.set_value_tolerance(eps)
+            tol = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+            assert np.abs(tol - exact).max() <= eps * 1.001 and np.all(tol <= exact)
+            check(case, tol)
+        with pytest.raises(Exception):
+            hip_ctx.set_value_tolerance(1e-3)                  # beyond the parity bound: refused
+    finally:
+        hip_ctx.set_value_tolerance(0.0)
+    assert np.array_equal(batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx), exact)
+
+
+def test_tolerance_aware_reach_on_full_size_cfg2_and_ligand_batches(hip_ctx):
+    """The knob on the shapes it is meant for: one full cfg2 system against the reference's sampled voxels (half of
+    its atoms are hydrogens, which lose their 3.5 .. 5 A shell: a third fewer entries per tile), and a batch of cfg3
+    poses through the workgroup-per-item kernel against the oracle."""
+    from moleculekit_amd import batch
+    g = golden("cfg2_sampled.npz")
+    p = synth_config(2, 1)
+    origin, nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])
+    try:
+        hip_ctx.set_value_tolerance(1e-6)
+        feats = batch.voxelize_lattice(p["coords"], p["atom_offsets"], p["sigmas"], origin[None], nv, p["voxelsize"], ctx=hip_ctx)[0]
+        assert np.abs(feats[g["sample_idx"]] - g["sample_features"]).max() <= TOL
+        q = synth_config(3, 64)
+        origins = np.stack([grid_origin(c, q["boxsize"], q["voxelsize"])[0] for c in q["centers"]])
+        nv3 = grid_origin(q["centers"][0], q["boxsize"], q["voxelsize"])[1]
+        got = batch.voxelize_lattice(q["coords"], q["atom_offsets"], q["sigmas"], origins, nv3, q["voxelsize"], ctx=hip_ctx)
+        exp = oracle_lattice(q["coords"], q["atom_offsets"], q["sigmas"], origins, nv3, q["voxelsize"])
+        assert np.abs(got - exp).max() <= TOL
+    finally:
+        hip_ctx.set_value_tolerance(0.0)
