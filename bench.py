@@ -301,53 +301,82 @@ def launch_ranks(args, argv):
     return subprocess.call(cmd, env=env)
 
 
+class _StandInContext:
+    """What run_workload asks of a device context, for --dry-run: there is no CPU voxelizer in the product, so the CPU
+    check of the N > 1 path runs the REAL run_workload (sharding, staging, timed loop, fences, max over ranks, both gathers)
+    around a stand-in compute and this stand-in context."""
+
+    device = -1
+
+    def synchronize(self):
+        pass
+
+    def enable_kernel_timing(self, on):
+        pass
+
+    def read_kernel_timing(self):
+        return 0.0, 0
+
+    def set_pipelining(self, on):
+        pass
+
+
+def _standin_compute(c, offs, s, o, nvox, vs, bx):
+    """Stand-in for the HIP path (dry run only): every voxel-channel of an item = 1 + its atom count + 1e-3 x the sum of
+    its coordinates -- a function of the ITEM alone, so any chunking / sharding / gather mistake shows up as a wrong row."""
+    import torch
+    n = len(offs) - 1
+    csum = np.concatenate([[0.0], np.cumsum(c.astype(np.float64).sum(axis=1))])
+    val = 1.0 + np.diff(offs) + 1e-3 * (csum[offs[1:]] - csum[offs[:-1]])
+    return torch.from_numpy(np.broadcast_to(val[:, None, None], (n, int(np.prod(nvox)), s.shape[1])).astype(np.float32).copy())
+
+
 def dry_run(args):
-    """CPU-only check of the N>1 plumbing (tests/test_bench_launch.py): ranks rendezvous over gloo, shard a tiny
-    batch with moleculekit_amd.distributed exactly as the timed path does, and gather it; the per-rank compute is a
-    stand-in that stamps every item with its global index (there is no CPU voxelizer in the product)."""
+    """CPU-only check of the N>1 plumbing (tests/test_bench_launch.py): the ranks rendezvous over gloo and go through
+    run_workload itself -- the function the timed GPU run uses -- on a small cfg3 batch with a stand-in compute; the
+    gathered tensors are then checked row by row against what every rank says its items are worth."""
     import torch
     import torch.distributed as dist
-    from moleculekit_amd.distributed import ShardedVoxelizer
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    B, nv = args.batch or 5, np.array([4, 3, 2])
-    seen = []
+    B = args.batch or 6
+    dev = torch.device("cpu")
 
-    def loader(lo, hi):                                       # this rank's items only; origin x = global item index
-        seen.append((lo, hi))
-        n = hi - lo
-        org = np.zeros((n, 3)); org[:, 0] = np.arange(lo, hi)
-        return (np.zeros((2 * n, 3), np.float32), np.arange(n + 1, dtype=np.int64) * 2, np.ones((2 * n, 8), np.float32), org, None)
+    def fence():
+        dist.barrier()
 
-    def compute(c, offs, s, o, nvox, vs, bx):
-        return torch.from_numpy(np.broadcast_to(o[:, :1, None], (len(o), int(np.prod(nvox)), 8)).astype(np.float32).copy())
-
-    sv = ShardedVoxelizer.from_loader(world * B, loader, nv, 1.0, compute=compute)
     t0 = time.perf_counter()
-    local = sv.voxelize()
-    full = sv.voxelize_gather(nchunks=3)
-    plain = sv.gather(local)
-    dist.barrier()
-    ok = (len(seen) == 1 and seen[0] == (rank * B, (rank + 1) * B) and tuple(full.shape) == (world * B, 24, 8)
-          and bool((full[:, 0, 0] == torch.arange(world * B, dtype=torch.float32)).all()) and torch.equal(full, plain))
+    res = run_workload("cfg3", B, 2, 1, _StandInContext(), dev, rank, world, args, fence, want_gather=True,
+                       compute=_standin_compute, keep=("full_plain", "full_overlapped", "out"))
+    mine = res["out"][:, 0, 0].tolist()                       # what this rank's items are worth
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    want = torch.tensor([v for part in everyone for v in part], dtype=torch.float32)
+    ok = ("gather_error" not in res and res["k_n"] == 0 and len(mine) == B and min(mine) > 1.0
+          and all(tuple(res[k].shape) == (world * B, 24 ** 3, 8) and torch.equal(res[k][:, 0, 0], want)
+                  and bool((res[k] == res[k][:, :1, :1]).all()) for k in ("full_plain", "full_overlapped")))
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
     if rank == 0:
-        print(json.dumps({"metric": "dry-run (gloo, stand-in compute)", "dry_run": True, "n_gpus": world, "ranks_joined": world,
-                          "items_per_rank": B, "ok": all(flags), "seconds": round(time.perf_counter() - t0, 3)}), flush=True)
+        print(json.dumps({"metric": "dry-run (gloo, stand-in compute)", "dry_run": True, "timed_path": "run_workload", "n_gpus": world,
+                          "ranks_joined": world, "items_per_rank": B, "ok": all(flags), "ms_per_step": round(res["elapsed"] / 2 * 1e3, 3),
+                          "gather_ms": res.get("gather_ms"), "gather_error": res.get("gather_error"),
+                          "seconds": round(time.perf_counter() - t0, 3)}), flush=True)
     dist.destroy_process_group()
     if not all(flags):
         raise SystemExit("dry run: sharding / gather mismatch")
 
 
-def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, want_gather=False, want_single=False):
+def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, want_gather=False, want_single=False,
+                 compute=None, keep=()):
     """Time `steps` passes of the hot path over this rank's resident shard of a batch of world x B items of workload
     `name` (weak scaling).  The shard lives in a moleculekit_amd.distributed.ShardedVoxelizer: loaded by this rank
-    alone, staged through pinned memory, resident in HBM before the timed region; no collective inside it."""
+    alone, staged through pinned memory, resident in HBM before the timed region; no collective inside it.
+    `compute` / `keep`: --dry-run only (a stand-in compute on CPU tensors; tensors to hand back for checking)."""
     import torch
     from moleculekit_amd.distributed import ShardedVoxelizer
     cfgno = int(name[3:])
@@ -363,7 +392,10 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     from tests.synth import grid_origin
     p0 = make_config(name, 1)
     nv = grid_origin(p0["centers"][0], p0["boxsize"], p0["voxelsize"])[1]
-    sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx)
+    if compute is None:
+        sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx)
+    else:
+        sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, compute=compute)
     p = cache["p"]
     V, C = int(np.prod(nv)), 8
     out = torch.empty((B, V, C), dtype=torch.float32, device=dev)
@@ -395,6 +427,8 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     chk = out[0].double().sum().item()
     assert os.environ.get("MKAMD_DIAG") == "1" or (np.isfinite(chk) and chk > 0), "bench produced an empty grid"
     res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C))
+    if "out" in keep:
+        res["out"] = out
 
     if want_gather:
         # (a secondary measurement: a failure in it -- RCCL, memory for the world x B result -- is reported on the line,
@@ -404,10 +438,17 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
             # (b) chunk-overlapped with the compute (what a consumer that needs everything everywhere would run)
             fence()
             g0 = time.perf_counter()
+            full = sv.gather(out)                 # (the first collective of a process also builds the communicator)
+            fence()
+            g0 = time.perf_counter()
             full = sv.gather(out)
             fence()
             res["gather_ms"] = (time.perf_counter() - g0) * 1e3
             assert full.shape[0] == world * B
+            if "full_plain" in keep:
+                res["full_plain"] = full
+            del full
+            full = sv.voxelize_gather(nchunks=4)  # (the first point-to-point exchange sets its channels up)
             del full
             fence()
             g0 = time.perf_counter()
@@ -417,6 +458,8 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
             res["compute_plus_overlapped_gather_ms"] = both
             res["gather_overlapped_extra_ms"] = both - elapsed / steps * 1e3
             assert full.shape[0] == world * B and torch.equal(full[rank * B:(rank + 1) * B], out)
+            if "full_overlapped" in keep:
+                res["full_overlapped"] = full
             del full
         except Exception as e:                                   # noqa: BLE001 -- reported, not swallowed
             res["gather_error"] = f"{type(e).__name__}: {e}"[:300]
@@ -446,7 +489,8 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         res["single_us"] = (time.perf_counter() - s0) / 20 * 1e6
         ctx.set_pipelining(not args.no_pipeline)
     del out, sv
-    torch.cuda.empty_cache()
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
     return res
 
 

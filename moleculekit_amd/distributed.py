@@ -9,7 +9,9 @@ bound, so it is offered
                            consumer wants; this is what ``bench.py --gpus N`` times),
   * after the compute   -- ``gather_features``: one padded RCCL all-gather (or gather-to-root),
   * overlapped          -- ``ShardedVoxelizer.voxelize_gather``: the shard is voxelized in chunks and
-                           chunk k travels on a communication stream while chunk k+1 is computed.
+                           chunk k travels on a communication stream while chunk k+1 is computed; equal shards are
+                           computed straight into the result and exchanged point to point (all seven xGMI links of a
+                           GPU busy at once, no staging copy).
 
 Data path of one rank: it holds ONLY its own shard -- host arrays are sliced (or produced by a
 ``loader(lo, hi)`` callback, so no rank ever materialises the whole batch), staged through pinned
@@ -98,10 +100,13 @@ def gather_features(local, bounds, group=None, dst=None):
         padded[: local.shape[0]] = local
     padded = padded.contiguous()
     if dst is None:
+        # equal shards (the weak-scaling case): the collective writes every shard at its final rows, nothing is copied after
         full = torch.empty((ws * bmax,) + tail, dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(full, padded, group=group)
+        if all(int(s) == bmax for s in sizes):
+            return full
         parts = [full[r * bmax: r * bmax + int(sizes[r])] for r in range(ws)]
-        return torch.cat(parts, dim=0) if any(int(s) != bmax for s in sizes) else full
+        return torch.cat(parts, dim=0)
     recv = [torch.empty_like(padded) for _ in range(ws)] if rank == dst else None
     dist.gather(padded, recv, dst=dst, group=group)
     if rank != dst:
@@ -253,11 +258,18 @@ class ShardedVoxelizer:
     def gather(self, local, dst=None):
         return gather_features(local, self.bounds, group=self.group, dst=dst) if self._collectives() else local
 
-    def voxelize_gather(self, nchunks=4, dst=None, timings=None):
+    def voxelize_gather(self, nchunks=4, dst=None, timings=None, exchange="auto"):
         """Voxelize the shard chunk by chunk and gather every finished chunk on a communication stream while the next
         one is computed.  Returns the full float32 [B, V, C] tensor on every rank (``dst=None``: all-gather) or on
-        ``dst`` only (others get None).  Chunks are padded to the largest chunk of any rank so that each step is one
-        equal-sized collective; the rows land at their final position in the result."""
+        ``dst`` only (others get None).
+
+        ``exchange="p2p"`` (what ``"auto"`` picks for an all-gather of equal shards -- the weak-scaling case): every
+        rank computes STRAIGHT INTO its own rows of the result, and each chunk travels as one batch of point-to-point
+        sends / receives between the rows' final positions -- no staging tensor, no second pass over the gathered data,
+        and on the xGMI mesh (every GPU wired to every other) all seven links of a GPU carry a chunk at once, where a
+        ring all-gather moves it over one link seven times.  ``exchange="allgather"`` (ragged shards, gather-to-root):
+        chunks are padded to the largest chunk of any rank so that each step is one equal-sized collective, received into
+        a staging tensor and copied to their final rows."""
         import torch
         import torch.distributed as dist
 
@@ -265,14 +277,49 @@ class ShardedVoxelizer:
             return self.voxelize()
         ws, rank = self.world, self.rank
         sizes = np.diff(self.bounds)
+        equal = bool(np.all(sizes == sizes[0]))
+        if exchange == "auto":
+            exchange = "p2p" if (dst is None and equal) else "allgather"
+        if exchange == "p2p" and not (dst is None and equal):
+            raise ValueError("the point-to-point exchange needs equal shards and an all-gather (dst=None)")
         cb = [chunk_bounds(int(s), nchunks) for s in sizes]               # per rank: its chunk boundaries (same count)
         tail = (self.V, self.C)
         cuda = self.device.type == "cuda"
+        comm = torch.cuda.Stream(device=self.device) if cuda else None
+        main = torch.cuda.current_stream(self.device) if cuda else None
+
+        if exchange == "p2p":
+            S = int(sizes[0])
+            full = torch.empty((ws, S) + tail, dtype=torch.float32, device=self.device)     # [rank][item]: the final layout
+            for c in range(len(cb[rank]) - 1):
+                lo, hi = int(cb[rank][c]), int(cb[rank][c + 1])
+                if hi == lo:
+                    continue
+                self._run(*self._items(lo, hi), out=full[rank, lo:hi])
+                if ws == 1:
+                    continue
+                ev = None
+                if cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                with (torch.cuda.stream(comm) if cuda else _null()):
+                    if cuda:
+                        comm.wait_event(ev)
+                    ops = []
+                    for k in range(1, ws):                                # staggered peers: rank r starts with r + 1
+                        to, frm = (rank + k) % ws, (rank - k) % ws
+                        ops.append(dist.P2POp(dist.isend, full[rank, lo:hi], self._global_rank(to), group=self.group))
+                        ops.append(dist.P2POp(dist.irecv, full[frm, lo:hi], self._global_rank(frm), group=self.group))
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+            if cuda:
+                main.wait_stream(comm)
+                full.record_stream(comm)
+            return full.view((self.n_items,) + tail)
+
         want = dst is None or rank == dst
         full = torch.empty((self.n_items,) + tail, dtype=torch.float32, device=self.device) if want else None
         local = torch.empty((self.n_local,) + tail, dtype=torch.float32, device=self.device)
-        comm = torch.cuda.Stream(device=self.device) if cuda else None
-        main = torch.cuda.current_stream(self.device) if cuda else None
         for c in range(len(cb[rank]) - 1):
             lo, hi = int(cb[rank][c]), int(cb[rank][c + 1])
             cmax = max(int(cb[r][c + 1] - cb[r][c]) for r in range(ws))
@@ -308,6 +355,13 @@ class ShardedVoxelizer:
             main.wait_stream(comm)
             local.record_stream(comm)
         return full
+
+    def _global_rank(self, group_rank):
+        """Rank in the default group of rank ``group_rank`` of this voxelizer's group (point-to-point ops address peers
+        by their global rank)."""
+        import torch.distributed as dist
+
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
 
 
 class _null:

@@ -1,6 +1,6 @@
 """CPU tier: `python bench.py --gpus 2` must start two ranks by itself (the driver's command shape) -- checked with
-`--dry-run`: gloo rendezvous on 127.0.0.1, the sharded data path of moleculekit_amd.distributed with a stand-in
-compute, both gathers.  Also: the launcher refuses to pretend when the node has fewer devices than asked for."""
+`--dry-run`: gloo rendezvous on 127.0.0.1, then bench.run_workload ITSELF (the function the timed GPU run uses: sharded
+loader, warm-up, timed loop between fences, max over ranks, both gathers) around a stand-in compute.  Also: the launcher refuses to pretend when the node has fewer devices than asked for."""
 import json
 import os
 import subprocess
@@ -24,6 +24,9 @@ def test_bench_gpus2_dry_run_spawns_two_ranks():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["ok"] is True
+    # the ranks went through bench.run_workload itself (sharded loader, timed loop, fences, max over ranks, the plain
+    # gather and the chunk-overlapped point-to-point one), not a look-alike
+    assert d["timed_path"] == "run_workload" and d["gather_error"] is None and d["gather_ms"] is not None and d["ms_per_step"] > 0
 
 
 def test_bench_refuses_more_gpus_than_devices():

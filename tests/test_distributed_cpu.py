@@ -67,12 +67,28 @@ def _worker(rank, world, port, B, q):
         sv = D.ShardedVoxelizer.from_loader(B, loader, nv, 1.0, weights=np.diff(p["atom_offsets"]) + 1.0, compute=compute)
         ok = ok and seen == [(int(sv.bounds[rank]), int(sv.bounds[rank + 1]))] and np.array_equal(sv.bounds, bounds)
         ok = ok and np.array_equal(sv.voxelize_gather(nchunks=2).numpy(), ref)
+        # equal shards (plain partition of an even batch): computed straight into the result, chunks exchanged point to
+        # point; the same values as the staged all-gather, whatever the chunking
+        if B % world == 0:
+            eq = D.ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0,
+                                              balance_by_atoms=False, compute=compute)
+            ok = ok and np.all(np.diff(eq.bounds) == B // world)
+            for nchunks in (1, 2, 5):
+                ok = ok and np.array_equal(eq.voxelize_gather(nchunks=nchunks).numpy(), ref)
+                ok = ok and np.array_equal(eq.voxelize_gather(nchunks=nchunks, exchange="allgather").numpy(), ref)
+            ok = ok and np.array_equal(eq.gather(eq.voxelize()).numpy(), ref)
+        else:
+            try:
+                sv.voxelize_gather(nchunks=2, exchange="p2p")
+                ok = False
+            except ValueError:
+                pass
         q.put((rank, bool(ok), [int(b) for b in bounds]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [7, 2, 1])
+@pytest.mark.parametrize("B", [7, 8, 2, 1])
 def test_sharded_voxelization_world2_gloo(B):
     import torch.multiprocessing as mp
 
