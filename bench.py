@@ -101,21 +101,29 @@ def pmc_traffic(workload, batch, tile_k):
     workload / batch (the passes are taken at the default batch)."""
     import glob
     if batch != DEFAULT_BATCH[workload] or tile_k not in (0, 8):
-        return None, None
+        return None, None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_counters.json")))
     if not files:
-        return None, None
+        return None, None, None
     d = json.load(open(files[-1]))
     if d.get("_items_per_launch") != batch:
-        return None, None
+        return None, None, None
     best = None                                    # the instance most launches ran (the LDS tier the host settled on)
     for k, v in d.items():
         if isinstance(v, dict) and ("k_voxelize_tiles<8" in k or "k_voxelize_tiles_lean<8" in k or "k_voxelize_items<8" in k) \
                 and "FETCH_SIZE" in v and "WRITE_SIZE" in v and (best is None or v.get("_launches", 0) > best.get("_launches", 0)):
             best = v
     if best is None:
-        return None, None
-    return int((best["WRITE_SIZE"] + 2.0 * best["FETCH_SIZE"]) * 1024), os.path.relpath(files[-1], ROOT)
+        return None, None, None
+    # the whole step: every kernel of the pass (pre-pass, tile kernel, tail), launches per step from the launch counts
+    step = None
+    if d.get("_full_batch_launches_only") and best.get("_launches"):
+        step = 0.0
+        for k, v in d.items():
+            if isinstance(v, dict) and k.startswith("mkamd::") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                step += (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024 * v.get("_launches", 0) / best["_launches"]
+        step = int(step)
+    return int((best["WRITE_SIZE"] + 2.0 * best["FETCH_SIZE"]) * 1024), os.path.relpath(files[-1], ROOT), step
 
 
 def algorithmic_bytes(p, nv, C=8):
@@ -371,8 +379,22 @@ def dry_run(args):
         raise SystemExit("dry run: sharding / gather mismatch")
 
 
+def _max_over_ranks(x, world):
+    """MAX of a host scalar over the ranks through a CPU tensor (the gloo side of the process group): nothing in or around
+    the timed region touches RCCL -- once an RCCL communicator exists in the process every kernel of the step runs 3-7 %
+    slower (measured with one rank, tools/gpu_r3_torchrun_probe2.sh), so it is first created by the gather legs, after
+    everything that is timed."""
+    if world > 1 or "RANK" in os.environ:
+        import torch
+        import torch.distributed as dist
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    return x
+
+
 def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, want_gather=False, want_single=False,
-                 compute=None, keep=()):
+                 compute=None, keep=(), sustain=False, defer_gather=False):
     """Time `steps` passes of the hot path over this rank's resident shard of a batch of world x B items of workload
     `name` (weak scaling).  The shard lives in a moleculekit_amd.distributed.ShardedVoxelizer: loaded by this rank
     alone, staged through pinned memory, resident in HBM before the timed region; no collective inside it.
@@ -418,11 +440,7 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     ctx.enable_kernel_timing(False)
     k_ms, k_n = ctx.read_kernel_timing()
     ctx.synchronize()
-    if world > 1 or "RANK" in os.environ:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = _max_over_ranks(elapsed, world)
     # sanity of what was produced inside the timed region (never a cached / skipped result)
     chk = out[0].double().sum().item()
     assert os.environ.get("MKAMD_DIAG") == "1" or (np.isfinite(chk) and chk > 0), "bench produced an empty grid"
@@ -430,7 +448,40 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     if "out" in keep:
         res["out"] = out
 
-    if want_gather:
+    if want_single:
+        # latency of ONE grid (SURVEY.md section 7 H2: a single 64^3 grid cannot fill 256 CUs for long)
+        from moleculekit_amd import batch
+        ctx.set_pipelining(False)
+        d = sv._d
+        o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
+        n1 = int(p["atom_offsets"][1])
+        offs1 = d["offs"][:2].contiguous()
+        args1 = (d["coords"][:n1], offs1, d["sigmas"][:n1], d["origins"][:1], nv, p["voxelsize"])
+        kw1 = dict(box=None if d["box"] is None else d["box"][:1], max_images=sv.max_images, out=o1, ctx=ctx)
+        for _ in range(3):
+            batch.voxelize_lattice_torch(*args1, **kw1)
+        torch.cuda.synchronize(dev)
+        s0 = time.perf_counter()
+        for _ in range(20):
+            batch.voxelize_lattice_torch(*args1, **kw1)
+        torch.cuda.synchronize(dev)
+        res["single_us"] = (time.perf_counter() - s0) / 20 * 1e6
+        ctx.set_pipelining(not args.no_pipeline)
+    min_s = float(getattr(args, "min_seconds", 0.0) or 0.0)
+    if sustain and min_s > 0 and elapsed > 0:
+        # the same steps again, long enough to be seen from outside (same fences, max over ranks): every rank runs the
+        # same number of steps, fixed up front from rank-independent numbers
+        n2 = int(min(max(steps, np.ceil(min_s / (elapsed / steps))), 200000))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        fence()
+        e2 = _max_over_ranks(time.perf_counter() - t0, world)
+        res["sustained"] = {"steps": n2, "seconds": round(e2, 4), "ms_per_step": round(e2 / n2 * 1e3, 4),
+                            "value": round(world * B * V * C * n2 / e2 / 1e6, 2), "unit": "Mvoxel-channels/s"}
+
+    def gather_legs():
         # (a secondary measurement: a failure in it -- RCCL, memory for the world x B result -- is reported on the line,
         #  it must not cost the primary one)
         try:
@@ -469,38 +520,31 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
             except Exception:                                    # noqa: BLE001
                 pass
 
-    if want_single:
-        # latency of ONE grid (SURVEY.md section 7 H2: a single 64^3 grid cannot fill 256 CUs for long)
-        from moleculekit_amd import batch
-        ctx.set_pipelining(False)
-        d = sv._d
-        o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
-        n1 = int(p["atom_offsets"][1])
-        offs1 = d["offs"][:2].contiguous()
-        args1 = (d["coords"][:n1], offs1, d["sigmas"][:n1], d["origins"][:1], nv, p["voxelsize"])
-        kw1 = dict(box=None if d["box"] is None else d["box"][:1], max_images=sv.max_images, out=o1, ctx=ctx)
-        for _ in range(3):
-            batch.voxelize_lattice_torch(*args1, **kw1)
-        torch.cuda.synchronize(dev)
-        s0 = time.perf_counter()
-        for _ in range(20):
-            batch.voxelize_lattice_torch(*args1, **kw1)
-        torch.cuda.synchronize(dev)
-        res["single_us"] = (time.perf_counter() - s0) / 20 * 1e6
-        ctx.set_pipelining(not args.no_pipeline)
-    del out, sv
-    if dev.type == "cuda":
-        torch.cuda.empty_cache()
+        return res
+
+    def release():
+        nonlocal out, sv
+        out = sv = None
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()
+
+    if want_gather and defer_gather:
+        res["_gather_legs"], res["_release"] = gather_legs, release     # main() runs them last: they create the RCCL communicator
+        return res
+    if want_gather:
+        gather_legs()
+    release()
     return res
 
 
 def roofline_of(res, workload, B, tile_k):
     k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
     achieved = res["alg"] / (k_avg_ms * 1e-3) / 1e9 if res["k_n"] else None
-    traffic, traffic_src = pmc_traffic(workload, B, tile_k)
+    traffic, traffic_src, step_traffic = pmc_traffic(workload, B, tile_k)
     return {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": "k_voxelize_tiles|_lean|_team|k_voxelize_items + k_tail (what runs between the timing events)",
+            "traffic": traffic, "traffic_of": "the dominant kernel alone (per launch)", "step_traffic": step_traffic,
+            "traffic_source": traffic_src, "kernel": "k_voxelize_tiles|_lean|_team|k_voxelize_items + k_tail (what runs between the timing events)",
             "kernel_avg_ms": round(k_avg_ms, 5), "kernel_launches": int(res["k_n"]),
             "algorithmic_bytes_per_launch": int(res["alg"])}
 
@@ -520,6 +564,11 @@ def main():
                     help="skip the secondary workloads (cfg1/cfg3/cfg4/cfg5 at N=1, the cfg3 batched-molecule leg at N>1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap step n+1's binning pre-pass with step n's tile kernel")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="after the timed K steps, keep stepping until this much wall time has been spent on the same workload and "
+                         "report it as `sustained` (the K-step region of a 64^3 workload is tens of milliseconds: too short for a "
+                         "utilisation sampler to see, and for the clocks to settle). 0 = skip")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-grid latency probe (profiling passes: every launch is a full batch)")
     ap.add_argument("--value-tol", type=float, default=0.0,
                     help="opt into the tolerance-aware reach (mkamd_ctx_set_value_tolerance): atoms are culled where they are "
                          "worth less than this (<= 1e-5). 0 (default) = the reference's hard 5 A cutoff; reported in `config`")
@@ -561,7 +610,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev)
+        # gloo for the fences / the max over ranks (CPU tensors), RCCL for the feature gathers: the RCCL communicator is
+        # created by the first GPU collective, i.e. by the gather legs at the very end -- its mere existence slows every
+        # kernel of the process by 3-7 % (_max_over_ranks), and the timed region has no collective to need it
+        dist.init_process_group("cpu:gloo,cuda:nccl")
 
     B = args.batch or DEFAULT_BATCH[args.workload]
     ctx = _lib.default_context(local)
@@ -579,11 +631,12 @@ def main():
     def fence():
         torch.cuda.synchronize(dev)
         if use_dist:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))                   # the barrier, on a CPU tensor: the gloo side of the group
         torch.cuda.synchronize(dev)
 
     res = run_workload(args.workload, B, args.steps, args.warmup, ctx, dev, rank, world, args, fence,
-                       want_gather=use_dist and not args.no_gather, want_single=rank == 0)
+                       want_gather=use_dist and not args.no_gather, want_single=rank == 0 and not args.no_single, sustain=True,
+                       defer_gather=True)
     p, nv, V, C, elapsed = res["p"], res["nv"], res["V"], res["C"], res["elapsed"]
 
     # secondary legs (every rank takes part; only rank 0 reports).  N = 1: the other BASELINE configs, so that their
@@ -605,6 +658,28 @@ def main():
                          "ms_per_step": round(r2["elapsed"] / steps2 * 1e3, 4), "grid": [int(v) for v in r2["nv"]],
                          "roofline": roofline_of(r2, nm, DEFAULT_BATCH[nm], args.tile_k)}
 
+    if not args.no_extra and args.workload == "cfg2" and not args.batch and world == 1 and args.value_tol == 0.0:
+        # the opt-in tolerance-aware reach (mkamd_ctx_set_value_tolerance, eps = 1e-6) on the headline workload: atoms
+        # are culled per tile where they are worth less than eps -- a secondary number, the headline keeps the hard cutoff
+        try:
+            ctx.set_value_tolerance(1e-6)
+            ctx.set_lds_tier(args.lds_tier)        # (the adaptive tier restarts from this workload's own statistics)
+            steps2 = max(3, args.steps // 2)
+            r3 = run_workload("cfg2", B, steps2, 4, ctx, dev, rank, world, args, fence)
+            extra["cfg2_value_tolerance_1e-6"] = {
+                "value": round(world * B * r3["V"] * r3["C"] * steps2 / r3["elapsed"] / 1e6, 2), "unit": "Mvoxel-channels/s",
+                "items_per_gpu_per_step": B, "steps": steps2, "ms_per_step": round(r3["elapsed"] / steps2 * 1e3, 4),
+                "note": "opt-in: values within 1e-6 of the exact mode (tests/test_gpu_parity.py), not bit-identical",
+                "roofline": {k: v for k, v in roofline_of(r3, "cfg2", B, args.tile_k).items() if k not in ("traffic", "step_traffic", "traffic_source", "traffic_of")}}
+        except Exception as e:                     # noqa: BLE001
+            extra["cfg2_value_tolerance_1e-6"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            ctx.set_value_tolerance(0.0)
+
+    if "_gather_legs" in res:                      # last: the first RCCL collective of the process
+        res.pop("_gather_legs")()
+        res.pop("_release")()
+
     if rank == 0:
         total_vc = world * B * V * C * args.steps
         k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
@@ -622,10 +697,12 @@ def main():
                        "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
                        "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
                        "value_tolerance": args.value_tol,
-                       "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region)",
+                       "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region; "
+                                      "fences over gloo, feature gathers over RCCL after everything timed)",
                        "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": roofline_of(res, args.workload, B, args.tile_k),
             "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if res["k_n"] else None,
+            "sustained": res.get("sustained"),
             "single_grid_latency_us": round(res["single_us"], 2) if "single_us" in res else None,
             "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
             "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
@@ -661,7 +738,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     if use_dist:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
 
 

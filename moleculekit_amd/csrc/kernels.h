@@ -108,10 +108,12 @@ struct GridDesc {
 };
 constexpr float REACH_STEP = 0.17f;   // levels 0..3: reach 5.00 / 4.56 / 4.06 / 3.50 A at the 5 A cutoff (H at eps = 1e-6: 3.48 A)
 
-// fraction of cutoff^2 within which a record can matter (1 unless the call runs with a value tolerance)
-MK_DEV float reach_frac(const GridDesc& g, int packed_cell)
+// r2 (a cutoff^2) scaled down to the reach of one record; untouched -- not even multiplied by one -- unless the call
+// runs with a value tolerance (a scalar branch around the arithmetic: the exact mode pays a register move at most)
+MK_DEV float reach_r2(const GridDesc& g, float r2, int packed_cell)
 {
-    return g.reach_tau > 0.f ? 1.f - REACH_STEP * (float)((unsigned)packed_cell >> 30) : 1.f;      // (a scalar branch)
+    if (g.reach_tau > 0.f) r2 *= 1.f - REACH_STEP * (float)((unsigned)packed_cell >> 30);
+    return r2;
 }
 
 // w of a present channel is clamped to a finite value (+inf is the "channel absent" marker): a
@@ -394,7 +396,6 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
     // ---- the atom's channels: w bit patterns (one pass over the sigmas serves the drop test AND the class
     //      discovery); registration is wave-cooperative, so every lane takes part ----
     bool any = false;
-    float w_min = mk_inf();                                          // the atom's widest sigma (tolerance-aware reach only)
     for (int c0 = 0; c0 < g.C; c0 += CHG) {
         unsigned wb[CHG];
         float w[CHG];
@@ -413,24 +414,9 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
 #pragma unroll
             for (int j = 0; j < CHG; ++j) any |= wb[j] != CLS_EMPTY;
         }
-        if (g.reach_tau > 0.f) {                                     // wave-uniform
-            if (!multi) {
-                if (cw.x != CLS_EMPTY) w_min = fminf(w_min, mk_uint_as_float(cw.x));
-            } else {
-#pragma unroll
-                for (int j = 0; j < CHG; ++j) w_min = fminf(w_min, w[j]);
-            }
-        }
         if (classes) wave_register_classes(cw.x, multi, wb, s_set, s_full);
     }
 
-    // reach level: the largest one whose reach^2 still covers tau / w_min (an entry is worth less than eps beyond it)
-    int level_bits = 0;
-    if (g.reach_tau > 0.f && w_min < mk_inf()) {
-        const float frac = g.reach_tau / (w_min * g.R2);             // (reach / cutoff)^2 this atom needs
-        const float lv = floorf((1.f - frac) * (1.f / REACH_STEP) - 1e-3f);
-        level_bits = (int)fminf(fmaxf(lv, 0.f), 3.f) << 30;           // NaN (w_min = 0 is impossible: clamped) -> 0
-    }
     const size_t t0 = (size_t)(act ? a : 0) * (size_t)g.img_cap;     // this atom's temp slots
     int used = 0;
     // an atom with no usable channel is dropped here (occupancy_utils.pyx:55-56)
@@ -492,7 +478,7 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         return inside;
     };
     auto park = [&](const int (&pc)[3], const float (&rel)[3], size_t cell, unsigned rank) {
-        tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20) | level_bits));
+        tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
         tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
         ++used;
     };
@@ -580,8 +566,29 @@ MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* 
                         float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                         unsigned* __restrict__ rec_cls, const unsigned (&tab)[NCLS], bool general)
 {
-    rec_pos[slot] = tmp_pos[t];
+    float4 pos = tmp_pos[t];
     const size_t a = g.img_cap == 1 ? t : t / (size_t)g.img_cap;
+    if (g.reach_tau > 0.f) {                                         // tolerance-aware reach (wave-uniform; off by default)
+        // the atom's widest sigma -> the largest reach level whose radius still covers tau / w_min (an entry is worth
+        // less than the tolerance beyond it); the level rides in the two spare bits of the packed cell word
+        float w_min = mk_inf();
+        for (int gq = 0; gq < g.G; ++gq) {
+            const uint2 cw = tmp_cls[a * (size_t)g.G + gq];
+            if (cw.y != ATOM_MULTI_SIGMA) {
+                if (cw.x != CLS_EMPTY) w_min = fminf(w_min, mk_uint_as_float(cw.x));
+            } else {
+                float w[CHG];
+                atom_channel_w(sigmas + a * (size_t)g.C, gq * CHG, g.C, g.w_scale, w);
+#pragma unroll
+                for (int c = 0; c < CHG; ++c) w_min = fminf(w_min, w[c]);
+            }
+        }
+        const float frac = g.reach_tau / (w_min * g.R2);             // (reach / cutoff)^2 this atom needs (0 for +inf)
+        const float lv = floorf((1.f - frac) * (1.f / REACH_STEP) - 1e-3f);
+        const int level = w_min < mk_inf() ? (int)fminf(fmaxf(lv, 0.f), 3.f) : 0;
+        pos.w = mk_int_as_float(mk_float_as_int(pos.w) | (level << 30));
+    }
+    rec_pos[slot] = pos;
     auto class_of = [&](unsigned bits) {
         unsigned id = 0;
 #pragma unroll
@@ -948,7 +955,7 @@ struct TileGeom {                     // wave-uniform description of the tile be
 // z-cells are adjacent in memory); the runs' bounds are fetched by one lane each, the chunks of all
 // runs are numbered 0..T-1 and processed in batches whose loads are all issued up front (the loads
 // are L2 / fabric round trips; chunk-at-a-time every chunk would pay ~1 us of exposed latency).
-// f(survives, record index, tile-relative x,y,z, class ids, reach fraction) is called by ALL lanes for every chunk.
+// f(survives, record index, tile-relative x,y,z, class ids, packed cell word) is called by ALL lanes for every chunk.
 struct CandChunk {                    // one chunk of 64 candidate records (one per lane), loads in flight
     float4 P;
     unsigned r, ids;
@@ -1068,9 +1075,8 @@ MK_DEV void cand_consume(const CandLoader& L, const CandChunk& ch, F&& f)
         const float gx = fmaxf(fabsf(ex) - HX, 0.f);
         const float gy = fmaxf(fabsf(ey) - 3.5f, 0.f);
         const float gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
-        const float fr = reach_frac(g, pk);
-        const bool surv = ch.valid && (gx * gx + gy * gy + gz * gz < g.R2cull * fr);
-        f(surv, LOAD_CODE ? ch.code : ch.r, ex, ey, ez, ch.ids, fr);
+        const bool surv = ch.valid && (gx * gx + gy * gy + gz * gz < reach_r2(g, g.R2cull, pk));
+        f(surv, LOAD_CODE ? ch.code : ch.r, ex, ey, ez, ch.ids, pk);
     }
 }
 
@@ -1276,17 +1282,17 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         // (how far along x an entry reaches depends on how far OUTSIDE the tile's y-z square it sits: rx^2 = R^2 - dyz^2;
         //  with the plain cutoff as reach 330 pair tests per voxel, tools/tile_model.py)
         const float R2m = R2 * 1.000002f;
-        auto x_reach = [&](float ex, float ey, float ez, float fr) {
+        auto x_reach = [&](float ex, float ey, float ez, int pk) {
             const float dy = mk_max(mk_abs(ey) - 3.5f, 0.f), dz = mk_max(mk_abs(ez) - 3.5f, 0.f);
-            const float rx2 = R2m * fr - mk_fma(dy, dy, dz * dz);
+            const float rx2 = reach_r2(g, R2m, pk) - mk_fma(dy, dy, dz * dz);
             const float lo = 0.5f - ex, hi = ex + 0.5f;               // distance to the nearest plane of the upper / lower half
             return (lo > 0.f && lo * lo > rx2) ? 1 : ((hi > 0.f && hi * hi > rx2) ? 2 : 0);
         };
 #pragma unroll
         for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
         mk_block_sync();
-        auto count_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, float fr) {
-            const int xr = x_reach(ex, ey, ez, fr);
+        auto count_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
+            const int xr = x_reach(ex, ey, ez, pk);
             for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
                 (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
             });
@@ -1328,14 +1334,14 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     const float ex = P[u].x + ((float)(pk & 1023) * tg.fcs + tg.offx);
                     const float ey = P[u].y + ((float)((pk >> 10) & 1023) * tg.fcs + tg.offy);
                     const float ez = P[u].z + ((float)((pk >> 20) & 1023) * tg.fcs + tg.offz);
-                    f(ok[u], 0u, ex, ey, ez, ids[u], reach_frac(g, pk));
+                    f(ok[u], 0u, ex, ey, ez, ids[u], pk);
                 }
             }
         };
         if constexpr (SURV_LIST) {
             // (worth it when most candidates are rejected, i.e. when there are many: a sparse tile's few chunks go the old way)
             if (!(MK_DIAG & 16) && runs.codable && runs.N > 4u * WAVE) {
-                auto keep_survivor = [&](bool surv, unsigned code, float, float, float, unsigned, float) {
+                auto keep_survivor = [&](bool surv, unsigned code, float, float, float, unsigned, int) {
                     const unsigned long long m = mk_ballot(surv);
                     const unsigned pos = nsurv + (unsigned)mk_rank_in_mask(m);
                     if (surv && pos < (unsigned)SURV_CAP) s_surv[pos] = (unsigned short)code;
@@ -1528,8 +1534,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
-            auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, float fr) {
-                const int xr = x_reach(ex, ey, ez, fr);
+            auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
+                const int xr = x_reach(ex, ey, ez, pk);
                 for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
                     const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                     sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
@@ -1581,7 +1587,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     for (int k = 0; k < K; ++k) m[k] = INF_BITS;
                     mk_block_sync();
                     for_each_candidate<K, true, 1>(g, tg, runs, rec_pos, clsp,
-                        [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, float) {
+                        [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int) {
                             const unsigned id = surv ? (ids >> (4 * c0)) & 0xfu : 0u;
                             const float wc = id ? mk_uint_as_float(table[id - 1u]) : INF;
                             const bool has = wc < INF;                       // false for +inf and NaN
@@ -1626,7 +1632,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         // ---- general path (arbitrary per-entry sigma: more sigma classes than the id table holds):
         //      chunk by chunk, per-channel compaction through LDS, cutoff test per (voxel, entry) ----
         mk_block_sync();
-        auto body = [&](bool surv, unsigned r, float ex, float ey, float ez, unsigned, float) {
+        auto body = [&](bool surv, unsigned r, float ex, float ey, float ez, unsigned, int) {
             float4 W0 = make_float4(INF, INF, INF, INF), W1 = W0;
             if (surv) { W0 = w0p[r]; W1 = w1p[r]; }
             const float wch[CHG] = {W0.x, W0.y, W0.z, W0.w, W1.x, W1.y, W1.z, W1.w};
@@ -1802,7 +1808,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
         const float ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
         const float ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
         const float gx = fmaxf(fabsf(ex) - HX, 0.f), gy = fmaxf(fabsf(ey) - 3.5f, 0.f), gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
-        if (gx * gx + gy * gy + gz * gz < g.R2cull * reach_frac(g, pk)) {
+        if (gx * gx + gy * gy + gz * gz < reach_r2(g, g.R2cull, pk)) {
             const unsigned slot = (s_gstart[gi] & ~1u) + mk_lds_add(&cur[gi], 1u);
             sx[slot] = ex; sx[ITEM_STRIDE + slot] = ey; sx[2 * ITEM_STRIDE + slot] = ez;
         }
@@ -1950,7 +1956,7 @@ MK_DEV void voxelize_item_tile_unsorted(const GridDesc& g, const int b, const in
             ey = P.y + ((float)((pk >> 10) & 1023) * fcs + offy);
             ez = P.z + ((float)((pk >> 20) & 1023) * fcs + offz);
             const float gx = fmaxf(fabsf(ex) - HX, 0.f), gy = fmaxf(fabsf(ey) - 3.5f, 0.f), gz = fmaxf(fabsf(ez) - 3.5f, 0.f);
-            surv = gx * gx + gy * gy + gz * gz < g.R2cull * reach_frac(g, pk);
+            surv = gx * gx + gy * gy + gz * gz < reach_r2(g, g.R2cull, pk);
             if (surv) {
                 if (carries_w) {
                     const float4 W0 = w0p[r], W1 = w0p[(size_t)g.M + r];
