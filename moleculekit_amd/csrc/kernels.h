@@ -2285,9 +2285,12 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
 
 // The last launch of a call: (a) the tiles the tile kernel left for the dense instance (usually none), (b) the
 // exact cut-off fix-up, which must see a tile's final values -- in ONE launch instead of two (5 us of every small
-// call).  Blocks [0, dense_wgs) take dense tiles; the rest are fix-up waves, and only when there WERE dense tiles do
-// they wait for the dense blocks to finish: those have lower block indices, so they were all dispatched -- running or
-// done -- before the first fix-up wave started, and the wait cannot starve them.
+// call).  `dense_wgs` workgroups take dense tiles; the rest are fix-up waves, and only when there WERE dense tiles do
+// they wait for the dense ones to finish.  That wait must not depend on the order workgroups are dispatched in (HIP
+// promises none): when there are dense tiles a workgroup's ROLE is not its block index but a ticket it draws as it
+// starts running -- the first `dense_wgs` tickets are the dense roles.  Whoever waits therefore drew a later ticket than
+// every dense role: those workgroups are already running (or done), hold their resources and cannot be starved by the
+// waiters.  Without dense tiles (nearly every call) nobody waits and the block index is the role, no atomic at all.
 // Block 0 also mirrors the tier statistics and the error flag to host-visible memory and clears the OTHER copy of the
 // dense words (two copies alternate from call to call, so that nothing still reads what is being cleared).
 template <int K, int ECAP, typename SigT>
@@ -2304,7 +2307,7 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
     __shared__ double s_best[WAVE];
     const unsigned n = dense_words[0], total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     if (blockIdx.x == 0) {
-        if (threadIdx.x <= (unsigned)DENSE_WORDS) other_words[threadIdx.x] = 0u;       // (word DENSE_WORDS = the done counter)
+        if (threadIdx.x <= (unsigned)DENSE_WORDS + 1u) other_words[threadIdx.x] = 0u;  // (+ the done counter and the role tickets)
         if (feedback && threadIdx.x == 0) {                                // host-visible: drives the next calls' tier
 #pragma unroll
             for (int t = 0; t < NTIER; ++t) feedback[t] = dense_words[1 + t];
@@ -2312,8 +2315,13 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
             feedback[NTIER + 1] = (unsigned)*err_flag;  // mirror of the device-side error flag (set by the binning, long done)
         }
     }
-    if (blockIdx.x < dense_wgs) {
-        for (unsigned i = blockIdx.x; i < n; i += dense_wgs) {             // wave-uniform
+    unsigned role = blockIdx.x;
+    if (n != 0u) {                                                         // wave-uniform, rare: roles by order of arrival
+        if (threadIdx.x == 0) role = mk_atomic_add(&dense_words[DENSE_WORDS + 1], 1u);
+        role = mk_uniform(mk_shfl(role, 0));
+    }
+    if (role < dense_wgs) {
+        for (unsigned i = role; i < n; i += dense_wgs) {                   // wave-uniform
             const unsigned e = dense_list[i];
             voxelize_tile<K, true, ECAP>(g, e % total_tiles, (int)(e / total_tiles), cell_start, rec_pos, nullptr, rec_cls, cls_table, out, nullptr, nullptr);
             mk_block_sync();                                               // LDS arrays are reused by the next tile
@@ -2331,7 +2339,7 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
         mk_block_sync();
         mk_threadfence();
     }
-    exact_fixup_block<SigT>(g, blockIdx.x - dense_wgs, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
+    exact_fixup_block<SigT>(g, role - dense_wgs, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
                             tmp_cls, out, s_best);
 }
 

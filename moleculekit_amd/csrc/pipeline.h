@@ -262,7 +262,7 @@ int launch_tiles(BE& be, int tier, int flavour, dim3 tgrid, const TailArgs& ta, 
 // The dense words (dense-tile list length, tier statistics, k_tail's done counter) live in a buffer of their own, in TWO
 // copies that alternate from call to call: a call's last launch clears the copy the NEXT call will use.
 struct CounterState { void* ptr = nullptr; size_t clean = 0; void* wptr = nullptr; bool wclean = false; unsigned parity = 0; };
-constexpr int DENSE_SET_WORDS = DENSE_WORDS + 1;     // + the done counter of k_tail's dense blocks
+constexpr int DENSE_SET_WORDS = DENSE_WORDS + 2;     // + the done counter of k_tail's dense blocks + its role tickets
 
 // The lattice hot path: bin -> scan -> fill -> tile kernel.  All pointers in P are device pointers.
 template <class BE>
