@@ -632,7 +632,13 @@ __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, 
                                unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
 {
     if (g.prepass_hurry) mk_wave_priority_high();
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware order: the dispatcher places block i on XCD i % 8; give each XCD a contiguous eighth of the temp slots =
+    // whole items.  The records of an item are a few hundred KB: written by ONE XCD they meet in its L2 and leave as full
+    // lines; spread over all eight (consecutive blocks of an item) every 128-byte line leaves in up to eight pieces
+    // (WRITE_SIZE 324 MB for 187 MB of records).  Placement is a speed matter only: any block may take any slots.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned lb = blockIdx.x < 8u * per_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    const size_t t = (size_t)lb * blockDim.x + threadIdx.x;
     if (t >= (size_t)g.M) return;
     const uint2 ix = tmp_idx[t];
     if (ix.x == TMP_UNUSED) return;

@@ -391,6 +391,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                                 (const unsigned*)chunks, (unsigned*)start))) return st;
         }
         if (P.total_atoms > 0) {
+            // (FOUR temp slots per thread with their loads in flight together -- for calls that run alone on the chip, where the
+            //  48-register budget does not apply -- were measured: 261 us against 212, the pass is bound by its scattered
+            //  stores, not by the round trips in front of them)
             st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
                                           (const uint2*)tidx, (const uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
                               : be.launch(k_bin_fill<float>, fgrid, ablk, g, (const float*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
