@@ -613,7 +613,10 @@ def main():
         # gloo for the fences / the max over ranks (CPU tensors), RCCL for the feature gathers: the RCCL communicator is
         # created by the first GPU collective, i.e. by the gather legs at the very end -- its mere existence slows every
         # kernel of the process by 3-7 % (_max_over_ranks), and the timed region has no collective to need it
-        dist.init_process_group("cpu:gloo,cuda:nccl")
+        import datetime
+        # (a collective that cannot complete raises after two minutes instead of holding the node: the gather legs are
+        #  secondary measurements wrapped in try / except, the headline line still prints)
+        dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=120))
 
     B = args.batch or DEFAULT_BATCH[args.workload]
     ctx = _lib.default_context(local)
@@ -627,6 +630,7 @@ def main():
     # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)
     ctx.set_pipelining(not args.no_pipeline)
     ctx.set_value_tolerance(args.value_tol)
+    ctx.set_direct_binning(int(os.environ.get("MKAMD_DIRECT", "-1")))          # A-B knob: one-pass direct binning (-1 auto, 0 off, 1 on)
 
     def fence():
         torch.cuda.synchronize(dev)

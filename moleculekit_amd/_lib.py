@@ -42,6 +42,7 @@ SIGNATURES = {
     "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_value_tolerance": (_c_int, [_vp, ctypes.c_double]),
+    "mkamd_ctx_set_direct_binning": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
@@ -194,6 +195,11 @@ class Context:
     def set_fine_cells(self, on: bool):
         """Half-cutoff cells instead of cutoff-sized ones (A-B benchmarking; same values to float32 noise)."""
         _check(load().mkamd_ctx_set_fine_cells(self._h, int(bool(on))))
+
+    def set_direct_binning(self, mode: int):
+        """-1 automatic (default), 0 the count / scan / fill chain always, 1 the one-pass direct binning whenever the
+        geometry allows (include/mkamd_voxel.h); bit-identical results."""
+        _check(load().mkamd_ctx_set_direct_binning(self._h, int(mode)))
 
     def set_value_tolerance(self, eps: float):
         """Tolerance-aware reach (include/mkamd_voxel.h): 0 = off (default, the reference's hard 5 A cutoff), else every

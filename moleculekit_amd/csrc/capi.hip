@@ -74,6 +74,7 @@ struct mkamd_ctx {
     int tile_items = -1;                   // -1 = automatic
     int tile_team = -1;                    // -1 = automatic
     int fine_cells = 0;                    // 1 = half-cutoff cells (A-B benchmarking)
+    int direct = -1;                       // direct binning: -1 automatic, 0 never, 1 whenever possible (mkamd_ctx_set_direct_binning)
     double value_tol = 0.0;                // tolerance-aware reach (mkamd_ctx_set_value_tolerance); 0 = the hard 5 A cutoff everywhere
     unsigned* fb_host = nullptr;           // pinned, device-visible: tier statistics of the last finished call
     unsigned* fb_dev = nullptr;
@@ -442,6 +443,14 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+int mkamd_ctx_set_direct_binning(mkamd_ctx* ctx, int mode)
+try {
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (mode < -1 || mode > 1) return fail(MKAMD_EINVAL, "direct binning mode must be -1 (automatic), 0 (never) or 1 (whenever possible)");
+    ctx->direct = mode;
+    return MKAMD_OK;
+} MK_API_CATCH
+
 int mkamd_ctx_set_value_tolerance(mkamd_ctx* ctx, double eps)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
@@ -615,7 +624,7 @@ try {
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
     P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
-    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol;
+    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol; P.direct = ctx->direct;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;

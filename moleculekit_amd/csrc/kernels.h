@@ -105,7 +105,14 @@ struct GridDesc {
     // an entry contributes less than eps beyond w * d^2 = reach_tau = eps^(-1/6), so its record carries a reach LEVEL
     // (bits 30-31 of the packed cell word) and the tile culls it at reach^2 = (1 - REACH_STEP * level) * cutoff^2
     float reach_tau;
+    // direct binning (round 3; k_bin_direct): records live at cell * cell_cap + rank, no scan and no fill pass.
+    // direct_words points at the call's direct counters [B * cstride] followed by DIRECT_WORDS control words; nullptr = the
+    // call has no direct pass.  Whether the records ARE in that layout is decided on the device (word DIRECT_FAILED).
+    int cell_cap;
+    unsigned spill_base, spill_cap;
+    const unsigned* direct_words;
 };
+enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4 };
 constexpr float REACH_STEP = 0.17f;   // levels 0..3: reach 5.00 / 4.56 / 4.06 / 3.50 A at the 5 A cutoff (H at eps = 1e-6: 3.48 A)
 
 // r2 (a cutoff^2) scaled down to the reach of one record; untouched -- not even multiplied by one -- unless the call
@@ -114,6 +121,12 @@ MK_DEV float reach_r2(const GridDesc& g, float r2, int packed_cell)
 {
     if (g.reach_tau > 0.f) r2 *= 1.f - REACH_STEP * (float)((unsigned)packed_cell >> 30);
     return r2;
+}
+
+// is the call's record array in the direct layout (k_bin_direct succeeded)?  One scalar load per wave.
+MK_DEV bool direct_layout(const GridDesc& g)
+{
+    return g.direct_words != nullptr && mk_uniform(g.direct_words[(size_t)g.B * g.cstride + DIRECT_FAILED]) == 0u;
 }
 
 // w of a present channel is clamped to a finite value (+inf is the "channel absent" marker): a
@@ -531,6 +544,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, uint2* __restrict__ tmp_cls,
                                 unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
 {
+    if (direct_layout(g)) return;                        // the direct pass of this call has binned everything (block-uniform)
     if (g.prepass_hurry) mk_wave_priority_high();
     __shared__ unsigned s_set[CLS_BLOCK_SET];
     __shared__ unsigned s_full;
@@ -554,6 +568,135 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
         if (threadIdx.x < CLS_BLOCK_SET)
             block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct binning (round 3): ONE pass instead of count -> reduce -> scan -> fill.  A cell owns `cell_cap` record slots;
+// an atom's rank inside its cell (the same returning atomic as k_bin_count) IS its slot, so the record -- position and
+// class ids -- is written in place: no temp records (32 B per atom written and read back), no scan, no permutation
+// pass (44 + 20 B per atom instead of 132).  What the pass cannot know it assumes and checks:
+//   * the class ids come from the class table the PREVIOUS call on this workspace left behind (the sigma classes of a
+//     workload do not change from call to call); an atom whose sigma is not in it, an atom with several distinct sigmas,
+//     an overflowed table;
+//   * a cell that receives more atoms than it has slots sends the surplus to the call's spill area, which every tile
+//     reads as one more candidate run; a full spill area
+// -- any of these raises DIRECT_FAILED, and the kernels of the count / scan / fill chain, which are enqueued behind this
+// pass in every call and return at once while the word is clear, do the call the old way (and leave the new class
+// table).  The tile kernels read the word too (find_candidate_runs).  Open boundaries, one channel group.
+// Measured on cfg2 (256 x 50 000 atoms, same box, tools/gpu_r3_direct.sh): 397 us against 338 + 189 + 48 for count + fill +
+// reductions, but the chain's kernels still cost 82 us to launch and leave, and the tile kernel reads 27 cell runs instead
+// of 9-16 column runs (+2 %): in-order step 2.47 against 2.55 ms (-3 %), pipelined 2.28 against 2.27 (nothing).  With an
+// XCD-aware block order (an item's atoms binned by one XCD, as k_bin_fill does) the pass takes 594 us: the item's rank
+// atomics then all arrive together.  OPT-IN (mkamd_ctx_set_direct_binning(1)); the automatic mode keeps the chain.
+// ------------------------------------------------------------------------------------------------
+template <typename SigT>
+MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
+                                 long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
+                                 const double* __restrict__ affine, unsigned* __restrict__ counts /* + DIRECT_WORDS */,
+                                 float4* __restrict__ rec_pos, unsigned* __restrict__ rec_cls,
+                                 const unsigned* __restrict__ cls_table, unsigned* __restrict__ block_sets)
+{
+    if (g.prepass_hurry) mk_wave_priority_high();
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_full;
+    if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
+    if (threadIdx.x == 0) s_full = 0u;
+    mk_block_sync();
+    unsigned* const words = counts + (size_t)g.B * g.cstride;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long a_first = (long long)blockIdx.x * blockDim.x;
+    const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
+    int b_lo, b_hi;
+    items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
+    const long long a = a_first + threadIdx.x;
+    const bool act = a < total_atoms;
+    // the class table of the previous call: lane s holds class s (CLS_EMPTY beyond the table's end)
+    const unsigned tab = lane < CLS_TABLE_WORDS ? cls_table[lane] : CLS_EMPTY;
+    bool failed = mk_readlane(tab, CLS_OVERFLOW) != CLS_EMPTY;                 // more classes than ids: that call took the general path
+
+    // ---- channels: one radius per atom is the rule; its class id by election (a handful of distinct values per wave) ----
+    float w[CHG];
+    uint2 cw = make_uint2(CLS_EMPTY, 0u);
+    if (act) cw = atom_channel_w(sigmas + (size_t)a * g.C, 0, g.C, g.w_scale, w);
+    const bool multi = cw.y == ATOM_MULTI_SIGMA;
+    const bool any = cw.x != CLS_EMPTY && !multi;
+    unsigned wb[CHG];
+#pragma unroll
+    for (int j = 0; j < CHG; ++j) wb[j] = CLS_EMPTY;
+    wave_register_classes(cw.x, false, wb, s_set, &s_full);                    // (the fix-up waves of k_tail read the blocks' sets)
+    unsigned id = 0u;
+    {
+        bool pending = any;
+        for (;;) {                                                             // wave-uniform: one trip per distinct value
+            const unsigned long long todo = mk_ballot(pending);
+            if (todo == 0ull) break;
+            const unsigned lb = mk_readlane(cw.x, mk_ctz64(todo));
+            const unsigned long long hit = mk_ballot(lane < NCLS && tab == lb);
+            const unsigned cid = hit ? (unsigned)mk_ctz64(hit) + 1u : 0u;
+            if (pending && cw.x == lb) { id = cid; pending = false; }
+            failed = failed || cid == 0u;
+        }
+    }
+    failed = failed || mk_ballot(multi) != 0ull;
+
+    // ---- position -> (cell, cell-relative offset) in double, exactly as bin_atom does ----
+    bool want = any;
+    int pc[3] = {0, 0, 0};
+    float rel[3] = {0.f, 0.f, 0.f};
+    int b = 0;
+    if (want) {
+        int lo = b_lo, hi = b_hi + 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+        }
+        b = lo;
+        const int nvox[3] = {g.nx, g.ny, g.nz};
+        float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
+        if (affine != nullptr) {
+            const double* A = affine + 12 * (size_t)b;
+            const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+            xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+            xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+            xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+        }
+        const double inv_cs = 1.0 / (double)g.cs, cmid = 0.5 * (double)(g.cs - 1);
+        const int nc[3] = {g.ncx, g.ncy, g.ncz};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double q = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+            if (q < -g.Rp || q > (double)(nvox[ax] - 1) + g.Rp) want = false;
+            const int ci = (int)floor((q + 0.5) * inv_cs);
+            pc[ax] = ci + g.h;
+            want = want && (pc[ax] >= 0) && (pc[ax] < nc[ax]);
+            rel[ax] = (float)(q - ((double)ci * (double)g.cs + cmid));
+        }
+    }
+    const size_t cell = want ? (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2] : (size_t)0;
+    const unsigned rank = wave_rank_in_cell(want, (unsigned)cell, counts);
+    if (want) {
+        unsigned slot;
+        if (rank < (unsigned)g.cell_cap) {
+            slot = (unsigned)cell * (unsigned)g.cell_cap + rank;
+        } else {                                                               // the cell is full: the call's spill area
+            const unsigned sp = mk_atomic_add(&words[DIRECT_SPILLED], 1u);
+            slot = g.spill_base + (sp < g.spill_cap ? sp : 0u);
+            if (sp >= g.spill_cap) { want = false; failed = true; }
+        }
+        if (want) {
+            int level = 0;
+            if (g.reach_tau > 0.f) {                                           // tolerance-aware reach (fill_record's rule)
+                const float frac = g.reach_tau / (mk_uint_as_float(cw.x) * g.R2);
+                level = (int)fminf(fmaxf(floorf((1.f - frac) * (1.f / REACH_STEP) - 1e-3f), 0.f), 3.f);
+            }
+            rec_pos[slot] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20) | (level << 30)));
+            rec_cls[slot] = id * cw.y;                                         // ids <= 15: no carry between nibbles
+        }
+    }
+    if (mk_ballot(failed) != 0ull && lane == 0) words[DIRECT_FAILED] = 1u;
+    mk_block_sync();
+    if (threadIdx.x < CLS_BLOCK_SET)
+        block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
 }
 
 // One cell-sorted record: the parked position + the atom's per-channel class ids (or w values on the general path).
@@ -631,6 +774,7 @@ __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, 
                                float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                                unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
 {
+    if (direct_layout(g)) return;                        // nothing to permute: the direct pass wrote the records in place
     if (g.prepass_hurry) mk_wave_priority_high();
     // XCD-aware order: the dispatcher places block i on XCD i % 8; give each XCD a contiguous eighth of the temp slots =
     // whole items.  The records of an item are a few hundred KB: written by ONE XCD they meet in its L2 and leave as full
@@ -855,8 +999,10 @@ MK_KERNEL(SCAN_THREADS) void k_scan_sums_inplace(unsigned* __restrict__ chunk_su
 static_assert(SCAN_THREADS == 256, "the fused pre-pass kernels run both jobs with 256 threads");
 MK_KERNEL(256) void k_prepass_reduce1(const unsigned* __restrict__ block_sets, unsigned nblk, unsigned rows_per_block,
                                       unsigned nl1, unsigned* __restrict__ l1sets,
-                                      const unsigned* __restrict__ counts, size_t n, unsigned* __restrict__ chunk_sums)
+                                      const unsigned* __restrict__ counts, size_t n, unsigned* __restrict__ chunk_sums,
+                                      const unsigned* __restrict__ direct_failed /* nullptr, or the call's DIRECT_FAILED word */)
 {
+    if (direct_failed != nullptr && *direct_failed == 0u) return;     // the direct pass binned everything: the class table stays
     mk_wave_priority_high();
     if (blockIdx.x < nl1)                                              // block-uniform
         merge_classes_block(block_sets, nblk, (unsigned)CLS_BLOCK_SET, rows_per_block, l1sets, nullptr, blockIdx.x);
@@ -865,8 +1011,10 @@ MK_KERNEL(256) void k_prepass_reduce1(const unsigned* __restrict__ block_sets, u
 }
 
 MK_KERNEL(256) void k_prepass_reduce2(const unsigned* __restrict__ l1sets, unsigned nl1, unsigned* __restrict__ cls_table,
-                                      unsigned* __restrict__ chunk_sums, unsigned nchunks)
+                                      unsigned* __restrict__ chunk_sums, unsigned nchunks,
+                                      const unsigned* __restrict__ direct_failed)
 {
+    if (direct_failed != nullptr && *direct_failed == 0u) return;
     mk_wave_priority_high();
     if (nl1 != 0u && blockIdx.x == 0)                                  // block-uniform
         merge_classes_block(l1sets, nl1, (unsigned)MERGE_SET, nl1, nullptr, cls_table, 0u);
@@ -901,8 +1049,9 @@ MK_KERNEL(SMALL_PREPASS_THREADS) void k_prepass_small(const unsigned* __restrict
 
 MK_KERNEL(SCAN_THREADS) void k_scan_finish(unsigned* __restrict__ in /* zeroed once read: see run_lattice */, size_t n,
                                            const unsigned* __restrict__ chunk_offsets,
-                                           unsigned* __restrict__ out /* n+1 */)
+                                           unsigned* __restrict__ out /* n+1 */, const unsigned* __restrict__ direct_failed)
 {
+    if (direct_failed != nullptr && *direct_failed == 0u) return;
     mk_wave_priority_high();
     __shared__ unsigned lds[8];
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_PER_THREAD;
@@ -991,10 +1140,37 @@ template <int K>
 MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const unsigned* __restrict__ cell_start)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int nyc = tg.cy_hi - tg.cy_lo + 1;
-    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 49 (cell edge > half the cutoff radius, plan_lattice)
     CandRuns cr;
     cr.r0 = 0; cr.len = 0;
+    if (direct_layout(g)) {
+        // direct layout: a cell's records sit at cell * cap (its count in the direct counters), so every CELL around the
+        // tile is a run of its own (<= 63 of them, the host checked), and the call's spill area -- records of cells that
+        // overflowed their capacity, normally none -- is one more run that every tile looks at: candidates are culled
+        // by their distance to the tile, so seeing a record too many is harmless
+        const unsigned* __restrict__ cnt = g.direct_words;
+        const int nxc = tg.cx_hi - tg.cx_lo + 1, nyc = tg.cy_hi - tg.cy_lo + 1, nzc = tg.cz_hi - tg.cz_lo + 1;
+        const int ncells = nxc * nyc * nzc;
+        if (lane < ncells) {
+            const int pcz = tg.cz_lo + lane % nzc, pcy = tg.cy_lo + (lane / nzc) % nyc, pcx = tg.cx_lo + lane / (nzc * nyc);
+            const float fcs = (float)g.cs;
+            const float cx0 = (float)((pcx - g.h) * g.cs) - 0.5f, cy0 = (float)((pcy - g.h) * g.cs) - 0.5f, cz0 = (float)((pcz - g.h) * g.cs) - 0.5f;
+            const float gx = fmaxf(fmaxf((float)tg.x0 - (cx0 + fcs), cx0 - (float)(tg.x0 + K - 1)), 0.f);
+            const float gy = fmaxf(fmaxf((float)tg.y0 - (cy0 + fcs), cy0 - (float)(tg.y0 + 7)), 0.f);
+            const float gz = fmaxf(fmaxf((float)tg.z0 - (cz0 + fcs), cz0 - (float)(tg.z0 + 7)), 0.f);
+            if (gx * gx + gy * gy + gz * gz < g.R2cull) {
+                const size_t cell = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz + pcz;
+                const unsigned n = cnt[cell];
+                cr.r0 = (unsigned)cell * (unsigned)g.cell_cap;
+                cr.len = n < (unsigned)g.cell_cap ? n : (unsigned)g.cell_cap;
+            }
+        } else if (lane == WAVE - 1) {
+            const unsigned n = cnt[(size_t)g.B * g.cstride + DIRECT_SPILLED];
+            cr.r0 = g.spill_base;
+            cr.len = n < g.spill_cap ? n : g.spill_cap;
+        }
+    } else {
+    const int nyc = tg.cy_hi - tg.cy_lo + 1;
+    const int ncols = (tg.cx_hi - tg.cx_lo + 1) * nyc;           // <= 49 (cell edge > half the cutoff radius, plan_lattice)
     if (lane < ncols) {
         const int pcx = tg.cx_lo + lane / nyc, pcy = tg.cy_lo + lane % nyc;
         // a cell holds positions in [c0 - 0.5, c0 + cs - 0.5), c0 = (pc - h) * cs (bin_atom: locate); its gap to the tile's voxel box
@@ -1015,6 +1191,7 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
                 cr.len = cell_start[cbase + cb + 1] - cr.r0;      // z-run of cells is contiguous
             }
         }
+    }
     }
     const unsigned incl = wave_scan_inclusive(cr.len);
     cr.pre = incl - cr.len;

@@ -30,7 +30,7 @@ namespace mkamd {
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT, WS_DENSE_WORDS,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT, WS_DENSE_WORDS, WS_DIRECT_COUNT,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS, WS_H_STAGE,
     // distance_utils row (dist_pipeline.h)
@@ -56,6 +56,9 @@ struct LatticeProblem {
     int prepass_mode = -1;                  // -1 = automatic, 0 = multi-kernel chain, 1 = one-launch per-item pre-pass (if it fits)
     int fine_cells = 0;                     // 1 = half-cutoff cells (A-B benchmarking, see plan_lattice)
     double value_tol = 0.0;                 // > 0: entries may be dropped where they are worth less than this (tolerance-aware reach)
+    int direct = -1;                        // direct binning (k_bin_direct): 1 = whenever the geometry allows; -1 (automatic) and 0 = the chain
+    int cell_cap = 0;                       // record slots per cell of the direct layout (0 = 128; tests shrink it to see cells spill)
+    unsigned spill_cap = 0;                 // slots of the direct layout's spill area (0 = max(4096, atoms / 16))
     int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
     int tile_items = -1;                    // -1 = automatic (a workgroup per item for batches of ligand-sized items), 0 = never, 1 = always
     // device pointers
@@ -92,6 +95,7 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     // value step at the cutoff = 1-exp(-(1/(R2 w))^6) > 5e-6  <=>  R2 w < (5e-6)^(-1/6) = 7.647  (sigma > 1.81 A)
     g.w_exact_max = (float)(7.647 / (R * R));
     // 1 - exp(-t^-6) < eps beyond t = w d^2 = eps^(-1/6); off (0) unless the caller opted in.  Capped at 1e-5: the parity bound
+    g.cell_cap = 0; g.spill_base = 0u; g.spill_cap = 0u; g.direct_words = nullptr;
     g.reach_tau = (P.value_tol > 0.0) ? (float)std::pow(std::min(P.value_tol, 1e-5), -1.0 / 6.0) : 0.f;
     g.Rp = R + 1e-3;
     g.rint = (int)std::ceil(R);
@@ -172,7 +176,7 @@ int run_scan(BE& be, unsigned* counts /* cleared by the last kernel */, size_t n
     if (st) return st;
     if ((st = be.launch(k_scan_chunk_sums, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (const unsigned*)counts, n, (unsigned*)chunks))) return st;
     if ((st = be.launch(k_scan_sums_inplace, dim3(1), dim3(SCAN_THREADS), (unsigned*)chunks, (unsigned)nchunks))) return st;
-    return be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (const unsigned*)chunks, starts);
+    return be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), counts, n, (const unsigned*)chunks, starts, (const unsigned*)nullptr);
 }
 
 // LDS tier of the tile kernel: forced (0..NTIER-1), or the leanest tier that at most 5 % of the tiles of
@@ -303,9 +307,37 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_DENSE_WORDS, 2 * DENSE_SET_WORDS * sizeof(unsigned), &dwords_all, set))) return st;
     if ((st = be.ensure(WS_CELL_COUNT, count_bytes, &count, set))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
-    if ((st = be.ensure(WS_REC_POS, (size_t)g.M * sizeof(float4), &rpos, set))) return st;
+    // direct binning (k_bin_direct): big open-boundary calls of one channel group whose tiles see at most 63 cells
+    void* dcnt = nullptr;
+    size_t mrec = (size_t)g.M;
+    {
+        auto span = [&](int width) {                 // most cells a tile of `width` voxels (aligned to it) sees along one axis
+            int best = 0;
+            for (int x0 = 0; x0 < (g.cs > width ? g.cs : width); x0 += width) {
+                const int n = ((x0 + width - 1 + g.rint) >> g.cs_log2) - ((x0 - g.rint) >> g.cs_log2) + 1;
+                best = n > best ? n : best;
+            }
+            return best;
+        };
+        const int cap = P.cell_cap > 0 ? P.cell_cap : 128;
+        const unsigned spill = P.spill_cap > 0 ? P.spill_cap : (unsigned)std::max<long long>(4096, P.total_atoms / 16);
+        const unsigned long long slots = (unsigned long long)ncells * (unsigned)cap + spill;
+        const bool direct = !per_item && !g.pbc && g.G == 1 && !g.force_general && P.direct != 0 && P.total_atoms > 0 &&
+                            P.direct == 1 && cap <= (1 << SURV_OFF_BITS) &&        // (opt-in: measured -3 % in order, nothing pipelined)
+                           
+                            span(g.K) * span(8) * span(8) <= WAVE - 1 && slots <= 0xFFFF0000ull;
+        if (direct) {
+            g.cell_cap = cap; g.spill_base = (unsigned)(ncells * (size_t)cap); g.spill_cap = spill;
+            mrec = std::max<size_t>(mrec, (size_t)slots);
+            const size_t dbytes = ((ncells + DIRECT_WORDS) * sizeof(unsigned) + 255) & ~(size_t)255;
+            if ((st = be.ensure(WS_DIRECT_COUNT, dbytes, &dcnt, set))) return st;
+            if ((st = be.fill(dcnt, 0, dbytes))) return st;         // the direct counters and the control words of this call
+            g.direct_words = (const unsigned*)dcnt;
+        }
+    }
+    if ((st = be.ensure(WS_REC_POS, mrec * sizeof(float4), &rpos, set))) return st;
     if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw, set))) return st;
-    if ((st = be.ensure(WS_REC_CLS, (size_t)g.M * sizeof(unsigned) * g.G, &rcls, set))) return st;
+    if ((st = be.ensure(WS_REC_CLS, (g.G == 1 ? mrec : (size_t)g.M) * sizeof(unsigned) * g.G, &rcls, set))) return st;
     if ((st = be.ensure(WS_CLS_TABLE, (per_item ? (size_t)g.B : (size_t)1) * CLS_TABLE_WORDS * sizeof(unsigned), &ctab, set))) return st;
     if ((st = be.ensure(WS_ERR, sizeof(int), &eflag, 0))) return st;
     if ((st = be.ensure(WS_TMP_POS, (size_t)g.M * sizeof(float4), &tpos, set))) return st;
@@ -362,6 +394,15 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
         fix_summary = g.force_general ? nullptr : (const unsigned*)bsets;
         fix_waves = P.total_atoms > 0 ? nblk : 0u;
+        const unsigned* dfail = g.direct_words ? g.direct_words + ncells + DIRECT_FAILED : nullptr;
+        if (g.direct_words) {
+            // the one-pass form first; the chain below is enqueued behind it and returns at once unless the pass gave up
+            st = P.sigmas_f64 ? be.launch(k_bin_direct<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas, P.origins,
+                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (unsigned*)rcls, (const unsigned*)ctab, (unsigned*)bsets)
+                              : be.launch(k_bin_direct<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas, P.origins,
+                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (unsigned*)rcls, (const unsigned*)ctab, (unsigned*)bsets);
+            if (st) return st;
+        }
         if (P.total_atoms > 0) {
             auto bin = [&](auto kern, auto* sig) {
                 return be.launch(kern, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine,
@@ -374,7 +415,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
         const bool do_classes = P.total_atoms > 0 && !g.force_general;
         if (!do_classes && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
-        if (ncells <= SMALL_PREPASS_MAX_CELLS && nblk <= SMALL_PREPASS_MAX_BLOCKS) {
+        if (!g.direct_words && ncells <= SMALL_PREPASS_MAX_CELLS && nblk <= SMALL_PREPASS_MAX_BLOCKS) {
             // a small call (one grid): one launch instead of three dependent ones
             if ((st = be.launch(k_prepass_small, dim3(1), dim3(SMALL_PREPASS_THREADS), (const unsigned*)bsets, do_classes ? nblk : 0u,
                                 (unsigned*)ctab, (unsigned*)count, (unsigned)ncells, (unsigned*)start))) return st;
@@ -384,11 +425,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
             if ((st = be.ensure(WS_SCAN_CHUNKS, nchunks * sizeof(unsigned), &chunks, set))) return st;
             const unsigned nl1_eff = do_classes ? nl1 : 0u;
             if ((st = be.launch(k_prepass_reduce1, dim3(nl1_eff + (unsigned)nchunks), dim3(256), (const unsigned*)bsets, nblk, rows_per_block,
-                                nl1_eff, (unsigned*)l1sets, (const unsigned*)count, ncells, (unsigned*)chunks))) return st;
+                                nl1_eff, (unsigned*)l1sets, (const unsigned*)count, ncells, (unsigned*)chunks, dfail))) return st;
             if ((st = be.launch(k_prepass_reduce2, dim3(do_classes ? 2u : 1u), dim3(256), (const unsigned*)l1sets, nl1_eff, (unsigned*)ctab,
-                                (unsigned*)chunks, (unsigned)nchunks))) return st;
+                                (unsigned*)chunks, (unsigned)nchunks, dfail))) return st;
             if ((st = be.launch(k_scan_finish, dim3((unsigned)nchunks), dim3(SCAN_THREADS), (unsigned*)count, ncells,
-                                (const unsigned*)chunks, (unsigned*)start))) return st;
+                                (const unsigned*)chunks, (unsigned*)start, dfail))) return st;
         }
         if (P.total_atoms > 0) {
             // (FOUR temp slots per thread with their loads in flight together -- for calls that run alone on the chip, where the

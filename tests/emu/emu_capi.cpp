@@ -68,7 +68,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
                          const float* box, int max_images, int tile_k, int force_general, const double* affine, float* features,
                          int* err_flag_out, int lds_tier, unsigned* feedback_io /* NTIER+1: in = previous call's, out = this call's */,
                          int prepass_mode, int tile_team, int fine_cells, int repeat /* calls on ONE backend */, int* fills_out, int tile_items,
-                         double value_tol)
+                         double value_tol, int direct, int cell_cap, unsigned spill_cap, unsigned* direct_words_out /* [DIRECT_WORDS] of the last call */)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -77,7 +77,7 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     LatticeProblem P;
     P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
     P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
-    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier; P.prepass_mode = prepass_mode; P.tile_team = tile_team; P.fine_cells = fine_cells; P.tile_items = tile_items; P.value_tol = value_tol;
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k; P.force_general = force_general; P.lds_tier = lds_tier; P.prepass_mode = prepass_mode; P.tile_team = tile_team; P.fine_cells = fine_cells; P.tile_items = tile_items; P.value_tol = value_tol; P.direct = direct; P.cell_cap = cell_cap; P.spill_cap = spill_cap;
     if (feedback_io) for (int i = 0; i <= NTIER; ++i) be.feedback[i] = feedback_io[i];
     if (box && max_images <= 0) {
         max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);
@@ -93,6 +93,13 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
         st = run_lattice(be, P, g_err);
     }
     if (fills_out) *fills_out = be.fills;
+    if (direct_words_out) {
+        // what the direct pass of the LAST call reported (all ones when the call had none)
+        GridDesc gd; std::string e2;
+        const bool had = be.bufs[WS_DIRECT_COUNT] != nullptr && plan_lattice(P, gd, e2) == ST_OK;
+        const size_t nc = had ? (size_t)gd.B * (size_t)gd.cstride : 0;
+        for (int i = 0; i < DIRECT_WORDS; ++i) direct_words_out[i] = had ? ((const unsigned*)be.bufs[WS_DIRECT_COUNT])[nc + i] : 0xffffffffu;
+    }
     if (err_flag_out) *err_flag_out = *(int*)be.bufs[WS_ERR];
     if (feedback_io) for (int i = 0; i <= NTIER; ++i) feedback_io[i] = be.feedback[i];
     return st;
@@ -124,7 +131,7 @@ int emu_calculate_occupancy(const double* centers, long long V, const float* coo
             if (inject_lattice_status) return inject_lattice_status;
             const long long offs[2] = {0, N};
             const int r = emu_voxelize_lattice(1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, 0, 0, nullptr, tmp.data(),
-                                               nullptr, -1, nullptr, -1, -1, 0, 1, nullptr, -1, 0.0);
+                                               nullptr, -1, nullptr, -1, -1, 0, 1, nullptr, -1, 0.0, 0, 0, 0u, nullptr);
             if (!r) route = 1;
             return r;
         },

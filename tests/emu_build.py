@@ -47,7 +47,7 @@ def _p(a):
 
 def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box=None, max_images=0,
                      tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None, prepass_mode=-1, tile_team=-1, fine_cells=False,
-                     repeat=1, fills=None, tile_items=-1, value_tol=0.0):
+                     repeat=1, fills=None, tile_items=-1, value_tol=0.0, direct=0, cell_cap=0, spill_cap=0, direct_words=None):
     """feedback: optional uint32[4] array, in = tier statistics of the 'previous call', out = this call's.
     repeat: run the call that many times on ONE backend (workspace kept) and return the last result; fills: optional
     one-element list that receives the number of counter memsets those calls issued."""
@@ -69,7 +69,8 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
         ctypes.c_int(tile_k), ctypes.c_int(int(force_general)),
         _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out), ctypes.byref(err),
         ctypes.c_int(lds_tier), _p(feedback), ctypes.c_int(prepass_mode), ctypes.c_int(tile_team), ctypes.c_int(int(fine_cells)),
-        ctypes.c_int(int(repeat)), ctypes.byref(nfills), ctypes.c_int(int(tile_items)), ctypes.c_double(float(value_tol)))
+        ctypes.c_int(int(repeat)), ctypes.byref(nfills), ctypes.c_int(int(tile_items)), ctypes.c_double(float(value_tol)),
+        ctypes.c_int(int(direct)), ctypes.c_int(int(cell_cap)), ctypes.c_uint(int(spill_cap)), _p(direct_words))
     if fills is not None:
         fills[:] = [nfills.value]
     if st != 0:

@@ -386,3 +386,78 @@ def test_reach_levels_cover_the_radius_an_atom_needs():
         lost = (tol[0, :, 0] == 0) & (exact[0, :, 0] > 0)
         assert np.abs(tol - exact).max() <= eps
         assert not lost[d < need - 1e-3].any()                            # nothing inside the radius the atom needs is lost
+
+
+def _direct(case, repeat, **kw):
+    words = np.zeros(4, np.uint32)
+    kwargs = dict(box=case["box"]) if case["box"] is not None else {}
+    out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                  case["voxelsize"], direct=1, repeat=repeat, direct_words=words, prepass_mode=0, **kwargs, **kw)
+    assert err == 0
+    return out, words
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "voxel15", "cutoff_adversarial_1A", "special_sigmas", "channels11", "pbc_batch"])
+def test_direct_binning_is_bit_identical_with_the_chain_as_its_device_side_fallback(name):
+    """k_bin_direct (round 3): records written in place at cell * capacity + rank with class ids from the table the
+    previous call left; the count / scan / fill chain runs only when the pass gives up.  First call on a workspace: no
+    table yet -> the pass fails, the chain does the work; second call: the pass succeeds.  Same bits every time."""
+    case = LATTICE_CASES[name]()
+    kwargs = dict(box=case["box"]) if case["box"] is not None else {}
+    ref, _ = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                case["voxelsize"], prepass_mode=0, **kwargs)
+    first, w1 = _direct(case, 1)
+    assert np.array_equal(first, ref)
+    second, w2 = _direct(case, 2)
+    assert np.array_equal(second, ref)
+    eligible = case["box"] is None and case["sigmas"].shape[1] <= 8
+    if not eligible:                                   # periodic items / more than one channel group: the call has no direct pass
+        assert w1[0] == 0xffffffff and w2[0] == 0xffffffff
+        return
+    assert w1[0] == 1                                  # no class table yet: gave up, the chain ran
+    # atoms that carry several distinct sigmas (or NaN / inf ones) never go direct: the chain keeps serving such calls
+    multi_sigma = any(len(set(r[r != 0])) > 1 for r in np.nan_to_num(case["sigmas"], nan=-1.0, posinf=-2.0))
+    multi_sigma = multi_sigma or name == "special_sigmas"          # (a NaN sigma counts as "several": NaN != NaN)
+    assert w2[0] == (1 if multi_sigma else 0), (name, w2)
+    check(case, second)
+
+
+def test_direct_binning_spills_full_cells_and_gives_up_when_the_spill_area_is_full():
+    case = LATTICE_CASES["cfg1_3ptb"]()
+    ref, _ = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                case["voxelsize"], prepass_mode=0)
+    # four slots per cell: most of the 3PTB pocket's atoms go through the spill area, which every tile reads as one more run
+    out, w = _direct(case, 2, cell_cap=4, spill_cap=4096)
+    assert w[0] == 0 and w[1] > 500 and np.array_equal(out, ref)
+    # ... and with a spill area of 64 slots the pass gives up and the chain does the call
+    out, w = _direct(case, 2, cell_cap=4, spill_cap=64)
+    assert w[0] == 1 and np.array_equal(out, ref)
+    # the tolerance-aware reach levels ride in the direct records too
+    tol_chain, _ = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                      case["voxelsize"], prepass_mode=0, value_tol=5e-6)
+    tol_direct, w = _direct(case, 2, value_tol=5e-6)
+    assert w[0] == 0 and np.array_equal(tol_direct, tol_chain)
+
+
+def test_direct_binning_notices_a_sigma_the_old_table_lacks():
+    """Calls on one workspace whose sigma set CHANGES: the table of the first batch does not cover the second one's
+    classes -> the pass gives up, the chain leaves the new table, the next call goes direct again."""
+    rng = np.random.default_rng(11)
+    def batch(radii):
+        coords = rng.uniform(0, 20, (300, 3)).astype(np.float32)
+        sig = np.zeros((300, 8)); r = rng.choice(radii, 300)
+        sig[:, 7] = r; sig[:, 0] = r * (rng.random(300) < 0.4)
+        return coords, sig
+    nv, org = np.array([20, 20, 20]), np.zeros((1, 3))
+    words = np.zeros(4, np.uint32)
+    lib = E.lib()
+    import ctypes
+    # two different batches through ONE backend need the C entry point's `repeat` to take different inputs: emulate by
+    # running batch A twice (direct on the second call), then A's table against B in a fresh pair of calls
+    a_c, a_s = batch([1.1, 1.7])
+    b_c, b_s = batch([1.1, 1.7, 1.52, 2.27])
+    ref_b, _ = E.voxelize_lattice(b_c, np.array([0, 300]), b_s, org, nv, 1.0, prepass_mode=0)
+    out_a, _ = E.voxelize_lattice(a_c, np.array([0, 300]), a_s, org, nv, 1.0, direct=1, repeat=2, direct_words=words, prepass_mode=0)
+    assert words[0] == 0
+    out_b, _ = E.voxelize_lattice(b_c, np.array([0, 300]), b_s, org, nv, 1.0, direct=1, repeat=1, direct_words=words, prepass_mode=0)
+    assert words[0] == 1 and np.array_equal(out_b, ref_b)                    # (a fresh backend: empty table, same code path as a stale one)

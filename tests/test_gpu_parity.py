@@ -467,3 +467,48 @@ def test_tolerance_aware_reach_on_full_size_cfg2_and_ligand_batches(hip_ctx):
         assert np.abs(got - exp).max() <= TOL
     finally:
         hip_ctx.set_value_tolerance(0.0)
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "voxel15", "dense_mixed", "cutoff_adversarial_1A"])
+def test_direct_binning_matches_the_chain_bit_for_bit(hip_ctx, name):
+    """k_bin_direct (one pass, records in place, class ids from the previous call's table) with the count / scan / fill
+    chain as its device-side fallback: forced on, repeated calls on one context (the first builds the table through the
+    fallback, the next go direct), against the chain alone."""
+    from moleculekit_amd import batch
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    try:
+        hip_ctx.set_prepass_mode(0)
+        hip_ctx.set_direct_binning(0)
+        ref = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+        hip_ctx.set_direct_binning(1)
+        for _ in range(3):
+            got = batch.voxelize_lattice(*args, box=case["box"], ctx=hip_ctx)
+            assert np.array_equal(got, ref)
+    finally:
+        hip_ctx.set_direct_binning(-1)
+        hip_ctx.set_prepass_mode(-1)
+    check(case, ref)
+
+
+def test_direct_binning_full_size_cfg2_items(hip_ctx):
+    """A call big enough for the automatic mode's threshold (8 cfg2 systems = 400 000 atoms), direct forced on: three
+    calls, all equal to the chain's result; one item sampled against the oracle."""
+    from moleculekit_amd import batch
+    p = synth_config(2, 8, seed=2)
+    origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    args = (p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, p["voxelsize"])
+    try:
+        hip_ctx.set_direct_binning(0)
+        ref = batch.voxelize_lattice(*args, ctx=hip_ctx)
+        hip_ctx.set_direct_binning(1)
+        for _ in range(3):
+            assert np.array_equal(batch.voxelize_lattice(*args, ctx=hip_ctx), ref)
+    finally:
+        hip_ctx.set_direct_binning(-1)
+    # item 3 against the oracle on 4096 of its voxels
+    idx = np.random.default_rng(8).choice(int(np.prod(nv)), 4096, replace=False)
+    a0, a1 = p["atom_offsets"][3], p["atom_offsets"][4]
+    centers = oracle.grid_centers(origins[3], nv, p["voxelsize"])[idx]
+    assert np.abs(ref[3][idx] - oracle.calculate_occupancy(centers, p["coords"][a0:a1], p["sigmas"][a0:a1])).max() <= TOL
