@@ -593,7 +593,7 @@ template <typename SigT>
 MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
                                  long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                  const double* __restrict__ affine, unsigned* __restrict__ counts /* + DIRECT_WORDS */,
-                                 float4* __restrict__ rec_pos, unsigned* __restrict__ rec_cls,
+                                 float4* __restrict__ rec_pos, unsigned* __restrict__ rec_cls, uint2* __restrict__ tmp_cls,
                                  const unsigned* __restrict__ cls_table, unsigned* __restrict__ block_sets)
 {
     if (g.prepass_hurry) mk_wave_priority_high();
@@ -617,7 +617,10 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
     // ---- channels: one radius per atom is the rule; its class id by election (a handful of distinct values per wave) ----
     float w[CHG];
     uint2 cw = make_uint2(CLS_EMPTY, 0u);
-    if (act) cw = atom_channel_w(sigmas + (size_t)a * g.C, 0, g.C, g.w_scale, w);
+    if (act) {
+        cw = atom_channel_w(sigmas + (size_t)a * g.C, 0, g.C, g.w_scale, w);
+        tmp_cls[a] = cw;                                                       // (the fix-up waves of k_tail find an atom's sigma here)
+    }
     const bool multi = cw.y == ATOM_MULTI_SIGMA;
     const bool any = cw.x != CLS_EMPTY && !multi;
     unsigned wb[CHG];

@@ -398,9 +398,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (g.direct_words) {
             // the one-pass form first; the chain below is enqueued behind it and returns at once unless the pass gave up
             st = P.sigmas_f64 ? be.launch(k_bin_direct<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas, P.origins,
-                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (unsigned*)rcls, (const unsigned*)ctab, (unsigned*)bsets)
+                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (unsigned*)rcls, (uint2*)tcls, (const unsigned*)ctab, (unsigned*)bsets)
                               : be.launch(k_bin_direct<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas, P.origins,
-                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (unsigned*)rcls, (const unsigned*)ctab, (unsigned*)bsets);
+                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (unsigned*)rcls, (uint2*)tcls, (const unsigned*)ctab, (unsigned*)bsets);
             if (st) return st;
         }
         if (P.total_atoms > 0) {

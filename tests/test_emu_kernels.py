@@ -8,7 +8,7 @@ import pytest
 
 from oracle import oracle
 from tests import emu_build as E
-from tests.cases import LATTICE_CASES, TOL, check, golden
+from tests.cases import LATTICE_CASES, TOL, check, golden, oracle_lattice
 
 
 @pytest.mark.parametrize("name", sorted(LATTICE_CASES))
@@ -461,3 +461,21 @@ def test_direct_binning_notices_a_sigma_the_old_table_lacks():
     assert words[0] == 0
     out_b, _ = E.voxelize_lattice(b_c, np.array([0, 300]), b_s, org, nv, 1.0, direct=1, repeat=1, direct_words=words, prepass_mode=0)
     assert words[0] == 1 and np.array_equal(out_b, ref_b)                    # (a fresh backend: empty table, same code path as a stale one)
+
+
+def test_direct_binning_feeds_the_exact_cutoff_fixup():
+    """The fix-up waves of k_tail find an atom's sigma in the temp class descriptors: the direct pass must leave them as the
+    chain does.  Wide single-sigma atoms (Na, user sigmas of 2.75 / 3 A) placed so that voxel centres sit at
+    d^2 = 25 +- {0, 1e-6, 1e-5, 1e-4} A^2: without the fix-up several of these values are wrong by up to 2e-3."""
+    from tests.cases import case_cutoff_adversarial
+    case = case_cutoff_adversarial(1.0)
+    sig = case["sigmas"].copy()
+    widest = sig.max(axis=1, keepdims=True)
+    sig = np.where(sig != 0, widest, 0.0)                                  # one sigma per atom: the direct pass can take them
+    exp = oracle_lattice(case["coords"], case["atom_offsets"], sig, case["origins"], case["nvoxels"], case["voxelsize"])
+    args = (case["coords"], case["atom_offsets"], sig, case["origins"], case["nvoxels"], case["voxelsize"])
+    chain, _ = E.voxelize_lattice(*args, prepass_mode=0)
+    words = np.zeros(4, np.uint32)
+    direct, _ = E.voxelize_lattice(*args, prepass_mode=0, direct=1, repeat=2, direct_words=words)
+    assert words[0] == 0                                                   # the second call did go direct
+    assert np.abs(chain - exp).max() <= TOL and np.array_equal(direct, chain)

@@ -512,3 +512,32 @@ def test_direct_binning_full_size_cfg2_items(hip_ctx):
     a0, a1 = p["atom_offsets"][3], p["atom_offsets"][4]
     centers = oracle.grid_centers(origins[3], nv, p["voxelsize"])[idx]
     assert np.abs(ref[3][idx] - oracle.calculate_occupancy(centers, p["coords"][a0:a1], p["sigmas"][a0:a1])).max() <= TOL
+
+
+def test_direct_binning_leaves_the_fixup_what_it_needs(hip_ctx):
+    """The exact cut-off fix-up reads every atom's sigma class from the temp descriptors of the SAME call.  A context that
+    voxelized another batch first (same sigma classes: the table is there, stale descriptors too) must still re-evaluate
+    the wide single-sigma atoms of an adversarial batch (voxel centres at d^2 = 25 +- 1e-6 .. 1e-4 A^2) when that batch
+    goes through the direct pass."""
+    from moleculekit_amd import batch
+    from tests.cases import case_cutoff_adversarial
+    case = case_cutoff_adversarial(1.0)
+    sig = np.where(case["sigmas"] != 0, case["sigmas"].max(axis=1, keepdims=True), 0.0)
+    args = (case["coords"], case["atom_offsets"], sig, case["origins"], case["nvoxels"], case["voxelsize"])
+    exp = oracle_lattice(*args)
+    rng = np.random.default_rng(4)
+    other = (rng.uniform(0, 30, case["coords"].shape).astype(np.float32), case["atom_offsets"], np.roll(sig, 37, axis=0),
+             case["origins"], case["nvoxels"], case["voxelsize"])
+    try:
+        hip_ctx.set_prepass_mode(0)
+        hip_ctx.set_direct_binning(0)
+        chain = batch.voxelize_lattice(*args, ctx=hip_ctx)
+        hip_ctx.set_direct_binning(1)
+        for _ in range(2):
+            batch.voxelize_lattice(*other, ctx=hip_ctx)                    # leaves the class table -- and ITS descriptors
+        direct = batch.voxelize_lattice(*args, ctx=hip_ctx)
+    finally:
+        hip_ctx.set_direct_binning(-1)
+        hip_ctx.set_prepass_mode(-1)
+    assert np.abs(chain - exp).max() <= TOL
+    assert np.array_equal(direct, chain)
