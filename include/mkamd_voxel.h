@@ -83,12 +83,18 @@ int mkamd_ctx_set_prepass_mode(mkamd_ctx* ctx, int mode);
  * Values agree to float32 noise (the cell-relative offsets are rounded at a different magnitude), both within the
  * 1e-5 parity bound. */
 int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on);
-/* Binning of open-boundary calls of one channel group: 1 = the one-pass direct form -- records written in place at
- * cell * capacity + rank, class ids from the class table the previous call on the context left, the count / scan / fill
- * chain enqueued behind it as a device-side fallback that returns at once unless the pass gave up (a sigma the table
- * lacks, an atom with several sigmas, a full spill area) --; 0 and -1 (default) = the chain alone.  Results are
- * bit-identical either way.  Opt-in because it is a small win only for calls that are NOT pipelined (cfg2, 256 grids:
- * 2.47 against 2.55 ms in order, 2.28 against 2.27 pipelined; pre-pass HBM traffic 0.9 GB instead of 1.9). */
+/* Binning of open-boundary calls of one channel group in the DIRECT layout (records written in place at
+ * cell * capacity + rank; surplus of a full cell in the item's spill area).  Results are bit-identical in every mode.
+ *  -1 (default): SMALL calls (the reference's pattern: one molecule per call; at most 1 024 tile waves) take the
+ *      one-launch pre-pass -- the class table lives across the calls of the context and is extended on the spot, atoms
+ *      with several sigmas and more classes than ids are handled in place, nothing is enqueued behind it: three launches
+ *      per call instead of five; big calls take the count / scan / fill chain;
+ *   0: the chain (or the per-item pre-pass) always;
+ *   1: additionally, big calls use the one-pass form with class ids from the table the previous call left and the chain
+ *      enqueued behind it as a device-side fallback that returns at once unless the pass gave up (a sigma the table lacks,
+ *      an atom with several sigmas, a full spill area).  Opt-in because it only pays for calls that are NOT pipelined
+ *      (cfg2, 256 grids: 2.47 against 2.55 ms in order, 2.28 against 2.27 pipelined; pre-pass traffic 0.9 GB, not 1.9);
+ *   2: the one-launch pre-pass for calls of any size whose geometry allows it (tests). */
 int mkamd_ctx_set_direct_binning(mkamd_ctx* ctx, int mode);
 /* Tolerance-aware reach (opt-in; 0 = off, the default: the reference's hard 5 A cutoff for every atom,
  * occupancy_utils.pyx:53).  An (atom, channel) entry is worth 1 - exp(-(sigma/r)^12) < eps beyond r = sigma * eps^(-1/12)

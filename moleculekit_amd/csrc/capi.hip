@@ -446,7 +446,7 @@ try {
 int mkamd_ctx_set_direct_binning(mkamd_ctx* ctx, int mode)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (mode < -1 || mode > 1) return fail(MKAMD_EINVAL, "direct binning mode must be -1 (automatic), 0 (never) or 1 (whenever possible)");
+    if (mode < -1 || mode > 2) return fail(MKAMD_EINVAL, "direct binning mode must be -1 (automatic), 0 (never), 1 (whenever possible) or 2 (the one-launch pre-pass whenever possible)");
     ctx->direct = mode;
     return MKAMD_OK;
 } MK_API_CATCH

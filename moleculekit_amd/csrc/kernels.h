@@ -109,7 +109,7 @@ struct GridDesc {
     // direct_words points at the call's direct counters [B * cstride] followed by DIRECT_WORDS control words; nullptr = the
     // call has no direct pass.  Whether the records ARE in that layout is decided on the device (word DIRECT_FAILED).
     int cell_cap;
-    unsigned spill_base, spill_cap;
+    unsigned spill_base, spill_cap;   // spill areas: item b owns slots [spill_base + b * spill_cap, + spill_cap), counted in its spare cell counter
     const unsigned* direct_words;
 };
 enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4 };
@@ -578,8 +578,8 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
 //   * the class ids come from the class table the PREVIOUS call on this workspace left behind (the sigma classes of a
 //     workload do not change from call to call); an atom whose sigma is not in it, an atom with several distinct sigmas,
 //     an overflowed table;
-//   * a cell that receives more atoms than it has slots sends the surplus to the call's spill area, which every tile
-//     reads as one more candidate run; a full spill area
+//   * a cell that receives more atoms than it has slots sends the surplus to its item's spill area, which every tile of
+//     the item reads as one more candidate run; a full spill area
 // -- any of these raises DIRECT_FAILED, and the kernels of the count / scan / fill chain, which are enqueued behind this
 // pass in every call and return at once while the word is clear, do the call the old way (and leave the new class
 // table).  The tile kernels read the word too (find_candidate_runs).  Open boundaries, one channel group.
@@ -681,9 +681,10 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         unsigned slot;
         if (rank < (unsigned)g.cell_cap) {
             slot = (unsigned)cell * (unsigned)g.cell_cap + rank;
-        } else {                                                               // the cell is full: the call's spill area
-            const unsigned sp = mk_atomic_add(&words[DIRECT_SPILLED], 1u);
-            slot = g.spill_base + (sp < g.spill_cap ? sp : 0u);
+        } else {                                                               // the cell is full: the item's spill area
+            const unsigned sp = mk_atomic_add(&counts[(size_t)b * g.cstride + g.ncell], 1u);     // (the item's spare counter)
+            (void)mk_atomic_add(&words[DIRECT_SPILLED], 1u);                   // statistics
+            slot = g.spill_base + (unsigned)b * g.spill_cap + (sp < g.spill_cap ? sp : 0u);
             if (sp >= g.spill_cap) { want = false; failed = true; }
         }
         if (want) {
@@ -697,6 +698,165 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         }
     }
     if (mk_ballot(failed) != 0ull && lane == 0) words[DIRECT_FAILED] = 1u;
+    mk_block_sync();
+    if (threadIdx.x < CLS_BLOCK_SET)
+        block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The pre-pass of a SMALL call in one launch (round 3: one molecule per call, the reference's own call pattern --
+// voxeldescriptors.py:251-365).  A grid-wide barrier inside one persistent kernel costs 12-25 us at 1 024 workgroups on
+// this chip (one device-scope atomic per workgroup serialises at ~12 ns; tools/gridsync.hip) against ~3.3 us for a launch
+// boundary, so the way to a short call is FEWER launches, not one: this kernel replaces count + class table / scan + fill
+// (26 us for a 50 000-atom item, three boundaries) by the direct layout of k_bin_direct made infallible:
+//   * the class table lives ACROSS calls; a w it does not hold yet is inserted on the spot (one CAS per wave and new
+//     value: the first call of a workload pays a few hundred of them, later calls none);
+//   * when the table is full the overflow word is raised: every record carries its w values too (rec_w), and the tile
+//     kernels then take the general path as they do for the chain (k_tail empties the table afterwards, so that the
+//     next call starts over);
+//   * atoms with several distinct sigmas look every channel up;
+//   * the spill area holds every atom of the call, so it cannot overflow.
+// Nothing is left to fall back to: no chain is enqueued behind it.  The counters are zero when the call starts and
+// k_tail zeroes them again (no memset launch).  Same arithmetic as bin_atom / fill_record: the records are the chain's.
+// ------------------------------------------------------------------------------------------------
+// class id (1..NCLS, 0 = the table is full) of one w bit pattern per lane (CLS_EMPTY: none).  `tab`: lane s holds what
+// this wave knows of table slot s.  All lanes of the wave call it.
+MK_DEV unsigned wave_class_id_insert(unsigned bits, unsigned& tab, unsigned* __restrict__ table)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    unsigned id = 0u;
+    bool pending = bits != CLS_EMPTY;
+    for (;;) {                                                                 // wave-uniform: one trip per distinct value
+        const unsigned long long todo = mk_ballot(pending);
+        if (todo == 0ull) break;
+        const unsigned lb = mk_readlane(bits, mk_ctz64(todo));
+        const unsigned long long hit = mk_ballot(lane < NCLS && tab == lb);
+        unsigned cid = hit ? (unsigned)mk_ctz64(hit) + 1u : 0u;
+        if (cid == 0u) {                                                       // not in the table as this wave knows it
+            unsigned got = 0u;
+            if (lane == 0) {
+                for (unsigned sl = 0; sl < (unsigned)NCLS; ++sl) {
+                    const unsigned old = mk_atomic_cas(&table[sl], CLS_EMPTY, lb);
+                    if (old == CLS_EMPTY || old == lb) { got = sl + 1u; break; }
+                }
+                if (got == 0u) table[CLS_OVERFLOW] = 0u;                       // more classes than ids: the general path
+            }
+            cid = mk_readlane(got, 0);
+            if (cid != 0u && lane == (int)cid - 1) tab = lb;
+        }
+        if (pending && bits == lb) { id = cid; pending = false; }
+    }
+    return id;
+}
+
+template <typename SigT>
+MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
+                               long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
+                               const double* __restrict__ affine, unsigned* __restrict__ counts /* + DIRECT_WORDS */,
+                               float4* __restrict__ rec_pos, float4* __restrict__ rec_w /* planes g.M apart */,
+                               unsigned* __restrict__ rec_cls, uint2* __restrict__ tmp_cls,
+                               unsigned* __restrict__ cls_table, unsigned* __restrict__ block_sets)
+{
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_full;
+    if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
+    if (threadIdx.x == 0) s_full = 0u;
+    mk_block_sync();
+    unsigned* const words = counts + (size_t)g.B * g.cstride;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long a_first = (long long)blockIdx.x * blockDim.x;
+    const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
+    int b_lo, b_hi;
+    items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
+    const long long a = a_first + threadIdx.x;
+    const bool act = a < total_atoms;
+    // everything the atom needs from memory is asked for up front: the call's length is a chain of round trips
+    unsigned tab = lane < CLS_TABLE_WORDS ? cls_table[lane] : CLS_EMPTY;
+    float xyz[3] = {0.f, 0.f, 0.f};
+    if (act) { xyz[0] = coords[3 * a + 0]; xyz[1] = coords[3 * a + 1]; xyz[2] = coords[3 * a + 2]; }
+    float w[CHG];
+#pragma unroll
+    for (int j = 0; j < CHG; ++j) w[j] = mk_inf();
+    uint2 cw = make_uint2(CLS_EMPTY, 0u);
+    if (act) {
+        cw = atom_channel_w(sigmas + (size_t)a * g.C, 0, g.C, g.w_scale, w);
+        tmp_cls[a] = cw;                                                       // (the fix-up waves of k_tail find an atom's sigma here)
+    }
+    const bool multi = cw.y == ATOM_MULTI_SIGMA;
+    unsigned wb[CHG];
+    bool any = cw.x != CLS_EMPTY;
+#pragma unroll
+    for (int j = 0; j < CHG; ++j) {
+        wb[j] = (w[j] < mk_inf()) ? mk_float_bits(w[j]) : CLS_EMPTY;
+        any |= multi && wb[j] != CLS_EMPTY;
+    }
+    wave_register_classes(cw.x, multi, wb, s_set, &s_full);                    // (the fix-up waves of k_tail read the blocks' sets)
+    // ---- class ids: one look-up per atom is the rule ----
+    unsigned ids = wave_class_id_insert(multi ? CLS_EMPTY : cw.x, tab, cls_table) * (multi ? 0u : cw.y);   // ids <= 15: no carry between nibbles
+    if (mk_ballot(multi) != 0ull) {                                            // wave-uniform, rare
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) ids |= wave_class_id_insert(multi ? wb[j] : CLS_EMPTY, tab, cls_table) << (4 * j);
+    }
+
+    // ---- position -> (cell, cell-relative offset) in double, exactly as bin_atom does ----
+    bool want = any;
+    int pc[3] = {0, 0, 0};
+    float rel[3] = {0.f, 0.f, 0.f};
+    int b = 0;
+    if (want) {
+        int lo = b_lo, hi = b_hi + 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+        }
+        b = lo;
+        const int nvox[3] = {g.nx, g.ny, g.nz};
+        if (affine != nullptr) {
+            const double* A = affine + 12 * (size_t)b;
+            const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+            xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+            xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+            xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+        }
+        const double inv_cs = 1.0 / (double)g.cs, cmid = 0.5 * (double)(g.cs - 1);
+        const int nc[3] = {g.ncx, g.ncy, g.ncz};
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            const double q = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+            if (q < -g.Rp || q > (double)(nvox[ax] - 1) + g.Rp) want = false;
+            const int ci = (int)floor((q + 0.5) * inv_cs);
+            pc[ax] = ci + g.h;
+            want = want && (pc[ax] >= 0) && (pc[ax] < nc[ax]);
+            rel[ax] = (float)(q - ((double)ci * (double)g.cs + cmid));
+        }
+    }
+    const size_t cell = want ? (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2] : (size_t)0;
+    const unsigned rank = wave_rank_in_cell(want, (unsigned)cell, counts);
+    if (want) {
+        unsigned slot;
+        if (rank < (unsigned)g.cell_cap) {
+            slot = (unsigned)cell * (unsigned)g.cell_cap + rank;
+        } else {                                                               // the cell is full: the item's spill area
+            const unsigned sp = mk_atomic_add(&counts[(size_t)b * g.cstride + g.ncell], 1u);     // (the item's spare counter)
+            (void)mk_atomic_add(&words[DIRECT_SPILLED], 1u);                   // statistics
+            slot = g.spill_base + (unsigned)b * g.spill_cap + sp;              // (it holds every atom of the call)
+            want = sp < g.spill_cap;
+        }
+        if (want) {
+            int level = 0;
+            if (g.reach_tau > 0.f) {                                           // tolerance-aware reach (fill_record's rule)
+                float w_min = mk_inf();
+#pragma unroll
+                for (int j = 0; j < CHG; ++j) w_min = fminf(w_min, w[j]);
+                const float frac = g.reach_tau / (w_min * g.R2);
+                level = (int)fminf(fmaxf(floorf((1.f - frac) * (1.f / REACH_STEP) - 1e-3f), 0.f), 3.f);
+            }
+            rec_pos[slot] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20) | (level << 30)));
+            rec_cls[slot] = ids;
+            rec_w[slot] = make_float4(w[0], w[1], w[2], w[3]);
+            rec_w[(size_t)g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
+        }
+    }
     mk_block_sync();
     if (threadIdx.x < CLS_BLOCK_SET)
         block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
@@ -1147,9 +1307,10 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
     cr.r0 = 0; cr.len = 0;
     if (direct_layout(g)) {
         // direct layout: a cell's records sit at cell * cap (its count in the direct counters), so every CELL around the
-        // tile is a run of its own (<= 63 of them, the host checked), and the call's spill area -- records of cells that
-        // overflowed their capacity, normally none -- is one more run that every tile looks at: candidates are culled
-        // by their distance to the tile, so seeing a record too many is harmless
+        // tile is a run of its own (<= 63 of them, the host checked), and the ITEM's spill area -- records of cells that
+        // overflowed their capacity, normally none -- is one more run that every tile of the item looks at: candidates
+        // are culled by their distance to the tile, so seeing a record too many is harmless (a record of ANOTHER item
+        // would not be: the packed cell word has no room for the item, hence one spill area per item)
         const unsigned* __restrict__ cnt = g.direct_words;
         const int nxc = tg.cx_hi - tg.cx_lo + 1, nyc = tg.cy_hi - tg.cy_lo + 1, nzc = tg.cz_hi - tg.cz_lo + 1;
         const int ncells = nxc * nyc * nzc;
@@ -1167,8 +1328,8 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
                 cr.len = n < (unsigned)g.cell_cap ? n : (unsigned)g.cell_cap;
             }
         } else if (lane == WAVE - 1) {
-            const unsigned n = cnt[(size_t)g.B * g.cstride + DIRECT_SPILLED];
-            cr.r0 = g.spill_base;
+            const unsigned n = cnt[(size_t)tg.b * g.cstride + g.ncell];         // the item's spare counter: its spilled records
+            cr.r0 = g.spill_base + (unsigned)tg.b * g.spill_cap;
             cr.len = n < g.spill_cap ? n : g.spill_cap;
         }
     } else {
@@ -2488,7 +2649,9 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
                           int per_item, const unsigned* __restrict__ summary, const float* __restrict__ coords,
                           const long long* __restrict__ atom_offsets, long long total_atoms, const SigT* __restrict__ sigmas,
                           const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
-                          const uint2* __restrict__ tmp_cls)
+                          const uint2* __restrict__ tmp_cls,
+                          unsigned* __restrict__ solo_counts /* k_bin_solo's counters + control words, or nullptr */, unsigned solo_n,
+                          unsigned* __restrict__ solo_table)
 {
     __shared__ double s_best[WAVE];
     const unsigned n = dense_words[0], total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
@@ -2524,6 +2687,16 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
             while (mk_load_relaxed(&dense_words[DENSE_WORDS]) < dense_wgs) mk_sleep();
         mk_block_sync();
         mk_threadfence();
+    }
+    if (solo_counts != nullptr) {
+        // a call binned by k_bin_solo: its counters go back to zero here, after the last reader (the dense tiles, if there
+        // were any, are done: see the wait above) -- the next call finds them clean without a memset launch; a class
+        // table that overflowed is emptied, so that the next call starts a new one
+        const unsigned me = role - dense_wgs, nfix = gridDim.x - dense_wgs;
+        for (unsigned i = me * WAVE + threadIdx.x; i < solo_n; i += nfix * WAVE) solo_counts[i] = 0u;
+        const unsigned overflow_word = cls_table[CLS_OVERFLOW];
+        mk_wave_sync();                                                    // (every lane has read the word before one clears it)
+        if (me == 0u && threadIdx.x < (unsigned)CLS_TABLE_WORDS && overflow_word != CLS_EMPTY) solo_table[threadIdx.x] = CLS_EMPTY;
     }
     exact_fixup_block<SigT>(g, role - dense_wgs, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
                             tmp_cls, out, s_best);

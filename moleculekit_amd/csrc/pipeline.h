@@ -58,7 +58,7 @@ struct LatticeProblem {
     double value_tol = 0.0;                 // > 0: entries may be dropped where they are worth less than this (tolerance-aware reach)
     int direct = -1;                        // direct binning (k_bin_direct): 1 = whenever the geometry allows; -1 (automatic) and 0 = the chain
     int cell_cap = 0;                       // record slots per cell of the direct layout (0 = 128; tests shrink it to see cells spill)
-    unsigned spill_cap = 0;                 // slots of the direct layout's spill area (0 = max(4096, atoms / 16))
+    unsigned spill_cap = 0;                 // slots of an item's spill area in the direct layout (0 = max(1024, an eighth of the average item))
     int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
     int tile_items = -1;                    // -1 = automatic (a workgroup per item for batches of ligand-sized items), 0 = never, 1 = always
     // device pointers
@@ -204,6 +204,8 @@ struct TailArgs {
     const unsigned* summary = nullptr;
     const LatticeProblem* P = nullptr;
     const void* tcls = nullptr;
+    unsigned* solo_counts = nullptr;        // a call binned by k_bin_solo: its counters (+ control words), zeroed by k_tail
+    unsigned solo_n = 0;
 };
 
 template <int K, int T, class BE>
@@ -243,7 +245,8 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
             return be.launch(kern, dim3(ta.dense_wgs + ta.fix_waves), dim3(WAVE), g, ta.dense_wgs, (const unsigned*)start, (const float4*)rpos,
                              (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, ta.other_words, (const unsigned*)dlist,
                              g.force_general ? (unsigned*)nullptr : be.feedback_dev(), (const int*)eflag, ta.per_item, ta.summary, P.coords,
-                             P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls);
+                             P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls, ta.solo_counts, ta.solo_n,
+                             (unsigned*)ctab);
         };
         st = P.sigmas_f64 ? tail(k_tail<K, E, double>, (const double*)P.sigmas) : tail(k_tail<K, E, float>, (const float*)P.sigmas);
     }
@@ -265,7 +268,10 @@ int launch_tiles(BE& be, int tier, int flavour, dim3 tgrid, const TailArgs& ta, 
 // how many of its leading bytes are known to be zero between calls.
 // The dense words (dense-tile list length, tier statistics, k_tail's done counter) live in a buffer of their own, in TWO
 // copies that alternate from call to call: a call's last launch clears the copy the NEXT call will use.
-struct CounterState { void* ptr = nullptr; size_t clean = 0; void* wptr = nullptr; bool wclean = false; unsigned parity = 0; };
+// dptr / dclean: the same for the counters of the one-launch pre-pass (k_bin_solo; k_tail zeroes them again); tptr: the
+// class-table buffer that holds a valid table (k_bin_solo keeps its table across calls: a new buffer starts empty).
+struct CounterState { void* ptr = nullptr; size_t clean = 0; void* wptr = nullptr; bool wclean = false; unsigned parity = 0;
+                      void* dptr = nullptr; size_t dclean = 0; void* tptr = nullptr; };
 constexpr int DENSE_SET_WORDS = DENSE_WORDS + 2;     // + the done counter of k_tail's dense blocks + its role tickets
 
 // The lattice hot path: bin -> scan -> fill -> tile kernel.  All pointers in P are device pointers.
@@ -286,10 +292,31 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     //  the kernel chain: its pre-pass then hides behind the previous call's tile kernel, the one-launch one never does;
     //  cfg1 x 4096 = 1 639 atoms per item: 2.00 -> 1.93 ms per step; 60-atom items lose 4 % that way)
     const bool chain_pays = be.pipelining_possible() && P.total_atoms >= 200000 && P.total_atoms > 1024LL * (long long)g.B;
-    const bool per_item = (g.ncell + 1 <= ITEM_HIST) && P.prepass_mode != 0 &&
+    const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
+    // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
+    const bool team = P.tile_team > 0 || (P.tile_team < 0 && (unsigned long long)total_tiles * (unsigned)g.G <= 1024ull);
+    // direct layouts (k_bin_direct, k_bin_solo): open boundaries, one channel group, tiles that see at most 63 cells
+    auto span = [&](int width) {                     // most cells a tile of `width` voxels (aligned to it) sees along one axis
+        int best = 0;
+        for (int x0 = 0; x0 < (g.cs > width ? g.cs : width); x0 += width) {
+            const int n = ((x0 + width - 1 + g.rint) >> g.cs_log2) - ((x0 - g.rint) >> g.cs_log2) + 1;
+            best = n > best ? n : best;
+        }
+        return best;
+    };
+    const int direct_cap = P.cell_cap > 0 ? P.cell_cap : 128;
+    const bool direct_geom = !g.pbc && g.G == 1 && !g.force_general && P.total_atoms > 0 && direct_cap <= (1 << SURV_OFF_BITS) &&
+                             span(g.K) * span(8) * span(8) <= WAVE - 1;
+    // a SMALL call (the team regime: one molecule per call) takes the one-launch pre-pass k_bin_solo, unless the caller
+    // chose a pre-pass (prepass_mode) or it is a ligand-sized call of the workgroup-per-item tile kernel; direct == 2
+    // forces it for any size (tests)
+    const bool items_sized = P.tile_items != 0 && P.total_atoms <= 96LL * (long long)g.B && g.ntiles <= 512;
+    const bool solo = direct_geom && (unsigned long long)P.total_atoms * (unsigned)g.B <= (1ull << 22) &&
+                      (P.direct == 2 || (P.direct != 0 && P.prepass_mode < 0 && team && !(items_sized && P.tile_team <= 0 && g.ncell + 1 <= ITEM_HIST)));
+    const bool per_item = !solo && (g.ncell + 1 <= ITEM_HIST) && P.prepass_mode != 0 &&
                           (P.prepass_mode == 1 || (P.total_atoms <= 4096LL * (long long)g.B && !chain_pays));
     g.cls_per_item = per_item ? 1 : 0;
-    const int set = be.acquire_set(P.total_atoms >= 200000 && !per_item);
+    const int set = be.acquire_set(P.total_atoms >= 200000 && !per_item && !solo);
     // Issue priority of the binning / fill waves that run beside the previous call's tile kernel.  Raised (s_setprio 3)
     // they take issue slots from the tile waves whenever they are ready; left at 0 they live on the slots the tile
     // kernel leaves idle, which is cheaper (cfg2 +2..4 % at 16..512 grids per step) as long as the chain still
@@ -307,36 +334,31 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_DENSE_WORDS, 2 * DENSE_SET_WORDS * sizeof(unsigned), &dwords_all, set))) return st;
     if ((st = be.ensure(WS_CELL_COUNT, count_bytes, &count, set))) return st;
     if ((st = be.ensure(WS_CELL_START, (ncells + 1) * sizeof(unsigned), &start, set))) return st;
-    // direct binning (k_bin_direct): big open-boundary calls of one channel group whose tiles see at most 63 cells
+    // direct binning (k_bin_direct: opt-in, big calls, the chain as its fall-back; k_bin_solo: small calls, nothing behind it)
     void* dcnt = nullptr;
-    size_t mrec = (size_t)g.M;
+    size_t mrec = (size_t)g.M, dbytes = 0;
+    CounterState& cs = be.counter_state(set);
     {
-        auto span = [&](int width) {                 // most cells a tile of `width` voxels (aligned to it) sees along one axis
-            int best = 0;
-            for (int x0 = 0; x0 < (g.cs > width ? g.cs : width); x0 += width) {
-                const int n = ((x0 + width - 1 + g.rint) >> g.cs_log2) - ((x0 - g.rint) >> g.cs_log2) + 1;
-                best = n > best ? n : best;
-            }
-            return best;
-        };
-        const int cap = P.cell_cap > 0 ? P.cell_cap : 128;
-        const unsigned spill = P.spill_cap > 0 ? P.spill_cap : (unsigned)std::max<long long>(4096, P.total_atoms / 16);
-        const unsigned long long slots = (unsigned long long)ncells * (unsigned)cap + spill;
-        const bool direct = !per_item && !g.pbc && g.G == 1 && !g.force_general && P.direct != 0 && P.total_atoms > 0 &&
-                            P.direct == 1 && cap <= (1 << SURV_OFF_BITS) &&        // (opt-in: measured -3 % in order, nothing pipelined)
-                           
-                            span(g.K) * span(8) * span(8) <= WAVE - 1 && slots <= 0xFFFF0000ull;
+        // spill slots PER ITEM (k_bin_solo: every atom of the call, so that it cannot run out)
+        const unsigned spill = solo ? (unsigned)P.total_atoms
+                                    : P.spill_cap > 0 ? P.spill_cap : (unsigned)std::max<long long>(1024, P.total_atoms / (8LL * g.B));
+        const unsigned long long slots = (unsigned long long)ncells * (unsigned)direct_cap + (unsigned long long)spill * (unsigned)g.B;
+        const bool direct = (solo || (!per_item && direct_geom && P.direct == 1)) && slots <= 0xFFFF0000ull;   // (k_bin_direct: measured -3 % in order, nothing pipelined)
+        if (solo && !direct) { err = "internal: the one-launch pre-pass does not fit its record slots"; return ST_EINVAL; }
         if (direct) {
-            g.cell_cap = cap; g.spill_base = (unsigned)(ncells * (size_t)cap); g.spill_cap = spill;
+            g.cell_cap = direct_cap; g.spill_base = (unsigned)(ncells * (size_t)direct_cap); g.spill_cap = spill;
             mrec = std::max<size_t>(mrec, (size_t)slots);
-            const size_t dbytes = ((ncells + DIRECT_WORDS) * sizeof(unsigned) + 255) & ~(size_t)255;
+            dbytes = ((ncells + DIRECT_WORDS) * sizeof(unsigned) + 255) & ~(size_t)255;
             if ((st = be.ensure(WS_DIRECT_COUNT, dbytes, &dcnt, set))) return st;
-            if ((st = be.fill(dcnt, 0, dbytes))) return st;         // the direct counters and the control words of this call
+            if (cs.dptr != dcnt) { cs.dptr = dcnt; cs.dclean = 0; }
+            // the direct counters and the control words of this call: zero -- k_tail leaves them so after a solo call
+            if (cs.dclean < dbytes && (st = be.fill(dcnt, 0, dbytes))) return st;
+            cs.dclean = 0;                                  // (vouched for again once this call has been enqueued in full)
             g.direct_words = (const unsigned*)dcnt;
         }
     }
     if ((st = be.ensure(WS_REC_POS, mrec * sizeof(float4), &rpos, set))) return st;
-    if ((st = be.ensure(WS_REC_W, (size_t)g.M * sizeof(float4) * 2 * g.G, &rw, set))) return st;
+    if ((st = be.ensure(WS_REC_W, (solo ? mrec : (size_t)g.M) * sizeof(float4) * 2 * g.G, &rw, set))) return st;
     if ((st = be.ensure(WS_REC_CLS, (g.G == 1 ? mrec : (size_t)g.M) * sizeof(unsigned) * g.G, &rcls, set))) return st;
     if ((st = be.ensure(WS_CLS_TABLE, (per_item ? (size_t)g.B : (size_t)1) * CLS_TABLE_WORDS * sizeof(unsigned), &ctab, set))) return st;
     if ((st = be.ensure(WS_ERR, sizeof(int), &eflag, 0))) return st;
@@ -344,7 +366,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if ((st = be.ensure(WS_TMP_IDX, (size_t)g.M * sizeof(uint2), &tidx, set))) return st;
     if ((st = be.ensure(WS_TMP_CLS, (size_t)(P.total_atoms > 0 ? P.total_atoms : 1) * g.G * sizeof(uint2), &tcls, set))) return st;
 
-    CounterState& cs = be.counter_state(set);
+    if (solo) {
+        g.M = (unsigned)mrec;                       // the record arrays' plane stride (rec_w) is the direct layout's slot count
+        if (cs.tptr != ctab) {                      // a table buffer nobody has written yet: k_bin_solo starts from an empty table
+            if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;
+        }
+    }
+    cs.tptr = nullptr;                              // (a call that fails half-way leaves no table behind)
     if (cs.ptr != count) { cs.ptr = count; cs.clean = 0; }
     size_t clean_after = cs.clean;
     cs.clean = 0;                                   // nothing is vouched for until this call has been enqueued in full
@@ -395,6 +423,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         fix_summary = g.force_general ? nullptr : (const unsigned*)bsets;
         fix_waves = P.total_atoms > 0 ? nblk : 0u;
         const unsigned* dfail = g.direct_words ? g.direct_words + ncells + DIRECT_FAILED : nullptr;
+        if (solo) {
+            st = P.sigmas_f64 ? be.launch(k_bin_solo<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas, P.origins,
+                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (uint2*)tcls, (unsigned*)ctab, (unsigned*)bsets)
+                              : be.launch(k_bin_solo<float>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.sigmas, P.origins,
+                                          P.affine, (unsigned*)dcnt, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (uint2*)tcls, (unsigned*)ctab, (unsigned*)bsets);
+            if (st) return st;
+        } else {
         if (g.direct_words) {
             // the one-pass form first; the chain below is enqueued behind it and returns at once unless the pass gave up
             st = P.sigmas_f64 ? be.launch(k_bin_direct<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas, P.origins,
@@ -441,17 +476,15 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                                           (const uint2*)tidx, (const uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
             if (st) return st;
         }
+        }                                           // (not solo)
     }
     be.prepass_done(set);
 
-    const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     const dim3 tgrid(((total_tiles + 7u) / 8u) * 8u, (unsigned)g.G);
     if ((unsigned long long)total_tiles * (unsigned)g.G > 0xFFFF0000ull) { err = "batch too large: more than 2^32 tiles x channel groups; split the batch"; return ST_EINVAL; }
     void* dlist = nullptr;
     if ((st = be.ensure(WS_DENSE_LIST, (size_t)total_tiles * g.G * sizeof(unsigned), &dlist, set))) return st;
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
-    // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
-    const bool team = P.tile_team > 0 || (P.tile_team < 0 && (unsigned long long)total_tiles * (unsigned)g.G <= 1024ull);
 #ifdef MK_NO_LEAN                                       // A-B builds: the plain kernel also beside the pre-pass
     const int flavour = team ? TILES_TEAM : TILES_PLAIN;
 #else
@@ -464,6 +497,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
     ta.fix_waves = fix_waves; ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
+    if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(ncells + DIRECT_WORDS); }
     be.hot_begin();
     st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
                   : launch_tiles<4>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);
@@ -471,6 +505,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (!st) {
         cs.clean = clean_after;
         cs.wclean = true;
+        cs.tptr = ctab;                             // every pre-pass leaves a whole table in the buffer
+        if (solo) cs.dclean = dbytes;               // k_tail has zeroed them
         if (ta.dense_wgs + ta.fix_waves != 0u) cs.parity ^= 1u;       // k_tail has cleared the other copy: the next call's
     }
     be.note_error_flag_mirrored(!st && !g.force_general && ta.dense_wgs != 0u && be.feedback_dev() != nullptr);

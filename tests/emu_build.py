@@ -47,7 +47,7 @@ def _p(a):
 
 def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box=None, max_images=0,
                      tile_k=0, force_general=False, affine=None, lds_tier=-1, feedback=None, prepass_mode=-1, tile_team=-1, fine_cells=False,
-                     repeat=1, fills=None, tile_items=-1, value_tol=0.0, direct=0, cell_cap=0, spill_cap=0, direct_words=None):
+                     repeat=1, fills=None, tile_items=-1, value_tol=0.0, direct=-1, cell_cap=0, spill_cap=0, direct_words=None):
     """feedback: optional uint32[4] array, in = tier statistics of the 'previous call', out = this call's.
     repeat: run the call that many times on ONE backend (workspace kept) and return the last result; fills: optional
     one-element list that receives the number of counter memsets those calls issued."""

@@ -397,7 +397,7 @@ def _direct(case, repeat, **kw):
     return out, words
 
 
-@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "voxel15", "cutoff_adversarial_1A", "special_sigmas", "channels11", "pbc_batch"])
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "voxel15", "cutoff_adversarial_1A", "special_sigmas", "channels11", "pbc_batch", "tiny_items"])
 def test_direct_binning_is_bit_identical_with_the_chain_as_its_device_side_fallback(name):
     """k_bin_direct (round 3): records written in place at cell * capacity + rank with class ids from the table the
     previous call left; the count / scan / fill chain runs only when the pass gives up.  First call on a workspace: no
@@ -479,3 +479,101 @@ def test_direct_binning_feeds_the_exact_cutoff_fixup():
     direct, _ = E.voxelize_lattice(*args, prepass_mode=0, direct=1, repeat=2, direct_words=words)
     assert words[0] == 0                                                   # the second call did go direct
     assert np.abs(chain - exp).max() <= TOL and np.array_equal(direct, chain)
+
+
+# ---- the one-launch pre-pass of small calls (k_bin_solo, round 3) ----------------------------------------------------
+def _solo(case, repeat=1, **kw):
+    words = np.zeros(4, np.uint32)
+    kwargs = dict(box=case["box"]) if case["box"] is not None else {}
+    fills = [0]
+    out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                  case["voxelsize"], direct=2, repeat=repeat, direct_words=words, fills=fills, **kwargs, **kw)
+    assert err == 0
+    return out, words, fills[0]
+
+
+def _chain(case, **kw):
+    kwargs = dict(box=case["box"]) if case["box"] is not None else {}
+    out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                  case["voxelsize"], direct=0, prepass_mode=0, **kwargs, **kw)
+    assert err == 0
+    return out
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "voxel15", "cutoff_adversarial_1A", "special_sigmas", "dense_mixed",
+                                  "channels11", "pbc_batch", "tiny_items", "nonfinite_coords", "dense_with_wide_sigmas", "cfg3_small", "voxel025"])
+def test_solo_prepass_is_bit_identical_with_the_chain(name):
+    """k_bin_solo: the whole pre-pass of a small call in one launch -- records in the direct layout, the class table kept
+    across calls and extended on the spot, every atom kind handled (several sigmas per atom, NaN / inf sigmas, more classes
+    than ids), nothing enqueued behind it.  First call on a workspace (empty table: every class is inserted) and third call
+    (table there, counters zeroed by k_tail) against the count / scan / fill chain: the same bits."""
+    if name not in LATTICE_CASES:
+        pytest.skip("no such case")
+    case = LATTICE_CASES[name]()
+    ref = _chain(case)
+    one, w1, f1 = _solo(case, 1)
+    assert np.array_equal(one, ref)
+    three, w3, f3 = _solo(case, 3)
+    assert np.array_equal(three, ref)
+    eligible = case["box"] is None and case["sigmas"].shape[1] <= 8 and len(case["coords"]) > 0
+    if eligible:
+        assert w1[0] == 0 and w3[0] == 0               # the pass never gives up ...
+        assert w3[1] == 0                              # ... and k_tail left the control words (and the counters) zero
+        assert f3 == f1                                # no memset per call: the later calls found everything clean
+    check(case, three)
+
+
+def test_solo_prepass_with_more_sigma_classes_than_ids():
+    """20 distinct radii: the table fills up, the overflow word is raised, the tile kernels read w from the records
+    (general path); k_tail empties the table, so the second call on the workspace goes the same way."""
+    rng = np.random.default_rng(5)
+    n = 400
+    coords = rng.uniform(-2, 22, (n, 3)).astype(np.float32)
+    radii = np.linspace(1.0, 2.9, 20)
+    sig = np.zeros((n, 8))
+    r = rng.choice(radii, n)
+    sig[:, 7] = r
+    sig[:, 2] = r * (rng.random(n) < 0.5)
+    sig[:, 4] = rng.choice(radii, n) * (rng.random(n) < 0.2)      # (some atoms carry two different radii)
+    case = dict(coords=coords, atom_offsets=np.array([0, n]), sigmas=sig, origins=np.zeros((1, 3)), nvoxels=np.array([20, 20, 20]),
+                voxelsize=1.0, box=None)
+    exp = oracle_lattice(coords, case["atom_offsets"], sig, case["origins"], case["nvoxels"], 1.0)
+    ref = _chain(case)
+    for rep in (1, 2):
+        out, w, _ = _solo(case, rep)
+        assert w[0] == 0 and np.array_equal(out, ref)
+    assert np.abs(ref - exp).max() <= TOL
+
+
+def test_solo_prepass_spills_full_cells():
+    case = LATTICE_CASES["cfg1_3ptb"]()
+    ref = _chain(case)
+    out, w, _ = _solo(case, 1, cell_cap=4)             # four slots per cell: most atoms go through the spill area
+    assert np.array_equal(out, ref)
+    out, w, _ = _solo(case, 2, cell_cap=4)
+    assert w[1] == 0 and np.array_equal(out, ref)
+    tol_chain = _chain(case, value_tol=5e-6)           # the tolerance-aware reach levels ride in these records too
+    tol_solo, _, _ = _solo(case, 2, value_tol=5e-6)
+    assert np.array_equal(tol_solo, tol_chain)
+
+
+def test_solo_prepass_feeds_the_exact_cutoff_fixup():
+    from tests.cases import case_cutoff_adversarial
+    case = case_cutoff_adversarial(1.0)
+    exp = oracle_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    ref = _chain(case)
+    out, w, _ = _solo(case, 2)
+    assert np.array_equal(out, ref) and np.abs(out - exp).max() <= TOL
+
+
+def test_small_calls_take_the_solo_prepass_by_default():
+    """Automatic mode: a one-molecule call (team regime) is binned by k_bin_solo -- seen through the direct control words,
+    which only exist when the call had a direct pass."""
+    case = LATTICE_CASES["cfg1_3ptb"]()
+    words = np.zeros(4, np.uint32)
+    out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                  case["voxelsize"], direct_words=words)
+    assert err == 0 and words[0] == 0 and np.array_equal(out, _chain(case))
+    out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                  case["voxelsize"], direct_words=words, prepass_mode=1)
+    assert words[0] == 0xffffffff and np.array_equal(out, _chain(case))        # the caller chose a pre-pass: no direct pass

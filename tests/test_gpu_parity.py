@@ -541,3 +541,84 @@ def test_direct_binning_leaves_the_fixup_what_it_needs(hip_ctx):
         hip_ctx.set_prepass_mode(-1)
     assert np.abs(chain - exp).max() <= TOL
     assert np.array_equal(direct, chain)
+
+
+# ---- the one-launch pre-pass of small calls (k_bin_solo) ---------------------------------------------------------------
+def _chain_then(hip_ctx, args, box, mode, calls=1):
+    from moleculekit_amd import batch
+    try:
+        hip_ctx.set_prepass_mode(0)
+        hip_ctx.set_direct_binning(0)
+        ref = batch.voxelize_lattice(*args, box=box, ctx=hip_ctx)
+        hip_ctx.set_prepass_mode(-1)
+        hip_ctx.set_direct_binning(mode)
+        outs = [batch.voxelize_lattice(*args, box=box, ctx=hip_ctx) for _ in range(calls)]
+    finally:
+        hip_ctx.set_direct_binning(-1)
+        hip_ctx.set_prepass_mode(-1)
+    return ref, outs
+
+
+@pytest.mark.parametrize("name", ["cfg1_3ptb", "ragged_batch", "voxel15", "dense_mixed", "cutoff_adversarial_1A", "special_sigmas",
+                                  "tiny_items", "dense_with_wide_sigmas", "nonfinite_coords", "channels11", "pbc_batch"])
+def test_solo_prepass_matches_the_chain_bit_for_bit(hip_ctx, name):
+    """k_bin_solo forced on (mode 2), three calls on the module's context -- whose class table has seen whatever the
+    tests before left in it -- against the count / scan / fill chain."""
+    case = LATTICE_CASES[name]()
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    ref, outs = _chain_then(hip_ctx, args, case["box"], 2, calls=3)
+    for got in outs:
+        assert np.array_equal(got, ref)
+    check(case, ref)
+
+
+def test_solo_prepass_keeps_its_class_table_across_workloads(hip_ctx):
+    """One context, a sequence of different molecules in the automatic mode (small calls: the one-launch pre-pass): radii
+    the table has, radii it has not (inserted on the spot), 20 radii at once (overflow: general path, table emptied by
+    k_tail), then the first molecule again -- each call equals the chain's result for the same input, and the oracle."""
+    from moleculekit_amd import batch
+    rng = np.random.default_rng(19)
+
+    def molecule(n, radii, two=0.0):
+        coords = rng.uniform(-2, 26, (n, 3)).astype(np.float32)
+        r = rng.choice(radii, n)
+        sig = np.zeros((n, 8))
+        sig[:, 7] = r
+        sig[:, 0] = r * (rng.random(n) < 0.4)
+        sig[:, 3] = rng.choice(radii, n) * (rng.random(n) < two)          # a second, different radius on some atoms
+        return coords, np.array([0, n]), sig, np.zeros((1, 3)), np.array([24, 24, 24]), 1.0
+
+    seq = [molecule(900, [1.1, 1.7]), molecule(1200, [1.1, 1.52, 1.55, 1.7, 1.8]), molecule(700, [2.27, 1.7, 3.0], two=0.2),
+           molecule(800, np.linspace(1.0, 2.9, 20), two=0.3), molecule(500, [1.2, 1.3])]
+    seq.append(seq[0])
+    try:
+        hip_ctx.set_prepass_mode(0)
+        hip_ctx.set_direct_binning(0)
+        refs = [batch.voxelize_lattice(*m, ctx=hip_ctx) for m in seq]
+        hip_ctx.set_prepass_mode(-1)
+        hip_ctx.set_direct_binning(-1)
+        for rep in range(2):
+            for m, ref in zip(seq, refs):
+                assert np.array_equal(batch.voxelize_lattice(*m, ctx=hip_ctx), ref)
+    finally:
+        hip_ctx.set_direct_binning(-1)
+        hip_ctx.set_prepass_mode(-1)
+    for m, ref in zip(seq[:4], refs):
+        assert np.abs(ref - oracle_lattice(*m)).max() <= TOL
+
+
+def test_one_cfg2_item_per_call_default_path(hip_ctx):
+    """The 64^3 grid of one 50 000-atom system in the automatic mode (1 024 tile waves: one-launch pre-pass + the team kernel),
+    repeated, against the chain and 4 096 oracle-sampled voxels."""
+    from moleculekit_amd import batch
+    p = synth_config(2, 1, seed=5)
+    o, nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])
+    args = (p["coords"], p["atom_offsets"], p["sigmas"], o[None], nv, p["voxelsize"])
+    ref, outs = _chain_then(hip_ctx, args, None, -1, calls=3)
+    for got in outs:
+        assert np.array_equal(got, ref)
+    rng = np.random.default_rng(0)
+    vox = rng.choice(int(np.prod(nv)), 4096, replace=False)
+    centers = np.stack(np.unravel_index(vox, nv), axis=1) * p["voxelsize"] + o
+    exp = oracle.calculate_occupancy(centers, p["coords"], p["sigmas"])
+    assert np.abs(ref[0][vox] - exp).max() <= TOL

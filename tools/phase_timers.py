@@ -36,6 +36,6 @@ v = np.array(list(buf)[:6], dtype=np.float64)
 names = ["prologue", "traversal 1 (histogram)", "counts -> starts", "traversal 2 (placement)", "pair loops + flushes", "epilogue"]
 print(f"{wl}: share of a tile wave's wall-clock cycles per phase, wave-per-tile kernel (sum over {n} launches)")
 for nm, x in zip(names, v):
-    print(f"  {nm:28s} {100 * x / v.sum():5.1f} %")
+    print(f"  {nm:28s} {100 * x / v.sum():5.1f} %   ({x / n / 1e3:9.1f} k cycles per launch, summed over the timed waves)")
 w = np.array(list(buf)[6:8], dtype=np.float64)
 print(f"  inside the traversals: issue + wait for the chunk loads {100 * w[0] / v.sum():5.1f} %, cull / histogram / placement {100 * w[1] / v.sum():5.1f} %")
