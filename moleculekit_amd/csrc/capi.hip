@@ -663,11 +663,24 @@ static void widen(const float* __restrict__ src, double* __restrict__ dst, size_
 
 // `features64` != NULL: the caller wants the reference's float64 [B,V,C] (voxeldescriptors.py:531); the widening is
 // done here, in the pass that takes the results out of the pinned buffer anyway, instead of in a second pass in numpy
+#ifdef MK_HOST_TIMERS   // tools/ build only: where a small synchronous host call spends its time (microseconds, summed)
+#include <chrono>
+static double g_host_us[6];
+static inline double host_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define MK_HOST_MARK(i) do { const double n_ = host_now(); g_host_us[i] += n_ - host_t_; host_t_ = n_; } while (0)
+#define MK_HOST_BEGIN() double host_t_ = host_now()
+extern "C" void mkamd_debug_host_timers(double* out6) { for (int i = 0; i < 6; ++i) { out6[i] = g_host_us[i]; g_host_us[i] = 0.0; } }
+#else
+#define MK_HOST_MARK(i) do {} while (0)
+#define MK_HOST_BEGIN() do {} while (0)
+#endif
+
 static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
                                       const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
                                       const int32_t* nvoxels, double voxelsize, const float* box,
                                       int32_t max_images, float* features, double* features64)
 {
+    MK_HOST_BEGIN();
     int st = check_ctx(ctx);
     if (st) return st;
     if (B < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_items must be >= 0 and n_channels > 0");
@@ -750,6 +763,7 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
     }
     // the per-item pre-pass gives every item ONE workgroup: here the offsets are visible, so a ragged batch whose
     // average is small but which holds a huge item is kept on the kernel chain (automatic mode only)
+    MK_HOST_MARK(0);                                                // checks + inputs packed
     long long biggest = 0;
     for (int b = 0; b < B; ++b) biggest = std::max<long long>(biggest, atom_offsets[b + 1] - atom_offsets[b]);
     const int saved_mode = ctx->prepass_mode;
@@ -759,6 +773,7 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
                                     max_images, (float*)dout);
     ctx->prepass_mode = saved_mode;
     if (st) return st;
+    MK_HOST_MARK(1);                                                // kernels enqueued
     const size_t nvals = out_bytes / 4;
     if (!mapped_out) prefault_big_result(features64 ? (void*)features64 : (void*)features, features64 ? out_bytes * 2 : out_bytes);
     if (features64) {
@@ -769,8 +784,12 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
             src = ctx->f32_stage.data();
         }
         HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
+        MK_HOST_MARK(2);                                            // waited for the stream
         widen(src, features64, nvals);
-        return collect_async_errors(ctx);
+        MK_HOST_MARK(3);                                            // float32 -> float64 into the caller's array
+        st = collect_async_errors(ctx);
+        MK_HOST_MARK(4);
+        return st;
     }
     if (!mapped_out) HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));

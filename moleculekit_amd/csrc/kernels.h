@@ -51,6 +51,9 @@ constexpr int CHG = 8;               // channels per channel-group (one group = 
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per class table (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
+#ifndef MK_TEAM_OWN_MAX   // team kernel: classes of up to this many (padded) entry slots go to one wave whole (voxelize_tile)
+#define MK_TEAM_OWN_MAX 64
+#endif
 #ifndef MK_DIAG           // tools/gpu_diag.sh builds only: compile parts of the tile kernel out to count what they cost
 #define MK_DIAG 0         // 1 pair loops, 2 class flushes, 4 epilogue arithmetic, 8 placement + all class work, 16 histogram traversal
 #endif
@@ -1550,6 +1553,19 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     // before the placement pass starts writing entries -- no LDS of its own, so every tier keeps its occupancy
     constexpr bool SURV_LIST = TEAM == 1 && !DENSE;
 #endif
+    // a team's waves share ONE survivor list: every wave culls its share of the candidate chunks once and appends what
+    // survives (tile-relative position, class ids, x-reach) -- the placement pass then walks ~450 survivors split over the
+    // team instead of re-culling ~1 500 candidates.  The list borrows the LDS of the end-of-tile reduction (s_red).
+    constexpr int SV_CAP = TEAM > 1 ? 1024 : 0;
+    constexpr int TEAM_WORDS = TEAM > 1 ? ((CHG * K * WAVE > 4 * SV_CAP + SV_CAP / 4) ? CHG * K * WAVE : 4 * SV_CAP + SV_CAP / 4) : 1;
+    __shared__ __attribute__((aligned(16))) unsigned s_team[TEAM_WORDS];
+    __shared__ unsigned s_nsv;
+    unsigned* const s_red = s_team;
+    float* const sv_x = reinterpret_cast<float*>(s_team);
+    float* const sv_y = sv_x + SV_CAP;
+    float* const sv_z = sv_y + SV_CAP;
+    unsigned* const sv_ids = s_team + 3 * SV_CAP;
+    unsigned char* const sv_xr = reinterpret_cast<unsigned char*>(s_team + 4 * SV_CAP);
     unsigned short* const s_surv = reinterpret_cast<unsigned short*>(sz);
     static_assert(2 * ESTRIDE >= SURV_CAP, "the survivor codes fit the z array");
     constexpr int SURV_REGS = (SURV_CAP + WAVE - 1) / WAVE;
@@ -1637,6 +1653,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         };
 #pragma unroll
         for (int i = 0; i < NBUCKET3 / WAVE; ++i) bucket[lane + i * WAVE] = 0u;
+        if (TEAM > 1 && threadIdx.x == 0) s_nsv = 0u;
         mk_block_sync();
         auto count_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
             const int xr = x_reach(ex, ey, ez, pk);
@@ -1644,13 +1661,18 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
             });
         };
-        // A team's wave sees only every TEAM-th chunk: when that is at most TEAM_KEEP of them (it nearly always is) they
-        // are loaded ONCE, all at the same time, and stay in registers for the placement pass -- the tile's latency is
-        // a chain of dependent memory round trips, and this removes all but one of the traversals'.
-        constexpr int TEAM_KEEP = TEAM > 1 ? 6 : 1;
-        CandChunk kept[TEAM_KEEP];
-        const bool keep = TEAM > 1 && runs.T <= (unsigned)(TEAM_KEEP * TEAM);                 // the same in every wave
-        const CandLoader loader{g, tg, runs, rec_pos, clsp};
+        // A team's wave sees every TEAM-th batch of chunks; what survives the cull goes to the team's list (see above)
+        auto count_and_list = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
+            const int xr = x_reach(ex, ey, ez, pk);
+            const unsigned long long m = mk_ballot(surv);
+            unsigned base = 0u;
+            if (lane == 0 && m != 0ull) base = mk_lds_add(&s_nsv, (unsigned)mk_popc64(m));
+            const unsigned pos = mk_readlane(base, 0) + (unsigned)mk_rank_in_mask(m);
+            if (surv && pos < (unsigned)SV_CAP) { sv_x[pos] = ex; sv_y[pos] = ey; sv_z[pos] = ez; sv_ids[pos] = ids; sv_xr[pos] = (unsigned char)xr; }
+            for_each_present_channel(surv ? ids : 0u, [&](int c, unsigned id) {
+                (void)mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+            });
+        };
         // ---- the hot kernel: ONE pass over the candidates (cull + compaction of the survivors' codes), then the
         //      histogram over the survivors only ----
         unsigned nsurv = 0u;                                  // wave-uniform
@@ -1709,16 +1731,14 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         }
         if (MK_DIAG & 16) {
         } else if (use_list) {
-        } else if (keep) {
-#pragma unroll
-            for (int i = 0; i < TEAM_KEEP; ++i) cand_issue<true>(loader, (unsigned)(wv + i * TEAM), kept[i]);
-#pragma unroll
-            for (int i = 0; i < TEAM_KEEP; ++i)
-                if ((unsigned)(wv + i * TEAM) < runs.T) cand_consume<K>(loader, kept[i], count_entry);
+        } else if (TEAM > 1) {
+            for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp, count_and_list, (unsigned)wv, (unsigned)TEAM);
         } else {
             for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp, count_entry, (unsigned)wv, (unsigned)TEAM);
         }
         mk_block_sync();
+        const unsigned nsv = TEAM > 1 ? mk_uniform(s_nsv) : 0u;             // the same in every wave of the team
+        const bool use_sv = TEAM > 1 && nsv <= (unsigned)SV_CAP;
         if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
             general = true;                      // this item alone has too many classes (its records carry w, not ids)
         } else {
@@ -1764,12 +1784,27 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         // ---- one channel, class by class: inner loop = sub, fma, half a min3 per (voxel, entry); the
         //      class flush applies the cutoff to the class minimum and scales by w ----
         unsigned deal = 0u;                                  // team: the wave the next pair goes to (wave-uniform)
+        unsigned next_owner = 0u;                            // team: the wave the next SMALL class goes to (wave-uniform)
         auto process_classes = [&](int c, unsigned bits, unsigned (&acc)[KL]) {
             while (bits) {                                                // wave-uniform
                 const int cls = __builtin_ctz(bits);
                 bits &= bits - 1u;
                 const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
                 const uint4 bg = make_uint4(mk_uniform(bgp[0]), mk_uniform(bgp[1]), mk_uniform(bgp[2]), mk_uniform(bgp[3]));
+                // A team deals the PAIRS of a class round-robin -- but every wave then pays the class's fixed work (three
+                // loop set-ups, the flush: ~100 instructions) for its share, and a one-grid call is bound by exactly that:
+                // cfg2's tiles hold 27 classes of ~12 entries.  A class of at most TEAM_OWN_MAX slots therefore goes to ONE
+                // wave, whole (the others skip it); the big classes of a real protein are dealt as before.  Minima are
+                // order-free: the bits do not depend on who looked at an entry.
+                bool owned = false;                                       // wave-uniform
+                if (TEAM > 1) {
+                    owned = (bg.w & ~1u) - (bg.x & ~1u) <= (unsigned)MK_TEAM_OWN_MAX;
+                    if (owned) {
+                        const unsigned owner = next_owner;
+                        next_owner = (next_owner + 1u) & (unsigned)(TEAM - 1);
+                        if ((unsigned)wv != owner) continue;
+                    }
+                }
                 const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
                 // m[k] = min over the class's entries of g_k = d^2 - c_k^2 (c_k = x of plane k relative to the tile centre):
                 // with D0 = ex^2 + dy^2 + dz^2 per (lane, entry), g_k = D0 - 2 c_k ex is ONE fma per (voxel, entry); the
@@ -1789,7 +1824,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     // is: the same in every wave) -- most sub-buckets hold one to three pairs, and starting each of them at
                     // wave 0 gave that wave 60 pairs of a cfg2 tile and the last one 20; the unpaired last entry is dealt too
                     const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
-                    const unsigned first = TEAM > 1 ? (((unsigned)wv + (unsigned)TEAM - deal) & (unsigned)(TEAM - 1)) : 0u;
+                    const unsigned first = (TEAM > 1 && !owned) ? (((unsigned)wv + (unsigned)TEAM - deal) & (unsigned)(TEAM - 1)) : 0u;
+                    const unsigned step = (TEAM > 1 && !owned) ? 2u * (unsigned)TEAM : 2u;
                     const float* e = sxyz + s0 + 2u * first;
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
                     //  have to be merged after every one of these short runs -- measured 7 % slower)
@@ -1797,7 +1833,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     //  compare -- one VALU instruction per trip more, PMC: 8 970 -> 8 739 per tile)
                     const float* const e_end = sxyz + s0 + 2u * npairs;
 #pragma clang loop vectorize(disable) interleave(disable)
-                    for (; TEAM > 1 ? e < e_end : e != e_end; e += 2 * TEAM) {
+                    for (; TEAM > 1 ? e < e_end : e != e_end; e += (TEAM > 1 ? step : 2u)) {
                         // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
                         // (fetching the next pair one trip ahead was measured: 2-4 % slower, the copies cost more)
                         const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
@@ -1809,8 +1845,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                             m[k] = mk_min3(m[k], gk[0], gk[1]);
                         }
                     }
-                    const bool tail_mine = TEAM == 1 || (unsigned)wv == ((deal + npairs) & (unsigned)(TEAM - 1));
-                    if (TEAM > 1) deal = (deal + npairs + odd) & (unsigned)(TEAM - 1);
+                    const bool tail_mine = TEAM == 1 || owned || (unsigned)wv == ((deal + npairs) & (unsigned)(TEAM - 1));
+                    if (TEAM > 1 && !owned) deal = (deal + npairs + odd) & (unsigned)(TEAM - 1);
                     if (odd && tail_mine) {                               // wave-uniform: the unpaired last entry
                         const float* t = sxyz + s0 + 2u * npairs;
                         const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
@@ -1827,7 +1863,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     const unsigned n = ((b1 & ~1u) - s0) - (b0 & 1u);
                     const float* e = sxyz + s0;
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                    for (unsigned i = (TEAM > 1 ? (unsigned)wv : 0u); i < n; i += TEAM) {   // (a team's wave: every TEAM-th entry)
+                    for (unsigned i = ((TEAM > 1 && !owned) ? (unsigned)wv : 0u); i < n; i += ((TEAM > 1 && !owned) ? (unsigned)TEAM : 1u)) {   // (a team's wave: every TEAM-th entry)
                         const float* ee = e + i;
                         const float px = ee[0], dy = Y - ee[ESTRIDE], dz = Z - ee[2 * ESTRIDE];
                         const float r = mk_fma(dy, dy, dz * dz);
@@ -1881,19 +1917,20 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
-            auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
-                const int xr = x_reach(ex, ey, ez, pk);
+            auto place_at = [&](bool surv, float ex, float ey, float ez, unsigned ids, int xr) {
                 for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
                     const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                     sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
                 });
             };
+            auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
+                place_at(surv, ex, ey, ez, ids, x_reach(ex, ey, ez, pk));
+            };
             if (use_list) {
                 for_each_survivor(IntC<1>{}, place_entry);
-            } else if (keep) {
-#pragma unroll
-                for (int i = 0; i < TEAM_KEEP; ++i)
-                    if ((unsigned)(wv + i * TEAM) < runs.T) cand_consume<K>(loader, kept[i], place_entry);
+            } else if (use_sv) {
+                for (unsigned i = (unsigned)(wv * WAVE + lane); i < nsv; i += (unsigned)(TEAM * WAVE))     // per-lane trip count: no collectives inside
+                    place_at(true, sv_x[i], sv_y[i], sv_z[i], sv_ids[i], (int)sv_xr[i]);
             } else {
                 for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp, place_entry, (unsigned)wv, (unsigned)TEAM);
             }
@@ -2011,7 +2048,6 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     // ---- a team: the waves' accumulators (each saw a quarter of the entries) meet in LDS -- unsigned minima of bit
     //      patterns, as everywhere -- and every wave takes K / TEAM planes of the result through the epilogue ----
     if constexpr (TEAM > 1) {
-        __shared__ unsigned s_red[CHG * K * WAVE];
 #pragma unroll
         for (int i = wv; i < CHG * K; i += TEAM) s_red[i * WAVE + lane] = INF_BITS;
         mk_block_sync();

@@ -38,6 +38,18 @@ t0 = time.perf_counter()
 for _ in range(n):
     ctx.voxelize_lattice_host(1, coords, offs, sig32, False, 8, org, nv32, 1.0, None, 1, out32)
 print(f"  float32 sigmas in, float32 features out: {(time.perf_counter() - t0) / n * 1e6:.1f} us per call")
+lib = _lib.load()
+if hasattr(lib, "mkamd_debug_host_timers"):
+    import ctypes
+    buf = (ctypes.c_double * 6)()
+    lib.mkamd_debug_host_timers(buf)
+    for _ in range(n):
+        ctx.voxelize_lattice_host(1, coords, offs, sig, True, 8, org, nv32, 1.0, None, 1, out)
+    lib.mkamd_debug_host_timers(buf)
+    names = ["checks + inputs packed into the pinned buffer", "kernels enqueued", "waiting for the stream", "float32 -> float64 into the caller's array", "error collection"]
+    print("inside mkamd_voxelize_lattice_host_f64 (us per call):")
+    for nm, v in zip(names, list(buf)):
+        print(f"  {nm:48s} {v / n:7.2f}")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(n):
