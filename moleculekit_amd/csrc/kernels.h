@@ -114,8 +114,12 @@ struct GridDesc {
     int cell_cap;
     unsigned spill_base, spill_cap;   // spill areas: item b owns slots [spill_base + b * spill_cap, + spill_cap), counted in its spare cell counter
     const unsigned* direct_words;
+    // counter of cell i = direct_words[DIRECT_HEAD + (i << cnt_shift)]: the one-launch pre-pass of ONE molecule sends 50 000
+    // rank atomics to ~1 000 counters, and device-scope atomics on one 128-byte line serialise at ~12 ns each (16 or 32
+    // counters per line: 9 us of a 13 us kernel) -- k_bin_solo gives every counter a line of its own (cnt_shift = 5)
+    int cnt_shift;
 };
-enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4 };
+enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4, DIRECT_HEAD = 32 /* words in front of the counters (one 128-byte line) */ };
 constexpr float REACH_STEP = 0.17f;   // levels 0..3: reach 5.00 / 4.56 / 4.06 / 3.50 A at the 5 A cutoff (H at eps = 1e-6: 3.48 A)
 
 // r2 (a cutoff^2) scaled down to the reach of one record; untouched -- not even multiplied by one -- unless the call
@@ -129,7 +133,7 @@ MK_DEV float reach_r2(const GridDesc& g, float r2, int packed_cell)
 // is the call's record array in the direct layout (k_bin_direct succeeded)?  One scalar load per wave.
 MK_DEV bool direct_layout(const GridDesc& g)
 {
-    return g.direct_words != nullptr && mk_uniform(g.direct_words[(size_t)g.B * g.cstride + DIRECT_FAILED]) == 0u;
+    return g.direct_words != nullptr && mk_uniform(g.direct_words[DIRECT_FAILED]) == 0u;
 }
 
 // w of a present channel is clamped to a finite value (+inf is the "channel absent" marker): a
@@ -557,8 +561,13 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
         if (threadIdx.x == 0) s_full = 0u;
         mk_block_sync();
     }
+    // (block i -> atoms [256 i, ...).  Giving concurrent blocks S different regions of the batch, so that their rank
+    //  atomics spread over the whole counter array, was measured -- S = 16 / 64 / 256: k_bin_count 333 -> 382 us at 64, the
+    //  in-order step 2.56 -> 2.80 / 2.60 / 2.53 ms: the batch binning is not bound by where its atomics land, unlike the
+    //  one-molecule call, see k_bin_solo)
+    const unsigned lb = blockIdx.x;
     // the items of the block's first and last atom (block-uniform: scalar loads); one block rarely spans several
-    const long long a_first = (long long)blockIdx.x * blockDim.x;
+    const long long a_first = (long long)lb * blockDim.x;
     const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
     int b_lo, b_hi;
     items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
@@ -569,7 +578,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     if (classes) {
         mk_block_sync();
         if (threadIdx.x < CLS_BLOCK_SET)
-            block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
+            block_sets[(size_t)lb * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
     }
 }
 
@@ -605,7 +614,8 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
     if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
     if (threadIdx.x == 0) s_full = 0u;
     mk_block_sync();
-    unsigned* const words = counts + (size_t)g.B * g.cstride;
+    unsigned* const words = counts;
+    counts += DIRECT_HEAD;
     const int lane = threadIdx.x & (WAVE - 1);
     const long long a_first = (long long)blockIdx.x * blockDim.x;
     const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
@@ -679,13 +689,13 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         }
     }
     const size_t cell = want ? (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2] : (size_t)0;
-    const unsigned rank = wave_rank_in_cell(want, (unsigned)cell, counts);
+    const unsigned rank = wave_rank_in_cell(want, (unsigned)cell << g.cnt_shift, counts);
     if (want) {
         unsigned slot;
         if (rank < (unsigned)g.cell_cap) {
             slot = (unsigned)cell * (unsigned)g.cell_cap + rank;
         } else {                                                               // the cell is full: the item's spill area
-            const unsigned sp = mk_atomic_add(&counts[(size_t)b * g.cstride + g.ncell], 1u);     // (the item's spare counter)
+            const unsigned sp = mk_atomic_add(&counts[((size_t)b * g.cstride + g.ncell) << g.cnt_shift], 1u);     // (the item's spare counter)
             (void)mk_atomic_add(&words[DIRECT_SPILLED], 1u);                   // statistics
             slot = g.spill_base + (unsigned)b * g.spill_cap + (sp < g.spill_cap ? sp : 0u);
             if (sp >= g.spill_cap) { want = false; failed = true; }
@@ -765,18 +775,22 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
     if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
     if (threadIdx.x == 0) s_full = 0u;
     mk_block_sync();
-    unsigned* const words = counts + (size_t)g.B * g.cstride;
+    unsigned* const words = counts;
+    counts += DIRECT_HEAD;
     const int lane = threadIdx.x & (WAVE - 1);
     const long long a_first = (long long)blockIdx.x * blockDim.x;
     const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
-    int b_lo, b_hi;
-    items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
     const long long a = a_first + threadIdx.x;
     const bool act = a < total_atoms;
     // everything the atom needs from memory is asked for up front: the call's length is a chain of round trips
     unsigned tab = lane < CLS_TABLE_WORDS ? cls_table[lane] : CLS_EMPTY;
     float xyz[3] = {0.f, 0.f, 0.f};
     if (act) { xyz[0] = coords[3 * a + 0]; xyz[1] = coords[3 * a + 1]; xyz[2] = coords[3 * a + 2]; }
+    const bool one = g.B == 1;                                                 // one molecule per call: no item to look up
+    double org[3] = {0.0, 0.0, 0.0};
+    if (one) { org[0] = origins[0]; org[1] = origins[1]; org[2] = origins[2]; }
+    int b_lo = 0, b_hi = 0;
+    if (!one) items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
     float w[CHG];
 #pragma unroll
     for (int j = 0; j < CHG; ++j) w[j] = mk_inf();
@@ -807,12 +821,15 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
     float rel[3] = {0.f, 0.f, 0.f};
     int b = 0;
     if (want) {
-        int lo = b_lo, hi = b_hi + 1;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+        if (!one) {
+            int lo = b_lo, hi = b_hi + 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+            }
+            b = lo;
+            org[0] = origins[3 * (size_t)b + 0]; org[1] = origins[3 * (size_t)b + 1]; org[2] = origins[3 * (size_t)b + 2];
         }
-        b = lo;
         const int nvox[3] = {g.nx, g.ny, g.nz};
         if (affine != nullptr) {
             const double* A = affine + 12 * (size_t)b;
@@ -825,7 +842,7 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
         const int nc[3] = {g.ncx, g.ncy, g.ncz};
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const double q = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+            const double q = ((double)xyz[ax] - org[ax]) * g.inv_res;
             if (q < -g.Rp || q > (double)(nvox[ax] - 1) + g.Rp) want = false;
             const int ci = (int)floor((q + 0.5) * inv_cs);
             pc[ax] = ci + g.h;
@@ -834,13 +851,13 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
         }
     }
     const size_t cell = want ? (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2] : (size_t)0;
-    const unsigned rank = wave_rank_in_cell(want, (unsigned)cell, counts);
+    const unsigned rank = wave_rank_in_cell(want, (unsigned)cell << g.cnt_shift, counts);
     if (want) {
         unsigned slot;
         if (rank < (unsigned)g.cell_cap) {
             slot = (unsigned)cell * (unsigned)g.cell_cap + rank;
         } else {                                                               // the cell is full: the item's spill area
-            const unsigned sp = mk_atomic_add(&counts[(size_t)b * g.cstride + g.ncell], 1u);     // (the item's spare counter)
+            const unsigned sp = mk_atomic_add(&counts[((size_t)b * g.cstride + g.ncell) << g.cnt_shift], 1u);     // (the item's spare counter)
             (void)mk_atomic_add(&words[DIRECT_SPILLED], 1u);                   // statistics
             slot = g.spill_base + (unsigned)b * g.spill_cap + sp;              // (it holds every atom of the call)
             want = sp < g.spill_cap;
@@ -856,8 +873,10 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
             }
             rec_pos[slot] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20) | (level << 30)));
             rec_cls[slot] = ids;
+#ifndef MK_SOLO_NO_RECW   // (timing experiment)
             rec_w[slot] = make_float4(w[0], w[1], w[2], w[3]);
             rec_w[(size_t)g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
+#endif
         }
     }
     mk_block_sync();
@@ -1314,7 +1333,7 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
         // overflowed their capacity, normally none -- is one more run that every tile of the item looks at: candidates
         // are culled by their distance to the tile, so seeing a record too many is harmless (a record of ANOTHER item
         // would not be: the packed cell word has no room for the item, hence one spill area per item)
-        const unsigned* __restrict__ cnt = g.direct_words;
+        const unsigned* __restrict__ cnt = g.direct_words + DIRECT_HEAD;
         const int nxc = tg.cx_hi - tg.cx_lo + 1, nyc = tg.cy_hi - tg.cy_lo + 1, nzc = tg.cz_hi - tg.cz_lo + 1;
         const int ncells = nxc * nyc * nzc;
         if (lane < ncells) {
@@ -1326,12 +1345,12 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
             const float gz = fmaxf(fmaxf((float)tg.z0 - (cz0 + fcs), cz0 - (float)(tg.z0 + 7)), 0.f);
             if (gx * gx + gy * gy + gz * gz < g.R2cull) {
                 const size_t cell = (size_t)tg.b * g.cstride + ((size_t)pcx * g.ncy + pcy) * g.ncz + pcz;
-                const unsigned n = cnt[cell];
+                const unsigned n = cnt[cell << g.cnt_shift];
                 cr.r0 = (unsigned)cell * (unsigned)g.cell_cap;
                 cr.len = n < (unsigned)g.cell_cap ? n : (unsigned)g.cell_cap;
             }
         } else if (lane == WAVE - 1) {
-            const unsigned n = cnt[(size_t)tg.b * g.cstride + g.ncell];         // the item's spare counter: its spilled records
+            const unsigned n = cnt[((size_t)tg.b * g.cstride + g.ncell) << g.cnt_shift];     // the item's spare counter: its spilled records
             cr.r0 = g.spill_base + (unsigned)tg.b * g.spill_cap;
             cr.len = n < g.spill_cap ? n : g.spill_cap;
         }

@@ -95,7 +95,7 @@ inline int plan_lattice(const LatticeProblem& P, GridDesc& g, std::string& err)
     // value step at the cutoff = 1-exp(-(1/(R2 w))^6) > 5e-6  <=>  R2 w < (5e-6)^(-1/6) = 7.647  (sigma > 1.81 A)
     g.w_exact_max = (float)(7.647 / (R * R));
     // 1 - exp(-t^-6) < eps beyond t = w d^2 = eps^(-1/6); off (0) unless the caller opted in.  Capped at 1e-5: the parity bound
-    g.cell_cap = 0; g.spill_base = 0u; g.spill_cap = 0u; g.direct_words = nullptr;
+    g.cell_cap = 0; g.spill_base = 0u; g.spill_cap = 0u; g.direct_words = nullptr; g.cnt_shift = 0;
     g.reach_tau = (P.value_tol > 0.0) ? (float)std::pow(std::min(P.value_tol, 1e-5), -1.0 / 6.0) : 0.f;
     g.Rp = R + 1e-3;
     g.rint = (int)std::ceil(R);
@@ -348,7 +348,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (direct) {
             g.cell_cap = direct_cap; g.spill_base = (unsigned)(ncells * (size_t)direct_cap); g.spill_cap = spill;
             mrec = std::max<size_t>(mrec, (size_t)slots);
-            dbytes = ((ncells + DIRECT_WORDS) * sizeof(unsigned) + 255) & ~(size_t)255;
+            g.cnt_shift = (solo && ncells <= (1u << 16)) ? 5 : 0;        // small calls: a 128-byte line per counter (see GridDesc)
+            dbytes = (((size_t)DIRECT_HEAD + (ncells << g.cnt_shift)) * sizeof(unsigned) + 255) & ~(size_t)255;
             if ((st = be.ensure(WS_DIRECT_COUNT, dbytes, &dcnt, set))) return st;
             if (cs.dptr != dcnt) { cs.dptr = dcnt; cs.dclean = 0; }
             // the direct counters and the control words of this call: zero -- k_tail leaves them so after a solo call
@@ -422,7 +423,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
         fix_summary = g.force_general ? nullptr : (const unsigned*)bsets;
         fix_waves = P.total_atoms > 0 ? nblk : 0u;
-        const unsigned* dfail = g.direct_words ? g.direct_words + ncells + DIRECT_FAILED : nullptr;
+        const unsigned* dfail = g.direct_words ? g.direct_words + DIRECT_FAILED : nullptr;
         if (solo) {
             st = P.sigmas_f64 ? be.launch(k_bin_solo<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas, P.origins,
                                           P.affine, (unsigned*)dcnt, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (uint2*)tcls, (unsigned*)ctab, (unsigned*)bsets)
@@ -497,7 +498,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
     ta.fix_waves = fix_waves; ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
-    if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(ncells + DIRECT_WORDS); }
+    if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(DIRECT_HEAD + (ncells << g.cnt_shift)); }
     be.hot_begin();
     st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
                   : launch_tiles<4>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);

@@ -95,10 +95,8 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     if (fills_out) *fills_out = be.fills;
     if (direct_words_out) {
         // what the direct pass of the LAST call reported (all ones when the call had none)
-        GridDesc gd; std::string e2;
-        const bool had = be.bufs[WS_DIRECT_COUNT] != nullptr && plan_lattice(P, gd, e2) == ST_OK;
-        const size_t nc = had ? (size_t)gd.B * (size_t)gd.cstride : 0;
-        for (int i = 0; i < DIRECT_WORDS; ++i) direct_words_out[i] = had ? ((const unsigned*)be.bufs[WS_DIRECT_COUNT])[nc + i] : 0xffffffffu;
+        const bool had = be.bufs[WS_DIRECT_COUNT] != nullptr;
+        for (int i = 0; i < DIRECT_WORDS; ++i) direct_words_out[i] = had ? ((const unsigned*)be.bufs[WS_DIRECT_COUNT])[i] : 0xffffffffu;
     }
     if (err_flag_out) *err_flag_out = *(int*)be.bufs[WS_ERR];
     if (feedback_io) for (int i = 0; i <= NTIER; ++i) feedback_io[i] = be.feedback[i];
