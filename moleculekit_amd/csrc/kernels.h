@@ -51,9 +51,6 @@ constexpr int CHG = 8;               // channels per channel-group (one group = 
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per class table (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
-#ifndef MK_TEAM_OWN_MAX   // team kernel: classes of up to this many (padded) entry slots go to one wave whole (voxelize_tile)
-#define MK_TEAM_OWN_MAX 64
-#endif
 #ifndef MK_DIAG           // tools/gpu_diag.sh builds only: compile parts of the tile kernel out to count what they cost
 #define MK_DIAG 0         // 1 pair loops, 2 class flushes, 4 epilogue arithmetic, 8 placement + all class work, 16 histogram traversal
 #endif
@@ -1791,8 +1788,21 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             if (lead) dense_list[mk_atomic_add(dense_count, 1u)] = lt + (unsigned)gq * ((unsigned)g.B * (unsigned)g.ntiles);
             return;                                                          // (the whole team: `total` is the same in every wave)
         }
-        const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u);
-        const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u);
+        // A team splits the tile's sorted entry SLOTS into TEAM contiguous ranges of whole pairs, one per wave: a wave walks
+        // only the classes its range touches (all of a small class, a part of a big one -- clamped in the loops below), so
+        // the fixed work of a class (loop set-ups, the flush: ~70 instructions) is paid about once per class and team, and
+        // the waves finish together.  (Dealing the pairs of every class round-robin made every wave pay for every class:
+        // cfg2's tiles hold 27 classes of ~12 entries, the one-grid call was bound by exactly that; whole small classes
+        // dealt round-robin were better but uneven.)  Minima are order-free and the flush is monotone in the class
+        // minimum: the bits do not depend on who looked at an entry.
+        unsigned my_b = 0u, my_e = 0xffffffffu;              // this wave's slots [my_b, my_e), both even (wave-uniform)
+        if (TEAM > 1) {
+            const unsigned share = (((total >> 1) + (unsigned)TEAM - 1u) / (unsigned)TEAM) << 1;
+            my_b = (unsigned)wv * share;
+            my_e = my_b + share;
+        }
+        const unsigned long long ne0 = mk_ballot((cnt[0] | cnt[1] | cnt[2]) != 0u && (TEAM == 1 || (start[0] < my_e && start[3] > my_b)));
+        const unsigned long long ne1 = mk_ballot((cnt[3] | cnt[4] | cnt[5]) != 0u && (TEAM == 1 || (start[3] < my_e && start[5] + pad[5] > my_b)));
         // non-empty classes of channel c (which owns groups 16c..16c+15 = lanes 8c..8c+7, two groups each)
         auto class_bits = [&](int c) {
             const unsigned e = (unsigned)(ne0 >> (8 * c)) & 0xffu, o = (unsigned)(ne1 >> (8 * c)) & 0xffu;
@@ -1802,28 +1812,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         };
         // ---- one channel, class by class: inner loop = sub, fma, half a min3 per (voxel, entry); the
         //      class flush applies the cutoff to the class minimum and scales by w ----
-        unsigned deal = 0u;                                  // team: the wave the next pair goes to (wave-uniform)
-        unsigned next_owner = 0u;                            // team: the wave the next SMALL class goes to (wave-uniform)
         auto process_classes = [&](int c, unsigned bits, unsigned (&acc)[KL]) {
             while (bits) {                                                // wave-uniform
                 const int cls = __builtin_ctz(bits);
                 bits &= bits - 1u;
                 const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
                 const uint4 bg = make_uint4(mk_uniform(bgp[0]), mk_uniform(bgp[1]), mk_uniform(bgp[2]), mk_uniform(bgp[3]));
-                // A team deals the PAIRS of a class round-robin -- but every wave then pays the class's fixed work (three
-                // loop set-ups, the flush: ~100 instructions) for its share, and a one-grid call is bound by exactly that:
-                // cfg2's tiles hold 27 classes of ~12 entries.  A class of at most TEAM_OWN_MAX slots therefore goes to ONE
-                // wave, whole (the others skip it); the big classes of a real protein are dealt as before.  Minima are
-                // order-free: the bits do not depend on who looked at an entry.
-                bool owned = false;                                       // wave-uniform
-                if (TEAM > 1) {
-                    owned = (bg.w & ~1u) - (bg.x & ~1u) <= (unsigned)MK_TEAM_OWN_MAX;
-                    if (owned) {
-                        const unsigned owner = next_owner;
-                        next_owner = (next_owner + 1u) & (unsigned)(TEAM - 1);
-                        if ((unsigned)wv != owner) continue;
-                    }
-                }
                 const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
                 // m[k] = min over the class's entries of g_k = d^2 - c_k^2 (c_k = x of plane k relative to the tile centre):
                 // with D0 = ex^2 + dy^2 + dz^2 per (lane, entry), g_k = D0 - 2 c_k ex is ONE fma per (voxel, entry); the
@@ -1839,35 +1833,33 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     if (MK_DIAG & 1) return;
                     constexpr int J0 = K0, J1 = K1;
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
-                    // a team's wave takes every TEAM-th pair, dealt round-robin ACROSS the sub-buckets (`deal` = whose turn it
-                    // is: the same in every wave) -- most sub-buckets hold one to three pairs, and starting each of them at
-                    // wave 0 gave that wave 60 pairs of a cfg2 tile and the last one 20; the unpaired last entry is dealt too
                     const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
-                    const unsigned first = (TEAM > 1 && !owned) ? (((unsigned)wv + (unsigned)TEAM - deal) & (unsigned)(TEAM - 1)) : 0u;
-                    const unsigned step = (TEAM > 1 && !owned) ? 2u * (unsigned)TEAM : 2u;
-                    const float* e = sxyz + s0 + 2u * first;
+                    unsigned lo = s0, hi = s0 + 2u * npairs;              // the pairs of the sub-bucket, clamped to this wave's range
+                    if (TEAM > 1) { lo = lo > my_b ? lo : my_b; hi = hi < my_e ? hi : my_e; }
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
                     //  have to be merged after every one of these short runs -- measured 7 % slower)
                     // (the LDS address is the only induction variable: a trip counter ends up in a VGPR with a carry-out
                     //  compare -- one VALU instruction per trip more, PMC: 8 970 -> 8 739 per tile)
-                    const float* const e_end = sxyz + s0 + 2u * npairs;
+                    if (TEAM == 1 || lo < hi) {
+                        const float* e = sxyz + lo;
+                        const float* const e_end = sxyz + hi;
 #pragma clang loop vectorize(disable) interleave(disable)
-                    for (; TEAM > 1 ? e < e_end : e != e_end; e += (TEAM > 1 ? step : 2u)) {
-                        // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
-                        // (fetching the next pair one trip ahead was measured: 2-4 % slower, the copies cost more)
-                        const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
-                        const mk_f2 dy = Y2 - py, dz = Z2 - pz;
-                        const mk_f2 d0 = mk_f2_fma(px, px, mk_f2_fma(dy, dy, dz * dz));
+                        for (; e != e_end; e += 2) {
+                            // a PAIR of entries per trip (s0 is even: 8-byte aligned), both halves of every packed op used
+                            // (fetching the next pair one trip ahead was measured: 2-4 % slower, the copies cost more)
+                            const mk_f2 px = mk_f2_load(e), py = mk_f2_load(e + ESTRIDE), pz = mk_f2_load(e + 2 * ESTRIDE);
+                            const mk_f2 dy = Y2 - py, dz = Z2 - pz;
+                            const mk_f2 d0 = mk_f2_fma(px, px, mk_f2_fma(dy, dy, dz * dz));
 #pragma unroll
-                        for (int k = J0; k < J1; ++k) {
-                            const mk_f2 gk = mk_f2_fma(mk_f2_splat(pl_slope(k)), px, d0);
-                            m[k] = mk_min3(m[k], gk[0], gk[1]);
+                            for (int k = J0; k < J1; ++k) {
+                                const mk_f2 gk = mk_f2_fma(mk_f2_splat(pl_slope(k)), px, d0);
+                                m[k] = mk_min3(m[k], gk[0], gk[1]);
+                            }
                         }
                     }
-                    const bool tail_mine = TEAM == 1 || owned || (unsigned)wv == ((deal + npairs) & (unsigned)(TEAM - 1));
-                    if (TEAM > 1 && !owned) deal = (deal + npairs + odd) & (unsigned)(TEAM - 1);
-                    if (odd && tail_mine) {                               // wave-uniform: the unpaired last entry
-                        const float* t = sxyz + s0 + 2u * npairs;
+                    const unsigned tslot = s0 + 2u * npairs;              // the unpaired last entry's slot
+                    if (odd && (TEAM == 1 || (tslot >= my_b && tslot < my_e))) {                  // wave-uniform
+                        const float* t = sxyz + tslot;
                         const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
                         const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
 #pragma unroll
@@ -1879,11 +1871,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 auto run_exact = [&](unsigned b0, unsigned b1) {
                     if (MK_DIAG & 1) return;
                     const unsigned s0 = b0 & ~1u;
-                    const unsigned n = ((b1 & ~1u) - s0) - (b0 & 1u);
-                    const float* e = sxyz + s0;
+                    unsigned lo = s0, hi = (b1 & ~1u) - (b0 & 1u);        // the entries of the sub-bucket, clamped to this wave's range
+                    if (TEAM > 1) { lo = lo > my_b ? lo : my_b; hi = hi < my_e ? hi : my_e; }
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
-                    for (unsigned i = ((TEAM > 1 && !owned) ? (unsigned)wv : 0u); i < n; i += ((TEAM > 1 && !owned) ? (unsigned)TEAM : 1u)) {   // (a team's wave: every TEAM-th entry)
-                        const float* ee = e + i;
+                    for (unsigned i = lo; i < hi; ++i) {
+                        const float* ee = sxyz + i;
                         const float px = ee[0], dy = Y - ee[ESTRIDE], dz = Z - ee[2 * ESTRIDE];
                         const float r = mk_fma(dy, dy, dz * dz);
 #pragma unroll
