@@ -97,6 +97,9 @@ struct mkamd_ctx {
     const volatile unsigned* feedback_host() const { return fb_host; }
     unsigned* feedback_dev() const { return fb_dev; }
     void note_error_flag_mirrored(bool yes) { err_mirrored = yes; }
+    void note_tail_reports(bool yes) { tail_reports = yes; }
+    bool tail_reports = false;             // the last lattice call's k_tail writes FB_TILES_DONE / FB_TAIL_WROTE with seq_next
+    unsigned seq_next = 0, seq_counter = 0; // sequence number handed to the next lattice call (0 = none)
     int ensure(int slot, size_t bytes, void** ptr, int set = 0)
     {
         slot += set * WS_NSLOTS;
@@ -423,7 +426,8 @@ try {
 int mkamd_ctx_set_tile_team(mkamd_ctx* ctx, int mode)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (mode < -1 || mode > 1) return fail(MKAMD_EINVAL, "tile team mode must be -1 (automatic), 0 (one wave per tile) or 1 (a team of waves per tile)");
+    if (mode < -1 || (mode > 1 && mode != 4 && mode != 8 && mode != 16))
+        return fail(MKAMD_EINVAL, "tile team mode must be -1 (automatic), 0 (one wave per tile), 1 (a team of waves per tile) or 4 / 8 / 16 (a team of that many waves)");
     ctx->tile_team = mode;
     return MKAMD_OK;
 } MK_API_CATCH
@@ -624,7 +628,7 @@ try {
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
     P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
-    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol; P.direct = ctx->direct;
+    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol; P.direct = ctx->direct; P.seq = ctx->seq_next; ctx->seq_next = 0u;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;
@@ -654,8 +658,26 @@ __attribute__((target("avx2"))) static void widen_avx2(const float* __restrict__
 {
     for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
 }
+// AVX-512 hosts: 16 values per trip, the source (device-written pinned memory: it comes from DRAM) prefetched ahead
+__attribute__((target("avx512f"))) static void widen_avx512(const float* __restrict__ src, double* __restrict__ dst, size_t n)
+{
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        __builtin_prefetch(src + i + 512, 0, 0);
+        typedef float v16f __attribute__((vector_size(64), aligned(4)));
+        typedef double v8d __attribute__((vector_size(64), aligned(8)));
+        typedef float v8f __attribute__((vector_size(32)));
+        const v16f v = *(const v16f*)(src + i);
+        const v8f lo = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(v, v, 8, 9, 10, 11, 12, 13, 14, 15);
+        *(v8d*)(dst + i) = __builtin_convertvector(lo, v8d);
+        *(v8d*)(dst + i + 8) = __builtin_convertvector(hi, v8d);
+    }
+    for (; i < n; ++i) dst[i] = (double)src[i];
+}
 static void widen(const float* __restrict__ src, double* __restrict__ dst, size_t n)
 {
+    static const bool avx512 = __builtin_cpu_supports("avx512f") && getenv("MKAMD_NO_AVX512") == nullptr;
+    if (avx512) { widen_avx512(src, dst, n); return; }
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) { widen_avx2(src, dst, n); return; }
     for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
@@ -768,13 +790,26 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
     for (int b = 0; b < B; ++b) biggest = std::max<long long>(biggest, atom_offsets[b + 1] - atom_offsets[b]);
     const int saved_mode = ctx->prepass_mode;
     if (saved_mode < 0 && biggest > 16384) ctx->prepass_mode = 0;
+    // small results: the host pass over them (copy / float64 widening) starts when the TILE kernel is done (k_tail says so in
+    // the host-visible feedback words as it starts), not when the stream is -- see FB_TILES_DONE
+    unsigned seq = 0u;
+    if (mapped_out && ctx->fb_host != nullptr) { if (++ctx->seq_counter == 0u) ctx->seq_counter = 1u; seq = ctx->seq_counter; }
+    ctx->seq_next = seq;
+    ctx->tail_reports = false;
     st = mkamd_voxelize_lattice_dev(ctx, B, (const float*)dx, (const int64_t*)doff, N, ds, sigmas_are_f64, C,
                                     (const double*)dorg, nvoxels, voxelsize, box ? (const float*)dbox : nullptr,
                                     max_images, (float*)dout);
     ctx->prepass_mode = saved_mode;
+    ctx->seq_next = 0u;
     if (st) return st;
     MK_HOST_MARK(1);                                                // kernels enqueued
     const size_t nvals = out_bytes / 4;
+    // wait for "tile kernel done" (a read of host memory per poll; gives up after ~1 ms: the stream wait below covers it)
+    bool early = false;
+    if (seq != 0u && ctx->tail_reports) {
+        const volatile unsigned* fb = ctx->fb_host;
+        for (int i = 0; i < 400000 && !early; ++i) early = fb[FB_TILES_DONE] == seq;
+    }
     if (!mapped_out) prefault_big_result(features64 ? (void*)features64 : (void*)features, features64 ? out_bytes * 2 : out_bytes);
     if (features64) {
         const float* src = (const float*)ctx->out_host;
@@ -783,15 +818,29 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
             HIP_TRY(hipMemcpyAsync(ctx->f32_stage.data(), dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
             src = ctx->f32_stage.data();
         }
-        HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
-        MK_HOST_MARK(2);                                            // waited for the stream
-        widen(src, features64, nvals);
-        MK_HOST_MARK(3);                                            // float32 -> float64 into the caller's array
+        if (early) {
+            MK_HOST_MARK(2);                                        // waited for the tile kernel
+            widen(src, features64, nvals);                          // ... while k_tail runs and the stream signals its completion
+            MK_HOST_MARK(3);
+            HIP_TRY(wait_for_small_call(ctx->stream));
+            if (((const volatile unsigned*)ctx->fb_host)[FB_TAIL_WROTE] == seq) widen(src, features64, nvals);     // k_tail changed values (rare): once more
+        } else {
+            HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
+            MK_HOST_MARK(2);                                        // waited for the stream
+            widen(src, features64, nvals);
+            MK_HOST_MARK(3);                                        // float32 -> float64 into the caller's array
+        }
         st = collect_async_errors(ctx);
         MK_HOST_MARK(4);
         return st;
     }
     if (!mapped_out) HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (early) {
+        memcpy(features, ctx->out_host, out_bytes);
+        HIP_TRY(wait_for_small_call(ctx->stream));
+        if (((const volatile unsigned*)ctx->fb_host)[FB_TAIL_WROTE] == seq) memcpy(features, ctx->out_host, out_bytes);
+        return collect_async_errors(ctx);
+    }
     HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
     if (mapped_out) memcpy(features, ctx->out_host, out_bytes);
     return collect_async_errors(ctx);

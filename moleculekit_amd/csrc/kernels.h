@@ -66,7 +66,10 @@ constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
 constexpr int NTIER = 3;
 constexpr int ECAP_TIER[NTIER] = {640, 768, 1024};
 constexpr int DENSE_WORDS = 1 + NTIER;   // [0] dense-list length, [1+t] tiles with more entries than tier t holds
-constexpr int FEEDBACK_WORDS = NTIER + 2; // host-visible: [t] tiles over tier t, [NTIER] tiles, [NTIER+1] the error flag
+constexpr int FEEDBACK_WORDS = NTIER + 4; // host-visible: [t] tiles over tier t, [NTIER] tiles, [NTIER+1] the error flag,
+                                          // [NTIER+2] sequence number of the call whose tile kernel has finished (k_tail
+                                          // writes it as it starts), [NTIER+3] of the last call whose k_tail changed values
+constexpr int FB_TILES_DONE = NTIER + 2, FB_TAIL_WROTE = NTIER + 3;
 constexpr int TRAV_BATCH = MK_TRAV_BATCH;   // candidate chunks whose loads are in flight together
 constexpr int NXR = 3;               // x-reach sub-buckets: 0 = all K planes, 1 = low half only, 2 = high half only
 constexpr int NBUCKET3 = NBUCKET * NXR;
@@ -1540,9 +1543,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                           unsigned* __restrict__ dense_count, unsigned* __restrict__ dense_list)
 {
     static_assert(K == 4 || K == 8, "K");
-    static_assert(TEAM == 1 || (!DENSE && K % TEAM == 0 && (TEAM & (TEAM - 1)) == 0), "a team (a power of two of waves) splits the planes of the epilogue evenly");
+    static_assert(TEAM == 1 || (!DENSE && (K % TEAM == 0 || TEAM % K == 0) && (TEAM & (TEAM - 1)) == 0 && TEAM <= K * CHG / 2),
+                  "a team (a power of two of waves) splits the planes -- and, beyond K waves, the channels -- of the epilogue evenly");
     constexpr int KL = K;                                 // planes in this wave's accumulators (all of them)
-    constexpr int KE = K / TEAM;                          // planes of the epilogue this wave owns: [kb, kb + KE)
+    constexpr int KE = TEAM <= K ? K / TEAM : 1;          // planes of the epilogue this wave owns: [kb, kb + KE)
+    constexpr int CSPLIT = TEAM <= K ? 1 : TEAM / K;      // ... and, for teams of more than K waves, which channels of them:
+    constexpr int CE = CHG / CSPLIT;                      //     [cb, cb + CE)
     MK_PHASE_BEGIN();
     // sorted path: entries as structure-of-arrays so that a PAIR of entries is three 8-byte
     // broadcast reads (ds_read_b64: 2 LDS cycles each).  LDS per tile is what bounds occupancy here
@@ -1589,7 +1595,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wv = TEAM > 1 ? (int)(threadIdx.x >> 6) : 0;
-    const int kb = wv * KE;
+    const int kb = TEAM <= K ? wv * KE : wv / CSPLIT;
+    const int cb = (wv % CSPLIT) * CE;
     const bool lead = lane == 0 && wv == 0;               // the one thread of the tile's team that reports to global memory
     // x of this wave's plane j relative to the tile centre (compile-time constants for the one-wave kernel)
     auto pl_x = [&](int j) { return plane_x<K>(j); };
@@ -2069,9 +2076,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 if (q[c][k] != INF_BITS) mk_lds_min(&s_red[(c * K + k) * WAVE + lane], q[c][k]);
         mk_block_sync();
 #pragma unroll
-        for (int c = 0; c < CHG; ++c)
+        for (int c = 0; c < CE; ++c)
 #pragma unroll
-            for (int k = 0; k < KE; ++k) q[c][k] = s_red[(c * K + kb + k) * WAVE + lane];    // (planes [kb, kb + KE) move to the front)
+            for (int k = 0; k < KE; ++k) q[c][k] = s_red[((cb + c) * K + kb + k) * WAVE + lane];   // (this wave's planes and channels move to the front)
     }
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
     const int y = tg.y0 + ly, z = tg.z0 + lz;
@@ -2081,10 +2088,20 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         const int x = tg.x0 + kb + k;
         float f[CHG];
 #pragma unroll
-        for (int c = 0; c < CHG; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
+        for (int c = 0; c < CE; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
         if (yz_in && x < g.nx) {
             const size_t vox = (size_t)tg.b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
-            if (g.C == CHG) {
+            if constexpr (CSPLIT > 1) {                      // a big team: this wave stores CE channels of the voxel (16 or 8 bytes)
+                float* o = out + vox * (size_t)g.C + (size_t)gq * CHG + cb;
+                if (g.C == CHG) {
+                    if constexpr (CE == 4) *reinterpret_cast<float4*>(o) = make_float4(f[0], f[1], f[2], f[3]);
+                    else *reinterpret_cast<float2*>(o) = float2{f[0], f[1]};
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CE; ++c)
+                        if (gq * CHG + cb + c < g.C) o[c] = f[c];
+                }
+            } else if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
                 o[0] = make_float4(f[0], f[1], f[2], f[3]);
                 o[1] = make_float4(f[4], f[5], f[6], f[7]);
@@ -2139,8 +2156,8 @@ __attribute__((amdgpu_num_vgpr(52))) MK_KERNEL(64) void k_voxelize_tiles_lean(Gr
 // TEAM waves per tile (voxelize_tile): for launches of fewer tiles than the chip has SIMDs, where the latency of one
 // tile is the latency of the call.
 constexpr int TILE_TEAM = 4;
-template <int K, int ECAP>
-MK_KERNEL(TILE_TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned* __restrict__ cell_start,
+template <int K, int ECAP, int TEAM = TILE_TEAM>
+MK_KERNEL(TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned* __restrict__ cell_start,
                                     const float4* __restrict__ rec_pos,
                                     const float4* __restrict__ rec_w, const unsigned* __restrict__ rec_cls,
                                     const unsigned* __restrict__ cls_table, float* __restrict__ out,
@@ -2149,7 +2166,7 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_tiles_team(GridDesc g, const unsigned*
     const unsigned per_xcd = gridDim.x >> 3;      // gridDim.x is a multiple of 8 (host pads)
     const unsigned lt = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (lt >= (unsigned)g.B * (unsigned)g.ntiles) return;                // the whole team leaves together
-    voxelize_tile<K, false, ECAP, TILE_TEAM>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
+    voxelize_tile<K, false, ECAP, TEAM>(g, lt, (int)blockIdx.y, cell_start, rec_pos, rec_w, rec_cls, cls_table, out, dense_count, dense_list);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2570,7 +2587,8 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
                               const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
                               long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                               const float* __restrict__ box, const double* __restrict__ affine,
-                              const uint2* __restrict__ tmp_cls, float* __restrict__ out, double* s_best)
+                              const uint2* __restrict__ tmp_cls, float* __restrict__ out, double* s_best,
+                              unsigned* __restrict__ feedback = nullptr, unsigned seq = 0u)
 {
     const int lane = threadIdx.x;
     const float wmax = g.w_exact_max;
@@ -2666,6 +2684,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
                             hits &= hits - 1ull;
                             const int vx = (int)mk_readlane((unsigned)ix, hl), vy = (int)mk_readlane((unsigned)iy, hl);
                             const int vz = (int)mk_readlane((unsigned)(int)iz, hl);
+                            if (feedback != nullptr && lane == 0) feedback[FB_TAIL_WROTE] = seq;   // (the host may have read the tile kernel's values already)
                             for (int c = 0; c < g.C; ++c)                  // the atom's wide channels
                                 if (sigma_to_w(sigmas[(size_t)a * g.C + c], g.w_scale) < wmax)
                                     exact_recompute<SigT>(g, b, vx, vy, vz, c, coords, atom_offsets, sigmas, origins, box, affine, out, s_best);
@@ -2698,13 +2717,18 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
                           const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
                           const uint2* __restrict__ tmp_cls,
                           unsigned* __restrict__ solo_counts /* k_bin_solo's counters + control words, or nullptr */, unsigned solo_n,
-                          unsigned* __restrict__ solo_table)
+                          unsigned* __restrict__ solo_table, unsigned seq /* of this call (small host calls), else 0 */)
 {
     __shared__ double s_best[WAVE];
     const unsigned n = dense_words[0], total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     if (blockIdx.x == 0) {
         if (threadIdx.x <= (unsigned)DENSE_WORDS + 1u) other_words[threadIdx.x] = 0u;  // (+ the done counter and the role tickets)
         if (feedback && threadIdx.x == 0) {                                // host-visible: drives the next calls' tier
+            // A small synchronous host call converts / copies the result on the host; it starts as soon as the TILE kernel is
+            // done -- this launch starting says so -- instead of waiting for this launch and the stream's completion signal
+            // too, and repeats the pass in the rare case that this launch changes values (dense tiles, exact cut-off hits).
+            if (n != 0u) feedback[FB_TAIL_WROTE] = seq;
+            feedback[FB_TILES_DONE] = seq;
 #pragma unroll
             for (int t = 0; t < NTIER; ++t) feedback[t] = dense_words[1 + t];
             feedback[NTIER] = total_tiles * (unsigned)g.G;
@@ -2746,7 +2770,7 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
         if (me == 0u && threadIdx.x < (unsigned)CLS_TABLE_WORDS && overflow_word != CLS_EMPTY) solo_table[threadIdx.x] = CLS_EMPTY;
     }
     exact_fixup_block<SigT>(g, role - dense_wgs, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
-                            tmp_cls, out, s_best);
+                            tmp_cls, out, s_best, feedback, seq);
 }
 
 // ------------------------------------------------------------------------------------------------

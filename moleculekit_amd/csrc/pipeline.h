@@ -59,7 +59,8 @@ struct LatticeProblem {
     int direct = -1;                        // direct binning (k_bin_direct): 1 = whenever the geometry allows; -1 (automatic) and 0 = the chain
     int cell_cap = 0;                       // record slots per cell of the direct layout (0 = 128; tests shrink it to see cells spill)
     unsigned spill_cap = 0;                 // slots of an item's spill area in the direct layout (0 = max(1024, an eighth of the average item))
-    int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always
+    unsigned seq = 0;                       // != 0: k_tail reports this number in the host-visible feedback words as it starts (FB_TILES_DONE)
+    int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always (4, 8, 16: with that many waves)
     int tile_items = -1;                    // -1 = automatic (a workgroup per item for batches of ligand-sized items), 0 = never, 1 = always
     // device pointers
     const float* coords = nullptr;
@@ -204,6 +205,7 @@ struct TailArgs {
     const unsigned* summary = nullptr;
     const LatticeProblem* P = nullptr;
     const void* tcls = nullptr;
+    int team_waves = 0;                     // waves per tile of the team kernel (0 = by the number of tiles; 4, 8, 16: K = 4 only)
     unsigned* solo_counts = nullptr;        // a call binned by k_bin_solo: its counters (+ control words), zeroed by k_tail
     unsigned solo_n = 0;
 };
@@ -226,9 +228,21 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
         const unsigned blocks_per_item = (unsigned)((g.ntiles + tpb - 1) / tpb);
         st = be.launch(k_voxelize_items<K>, dim3((unsigned)g.B * blocks_per_item, (unsigned)g.G), dim3(WAVE * TILE_TEAM), g, (const unsigned*)start,
                        (const float4*)rpos, (const float4*)rw, (const unsigned*)rcls, (const unsigned*)ctab, out, tpb);
-    } else if (flavour == TILES_TEAM) {      // a handful of tiles (one grid per call): TILE_TEAM waves per tile
-        st = be.launch(k_voxelize_tiles_team<K, E>, tgrid, dim3(WAVE * TILE_TEAM), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
-                       (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
+    } else if (flavour == TILES_TEAM) {      // a handful of tiles (one grid per call): a team of waves per tile --
+        // four when that fills the chip (a 64^3 grid: 1 024 tiles), more for fewer tiles (a pocket: 54 tiles of K = 4)
+        auto go = [&](auto kern, int team) {
+            return be.launch(kern, tgrid, dim3((unsigned)(WAVE * team)), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
+                             (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist);
+        };
+        const unsigned long long tw = (unsigned long long)g.B * (unsigned)g.ntiles * (unsigned)g.G;
+        // (the 3PTB pocket, 54 tiles: 30.0 us per call with 4 waves per tile, 27.8 with 8, 28.3 with 16; a cfg2 grid, 1 024 tiles:
+        //  39.9 with 4, 46.6 with 8)
+        const int team = ta.team_waves > 0 ? ta.team_waves : (K == 4 && tw <= 256ull) ? 8 : TILE_TEAM;
+        if constexpr (K == 4) {
+            st = team == 16 ? go(k_voxelize_tiles_team<K, E, 16>, 16) : team == 8 ? go(k_voxelize_tiles_team<K, E, 8>, 8) : go(k_voxelize_tiles_team<K, E, TILE_TEAM>, TILE_TEAM);
+        } else {
+            st = go(k_voxelize_tiles_team<K, E, TILE_TEAM>, TILE_TEAM);
+        }
     } else if constexpr (T <= 1) {    // the biggest tier is LDS-bound to < 3 waves/SIMD anyway: no lean instance of it
         st = lean ? be.launch(k_voxelize_tiles_lean<K, E>, tgrid, dim3(WAVE), g, (const unsigned*)start, (const float4*)rpos, (const float4*)rw,
                               (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, (unsigned*)dlist)
@@ -246,7 +260,7 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
                              (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, ta.other_words, (const unsigned*)dlist,
                              g.force_general ? (unsigned*)nullptr : be.feedback_dev(), (const int*)eflag, ta.per_item, ta.summary, P.coords,
                              P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls, ta.solo_counts, ta.solo_n,
-                             (unsigned*)ctab);
+                             (unsigned*)ctab, g.force_general ? 0u : P.seq);
         };
         st = P.sigmas_f64 ? tail(k_tail<K, E, double>, (const double*)P.sigmas) : tail(k_tail<K, E, float>, (const float*)P.sigmas);
     }
@@ -498,6 +512,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
     ta.fix_waves = fix_waves; ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
+    ta.team_waves = (P.tile_team == 4 || P.tile_team == 8 || P.tile_team == 16) ? P.tile_team : 0;
     if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(DIRECT_HEAD + (ncells << g.cnt_shift)); }
     be.hot_begin();
     st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
@@ -511,6 +526,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (ta.dense_wgs + ta.fix_waves != 0u) cs.parity ^= 1u;       // k_tail has cleared the other copy: the next call's
     }
     be.note_error_flag_mirrored(!st && !g.force_general && ta.dense_wgs != 0u && be.feedback_dev() != nullptr);
+    be.note_tail_reports(!st && !g.force_general && ta.dense_wgs + ta.fix_waves != 0u && be.feedback_dev() != nullptr && P.seq != 0u);
     be.tile_done(set);
     return st;
 }

@@ -21,6 +21,7 @@ struct EmuBackend {
     int fills = 0;                      // memsets of the cell counters (the tests count them)
     CounterState& counter_state(int set) { return counters[set & 1]; }
     void note_error_flag_mirrored(bool) {}
+    void note_tail_reports(bool) {}
     const volatile unsigned* feedback_host() const { return feedback; }
     unsigned* feedback_dev() { return feedback; }
     ~EmuBackend() { for (void* p : bufs) free(p); }

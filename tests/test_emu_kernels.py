@@ -277,6 +277,13 @@ def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
     if name in ("ragged_batch", "channels11"):
         gen, e3 = E.voxelize_lattice(*args, box=case["box"], tile_k=tile_k, tile_team=1, force_general=True)
         assert e3 == 0 and np.array_equal(gen, one)
+    if tile_k == 4 and name in ("cfg1_3ptb", "ragged_batch", "channels11", "special_sigmas"):
+        # teams of 8 and 16 waves (a pocket's few dozen tiles): more waves than planes, so the epilogue splits the channels too
+        for waves in (8, 16):
+            big, e4 = E.voxelize_lattice(*args, box=case["box"], tile_k=4, tile_team=waves)
+            assert e4 == 0 and np.array_equal(big, one), waves
+        gen, e5 = E.voxelize_lattice(*args, box=case["box"], tile_k=4, tile_team=16, force_general=True)
+        assert e5 == 0 and np.array_equal(gen, one)
 
 
 @pytest.mark.parametrize("name", ["cfg3_small", "cfg5_small", "tiny_items", "ragged_batch", "pbc_batch", "channels11", "special_sigmas",
