@@ -175,6 +175,17 @@ int mkamd_voxelize_lattice_host_f64(mkamd_ctx* ctx, int32_t n_items, const float
                                     int sigmas_are_f64, int32_t n_channels, const double* origins,
                                     const int32_t* nvoxels, double voxelsize, const float* box,
                                     int32_t max_images_per_atom, double* features);
+/* The same call in two halves, for a caller with host work of its own to do while the device computes (the drop-in
+ * getVoxelDescriptors copies its cached voxel centres there, voxeldescriptors.py:245-247): `begin` checks the arguments,
+ * ships the inputs and enqueues the kernels (the input arrays must stay valid until `end`); `end` waits and writes the
+ * result into ONE of the two arrays (the other NULL).  One call at a time per context; a `begin` that is never ended is
+ * abandoned by the next `begin`. */
+int mkamd_voxelize_lattice_host_begin(mkamd_ctx* ctx, int32_t n_items, const float* coords,
+                                      const int64_t* atom_offsets, const void* sigmas,
+                                      int sigmas_are_f64, int32_t n_channels, const double* origins,
+                                      const int32_t* nvoxels, double voxelsize, const float* box,
+                                      int32_t max_images_per_atom);
+int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64);
 int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_coords,
                                const int64_t* d_atom_offsets, int64_t total_atoms,
                                const void* d_sigmas, int sigmas_are_f64, int32_t n_channels,

@@ -52,6 +52,8 @@ SIGNATURES = {
                                              _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_host_f64": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl,
                                                  _vp, _c_i32, _vp]),
+    "mkamd_voxelize_lattice_host_begin": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl, _vp, _c_i32]),
+    "mkamd_voxelize_lattice_host_end": (_c_int, [_vp, _vp, _vp]),
     "mkamd_voxelize_lattice_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
                                             _c_dbl, _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_aug_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
@@ -250,6 +252,18 @@ class Context:
         _check(fn(self._h, B, _ptr(coords), _ptr(offsets), _ptr(sigmas),
                                                   int(sig_f64), C, _ptr(origins), _ptr(nvox), float(voxelsize),
                                                   _ptr(box), int(max_images), _ptr(out)))
+
+    def voxelize_lattice_host_begin(self, B, coords, offsets, sigmas, sig_f64, C, origins, nvox, voxelsize, box, max_images):
+        """First half of voxelize_lattice_host: inputs shipped, kernels enqueued (the arrays must outlive ..._end)."""
+        _check(load().mkamd_voxelize_lattice_host_begin(self._h, B, _ptr(coords), _ptr(offsets), _ptr(sigmas), int(sig_f64), C,
+                                                        _ptr(origins), _ptr(nvox), float(voxelsize), _ptr(box), int(max_images)))
+
+    def voxelize_lattice_host_end(self, out):
+        """Second half: wait, result into `out` (float32 or float64, C-contiguous, B*V*C elements)."""
+        if out.dtype == np.float64:
+            _check(load().mkamd_voxelize_lattice_host_end(self._h, None, _ptr(out)))
+        else:
+            _check(load().mkamd_voxelize_lattice_host_end(self._h, _ptr(out), None))
 
     def voxelize_lattice_dev(self, B, d_coords, d_offsets, total_atoms, d_sigmas, sig_f64, C, d_origins, nvox,
                              voxelsize, d_box, max_images, d_out, d_affine=None):

@@ -83,6 +83,35 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, 
     return out.reshape(B, V, C)
 
 
+def voxelize_lattice_begin(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None, ctx=None, dtype=np.float32):
+    """``voxelize_lattice`` in two halves: the inputs are shipped and the kernels enqueued here; the function returned
+    waits and hands back features [B, V, C] of ``dtype`` (float32, or float64: widened by the library).  Host work done
+    between the two runs beside the device (the drop-in getVoxelDescriptors copies its voxel centres there)."""
+    ctx = ctx or _lib.default_context()
+    coords = np.ascontiguousarray(coords, dtype=np.float32).reshape(-1, 3)
+    atom_offsets = np.ascontiguousarray(atom_offsets, dtype=np.int64)
+    sigmas, sig64 = _sigma_array(sigmas)
+    if sigmas.ndim != 2 or sigmas.shape[0] != coords.shape[0]:
+        raise ValueError("sigmas must be (natoms, nchannels) matching coords")
+    origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    B = origins.shape[0]
+    if atom_offsets.shape != (B + 1,) or (B >= 0 and atom_offsets[-1] != coords.shape[0]):
+        raise ValueError("atom_offsets must have B+1 entries ending at the total atom count")
+    nv = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
+    C = int(sigmas.shape[1])
+    V = int(nv[0]) * int(nv[1]) * int(nv[2])
+    bx = None if box is None else np.ascontiguousarray(box, dtype=np.float32).reshape(B, 3)
+    ctx.voxelize_lattice_host_begin(B, coords, atom_offsets, sigmas, sig64, C, origins, nv, float(voxelsize), bx, 0)
+    keep = (coords, atom_offsets, sigmas, origins, nv, bx)            # the inputs outlive the call
+
+    def end(_keep=keep):
+        out = np.empty((B, V, C), dtype=dtype)
+        ctx.voxelize_lattice_host_end(out)
+        return out
+
+    return end
+
+
 def occupancy_centers(centers, coords, sigmas, box=None, ctx=None):
     """Arbitrary (non-lattice) centres: float32 [V, C] occupancies (calculate_occupancy semantics)."""
     ctx = ctx or _lib.default_context()

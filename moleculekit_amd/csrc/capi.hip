@@ -84,6 +84,8 @@ struct mkamd_ctx {
     size_t stage_cap = 0;
     std::vector<uint32_t> contacts_host;   // result of the last mkamd_contacts_trajectory_host call (owned here)
     std::vector<float> f32_stage;          // host staging of big float64-out results
+    struct PendingHostCall { bool active = false; size_t out_bytes = 0; bool mapped_out = false; unsigned seq = 0; void* dout = nullptr; };
+    PendingHostCall pending;               // a host call between its begin and its end (voxelize_lattice_host_begin_impl)
     void* out_host = nullptr;              // pinned, device-mapped result buffer of small _host calls (no D2H copy)
     void* out_host_dev = nullptr;          // its device-side address
     // tile-kernel timing
@@ -697,20 +699,26 @@ extern "C" void mkamd_debug_host_timers(double* out6) { for (int i = 0; i < 6; +
 #define MK_HOST_BEGIN() do {} while (0)
 #endif
 
-static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
-                                      const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
-                                      const int32_t* nvoxels, double voxelsize, const float* box,
-                                      int32_t max_images, float* features, double* features64)
+// A host call in two halves: `begin` checks, ships the inputs and enqueues the kernels; `end` waits and takes the result
+// out.  The one-piece entry points run them back to back; the drop-in getVoxelDescriptors does its own host work (the copy
+// of the cached voxel centres, 330 KB for a 24^3 grid) between the two, while the device computes.
+static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                            const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                            const int32_t* nvoxels, double voxelsize, const float* box, int32_t max_images)
 {
     MK_HOST_BEGIN();
     int st = check_ctx(ctx);
     if (st) return st;
+    if (ctx->pending.active) {                                      // a begin without its end: that call is abandoned
+        (void)hipStreamSynchronize(ctx->stream);
+        ctx->pending.active = false;
+    }
     if (B < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_items must be >= 0 and n_channels > 0");
     if (!nvoxels) return fail(MKAMD_EINVAL, "nvoxels pointer is NULL");
     if (nvoxels[0] < 0 || nvoxels[1] < 0 || nvoxels[2] < 0) return fail(MKAMD_EINVAL, "nvoxels must be >= 0");
     const long long V = (long long)nvoxels[0] * nvoxels[1] * nvoxels[2];
-    if (B == 0 || V == 0) return MKAMD_OK;
-    if (!atom_offsets || !origins || (!features && !features64)) return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
+    if (B == 0 || V == 0) { ctx->pending = mkamd_ctx::PendingHostCall{}; ctx->pending.active = true; return MKAMD_OK; }
+    if (!atom_offsets || !origins) return fail(MKAMD_EINVAL, "atom_offsets/origins pointer is NULL");
     if (atom_offsets[0] != 0) return fail(MKAMD_EINVAL, "atom_offsets[0] must be 0");
     for (int b = 0; b < B; ++b)
         if (atom_offsets[b + 1] < atom_offsets[b]) return fail(MKAMD_EINVAL, "atom_offsets must be non-decreasing");
@@ -803,6 +811,24 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
     ctx->seq_next = 0u;
     if (st) return st;
     MK_HOST_MARK(1);                                                // kernels enqueued
+    ctx->pending.active = true; ctx->pending.out_bytes = out_bytes; ctx->pending.mapped_out = mapped_out; ctx->pending.seq = seq;
+    ctx->pending.dout = dout;
+    return MKAMD_OK;
+}
+
+static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, double* features64)
+{
+    MK_HOST_BEGIN();
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (!ctx->pending.active) return fail(MKAMD_EINVAL, "no host call was begun on this context");
+    const size_t out_bytes = ctx->pending.out_bytes;
+    const bool mapped_out = ctx->pending.mapped_out;
+    const unsigned seq = ctx->pending.seq;
+    void* const dout = ctx->pending.dout;
+    ctx->pending.active = false;
+    if (out_bytes == 0) return MKAMD_OK;                            // no items / no voxels
+    if (!features && !features64) { (void)hipStreamSynchronize(ctx->stream); return fail(MKAMD_EINVAL, "features pointer is NULL"); }
     const size_t nvals = out_bytes / 4;
     // wait for "tile kernel done" (a read of host memory per poll; gives up after ~1 ms: the stream wait below covers it)
     bool early = false;
@@ -845,6 +871,31 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
     if (mapped_out) memcpy(features, ctx->out_host, out_bytes);
     return collect_async_errors(ctx);
 }
+
+static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                      const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                      const int32_t* nvoxels, double voxelsize, const float* box,
+                                      int32_t max_images, float* features, double* features64)
+{
+    if (ctx && B > 0 && nvoxels && nvoxels[0] > 0 && nvoxels[1] > 0 && nvoxels[2] > 0 && !features && !features64)
+        return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
+    const int st = voxelize_lattice_host_begin_impl(ctx, B, coords, atom_offsets, sigmas, sigmas_are_f64, C, origins, nvoxels, voxelsize, box, max_images);
+    if (st) return st;
+    return voxelize_lattice_host_end_impl(ctx, features, features64);
+}
+
+int mkamd_voxelize_lattice_host_begin(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                      const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                      const int32_t* nvoxels, double voxelsize, const float* box, int32_t max_images)
+try {
+    return voxelize_lattice_host_begin_impl(ctx, B, coords, atom_offsets, sigmas, sigmas_are_f64, C, origins, nvoxels, voxelsize, box, max_images);
+} MK_API_CATCH
+
+int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64)
+try {
+    if (features && features_f64) return fail(MKAMD_EINVAL, "pass ONE result array: float32 or float64");
+    return voxelize_lattice_host_end_impl(ctx, features, features_f64);
+} MK_API_CATCH
 
 int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
                                 const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,

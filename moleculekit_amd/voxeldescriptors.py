@@ -163,8 +163,7 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
     centers = usercenters
     if centers is None:
         bb_min, nvoxels = _gridSpec(mol, buffer, boxsize, center, voxelsize)
-        centers = _centersFromSpec(bb_min, nvoxels, voxelsize)
-        lattice = (np.asarray(bb_min, dtype=np.float64), nvoxels, voxelsize)
+        lattice = (np.asarray(bb_min, dtype=np.float64), nvoxels, voxelsize)     # (the centres themselves: below, beside the device)
 
     coords = usercoords
     if coords is None:
@@ -177,10 +176,18 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
                 "Make sure your coordinates are either 3D with a last dim of 1 or 2D.")
         coords = coords[:, :, 0]
 
-    if method.upper() in ("C", "HIP"):
-        features = _getOccupancyC(coords, centers, channels, _lattice=lattice)
-    else:
+    if method.upper() not in ("C", "HIP"):
         raise RuntimeError("As of moleculekit 0.9.2 we only support C implementation of voxelization")
+    if lattice is not None:
+        # the grid is ours: the kernels are enqueued first, the centres (a copy of the cached array: 330 KB for a 24^3
+        # grid) are made while the device computes, then the features are taken out
+        finish = _occupancyLatticeBegin(coords, channels, lattice)
+        try:
+            centers = _centersFromSpec(bb_min, nvoxels, voxelsize)
+        finally:
+            features = finish()
+    else:
+        features = _getOccupancyC(coords, centers, channels)
 
     if nvoxels is None:
         return features, centers
@@ -246,6 +253,22 @@ def _recognise_lattice_numpy(c):
     if np.abs(rebuilt - c).max() > tol:
         return None
     return c[0].copy(), np.array([nx, ny, nz]), vs
+
+
+def _occupancyLatticeBegin(coords, channelsigmas, lattice):
+    """First half of ``_getOccupancyC`` for a lattice this module built itself: inputs checked and shipped, kernels
+    enqueued; the function returned waits and hands back the float64 [V, C] features."""
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    channelsigmas = np.ascontiguousarray(channelsigmas, dtype=np.float64)
+    if coords.ndim != 2 or coords.shape[1] != 3:
+        raise ValueError("coords and centers must be (n, 3) arrays")
+    if channelsigmas.ndim != 2 or channelsigmas.shape[0] != coords.shape[0]:
+        raise ValueError("channel sigmas must be (natoms, nchannels)")
+    bb_min, nvoxels, voxelsize = lattice
+    offs = np.array([0, coords.shape[0]], dtype=np.int64)
+    end = _batch.voxelize_lattice_begin(coords, offs, channelsigmas, np.asarray(bb_min, np.float64)[None, :], nvoxels, voxelsize,
+                                        dtype=np.float64)
+    return lambda: end()[0]
 
 
 def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):

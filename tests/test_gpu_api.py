@@ -273,3 +273,27 @@ def test_streaming_paths_raise_on_bad_frames_instead_of_yielding_incomplete_feat
         ctx.poll_errors()
     ctx.poll_errors()                                         # reported once, then clean again
     del out
+
+
+def test_host_call_in_two_halves(hip_ctx):
+    """mkamd_voxelize_lattice_host_begin / _end (the drop-in getVoxelDescriptors copies its voxel centres between the two):
+    the same bits as the one-piece call, float32 and float64; an `end` without a `begin` is an error; a `begin` that is
+    never ended is abandoned by the next one."""
+    from moleculekit_amd import batch, _lib
+    g = golden("cfg1_3ptb.npz")
+    from tests.synth import grid_origin
+    o, nv = grid_origin(g["center"], g["boxsize"], float(g["voxelsize"]))
+    args = (g["coords"], np.array([0, len(g["coords"])]), g["sigmas"], o[None], nv, float(g["voxelsize"]))
+    ref = batch.voxelize_lattice(*args, ctx=hip_ctx)
+    end = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)
+    busy = np.arange(100000).sum()                                         # (host work beside the device)
+    got = end()
+    assert got.dtype == np.float32 and np.array_equal(got, ref) and busy > 0
+    got64 = batch.voxelize_lattice_begin(*args, ctx=hip_ctx, dtype=np.float64)()
+    assert got64.dtype == np.float64 and np.array_equal(got64, ref.astype(np.float64))
+    with pytest.raises(_lib.MkamdError):
+        hip_ctx.voxelize_lattice_host_end(np.empty_like(ref))
+    batch.voxelize_lattice_begin(*args, ctx=hip_ctx)                       # never ended ...
+    again = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)()             # ... the next call is not disturbed
+    assert np.array_equal(again, ref)
+    assert np.abs(ref[0].astype(np.float64) - g["features"]).max() <= 1e-5
