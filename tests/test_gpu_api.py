@@ -291,7 +291,7 @@ def test_host_call_in_two_halves(hip_ctx):
     assert got.dtype == np.float32 and np.array_equal(got, ref) and busy > 0
     got64 = batch.voxelize_lattice_begin(*args, ctx=hip_ctx, dtype=np.float64)()
     assert got64.dtype == np.float64 and np.array_equal(got64, ref.astype(np.float64))
-    with pytest.raises(_lib.MkamdError):
+    with pytest.raises(ValueError, match="no host call was begun"):
         hip_ctx.voxelize_lattice_host_end(np.empty_like(ref))
     batch.voxelize_lattice_begin(*args, ctx=hip_ctx)                       # never ended ...
     again = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)()             # ... the next call is not disturbed
