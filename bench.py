@@ -458,14 +458,18 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         offs1 = d["offs"][:2].contiguous()
         args1 = (d["coords"][:n1], offs1, d["sigmas"][:n1], d["origins"][:1], nv, p["voxelsize"])
         kw1 = dict(box=None if d["box"] is None else d["box"][:1], max_images=sv.max_images, out=o1, ctx=ctx)
-        for _ in range(3):
+        for _ in range(10):                              # (the first small call of a context also builds its workspace)
             batch.voxelize_lattice_torch(*args1, **kw1)
         torch.cuda.synchronize(dev)
-        s0 = time.perf_counter()
-        for _ in range(20):
-            batch.voxelize_lattice_torch(*args1, **kw1)
-        torch.cuda.synchronize(dev)
-        res["single_us"] = (time.perf_counter() - s0) / 20 * 1e6
+        runs = []
+        for _ in range(3):                               # three runs of 40 calls back to back; the median is reported
+            s0 = time.perf_counter()
+            for _ in range(40):
+                batch.voxelize_lattice_torch(*args1, **kw1)
+            torch.cuda.synchronize(dev)
+            runs.append((time.perf_counter() - s0) / 40 * 1e6)
+        res["single_us"] = sorted(runs)[1]
+        res["single_us_runs"] = [round(r, 2) for r in runs]
         ctx.set_pipelining(not args.no_pipeline)
     min_s = float(getattr(args, "min_seconds", 0.0) or 0.0)
     if sustain and min_s > 0 and elapsed > 0:
@@ -708,6 +712,7 @@ def main():
             "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if res["k_n"] else None,
             "sustained": res.get("sustained"),
             "single_grid_latency_us": round(res["single_us"], 2) if "single_us" in res else None,
+            "single_grid_latency_us_runs": res.get("single_us_runs"),
             "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
             "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
             **({"gather_error": res["gather_error"]} if "gather_error" in res else {}),
