@@ -115,8 +115,8 @@ struct GridDesc {
     unsigned spill_base, spill_cap;   // spill areas: item b owns slots [spill_base + b * spill_cap, + spill_cap), counted in its spare cell counter
     const unsigned* direct_words;
     // counter of cell i = direct_words[DIRECT_HEAD + (i << cnt_shift)]: the one-launch pre-pass of ONE molecule sends 50 000
-    // rank atomics to ~1 000 counters, and device-scope atomics on one 128-byte line serialise at ~12 ns each (16 or 32
-    // counters per line: 9 us of a 13 us kernel) -- k_bin_solo gives every counter a line of its own (cnt_shift = 5)
+    // rank atomics to ~1 000 counters, and device-scope atomics on neighbouring words serialise (packed 4 bytes apart they
+    // were 9 us of a 13 us kernel) -- k_bin_solo keeps them 32 bytes apart (cnt_shift = 3; 64 and 128 bytes: the same time)
     int cnt_shift;
 };
 enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4, DIRECT_HEAD = 32 /* words in front of the counters (one 128-byte line) */ };

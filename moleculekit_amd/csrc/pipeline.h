@@ -25,6 +25,9 @@
 #include <cstdio>
 #include <string>
 
+#ifndef MK_SOLO_CNT_SHIFT
+#define MK_SOLO_CNT_SHIFT 3     // k_bin_solo's cell counters 32 bytes apart (GridDesc::cnt_shift); 16 and 128 bytes measured the same
+#endif
 namespace mkamd {
 
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
@@ -362,7 +365,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (direct) {
             g.cell_cap = direct_cap; g.spill_base = (unsigned)(ncells * (size_t)direct_cap); g.spill_cap = spill;
             mrec = std::max<size_t>(mrec, (size_t)slots);
-            g.cnt_shift = (solo && ncells <= (1u << 16)) ? 5 : 0;        // small calls: a 128-byte line per counter (see GridDesc)
+            g.cnt_shift = (solo && ncells <= (1u << 16)) ? MK_SOLO_CNT_SHIFT : 0;        // small calls: the counters spread out (see GridDesc)
             dbytes = (((size_t)DIRECT_HEAD + (ncells << g.cnt_shift)) * sizeof(unsigned) + 255) & ~(size_t)255;
             if ((st = be.ensure(WS_DIRECT_COUNT, dbytes, &dcnt, set))) return st;
             if (cs.dptr != dcnt) { cs.dptr = dcnt; cs.dclean = 0; }
