@@ -622,3 +622,35 @@ def test_one_cfg2_item_per_call_default_path(hip_ctx):
     centers = np.stack(np.unravel_index(vox, nv), axis=1) * p["voxelsize"] + o
     exp = oracle.calculate_occupancy(centers, p["coords"], p["sigmas"])
     assert np.abs(ref[0][vox] - exp).max() <= TOL
+
+
+def test_host_pass_is_repeated_when_the_tail_changes_values(hip_ctx):
+    """A small synchronous host call takes its result out of the pinned buffer as soon as the TILE kernel is done -- while
+    k_tail still runs.  When k_tail changes values (wide sigmas with voxel centres on the cut-off shell: the exact
+    fix-up; tiles too dense for the LDS tier) it says so and the pass is repeated: 300 calls of the adversarial case,
+    float32 and float64 results, every one equal to the first and inside the bound against the oracle."""
+    from moleculekit_amd import batch
+    from tests.cases import case_cutoff_adversarial
+    case = case_cutoff_adversarial(1.0)
+    args = (case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"], case["voxelsize"])
+    exp = oracle_lattice(*args)
+    first = batch.voxelize_lattice(*args, ctx=hip_ctx)
+    assert np.abs(first - exp).max() <= TOL
+    out64 = np.empty(first.shape, np.float64)
+    for i in range(300):
+        if i % 2:
+            got = batch.voxelize_lattice(*args, ctx=hip_ctx)
+            assert np.array_equal(got, first), i
+        else:
+            batch.voxelize_lattice(*args, out=out64, ctx=hip_ctx)
+            assert np.array_equal(out64, first.astype(np.float64)), i
+    try:                                                                   # ... and with the tiles forced through the dense instance
+        hip_ctx.set_lds_tier(0)
+        dense = LATTICE_CASES["dense_with_wide_sigmas"]()
+        dargs = (dense["coords"], dense["atom_offsets"], dense["sigmas"], dense["origins"], dense["nvoxels"], dense["voxelsize"])
+        dref = batch.voxelize_lattice(*dargs, ctx=hip_ctx)
+        check(dense, dref)
+        for i in range(100):
+            assert np.array_equal(batch.voxelize_lattice(*dargs, ctx=hip_ctx), dref), i
+    finally:
+        hip_ctx.set_lds_tier(-1)
