@@ -196,8 +196,13 @@ struct mkamd_ctx {
     void tile_done(int set)
     {
         if (!side_stream) return;
+        // Only a PIPELINED call needs the marker (the pre-pass that reuses its workspace set two calls later waits for
+        // it).  An in-order call is covered by stream order: the next pipelined pre-pass first waits for a marker recorded
+        // on the main stream after everything enqueued so far (acquire_set, !have_pre_tile_event).  The event is a barrier
+        // packet of its own -- ~2 us of every one-molecule call on a context that has ever had pipelining switched on.
+        const bool piped = in_pipelined_prepass;
         in_pipelined_prepass = false;
-        if (pipeline_broken) { last_hot_end = nullptr; return; }
+        if (pipeline_broken || !piped) { last_hot_end = nullptr; return; }
         if (last_hot_end) { tile_marker[set] = last_hot_end; tile_pending[set] = true; }   // the timing event sits at the same place
         else if (sync_ok(hipEventRecord(ev_tile_done[set], main_stream))) { tile_marker[set] = ev_tile_done[set]; tile_pending[set] = true; }
         last_hot_end = nullptr;

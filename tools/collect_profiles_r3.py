@@ -61,3 +61,12 @@ collect(("sq1", "sq2", "fetch", "write"), f"{tag}_cfg2_pmc_counters.json", "")
 collect(("nopipe_fetch", "nopipe_write"), f"{tag}_cfg2_nopipe_pmc_traffic.json", "--no-pipeline")
 collect(("tol_sq1",), f"{tag}_cfg2_tolerance_pmc_counters.json", "--value-tol 1e-6")
 print("\n".join(sorted(f for f in os.listdir("profiles") if f.startswith(tag))))
+
+# the one-molecule call (round 3)
+for src, dst in (("single_call_timeline.txt", "single_call_timeline.txt"), ("single_latency.txt", "single_latency.txt"),
+                 ("team_probe.txt", "team_probe.txt"), ("gridsync.txt", "gridsync_ubench.txt"), ("dropin_profile.txt", "dropin_profile.txt")):
+    f = f"gpurun_out/{src}"
+    if os.path.exists(f):
+        with open(f) as fh:
+            text = "".join(l for l in fh if "amdgpu.ids" not in l)
+        open(f"profiles/{tag}_{dst}", "w").write(text)

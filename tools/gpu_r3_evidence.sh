@@ -25,6 +25,12 @@ pmc nopipe_fetch FETCH_SIZE
 pmc nopipe_write WRITE_SIZE
 PMC_EXTRA="--value-tol 1e-6"
 pmc tol_sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
-tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
+# the one-molecule call: per-kernel timeline of one cfg2 grid / one 3PTB pocket per call, latencies, the host side of the drop-in call
+(bash tools/gpu_timeline_ab.sh moleculekit_amd/csrc/libmkamd.so > gpurun_out/single_call_timeline.txt 2>&1)
+(for i in 1 2 3; do timeout 120 python tools/single_latency.py; done > gpurun_out/single_latency.txt 2>&1)
+(timeout 200 python tools/team_probe.py > gpurun_out/team_probe.txt 2>&1)
+(timeout 120 tools/gridsync > gpurun_out/gridsync.txt 2>&1)
+(timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
+tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log; grep -v amdgpu.ids gpurun_out/single_latency.txt
 python tools/summarize.py 2>/dev/null | head -20
 python tools/collect_profiles_r3.py
