@@ -53,6 +53,7 @@ struct mkamd_ctx {
     hipStream_t stream = nullptr;          // stream the launches of the current call go to (main or side)
     hipStream_t main_stream = nullptr;     // the caller-visible stream
     hipStream_t side_stream = nullptr;     // internal: pre-pass of pipelined calls
+    hipEvent_t ev_host_done = nullptr;     // end of a small synchronous host call's launches (voxelize_lattice_host_begin_impl)
     hipEvent_t ev_inputs = nullptr;        // main -> side: the call's inputs are ready
     hipEvent_t ev_pre_done[2] = {};        // side -> main: workspace set s is filled
     hipEvent_t ev_tile_done[2] = {};       // main -> side: the tile kernel that read set s has finished
@@ -84,7 +85,7 @@ struct mkamd_ctx {
     size_t stage_cap = 0;
     std::vector<uint32_t> contacts_host;   // result of the last mkamd_contacts_trajectory_host call (owned here)
     std::vector<float> f32_stage;          // host staging of big float64-out results
-    struct PendingHostCall { bool active = false; size_t out_bytes = 0; bool mapped_out = false; unsigned seq = 0; void* dout = nullptr; };
+    struct PendingHostCall { bool active = false; size_t out_bytes = 0; bool mapped_out = false; unsigned seq = 0; void* dout = nullptr; hipEvent_t done = nullptr; };
     PendingHostCall pending;               // a host call between its begin and its end (voxelize_lattice_host_begin_impl)
     void* out_host = nullptr;              // pinned, device-mapped result buffer of small _host calls (no D2H copy)
     void* out_host_dev = nullptr;          // its device-side address
@@ -340,6 +341,7 @@ try {
     for (auto& ev : ctx->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : ctx->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->ev_host_done) (void)hipEventDestroy(ctx->ev_host_done);
     if (ctx->ev_inputs) (void)hipEventDestroy(ctx->ev_inputs);
     for (int i = 0; i < 2; ++i) {
         if (ctx->ev_pre_done[i]) (void)hipEventDestroy(ctx->ev_pre_done[i]);
@@ -646,17 +648,20 @@ try {
 
 // End of a small synchronous call (tens of microseconds of GPU work): poll the stream instead of blocking on it -- the
 // blocking wait's wake-up costs more than the polls; a call that is still running after ~2 000 polls blocks after all.
-static hipError_t wait_for_small_call(hipStream_t s)
+// The runtime answers a stream query with a marker packet of its own when the stream's last command is a kernel -- and that
+// packet then takes its ~5-10 us to retire while the caller polls.  A small host call therefore records an event right
+// behind its last launch (it retires while the host is busy with the result) and asks the EVENT.
+static hipError_t wait_for_small_call(hipStream_t s, hipEvent_t done = nullptr)
 {
     for (int i = 0; i < 2000; ++i) {
-        const hipError_t e = hipStreamQuery(s);
+        const hipError_t e = done ? hipEventQuery(done) : hipStreamQuery(s);
         if (e != hipErrorNotReady) {
             if (i != 0 && e == hipSuccess) (void)hipGetLastError();    // "not ready" is an answer, not an error to find later
             return e;
         }
     }
     (void)hipGetLastError();
-    return hipStreamSynchronize(s);
+    return done ? hipEventSynchronize(done) : hipStreamSynchronize(s);
 }
 
 // float32 -> float64 over the result of a call (the drop-in path returns the reference's float64 [V, C]): the baseline
@@ -818,6 +823,12 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
     MK_HOST_MARK(1);                                                // kernels enqueued
     ctx->pending.active = true; ctx->pending.out_bytes = out_bytes; ctx->pending.mapped_out = mapped_out; ctx->pending.seq = seq;
     ctx->pending.dout = dout;
+    ctx->pending.done = nullptr;
+    if (mapped_out) {
+        if (!ctx->ev_host_done && hipEventCreateWithFlags(&ctx->ev_host_done, hipEventDisableTiming) != hipSuccess) { ctx->ev_host_done = nullptr; (void)hipGetLastError(); }
+        if (ctx->ev_host_done && hipEventRecord(ctx->ev_host_done, ctx->stream) == hipSuccess) ctx->pending.done = ctx->ev_host_done;
+        else (void)hipGetLastError();
+    }
     return MKAMD_OK;
 }
 
@@ -831,6 +842,7 @@ static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, doubl
     const bool mapped_out = ctx->pending.mapped_out;
     const unsigned seq = ctx->pending.seq;
     void* const dout = ctx->pending.dout;
+    const hipEvent_t done = ctx->pending.done;
     ctx->pending.active = false;
     if (out_bytes == 0) return MKAMD_OK;                            // no items / no voxels
     if (!features && !features64) { (void)hipStreamSynchronize(ctx->stream); return fail(MKAMD_EINVAL, "features pointer is NULL"); }
@@ -853,12 +865,12 @@ static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, doubl
             MK_HOST_MARK(2);                                        // waited for the tile kernel
             widen(src, features64, nvals);                          // ... while k_tail runs and the stream signals its completion
             MK_HOST_MARK(3);
-            HIP_TRY(wait_for_small_call(ctx->stream));
+            HIP_TRY(wait_for_small_call(ctx->stream, done));
 #ifndef MK_NO_REPASS   // (tests/: a build without the second pass must FAIL test_host_pass_is_repeated_when_the_tail_changes_values)
             if (((const volatile unsigned*)ctx->fb_host)[FB_TAIL_WROTE] == seq) widen(src, features64, nvals);     // k_tail changed values (rare): once more
 #endif
         } else {
-            HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
+            HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream, done) : hipStreamSynchronize(ctx->stream));
             MK_HOST_MARK(2);                                        // waited for the stream
             widen(src, features64, nvals);
             MK_HOST_MARK(3);                                        // float32 -> float64 into the caller's array
@@ -870,13 +882,13 @@ static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, doubl
     if (!mapped_out) HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (early) {
         memcpy(features, ctx->out_host, out_bytes);
-        HIP_TRY(wait_for_small_call(ctx->stream));
+        HIP_TRY(wait_for_small_call(ctx->stream, done));
 #ifndef MK_NO_REPASS
         if (((const volatile unsigned*)ctx->fb_host)[FB_TAIL_WROTE] == seq) memcpy(features, ctx->out_host, out_bytes);
 #endif
         return collect_async_errors(ctx);
     }
-    HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream) : hipStreamSynchronize(ctx->stream));
+    HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream, done) : hipStreamSynchronize(ctx->stream));
     if (mapped_out) memcpy(features, ctx->out_host, out_bytes);
     return collect_async_errors(ctx);
 }
