@@ -2085,6 +2085,10 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     // ---- epilogue: q -> occupancy, one 32-byte store per voxel (z fastest across lanes) ----
     const int y = tg.y0 + ly, z = tg.z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
+    // the lane's voxel in the wave's first plane, and the (wave-uniform) step to the next x-plane: one 64-bit add per plane
+    // instead of the index arithmetic (three 64-bit multiplies: 15 instructions per plane, 9 % of a ligand tile's work)
+    const size_t plane_vox = (size_t)g.ny * (size_t)g.nz;
+    const size_t vox0 = (size_t)tg.b * (size_t)g.V + (size_t)(tg.x0 + kb) * plane_vox + (size_t)y * (size_t)g.nz + (size_t)z;
 #pragma unroll
     for (int k = 0; k < KE; ++k) {
         const int x = tg.x0 + kb + k;
@@ -2092,7 +2096,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
         for (int c = 0; c < CE; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
         if (yz_in && x < g.nx) {
-            const size_t vox = (size_t)tg.b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+            const size_t vox = vox0 + (size_t)k * plane_vox;
             if constexpr (CSPLIT > 1) {                      // a big team: this wave stores CE channels of the voxel (16 or 8 bytes)
                 float* o = out + vox * (size_t)g.C + (size_t)gq * CHG + cb;
                 if (g.C == CHG) {
@@ -2305,6 +2309,8 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
     }
     const int y = y0 + ly, z = z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
+    const size_t plane_vox = (size_t)g.ny * (size_t)g.nz;                 // (see voxelize_tile: one add per plane)
+    const size_t vox0 = (size_t)b * (size_t)g.V + (size_t)x0 * plane_vox + (size_t)y * (size_t)g.nz + (size_t)z;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int x = x0 + k;
@@ -2312,7 +2318,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
 #pragma unroll
         for (int c = 0; c < CHG; ++c) f[c] = mk_uint_as_float(q[c][k]);
         if (yz_in && x < g.nx) {
-            const size_t vox = (size_t)b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+            const size_t vox = vox0 + (size_t)k * plane_vox;
             if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
                 o[0] = make_float4(f[0], f[1], f[2], f[3]);
@@ -2408,6 +2414,8 @@ MK_DEV void voxelize_item_tile_unsorted(const GridDesc& g, const int b, const in
     }
     const int y = y0 + ly, z = z0 + lz;
     const bool yz_in = (y < g.ny) && (z < g.nz);
+    const size_t plane_vox = (size_t)g.ny * (size_t)g.nz;
+    const size_t vox0 = (size_t)b * (size_t)g.V + (size_t)x0 * plane_vox + (size_t)y * (size_t)g.nz + (size_t)z;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int x = x0 + k;
@@ -2415,7 +2423,7 @@ MK_DEV void voxelize_item_tile_unsorted(const GridDesc& g, const int b, const in
 #pragma unroll
         for (int c = 0; c < CHG; ++c) f[c] = occupancy_from_q(mk_uint_as_float(q[c][k]));
         if (yz_in && x < g.nx) {
-            const size_t vox = (size_t)b * (size_t)g.V + ((size_t)x * g.ny + y) * g.nz + z;
+            const size_t vox = vox0 + (size_t)k * plane_vox;
             if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
                 o[0] = make_float4(f[0], f[1], f[2], f[3]);
