@@ -2727,7 +2727,8 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
                           const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
                           const uint2* __restrict__ tmp_cls,
                           unsigned* __restrict__ solo_counts /* k_bin_solo's counters + control words, or nullptr */, unsigned solo_n,
-                          unsigned* __restrict__ solo_table, unsigned seq /* of this call (small host calls), else 0 */)
+                          unsigned* __restrict__ solo_table, unsigned seq /* of this call (small host calls), else 0 */,
+                          unsigned fix_jobs /* fix-up jobs (256-atom blocks, or items): the fix-up waves share them */)
 {
     __shared__ double s_best[WAVE];
     const unsigned n = dense_words[0], total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
@@ -2779,8 +2780,11 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
         mk_wave_sync();                                                    // (every lane has read the word before one clears it)
         if (me == 0u && threadIdx.x < (unsigned)CLS_TABLE_WORDS && overflow_word != CLS_EMPTY) solo_table[threadIdx.x] = CLS_EMPTY;
     }
-    exact_fixup_block<SigT>(g, role - dense_wgs, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
-                            tmp_cls, out, s_best, feedback, seq);
+    // (a big batch has tens of thousands of fix-up jobs, nearly all of which end at their summary: a few thousand waves that
+    //  take several each start and drain faster than one wave per job -- 18 -> ~6 us per 256-grid step)
+    for (unsigned job = role - dense_wgs; job < fix_jobs; job += gridDim.x - dense_wgs)
+        exact_fixup_block<SigT>(g, job, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
+                                tmp_cls, out, s_best, feedback, seq);
 }
 
 // ------------------------------------------------------------------------------------------------

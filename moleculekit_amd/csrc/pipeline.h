@@ -202,7 +202,7 @@ enum TileFlavour { TILES_PLAIN = 0, TILES_LEAN = 1, TILES_TEAM = 2, TILES_ITEMS 
 
 // what the call's last launch (k_tail: dense tiles + exact cut-off fix-up) needs besides the tile kernel's arguments
 struct TailArgs {
-    unsigned dense_wgs = 0, fix_waves = 0;
+    unsigned dense_wgs = 0, fix_waves = 0, fix_jobs = 0;
     unsigned* other_words = nullptr;
     int per_item = 0;
     const unsigned* summary = nullptr;
@@ -263,7 +263,7 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
                              (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, ta.other_words, (const unsigned*)dlist,
                              g.force_general ? (unsigned*)nullptr : be.feedback_dev(), (const int*)eflag, ta.per_item, ta.summary, P.coords,
                              P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls, ta.solo_counts, ta.solo_n,
-                             (unsigned*)ctab, g.force_general ? 0u : P.seq);
+                             (unsigned*)ctab, g.force_general ? 0u : P.seq, ta.fix_jobs);
         };
         st = P.sigmas_f64 ? tail(k_tail<K, E, double>, (const double*)P.sigmas) : tail(k_tail<K, E, float>, (const float*)P.sigmas);
     }
@@ -514,7 +514,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     TailArgs ta;
     // (the general path has no dense tiles; its fix-up waves still run, and its statistics stay what they were)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
-    ta.fix_waves = fix_waves; ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
+    ta.fix_jobs = fix_waves;
+    ta.fix_waves = fix_waves < 8192u ? fix_waves : 8192u;         // (the fix-up waves share the jobs: see k_tail)
+    ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
     ta.team_waves = (P.tile_team == 4 || P.tile_team == 8 || P.tile_team == 16) ? P.tile_team : 0;
     if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(DIRECT_HEAD + (ncells << g.cnt_shift)); }
     be.hot_begin();
