@@ -425,7 +425,7 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
 
     def single_probe():
         """Latency of ONE grid per call (the reference's call pattern; SURVEY.md section 7 H2: a single 64^3 grid cannot fill
-        256 CUs for long): device-resident inputs, calls back to back, three runs of 40 calls -> (median, runs) in us."""
+        256 CUs for long): device-resident inputs, calls back to back, five runs of 40 calls -> (median, runs) in us."""
         from moleculekit_amd import batch
         ctx.set_pipelining(False)
         d = sv._d
@@ -434,18 +434,18 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         offs1 = d["offs"][:2].contiguous()
         args1 = (d["coords"][:n1], offs1, d["sigmas"][:n1], d["origins"][:1], nv, p["voxelsize"])
         kw1 = dict(box=None if d["box"] is None else d["box"][:1], max_images=sv.max_images, out=o1, ctx=ctx)
-        for _ in range(10):                              # (the first small call of a context also builds its workspace)
-            batch.voxelize_lattice_torch(*args1, **kw1)
+        for _ in range(50):                              # (the first small call of a context also builds its workspace;
+            batch.voxelize_lattice_torch(*args1, **kw1)  #  ~2 ms of calls: the steady state of a screening loop)
         torch.cuda.synchronize(dev)
         runs = []
-        for _ in range(3):
+        for _ in range(5):                               # five runs of 40 calls back to back; the median is reported
             s0 = time.perf_counter()
             for _ in range(40):
                 batch.voxelize_lattice_torch(*args1, **kw1)
             torch.cuda.synchronize(dev)
             runs.append((time.perf_counter() - s0) / 40 * 1e6)
         ctx.set_pipelining(not args.no_pipeline)
-        return sorted(runs)[1], [round(r, 2) for r in runs]
+        return sorted(runs)[2], [round(r, 2) for r in runs]
 
     # the one-molecule-per-call probe comes FIRST, on a quiet GPU as such a caller finds it (the same probe right after the
     # batch steps reads ~2 us more: clocks under load -- reported next to it)
