@@ -1569,6 +1569,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #endif
     // per-tile histogram -> placement cursors -> (after placement) sub-bucket starts again; [NBUCKET3] = end
     __shared__ unsigned bucket[NBUCKET3 + 1];
+    // a team keeps the placement cursors in an array of their own: the counts, the cursors and the final table of starts then
+    // need two workgroup barriers between them, not four (a barrier of four unevenly loaded waves is ~0.3 us of a 28 us call)
+    __shared__ unsigned bucket_cur[TEAM > 1 ? NBUCKET3 + 1 : 1];
 #ifdef MK_NO_SURV_LIST                                 // A-B builds (tools/gpu_ab.sh): the two-traversal kernel of round 1
     constexpr bool SURV_LIST = false;
 #else
@@ -1929,17 +1932,18 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         // ---- placement of channels [c0, c1) (`count` padded entries starting at `base` of the scan) ----
         auto place = [&](int c0, int c1, unsigned base, unsigned count) {
             const bool in_round = (lane >> 3) >= c0 && (lane >> 3) < c1;
-            mk_block_sync();                                                 // counts read; previous round done
+            unsigned* const cursor = TEAM > 1 ? bucket_cur : bucket;
+            if (TEAM == 1) mk_block_sync();                                  // counts read; previous round done
             if (in_round) {
 #pragma unroll
-                for (int i = 0; i < 2 * NXR; ++i) bucket[2 * NXR * lane + i] = start[i] - base;     // placement cursors
+                for (int i = 0; i < 2 * NXR; ++i) cursor[2 * NXR * lane + i] = start[i] - base;     // placement cursors
             }
             mk_block_sync();
             // ---- traversal 2: place the entries into their buckets ----
             const unsigned rmask = (c1 == CHG ? 0xffffffffu : ((1u << (4 * c1)) - 1u)) & ~((1u << (4 * c0)) - 1u);
             auto place_at = [&](bool surv, float ex, float ey, float ez, unsigned ids, int xr) {
                 for_each_present_channel(surv ? (ids & rmask) : 0u, [&](int c, unsigned id) {
-                    const unsigned pos = mk_lds_add(&bucket[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
+                    const unsigned pos = mk_lds_add(&cursor[(c * NSLOT + (int)id - 1) * NXR + xr], 1u);
                     sx[pos] = ex; sy[pos] = ey; sz[pos] = ez;
                 });
             };
@@ -1954,7 +1958,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             } else {
                 for_each_candidate<K, true, TRAV_BATCH>(g, tg, runs, rec_pos, clsp, place_entry, (unsigned)wv, (unsigned)TEAM);
             }
-            mk_block_sync();
+            if (TEAM == 1) mk_block_sync();       // (a team writes the table into the COUNTS' array, which every wave has read by now)
             // cursors are dead now: the array becomes the table of sub-bucket starts (even; bit 0 = "odd count, the
             // last slot is padding"; sub-buckets are contiguous, so a group's three ranges are four consecutive words; the word after the
             // last group placed belongs to a channel outside the round, whose counts live in registers)
