@@ -873,10 +873,8 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
             }
             rec_pos[slot] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20) | (level << 30)));
             rec_cls[slot] = ids;
-#ifndef MK_SOLO_NO_RECW   // (timing experiment)
-            rec_w[slot] = make_float4(w[0], w[1], w[2], w[3]);
+            rec_w[slot] = make_float4(w[0], w[1], w[2], w[3]);                // (measured: these two stores cost the call nothing)
             rec_w[(size_t)g.M + slot] = make_float4(w[4], w[5], w[6], w[7]);
-#endif
         }
     }
     mk_block_sync();
