@@ -575,6 +575,11 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
+                                            const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
+                                            const int32_t* nvoxels, double voxelsize, const float* box, int32_t max_images);
+static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, double* features64, double* max_into);
+
 int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t V, const float* coords,
                               int64_t N, const double* sigmas, int32_t C, double* results)
 try {
@@ -584,7 +589,6 @@ try {
     int st0 = check_ctx(ctx);
     if (st0) return st0;
     std::vector<float>& tmp = ctx->f32_stage;               // context-owned: no fresh pages to fault in on every call
-    tmp.resize((size_t)V * C);
     // The reference's only caller hands this function a getCenters LATTICE (voxeldescriptors.py:356 via _getOccupancyC):
     // recognised (two passes over the centres, host) it takes the tiled lattice kernels -- microseconds where the
     // pairwise kernel below tests N x V pairs in double.
@@ -594,11 +598,17 @@ try {
     double bb_min[3], vs = 0.0;
     int32_t nv[3];
     const bool is_lattice = mkamd::lattice_from_centers(centers, (long long)V, bb_min, nv, &vs);
+    bool lattice_done = false;
     const int st = mkamd::route_calculate_occupancy(is_lattice,
-        [&] { const int64_t offs[2] = {0, N};
-              return mkamd_voxelize_lattice_host(ctx, 1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0, tmp.data()); },
-        [&] { return mkamd_occupancy_centers_host(ctx, centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data()); });
+        [&] { const int64_t offs[2] = {0, N};                  // (the in-place maximum is taken by the call's second half)
+              const int s1 = voxelize_lattice_host_begin_impl(ctx, 1, coords, offs, sigmas, 1, C, bb_min, nv, vs, nullptr, 0);
+              if (s1) return s1;
+              lattice_done = true;
+              return voxelize_lattice_host_end_impl(ctx, nullptr, nullptr, results); },
+        [&] { tmp.resize((size_t)V * C);
+              return mkamd_occupancy_centers_host(ctx, centers, V, coords, N, sigmas, 1, C, nullptr, tmp.data()); });
     if (st) return st;
+    if (lattice_done) return MKAMD_OK;
     // in-place max-accumulate, `value > old ? value : old` as occupancy_utils.pyx:61
     const size_t nvals = (size_t)V * C;
     for (size_t i = 0; i < nvals; ++i) {
@@ -832,7 +842,7 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
     return MKAMD_OK;
 }
 
-static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, double* features64)
+static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, double* features64, double* max_into)
 {
     MK_HOST_BEGIN();
     int st = check_ctx(ctx);
@@ -845,8 +855,24 @@ static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, doubl
     const hipEvent_t done = ctx->pending.done;
     ctx->pending.active = false;
     if (out_bytes == 0) return MKAMD_OK;                            // no items / no voxels
-    if (!features && !features64) { (void)hipStreamSynchronize(ctx->stream); return fail(MKAMD_EINVAL, "features pointer is NULL"); }
+    if (!features && !features64 && !max_into) { (void)hipStreamSynchronize(ctx->stream); return fail(MKAMD_EINVAL, "features pointer is NULL"); }
     const size_t nvals = out_bytes / 4;
+    if (max_into) {
+        // calculate_occupancy's contract (occupancy_utils.pyx:61): results[i] = max(results[i], value) -- straight out of the
+        // mapped result buffer, once the whole call is done (an early pass could not be repeated: a maximum does not undo)
+        const float* src = (const float*)ctx->out_host;
+        if (!mapped_out) {
+            ctx->f32_stage.resize(nvals);
+            HIP_TRY(hipMemcpyAsync(ctx->f32_stage.data(), dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+            src = ctx->f32_stage.data();
+        }
+        HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream, done) : hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < nvals; ++i) {
+            const double v = (double)src[i];
+            if (v > max_into[i]) max_into[i] = v;
+        }
+        return collect_async_errors(ctx);
+    }
     // wait for "tile kernel done" (a read of host memory per poll; gives up after ~1 ms: the stream wait below covers it)
     bool early = false;
     if (seq != 0u && ctx->tail_reports) {
@@ -902,7 +928,7 @@ static int voxelize_lattice_host_impl(mkamd_ctx* ctx, int32_t B, const float* co
         return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
     const int st = voxelize_lattice_host_begin_impl(ctx, B, coords, atom_offsets, sigmas, sigmas_are_f64, C, origins, nvoxels, voxelsize, box, max_images);
     if (st) return st;
-    return voxelize_lattice_host_end_impl(ctx, features, features64);
+    return voxelize_lattice_host_end_impl(ctx, features, features64, nullptr);
 }
 
 int mkamd_voxelize_lattice_host_begin(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
@@ -915,7 +941,7 @@ try {
 int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64)
 try {
     if (features && features_f64) return fail(MKAMD_EINVAL, "pass ONE result array: float32 or float64");
-    return voxelize_lattice_host_end_impl(ctx, features, features_f64);
+    return voxelize_lattice_host_end_impl(ctx, features, features_f64, nullptr);
 } MK_API_CATCH
 
 int mkamd_voxelize_lattice_host(mkamd_ctx* ctx, int32_t B, const float* coords, const int64_t* atom_offsets,
