@@ -271,6 +271,9 @@ def _occupancyLatticeBegin(coords, channelsigmas, lattice):
     return lambda: end()[0]
 
 
+_LAST_LATTICE = {}          # number of centres -> (nvoxels, voxelsize) of the last lattice recognised in an array of that length
+
+
 def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
     """Occupancy of every (centre, channel): float64 [V, C] -- the job of the reference's
     ``_getOccupancyC`` (voxeldescriptors.py:515-533), executed by the HIP kernels.
@@ -288,7 +291,38 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
         raise ValueError("coords and centers must be (n, 3) arrays")
     if channelsigmas.ndim != 2 or channelsigmas.shape[0] != coords.shape[0]:
         raise ValueError("channel sigmas must be (natoms, nchannels)")
-    lattice = _lattice if _lattice is not None else _lattice_from_centers(centers)
+    if _lattice is None and centers.shape[0] >= 2:
+        # The caller brought the centres (`usercenters`; every call through install(): the reference computes them and
+        # hands over a copy).  Whether they are a getCenters lattice is asked on every call (~10 us for a 24^3 grid) -- but
+        # the answer is nearly always what it was for the last array of this length, shifted to this array's first centre.
+        # So the kernels are started on that guess, the centres are checked WHILE the device computes, and only a wrong
+        # guess (a different grid of the same size, centres that are no lattice) is thrown away and done again.
+        guess = _LAST_LATTICE.get(centers.shape[0])
+        finish = None
+        if guess is not None:
+            first = centers[0].copy()
+            try:
+                finish = _occupancyLatticeBegin(coords, channelsigmas, (first, guess[0], guess[1]))
+            except Exception:                              # noqa: BLE001 -- the guess is only a guess: the plain way below
+                finish = None
+        if finish is not None:
+            try:
+                lattice = _recognise_lattice(centers)
+            finally:
+                features = finish()
+            if (lattice is not None and np.array_equal(lattice[0], first) and np.array_equal(lattice[1], guess[0])
+                    and lattice[2] == guess[1]):
+                return features
+            del features                                   # a wrong guess: the call below does it with what was found,
+            _LAST_LATTICE.pop(centers.shape[0], None)      # and arrays of this length are not guessed at until one is a lattice again
+        else:
+            lattice = _recognise_lattice(centers)
+        if lattice is not None:
+            _LAST_LATTICE[centers.shape[0]] = (np.asarray(lattice[1]).copy(), lattice[2])
+            if len(_LAST_LATTICE) > 8:
+                _LAST_LATTICE.pop(next(iter(_LAST_LATTICE)), None)
+    else:
+        lattice = _lattice
     if lattice is not None:
         bb_min, nvoxels, voxelsize = lattice
         offs = np.array([0, coords.shape[0]], dtype=np.int64)

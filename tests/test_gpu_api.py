@@ -297,3 +297,27 @@ def test_host_call_in_two_halves(hip_ctx):
     again = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)()             # ... the next call is not disturbed
     assert np.array_equal(again, ref)
     assert np.abs(ref[0].astype(np.float64) - g["features"]).max() <= 1e-5
+
+
+def test_usercenters_guess_is_checked(hip_ctx):
+    """Centres brought by the caller: the kernels start on the lattice recognised in the LAST array of that length while
+    this one is checked.  Right guess (same grid, and the same grid shifted), wrong guess (another voxel size with the same
+    number of centres; the same centres jittered: no lattice at all) -- every call equals what the explicit path gives."""
+    from moleculekit_amd import voxeldescriptors as vd
+    from moleculekit_amd.voxeldescriptors import getCenters, getVoxelDescriptors
+    g = golden("cfg1_3ptb.npz")
+    coords, chans = g["coords"], g["sigmas"]
+    a, _ = getCenters(boxsize=[24, 24, 24], center=g["center"], voxelsize=1)
+    b, _ = getCenters(boxsize=[12, 12, 12], center=g["center"], voxelsize=0.5)          # also 24^3 centres
+    assert a.shape == b.shape
+    rng = np.random.default_rng(1)
+    jit = a + rng.normal(0, 1e-3, a.shape)
+    def direct(c):                                                                      # boxsize / explicit path, no guessing
+        vd._LAST_LATTICE.clear()
+        return getVoxelDescriptors(None, usercenters=c, usercoords=coords, userchannels=chans)[0]
+    ref = {k: direct(c) for k, c in (("a", a), ("a+", a + 0.25), ("b", b), ("jit", jit))}
+    assert np.abs(ref["a"] - g["features"]).max() <= TOL
+    vd._LAST_LATTICE.clear()
+    for k, c in (("a", a), ("a", a), ("a+", a + 0.25), ("b", b), ("b", b), ("jit", jit), ("jit", jit), ("a", a), ("a", a)):
+        got = getVoxelDescriptors(None, usercenters=c, usercoords=coords, userchannels=chans)[0]
+        assert np.array_equal(got, ref[k]), k
