@@ -314,13 +314,15 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
                     and lattice[2] == guess[1]):
                 return features
             del features                                   # a wrong guess: the call below does it with what was found,
-            _LAST_LATTICE.pop(centers.shape[0], None)      # and arrays of this length are not guessed at until one is a lattice again
+            with _CENTERS_LOCK:                            # and arrays of this length are not guessed at until one is a lattice again
+                _LAST_LATTICE.pop(centers.shape[0], None)
         else:
             lattice = _recognise_lattice(centers)
         if lattice is not None:
-            _LAST_LATTICE[centers.shape[0]] = (np.asarray(lattice[1]).copy(), lattice[2])
-            if len(_LAST_LATTICE) > 8:
-                _LAST_LATTICE.pop(next(iter(_LAST_LATTICE)), None)
+            with _CENTERS_LOCK:                            # (shared between the threads that use the drop-in API)
+                _LAST_LATTICE[centers.shape[0]] = (np.asarray(lattice[1]).copy(), lattice[2])
+                while len(_LAST_LATTICE) > 8:
+                    _LAST_LATTICE.pop(next(iter(_LAST_LATTICE)), None)
     else:
         lattice = _lattice
     if lattice is not None:
