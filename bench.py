@@ -434,8 +434,9 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         offs1 = d["offs"][:2].contiguous()
         args1 = (d["coords"][:n1], offs1, d["sigmas"][:n1], d["origins"][:1], nv, p["voxelsize"])
         kw1 = dict(box=None if d["box"] is None else d["box"][:1], max_images=sv.max_images, out=o1, ctx=ctx)
-        for _ in range(50):                              # (the first small call of a context also builds its workspace;
-            batch.voxelize_lattice_torch(*args1, **kw1)  #  ~2 ms of calls: the steady state of a screening loop)
+        for _ in range(250):                             # (the first small call of a context also builds its workspace;
+            batch.voxelize_lattice_torch(*args1, **kw1)  #  ~10 ms of calls: the steady state of a screening loop -- the
+                                                         #  per-call time still falls over the first few hundred calls)
         torch.cuda.synchronize(dev)
         runs = []
         for _ in range(5):                               # five runs of 40 calls back to back; the median is reported
