@@ -104,10 +104,12 @@ int mkamd_ctx_set_direct_binning(mkamd_ctx* ctx, int mode);
  * any distance below 5 A as before.  Results stay within eps (+ the float32 noise of the exact mode, <= 3.4e-6) of the
  * reference; they are no longer bit-identical between tilings / kernels.  eps in [0, 1e-5]. */
 int mkamd_ctx_set_value_tolerance(mkamd_ctx* ctx, double eps);
-/* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team of four that shares the tile's
- * candidate traversal and splits its entries (latency: one grid per call, the reference's own usage), -1 (default) =
- * a team when the whole launch has fewer tiles than the chip has SIMDs (ligand-sized items take the workgroup-per-item
- * kernel below instead, whatever the batch size).  Results are bit-identical either way. */
+/* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team that shares the tile's candidate
+ * traversal (one survivor list) and splits its sorted entries into one range per wave (latency: one grid per call, the
+ * reference's own usage) -- four waves, eight for launches of up to 256 tiles of depth 4; 4 / 8 / 16 = a team of exactly
+ * that many (8, 16: depth-4 tiles only); -1 (default) = a team when the whole launch has fewer tiles than the chip has
+ * SIMDs (ligand-sized items take the workgroup-per-item kernel below instead, whatever the batch size).  Results are
+ * bit-identical either way. */
 int mkamd_ctx_set_tile_team(mkamd_ctx* ctx, int mode);
 /* A workgroup per ITEM instead of a wave per tile: 1 = always (when no team is used), 0 = never, -1 (default) = for
  * ligand-sized items (<= 96 atoms on average) on the per-item pre-pass, any batch size: the item's entries are sorted

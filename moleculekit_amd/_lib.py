@@ -186,7 +186,8 @@ class Context:
         _check(load().mkamd_ctx_set_prepass_mode(self._h, int(mode)))
 
     def set_tile_team(self, mode: int):
-        """-1 automatic (default), 0 one wave per tile, 1 a team of four waves per tile (include/mkamd_voxel.h)."""
+        """-1 automatic (default), 0 one wave per tile, 1 a team of waves per tile, 4 / 8 / 16 a team of that many
+        (include/mkamd_voxel.h)."""
         _check(load().mkamd_ctx_set_tile_team(self._h, int(mode)))
 
     def set_tile_items(self, mode: int):

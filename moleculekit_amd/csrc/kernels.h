@@ -24,7 +24,9 @@
 //   big items  : k_bin_count, k_prepass_reduce1/2, k_scan_finish, k_bin_fill              (cell lists; the counters
 //                clear themselves, pipeline.h)
 //   small items: k_prepass_items                                  (the same, one workgroup per item)
-//   then       : k_voxelize_tiles[_lean|_team]<K,ECAP>, k_tail<K,ECAP,SigT>                 (the grid; dense tiles + fix-up)
+//   one molecule per call (<= 1 024 tile waves): k_bin_solo       (the whole pre-pass in one launch: records in the direct
+//                layout, the class table kept across calls; big calls can opt into k_bin_direct + the chain as fallback)
+//   then       : k_voxelize_tiles[_lean|_team]<K,ECAP[,TEAM]>, k_voxelize_items<K>, k_tail<K,ECAP,SigT>   (the grid; dense tiles + fix-up)
 //   explicit centres: k_sigma_to_w, k_occupancy_centers;   lattice centres: k_grid_centers.
 //
 // Coordinates: everything is in VOXEL units relative to the grid origin (voxel i's centre sits at
