@@ -2113,8 +2113,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 }
             } else if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
-                o[0] = make_float4(f[0], f[1], f[2], f[3]);
-                o[1] = make_float4(f[4], f[5], f[6], f[7]);
+                mk_store_result<TEAM == 1>(o, make_float4(f[0], f[1], f[2], f[3]));
+                mk_store_result<TEAM == 1>(o + 1, make_float4(f[4], f[5], f[6], f[7]));
             } else {
                 float* o = out + vox * (size_t)g.C + (size_t)gq * CHG;
 #pragma unroll
@@ -2325,8 +2325,8 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
             const size_t vox = vox0 + (size_t)k * plane_vox;
             if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
-                o[0] = make_float4(f[0], f[1], f[2], f[3]);
-                o[1] = make_float4(f[4], f[5], f[6], f[7]);
+                mk_store_result<false>(o, make_float4(f[0], f[1], f[2], f[3]));
+                mk_store_result<false>(o + 1, make_float4(f[4], f[5], f[6], f[7]));
             } else {
                 float* o = out + vox * (size_t)g.C + (size_t)gq * CHG;
 #pragma unroll
@@ -2430,8 +2430,8 @@ MK_DEV void voxelize_item_tile_unsorted(const GridDesc& g, const int b, const in
             const size_t vox = vox0 + (size_t)k * plane_vox;
             if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
-                o[0] = make_float4(f[0], f[1], f[2], f[3]);
-                o[1] = make_float4(f[4], f[5], f[6], f[7]);
+                mk_store_result<false>(o, make_float4(f[0], f[1], f[2], f[3]));
+                mk_store_result<false>(o + 1, make_float4(f[4], f[5], f[6], f[7]));
             } else {
                 float* o = out + vox * (size_t)g.C + (size_t)gq * CHG;
 #pragma unroll

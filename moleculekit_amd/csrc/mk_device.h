@@ -105,6 +105,21 @@ MK_DEV void mk_lds_min(unsigned* p, unsigned v) { (void)atomicMin(p, v); }      
 // kernels raise it so that they are not starved of issue slots by the VALU-saturating tile kernel of the
 // previous call when the two overlap
 MK_DEV void mk_wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
+// A 16-byte piece of the result: written once, never read back by the kernels.  STREAM = a non-temporal store (`nt`): the
+// 2 GB a 256-grid step writes then do not push the candidate records (read ~27 times each) out of the L2 -- the VALU-bound
+// wave-per-tile kernel gains 1.5-2 % on cfg2 (2.204 -> 2.160 ms), 8 % on the 3PTB batch, 6 % on cfg4 (in a team of waves per
+// tile, one grid per call, it changes nothing: plain stores there).  NOT for the store-bound workgroup-per-item kernel: its
+// 16-byte pieces are merged into full lines by the L2, and non-temporal they reach the HBM one by one (3.28 -> 5.69 ms).
+template <bool STREAM>
+MK_DEV void mk_store_result(float4* p, float4 v)
+{
+    if constexpr (STREAM) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+    } else {
+        *p = v;
+    }
+}
 // value of `v` in lane `lane` (wave-uniform index) -> SGPR (v_readlane_b32)
 MK_DEV unsigned mk_readlane(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
 

@@ -236,6 +236,7 @@ MK_DEV float mk_fma(float a, float b, float c) { return fmaf(a, b, c); }
 MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
 MK_DEV void mk_lds_min(unsigned* p, unsigned v) { if (v < *p) *p = v; }
 MK_DEV void mk_wave_priority_high() {}
+template <bool STREAM> MK_DEV void mk_store_result(float4* p, float4 v) { *p = v; }
 MK_DEV unsigned mk_readlane(unsigned v, int lane)
 {
     const int wv = (int)threadIdx.x >> 6;
