@@ -426,7 +426,7 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         uint2 cw = make_uint2(CLS_EMPTY, 0u);
         if (act) {
             cw = atom_channel_w(sigmas + (size_t)a * g.C, c0, g.C, g.w_scale, w);
-            tmp_cls[(size_t)a * g.G + (c0 / CHG)] = cw;              // parked for the fill pass
+            mk_tmp_store(&tmp_cls[(size_t)a * g.G + (c0 / CHG)], cw);              // parked for the fill pass
         }
         const bool multi = cw.y == ATOM_MULTI_SIGMA;
 #pragma unroll
@@ -500,8 +500,8 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         return inside;
     };
     auto park = [&](const int (&pc)[3], const float (&rel)[3], size_t cell, unsigned rank) {
-        tmp_pos[t0 + used] = make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20)));
-        tmp_idx[t0 + used] = make_uint2((unsigned)cell, rank);
+        mk_tmp_store(&tmp_pos[t0 + used], make_float4(rel[0], rel[1], rel[2], mk_int_as_float(pc[0] | (pc[1] << 10) | (pc[2] << 20))));
+        mk_tmp_store(&tmp_idx[t0 + used], make_uint2((unsigned)cell, rank));
         ++used;
     };
     if (!pbc) {
@@ -894,7 +894,7 @@ MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* 
                         float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
                         unsigned* __restrict__ rec_cls, const unsigned (&tab)[NCLS], bool general)
 {
-    float4 pos = tmp_pos[t];
+    float4 pos = mk_tmp_load(&tmp_pos[t]);
     const size_t a = g.img_cap == 1 ? t : t / (size_t)g.img_cap;
     if (g.reach_tau > 0.f) {                                         // tolerance-aware reach (wave-uniform; off by default)
         // the atom's widest sigma -> the largest reach level whose radius still covers tau / w_min (an entry is worth
@@ -924,7 +924,7 @@ MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* 
         return id;
     };
     for (int gq = 0; gq < g.G; ++gq) {
-        const uint2 cw = tmp_cls[a * (size_t)g.G + gq];
+        const uint2 cw = mk_tmp_load(&tmp_cls[a * (size_t)g.G + gq]);
         if (cw.y != ATOM_MULTI_SIGMA) {
             if (general) {
                 float w[CHG];
@@ -969,7 +969,7 @@ __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, 
     const unsigned lb = blockIdx.x < 8u * per_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
     const size_t t = (size_t)lb * blockDim.x + threadIdx.x;
     if (t >= (size_t)g.M) return;
-    const uint2 ix = tmp_idx[t];
+    const uint2 ix = mk_tmp_load(&tmp_idx[t]);
     if (ix.x == TMP_UNUSED) return;
     const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
     unsigned tab[NCLS];
