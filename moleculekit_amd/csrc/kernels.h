@@ -2113,6 +2113,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 }
             } else if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
+                // (the same turned through LDS so that every instruction writes whole lines, as in voxelize_item_tile, was
+                //  measured here too: +1 % on cfg2, nothing on the 3PTB batch and cfg4 -- this kernel is not store-bound)
                 mk_store_result<TEAM == 1>(o, make_float4(f[0], f[1], f[2], f[3]));
                 mk_store_result<TEAM == 1>(o + 1, make_float4(f[4], f[5], f[6], f[7]));
             } else {
@@ -2315,12 +2317,42 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
     const bool yz_in = (y < g.ny) && (z < g.nz);
     const size_t plane_vox = (size_t)g.ny * (size_t)g.nz;                 // (see voxelize_tile: one add per plane)
     const size_t vox0 = (size_t)b * (size_t)g.V + (size_t)x0 * plane_vox + (size_t)y * (size_t)g.nz + (size_t)z;
+    // the two half-voxels this lane STORES (see below): voxel s2 * 32 + lane / 2 of the tile's y-z face
+    size_t t_vox[2];
+    bool t_in[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int vv = s2 * 32 + (lane >> 1);
+        const int yy = y0 + (vv >> 3), zz = z0 + (vv & 7);
+        t_in[s2] = (yy < g.ny) && (zz < g.nz);
+        t_vox[s2] = (size_t)b * (size_t)g.V + (size_t)x0 * plane_vox + (size_t)yy * (size_t)g.nz + (size_t)zz;
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int x = x0 + k;
         float f[CHG];
 #pragma unroll
         for (int c = 0; c < CHG; ++c) f[c] = mk_uint_as_float(q[c][k]);
+        if (g.C == CHG) {
+            // A lane holds the 32 bytes of ONE voxel but a store instruction takes 16 per lane: written from where they are,
+            // the two instructions of a plane each put every other 16-byte piece into 16 lines, and the L2 has to merge
+            // them -- the kernel was store-bound at 4.4 TB/s with its arithmetic half exposed (round 3: 3.29 ms per cfg3 step,
+            // 2.06 without the stores, 2.70 with the stores alone).  Turned through 2 KB of the wave's staging area, lane L
+            // writes piece L of 1 KB = 32 voxels: 16 consecutive lanes cover one 256-byte z-row, every instruction writes
+            // whole lines, and they can go non-temporal: 3.29 -> 2.64 ms (0.555 -> 0.69 of the HBM peak), cfg5 6.55 -> 5.68.
+            static_assert(3 * ITEM_STRIDE * sizeof(float) >= 2 * WAVE * sizeof(float4), "the staging area holds a plane");
+            float4* const tb = reinterpret_cast<float4*>(stage);
+            mk_wave_sync();                                               // (the previous plane has been read)
+            tb[2 * lane] = make_float4(f[0], f[1], f[2], f[3]);
+            tb[2 * lane + 1] = make_float4(f[4], f[5], f[6], f[7]);
+            mk_wave_sync();
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const float4 v = tb[2 * (s2 * 32 + (lane >> 1)) + (lane & 1)];
+                if (t_in[s2] && x < g.nx)
+                    mk_store_result<true>(reinterpret_cast<float4*>(out + (t_vox[s2] + (size_t)k * plane_vox) * CHG) + (lane & 1), v);
+            }
+        } else
         if (yz_in && x < g.nx) {
             const size_t vox = vox0 + (size_t)k * plane_vox;
             if (g.C == CHG) {
