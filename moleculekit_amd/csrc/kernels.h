@@ -544,20 +544,26 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
 }
 
-template <typename SigT, int PBC>
+template <typename SigT, int PBC, bool SHARED = false>
 MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 const long long* __restrict__ atom_offsets, long long total_atoms,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                                 const float* __restrict__ box, const double* __restrict__ affine,
                                 unsigned* __restrict__ cell_count,
                                 float4* __restrict__ tmp_pos, uint2* __restrict__ tmp_idx, uint2* __restrict__ tmp_cls,
-                                unsigned* __restrict__ block_sets, int* __restrict__ err_flag)
+                                unsigned* __restrict__ block_sets, int* __restrict__ err_flag,
+                                unsigned nblk /* blocks of 256 atoms; the grid may be smaller: see below */)
 {
     if (direct_layout(g)) return;                        // the direct pass of this call has binned everything (block-uniform)
     if (g.prepass_hurry) mk_wave_priority_high();
     __shared__ unsigned s_set[CLS_BLOCK_SET];
     __shared__ unsigned s_full;
     const bool classes = !g.force_general;
+    // One workgroup per 256 atoms -- except behind a direct pass (SHARED), where this kernel is only the fall-back: the
+    // launch is then a few thousand workgroups that share the blocks (leaving at once when the pass succeeded costs 5 us,
+    // not the 39 us of 50 000 empty workgroups).  A separate instance: as a loop the kernel needs 80 VGPRs, and the one that
+    // runs beside the previous call's tile kernel must stay within 48 (tests/test_register_budgets.py).
+    for (unsigned lb = blockIdx.x; lb < (SHARED ? nblk : blockIdx.x + 1u); lb += (SHARED ? gridDim.x : 1u)) {
     if (classes) {
         if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
         if (threadIdx.x == 0) s_full = 0u;
@@ -567,7 +573,6 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     //  atomics spread over the whole counter array, was measured -- S = 16 / 64 / 256: k_bin_count 333 -> 382 us at 64, the
     //  in-order step 2.56 -> 2.80 / 2.60 / 2.53 ms: the batch binning is not bound by where its atomics land, unlike the
     //  one-molecule call, see k_bin_solo)
-    const unsigned lb = blockIdx.x;
     // the items of the block's first and last atom (block-uniform: scalar loads); one block rarely spans several
     const long long a_first = (long long)lb * blockDim.x;
     const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
@@ -581,6 +586,8 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
         mk_block_sync();
         if (threadIdx.x < CLS_BLOCK_SET)
             block_sets[(size_t)lb * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
+        if (SHARED && lb + gridDim.x < nblk) mk_block_sync();         // (the set is re-initialised for the next block)
+    }
     }
 }
 
@@ -951,13 +958,13 @@ MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* 
     }
 }
 
-template <typename SigT>
+template <typename SigT, bool SHARED = false>
 __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
                                const unsigned* __restrict__ cell_start,
                                const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_idx,
                                const uint2* __restrict__ tmp_cls,
                                float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
-                               unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table)
+                               unsigned* __restrict__ rec_cls, const unsigned* __restrict__ cls_table, unsigned nblk)
 {
     if (direct_layout(g)) return;                        // nothing to permute: the direct pass wrote the records in place
     if (g.prepass_hurry) mk_wave_priority_high();
@@ -965,17 +972,22 @@ __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, 
     // whole items.  The records of an item are a few hundred KB: written by ONE XCD they meet in its L2 and leave as full
     // lines; spread over all eight (consecutive blocks of an item) every 128-byte line leaves in up to eight pieces
     // (WRITE_SIZE 324 MB for 187 MB of records).  Placement is a speed matter only: any block may take any slots.
-    const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned lb = blockIdx.x < 8u * per_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-    const size_t t = (size_t)lb * blockDim.x + threadIdx.x;
-    if (t >= (size_t)g.M) return;
-    const uint2 ix = mk_tmp_load(&tmp_idx[t]);
-    if (ix.x == TMP_UNUSED) return;
-    const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
-    unsigned tab[NCLS];
+    // (the grid is one workgroup per 256 slots, or -- SHARED: behind a direct pass, where this kernel is the fall-back -- a few
+    //  thousand that share them, a multiple of eight so that a virtual block stays on its XCD; a separate instance: as a loop
+    //  the kernel spills under its 48-register cap, tests/test_register_budgets.py)
+    const unsigned per_xcd = nblk >> 3;
+    for (unsigned vb = blockIdx.x; vb < (SHARED ? nblk : blockIdx.x + 1u); vb += (SHARED ? gridDim.x : 1u)) {
+        const unsigned lb = vb < 8u * per_xcd ? (vb & 7u) * per_xcd + (vb >> 3) : vb;
+        const size_t t = (size_t)lb * blockDim.x + threadIdx.x;
+        if (t >= (size_t)g.M) continue;
+        const uint2 ix = mk_tmp_load(&tmp_idx[t]);
+        if (ix.x == TMP_UNUSED) continue;
+        const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+        unsigned tab[NCLS];
 #pragma unroll
-    for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
-    fill_record<SigT>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, tmp_cls, rec_pos, rec_w, rec_cls, tab, general);
+        for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
+        fill_record<SigT>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, tmp_cls, rec_pos, rec_w, rec_cls, tab, general);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -360,7 +360,11 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         const unsigned spill = solo ? (unsigned)P.total_atoms
                                     : P.spill_cap > 0 ? P.spill_cap : (unsigned)std::max<long long>(1024, P.total_atoms / (8LL * g.B));
         const unsigned long long slots = (unsigned long long)ncells * (unsigned)direct_cap + (unsigned long long)spill * (unsigned)g.B;
-        const bool direct = (solo || (!per_item && direct_geom && P.direct == 1)) && slots <= 0xFFFF0000ull;   // (k_bin_direct: measured -3 % in order, nothing pipelined)
+        // k_bin_direct for a big call: whenever asked for (1), and by itself (-1) when the call is NOT pipelined -- in order
+        // the one-pass form is 3 % faster (the class table of the previous call on the workspace serves; the chain behind
+        // it leaves at once), beside the previous call's tile kernel it gains nothing
+        const bool direct_big = !per_item && direct_geom && (P.direct == 1 || (P.direct < 0 && !be.set_is_pipelined(set) && P.total_atoms >= 200000));
+        const bool direct = (solo || direct_big) && slots <= 0xFFFF0000ull;
         if (solo && !direct) { err = "internal: the one-launch pre-pass does not fit its record slots"; return ST_EINVAL; }
         if (direct) {
             g.cell_cap = direct_cap; g.spill_base = (unsigned)(ncells * (size_t)direct_cap); g.spill_cap = spill;
@@ -431,8 +435,12 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
             clean_after = count_bytes;
         }
         const dim3 ablk(256), agrid((unsigned)ceil_div(P.total_atoms > 0 ? P.total_atoms : 1, 256));
-        const dim3 fgrid((unsigned)ceil_div((long long)g.M, 256));
-        const unsigned nblk = agrid.x;
+        const unsigned nblk = agrid.x, nfblk = (unsigned)ceil_div((long long)g.M, 256);
+        // behind a direct pass the chain is a fall-back that usually leaves at once: a few thousand workgroups that share
+        // the blocks instead of one each (k_bin_count, k_bin_fill)
+        const bool fallback_only = g.direct_words != nullptr && !solo;
+        const dim3 cgrid(fallback_only && nblk > 4096u ? 4096u : nblk);
+        const dim3 fgrid(fallback_only && nfblk > 4096u ? 4096u : nfblk);
         const unsigned rows_per_block = 128;
         const unsigned nl1 = (nblk + rows_per_block - 1) / rows_per_block;
         void *bsets = nullptr, *l1sets = nullptr;
@@ -458,10 +466,12 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         }
         if (P.total_atoms > 0) {
             auto bin = [&](auto kern, auto* sig) {
-                return be.launch(kern, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine,
-                                 (unsigned*)count, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (unsigned*)bsets, (int*)eflag);
+                return be.launch(kern, cgrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine,
+                                 (unsigned*)count, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (unsigned*)bsets, (int*)eflag, nblk);
             };
-            if (P.sigmas_f64) st = g.pbc ? bin(k_bin_count<double, 1>, (const double*)P.sigmas) : bin(k_bin_count<double, 0>, (const double*)P.sigmas);
+            if (fallback_only) {                             // (open boundaries: the direct layouts have no periodic form)
+                st = P.sigmas_f64 ? bin(k_bin_count<double, 0, true>, (const double*)P.sigmas) : bin(k_bin_count<float, 0, true>, (const float*)P.sigmas);
+            } else if (P.sigmas_f64) st = g.pbc ? bin(k_bin_count<double, 1>, (const double*)P.sigmas) : bin(k_bin_count<double, 0>, (const double*)P.sigmas);
             else              st = g.pbc ? bin(k_bin_count<float, 1>, (const float*)P.sigmas) : bin(k_bin_count<float, 0>, (const float*)P.sigmas);
             if (st) return st;
         }
@@ -488,10 +498,12 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
             // (FOUR temp slots per thread with their loads in flight together -- for calls that run alone on the chip, where the
             //  48-register budget does not apply -- were measured: 261 us against 212, the pass is bound by its scattered
             //  stores, not by the round trips in front of them)
-            st = P.sigmas_f64 ? be.launch(k_bin_fill<double>, fgrid, ablk, g, (const double*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
-                                          (const uint2*)tidx, (const uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab)
-                              : be.launch(k_bin_fill<float>, fgrid, ablk, g, (const float*)P.sigmas, (const unsigned*)start, (const float4*)tpos,
-                                          (const uint2*)tidx, (const uint2*)tcls, (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab);
+            auto fill = [&](auto kern, auto* sig) {
+                return be.launch(kern, fgrid, ablk, g, sig, (const unsigned*)start, (const float4*)tpos, (const uint2*)tidx, (const uint2*)tcls,
+                                 (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab, nfblk);
+            };
+            if (fallback_only) st = P.sigmas_f64 ? fill(k_bin_fill<double, true>, (const double*)P.sigmas) : fill(k_bin_fill<float, true>, (const float*)P.sigmas);
+            else               st = P.sigmas_f64 ? fill(k_bin_fill<double>, (const double*)P.sigmas) : fill(k_bin_fill<float>, (const float*)P.sigmas);
             if (st) return st;
         }
         }                                           // (not solo)

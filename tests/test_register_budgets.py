@@ -16,8 +16,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGETS = {
     "k_voxelize_tiles_leanILi8ELi640E": (104, 64),     # 4 waves per SIMD leave 96 registers for the pre-pass
     "k_voxelize_tilesILi8ELi640E": (128, 0),           # 4 waves per SIMD
-    "k_bin_countIfLi0EE": (48, 0),                     # two pre-pass waves per SIMD beside four lean tile waves
-    "k_bin_fillIfE": (48, 0),
+    "k_bin_countIfLi0ELb0EE": (48, 0),                 # two pre-pass waves per SIMD beside four lean tile waves (the shared-loop instance: free)
+    "k_bin_fillIfLb0EE": (48, 0),
     "k_voxelize_itemsILi8E": (128, 0),                 # 4 waves per SIMD
 }
 
