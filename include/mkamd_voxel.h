@@ -88,12 +88,14 @@ int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on);
  *  -1 (default): SMALL calls (the reference's pattern: one molecule per call; at most 1 024 tile waves) take the
  *      one-launch pre-pass -- the class table lives across the calls of the context and is extended on the spot, atoms
  *      with several sigmas and more classes than ids are handled in place, nothing is enqueued behind it: three launches
- *      per call instead of five; big calls take the count / scan / fill chain;
+ *      per call instead of five; BIG calls that are not pipelined (mkamd_ctx_set_pipelining) take the one-pass form
+ *      k_bin_direct -- class ids from the table the previous call on the workspace left, the count / scan / fill chain
+ *      enqueued behind it as a device-side fallback (a few thousand workgroups that leave at once unless the pass gave up:
+ *      a sigma the table lacks, an atom with several sigmas, a full spill area): cfg2, 256 grids in order 2.41-2.43 against
+ *      2.47-2.48 ms, pre-pass traffic 0.9 GB instead of 1.7; pipelined calls keep the chain (the one-pass form gains
+ *      nothing beside the previous call's tile kernel);
  *   0: the chain (or the per-item pre-pass) always;
- *   1: additionally, big calls use the one-pass form with class ids from the table the previous call left and the chain
- *      enqueued behind it as a device-side fallback that returns at once unless the pass gave up (a sigma the table lacks,
- *      an atom with several sigmas, a full spill area).  Opt-in because it only pays for calls that are NOT pipelined
- *      (cfg2, 256 grids: 2.47 against 2.55 ms in order, 2.28 against 2.27 pipelined; pre-pass traffic 0.9 GB, not 1.9);
+ *   1: the one-pass form for every big call, pipelined or not;
  *   2: the one-launch pre-pass for calls of any size whose geometry allows it (tests). */
 int mkamd_ctx_set_direct_binning(mkamd_ctx* ctx, int mode);
 /* Tolerance-aware reach (opt-in; 0 = off, the default: the reference's hard 5 A cutoff for every atom,

@@ -200,8 +200,9 @@ class Context:
         _check(load().mkamd_ctx_set_fine_cells(self._h, int(bool(on))))
 
     def set_direct_binning(self, mode: int):
-        """-1 automatic (default: small calls take the one-launch pre-pass), 0 the count / scan / fill chain always, 1 also the
-        one-pass direct binning of big calls, 2 the one-launch pre-pass for any size (include/mkamd_voxel.h); bit-identical results."""
+        """-1 automatic (default: small calls take the one-launch pre-pass, big calls that are not pipelined the one-pass direct
+        binning), 0 the count / scan / fill chain always, 1 the one-pass direct binning for every big call, 2 the one-launch
+        pre-pass for any size (include/mkamd_voxel.h); bit-identical results."""
         _check(load().mkamd_ctx_set_direct_binning(self._h, int(mode)))
 
     def set_value_tolerance(self, eps: float):
