@@ -395,7 +395,8 @@ MK_DEV void items_of_block(const long long* __restrict__ atom_offsets, int B, lo
                            long long a_last, int& b_lo, int& b_hi)
 {
     if (B == 1) { b_lo = b_hi = 0; return; }                       // one item per call (the reference's usage): nothing to look up
-    int b = (int)((double)a_first * (double)B / (double)(total_atoms > 0 ? total_atoms : 1));
+    // (a guess, verified below: single precision and v_rcp_f32 -- the double-precision division was a dozen f64 instructions per wave)
+    int b = (int)((float)a_first * ((float)B * mk_rcp((float)(total_atoms > 0 ? total_atoms : 1))));
     b = b < 0 ? 0 : (b > B - 1 ? B - 1 : b);
     const long long o0 = atom_offsets[b], o1 = atom_offsets[b + 1];
     long long next = o1;
@@ -484,15 +485,14 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
             }
         }
     }
-    const double inv_cs = 1.0 / (double)g.cs;
-    const double cmid = 0.5 * (double)(g.cs - 1);
+    const double cmid = 0.5 * (double)(g.cs - 1);                     // (the cell edge is a power of two: ldexp divides by it exactly)
     const int nc[3] = {g.ncx, g.ncy, g.ncz};
     // cell and cell-relative offset of one image position q
     auto locate = [&](const double (&q)[3], int (&pc)[3], float (&rel)[3]) {
         bool inside = true;
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const int ci = (int)floor((q[ax] + 0.5) * inv_cs);           // unpadded cell index
+            const int ci = (int)floor(ldexp(q[ax] + 0.5, -g.cs_log2));   // unpadded cell index
             pc[ax] = ci + g.h;
             inside &= (pc[ax] >= 0) && (pc[ax] < nc[ax]);
             rel[ax] = (float)(q[ax] - ((double)ci * (double)g.cs + cmid));
@@ -685,13 +685,13 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
             xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
             xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
         }
-        const double inv_cs = 1.0 / (double)g.cs, cmid = 0.5 * (double)(g.cs - 1);
+        const double cmid = 0.5 * (double)(g.cs - 1);
         const int nc[3] = {g.ncx, g.ncy, g.ncz};
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const double q = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
             if (q < -g.Rp || q > (double)(nvox[ax] - 1) + g.Rp) want = false;
-            const int ci = (int)floor((q + 0.5) * inv_cs);
+            const int ci = (int)floor(ldexp(q + 0.5, -g.cs_log2));
             pc[ax] = ci + g.h;
             want = want && (pc[ax] >= 0) && (pc[ax] < nc[ax]);
             rel[ax] = (float)(q - ((double)ci * (double)g.cs + cmid));
@@ -847,13 +847,13 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
             xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
             xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
         }
-        const double inv_cs = 1.0 / (double)g.cs, cmid = 0.5 * (double)(g.cs - 1);
+        const double cmid = 0.5 * (double)(g.cs - 1);
         const int nc[3] = {g.ncx, g.ncy, g.ncz};
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
             const double q = ((double)xyz[ax] - org[ax]) * g.inv_res;
             if (q < -g.Rp || q > (double)(nvox[ax] - 1) + g.Rp) want = false;
-            const int ci = (int)floor((q + 0.5) * inv_cs);
+            const int ci = (int)floor(ldexp(q + 0.5, -g.cs_log2));
             pc[ax] = ci + g.h;
             want = want && (pc[ax] >= 0) && (pc[ax] < nc[ax]);
             rel[ax] = (float)(q - ((double)ci * (double)g.cs + cmid));
