@@ -41,12 +41,22 @@ namespace mkamd {
 
 #ifdef MK_PHASE_TIMERS   // tools/phase_timers build only: wall-clock cycles a tile wave spends in each phase
 __device__ unsigned long long g_phase_cycles[8];
+#endif
+#if defined(MK_PHASE_TIMERS) && !defined(MK_BIN_TIMERS)
 #define MK_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
         if (!DENSE && threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], now_ - phase_t_); phase_t_ = now_; } while (0)
 #define MK_PHASE_BEGIN() unsigned long long phase_t_ = __builtin_readcyclecounter()
 #else
 #define MK_PHASE_MARK(i) do {} while (0)
 #define MK_PHASE_BEGIN() do {} while (0)
+#endif
+#if defined(MK_PHASE_TIMERS) && defined(MK_BIN_TIMERS)      // tools/bin_timers.py build: the same for the sections of k_bin_direct (wave 0 of every 64th block)
+#define MK_BIN_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[i], now_ - bin_t_); bin_t_ = now_; } while (0)   /* a sample: same-address atomics serialise */
+#define MK_BIN_BEGIN() unsigned long long bin_t_ = __builtin_readcyclecounter()
+#else
+#define MK_BIN_MARK(i) do {} while (0)
+#define MK_BIN_BEGIN() do {} while (0)
 #endif
 
 constexpr int CHG = 8;               // channels per channel-group (one group = one pass of the tile kernel)
@@ -168,10 +178,10 @@ MK_DEV float sigma_to_w(SigT sigma, double w_scale)
 //          sigmas (rare), which sends the fill pass back to the sigma row.
 constexpr unsigned ATOM_MULTI_SIGMA = 0xffffffffu;
 
+// (in two halves -- the loads, then the arithmetic -- so that a caller can have the row in flight beside its other loads)
 template <typename SigT>
-MK_DEV uint2 atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w_scale, float (&w)[CHG])
+MK_DEV void load_channel_sigmas(const SigT* __restrict__ row, int c0, int C, SigT (&s)[CHG])
 {
-    SigT s[CHG];
     // a full group of channels in a 16-byte aligned row (C = 8, the reference's channel set): 16-byte loads -- as eight
     // separate dwords with the `c0 + j < C` branches between them the wave asked the L1 for four times the lines
     struct alignas(16) Vec16 { SigT v[16 / sizeof(SigT)]; };
@@ -187,6 +197,11 @@ MK_DEV uint2 atom_channel_w(const SigT* __restrict__ row, int c0, int C, double 
 #pragma unroll
         for (int j = 0; j < CHG; ++j) s[j] = (c0 + j < C) ? row[c0 + j] : (SigT)0;
     }
+}
+
+template <typename SigT>
+MK_DEV uint2 channel_w_of(const SigT (&s)[CHG], double w_scale, float (&w)[CHG])
+{
     SigT s0 = (SigT)0;
 #pragma unroll
     for (int j = CHG - 1; j >= 0; --j) s0 = (s[j] != (SigT)0) ? s[j] : s0;
@@ -206,6 +221,14 @@ MK_DEV uint2 atom_channel_w(const SigT* __restrict__ row, int c0, int C, double 
     }
     const bool none = !(w0 < mk_inf());
     return make_uint2(none ? CLS_EMPTY : mk_float_bits(w0), other ? ATOM_MULTI_SIGMA : (none ? 0u : nib));
+}
+
+template <typename SigT>
+MK_DEV uint2 atom_channel_w(const SigT* __restrict__ row, int c0, int C, double w_scale, float (&w)[CHG])
+{
+    SigT s[CHG];
+    load_channel_sigmas(row, c0, C, s);
+    return channel_w_of(s, w_scale, w);
 }
 
 // Class table: NCLS slots of w bit patterns (CLS_EMPTY = unused), word NCLS = overflow marker.
@@ -619,36 +642,62 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
 {
     if (g.prepass_hurry) mk_wave_priority_high();
     __shared__ unsigned s_set[CLS_BLOCK_SET];
+    MK_BIN_BEGIN();
+    // A wave's life here is a chain of memory round trips (75 % of it is s_waitcnt), so the loads are ISSUED together and
+    // waited for once: the position first (its address depends on the atom index alone: it flies during the set-up and the
+    // item look-up), the origin as soon as the item is known, the sigma row last -- one round trip instead of three.
+    // (All of them unconditional, from clamped indices: a load inside `if (act)` is followed by a wait where the branch
+    //  ends -- the register allocator puts a copy there.)
+    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = a < total_atoms;
+    const long long a_c = act ? a : total_atoms - 1;                            // (the kernel is not launched without atoms)
+    const int lane = threadIdx.x & (WAVE - 1);
+    float xyz[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) xyz[ax] = coords[3 * a_c + ax];
+    // the class table of the previous call: lane s holds class s (CLS_EMPTY beyond the table's end)
+    const unsigned tab_word = cls_table[lane < CLS_TABLE_WORDS ? lane : 0];
     __shared__ unsigned s_full;
     if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
     if (threadIdx.x == 0) s_full = 0u;
     mk_block_sync();
     unsigned* const words = counts;
     counts += DIRECT_HEAD;
-    const int lane = threadIdx.x & (WAVE - 1);
     const long long a_first = (long long)blockIdx.x * blockDim.x;
     const long long a_last = (a_first + blockDim.x < total_atoms ? a_first + blockDim.x : total_atoms) - 1;
     int b_lo, b_hi;
     items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
-    const long long a = a_first + threadIdx.x;
-    const bool act = a < total_atoms;
-    // the class table of the previous call: lane s holds class s (CLS_EMPTY beyond the table's end)
-    const unsigned tab = lane < CLS_TABLE_WORDS ? cls_table[lane] : CLS_EMPTY;
-    bool failed = mk_readlane(tab, CLS_OVERFLOW) != CLS_EMPTY;                 // more classes than ids: that call took the general path
+    MK_BIN_MARK(0);
+
+    // ---- the atom's item and its origin ----
+    int b = b_lo;
+    if (b_hi != b_lo) {                                                        // block-uniform: the block straddles items
+        int lo = b_lo, hi = b_hi + 1;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (atom_offsets[mid] <= a_c) lo = mid; else hi = mid;
+        }
+        b = lo;
+    }
+    double org[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) org[ax] = origins[3 * (size_t)b + ax];
 
     // ---- channels: one radius per atom is the rule; its class id by election (a handful of distinct values per wave) ----
     float w[CHG];
-    uint2 cw = make_uint2(CLS_EMPTY, 0u);
-    if (act) {
-        cw = atom_channel_w(sigmas + (size_t)a * g.C, 0, g.C, g.w_scale, w);
-        tmp_cls[a] = cw;                                                       // (the fix-up waves of k_tail find an atom's sigma here)
-    }
+    uint2 cw = atom_channel_w(sigmas + (size_t)a_c * g.C, 0, g.C, g.w_scale, w);
+    if (!act) cw = make_uint2(CLS_EMPTY, 0u);
+    if (act) tmp_cls[a] = cw;                                                  // (the fix-up waves of k_tail find an atom's sigma here)
+    const unsigned tab = lane < CLS_TABLE_WORDS ? tab_word : CLS_EMPTY;
+    bool failed = mk_readlane(tab, CLS_OVERFLOW) != CLS_EMPTY;                 // more classes than ids: that call took the general path
     const bool multi = cw.y == ATOM_MULTI_SIGMA;
     const bool any = cw.x != CLS_EMPTY && !multi;
+    MK_BIN_MARK(1);
     unsigned wb[CHG];
 #pragma unroll
     for (int j = 0; j < CHG; ++j) wb[j] = CLS_EMPTY;
     wave_register_classes(cw.x, false, wb, s_set, &s_full);                    // (the fix-up waves of k_tail read the blocks' sets)
+    MK_BIN_MARK(2);
     unsigned id = 0u;
     {
         bool pending = any;
@@ -663,21 +712,14 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         }
     }
     failed = failed || mk_ballot(multi) != 0ull;
+    MK_BIN_MARK(3);
 
     // ---- position -> (cell, cell-relative offset) in double, exactly as bin_atom does ----
     bool want = any;
     int pc[3] = {0, 0, 0};
     float rel[3] = {0.f, 0.f, 0.f};
-    int b = 0;
     if (want) {
-        int lo = b_lo, hi = b_hi + 1;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
-        }
-        b = lo;
         const int nvox[3] = {g.nx, g.ny, g.nz};
-        float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
         if (affine != nullptr) {
             const double* A = affine + 12 * (size_t)b;
             const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
@@ -689,7 +731,7 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         const int nc[3] = {g.ncx, g.ncy, g.ncz};
 #pragma unroll
         for (int ax = 0; ax < 3; ++ax) {
-            const double q = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+            const double q = ((double)xyz[ax] - org[ax]) * g.inv_res;
             if (q < -g.Rp || q > (double)(nvox[ax] - 1) + g.Rp) want = false;
             const int ci = (int)floor(ldexp(q + 0.5, -g.cs_log2));
             pc[ax] = ci + g.h;
@@ -698,7 +740,9 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         }
     }
     const size_t cell = want ? (size_t)b * g.cstride + ((size_t)pc[0] * g.ncy + pc[1]) * g.ncz + pc[2] : (size_t)0;
+    MK_BIN_MARK(4);
     const unsigned rank = wave_rank_in_cell(want, (unsigned)cell << g.cnt_shift, counts);
+    MK_BIN_MARK(5);
     if (want) {
         unsigned slot;
         if (rank < (unsigned)g.cell_cap) {
@@ -720,9 +764,11 @@ MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, c
         }
     }
     if (mk_ballot(failed) != 0ull && lane == 0) words[DIRECT_FAILED] = 1u;
+    MK_BIN_MARK(6);
     mk_block_sync();
     if (threadIdx.x < CLS_BLOCK_SET)
         block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
+    MK_BIN_MARK(7);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1348,8 +1394,15 @@ MK_DEV CandRuns find_candidate_runs(const GridDesc& g, const TileGeom& tg, const
         const unsigned* __restrict__ cnt = g.direct_words + DIRECT_HEAD;
         const int nxc = tg.cx_hi - tg.cx_lo + 1, nyc = tg.cy_hi - tg.cy_lo + 1, nzc = tg.cz_hi - tg.cz_lo + 1;
         const int ncells = nxc * nyc * nzc;
-        if (lane < ncells) {
-            const int pcz = tg.cz_lo + lane % nzc, pcy = tg.cy_lo + (lane / nzc) % nyc, pcx = tg.cx_lo + lane / (nzc * nyc);
+        // lane -> cell: at most 4 cells per axis (the rule: an 8-voxel tile edge + 2 x the cutoff over cells of at least the
+        // cutoff) are dealt out by the lane's bit fields -- three divisions by run-time numbers cost ~70 instructions per tile
+        const bool boxed = nxc <= 4 && nyc <= 4 && nzc <= 4 && ncells < WAVE;            // wave-uniform (lane 63 stays free for the spill run)
+        int ix, iy, iz;
+        bool holds_cell;
+        if (boxed) { ix = lane >> 4; iy = (lane >> 2) & 3; iz = lane & 3; holds_cell = ix < nxc && iy < nyc && iz < nzc; }
+        else { ix = lane / (nzc * nyc); iy = (lane / nzc) % nyc; iz = lane % nzc; holds_cell = lane < ncells; }
+        if (holds_cell) {
+            const int pcz = tg.cz_lo + iz, pcy = tg.cy_lo + iy, pcx = tg.cx_lo + ix;
             const float fcs = (float)g.cs;
             const float cx0 = (float)((pcx - g.h) * g.cs) - 0.5f, cy0 = (float)((pcy - g.h) * g.cs) - 0.5f, cz0 = (float)((pcz - g.h) * g.cs) - 0.5f;
             const float gx = fmaxf(fmaxf((float)tg.x0 - (cx0 + fcs), cx0 - (float)(tg.x0 + K - 1)), 0.f);
