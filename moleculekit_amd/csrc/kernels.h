@@ -627,11 +627,14 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
 // -- any of these raises DIRECT_FAILED, and the kernels of the count / scan / fill chain, which are enqueued behind this
 // pass in every call and return at once while the word is clear, do the call the old way (and leave the new class
 // table).  The tile kernels read the word too (find_candidate_runs).  Open boundaries, one channel group.
-// Measured on cfg2 (256 x 50 000 atoms, same box, tools/gpu_r3_direct.sh): 397 us against 338 + 189 + 48 for count + fill +
-// reductions, but the chain's kernels still cost 82 us to launch and leave, and the tile kernel reads 27 cell runs instead
-// of 9-16 column runs (+2 %): in-order step 2.47 against 2.55 ms (-3 %), pipelined 2.28 against 2.27 (nothing).  With an
+// Measured on cfg2 (256 x 50 000 atoms, same box, tools/gpu_r3_direct.sh): 390 us against 338 + 189 + 48 for count + fill +
+// reductions (pre-pass traffic 0.9-1.2 GB instead of 1.7); the chain behind it is launched as <= 4 096 workgroups that leave
+// at once (as one workgroup per block it cost 82 us to launch and leave), and the tile kernel reads 27 cell runs instead
+// of 9-16 column runs (+4 %): in-order step 2.41 against 2.55 ms, pipelined 2.28 against 2.27 (nothing).  What bounds the pass
+// is its 12.8 M scattered 16 + 4 B record stores, not its arithmetic or its round trips (docs/EXPERIMENTS_r3.md).  With an
 // XCD-aware block order (an item's atoms binned by one XCD, as k_bin_fill does) the pass takes 594 us: the item's rank
-// atomics then all arrive together.  OPT-IN (mkamd_ctx_set_direct_binning(1)); the automatic mode keeps the chain.
+// atomics then all arrive together.  AUTOMATIC for big calls that are not pipelined (pipeline.h: direct_big); the
+// pipelined ones keep the chain, whose cost hides beside the previous call's tile kernel.
 // ------------------------------------------------------------------------------------------------
 template <typename SigT>
 MK_KERNEL(256) void k_bin_direct(GridDesc g, const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
