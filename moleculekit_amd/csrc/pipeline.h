@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstdio>
 #include <string>
+#include <cstdlib>
 
 #ifndef MK_SOLO_CNT_SHIFT
 #define MK_SOLO_CNT_SHIFT 3     // k_bin_solo's cell counters 32 bytes apart (GridDesc::cnt_shift); 16 and 128 bytes measured the same
@@ -321,7 +322,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         }
         return best;
     };
-    const int direct_cap = P.cell_cap > 0 ? P.cell_cap : 128;
+    static const int env_cap = [] { const char* e = std::getenv("MKAMD_CELL_CAP"); return e ? std::atoi(e) : 0; }();     // A-B knob
+    const int direct_cap = P.cell_cap > 0 ? P.cell_cap : (env_cap > 0 ? env_cap : 128);
     const bool direct_geom = !g.pbc && g.G == 1 && !g.force_general && P.total_atoms > 0 && direct_cap <= (1 << SURV_OFF_BITS) &&
                              span(g.K) * span(8) * span(8) <= WAVE - 1;
     // a SMALL call (the team regime: one molecule per call) takes the one-launch pre-pass k_bin_solo, unless the caller
