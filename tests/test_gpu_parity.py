@@ -296,6 +296,50 @@ def test_cfg5_full_resolution_batch(hip_ctx):
         assert np.abs(full[b] - exp[0]).max() <= TOL
 
 
+def test_cfg5_full_count_in_one_call(hip_ctx):
+    """BASELINE configs[4] at its FULL count on one GPU: 100 000 ragged molecules, 24^3 grid at 0.5 A, one call -- 1.1e10
+    result elements (44 GB, past 2^33: every index of the path has to be 64-bit where it counts), result kept on the
+    device.  The oracle on items at both ends and around the 2^32 / 2^33-element marks, bitwise agreement with the same
+    molecules voxelized as a small batch, and nothing left unwritten (the buffer is pre-filled with NaN)."""
+    import torch
+    from moleculekit_amd import batch
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(0).total_memory < 64 * 2 ** 30:
+        pytest.skip("needs 64 GB of device memory")
+    B = 100_000
+    p = synth_config(5, B)
+    origins = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    V = int(np.prod(nv))
+    assert B * V * 8 > 2 ** 33
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    out = torch.full((B, V, 8), float("nan"), dtype=torch.float32, device=dev)
+    hip_ctx.set_tile_k(8)                                        # (both calls at one tile depth: the same roundings)
+    res = batch.voxelize_lattice_torch(t(p["coords"], np.float32), t(p["atom_offsets"], np.int64), t(p["sigmas"], np.float64),
+                                       t(origins, np.float64), nv, p["voxelsize"], ctx=hip_ctx, out=out)   # (float64 sigmas, as below)
+    hip_ctx.synchronize()
+    torch.cuda.synchronize()
+    assert res.data_ptr() == out.data_ptr()
+    sums = out.sum(dim=(1, 2))                                   # one number per molecule: NaN anywhere would show
+    assert bool(torch.isfinite(sums).all()) and float(sums.min()) > 0.0
+    per_item = V * 8
+    marks = [2 ** 32 // per_item, 2 ** 32 // per_item + 1, 2 ** 33 // per_item, 2 ** 33 // per_item + 1]
+    pick = sorted({0, 1, B // 2, B - 2, B - 1, *marks} | set(np.random.default_rng(5).choice(B, 8, replace=False).tolist()))
+    for b in pick:
+        s, e = p["atom_offsets"][b], p["atom_offsets"][b + 1]
+        exp = oracle_lattice(p["coords"][s:e], np.array([0, e - s]), p["sigmas"][s:e], origins[b:b + 1], nv, p["voxelsize"])
+        got = out[b].cpu().numpy()
+        assert np.abs(got - exp[0]).max() <= TOL, b
+    # the last 64 molecules again as a batch of their own: the same bits
+    s0 = p["atom_offsets"][B - 64]
+    small = batch.voxelize_lattice(p["coords"][s0:], p["atom_offsets"][B - 64:] - s0, p["sigmas"][s0:], origins[B - 64:], nv,
+                                   p["voxelsize"], ctx=hip_ctx)
+    hip_ctx.set_tile_k(0)
+    tail = out[B - 64:].cpu().numpy()
+    assert np.array_equal(small, tail), float(np.abs(small - tail).max())
+    del out, res
+
+
 def test_periodic_frames_match_27_image_composition_on_gpu(hip_ctx):
     """PBC result == max over the 27 shifted NON-periodic GPU runs (the composition SURVEY 8c uses to
     pin the extension on the reference kernel), when the grid lies inside the box."""
