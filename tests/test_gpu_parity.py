@@ -223,6 +223,55 @@ def test_cfg4_full_size_against_reference_samples(hip_ctx):
             assert np.abs(f.max(0) - g[f"f{frame}_channel_max"]).max() <= TOL
 
 
+def test_cfg4_full_count_in_one_call(hip_ctx):
+    """BASELINE configs[3] at its FULL count on one GPU: 10 000 periodic frames of 30 000 atoms (3e8 atoms, a 66.9 A box,
+    48^3 x 8: 8.8e9 result elements, 35 GB) in ONE call, generated and kept on the device.  Frames at both ends and around
+    the 2^32 / 2^33-element marks must carry the bits the same frames get as a small batch (whose path the golden samples
+    of the test above pin), and no frame may be left unwritten (the buffer is pre-filled with NaN)."""
+    import torch
+    from moleculekit_amd import batch
+    from tests.synth import synth_sigmas
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(0).total_memory < 128 * 2 ** 30:
+        pytest.skip("needs 128 GB of device memory")
+    F, N, L = 10_000, 30_000, 66.9
+    p1 = synth_config(4, 1)
+    origin, nv = grid_origin(p1["centers"][0], p1["boxsize"], p1["voxelsize"])
+    V = int(np.prod(nv))
+    gen = torch.Generator(device=dev).manual_seed(4)
+    x0 = torch.rand((N, 3), generator=gen, device=dev, dtype=torch.float32) * L
+    walk = torch.randn((F, N, 3), generator=gen, device=dev, dtype=torch.float32) * 0.3
+    walk[0] = 0
+    coords = torch.remainder(x0 + torch.cumsum(walk, 0), L).reshape(F * N, 3).contiguous()
+    del walk
+    sig1 = synth_sigmas(np.random.default_rng(4), N).astype(np.float32)
+    sigmas = torch.as_tensor(sig1, device=dev).repeat(F, 1)
+    offsets = torch.arange(F + 1, device=dev, dtype=torch.int64) * N
+    origins = torch.as_tensor(np.tile(origin, (F, 1)), device=dev, dtype=torch.float64)
+    box = torch.full((F, 3), L, device=dev, dtype=torch.float32)
+    mi = batch.max_images_per_atom(np.full((1, 3), L), nv, p1["voxelsize"])
+    out = torch.full((F, V, 8), float("nan"), dtype=torch.float32, device=dev)
+    hip_ctx.set_tile_k(8)                                        # (both calls at one tile depth: the same roundings)
+    try:
+        batch.voxelize_lattice_torch(coords, offsets, sigmas, origins, nv, p1["voxelsize"], box=box, max_images=mi, ctx=hip_ctx, out=out)
+        hip_ctx.synchronize()
+        torch.cuda.synchronize()
+        sums = out.sum(dim=(1, 2))
+        assert bool(torch.isfinite(sums).all()) and float(sums.min()) > 0.0
+        per_frame = V * 8
+        pick = sorted({0, 1, F // 2, F - 2, F - 1, 2 ** 32 // per_frame, 2 ** 32 // per_frame + 1, 2 ** 33 // per_frame, 2 ** 33 // per_frame + 1})
+        idx = torch.as_tensor(pick, device=dev)
+        sub_coords = coords.reshape(F, N, 3)[idx].reshape(-1, 3).cpu().numpy()
+        small = batch.voxelize_lattice(sub_coords, np.arange(len(pick) + 1) * N, np.tile(sig1, (len(pick), 1)), np.tile(origin, (len(pick), 1)),
+                                       nv, p1["voxelsize"], box=np.full((len(pick), 3), L, dtype=np.float32), ctx=hip_ctx)
+        big = out[idx].cpu().numpy()
+        assert np.array_equal(small, big), float(np.abs(small - big).max())
+        assert small.max() > 0.5
+    finally:
+        hip_ctx.set_tile_k(0)
+    del out, coords, sigmas
+
+
 def test_3ptb_bbox_buffer8_against_reference_samples(hip_ctx):
     """The reference test's own call shape (test_voxeldescriptors.py:77-79: buffer=8 -> 60x55x65 grid)."""
     from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
