@@ -270,6 +270,7 @@ def test_cfg4_full_count_in_one_call(hip_ctx):
     finally:
         hip_ctx.set_tile_k(0)
     del out, coords, sigmas
+    torch.cuda.empty_cache()
 
 
 def test_3ptb_bbox_buffer8_against_reference_samples(hip_ctx):
@@ -387,6 +388,7 @@ def test_cfg5_full_count_in_one_call(hip_ctx):
     tail = out[B - 64:].cpu().numpy()
     assert np.array_equal(small, tail), float(np.abs(small - tail).max())
     del out, res
+    torch.cuda.empty_cache()
 
 
 def test_periodic_frames_match_27_image_composition_on_gpu(hip_ctx):
