@@ -273,6 +273,45 @@ def test_cfg4_full_count_in_one_call(hip_ctx):
     torch.cuda.empty_cache()
 
 
+def test_one_grid_past_2_to_the_32_elements(hip_ctx):
+    """ONE item whose result passes 2^32 elements: an 832^3 x 8 grid (4.6e9 floats, 18 GB), 11.5 M atoms, generated on the
+    device.  64^3 windows at the first and the last corner and in the middle must carry the bits the same window gets as a
+    grid of its own (origin moved by whole cells, the atoms within reach): voxel indices are 64-bit where they have to be."""
+    import torch
+    from moleculekit_amd import batch
+    from tests.synth import synth_sigmas
+    dev = torch.device("cuda", 0)
+    if torch.cuda.get_device_properties(0).total_memory < 64 * 2 ** 30:
+        pytest.skip("needs 64 GB of device memory")
+    n, N = 832, 11_500_000
+    assert n ** 3 * 8 > 2 ** 32
+    gen = torch.Generator(device=dev).manual_seed(8)
+    coords = (torch.rand((N, 3), generator=gen, device=dev, dtype=torch.float32) * (n + 10.0) - 5.0).contiguous()
+    sig1 = synth_sigmas(np.random.default_rng(8), 1_000_000).astype(np.float32)
+    sigmas = torch.as_tensor(sig1, device=dev).repeat(12, 1)[:N].contiguous()
+    nv = np.array([n, n, n])
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    out = torch.full((1, n ** 3, 8), float("nan"), dtype=torch.float32, device=dev)
+    hip_ctx.set_tile_k(8)
+    try:
+        batch.voxelize_lattice_torch(coords, t([0, N], np.int64), sigmas, t(np.zeros((1, 3)), np.float64), nv, 1.0, ctx=hip_ctx, out=out)
+        hip_ctx.synchronize()
+        torch.cuda.synchronize()
+        grid = out.view(n, n, n, 8)
+        assert bool(torch.isfinite(grid.sum(dim=(1, 2, 3))).all())
+        for lo in (0, 384, n - 64):
+            near = ((coords > lo - 6.0) & (coords < lo + 64 + 6.0)).all(dim=1)
+            c, sg = coords[near].cpu().numpy(), sigmas[near].cpu().numpy()
+            win = batch.voxelize_lattice(c, np.array([0, len(c)]), sg, np.full((1, 3), float(lo)), np.array([64, 64, 64]), 1.0, ctx=hip_ctx)
+            big = grid[lo:lo + 64, lo:lo + 64, lo:lo + 64].reshape(1, 64 ** 3, 8).cpu().numpy()
+            assert np.array_equal(win, big), (lo, float(np.abs(win - big).max()))
+            assert win.max() > 0.5
+    finally:
+        hip_ctx.set_tile_k(0)
+    del out, grid, coords, sigmas
+    torch.cuda.empty_cache()
+
+
 def test_3ptb_bbox_buffer8_against_reference_samples(hip_ctx):
     """The reference test's own call shape (test_voxeldescriptors.py:77-79: buffer=8 -> 60x55x65 grid)."""
     from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
