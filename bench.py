@@ -30,6 +30,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -379,6 +380,22 @@ def dry_run(args):
         raise SystemExit("dry run: sharding / gather mismatch")
 
 
+def guarded(fn, seconds, on_timeout):
+    """fn() under a watchdog: when it has not returned after `seconds`, on_timeout() is called from another thread (fn
+    itself keeps running: a collective that hangs cannot be cancelled, only left behind)."""
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(seconds):
+            on_timeout()
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        return fn()
+    finally:
+        done.set()
+
+
 def _max_over_ranks(x, world):
     """MAX of a host scalar over the ranks through a CPU tensor (the gloo side of the process group): nothing in or around
     the timed region touches RCCL -- once an RCCL communicator exists in the process every kernel of the step runs 3-7 %
@@ -573,6 +590,7 @@ def main():
     ap.add_argument("--lds-tier", type=int, default=-1, help="-1 adaptive (default), 0/1/2 = 640/768/1024 LDS entries per tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather-timeout", type=float, default=300.0, help="seconds the (untimed, secondary) RCCL feature-gather legs may take before they are abandoned")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary workloads (cfg1/cfg3/cfg4/cfg5 at N=1, the cfg3 batched-molecule leg at N>1)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -719,62 +737,85 @@ def main():
         finally:
             ctx.set_value_tolerance(0.0)
 
+    printed = threading.Lock()
+    timed_out = []                                 # non-empty once the watchdog of the gather legs has fired
+
+    def emit():
+        """rank 0's ONE JSON line (called once: after the gather legs, or by their watchdog)"""
+        if not printed.acquire(blocking=False):
+            return
+        if rank == 0:
+            total_vc = world * B * V * C * args.steps
+            k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
+            info = ctx.device_info()
+            line = {
+                "metric": "Mvoxel-channels/s (64^3 grid, 8 ch)" if args.workload == "cfg2" else f"Mvoxel-channels/s ({args.workload})",
+                "value": round(total_vc / elapsed / 1e6, 2),
+                "unit": "Mvoxel-channels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.workload}: BASELINE.json configs[{int(args.workload[3:]) - 1}]",
+                           "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
+                           "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
+                           "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
+                           "value_tolerance": args.value_tol,
+                           "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region; "
+                                          "fences over gloo, feature gathers over RCCL after everything timed)",
+                           "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
+                "roofline": roofline_of(res, args.workload, B, args.tile_k),
+                "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if res["k_n"] else None,
+                "sustained": res.get("sustained"),
+                "single_grid_latency_us": round(res["single_us"], 2) if "single_us" in res else None,
+                "single_grid_latency_us_runs": res.get("single_us_runs"),
+                "single_grid_latency_after_batch_load_us": round(res["single_us_after_load"], 2) if "single_us_after_load" in res else None,
+                "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
+                "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
+                **({"gather_error": res["gather_error"]} if "gather_error" in res else {}),
+            }
+            if extra:
+                line["other_workloads" if world == 1 else "batched_molecules"] = extra
+            if world == 1 and not args.no_extra and args.workload == "cfg2" and not timed_out:     # (no more GPU work behind a hung leg)
+                try:
+                    if isinstance(dropin0, tuple):
+                        line["dropin_call_ms"] = round(dropin0[0], 4)
+                        line["dropin_max_abs_err_vs_reference"] = dropin0[1]
+                        line["dropin_call_after_batch_load_ms"] = round(dropin_probe()[0], 4)
+                    elif dropin0 is not None:
+                        line["secondary_error"] = dropin0
+                    # the distance_utils row (SURVEY.md section 8f-1) next to it: dist_trajectory, bit-exact float32
+                    dargs = argparse.Namespace(batch=0, steps=max(3, args.steps // 4), warmup=2, no_cpu_baseline=True)
+                    dl = bench_distances(dargs, emit=False)
+                    line.setdefault("other_workloads", {})["dist_trajectory"] = {
+                        "value": dl["value"], "unit": dl["unit"], "ms_per_step": dl["ms_per_step"], "config": dl["config"]["workload"],
+                        "roofline": dl["roofline"]}
+                except Exception as e:             # noqa: BLE001 -- secondary numbers: reported, the headline line still prints
+                    line["secondary_error"] = f"{type(e).__name__}: {e}"[:300]
+
+            if world == 1 and not args.no_cpu_baseline and not timed_out:
+                line["cpu_baseline"] = cpu_baseline(args.workload)
+            print(json.dumps(line), flush=True)
+
     if "_gather_legs" in res:                      # last: the first RCCL collective of the process
-        res.pop("_gather_legs")()
-        res.pop("_release")()
+        # Nothing with N > 1 has ever run on RCCL where this file was written: should the legs hang (they come after
+        # everything timed), the headline line must still come out -- a watchdog in every rank reports the time-out on
+        # the line (rank 0) and ends the process.
+        legs, rel = res.pop("_gather_legs"), res.pop("_release")
 
-    if rank == 0:
-        total_vc = world * B * V * C * args.steps
-        k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
-        info = ctx.device_info()
-        line = {
-            "metric": "Mvoxel-channels/s (64^3 grid, 8 ch)" if args.workload == "cfg2" else f"Mvoxel-channels/s ({args.workload})",
-            "value": round(total_vc / elapsed / 1e6, 2),
-            "unit": "Mvoxel-channels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: BASELINE.json configs[{int(args.workload[3:]) - 1}]",
-                       "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
-                       "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
-                       "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
-                       "value_tolerance": args.value_tol,
-                       "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region; "
-                                      "fences over gloo, feature gathers over RCCL after everything timed)",
-                       "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
-            "roofline": roofline_of(res, args.workload, B, args.tile_k),
-            "tile_kernel_share_of_step": round(k_avg_ms / (elapsed / args.steps * 1e3), 4) if res["k_n"] else None,
-            "sustained": res.get("sustained"),
-            "single_grid_latency_us": round(res["single_us"], 2) if "single_us" in res else None,
-            "single_grid_latency_us_runs": res.get("single_us_runs"),
-            "single_grid_latency_after_batch_load_us": round(res["single_us_after_load"], 2) if "single_us_after_load" in res else None,
-            "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
-            "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
-            **({"gather_error": res["gather_error"]} if "gather_error" in res else {}),
-        }
-        if extra:
-            line["other_workloads" if world == 1 else "batched_molecules"] = extra
-        if world == 1 and not args.no_extra and args.workload == "cfg2":
+        def abandon():
+            timed_out.append(True)
+            res["gather_error"] = f"the feature-gather legs did not return within {args.gather_timeout:.0f} s (abandoned; everything timed was done before them)"
+            for k in ("gather_ms", "gather_overlapped_extra_ms", "compute_plus_overlapped_gather_ms"):
+                res.pop(k, None)
             try:
-                if isinstance(dropin0, tuple):
-                    line["dropin_call_ms"] = round(dropin0[0], 4)
-                    line["dropin_max_abs_err_vs_reference"] = dropin0[1]
-                    line["dropin_call_after_batch_load_ms"] = round(dropin_probe()[0], 4)
-                elif dropin0 is not None:
-                    line["secondary_error"] = dropin0
-                # the distance_utils row next to it: dist_trajectory, bit-exact float32
-                dargs = argparse.Namespace(batch=0, steps=max(3, args.steps // 4), warmup=2, no_cpu_baseline=True)
-                dl = bench_distances(dargs, emit=False)
-                line.setdefault("other_workloads", {})["dist_trajectory"] = {
-                    "value": dl["value"], "unit": dl["unit"], "ms_per_step": dl["ms_per_step"], "config": dl["config"]["workload"],
-                    "roofline": dl["roofline"]}
-            except Exception as e:             # noqa: BLE001 -- secondary numbers: reported, the headline line still prints
-                line["secondary_error"] = f"{type(e).__name__}: {e}"[:300]
+                emit()
+            finally:
+                os._exit(0)
 
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(line), flush=True)
+        guarded(lambda: (legs(), rel()), args.gather_timeout, abandon)
+
+    emit()
 
     if use_dist:
         dist.all_reduce(torch.zeros(1))

@@ -35,3 +35,20 @@ def test_bench_refuses_more_gpus_than_devices():
     r = _run("--gpus", str(have + 2), "--steps", "1", "--warmup", "0")
     assert r.returncode != 0
     assert "HIP device(s) visible" in (r.stderr + r.stdout)
+
+
+def test_watchdog_of_the_gather_legs():
+    """bench.guarded: the (untimed, secondary) RCCL legs run under a watchdog, so that a collective that hangs cannot cost
+    the headline line -- the handler fires once for a function that overstays, never for one that returns in time."""
+    import threading
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    fired = []
+    assert bench.guarded(lambda: 7, 5.0, lambda: fired.append("early")) == 7
+    time.sleep(0.05)
+    assert fired == []
+    release = threading.Event()
+    t0 = time.perf_counter()
+    bench.guarded(lambda: release.wait(2.0), 0.1, lambda: (fired.append("late"), release.set()))
+    assert fired == ["late"] and time.perf_counter() - t0 < 1.5
