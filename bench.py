@@ -590,7 +590,8 @@ def main():
     ap.add_argument("--lds-tier", type=int, default=-1, help="-1 adaptive (default), 0/1/2 = 640/768/1024 LDS entries per tile")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--gather-timeout", type=float, default=300.0, help="seconds the (untimed, secondary) RCCL feature-gather legs may take before they are abandoned")
+    ap.add_argument("--gather-timeout", type=float, default=100.0,
+                    help="seconds the (untimed, secondary) RCCL feature-gather legs may take before they are abandoned (below the process group's own 120 s, whose expiry ends the process without the line)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary workloads (cfg1/cfg3/cfg4/cfg5 at N=1, the cfg3 batched-molecule leg at N>1)")
     ap.add_argument("--no-pipeline", action="store_true",
