@@ -25,7 +25,8 @@
 //                clear themselves, pipeline.h)
 //   small items: k_prepass_items                                  (the same, one workgroup per item)
 //   one molecule per call (<= 1 024 tile waves): k_bin_solo       (the whole pre-pass in one launch: records in the direct
-//                layout, the class table kept across calls; big calls can opt into k_bin_direct + the chain as fallback)
+//                layout, the class table kept across calls); big calls that are not pipelined: k_bin_direct (one pass,
+//                the chain enqueued behind it as its device-side fall-back)
 //   then       : k_voxelize_tiles[_lean|_team]<K,ECAP[,TEAM]>, k_voxelize_items<K>, k_tail<K,ECAP,SigT>   (the grid; dense tiles + fix-up)
 //   explicit centres: k_sigma_to_w, k_occupancy_centers;   lattice centres: k_grid_centers.
 //
