@@ -1906,7 +1906,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 // adding it per entry).  g_k may be negative (>= -c_k^2), so these minima are float minima (v_min3_f32).
                 float m[KL];
 #pragma unroll
-                for (int k = 0; k < KL; ++k) m[k] = INF;
+                for (int k = 0; k < KL; ++k) { m[k] = INF; mk_keep(m[k]); }
                 // planes [K0, K1) against the entries of one sub-bucket: start words b0 (this) and b1 (next); the
                 // slots are padded to an even count, bit 0 of b0 says that the last slot is padding
                 auto run = [&](auto k0_, auto k1_, unsigned b0, unsigned b1) {
@@ -1944,7 +1944,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                         const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
                         const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
 #pragma unroll
-                        for (int k = J0; k < J1; ++k) m[k] = mk_min(m[k], mk_fma(pl_slope(k), ex, d0));
+                        for (int k = J0; k < J1; ++k) m[k] = mk_min_raw(m[k], mk_fma(pl_slope(k), ex, d0));
                     }
                 };
                 // exact form for a class of small sigmas (w > FAST_W_MAX, rare): one compact loop, every plane against
@@ -2325,7 +2325,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
             const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
             float m[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) m[k] = INF;
+            for (int k = 0; k < K; ++k) { m[k] = INF; mk_keep(m[k]); }
             const bool fast = wcls <= fast_w_max<K>();                    // wave-uniform
             if (fast) {                                                   // (the pair loop of voxelize_tile, all K planes)
                 const unsigned npairs = n_in >> 1;
@@ -2346,7 +2346,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
                     const float ex = e[0], dy = Y - e[ITEM_STRIDE], dz = Z - e[2 * ITEM_STRIDE];
                     const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
 #pragma unroll
-                    for (int k = 0; k < K; ++k) m[k] = mk_min(m[k], mk_fma(plane_slope<K>(k), ex, d0));
+                    for (int k = 0; k < K; ++k) m[k] = mk_min_raw(m[k], mk_fma(plane_slope<K>(k), ex, d0));
                 }
             } else {                                                      // exact form for a class of small sigmas
                 const unsigned n = n_in;

@@ -41,6 +41,12 @@ MK_DEV float mk_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f
 
 MK_DEV float mk_min(float a, float b) { return __builtin_fminf(a, b); }  // v_min_f32: NaN-ignoring
 MK_DEV float mk_abs(float a) { return __builtin_fabsf(a); }             // |x| source modifier
+// v_min_f32 as the hardware does it, without the canonicalising v_max_f32 x, x, x the compiler puts in front of fminf when it
+// cannot see where an operand comes from (a running minimum carried through a loop): the operands here are never signalling NaNs
+MK_DEV float mk_min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the value stays in its register from here on: the compiler forgets that it is a constant it could build again (it
+// re-materialised the eight +inf of an accumulator set in front of every loop that uses them)
+MK_DEV void mk_keep(float& x) { asm("" : "+v"(x)); }
 MK_DEV float mk_max(float a, float b) { return __builtin_fmaxf(a, b); }  // v_max_f32: NaN-ignoring
 MK_DEV float mk_min3(float m, float a, float b) { return __builtin_fminf(__builtin_fminf(a, b), m); }   // v_min3_f32
 // min of a running bit pattern with a non-negative float (v_min_u32; see k_voxelize_tiles)

@@ -204,6 +204,8 @@ MK_DEV int mk_ctz64(unsigned long long m) { return __builtin_ctzll(m); }
 MK_DEV float mk_rcp(float x) { return 1.0f / x; }
 MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
+MK_DEV float mk_min_raw(float a, float b) { return fminf(a, b); }
+MK_DEV void mk_keep(float&) {}
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 MK_DEV float mk_abs(float a) { return fabsf(a); }
 MK_DEV float mk_max(float a, float b) { return fmaxf(a, b); }
