@@ -1962,7 +1962,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 #pragma unroll
                         for (int k = 0; k < KL; ++k) {
                             const float dx = pl_x(k) - px;
-                            m[k] = mk_min(m[k], mk_fma(dx, dx, r));
+                            m[k] = mk_min_raw(m[k], mk_fma(dx, dx, r));
                         }
                     }
                 };
@@ -2358,7 +2358,7 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const float dx = plane_x<K>(k) - px;
-                        m[k] = mk_min(m[k], mk_fma(dx, dx, r));
+                        m[k] = mk_min_raw(m[k], mk_fma(dx, dx, r));
                     }
                 }
             }
