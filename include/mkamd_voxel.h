@@ -103,7 +103,7 @@ int mkamd_ctx_set_direct_binning(mkamd_ctx* ctx, int mode);
  * (hydrogens, sigma 1.1 A: 3.48 A at eps = 1e-6), and the channel value is a maximum over entries, so dropping an
  * entry wherever it is worth less than eps moves no value by more than eps.  With eps > 0 every atom is culled per
  * TILE at min(5 A, that radius) (rounded up to one of four levels); voxels of a tile the atom still reaches see it at
- * any distance below 5 A as before.  Results stay within eps (+ the float32 noise of the exact mode, <= 3.4e-6) of the
+ * any distance below 5 A as before.  Results stay within eps (+ the float32 noise of the exact mode, <= 3.7e-6 seen) of the
  * reference; they are no longer bit-identical between tilings / kernels.  eps in [0, 1e-5]. */
 int mkamd_ctx_set_value_tolerance(mkamd_ctx* ctx, double eps);
 /* Waves per tile of the lattice kernel: 0 = one (throughput: big batches), 1 = a team that shares the tile's candidate
