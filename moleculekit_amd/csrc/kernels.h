@@ -139,7 +139,10 @@ constexpr float REACH_STEP = 0.17f;   // levels 0..3: reach 5.00 / 4.56 / 4.06 /
 // runs with a value tolerance (a scalar branch around the arithmetic: the exact mode pays a register move at most)
 MK_DEV float reach_r2(const GridDesc& g, float r2, int packed_cell)
 {
-    if (g.reach_tau > 0.f) r2 *= 1.f - REACH_STEP * (float)((unsigned)packed_cell >> 30);
+    if (g.reach_tau > 0.f) {
+        mk_stay_in_branch();             // (left alone the compiler turns this into five instructions and a select, run always)
+        r2 *= 1.f - REACH_STEP * (float)((unsigned)packed_cell >> 30);
+    }
     return r2;
 }
 

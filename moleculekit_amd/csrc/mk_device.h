@@ -44,6 +44,8 @@ MK_DEV float mk_abs(float a) { return __builtin_fabsf(a); }             // |x| s
 // v_min_f32 as the hardware does it, without the canonicalising v_max_f32 x, x, x the compiler puts in front of fminf when it
 // cannot see where an operand comes from (a running minimum carried through a loop): the operands here are never signalling NaNs
 MK_DEV float mk_min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// keeps what follows inside its (wave-uniform) branch: a volatile asm is never speculated, so the branch is not if-converted
+MK_DEV void mk_stay_in_branch() { asm volatile(""); }
 // the value stays in its register from here on: the compiler forgets that it is a constant it could build again (it
 // re-materialised the eight +inf of an accumulator set in front of every loop that uses them)
 MK_DEV void mk_keep(float& x) { asm("" : "+v"(x)); }

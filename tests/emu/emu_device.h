@@ -206,6 +206,7 @@ MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
 MK_DEV float mk_min_raw(float a, float b) { return fminf(a, b); }
 MK_DEV void mk_keep(float&) {}
+MK_DEV void mk_stay_in_branch() {}
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 MK_DEV float mk_abs(float a) { return fabsf(a); }
 MK_DEV float mk_max(float a, float b) { return fmaxf(a, b); }
