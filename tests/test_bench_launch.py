@@ -52,3 +52,26 @@ def test_watchdog_of_the_gather_legs():
     t0 = time.perf_counter()
     bench.guarded(lambda: release.wait(2.0), 0.1, lambda: (fired.append("late"), release.set()))
     assert fired == ["late"] and time.perf_counter() - t0 < 1.5
+
+
+def test_algorithmic_bytes_are_survey_8d():
+    """bench.algorithmic_bytes -- the numerator of `roofline.achieved` -- is SURVEY.md section 8d's figure: per grid V*C*4
+    (one float32 per voxel-channel) + N*(12 + 4*C) (coords and per-channel sigmas read once).  cfg2: 8 388 608 + 2 200 000
+    bytes per grid (2 710.7 MB per 256-grid launch, the number DESIGN.md quotes); cfg3: (442 368 + 2 640) per pose."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    p, _, nv = bench.make_workload("cfg2", 2, seed=7)
+    assert [int(v) for v in nv] == [64, 64, 64] and int(p["atom_offsets"][-1]) == 100_000
+    assert bench.algorithmic_bytes(p, nv) == 2 * (8_388_608 + 2_200_000)
+    assert abs(256 * (8_388_608 + 2_200_000) / 1e6 - 2710.7) < 0.05
+    p, _, nv = bench.make_workload("cfg3", 5, seed=3)
+    assert bench.algorithmic_bytes(p, nv) == 5 * (442_368 + 2_640)
+    # ragged items (cfg5): the atoms are counted, not assumed
+    p, _, nv = bench.make_workload("cfg5", 7, seed=5)
+    n = int(p["atom_offsets"][-1])
+    assert 7 * 20 <= n <= 7 * 50 and bench.algorithmic_bytes(p, nv) == 7 * 24 ** 3 * 8 * 4 + n * 44
+    # the roofline object divides by the kernel time measured between the events
+    r = bench.roofline_of({"k_ms": 4.0, "k_n": 2, "alg": 2 * 10_588_608}, "cfg2", 2, 0)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["achieved"] - 2 * 10_588_608 / 2e-3 / 1e9) < 0.01 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
