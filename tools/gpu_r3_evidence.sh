@@ -11,10 +11,13 @@ R=$GRAFT_REPO_ROOT
 (timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
 rm -rf gpurun_out/prof_* gpurun_out/pmc_*
 PROF="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
+# (the kernel-trace passes run 40 timed steps after 5 warm-up calls: under the profiler the first dozen launches of a process
+#  are 5-10 % slower than the rest -- clocks -- and a 12-launch average says more about that than about the kernel)
+TRACE="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 40 --warmup 5"
 for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py $PROF --workload $wl > $R/gpurun_out/rocprof_$wl.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py $TRACE --workload $wl > $R/gpurun_out/rocprof_$wl.log 2>&1)
 done
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py $PROF --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py $TRACE --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
 pmc() { name=$1; shift; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_$name -- python $R/bench.py $PROF $PMC_EXTRA > $R/gpurun_out/pmc_$name.log 2>&1); }
 pmc sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS
 pmc sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_IFETCH
