@@ -329,6 +329,9 @@ class _StandInContext:
     def set_pipelining(self, on):
         pass
 
+    def promise_inputs(self, event=None):
+        pass
+
 
 def _standin_compute(c, offs, s, o, nvox, vs, bx):
     """Stand-in for the HIP path (dry run only): every voxel-channel of an item = 1 + its atom count + 1e-3 x the sum of
@@ -432,7 +435,9 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     p0 = make_config(name, 1)
     nv = grid_origin(p0["centers"][0], p0["boxsize"], p0["voxelsize"])[1]
     if compute is None:
-        sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx)
+        # (pipelined steps are the package's own behaviour now: ShardedVoxelizer promises its resident shard to every call)
+        sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx,
+                                          pipelined=not getattr(args, "no_pipeline", False))
     else:
         sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, compute=compute)
     p = cache["p"]
@@ -444,7 +449,6 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         """Latency of ONE grid per call (the reference's call pattern; SURVEY.md section 7 H2: a single 64^3 grid cannot fill
         256 CUs for long): device-resident inputs, calls back to back, five runs of 40 calls -> (median, runs) in us."""
         from moleculekit_amd import batch
-        ctx.set_pipelining(False)
         d = sv._d
         o1 = torch.empty((1, V, C), dtype=torch.float32, device=dev)
         n1 = int(p["atom_offsets"][1])
@@ -462,7 +466,6 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
                 batch.voxelize_lattice_torch(*args1, **kw1)
             torch.cuda.synchronize(dev)
             runs.append((time.perf_counter() - s0) / 40 * 1e6)
-        ctx.set_pipelining(not args.no_pipeline)
         return sorted(runs)[2], [round(r, 2) for r in runs]
 
     # the one-molecule-per-call probe comes FIRST, on a quiet GPU as such a caller finds it (the same probe right after the
@@ -658,9 +661,9 @@ def main():
     ctx.set_force_general(os.environ.get("MKAMD_FORCE_GENERAL", "0") == "1")
     ctx.set_fine_cells(os.environ.get("MKAMD_FINE_CELLS", "0") == "1")         # A-B knob: half-cutoff cells
     ctx.set_tile_items(int(os.environ.get("MKAMD_TILE_ITEMS", "-1")))          # A-B knob: a workgroup per item (ligand-sized batches)
-    # steps are independent batches whose inputs are resident before the loop: the library may overlap the
-    # pre-pass of step n+1 with the tile kernel of step n (a data loader would double-buffer the same way)
-    ctx.set_pipelining(not args.no_pipeline)
+    # steps are independent batches whose inputs are resident before the loop: ShardedVoxelizer promises them to the
+    # library per call, which then overlaps the pre-pass of step n+1 with the tile kernel of step n -- the package's
+    # own product path (run_workload), not a knob of this file
     ctx.set_value_tolerance(args.value_tol)
     ctx.set_direct_binning(int(os.environ.get("MKAMD_DIRECT", "-1")))          # A-B knob: one-pass direct binning (-1 auto, 0 off, 1 on)
 

@@ -125,6 +125,20 @@ int mkamd_ctx_set_tile_items(mkamd_ctx* ctx, int mode);
  * stream AFTER the previous voxelize call (the pre-pass is only ordered after everything before that call's
  * tile kernel) and must stay untouched until the call's features have been consumed. */
 int mkamd_ctx_set_pipelining(mkamd_ctx* ctx, int on);
+/* The same pipelining for ONE call, by promise (what the package's own streaming drivers use -- batch.iterVoxelize*,
+ * distributed.ShardedVoxelizer -- so the context-wide knob above is not needed to get it): a one-shot statement about
+ * the NEXT mkamd_voxelize_lattice(_aug)_dev call on this context.  Its inputs (coords, offsets, sigmas, origins, box,
+ * affine) are complete once `hip_event` (a hipEvent_t recorded on ANY stream of this device) has completed -- NULL: they
+ * are complete already and were not produced by work enqueued on the context's stream after the previous voxelize
+ * call, e.g. a resident shard -- and they stay untouched until the call's features have been consumed.  The call's
+ * pre-pass waits for the event on whichever stream runs it and may then run beside the previous call's tile kernel.
+ * The promise is consumed by that call, pipelined or not (a small call runs in order and still waits for the event). */
+int mkamd_ctx_promise_inputs(mkamd_ctx* ctx, void* hip_event);
+/* Drop a promise that no call has consumed (a driver that stops between the promise and its call). */
+int mkamd_ctx_withdraw_promise(mkamd_ctx* ctx);
+/* How many lattice calls of this context have run their pre-pass beside a previous call's tile kernel so far (tests
+ * and benchmarks check with it that a driver really is pipelined). */
+int mkamd_ctx_pipelined_calls(mkamd_ctx* ctx, int64_t* n);
 /* Per-kernel timing of the tile kernel with HIP events on the context's stream (bench.py's
  * roofline leg): enable, run, then read back the accumulated time and launch count (resets). */
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable);

@@ -38,6 +38,9 @@ SIGNATURES = {
     "mkamd_ctx_set_lds_tier": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_prepass_mode": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_pipelining": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_promise_inputs": (_c_int, [_vp, _vp]),
+    "mkamd_ctx_withdraw_promise": (_c_int, [_vp]),
+    "mkamd_ctx_pipelined_calls": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
@@ -216,6 +219,24 @@ class Context:
     def set_pipelining(self, on: bool):
         """Overlap the pre-pass of a call with the tile kernel of the previous one (see the header for the contract)."""
         _check(load().mkamd_ctx_set_pipelining(self._h, int(bool(on))))
+
+    def promise_inputs(self, event=None):
+        """One-shot promise about the NEXT ``voxelize_lattice_dev`` call (include/mkamd_voxel.h): its inputs are complete
+        once ``event`` (a ``torch.cuda.Event`` that has been recorded, a raw ``hipEvent_t``, or None = complete already and
+        not produced on this context's stream since the previous call) has completed, and stay untouched until the
+        features have been consumed -- the call may then run its pre-pass beside the previous call's tile kernel."""
+        h = None if event is None else int(getattr(event, "cuda_event", event))
+        _check(load().mkamd_ctx_promise_inputs(self._h, h))
+
+    def withdraw_promise(self):
+        """Drop a promise no call has consumed."""
+        _check(load().mkamd_ctx_withdraw_promise(self._h))
+
+    def pipelined_calls(self) -> int:
+        """Lattice calls of this context whose pre-pass ran beside a previous call's tile kernel so far."""
+        n = _c_i64(0)
+        _check(load().mkamd_ctx_pipelined_calls(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def enable_kernel_timing(self, on=True):
         _check(load().mkamd_ctx_enable_kernel_timing(self._h, int(bool(on))))

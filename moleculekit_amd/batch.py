@@ -329,10 +329,16 @@ def _pinned_give(key, t):
 
 
 def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first, ctx,
-                     max_images):
-    """Core of the streamed voxelizers: ``fill(coords_np [N,3,n], box_np [3,n] | None, idx)`` produces chunk ``idx``
-    (frame indices) straight into pinned staging; a copy stream uploads chunk k+1 while the current stream
-    voxelizes chunk k; ``scale`` converts the coordinates to Angstrom on the device (XTC stores nm).
+                     max_images, fill_dev=None, pipelined=True):
+    """Core of the streamed voxelizers.  Host sources: ``fill(coords_np [N,3,n], box_np [3,n] | None, idx)`` produces chunk
+    ``idx`` (frame indices) straight into pinned staging; device sources: ``fill_dev(xyz [n,N,3], box [n,3] | None, idx)``
+    writes the chunk's frame-major device tensors itself.  Everything a chunk needs on the device -- the upload, the
+    transpose to frame-major, the nm -> Angstrom ``scale`` (XTC stores nm), the box transpose -- is enqueued on a COPY
+    stream into one of two slot-owned input buffers and ends in an event; the voxelize call of chunk k is handed that
+    event as a promise (``Context.promise_inputs``, include/mkamd_voxel.h), so the library runs chunk k's binning pre-pass
+    beside chunk k-1's tile kernel and nothing the consumer enqueues on its own stream between two chunks can sit in
+    front of the inputs.  ``pipelined=False``: the same buffers, the compute stream waits for the event itself and the
+    calls run in order (the cross-check of tests/test_gpu_api.py; bit-identical).
 
     Periodic boxes are checked per chunk on the host, where they are already at hand (``_chunk_images``: every edge
     > 10 A, images per atom recomputed from THIS chunk's boxes -- an NPT trajectory may shrink after its first frame);
@@ -361,31 +367,51 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
     origin = np.asarray(center, dtype=np.float64) - boxsize / 2
     main = torch.cuda.current_stream(dev)
     copy = torch.cuda.Stream(device=dev)
+    host_source = fill_dev is None
     with torch.cuda.device(dev):
         d_sig = torch.as_tensor(sig, device=dev).repeat(chunk, 1).contiguous()            # [chunk*N, C], shared by the frames
         d_offs = torch.arange(chunk + 1, dtype=torch.int64, device=dev) * N
         d_org = torch.as_tensor(np.broadcast_to(origin, (chunk, 3)).copy(), device=dev)
-        stage = [_pinned_take(("traj", i), (N * 3 * chunk,)) for i in range(2)]
-        stage_box = [_pinned_take(("trajbox", i), (3 * chunk,)) for i in range(2)]
-        free = [torch.cuda.Event(), torch.cuda.Event()]          # staging buffer i may be overwritten
-        ready = [torch.cuda.Event(), torch.cuda.Event()]         # device copy of chunk in slot i has landed
-        dslab = [None, None]
-        dbox = [None, None]
+        # two slots, each owning its pinned staging (host sources), its device slab and its frame-major inputs
+        stage = [_pinned_take(("traj", i), (N * 3 * chunk,)) for i in range(2)] if host_source else None
+        stage_box = [_pinned_take(("trajbox", i), (3 * chunk,)) for i in range(2)] if host_source else None
+        d_slab = [torch.empty(N * 3 * chunk, dtype=torch.float32, device=dev) for _ in range(2)] if host_source else None
+        d_slab_box = [torch.empty(3 * chunk, dtype=torch.float32, device=dev) for _ in range(2)] if host_source and has_box else None
+        d_xyz = [torch.empty((chunk * N, 3), dtype=torch.float32, device=dev) for _ in range(2)]
+        d_bx = [torch.empty((chunk, 3), dtype=torch.float32, device=dev) for _ in range(2)] if has_box else [None, None]
+        main.synchronize()                                        # the constants above (and a device-resident source, as far as
+                                                                  # this stream produced it) are complete before any promise is made
+        free = [torch.cuda.Event(), torch.cuda.Event()]          # staging buffer i may be overwritten (its H2D is done)
+        ready = [torch.cuda.Event(), torch.cuda.Event()]         # the inputs of the chunk in slot i are complete
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]      # the call that read slot i's inputs is done (compute stream)
         images = [max_images, max_images]
         run_ctx = ctx or _lib.default_context(dev.index)
 
         def upload(k, slot):
             idx = fr[k * chunk:(k + 1) * chunk]
             n = len(idx)
-            free[slot].synchronize()                              # the previous H2D out of this buffer is done
-            hc = stage[slot][:N * 3 * n].view(N, 3, n)            # tight [N,3,n]: one contiguous H2D
-            hb = stage_box[slot][:3 * n].view(3, n) if has_box else None
-            fill(hc.numpy(), hb.numpy() if has_box else None, idx)
-            images[slot] = max(max_images, _chunk_images(hb.numpy(), nvoxels, voxelsize)) if has_box else 1
+            xyz = d_xyz[slot][:n * N].view(n, N, 3)
+            if host_source:
+                free[slot].synchronize()                          # the previous H2D out of this buffer is done
+                hc = stage[slot][:N * 3 * n].view(N, 3, n)        # tight [N,3,n]: one contiguous H2D
+                hb = stage_box[slot][:3 * n].view(3, n) if has_box else None
+                fill(hc.numpy(), hb.numpy() if has_box else None, idx)
+                images[slot] = max(max_images, _chunk_images(hb.numpy(), nvoxels, voxelsize)) if has_box else 1
             with torch.cuda.stream(copy):
-                dslab[slot] = hc.to(dev, non_blocking=True)
-                dbox[slot] = hb.to(dev, non_blocking=True) if has_box else None
-                free[slot].record(copy)
+                copy.wait_event(consumed[slot])                   # (never recorded yet for the first two chunks: no wait)
+                if host_source:
+                    slab = d_slab[slot][:N * 3 * n]
+                    slab.copy_(hc.reshape(-1), non_blocking=True)
+                    if has_box:
+                        d_slab_box[slot][:3 * n].copy_(hb.reshape(-1), non_blocking=True)
+                    free[slot].record(copy)
+                    xyz.copy_(slab.view(N, 3, n).permute(2, 0, 1))                        # frame-major, on the device
+                    if has_box:
+                        d_bx[slot][:n].copy_(d_slab_box[slot][:3 * n].view(3, n).t())
+                else:
+                    images[slot] = fill_dev(xyz, d_bx[slot][:n] if has_box else None, idx) or max_images
+                if scale != 1.0:
+                    xyz.mul_(scale)
                 ready[slot].record(copy)
             return idx
 
@@ -398,51 +424,57 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
                 if k + 1 < nchunks:
                     pending = upload(k + 1, slot ^ 1)
                 n = len(idx)
-                main.wait_event(ready[slot])
-                slab, bx = dslab[slot], dbox[slot]
-                slab.record_stream(main)
-                xyz = slab.permute(2, 0, 1).contiguous().view(n * N, 3)                   # frame-major, on the device
-                if scale != 1.0:
-                    xyz.mul_(scale)
-                d_b = None
-                if bx is not None:
-                    bx.record_stream(main)
-                    d_b = bx.t().contiguous()
-                feats = voxelize_lattice_torch(xyz, d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize, box=d_b,
-                                               max_images=images[slot], ctx=run_ctx, channel_first=channel_first)
+                if pipelined:
+                    run_ctx.promise_inputs(ready[slot])           # the library waits for it where the pre-pass runs
+                else:
+                    main.wait_event(ready[slot])
+                feats = voxelize_lattice_torch(d_xyz[slot][:n * N], d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize,
+                                               box=d_bx[slot][:n] if has_box else None, max_images=images[slot], ctx=run_ctx,
+                                               channel_first=channel_first)
+                consumed[slot].record(torch.cuda.current_stream(dev))
                 run_ctx.poll_errors()                             # non-blocking: errors of the chunks already finished
                 yield idx, feats
             run_ctx.synchronize()                                 # the last chunks' asynchronous errors, if any
         finally:                                                  # also when the consumer stops early
             copy.synchronize()                                    # no H2D still reading the staging buffers
-            for i in range(2):
-                _pinned_give(("traj", i), stage[i])
-                _pinned_give(("trajbox", i), stage_box[i])
+            run_ctx.withdraw_promise()                            # (a consumer that stopped between a promise and its call)
+            if host_source:
+                for i in range(2):
+                    _pinned_give(("traj", i), stage[i])
+                    _pinned_give(("trajbox", i), stage_box[i])
 
 
 def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=None, frames=None, chunk=512,
-                           device=None, channel_first=False, ctx=None):
-    """Stream a host-resident trajectory through the GPU chunk by chunk ("trajectory
-    feeding"): yields ``(frame_indices, features)`` with ``features`` a float32 CUDA tensor ``[n, V, C]`` (or
-    ``[n, C, nx, ny, nz]`` with ``channel_first``) for ``n <= chunk`` frames at a time.
+                           device=None, channel_first=False, ctx=None, pipelined=True):
+    """Stream a trajectory through the GPU chunk by chunk ("trajectory feeding"): yields
+    ``(frame_indices, features)`` with ``features`` a float32 CUDA tensor ``[n, V, C]`` (or ``[n, C, nx, ny, nz]`` with
+    ``channel_first``) for ``n <= chunk`` frames at a time.
 
-    ``coords`` is ``Molecule.coords`` (float32 ``[N, 3, F]``, frame fastest), ``box`` ``Molecule.box`` (``[3, F]``)
-    or None.  Per chunk the host only copies the ``[N, 3, n]`` slab into one of two pinned staging buffers (a few
-    host threads; runs of ``n`` contiguous floats); the transpose to frame-major happens on the device.  A copy
-    stream uploads chunk k+1 while the current stream voxelizes chunk k, so the consumer (a model, a reduction) sees
-    a steady feed whose rate is the slower of PCIe and the voxelizer.  The tensors are yours to keep: each chunk
-    gets fresh memory.
+    ``coords`` is ``Molecule.coords`` (float32 ``[N, 3, F]``, frame fastest) on the host -- or the same array as a CUDA
+    tensor when the trajectory already lives in HBM (a simulation engine's output, a previous stage) --, ``box``
+    ``Molecule.box`` (``[3, F]``) or None.  Host source: per chunk the host only copies the ``[N, 3, n]`` slab into one of
+    two pinned staging buffers (a few host threads; runs of ``n`` contiguous floats); the transpose to frame-major happens
+    on the device.  A copy stream prepares chunk k+1 while chunk k is voxelized, and the library overlaps chunk k+1's
+    binning pre-pass with chunk k's tile kernel (``_stream_voxelize``), so the consumer (a model, a reduction) sees a
+    steady feed whose rate is the slower of PCIe and the voxelizer.  The tensors are yours to keep: each chunk gets
+    fresh memory.
     """
-    coords = np.asarray(coords)
-    if coords.dtype != np.float32:
-        coords = coords.astype(np.float32)
+    on_device = hasattr(coords, "is_cuda") and bool(coords.is_cuda)
+    if not on_device:
+        coords = np.asarray(coords)
+        if coords.dtype != np.float32:
+            coords = coords.astype(np.float32)
     if coords.ndim != 3 or coords.shape[1] != 3:
         raise ValueError("coords must be (natoms, 3, nframes)")
-    N = coords.shape[0]
+    N = int(coords.shape[0])
     fr = np.arange(coords.shape[2]) if frames is None else np.asarray(frames, dtype=np.int64)
     contiguous = frames is None or (len(fr) > 0 and np.array_equal(fr, np.arange(fr[0], fr[0] + len(fr))))
     max_images = 1
+    box_t = None
     if box is not None:
+        if hasattr(box, "is_cuda"):
+            box_t = box if box.is_cuda else None
+            box = box.detach().cpu().numpy()
         box = np.asarray(box, dtype=np.float32)
         nvoxels = np.ceil(np.array(boxsize, dtype=np.float64) / voxelsize).astype(int)
         max_images = max_images_per_atom(np.ascontiguousarray(box[:, fr].T), nvoxels, voxelsize)
@@ -461,12 +493,36 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
             if dst_box is not None:
                 np.copyto(dst_box, box[:, idx])
 
+    fill_dev = None
+    if on_device:
+        import torch
+        if coords.dtype != torch.float32:
+            raise ValueError("a device-resident trajectory must be float32")
+        if device is None:
+            device = coords.device
+        if box is not None and box_t is None:
+            box_t = torch.as_tensor(box, device=coords.device)
+
+        def fill_dev(xyz, bx, idx):                               # on the copy stream of _stream_voxelize
+            n = len(idx)
+            if contiguous:
+                f0 = int(idx[0])
+                xyz.copy_(coords[:, :, f0:f0 + n].permute(2, 0, 1))
+                if bx is not None:
+                    bx.copy_(box_t[:, f0:f0 + n].t())
+            else:
+                sel = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=coords.device)
+                xyz.copy_(coords.index_select(2, sel).permute(2, 0, 1))
+                if bx is not None:
+                    bx.copy_(box_t.index_select(1, sel).t())
+            return _chunk_images(box[:, idx], nvoxels, voxelsize) if box is not None else 1
+
     yield from _stream_voxelize(N, fr, fill, 1.0, box is not None, channels, center, boxsize, voxelsize, chunk, device,
-                                channel_first, ctx, max_images)
+                                channel_first, ctx, max_images, fill_dev=fill_dev, pipelined=pipelined)
 
 
 def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, frames=None, chunk=1024, device=None,
-                    channel_first=False, ctx=None, nthreads=0):
+                    channel_first=False, ctx=None, nthreads=0, pipelined=True):
     """``iterVoxelizeTrajectory`` fed straight from an XTC file: chunk k+1 is decoded by host threads (libmkamd.so's
     decoder, ``moleculekit_amd.xtc``) directly into pinned staging and uploaded while chunk k is voxelized.
     ``pbc``: use the frames' box (orthorhombic lengths of the box vectors) for the minimum image.  Coordinates are
@@ -502,4 +558,4 @@ def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, 
             np.copyto(dst_box, np.sqrt(np.sum(bv * bv, axis=1)))
 
     yield from _stream_voxelize(natoms, fr, fill, 10.0, bool(pbc), channels, center, boxsize, voxelsize, chunk, device,
-                                channel_first, ctx, max_images)
+                                channel_first, ctx, max_images, pipelined=pipelined)

@@ -64,6 +64,9 @@ struct mkamd_ctx {
     int next_set = 0;
     bool in_pipelined_prepass = false;
     bool pipelining = false;               // opt-in (mkamd_ctx_set_pipelining)
+    bool promise = false;                  // one-shot: the NEXT lattice call's inputs are promised (mkamd_ctx_promise_inputs)
+    hipEvent_t promise_event = nullptr;    // ... complete once this event has completed (nullptr: complete already)
+    long long n_pipelined = 0;             // lattice calls whose pre-pass went to the side stream (mkamd_ctx_pipelined_calls)
     bool have_pre_tile_event = false;
     void* bufs[2 * WS_NSLOTS] = {};        // two workspace sets (set 1 only used by pipelined calls)
     CounterState counters[2];              // what is known about each set's cell counters between calls
@@ -164,9 +167,16 @@ struct mkamd_ctx {
     int acquire_set(bool big_enough)
     {
         in_pipelined_prepass = false;
-        if (!big_enough || !pipelining || !side_stream || pipeline_broken) {
+        // a promised call (mkamd_ctx_promise_inputs) waits for the event its inputs come with, on whichever stream runs its
+        // pre-pass; should that wait fail, the streams have been drained and the event is awaited on the host
+        auto await_promise = [&](hipStream_t s) {
+            if (!promise_event) return;
+            if (!sync_ok(hipStreamWaitEvent(s, promise_event, 0))) (void)hipEventSynchronize(promise_event);
+        };
+        if (!big_enough || !(pipelining || promise) || !side_stream || pipeline_broken) {
             // in-order call on the caller's stream, set 0 (any earlier pipelined call has already made the
             // main stream wait for its pre-pass; its tile kernel is ahead of us on the same stream)
+            await_promise(main_stream);
             have_pre_tile_event = false;
             return 0;
         }
@@ -174,18 +184,20 @@ struct mkamd_ctx {
         // Inputs must not depend on work enqueued after the PREVIOUS call's tile kernel (the opt-in contract of
         // mkamd_ctx_set_pipelining): the side stream is ordered after everything before that launch only.
         if (!have_pre_tile_event) {
-            if (!sync_ok(hipEventRecord(ev_inputs, main_stream))) return 0;
+            if (!sync_ok(hipEventRecord(ev_inputs, main_stream))) { await_promise(main_stream); return 0; }
             inputs_marker = ev_inputs;
         }
-        if (!sync_ok(hipStreamWaitEvent(side_stream, inputs_marker, 0))) return 0;
-        if (tile_pending[set] && !sync_ok(hipStreamWaitEvent(side_stream, tile_marker[set], 0))) return 0;
+        if (!sync_ok(hipStreamWaitEvent(side_stream, inputs_marker, 0))) { await_promise(main_stream); return 0; }
+        if (tile_pending[set] && !sync_ok(hipStreamWaitEvent(side_stream, tile_marker[set], 0))) { await_promise(main_stream); return 0; }
+        if (promise_event && !sync_ok(hipStreamWaitEvent(side_stream, promise_event, 0))) { (void)hipEventSynchronize(promise_event); return 0; }
         next_set ^= 1;
         stream = side_stream;
         in_pipelined_prepass = true;
+        ++n_pipelined;
         return set;
     }
     bool set_is_pipelined(int) const { return in_pipelined_prepass; }
-    bool pipelining_possible() const { return pipelining && side_stream && !pipeline_broken; }
+    bool pipelining_possible() const { return (pipelining || promise) && side_stream && !pipeline_broken; }
     void prepass_done(int set)
     {
         if (!in_pipelined_prepass) return;
@@ -366,6 +378,7 @@ try {
     HIP_TRY(hipStreamSynchronize(ctx->main_stream)); // workspace is shared between the streams
     if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     ctx->tile_pending[0] = ctx->tile_pending[1] = false;
+    ctx->have_pre_tile_event = false;         // the next pipelined pre-pass takes its marker from the NEW stream
     ctx->stream = ctx->main_stream = next;
     return MKAMD_OK;
 } MK_API_CATCH
@@ -488,6 +501,29 @@ try {
     ctx->pipelining = on != 0;
     ctx->pipeline_broken = false;             // both streams are drained: a fresh start
     ctx->have_pre_tile_event = false;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_promise_inputs(mkamd_ctx* ctx, void* hip_event)
+try {
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    ctx->promise = true;
+    ctx->promise_event = (hipEvent_t)hip_event;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_pipelined_calls(mkamd_ctx* ctx, int64_t* n)
+try {
+    if (!ctx || !n) return fail(MKAMD_EINVAL, "ctx / n is NULL");
+    *n = (int64_t)ctx->n_pipelined;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_withdraw_promise(mkamd_ctx* ctx)
+try {
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    ctx->promise = false;
+    ctx->promise_event = nullptr;
     return MKAMD_OK;
 } MK_API_CATCH
 
@@ -652,6 +688,7 @@ try {
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;
     st = run_lattice(*ctx, P, err);
+    ctx->promise = false; ctx->promise_event = nullptr;       // one call's worth
     if (st && !err.empty()) return fail(st, err);
     return st;
 } MK_API_CATCH

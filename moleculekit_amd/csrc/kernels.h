@@ -1726,6 +1726,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     for (int c = 0; c < CHG; ++c)
 #pragma unroll
         for (int k = 0; k < KL; ++k) q[c][k] = INF_BITS;
+    bool q_final = false;                                  // (MK_ROLLED_CHANNELS >= 2 only: q already holds the occupancies; wave-uniform)
 
     // "more sigma classes than the table holds": for a call-wide table (one hot line) this is checked up front; a
     // per-item table is a fresh line per item, so the check waits until the first traversal has hidden the load
@@ -1903,6 +1904,30 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
                 const uint4 bg = make_uint4(mk_uniform(bgp[0]), mk_uniform(bgp[1]), mk_uniform(bgp[2]), mk_uniform(bgp[3]));
                 const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
+#ifdef MK_DIRECT_SINGLE       // round-4 experiment (docs/EXPERIMENTS_r4.md), OFF: ~200 VALU instructions fewer per cfg2 tile, tile kernel +3.4 % SLOWER
+                // (+13 % code in the eight unrolled copies of this loop).
+                // A group of ONE entry (cfg2: 4.9 of a tile's 27 groups; most groups of a ligand's tile) needs no accumulator set:
+                // its d^2 goes straight through the flush arithmetic into the channel minimum -- min(+inf, g) == g, so the bits are
+                // the loop's; what is saved is the eight +inf moves, the raw minima and the planes its sub-bucket does not reach
+                // (two slots in all = one sub-bucket of one or two entries; the odd flag of the only non-empty one says which)
+                if (TEAM == 1 && (MK_DIAG & 3) == 0 && wcls <= fast_w_max<K>() && (bg.w & ~1u) - (bg.x & ~1u) == 2u && ((bg.x | bg.y | bg.z) & 1u)) {
+                    const float* t = sxyz + (bg.x & ~1u);
+                    const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
+                    const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
+                    auto direct = [&](auto k0_, auto k1_) {
+                        constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
+#pragma unroll
+                        for (int k = K0; k < K1; ++k) {
+                            const float d2 = plane_d2<K>(k, mk_fma(pl_slope(k), ex, d0));
+                            acc[k] = mk_min_bits(acc[k], d2 < R2 ? mk_abs(d2) * wcls : INF);
+                        }
+                    };
+                    if ((bg.y & ~1u) != (bg.x & ~1u)) direct(IntC<0>{}, IntC<K>{});                  // wave-uniform
+                    else if ((bg.z & ~1u) != (bg.y & ~1u)) direct(IntC<0>{}, IntC<K / 2>{});
+                    else direct(IntC<K / 2>{}, IntC<K>{});
+                    continue;
+                }
+#endif
                 // m[k] = min over the class's entries of g_k = d^2 - c_k^2 (c_k = x of plane k relative to the tile centre):
                 // with D0 = ex^2 + dy^2 + dz^2 per (lane, entry), g_k = D0 - 2 c_k ex is ONE fma per (voxel, entry); the
                 // plane constant c_k^2 is added to the class minimum at the flush (rounding is monotone: the same bits as
@@ -1917,7 +1942,11 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     if (MK_DIAG & 1) return;
                     constexpr int J0 = K0, J1 = K1;
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
-                    const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
+                    unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
+#ifdef MK_DIAG_TRIPCUT        // TIMING-ONLY build (tools/gpu_r4_tile_ab.sh; wrong values): the pair trips of the big groups (>= 28 slots) scaled
+                              // by MK_DIAG_TRIPCUT / 64 -- the upper bound of what sub-wave candidate lists could save (docs/EXPERIMENTS_r4.md)
+                    if ((bg.w & ~1u) - (bg.x & ~1u) >= 28u) npairs = (npairs * (unsigned)(MK_DIAG_TRIPCUT) + 63u) >> 6;
+#endif
                     unsigned lo = s0, hi = s0 + 2u * npairs;              // the pairs of the sub-bucket, clamped to this wave's range
                     if (TEAM > 1) { lo = lo > my_b ? lo : my_b; hi = hi < my_e ? hi : my_e; }
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
@@ -2047,9 +2076,44 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             MK_PHASE_MARK(2);                               // counts -> starts
             if (!(MK_DIAG & 8)) place(0, CHG, 0u, total);
             MK_PHASE_MARK(3);                               // traversal 2 (placement)
+#ifdef MK_ROLLED_CHANNELS      // round-4 experiment: ONE copy of the class code (pair loops, tails, flush) instead of eight -- the channel is a run-time
+                              // number, a finished channel's minima are moved into their registers behind a scalar branch
+            if (!(MK_DIAG & 8)) {
+#if MK_ROLLED_CHANNELS >= 2
+                if (TEAM == 1 && !(MK_DIAG & 4)) {
+                    q_final = true;                                            // channels without entries: occupancy 0
+#pragma unroll
+                    for (int c = 0; c < CHG; ++c)
+#pragma unroll
+                        for (int k = 0; k < KL; ++k) q[c][k] = 0u;
+                }
+#endif
+#pragma clang loop unroll(disable)
+                for (int c = 0; c < CHG; ++c) {
+                    const unsigned bits = class_bits(c);
+                    if (bits == 0u) continue;                                  // wave-uniform: the channel's minima stay +inf
+                    unsigned acc[KL];
+#pragma unroll
+                    for (int k = 0; k < KL; ++k) acc[k] = INF_BITS;
+                    process_classes(c, bits, acc);
+#if MK_ROLLED_CHANNELS >= 2     // ... and the channel's occupancies computed here, by the loop's one copy of the epilogue arithmetic
+                    if (TEAM == 1 && !(MK_DIAG & 4)) {
+#pragma unroll
+                        for (int k = 0; k < KL; ++k) acc[k] = mk_float_bits(occupancy_from_q(mk_uint_as_float(acc[k])));
+                    }
+#endif
+                    switch (c) {
+#define MK_CH_CASE(CC) case CC: { _Pragma("unroll") for (int k = 0; k < KL; ++k) { q[CC][k] = acc[k]; asm volatile("" : "+v"(q[CC][k])); } } break;
+                        MK_CH_CASE(0) MK_CH_CASE(1) MK_CH_CASE(2) MK_CH_CASE(3) MK_CH_CASE(4) MK_CH_CASE(5) MK_CH_CASE(6) MK_CH_CASE(7)
+#undef MK_CH_CASE
+                    }
+                }
+            }
+#else
             if (!(MK_DIAG & 8))
 #pragma unroll
             for (int c = 0; c < CHG; ++c) process_classes(c, class_bits(c), q[c]);
+#endif
             MK_PHASE_MARK(4);                               // pair loops + class flushes
         } else {
             // ---- dense tile: consecutive channels whose padded entries fit the LDS arrays together are
@@ -2169,8 +2233,13 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     for (int k = 0; k < KE; ++k) {
         const int x = tg.x0 + kb + k;
         float f[CHG];
+        if (q_final) {                                      // wave-uniform
 #pragma unroll
-        for (int c = 0; c < CE; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
+            for (int c = 0; c < CE; ++c) { f[c] = mk_uint_as_float(q[c][k]); mk_keep(f[c]); }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CE; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
+        }
         if (yz_in && x < g.nx) {
             const size_t vox = vox0 + (size_t)k * plane_vox;
             if constexpr (CSPLIT > 1) {                      // a big team: this wave stores CE channels of the voxel (16 or 8 bytes)

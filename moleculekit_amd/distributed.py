@@ -124,9 +124,15 @@ class ShardedVoxelizer:
     sharding / staging / gather logic under ``gloo`` -- the product never does.
     """
 
-    def __init__(self, n_items, bounds, shard, nvoxels, voxelsize, device=None, compute=None, group=None, ctx=None):
+    def __init__(self, n_items, bounds, shard, nvoxels, voxelsize, device=None, compute=None, group=None, ctx=None,
+                 pipelined=True):
         import torch
 
+        # The shard's buffers belong to this object and never change after the upload below has completed: every voxelize
+        # call over them is made with the library's per-call promise (Context.promise_inputs, include/mkamd_voxel.h), so
+        # the binning pre-pass of one call runs beside the tile kernel of the previous one -- back-to-back `voxelize()`
+        # calls and the chunks of `voxelize_gather` alike.  `pipelined = False` runs the calls in order (bit-identical).
+        self.pipelined = bool(pipelined)
         self.group = group
         self.rank, self.world = world(group)
         self.n_items = int(n_items)
@@ -222,10 +228,13 @@ class ShardedVoxelizer:
                 out.copy_(res)
                 return out
             return res
-        from . import batch
+        from . import _lib, batch
 
+        ctx = self._ctx or _lib.default_context(self.device.index if self.device.index is not None else 0)
+        if self.pipelined:
+            ctx.promise_inputs(None)          # resident since _upload's host-side wait: complete, and nobody writes them
         return batch.voxelize_lattice_torch(coords, offs, sigmas, origins, self.nvoxels, self.voxelsize, box=box,
-                                            max_images=self.max_images, out=out, ctx=self._ctx)
+                                            max_images=self.max_images, out=out, ctx=ctx)
 
     def _items(self, lo, hi):
         """Views of the resident shard for local items [lo, hi) (the rebased offsets are built once per range)."""

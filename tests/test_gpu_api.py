@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from tests.cases import TOL, golden
+from tests.synth import grid_origin, synth_config
 from tests.test_host_logic import Mol
 
 pytestmark = pytest.mark.gpu
@@ -321,3 +322,79 @@ def test_usercenters_guess_is_checked(hip_ctx):
     for k, c in (("a", a), ("a", a), ("a+", a + 0.25), ("b", b), ("b", b), ("jit", jit), ("jit", jit), ("a", a), ("a", a)):
         got = getVoxelDescriptors(None, usercenters=c, usercoords=coords, userchannels=chans)[0]
         assert np.array_equal(got, ref[k]), k
+
+
+@pytest.mark.gpu
+def test_promised_calls_and_the_streaming_drivers_are_pipelined_and_bitwise_equal(hip_ctx):
+    """Round 4: pipelining is a PRODUCT path.  (1) the per-call promise (mkamd_ctx_promise_inputs), with the inputs complete
+    already and with inputs produced on ANOTHER stream that come with an event; (2) ShardedVoxelizer.voxelize promises its
+    resident shard; (3) iterVoxelizeTrajectory prepares chunk k+1 on its copy stream and hands the library the event --
+    host source and device-resident source.  Every one of them bitwise equal to the in-order run, and the context's
+    counter says the pre-passes really went to the side stream."""
+    import torch
+    from moleculekit_amd import batch
+    from moleculekit_amd.distributed import ShardedVoxelizer
+    dev = torch.device("cuda", hip_ctx.device)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    hip_ctx.set_pipelining(False)
+    # (1) the raw promise
+    p = synth_config(2, 5, seed=71)
+    o = np.stack([grid_origin(c, p["boxsize"], p["voxelsize"])[0] for c in p["centers"]])
+    nv = grid_origin(p["centers"][0], p["boxsize"], p["voxelsize"])[1]
+    w = (t(p["coords"], np.float32), t(p["atom_offsets"], np.int64), t(p["sigmas"], np.float32), t(o, np.float64), nv, p["voxelsize"])
+    ref = [batch.voxelize_lattice_torch(*w, ctx=hip_ctx).cpu().numpy() for _ in range(2)]
+    n0 = hip_ctx.pipelined_calls()
+    outs = []
+    for _ in range(4):
+        hip_ctx.promise_inputs(None)
+        outs.append(batch.voxelize_lattice_torch(*w, ctx=hip_ctx))
+    torch.cuda.synchronize(); hip_ctx.synchronize()
+    assert hip_ctx.pipelined_calls() - n0 == 4
+    assert all(np.array_equal(x.cpu().numpy(), ref[0]) for x in outs)
+    # inputs produced on another stream: a scaled copy made there, the event handed over, nothing awaited by the caller
+    side = torch.cuda.Stream(device=dev)
+    outs = []
+    for i in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(20):                                   # (something in front of it, so that the copy really is late)
+                junk = w[0] * 1.0001
+            c2 = (w[0] * 0.5).mul_(2.0)                           # == w[0] bit for bit
+            ev = torch.cuda.Event(); ev.record(side)
+        hip_ctx.promise_inputs(ev)
+        outs.append((batch.voxelize_lattice_torch(c2, *w[1:], ctx=hip_ctx), c2, junk))
+    torch.cuda.synchronize(); hip_ctx.synchronize()
+    assert all(np.array_equal(x[0].cpu().numpy(), ref[0]) for x in outs)
+    hip_ctx.promise_inputs(None); hip_ctx.withdraw_promise()      # a withdrawn promise pipelines nothing
+    n1 = hip_ctx.pipelined_calls()
+    assert np.array_equal(batch.voxelize_lattice_torch(*w, ctx=hip_ctx).cpu().numpy(), ref[0]) and hip_ctx.pipelined_calls() == n1
+    # (2) the sharded voxelizer over its resident shard
+    got = {}
+    for piped in (False, True):
+        sv = ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], p["sigmas"].astype(np.float32), o, nv, p["voxelsize"], device=dev, ctx=hip_ctx,
+                                        pipelined=piped)
+        n1 = hip_ctx.pipelined_calls()
+        outs = [sv.voxelize() for _ in range(3)]
+        torch.cuda.synchronize(); hip_ctx.synchronize()
+        assert (hip_ctx.pipelined_calls() - n1 == 3) == piped
+        got[piped] = [x.cpu().numpy() for x in outs]
+    assert all(np.array_equal(a, ref[0]) for a in got[False] + got[True])
+    # (3) the streamed trajectory: 12 frames of 30 000 atoms in chunks of 8 (240 000 atoms per call: a big call)
+    q = synth_config(4, 12, seed=72)
+    N = 30000
+    xyz = np.ascontiguousarray(q["coords"].reshape(12, N, 3).transpose(1, 2, 0))      # [N, 3, F]
+    sig = q["sigmas"][:N]
+    box = np.ascontiguousarray(q["box"].T)                                             # [3, F]
+    center = q["centers"][0]
+    res = {}
+    for name, src, bx in (("host", xyz, box), ("device", t(xyz, np.float32), box)):
+        for piped in (False, True):
+            n1 = hip_ctx.pipelined_calls()
+            outs = [f for _, f in batch.iterVoxelizeTrajectory(src, sig, center, [32, 32, 32], 1.0, box=bx, chunk=8, ctx=hip_ctx,
+                                                               pipelined=piped)]
+            torch.cuda.synchronize()
+            assert (hip_ctx.pipelined_calls() - n1 >= 1) == piped, (name, piped)
+            res[name, piped] = torch.cat(outs).cpu().numpy()
+    want, _, _ = batch._voxelizeTrajectory_packed(xyz, sig, center, [32, 32, 32], 1.0, box=box)
+    for k, v in res.items():
+        assert np.array_equal(v, want), k
+    assert want.max() > 0.5
