@@ -95,27 +95,33 @@ def make_workload(name, batch, seed):
     return p, origins, nv
 
 
-def pmc_traffic(workload, batch, tile_k):
-    """HBM bytes per launch of the tile kernel from the committed PMC passes (rocprofv3 cannot run inside
-    the bench): profiles/r*_<workload>_pmc_counters.json, WRITE_SIZE + 2 x FETCH_SIZE KiB (the gfx950
-    FETCH_SIZE correction of MI355X_MICROARCH.md, HBM section). None when no pass exists for this
-    workload / batch (the passes are taken at the default batch)."""
+def pmc_entry(workload, batch, tile_k, kernel=None):
+    """Counters of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside the bench):
+    profiles/r*_<workload>_pmc_counters.json of THIS build -- the file carries the source hash of the library it was taken
+    on (`_library_src`, moleculekit_amd._lib.source_hash()) and counters of another build are refused, with the reason on
+    the line.  -> (entry dict | None, file | reason, whole-step HBM bytes | None)"""
     import glob
+    from moleculekit_amd import _lib
     if batch != DEFAULT_BATCH[workload] or tile_k not in (0, 8):
-        return None, None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_counters.json")))
+        return None, "no pass at this batch / tile depth (the passes are taken at the defaults)", None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_counters.json")),
+                   key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
     if not files:
-        return None, None, None
+        return None, "no PMC pass committed for this workload", None
     d = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], ROOT)
+    if d.get("_library_src") != _lib.source_hash():
+        return None, f"refused: {rel} was taken on build {d.get('_library_src')}, this is {_lib.source_hash()}", None
     if d.get("_items_per_launch") != batch:
-        return None, None, None
-    best = None                                    # the instance most launches ran (the LDS tier the host settled on)
-    for k, v in d.items():
-        if isinstance(v, dict) and ("k_voxelize_tiles<8" in k or "k_voxelize_tiles_lean<8" in k or "k_voxelize_items<8" in k) \
-                and "FETCH_SIZE" in v and "WRITE_SIZE" in v and (best is None or v.get("_launches", 0) > best.get("_launches", 0)):
-            best = v
-    if best is None:
-        return None, None, None
+        return None, f"refused: {rel} was taken at another batch", None
+    best = d.get(kernel) if kernel and isinstance(d.get(kernel), dict) else None
+    if best is None:                               # the instance most launches ran (the LDS tier the host settled on)
+        for k, v in d.items():
+            if isinstance(v, dict) and ("k_voxelize_tiles<8" in k or "k_voxelize_tiles_lean<8" in k or "k_voxelize_items<8" in k) \
+                    and "FETCH_SIZE" in v and "WRITE_SIZE" in v and (best is None or v.get("_launches", 0) > best.get("_launches", 0)):
+                best = v
+    if best is None or "FETCH_SIZE" not in best or "WRITE_SIZE" not in best:
+        return None, f"refused: {rel} holds no counters of {kernel}", None
     # the whole step: every kernel of the pass (pre-pass, tile kernel, tail), launches per step from the launch counts
     step = None
     if d.get("_full_batch_launches_only") and best.get("_launches"):
@@ -124,7 +130,49 @@ def pmc_traffic(workload, batch, tile_k):
             if isinstance(v, dict) and k.startswith("mkamd::") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 step += (v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024 * v.get("_launches", 0) / best["_launches"]
         step = int(step)
-    return int((best["WRITE_SIZE"] + 2.0 * best["FETCH_SIZE"]) * 1024), os.path.relpath(files[-1], ROOT), step
+    return best, rel, step
+
+
+def in_range_pairs(p, nv, items):
+    """(voxel, atom x channel) pairs within the 5 A cutoff -- what the reference's loop accepts (occupancy_utils.pyx:53) --
+    counted exactly on `items` of the workload (host, numpy): every atom against the lattice points of the 11^3 voxels
+    around it (periodic items: its images within reach of the grid)."""
+    from tests.synth import grid_origin
+    vs = float(p["voxelsize"])
+    R = 5.0 / vs
+    w = int(np.ceil(R)) + 1
+    off = np.stack(np.meshgrid(*[np.arange(-w, w + 1)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    total = 0
+    for b in items:
+        s, e = int(p["atom_offsets"][b]), int(p["atom_offsets"][b + 1])
+        o, _ = grid_origin(p["centers"][b], p["boxsize"], vs)
+        x = (p["coords"][s:e].astype(np.float64) - o) / vs                      # voxel units, voxel i at i
+        nch = (np.asarray(p["sigmas"][s:e]) != 0).sum(1).astype(np.int64)
+        if p["box"] is not None:                                                # images that can reach the grid
+            L = p["box"][b].astype(np.float64) / vs
+            sh = np.stack(np.meshgrid(*[np.arange(-1, 2)] * 3, indexing="ij"), -1).reshape(-1, 3) * L
+            x = (x[None] + sh[:, None]).reshape(-1, 3)
+            nch = np.tile(nch, 27)
+        keep = np.all((x > -R) & (x < np.asarray(nv) - 1 + R), axis=1) & (nch > 0)
+        x, nch = x[keep], nch[keep]
+        for i in range(0, len(x), 4096):
+            xi = x[i:i + 4096]
+            base = np.rint(xi)
+            pts = base[:, None, :] + off[None]                                  # [n, (2w+1)^3, 3]
+            ok = (((pts - xi[:, None]) ** 2).sum(-1) < R * R) & np.all((pts >= 0) & (pts < np.asarray(nv)), axis=-1)
+            total += int((ok.sum(1) * nch[i:i + 4096]).sum())
+    return total
+
+
+def algorithmic_flops(p, nv, C=8):
+    """SURVEY.md section 8d, secondary roofline: ~22 lane-operations per in-range (voxel, entry) pair (with the min-q
+    shortcut) + ~14 per voxel-channel of epilogue (12 operations, 2 transcendentals); the pairs counted on the first items
+    of the batch (all of a cfg2 / cfg4 item; 16 small molecules) and scaled to the batch."""
+    B = len(p["atom_offsets"]) - 1
+    V = int(np.prod(nv))
+    items = list(range(min(B, 1 if int(p["atom_offsets"][1]) > 5000 else 16)))
+    pairs = in_range_pairs(p, nv, items) / len(items)
+    return int(B * (22.0 * pairs + 14.0 * V * C)), pairs / V
 
 
 def algorithmic_bytes(p, nv, C=8):
@@ -178,17 +226,21 @@ def cpu_baseline(name):
 
 
 def dist_traffic(F):
-    """HBM bytes per launch of k_dist_pairs from the committed PMC passes (profiles/r*_dist_pmc_counters.json, taken at
-    the default frame count): WRITE_SIZE + 2 x FETCH_SIZE KiB, as pmc_traffic."""
+    """HBM bytes per launch of k_dist_pairs from the committed PMC passes of THIS build (profiles/r*_dist_pmc_counters.json, taken
+    at the default frame count; stamped and checked like pmc_entry): WRITE_SIZE + 2 x FETCH_SIZE KiB.  -> (bytes | None, file | reason)"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dist_pmc_counters.json")))
+    from moleculekit_amd import _lib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dist_pmc_counters.json")), key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
     if not files:
-        return None
+        return None, "no PMC pass committed"
     d = json.load(open(files[-1]))
+    rel = os.path.relpath(files[-1], ROOT)
+    if d.get("_library_src") != _lib.source_hash():
+        return None, f"refused: {rel} was taken on build {d.get('_library_src')}, this is {_lib.source_hash()}"
     v = next((v for k, v in d.items() if isinstance(v, dict) and "k_dist_pairs" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v), None)
     if v is None or d.get("_items_per_launch") != F:
-        return None
-    return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024)
+        return None, f"refused: {rel} holds no k_dist_pairs counters at this frame count"
+    return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024), rel
 
 
 def bench_distances(args, emit=True):
@@ -212,31 +264,46 @@ def bench_distances(args, emit=True):
     ctx = _lib.default_context(0)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
-    def step():
-        ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2,
-                                chains.data_ptr(), False, True, False, out.data_ptr())
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the kernel
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    k_ms = e0.elapsed_time(e1) / args.steps
+    def timed(pbc):
+        def step():
+            ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2,
+                                    chains.data_ptr(), False, pbc, False, out.data_ptr())
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # same stream as the kernel
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(args.steps):
+            step()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, e0.elapsed_time(e1) / args.steps
+
+    # the common MetricDistance call first (pbc = False: no pair wraps; projections/util.py:30-37), then the headline of this
+    # leg, periodic by chain -- whose result stays in `out` for the bit-exactness check below
     ndist = F * n1 * n2
     alg = ndist * 4 + (n1 + n2) * 3 * F * 4 + 3 * F * 4
+    np_elapsed, np_ms = timed(False)
+    nonperiodic = {"value": round(ndist * args.steps / np_elapsed / 1e6, 1), "unit": "Mdist/s", "ms_per_step": round(np_elapsed / args.steps * 1e3, 4),
+                   "roofline": {"bound": "hbm", "achieved": round(alg / np_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": "k_dist_pairs", "kernel_avg_ms": round(np_ms, 5)}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        Fs = min(16, F)
+        ref = oracle.dist_trajectory(coords[:, :, :Fs].contiguous().cpu().numpy(), box[:, :Fs].contiguous().cpu().numpy(), s1, s2, chains_h, False, False)
+        if not np.array_equal(out[:Fs].cpu().numpy(), ref):
+            raise SystemExit("dist_trajectory (pbc = False) on the GPU is not bit-exact with the oracle")
+    elapsed, k_ms = timed(True)
     line = {"metric": "Mdist/s (dist_trajectory, periodic by chain)", "value": round(ndist * args.steps / elapsed / 1e6, 1),
             "unit": "Mdist/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"},
             "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F), "kernel": "k_dist_pairs",
-                         "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg}}
+                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F)[0], "traffic_source": dist_traffic(F)[1], "kernel": "k_dist_pairs",
+                         "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg},
+            "nonperiodic": nonperiodic}
     if not args.no_cpu_baseline:
         from oracle import oracle
         Fs = min(64, F)
@@ -488,12 +555,13 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     elapsed = time.perf_counter() - t0
     ctx.enable_kernel_timing(False)
     k_ms, k_n = ctx.read_kernel_timing()
+    kernel_name = ctx.last_tile_kernel() if hasattr(ctx, "last_tile_kernel") else None
     ctx.synchronize()
     elapsed = _max_over_ranks(elapsed, world)
     # sanity of what was produced inside the timed region (never a cached / skipped result)
     chk = out[0].double().sum().item()
     assert os.environ.get("MKAMD_DIAG") == "1" or (np.isfinite(chk) and chk > 0), "bench produced an empty grid"
-    res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C))
+    res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C), kernel=kernel_name)
     if "out" in keep:
         res["out"] = out
 
@@ -570,16 +638,45 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     return res
 
 
+_FLOPS_MEMO = {}
+
+
 def roofline_of(res, workload, B, tile_k):
     k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
     achieved = res["alg"] / (k_avg_ms * 1e-3) / 1e9 if res["k_n"] else None
-    traffic, traffic_src, step_traffic = pmc_traffic(workload, B, tile_k)
-    return {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
-            "traffic": traffic, "traffic_of": "the dominant kernel alone (per launch)", "step_traffic": step_traffic,
-            "traffic_source": traffic_src, "kernel": "k_voxelize_tiles|_lean|_team|k_voxelize_items + k_tail (what runs between the timing events)",
-            "kernel_avg_ms": round(k_avg_ms, 5), "kernel_launches": int(res["k_n"]),
-            "algorithmic_bytes_per_launch": int(res["alg"])}
+    kernel = res.get("kernel") or None
+    entry, src, step_traffic = pmc_entry(workload, B, tile_k, kernel)
+    traffic = int((entry["WRITE_SIZE"] + 2.0 * entry["FETCH_SIZE"]) * 1024) if entry else None
+    out = {"bound": "hbm", "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+           "traffic": traffic, "traffic_of": "the dominant kernel alone (per launch)", "step_traffic": step_traffic,
+           "traffic_source": src, "kernel": kernel, "timed_region": "the tile kernel + k_tail (what runs between the library's timing events)",
+           "kernel_avg_ms": round(k_avg_ms, 5), "kernel_launches": int(res["k_n"]),
+           "algorithmic_bytes_per_launch": int(res["alg"])}
+    # the secondary roofline SURVEY.md section 8d / 7-H3 asks for next to the HBM one: vector FP32
+    try:
+        if (workload, B) not in _FLOPS_MEMO:
+            _FLOPS_MEMO[(workload, B)] = algorithmic_flops(res["p"], res["nv"], res["C"])
+        flops, pairs_per_voxel = _FLOPS_MEMO[(workload, B)]
+        tf = flops / (k_avg_ms * 1e-3) / 1e12 if res["k_n"] else None
+        sec = {"bound": "valu", "achieved": round(tf, 2) if tf else None, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+               "frac": round(tf / FP32_VALU_PEAK_TFLOPS, 4) if tf else None, "algorithmic_flops_per_launch": flops,
+               "flop_per_byte": round(flops / res["alg"], 2), "in_range_pairs_per_voxel": round(pairs_per_voxel, 2),
+               "formula": "22 x in-range (voxel, atom x channel) pairs + 14 x voxel-channels (SURVEY.md 8d)"}
+        if entry and entry.get("SQ_WAVES") and entry.get("SQ_INSTS_VALU") is not None:
+            sec["valu_insts_per_wave"] = round(entry["SQ_INSTS_VALU"] / entry["SQ_WAVES"], 1)
+            if kernel and "k_voxelize_tiles" in kernel and "team" not in kernel:
+                sec["valu_insts_per_tile"] = sec["valu_insts_per_wave"]        # one wave per 512-voxel tile
+            clk = entry.get("GRBM_GUI_ACTIVE") or (entry.get("SQ_BUSY_CYCLES", 0) / 32.0)      # shader cycles of the launch
+            if clk and entry.get("SQ_ACTIVE_INST_VALU") is not None:
+                # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1 024 SIMDs
+                sec["valu_busy"] = round(entry["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / clk, 3)
+                sec["valu_busy_of"] = "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / " + ("GRBM_GUI_ACTIVE" if entry.get("GRBM_GUI_ACTIVE") else "(SQ_BUSY_CYCLES / 32 shader engines)")
+            sec["counters_source"] = src
+        out["secondary"] = sec
+    except Exception as e:                             # noqa: BLE001 -- a secondary number
+        out["secondary"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def main():
@@ -599,7 +696,7 @@ def main():
                     help="skip the secondary workloads (cfg1/cfg3/cfg4/cfg5 at N=1, the cfg3 batched-molecule leg at N>1)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap step n+1's binning pre-pass with step n's tile kernel")
-    ap.add_argument("--min-seconds", type=float, default=1.0,
+    ap.add_argument("--min-seconds", type=float, default=6.0,
                     help="after the timed K steps, keep stepping until this much wall time has been spent on the same workload and "
                          "report it as `sustained` (the K-step region of a 64^3 workload is tens of milliseconds: too short for a "
                          "utilisation sampler to see, and for the clocks to settle). 0 = skip")
@@ -735,7 +832,7 @@ def main():
                 "value": round(world * B * r3["V"] * r3["C"] * steps2 / r3["elapsed"] / 1e6, 2), "unit": "Mvoxel-channels/s",
                 "items_per_gpu_per_step": B, "steps": steps2, "ms_per_step": round(r3["elapsed"] / steps2 * 1e3, 4),
                 "note": "opt-in: values within 1e-6 of the exact mode (tests/test_gpu_parity.py), not bit-identical",
-                "roofline": {k: v for k, v in roofline_of(r3, "cfg2", B, args.tile_k).items() if k not in ("traffic", "step_traffic", "traffic_source", "traffic_of")}}
+                "roofline": {k: v for k, v in roofline_of(r3, "cfg2", B, args.tile_k).items() if k not in ("traffic", "step_traffic", "traffic_source", "traffic_of", "secondary")}}
         except Exception as e:                     # noqa: BLE001
             extra["cfg2_value_tolerance_1e-6"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         finally:
@@ -793,7 +890,7 @@ def main():
                     dl = bench_distances(dargs, emit=False)
                     line.setdefault("other_workloads", {})["dist_trajectory"] = {
                         "value": dl["value"], "unit": dl["unit"], "ms_per_step": dl["ms_per_step"], "config": dl["config"]["workload"],
-                        "roofline": dl["roofline"]}
+                        "roofline": dl["roofline"], "nonperiodic": dl["nonperiodic"]}
                 except Exception as e:             # noqa: BLE001 -- secondary numbers: reported, the headline line still prints
                     line["secondary_error"] = f"{type(e).__name__}: {e}"[:300]
 

@@ -139,6 +139,9 @@ int mkamd_ctx_withdraw_promise(mkamd_ctx* ctx);
 /* How many lattice calls of this context have run their pre-pass beside a previous call's tile kernel so far (tests
  * and benchmarks check with it that a driver really is pipelined). */
 int mkamd_ctx_pipelined_calls(mkamd_ctx* ctx, int64_t* n);
+/* Name of the tile kernel the last lattice call launched, as a profiler prints it ("mkamd::k_voxelize_tiles_lean<8, 640>";
+ * the team kernel without its team size; empty before the first call): what bench.py reports as `roofline.kernel`. */
+int mkamd_ctx_last_tile_kernel(mkamd_ctx* ctx, char* name, size_t name_cap);
 /* Per-kernel timing of the tile kernel with HIP events on the context's stream (bench.py's
  * roofline leg): enable, run, then read back the accumulated time and launch count (resets). */
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable);

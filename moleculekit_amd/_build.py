@@ -21,9 +21,36 @@ def hipcc_path():
     return "hipcc"
 
 
+def source_hash() -> str:
+    """sha256 over the sources of the library (names and contents), first 16 hex digits: compiled into mkamd_version(), so that
+    a measurement can name the build it was taken on (profiles/*_pmc_counters.json; bench.py compares)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + [HEADER, HEADER2, HEADER3]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(lib: str = LIB):
+    """The source hash a built library carries (None: missing / unstamped)."""
+    import re
+    try:
+        blob = open(lib, "rb").read()
+    except OSError:
+        return None
+    m = re.search(rb"moleculekit_amd [0-9.]+ \(gfx950, HIP\) src ([0-9a-f]{16})", blob)
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER, HEADER2, HEADER3]
     stale = (not os.path.exists(LIB)) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+    # (a checkout resets mtimes: the stamp in the library decides then -- same sources, no rebuild)
+    if stale and not force and built_hash() == source_hash():
+        os.utime(LIB, None)
+        stale = False
     if force or stale:
         # hipcc reads the sources twice (device pass, then host pass): a header edited in between gives a library whose
         # host stubs and device code disagree.  Build beside the target, stamp it with the time the compile STARTED
@@ -31,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         started = time.time()
         tmp = "%s.%d.tmp" % (LIB, os.getpid())
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-function", os.path.join(CSRC, "capi.hip"), "-o", tmp]
+               "-Wno-unused-function", '-DMKAMD_SRC_HASH="%s"' % source_hash(), os.path.join(CSRC, "capi.hip"), "-o", tmp]
         if verbose:
             print(" ".join(cmd))
         try:

@@ -41,6 +41,7 @@ SIGNATURES = {
     "mkamd_ctx_promise_inputs": (_c_int, [_vp, _vp]),
     "mkamd_ctx_withdraw_promise": (_c_int, [_vp]),
     "mkamd_ctx_pipelined_calls": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
+    "mkamd_ctx_last_tile_kernel": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
@@ -107,6 +108,19 @@ def load() -> ctypes.CDLL:
                 fn.restype, fn.argtypes = res, args
             _lib = L
     return _lib
+
+
+def version() -> str:
+    """``mkamd_version()`` of the loaded library: name, version, and the hash of the sources it was built from."""
+    return load().mkamd_version().decode()
+
+
+def source_hash():
+    """The 16-hex-digit source hash the loaded library carries (``None`` for a build without a stamp, e.g. a tools/ variant):
+    what ties a profile under profiles/ to the build it was taken on."""
+    import re
+    m = re.search(r"src ([0-9a-f]{16})", version())
+    return m.group(1) if m else None
 
 
 class MkamdError(RuntimeError):
@@ -231,6 +245,12 @@ class Context:
     def withdraw_promise(self):
         """Drop a promise no call has consumed."""
         _check(load().mkamd_ctx_withdraw_promise(self._h))
+
+    def last_tile_kernel(self) -> str:
+        """Name of the tile kernel the last lattice call launched, as rocprofv3 prints it ('' before the first call)."""
+        buf = ctypes.create_string_buffer(128)
+        _check(load().mkamd_ctx_last_tile_kernel(self._h, buf, 128))
+        return buf.value.decode()
 
     def pipelined_calls(self) -> int:
         """Lattice calls of this context whose pre-pass ran beside a previous call's tile kernel so far."""

@@ -222,8 +222,10 @@ struct mkamd_ctx {
     }
     // Events are barrier packets the command processor takes ~5 us each to retire, and they sit between one
     // call's tile kernel and the next one's: the timing events double as the pipeline's markers when both exist.
-    void hot_begin()
+    int last_flavour = -1, last_K = 0, last_ecap = 0;      // the tile kernel of the last lattice call (mkamd_ctx_last_tile_kernel)
+    void hot_begin(int flavour, int K, int ecap)
     {
+        last_flavour = flavour; last_K = K; last_ecap = ecap;
         last_hot_end = nullptr;
         if (timing) {
             std::pair<hipEvent_t, hipEvent_t> ev;
@@ -290,7 +292,11 @@ static int ensure_err_flag(mkamd_ctx* ctx)
 
 extern "C" {
 
-const char* mkamd_version(void) { return "moleculekit_amd 0.2.0 (gfx950, HIP)"; }
+#ifndef MKAMD_SRC_HASH            // _build.py: sha256 over the sources this library was compiled from (first 16 hex digits)
+#define MKAMD_SRC_HASH "unstamped"
+#endif
+// (the hash is what ties a measurement to a build: profiles/*_pmc_counters.json carry it, bench.py refuses counters of another build)
+const char* mkamd_version(void) { return "moleculekit_amd 0.3.0 (gfx950, HIP) src " MKAMD_SRC_HASH; }
 
 const char* mkamd_last_error(void) { return g_last_error; }
 
@@ -516,6 +522,16 @@ int mkamd_ctx_pipelined_calls(mkamd_ctx* ctx, int64_t* n)
 try {
     if (!ctx || !n) return fail(MKAMD_EINVAL, "ctx / n is NULL");
     *n = (int64_t)ctx->n_pipelined;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_last_tile_kernel(mkamd_ctx* ctx, char* name, size_t name_cap)
+try {
+    if (!ctx || !name || name_cap == 0) return fail(MKAMD_EINVAL, "ctx / name is NULL");
+    static const char* const base[] = {"k_voxelize_tiles", "k_voxelize_tiles_lean", "k_voxelize_tiles_team", "k_voxelize_items"};
+    if (ctx->last_flavour < 0 || ctx->last_flavour > 3) snprintf(name, name_cap, "%s", "");
+    else if (ctx->last_flavour == 3) snprintf(name, name_cap, "mkamd::%s<%d>", base[3], ctx->last_K);
+    else snprintf(name, name_cap, "mkamd::%s<%d, %d>", base[ctx->last_flavour], ctx->last_K, ctx->last_ecap);
     return MKAMD_OK;
 } MK_API_CATCH
 

@@ -109,6 +109,7 @@ MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long l
 // is used: the first version looked its pair up, waited, loaded its three coordinates, waited -- 32 dependent round
 // trips to L2 per wave, which is what bounded it (0.56 ms for 100 000 pairs x 2 048 frames: 1.5 TB/s of stores).
 constexpr int DP_RUN = DT / (DT_THREADS / DT);   // 16
+template <bool B> struct DistFlag { static constexpr bool value = B; };
 #ifndef MK_DP_BATCH
 #define MK_DP_BATCH 4
 #endif
@@ -123,7 +124,6 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
                          long long P, long long pw, Emit&& emit)
 {
     const int lane = threadIdx.x & (WAVE - 1);
-    const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
     const long long left = P - pw;                                   // wave-uniform, > 0
     const long long pi = pw + (lane & (DP_RUN - 1)) < P ? pw + (lane & (DP_RUN - 1)) : P - 1;
     // lane k: first atom of pair k, and its second atom with the wrap flag in bit 31 (atom indices are int32)
@@ -131,12 +131,29 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
     const unsigned a_first = mk_readlane(va, 0);
     const bool one_a = mk_ballot(va != a_first) == 0ull;              // the usual case in i-major order: one first atom for the run
     // a coordinate row is a wave-uniform base (the atom index sits in a scalar register) plus this lane's frame as a
-    // 32-bit byte offset: the addresses cost no vector instructions
-    auto at = [&](unsigned atom, int ax) {
-        return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
-    };
+    // 32-bit byte offset: the addresses cost no vector instructions.  When every row this run touches ends below 4 GiB from
+    // the start of the array (wave-uniform; a 30 000-atom, 2 048-frame trajectory is 0.7 GiB) the row is a 32-bit scalar
+    // offset from ONE descriptor (mk_load_f32_base_soffset), else a 64-bit base and a descriptor per row.
+    const unsigned F4 = (unsigned)F * 4u;                             // (F < 2^30: the host checks)
+    const unsigned hi_atom = va > (vb & 0x7fffffffu) ? va : (vb & 0x7fffffffu);
+    const bool small_rows = mk_ballot(((unsigned long long)hi_atom * 3ull + 3ull) * (unsigned long long)F4 > 0xffffffffull) == 0ull;
+    // Does ANY pair of this run wrap (pbc and different chains, distance_utils.pyx:49)?  Wave-uniform.  A run without one --
+    // every call with pbc = False, the common MetricDistance call, and every intra-chain stretch of a periodic one -- takes
+    // a body that holds no image arithmetic at all; the reciprocals of the box are only formed (three IEEE divisions: 30
+    // vector instructions) for runs that wrap, ONCE per run: left to itself the optimizer sinks them into every batch
+    // (round 4: 99 v_rcp_f32 in the kernel, 7.5 instructions per distance).
+    const bool run_wraps = mk_ballot((vb & 0x80000000u) != 0u) != 0ull;
+    float ibx = 0.f, iby = 0.f, ibz = 0.f;
+    if (run_wraps) { ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz); }
+    mk_keep(ibx); mk_keep(iby); mk_keep(ibz);
     unsigned cur_a = 0xffffffffu;
     float xa = 0.f, ya = 0.f, za = 0.f;
+    auto run_body = [&](auto wraps_, auto small_) {
+    constexpr bool WR = decltype(wraps_)::value, SMALL = decltype(small_)::value;
+    auto at = [&](unsigned atom, int ax) {
+        if constexpr (SMALL) return mk_load_f32_base_soffset(coords, (atom * 3u + (unsigned)ax) * F4, fb);
+        else return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
+    };
 #pragma unroll
     for (int k0 = 0; k0 < DP_RUN; k0 += DP_BATCH) {
         if ((long long)k0 >= left) break;                            // wave-uniform
@@ -155,20 +172,23 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
         if (same) {
 #pragma unroll
             for (int u = 0; u < DP_BATCH; ++u)
-                d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
+                d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, WR && w[u] != 0u);
         } else {
             float A3[DP_BATCH][3];
 #pragma unroll
             for (int u = 0; u < DP_BATCH; ++u) { A3[u][0] = at(a[u], 0); A3[u][1] = at(a[u], 1); A3[u][2] = at(a[u], 2); }
 #pragma unroll
             for (int u = 0; u < DP_BATCH; ++u)
-                d2[u] = dist2_min_image_f32(A3[u][0], A3[u][1], A3[u][2], B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, w[u] != 0u);
+                d2[u] = dist2_min_image_f32(A3[u][0], A3[u][1], A3[u][2], B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, WR && w[u] != 0u);
             cur_a = a[DP_BATCH - 1];
             xa = A3[DP_BATCH - 1][0]; ya = A3[DP_BATCH - 1][1]; za = A3[DP_BATCH - 1][2];
         }
 #pragma unroll
         for (int u = 0; u < DP_BATCH; ++u) emit(k0 + u, d2[u]);
     }
+    };
+    if (small_rows) { if (run_wraps) run_body(DistFlag<true>{}, DistFlag<true>{}); else run_body(DistFlag<false>{}, DistFlag<true>{}); }
+    else { if (run_wraps) run_body(DistFlag<true>{}, DistFlag<false>{}); else run_body(DistFlag<false>{}, DistFlag<false>{}); }
 }
 
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,

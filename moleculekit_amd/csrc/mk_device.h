@@ -187,6 +187,20 @@ MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)0xffffffffu, 0x00020000);
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_offset, 0, 0));
 }
+// The same with the wave-uniform part of the address as a 32-bit SCALAR byte offset from one base: the descriptor is built once
+// (the base never changes), a row costs one s_mul / s_add instead of a 64-bit multiply-add and a fresh descriptor (~11 scalar
+// instructions per load: k_dist_pairs issued 600 of them per wave, as many as its vector instructions, on the ONE scalar unit
+// the four SIMDs of a CU share).  The caller guarantees uniform_byte_offset + byte_offset < 2^32.
+MK_DEV float mk_load_f32_base_soffset(const float* base, unsigned uniform_byte_offset, unsigned byte_offset)
+{
+    const unsigned long long b = (unsigned long long)reinterpret_cast<uintptr_t>(base);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    void* p = reinterpret_cast<void*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)0xffffffffu, 0x00020000);
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((int)uniform_byte_offset);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_offset, (int)so, 0));
+}
 MK_DEV float mk_max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32 (NaN operands are ignored)
 MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // round half to even: v_rndne_f32
 // IEEE correctly rounded sqrt.  (hipcc lowers __fsqrt_rn / sqrtf in this build to a bare v_sqrt_f32, which

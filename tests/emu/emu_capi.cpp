@@ -46,7 +46,7 @@ struct EmuBackend {
         emu::launch(kernel, grid, block, args...);
         return 0;
     }
-    void hot_begin() {}
+    void hot_begin(int = 0, int = 0, int = 0) {}
     void hot_end() {}
     int acquire_set(bool) { return 0; }
     bool set_is_pipelined(int) const { return false; }

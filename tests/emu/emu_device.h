@@ -291,6 +291,10 @@ MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
 {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_offset);
 }
+MK_DEV float mk_load_f32_base_soffset(const float* base, unsigned uniform_byte_offset, unsigned byte_offset)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)uniform_byte_offset + (size_t)byte_offset);
+}
 MK_DEV float mk_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 MK_DEV float mk_rint(float a) { return nearbyintf(a); }              // round half to even (default rounding mode)
 MK_DEV float mk_int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
