@@ -352,6 +352,101 @@ def bench_dropin(args):
     print(json.dumps(line), flush=True)
 
 
+def bench_stream_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
+    """Secondary leg `stream_cfg4`: cfg4 frames (30 000 atoms, periodic, 48^3 grid) through the PRODUCT streaming driver
+    batch.iterVoxelizeTrajectory from a device-resident trajectory ([N, 3, F], the Molecule.coords layout), `chunk` frames per
+    call -- next to the raw pipelined cfg4 step of run_workload (the same 256 frames per call, inputs resident and packed).
+    What it adds per chunk: the frame-major transpose on the copy stream, fresh feature memory, the promise / events."""
+    import torch
+    from moleculekit_amd import batch
+    p, _, _ = make_workload("cfg4", chunk, seed=4000)
+    N = int(p["atom_offsets"][1])
+    src = torch.as_tensor(p["coords"].reshape(chunk, N, 3)).to(dev).permute(1, 2, 0).contiguous().repeat(1, 1, frames // chunk)
+    box = np.tile(np.ascontiguousarray(p["box"].T), (1, frames // chunk))
+    sig = np.ascontiguousarray(p["sigmas"][:N], dtype=np.float32)
+
+    def run():
+        n = 0
+        for idx, feats in batch.iterVoxelizeTrajectory(src, sig, p["centers"][0], p["boxsize"], p["voxelsize"], box=box, chunk=chunk, ctx=ctx):
+            n += len(idx)
+            del feats
+        torch.cuda.synchronize(dev)
+        return n
+
+    run()
+    n0 = ctx.pipelined_calls()
+    t0 = time.perf_counter()
+    n = run()
+    dt = time.perf_counter() - t0
+    ms_chunk = dt / (n / chunk) * 1e3
+    V = int(np.prod(np.ceil(p["boxsize"] / p["voxelsize"]).astype(int)))
+    out = {"frames": n, "frames_per_call": chunk, "frames_per_s": round(n / dt, 1), "ms_per_call": round(ms_chunk, 4),
+           "value": round(n * V * 8 / dt / 1e6, 2), "unit": "Mvoxel-channels/s", "pipelined_calls": ctx.pipelined_calls() - n0,
+           "source": "device-resident [N,3,F] float32 tensor", "driver": "batch.iterVoxelizeTrajectory (promised inputs, include/mkamd_voxel.h)"}
+    if raw_ms_per_step:
+        out["raw_pipelined_cfg4_ms_per_step"] = raw_ms_per_step
+        out["over_raw_step"] = round(ms_chunk / raw_ms_per_step, 4)
+    del src
+    torch.cuda.empty_cache()
+    return out
+
+
+def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=1024, chunk=256):
+    """Secondary leg `xtc_cfg4`: the cfg4 FEEDER -- a synthetic 30 000-atom XTC trajectory (64 frames of the cfg4 random walk
+    written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) decoded by
+    libmkamd.so's host threads straight into pinned staging and voxelized through batch.iterVoxelizeXTC.  Reports the
+    decode rate alone, the end-to-end rate and how idle the GPU is (its share of the wall time at the raw cfg4 step)."""
+    import tempfile
+    import torch
+    from moleculekit_amd import batch, xtc
+    base = 64
+    p, _, _ = make_workload("cfg4", base, seed=4001)
+    N = int(p["atom_offsets"][1])
+    L = float(p["box"][0, 0])
+    nm = np.ascontiguousarray((p["coords"].reshape(base, N, 3) * np.float32(0.1)).transpose(1, 2, 0))      # [N,3,F] in nm
+    bv = np.zeros((3, 3, base), np.float32)
+    bv[0, 0] = bv[1, 1] = bv[2, 2] = L * 0.1
+    sig = np.ascontiguousarray(p["sigmas"][:N], dtype=np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        one = os.path.join(d, "one.xtc")
+        xtc.write_xtc(one, nm, bv, np.zeros(base, np.float32), np.arange(base))
+        blob = open(one, "rb").read()
+        fn = os.path.join(d, "cfg4.xtc")
+        with open(fn, "wb") as fh:
+            for _ in range(frames // base):
+                fh.write(blob)
+        F = xtc.get_xtc_nframes(fn)
+        xtc.read_xtc_frames(fn, np.arange(chunk))                               # warm (page cache, threads)
+        t0 = time.perf_counter()
+        xtc.read_xtc(fn)
+        t_dec = time.perf_counter() - t0
+
+        def run():
+            n = 0
+            for idx, feats in batch.iterVoxelizeXTC(fn, sig, p["centers"][0], p["boxsize"], p["voxelsize"], pbc=True, chunk=chunk, ctx=ctx):
+                n += len(idx)
+                del feats
+            torch.cuda.synchronize(dev)
+            return n
+
+        run()
+        t0 = time.perf_counter()
+        n = run()
+        dt = time.perf_counter() - t0
+    out = {"atoms": N, "frames": F, "file_MB": round(len(blob) * (frames // base) / 1e6, 1), "bytes_per_atom": round(len(blob) / base / N, 2),
+           "decode_frames_per_s": round(F / t_dec, 1), "decode_Matoms_per_s": round(F * N / t_dec / 1e6, 1), "host_threads": "automatic (<= 64)",
+           "frames_per_s": round(n / dt, 1), "frames_per_call": chunk,
+           "driver": "batch.iterVoxelizeXTC: decode -> pinned staging -> copy stream -> promised voxelize call"}
+    if raw_ms_per_step:
+        gpu_s = n / chunk * raw_ms_per_step * 1e-3
+        out["gpu_busy_fraction"] = round(gpu_s / dt, 4)
+        out["gpu_idle_fraction"] = round(1.0 - gpu_s / dt, 4)
+        out["kernels_alone_frames_per_s"] = round(chunk / (raw_ms_per_step * 1e-3), 1)
+        out["bottleneck"] = "host XTC decode" if F / t_dec < 0.5 * chunk / (raw_ms_per_step * 1e-3) else "GPU"
+    torch.cuda.empty_cache()
+    return out
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -426,11 +521,26 @@ def dry_run(args):
     dev = torch.device("cpu")
 
     def fence():
-        dist.barrier()
+        _collective(dist.barrier)
 
+    once = threading.Lock()
+
+    def report_degraded():
+        if not once.acquire(blocking=False):
+            return
+        print(json.dumps({"metric": "dry-run (gloo, stand-in compute)", "dry_run": True, "timed_path": "run_workload", "n_gpus": world,
+                          "ok": False, "ranks_alive": ranks_done(world), "degraded": _RANKS["broken"]}), flush=True)
+
+    if rank == 0:
+        _RANKS["emit"] = report_degraded
+        term_reporter()
     t0 = time.perf_counter()
-    res = run_workload("cfg3", B, 2, 1, _StandInContext(), dev, rank, world, args, fence, want_gather=True,
+    res = run_workload("cfg3", B, 2, 1, _StandInContext(), dev, rank, world, args, fence, want_gather=not os.environ.get("MKAMD_BENCH_KILL_RANK"),
                        compute=_standin_compute, keep=("full_plain", "full_overlapped", "out"))
+    if _RANKS["broken"]:                                      # a rank died: rank 0 says so on its line (the N > 1 GPU run does the same)
+        if rank == 0:
+            report_degraded()
+        os._exit(1)
     mine = res["out"][:, 0, 0].tolist()                       # what this rank's items are worth
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
@@ -466,6 +576,79 @@ def guarded(fn, seconds, on_timeout):
         done.set()
 
 
+# ---- a rank that dies must not cost rank 0 its line ----------------------------------------------------------------------
+# Nothing here has run with N > 1 on RCCL where this file was written.  Every collective BETWEEN the ranks (the gloo fences,
+# the max over ranks, the gather legs) goes through _collective(): the first failure is remembered, nothing is attempted
+# after it, and rank 0 reports what it measured itself with `ranks_alive` (ranks that finished the timed region, read
+# from the rendezvous store, which lives in the launcher) and `degraded` on the line.  torchrun answers a dead worker by
+# sending the others SIGTERM: rank 0 turns that into its line too (term_reporter: a wake-up fd and a thread, so that it
+# works while the main thread sits inside a collective).
+_RANKS = {"broken": None, "emit": None}
+
+
+def _collective(fn, default=None):
+    if _RANKS["broken"]:
+        return default
+    try:
+        return fn()
+    except Exception as e:                                    # noqa: BLE001 -- reported on the line
+        _RANKS["broken"] = f"{type(e).__name__}: {e}"[:200]
+        return default
+
+
+def _store():
+    try:
+        import torch.distributed as dist
+        return dist.distributed_c10d._get_default_store() if dist.is_initialized() else None
+    except Exception:                                         # noqa: BLE001
+        return None
+
+
+def mark_done(rank):
+    st = _store()
+    if st is not None:
+        try:
+            st.set(f"mkamd_bench_timed_{rank}", "1")
+        except Exception:                                     # noqa: BLE001
+            pass
+
+
+def ranks_done(world):
+    st = _store()
+    if st is None:
+        return world
+    n = 0
+    for r in range(world):
+        try:
+            n += bool(st.check([f"mkamd_bench_timed_{r}"]))
+        except Exception:                                     # noqa: BLE001
+            pass
+    return n
+
+
+def term_reporter():
+    """SIGTERM -> whatever _RANKS['emit'] holds is called (rank 0's line, as far as it got), then the process ends."""
+    import select
+    import signal
+    r, w = os.pipe()
+    os.set_blocking(w, False)
+    signal.signal(signal.SIGTERM, lambda *_: None)            # (a Python-level handler must exist for the wake-up fd to fire)
+    signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+
+    def watch():
+        while True:
+            select.select([r], [], [])
+            if signal.SIGTERM in os.read(r, 64):
+                _RANKS["broken"] = _RANKS["broken"] or "SIGTERM: the launcher is taking the job down (a rank failed)"
+                try:
+                    if _RANKS["emit"]:
+                        _RANKS["emit"]()
+                finally:
+                    os._exit(1)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def _max_over_ranks(x, world):
     """MAX of a host scalar over the ranks through a CPU tensor (the gloo side of the process group): nothing in or around
     the timed region touches RCCL -- once an RCCL communicator exists in the process every kernel of the step runs 3-7 %
@@ -475,8 +658,7 @@ def _max_over_ranks(x, world):
         import torch
         import torch.distributed as dist
         tt = torch.tensor([x], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
+        return _collective(lambda: (dist.all_reduce(tt, op=dist.ReduceOp.MAX), float(tt.item()))[1], default=x)
     return x
 
 
@@ -551,6 +733,10 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    if os.environ.get("MKAMD_BENCH_KILL_RANK") == str(rank):      # tests/test_bench_launch.py: a rank that dies in the timed region
+        os._exit(17)
+    ctx.synchronize()
+    mark_done(rank)                                               # this rank's steps are done (rank 0 counts these if a fence fails)
     fence()
     elapsed = time.perf_counter() - t0
     ctx.enable_kernel_timing(False)
@@ -585,6 +771,9 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     def gather_legs():
         # (a secondary measurement: a failure in it -- RCCL, memory for the world x B result -- is reported on the line,
         #  it must not cost the primary one)
+        if _RANKS["broken"]:
+            res["gather_error"] = "skipped: a rank had already failed"
+            return res
         try:
             # the trivial gather of the feature tensors, timed on its own: (a) one padded all-gather after the compute,
             # (b) chunk-overlapped with the compute (what a consumer that needs everything everywhere would run)
@@ -600,12 +789,13 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
             if "full_plain" in keep:
                 res["full_plain"] = full
             del full
-            full = sv.voxelize_gather(nchunks=4)  # (the first point-to-point exchange sets its channels up)
+            full = sv.voxelize_gather(nchunks=4, loopback=world == 1)  # (the first point-to-point exchange sets its channels up)
             del full
             fence()
             g0 = time.perf_counter()
-            full = sv.voxelize_gather(nchunks=4)
+            full = sv.voxelize_gather(nchunks=4, loopback=world == 1)
             fence()
+            res["gather_exchange"] = getattr(sv, "last_exchange", "?") + (" (one rank: batched send / receive to itself)" if world == 1 else "")
             both = (time.perf_counter() - g0) * 1e3
             res["compute_plus_overlapped_gather_ms"] = both
             res["gather_overlapped_extra_ms"] = both - elapsed / steps * 1e3
@@ -767,8 +957,14 @@ def main():
     def fence():
         torch.cuda.synchronize(dev)
         if use_dist:
-            dist.all_reduce(torch.zeros(1))                   # the barrier, on a CPU tensor: the gloo side of the group
+            _collective(lambda: dist.all_reduce(torch.zeros(1)))      # the barrier, on a CPU tensor: the gloo side of the group
         torch.cuda.synchronize(dev)
+
+    if use_dist and rank == 0:
+        _RANKS["emit"] = lambda: print(json.dumps({"metric": "Mvoxel-channels/s (64^3 grid, 8 ch)", "value": None, "unit": "Mvoxel-channels/s",
+                                                    "n_gpus": world, "ranks_alive": ranks_done(world), "degraded": _RANKS["broken"],
+                                                    "error": "the job was taken down before rank 0 finished its timed region"}), flush=True)
+        term_reporter()
 
     def dropin_probe():
         """The reference's own call pattern: ONE molecule per synchronous call, host arrays in, float64 [V, C] out
@@ -838,6 +1034,15 @@ def main():
         finally:
             ctx.set_value_tolerance(0.0)
 
+    if not args.no_extra and args.workload == "cfg2" and not args.batch and world == 1:
+        # the package's streaming drivers on cfg4-shaped work: pipelined by promise (device-resident source), and fed from an XTC file
+        raw4 = extra.get("cfg4", {}).get("ms_per_step")
+        for nm, fn in (("stream_cfg4", bench_stream_cfg4), ("xtc_cfg4", bench_xtc_cfg4)):
+            try:
+                extra[nm] = fn(ctx, dev, raw4)
+            except Exception as e:                 # noqa: BLE001
+                extra[nm] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     printed = threading.Lock()
     timed_out = []                                 # non-empty once the watchdog of the gather legs has fired
 
@@ -846,7 +1051,8 @@ def main():
         if not printed.acquire(blocking=False):
             return
         if rank == 0:
-            total_vc = world * B * V * C * args.steps
+            alive = world if not _RANKS["broken"] else max(ranks_done(world), 1)
+            total_vc = alive * B * V * C * args.steps
             k_avg_ms = res["k_ms"] / max(res["k_n"], 1)
             info = ctx.device_info()
             line = {
@@ -874,6 +1080,10 @@ def main():
                 "gather_ms": round(res["gather_ms"], 3) if "gather_ms" in res else None,
                 "gather_overlapped_extra_ms": round(res["gather_overlapped_extra_ms"], 3) if "gather_overlapped_extra_ms" in res else None,
                 **({"gather_error": res["gather_error"]} if "gather_error" in res else {}),
+                **({"gather_exchange": res["gather_exchange"]} if "gather_exchange" in res else {}),
+                "ranks_alive": alive,
+                **({"degraded": f"a collective between the ranks failed ({_RANKS['broken']}): `value` counts the {alive} rank(s) that finished "
+                                "the timed region, timed on rank 0 alone"} if _RANKS["broken"] else {}),
             }
             if extra:
                 line["other_workloads" if world == 1 else "batched_molecules"] = extra
@@ -898,6 +1108,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args.workload)
             print(json.dumps(line), flush=True)
 
+    _RANKS["emit"] = emit                          # from here on a SIGTERM prints the real line (rank 0; emit() prints once)
     if "_gather_legs" in res:                      # last: the first RCCL collective of the process
         # Nothing with N > 1 has ever run on RCCL where this file was written: should the legs hang (they come after
         # everything timed), the headline line must still come out -- a watchdog in every rank reports the time-out on
@@ -919,7 +1130,9 @@ def main():
     emit()
 
     if use_dist:
-        dist.all_reduce(torch.zeros(1))
+        _collective(lambda: dist.all_reduce(torch.zeros(1)))
+        if _RANKS["broken"]:
+            os._exit(1 if rank else 0)             # (no orderly shutdown with a dead peer: rank 0 has printed its line)
         dist.destroy_process_group()
 
 

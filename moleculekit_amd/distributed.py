@@ -267,18 +267,19 @@ class ShardedVoxelizer:
     def gather(self, local, dst=None):
         return gather_features(local, self.bounds, group=self.group, dst=dst) if self._collectives() else local
 
-    def voxelize_gather(self, nchunks=4, dst=None, timings=None, exchange="auto"):
+    def voxelize_gather(self, nchunks=4, dst=None, timings=None, exchange="auto", loopback=False):
         """Voxelize the shard chunk by chunk and gather every finished chunk on a communication stream while the next
         one is computed.  Returns the full float32 [B, V, C] tensor on every rank (``dst=None``: all-gather) or on
         ``dst`` only (others get None).
 
-        ``exchange="p2p"`` (what ``"auto"`` picks for an all-gather of equal shards -- the weak-scaling case): every
-        rank computes STRAIGHT INTO its own rows of the result, and each chunk travels as one batch of point-to-point
-        sends / receives between the rows' final positions -- no staging tensor, no second pass over the gathered data,
-        and on the xGMI mesh (every GPU wired to every other) all seven links of a GPU carry a chunk at once, where a
-        ring all-gather moves it over one link seven times.  ``exchange="allgather"`` (ragged shards, gather-to-root):
-        chunks are padded to the largest chunk of any rank so that each step is one equal-sized collective, received into
-        a staging tensor and copied to their final rows."""
+        ``exchange="p2p"`` (what ``"auto"`` picks for an all-gather, equal or ragged shards): every rank computes
+        STRAIGHT INTO its own rows of the result, and each chunk travels as one batch of point-to-point sends / receives
+        between the rows' final positions -- no staging tensor, no padding, no second pass over the gathered data, and on
+        the xGMI mesh (every GPU wired to every other) all seven links of a GPU carry a chunk at once, where a ring
+        all-gather moves it over one link seven times.  ``exchange="allgather"`` (what gather-to-root takes): chunks are
+        padded to the largest chunk of any rank so that each step is one equal-sized collective, received into a staging
+        tensor and copied to their final rows.  ``loopback``: with ONE rank the point-to-point batch is sent to the rank
+        itself and checked (a 1-GPU box exercises the exchange code on RCCL that way); ``self.last_exchange`` names what ran."""
         import torch
         import torch.distributed as dist
 
@@ -286,11 +287,11 @@ class ShardedVoxelizer:
             return self.voxelize()
         ws, rank = self.world, self.rank
         sizes = np.diff(self.bounds)
-        equal = bool(np.all(sizes == sizes[0]))
         if exchange == "auto":
-            exchange = "p2p" if (dst is None and equal) else "allgather"
-        if exchange == "p2p" and not (dst is None and equal):
-            raise ValueError("the point-to-point exchange needs equal shards and an all-gather (dst=None)")
+            exchange = "p2p" if dst is None else "allgather"
+        if exchange == "p2p" and dst is not None:
+            raise ValueError("the point-to-point exchange is an all-gather (dst=None)")
+        self.last_exchange = exchange
         cb = [chunk_bounds(int(s), nchunks) for s in sizes]               # per rank: its chunk boundaries (same count)
         tail = (self.V, self.C)
         cuda = self.device.type == "cuda"
@@ -298,14 +299,16 @@ class ShardedVoxelizer:
         main = torch.cuda.current_stream(self.device) if cuda else None
 
         if exchange == "p2p":
-            S = int(sizes[0])
-            full = torch.empty((ws, S) + tail, dtype=torch.float32, device=self.device)     # [rank][item]: the final layout
+            # every rank computes STRAIGHT INTO its own rows of the result; chunk c of rank r belongs at rows
+            # bounds[r] + cb[r][c] .. bounds[r] + cb[r][c+1] on every rank (shards and chunks may be ragged: both sides of a
+            # transfer know its size from the partition, an empty chunk is skipped by both)
+            full = torch.empty((self.n_items,) + tail, dtype=torch.float32, device=self.device)
+            row = lambda r, c: int(self.bounds[r] + cb[r][c])
             for c in range(len(cb[rank]) - 1):
                 lo, hi = int(cb[rank][c]), int(cb[rank][c + 1])
-                if hi == lo:
-                    continue
-                self._run(*self._items(lo, hi), out=full[rank, lo:hi])
-                if ws == 1:
+                if hi > lo:
+                    self._run(*self._items(lo, hi), out=full[row(rank, c):row(rank, c + 1)])
+                if ws == 1 and not loopback:
                     continue
                 ev = None
                 if cuda:
@@ -314,17 +317,28 @@ class ShardedVoxelizer:
                 with (torch.cuda.stream(comm) if cuda else _null()):
                     if cuda:
                         comm.wait_event(ev)
-                    ops = []
+                    ops, check = [], None
                     for k in range(1, ws):                                # staggered peers: rank r starts with r + 1
                         to, frm = (rank + k) % ws, (rank - k) % ws
-                        ops.append(dist.P2POp(dist.isend, full[rank, lo:hi], self._global_rank(to), group=self.group))
-                        ops.append(dist.P2POp(dist.irecv, full[frm, lo:hi], self._global_rank(frm), group=self.group))
-                    for req in dist.batch_isend_irecv(ops):
-                        req.wait()
+                        if hi > lo:
+                            ops.append(dist.P2POp(dist.isend, full[row(rank, c):row(rank, c + 1)], self._global_rank(to), group=self.group))
+                        if cb[frm][c + 1] > cb[frm][c]:
+                            ops.append(dist.P2POp(dist.irecv, full[row(frm, c):row(frm, c + 1)], self._global_rank(frm), group=self.group))
+                    if ws == 1 and hi > lo:
+                        # one rank (a 1-GPU box under torchrun): the same batched send / receive, to itself, into a scratch
+                        # tensor that must come back equal -- the exchange code touches the communicator at least once
+                        check = torch.empty_like(full[row(rank, c):row(rank, c + 1)])
+                        ops = [dist.P2POp(dist.isend, full[row(rank, c):row(rank, c + 1)], self._global_rank(rank), group=self.group),
+                               dist.P2POp(dist.irecv, check, self._global_rank(rank), group=self.group)]
+                    if ops:
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()
+                    if check is not None and not torch.equal(check, full[row(rank, c):row(rank, c + 1)]):
+                        raise RuntimeError("loopback exchange returned different data")
             if cuda:
                 main.wait_stream(comm)
                 full.record_stream(comm)
-            return full.view((self.n_items,) + tail)
+            return full
 
         want = dst is None or rank == dst
         full = torch.empty((self.n_items,) + tail, dtype=torch.float32, device=self.device) if want else None

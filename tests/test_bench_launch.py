@@ -75,3 +75,20 @@ def test_algorithmic_bytes_are_survey_8d():
     r = bench.roofline_of({"k_ms": 4.0, "k_n": 2, "alg": 2 * 10_588_608}, "cfg2", 2, 0)
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["achieved"] - 2 * 10_588_608 / 2e-3 / 1e9) < 0.01 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
+
+
+def test_rank_0_prints_its_line_when_another_rank_dies():
+    """Round 4: `python bench.py --gpus N` must leave a JSON line from rank 0 even if another rank dies in the timed region
+    (nothing has run with N > 1 on RCCL yet).  Dry run, gloo: rank 1 exits hard right after its timed steps
+    (MKAMD_BENCH_KILL_RANK) -- rank 0's closing fence fails or the launcher's SIGTERM arrives, whichever is first; either
+    way its line comes out, says `ranks_alive` = 1 and why, and the launcher reports failure."""
+    env = dict(os.environ, MKAMD_BENCH_KILL_RANK="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = lines[0]
+    assert d["ok"] is False and d["n_gpus"] == 2 and d["ranks_alive"] == 1 and d["degraded"]

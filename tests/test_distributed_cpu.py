@@ -77,31 +77,48 @@ def _worker(rank, world, port, B, q):
                 ok = ok and np.array_equal(eq.voxelize_gather(nchunks=nchunks).numpy(), ref)
                 ok = ok and np.array_equal(eq.voxelize_gather(nchunks=nchunks, exchange="allgather").numpy(), ref)
             ok = ok and np.array_equal(eq.gather(eq.voxelize()).numpy(), ref)
-        else:
-            try:
-                sv.voxelize_gather(nchunks=2, exchange="p2p")
-                ok = False
-            except ValueError:
-                pass
+        # ragged shards (balanced by atoms): since round 4 the point-to-point exchange takes them too (both ends of a transfer
+        # know its size from the partition; an empty chunk is skipped by both) -- it is what "auto" picks for an all-gather
+        for nchunks in (1, 3):
+            got = sv.voxelize_gather(nchunks=nchunks, exchange="p2p")
+            ok = ok and sv.last_exchange == "p2p" and np.array_equal(got.numpy(), ref)
+            ok = ok and np.array_equal(sv.voxelize_gather(nchunks=nchunks, exchange="allgather").numpy(), ref) and sv.last_exchange == "allgather"
+        try:
+            sv.voxelize_gather(nchunks=2, exchange="p2p", dst=0)          # the point-to-point exchange is an all-gather
+            ok = False
+        except ValueError:
+            pass
         q.put((rank, bool(ok), [int(b) for b in bounds]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [7, 8, 2, 1])
-def test_sharded_voxelization_world2_gloo(B):
+def _run_world(world, B):
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     b = res[0][2]
-    assert b[0] == 0 and b[-1] == B and len(b) == 3
+    assert b[0] == 0 and b[-1] == B and len(b) == world + 1
+
+
+@pytest.mark.parametrize("B", [7, 8, 2, 1])
+def test_sharded_voxelization_world2_gloo(B):
+    _run_world(2, B)
+
+
+@pytest.mark.parametrize("B", [11, 3])
+def test_sharded_voxelization_world4_gloo(B):
+    """Four ranks (round 4): every rank exchanges with THREE peers per chunk -- the batched isend / irecv pattern of the
+    8-GPU run, where gloo runs with two ranks proved little; 11 ragged molecules over 4 ranks (shards of 2-4 items, chunks
+    of 0-2), and 3 items over 4 ranks (an empty shard: a rank that only receives)."""
+    _run_world(4, B)
