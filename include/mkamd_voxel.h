@@ -199,14 +199,17 @@ int mkamd_voxelize_lattice_host_f64(mkamd_ctx* ctx, int32_t n_items, const float
 /* The same call in two halves, for a caller with host work of its own to do while the device computes (the drop-in
  * getVoxelDescriptors copies its cached voxel centres there, voxeldescriptors.py:245-247): `begin` checks the arguments,
  * ships the inputs and enqueues the kernels (the input arrays must stay valid until `end`); `end` waits and writes the
- * result into ONE of the two arrays (the other NULL).  One call at a time per context; a `begin` that is never ended is
- * abandoned by the next `begin`. */
+ * result into ONE of the two arrays (the other NULL) of `n_values` elements -- which must be the n_items * n_voxels *
+ * n_channels values the pending call produced (else MKAMD_EINVAL, nothing is written, the call is abandoned).  One call at
+ * a time per context; a `begin` that is never ended is abandoned by the next `begin`; between the two halves only queries,
+ * mkamd_grid_centers_*, mkamd_copy_to_host and mkamd_frames_to_items_dev are accepted on the context -- any other entry
+ * point would regrow or overwrite what `end` hands back and returns MKAMD_EINVAL. */
 int mkamd_voxelize_lattice_host_begin(mkamd_ctx* ctx, int32_t n_items, const float* coords,
                                       const int64_t* atom_offsets, const void* sigmas,
                                       int sigmas_are_f64, int32_t n_channels, const double* origins,
                                       const int32_t* nvoxels, double voxelsize, const float* box,
                                       int32_t max_images_per_atom);
-int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64);
+int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64, uint64_t n_values);
 int mkamd_voxelize_lattice_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_coords,
                                const int64_t* d_atom_offsets, int64_t total_atoms,
                                const void* d_sigmas, int sigmas_are_f64, int32_t n_channels,
@@ -238,6 +241,13 @@ int mkamd_prefault(void* buffer, uint64_t bytes);
 /* Synchronous device -> host copy on the context's stream (hipMemcpyAsync + wait): what the _host entry points use for
  * their results, for callers of the _dev entry points that collect chunks into a host array. */
 int mkamd_copy_to_host(mkamd_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes);
+/* Trajectory slab -> packed items, on the device, on a stream of the CALLER's choice (a copy stream: batch._stream_voxelize
+ * prepares chunk k+1 there while chunk k is voxelized): `d_src` holds `rows` rows (atoms x 3 of Molecule.coords, or the 3 box
+ * lengths) of `src_pitch` floats each, frame fastest; frames [0, n_frames) of it are written frame-major,
+ * d_dst[f * rows + r] = d_src[r * src_pitch + f] * scale (one float32 multiply: nm -> Angstrom for XTC input, 1 otherwise).
+ * Replaces reader-side work of readers.py:1848-1859 (the x10 of XTCread) and the host transpose of a [N,3,F] slab. */
+int mkamd_frames_to_items_dev(mkamd_ctx* ctx, void* hip_stream, const float* d_src, int64_t rows, int64_t src_pitch,
+                              int64_t n_frames, float scale, float* d_dst);
 
 /* (5) the inverse, on the host (no context, no GPU): is `centers` float64 [V,3] a getCenters lattice -- bb_min +
  * fl64(index * voxelsize), x slowest / z fastest (voxeldescriptors.py:125-132, :245-247) -- to 1e-9 A?  Returns 1 and

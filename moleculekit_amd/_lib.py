@@ -42,6 +42,7 @@ SIGNATURES = {
     "mkamd_ctx_withdraw_promise": (_c_int, [_vp]),
     "mkamd_ctx_pipelined_calls": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
     "mkamd_ctx_last_tile_kernel": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "mkamd_frames_to_items_dev": (_c_int, [_vp, _vp, _vp, _c_i64, _c_i64, _c_i64, ctypes.c_float, _vp]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
@@ -57,7 +58,7 @@ SIGNATURES = {
     "mkamd_voxelize_lattice_host_f64": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl,
                                                  _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_host_begin": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl, _vp, _c_i32]),
-    "mkamd_voxelize_lattice_host_end": (_c_int, [_vp, _vp, _vp]),
+    "mkamd_voxelize_lattice_host_end": (_c_int, [_vp, _vp, _vp, ctypes.c_uint64]),
     "mkamd_voxelize_lattice_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
                                             _c_dbl, _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_aug_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
@@ -246,6 +247,11 @@ class Context:
         """Drop a promise no call has consumed."""
         _check(load().mkamd_ctx_withdraw_promise(self._h))
 
+    def frames_to_items_dev(self, stream, d_src, rows, src_pitch, n_frames, scale, d_dst):
+        """[rows][frames] (frame fastest, pitch ``src_pitch``) -> [frames][rows] * scale on ``stream`` (include/mkamd_voxel.h)."""
+        _check(load().mkamd_frames_to_items_dev(self._h, int(stream) or None, int(d_src), int(rows), int(src_pitch), int(n_frames),
+                                                float(scale), int(d_dst)))
+
     def last_tile_kernel(self) -> str:
         """Name of the tile kernel the last lattice call launched, as rocprofv3 prints it ('' before the first call)."""
         buf = ctypes.create_string_buffer(128)
@@ -302,11 +308,14 @@ class Context:
                                                         _ptr(origins), _ptr(nvox), float(voxelsize), _ptr(box), int(max_images)))
 
     def voxelize_lattice_host_end(self, out):
-        """Second half: wait, result into `out` (float32 or float64, C-contiguous, B*V*C elements)."""
+        """Second half: wait, result into `out` (float32 or float64, C-contiguous, B*V*C elements -- checked here and, the
+        element count, by the library against what the pending call produced: it writes through a bare pointer)."""
+        if not isinstance(out, np.ndarray) or out.dtype not in (np.float32, np.float64) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 or float64 ndarray")
         if out.dtype == np.float64:
-            _check(load().mkamd_voxelize_lattice_host_end(self._h, None, _ptr(out)))
+            _check(load().mkamd_voxelize_lattice_host_end(self._h, None, _ptr(out), int(out.size)))
         else:
-            _check(load().mkamd_voxelize_lattice_host_end(self._h, _ptr(out), None))
+            _check(load().mkamd_voxelize_lattice_host_end(self._h, _ptr(out), None, int(out.size)))
 
     def voxelize_lattice_dev(self, B, d_coords, d_offsets, total_atoms, d_sigmas, sig_f64, C, d_origins, nvox,
                              voxelsize, d_box, max_images, d_out, d_affine=None):

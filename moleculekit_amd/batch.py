@@ -88,6 +88,9 @@ def voxelize_lattice_begin(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     waits and hands back features [B, V, C] of ``dtype`` (float32, or float64: widened by the library).  Host work done
     between the two runs beside the device (the drop-in getVoxelDescriptors copies its voxel centres there)."""
     ctx = ctx or _lib.default_context()
+    dtype = np.dtype(dtype)
+    if dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError("dtype must be float32 or float64 (the library writes 4- or 8-byte floats into the result)")
     coords = np.ascontiguousarray(coords, dtype=np.float32).reshape(-1, 3)
     atom_offsets = np.ascontiguousarray(atom_offsets, dtype=np.int64)
     sigmas, sig64 = _sigma_array(sigmas)
@@ -405,13 +408,12 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
                     if has_box:
                         d_slab_box[slot][:3 * n].copy_(hb.reshape(-1), non_blocking=True)
                     free[slot].record(copy)
-                    xyz.copy_(slab.view(N, 3, n).permute(2, 0, 1))                        # frame-major, on the device
+                    # frame-major and in Angstrom, by the library's transposing kernel on THIS stream (whole lines on both sides)
+                    run_ctx.frames_to_items_dev(copy.cuda_stream, slab.data_ptr(), 3 * N, n, n, scale, xyz.data_ptr())
                     if has_box:
-                        d_bx[slot][:n].copy_(d_slab_box[slot][:3 * n].view(3, n).t())
+                        run_ctx.frames_to_items_dev(copy.cuda_stream, d_slab_box[slot].data_ptr(), 3, n, n, 1.0, d_bx[slot].data_ptr())
                 else:
-                    images[slot] = fill_dev(xyz, d_bx[slot][:n] if has_box else None, idx) or max_images
-                if scale != 1.0:
-                    xyz.mul_(scale)
+                    images[slot] = fill_dev(copy, xyz, d_bx[slot][:n] if has_box else None, idx) or max_images
                 ready[slot].record(copy)
             return idx
 
@@ -503,13 +505,20 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
         if box is not None and box_t is None:
             box_t = torch.as_tensor(box, device=coords.device)
 
-        def fill_dev(xyz, bx, idx):                               # on the copy stream of _stream_voxelize
+        cctx = ctx or _lib.default_context(coords.device.index if coords.device.index is not None else 0)
+        F_all = int(coords.shape[2])
+        if not coords.is_contiguous():
+            coords = coords.contiguous()
+        if box_t is not None:
+            box_t = box_t.to(torch.float32).contiguous()
+
+        def fill_dev(copy, xyz, bx, idx):                         # inside the copy-stream context of _stream_voxelize
             n = len(idx)
-            if contiguous:
+            if contiguous:                                        # a window of the resident array: the library's transposing kernel
                 f0 = int(idx[0])
-                xyz.copy_(coords[:, :, f0:f0 + n].permute(2, 0, 1))
+                cctx.frames_to_items_dev(copy.cuda_stream, coords.data_ptr() + 4 * f0, 3 * N, F_all, n, 1.0, xyz.data_ptr())
                 if bx is not None:
-                    bx.copy_(box_t[:, f0:f0 + n].t())
+                    cctx.frames_to_items_dev(copy.cuda_stream, box_t.data_ptr() + 4 * f0, 3, F_all, n, 1.0, bx.data_ptr())
             else:
                 sel = torch.as_tensor(np.asarray(idx, dtype=np.int64), device=coords.device)
                 xyz.copy_(coords.index_select(2, sel).permute(2, 0, 1))

@@ -6,6 +6,7 @@
 #include "../../include/mkamd_distance.h"
 #include "../../include/mkamd_xtc.h"
 #include "xtc_reader.h"
+#include <atomic>
 #include "pipeline.h"
 #include "dist_pipeline.h"
 
@@ -257,9 +258,15 @@ struct mkamd_ctx {
     }
 };
 
-static int check_ctx(mkamd_ctx* ctx)
+// `pending_ok`: the entry point may run between the two halves of a host call (mkamd_voxelize_lattice_host_begin / _end): the
+// halves themselves, and what touches neither the pending call's result buffer nor the workspace it reads (queries, the
+// centre generator, copies out).  Every other entry point would regrow or overwrite what `end` is about to hand back --
+// it is refused, not guessed at.
+static int check_ctx(mkamd_ctx* ctx, bool pending_ok = false)
 {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (!pending_ok && ctx->pending.active)
+        return fail(MKAMD_EINVAL, "a host call begun on this context (mkamd_voxelize_lattice_host_begin) has not been ended: call _end first");
     HIP_TRY(hipSetDevice(ctx->device));
     ctx->stream = ctx->main_stream;           // a failed call may have left the side stream selected
     return 0;
@@ -391,7 +398,7 @@ try {
 
 int mkamd_ctx_synchronize(mkamd_ctx* ctx)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
     HIP_TRY(hipStreamSynchronize(ctx->main_stream));
@@ -400,7 +407,7 @@ try {
 
 int mkamd_ctx_poll_errors(mkamd_ctx* ctx)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     // the dense pass of every lattice call mirrors the device-side flag into pinned host memory: reading it costs
     // nothing and needs no synchronisation; only a raised flag pays for the drain + the precise report
@@ -416,7 +423,7 @@ try {
 int mkamd_ctx_device_info(mkamd_ctx* ctx, char* name, size_t len, int* compute_units,
                           uint64_t* hbm_bytes, char* arch, size_t arch_len)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     hipDeviceProp_t p;
     HIP_TRY(hipGetDeviceProperties(&p, ctx->device));
@@ -552,7 +559,7 @@ try {
 
 int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* launches)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     double tot = 0.0;
@@ -638,7 +645,7 @@ try {
     if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
     if (V == 0 || N == 0) return ctx ? MKAMD_OK : fail(MKAMD_EINVAL, "ctx is NULL");
     if (!results) return fail(MKAMD_EINVAL, "results pointer is NULL");
-    int st0 = check_ctx(ctx);
+    int st0 = check_ctx(ctx, true);
     if (st0) return st0;
     std::vector<float>& tmp = ctx->f32_stage;               // context-owned: no fresh pages to fault in on every call
     // The reference's only caller hands this function a getCenters LATTICE (voxeldescriptors.py:356 via _getOccupancyC):
@@ -898,7 +905,7 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
 static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, double* features64, double* max_into)
 {
     MK_HOST_BEGIN();
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     if (!ctx->pending.active) return fail(MKAMD_EINVAL, "no host call was begun on this context");
     const size_t out_bytes = ctx->pending.out_bytes;
@@ -928,9 +935,13 @@ static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, doubl
     }
     // wait for "tile kernel done" (a read of host memory per poll; gives up after ~1 ms: the stream wait below covers it)
     bool early = false;
-    if (seq != 0u && ctx->tail_reports) {
+    static const bool no_early = [] { const char* e = std::getenv("MKAMD_NO_EARLY_PASS"); return e && e[0] == '1'; }();   // debugging switch
+    if (seq != 0u && ctx->tail_reports && !no_early) {
         const volatile unsigned* fb = ctx->fb_host;
         for (int i = 0; i < 400000 && !early; ++i) early = fb[FB_TILES_DONE] == seq;
+        // the result buffer is coherent, uncached host memory the tile kernel wrote before k_tail (same stream) released its
+        // system-scope fence and raised the word: nothing of the result may be read ahead of the poll
+        std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!mapped_out) prefault_big_result(features64 ? (void*)features64 : (void*)features, features64 ? out_bytes * 2 : out_bytes);
     if (features64) {
@@ -991,9 +1002,15 @@ try {
     return voxelize_lattice_host_begin_impl(ctx, B, coords, atom_offsets, sigmas, sigmas_are_f64, C, origins, nvoxels, voxelsize, box, max_images);
 } MK_API_CATCH
 
-int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64)
+int mkamd_voxelize_lattice_host_end(mkamd_ctx* ctx, float* features, double* features_f64, uint64_t n_values)
 try {
     if (features && features_f64) return fail(MKAMD_EINVAL, "pass ONE result array: float32 or float64");
+    // the array the caller brings must hold exactly what the pending call produced: the library writes B*V*C values into it
+    if (ctx && ctx->pending.active && ctx->pending.out_bytes / 4 != (size_t)n_values) {
+        (void)hipStreamSynchronize(ctx->main_stream);
+        ctx->pending.active = false;
+        return fail(MKAMD_EINVAL, "the result array does not hold n_items * n_voxels * n_channels values (the pending call is abandoned)");
+    }
     return voxelize_lattice_host_end_impl(ctx, features, features_f64, nullptr);
 } MK_API_CATCH
 
@@ -1021,7 +1038,7 @@ try {
 int mkamd_grid_centers_dev(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels, double voxelsize,
                            double* d_centers)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     if (!bb_min || !nvoxels) return fail(MKAMD_EINVAL, "bb_min/nvoxels pointer is NULL");
     const int nv[3] = {nvoxels[0], nvoxels[1], nvoxels[2]};
@@ -1034,7 +1051,7 @@ try {
 int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels, double voxelsize,
                             double* centers)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     if (!bb_min || !nvoxels) return fail(MKAMD_EINVAL, "bb_min/nvoxels pointer is NULL");
     if (nvoxels[0] < 0 || nvoxels[1] < 0 || nvoxels[2] < 0) return fail(MKAMD_EINVAL, "nvoxels must be >= 0");
@@ -1049,9 +1066,29 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+extern "C" int mkamd_frames_to_items_dev(mkamd_ctx* ctx, void* hip_stream, const float* d_src, int64_t rows, int64_t src_pitch,
+                                         int64_t n_frames, float scale, float* d_dst)
+try {
+    int st = check_ctx(ctx, true);
+    if (st) return st;
+    if (rows < 0 || n_frames < 0 || src_pitch < n_frames) return fail(MKAMD_EINVAL, "rows / n_frames must be >= 0 and src_pitch >= n_frames");
+    if (rows == 0 || n_frames == 0) return MKAMD_OK;
+    if (!d_src || !d_dst) return fail(MKAMD_EINVAL, "NULL pointer");
+    const long long gx = (n_frames + 63) / 64, gy = (rows + 63) / 64;
+    if (gy > 65535 * 64LL) return fail(MKAMD_EINVAL, "too many rows");
+    // (rows beyond 65 535 tiles: y-slabs, launched one after the other -- 4 M rows each)
+    for (long long y0 = 0; y0 < gy; y0 += 65535) {
+        const long long ny = gy - y0 < 65535 ? gy - y0 : 65535;
+        hipLaunchKernelGGL(mkamd::k_frames_to_items, dim3((unsigned)gx, (unsigned)ny), dim3(256), 0, (hipStream_t)hip_stream,
+                           d_src + y0 * 64 * src_pitch, rows - y0 * 64, (long long)src_pitch, (long long)n_frames, scale, d_dst + y0 * 64);
+        HIP_TRY(hipGetLastError());
+    }
+    return MKAMD_OK;
+} MK_API_CATCH
+
 extern "C" int mkamd_copy_to_host(mkamd_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes)
 try {
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     if (bytes == 0) return MKAMD_OK;
     if (!host_dst || !device_src) return fail(MKAMD_EINVAL, "NULL pointer");

@@ -1730,7 +1730,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
 
     // "more sigma classes than the table holds": for a call-wide table (one hot line) this is checked up front; a
     // per-item table is a fresh line per item, so the check waits until the first traversal has hidden the load
+#ifdef MK_DIAG_NO_GENERAL      // A-B build (docs/EXPERIMENTS_r4.md): without the general path the candidate runs need not stay alive across the
+                              // class loops -- what the register-capped instance spills (24 bytes: three dwords stored once per tile)
+    constexpr bool general = false;
+#else
     bool general = !DENSE && (g.force_general || (!g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY));
+#endif
     const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
     const float4* __restrict__ w0p = rec_w + (size_t)(gq * 2 + 0) * g.M;
     const float4* __restrict__ w1p = rec_w + (size_t)(gq * 2 + 1) * g.M;
@@ -1840,9 +1845,13 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         mk_block_sync();
         const unsigned nsv = TEAM > 1 ? mk_uniform(s_nsv) : 0u;             // the same in every wave of the team
         const bool use_sv = TEAM > 1 && nsv <= (unsigned)SV_CAP;
+#ifdef MK_DIAG_NO_GENERAL
+        {
+#else
         if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
             general = true;                      // this item alone has too many classes (its records carry w, not ids)
         } else {
+#endif
         MK_PHASE_MARK(1);                                   // traversal 1 (histogram)
         // ---- bucket starts: lane owns groups 2*lane, 2*lane+1 (3 sub-buckets each); every sub-bucket
         //      is padded to an even count so the pair loop never straddles two of them ----
@@ -2915,6 +2924,8 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
             // A small synchronous host call converts / copies the result on the host; it starts as soon as the TILE kernel is
             // done -- this launch starting says so -- instead of waiting for this launch and the stream's completion signal
             // too, and repeats the pass in the rare case that this launch changes values (dense tiles, exact cut-off hits).
+            // (system scope: the tile kernel's stores into the mapped result buffer are ordered before the word the host polls)
+            mk_threadfence_system();
             if (n != 0u) feedback[FB_TAIL_WROTE] = seq;
             feedback[FB_TILES_DONE] = seq;
 #pragma unroll
@@ -3058,6 +3069,33 @@ MK_KERNEL(256) void k_sigma_to_w(const SigT* __restrict__ sigmas, long long N, i
         }
         w[(size_t)(gq * 2 + 0) * N + a] = make_float4(t[0], t[1], t[2], t[3]);
         w[(size_t)(gq * 2 + 1) * N + a] = make_float4(t[4], t[5], t[6], t[7]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Trajectory slab -> packed items (batch._stream_voxelize): frames of Molecule.coords
+// ([rows = atoms x 3][frames], frame fastest, row pitch `src_pitch` floats) become frame-major items
+// ([frames][rows]), scaled on the way (XTC stores nm).  A 64 x 64 tile through LDS (65-float pitch: conflict-free):
+// read with lanes along frames, written with lanes along rows -- both sides whole 256-byte segments.  The same kernel
+// turns the box lengths ([3][frames]) into [frames][3] (rows = 3).  One float32 multiply per value: torch's
+// `x.mul_(scale)` bits.
+// ------------------------------------------------------------------------------------------------
+MK_KERNEL(256) void k_frames_to_items(const float* __restrict__ src, long long rows, long long src_pitch, long long nframes,
+                                      float scale, float* __restrict__ dst)
+{
+    __shared__ float tile[64][65];
+    const long long f0 = (long long)blockIdx.x * 64, r0 = (long long)blockIdx.y * 64;
+    const int a = threadIdx.x & 63, b = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long long r = r0 + b + 4 * i, f = f0 + a;
+        if (r < rows && f < nframes) tile[b + 4 * i][a] = src[r * src_pitch + f] * scale;
+    }
+    mk_block_sync();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const long long f = f0 + b + 4 * i, r = r0 + a;
+        if (f < nframes && r < rows) dst[f * rows + r] = tile[a][b + 4 * i];
     }
 }
 

@@ -78,6 +78,7 @@ MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
 
 // device-scope fence: this thread's earlier writes are visible to every CU before its later ones (and vice versa for reads)
 MK_DEV void mk_threadfence() { __threadfence(); }
+MK_DEV void mk_threadfence_system() { __threadfence_system(); }   // release / acquire at system scope (host-visible memory)
 MK_DEV void mk_sleep() { __builtin_amdgcn_s_sleep(8); }
 
 // the lanes of ONE wave have all passed this point and see each other's LDS writes (a wave's LDS operations complete in

@@ -272,6 +272,8 @@ def _occupancyLatticeBegin(coords, channelsigmas, lattice):
 
 
 _LAST_LATTICE = {}          # number of centres -> (nvoxels, voxelsize) of the last lattice recognised in an array of that length
+_GUESS_HOLD = {}       # length -> calls still to go without a guess (after mis-guesses)
+_GUESS_MISSES = {}     # length -> mis-guesses in a row
 
 
 def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
@@ -297,8 +299,14 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
         # the answer is nearly always what it was for the last array of this length, shifted to this array's first centre.
         # So the kernels are started on that guess, the centres are checked WHILE the device computes, and only a wrong
         # guess (a different grid of the same size, centres that are no lattice) is thrown away and done again.
-        guess = _LAST_LATTICE.get(centers.shape[0])
+        nkey = centers.shape[0]
+        guess = _LAST_LATTICE.get(nkey)
         finish = None
+        with _CENTERS_LOCK:
+            hold = _GUESS_HOLD.get(nkey, 0)
+            if hold > 0:                                   # this length mis-guessed lately (grids of the same size that alternate,
+                _GUESS_HOLD[nkey] = hold - 1               # steps that differ in the last bit): no guessing for a while
+                guess = None
         if guess is not None:
             first = centers[0].copy()
             try:
@@ -306,16 +314,27 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
             except Exception:                              # noqa: BLE001 -- the guess is only a guess: the plain way below
                 finish = None
         if finish is not None:
+            rec_err, features = None, None
             try:
                 lattice = _recognise_lattice(centers)
-            finally:
+            except Exception as e:                         # noqa: BLE001 -- raised below, once the speculative call has been collected
+                lattice, rec_err = None, e
+            try:
                 features = finish()
-            if (lattice is not None and np.array_equal(lattice[0], first) and np.array_equal(lattice[1], guess[0])
-                    and lattice[2] == guess[1]):
+            except Exception:                              # noqa: BLE001 -- a failed GUESS is not this call's failure: the plain way below
+                features = None
+            if rec_err is not None:
+                raise rec_err
+            if (features is not None and lattice is not None and np.array_equal(lattice[0], first)
+                    and np.array_equal(lattice[1], guess[0]) and lattice[2] == guess[1]):
+                with _CENTERS_LOCK:
+                    _GUESS_MISSES.pop(nkey, None)
                 return features
-            del features                                   # a wrong guess: the call below does it with what was found,
-            with _CENTERS_LOCK:                            # and arrays of this length are not guessed at until one is a lattice again
-                _LAST_LATTICE.pop(centers.shape[0], None)
+            del features                                   # a wrong guess: the call below does it with what was found; every
+            with _CENTERS_LOCK:                            # further miss in a row doubles the calls this length goes unguessed
+                _LAST_LATTICE.pop(nkey, None)
+                m = _GUESS_MISSES[nkey] = min(_GUESS_MISSES.get(nkey, 0) + 1, 6)
+                _GUESS_HOLD[nkey] = (1 << m) - 2           # 0, 2, 6, 14, 30, 62 calls
         else:
             lattice = _recognise_lattice(centers)
         if lattice is not None:

@@ -212,6 +212,7 @@ MK_DEV float mk_abs(float a) { return fabsf(a); }
 MK_DEV float mk_max(float a, float b) { return fmaxf(a, b); }
 MK_DEV float mk_min3(float m, float a, float b) { return fminf(fminf(a, b), m); }
 MK_DEV void mk_threadfence() {}
+MK_DEV void mk_threadfence_system() {}
 MK_DEV void mk_sleep() {}
 MK_DEV unsigned mk_uniform(unsigned v) { return v; }
 typedef float mk_f2 __attribute__((vector_size(8)));

@@ -97,3 +97,24 @@ def test_driver_takes_openbabel_properties_and_applies_the_hip_rule():
     except ImportError:
         with pytest.raises(RuntimeError, match="OpenBabel"):
             atomtyper.getPDBQTAtomTypesAndCharges(mol, validitychecks=False)
+
+
+def test_segment_count_check_is_skipped_loudly_where_the_prediction_cannot_place_a_residue(monkeypatch):
+    """Round 4 (ADVICE): `predicted_segments` raises NotImplementedError for residues its array-level rules cannot place
+    (nucleic residues; a residue that counts as protein by its bonded backbone cluster but carries no N / CA / C names) --
+    molecules that pass the reference's checks must not fail getChannels for that: the segment-count check is skipped with
+    a RuntimeWarning, every other check still runs, the channels come out as before."""
+    mol = mol_like(G, atomtype=G["atomtype"], charge=G["charge"])
+
+    def cannot(*a, **k):
+        raise NotImplementedError("segments of non-polymer molecules (split by bonded components) are not predicted here")
+
+    monkeypatch.setattr(atomtyper, "predicted_segments", cannot)
+    with pytest.warns(RuntimeWarning, match="segment-count check skipped"):
+        chan, _ = channels.getChannels(mol, version=2, validitychecks=True)
+    assert np.array_equal(chan, G["ref_channels"])
+    # the checks behind it still bite: no hydrogens
+    noh = mol_like(G, atomtype=G["atomtype"], charge=G["charge"])
+    noh.element = np.where(G["element"] == "H", "D", G["element"])
+    with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="No hydrogens found"):
+        atomtyper.atomtypingValidityChecks(noh)

@@ -398,3 +398,32 @@ def test_promised_calls_and_the_streaming_drivers_are_pipelined_and_bitwise_equa
     for k, v in res.items():
         assert np.array_equal(v, want), k
     assert want.max() > 0.5
+
+
+def test_host_call_halves_are_guarded(hip_ctx):
+    """Round 4 (ADVICE): `end` writes through a bare pointer -- the array must be float32 / float64, C-contiguous and hold exactly
+    the pending call's B*V*C values (the library checks the count itself); and between `begin` and `end` the context refuses
+    every entry point that would regrow or overwrite what `end` hands back, while queries and the centre generator pass."""
+    from moleculekit_amd import batch
+    g = golden("cfg1_3ptb.npz")
+    o, nv = grid_origin(g["center"], g["boxsize"], float(g["voxelsize"]))
+    args = (g["coords"], np.array([0, len(g["coords"])]), g["sigmas"], o[None], nv, float(g["voxelsize"]))
+    ref = batch.voxelize_lattice(*args, ctx=hip_ctx)
+    with pytest.raises(ValueError, match="float32 or float64"):
+        batch.voxelize_lattice_begin(*args, ctx=hip_ctx, dtype=np.float16)
+    batch.voxelize_lattice_begin(*args, ctx=hip_ctx)
+    with pytest.raises(ValueError):
+        hip_ctx.voxelize_lattice_host_end(np.empty(ref.size, dtype=np.int32))           # not a float array
+    with pytest.raises(ValueError, match="does not hold"):
+        hip_ctx.voxelize_lattice_host_end(np.empty(ref.size - 8, dtype=np.float32))      # too small: refused by the library
+    with pytest.raises(ValueError, match="no host call was begun"):                      # ... and the call was abandoned
+        hip_ctx.voxelize_lattice_host_end(np.empty_like(ref))
+    end = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)
+    with pytest.raises(ValueError, match="has not been ended"):
+        batch.voxelize_lattice(*args, ctx=hip_ctx)                                       # would reuse the mapped result buffer
+    with pytest.raises(ValueError, match="has not been ended"):
+        batch.occupancy_centers(np.zeros((4, 3)), g["coords"], g["sigmas"], ctx=hip_ctx)
+    cen = batch.grid_centers(o, nv, float(g["voxelsize"]), ctx=hip_ctx)                  # allowed: touches neither
+    hip_ctx.poll_errors()
+    assert np.array_equal(end(), ref) and cen.shape == (int(np.prod(nv)), 3)
+    assert np.array_equal(batch.voxelize_lattice(*args, ctx=hip_ctx), ref)
