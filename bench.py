@@ -284,17 +284,18 @@ def bench_distances(args, emit=True):
     # leg, periodic by chain -- whose result stays in `out` for the bit-exactness check below
     ndist = F * n1 * n2
     alg = ndist * 4 + (n1 + n2) * 3 * F * 4 + 3 * F * 4
-    np_elapsed, np_ms = timed(False)
+    only = os.environ.get("MKAMD_DIST_ONLY", "")           # profiling passes: "periodic" / "nonperiodic" = that leg alone (one kernel variant per pass)
+    np_elapsed, np_ms = timed(False) if only != "periodic" else (1.0, 1.0)
     nonperiodic = {"value": round(ndist * args.steps / np_elapsed / 1e6, 1), "unit": "Mdist/s", "ms_per_step": round(np_elapsed / args.steps * 1e3, 4),
                    "roofline": {"bound": "hbm", "achieved": round(alg / np_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": "k_dist_pairs", "kernel_avg_ms": round(np_ms, 5)}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and only != "periodic":
         from oracle import oracle
         Fs = min(16, F)
         ref = oracle.dist_trajectory(coords[:, :, :Fs].contiguous().cpu().numpy(), box[:, :Fs].contiguous().cpu().numpy(), s1, s2, chains_h, False, False)
         if not np.array_equal(out[:Fs].cpu().numpy(), ref):
             raise SystemExit("dist_trajectory (pbc = False) on the GPU is not bit-exact with the oracle")
-    elapsed, k_ms = timed(True)
+    elapsed, k_ms = timed(True) if only != "nonperiodic" else (np_elapsed, np_ms)
     line = {"metric": "Mdist/s (dist_trajectory, periodic by chain)", "value": round(ndist * args.steps / elapsed / 1e6, 1),
             "unit": "Mdist/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
@@ -366,32 +367,42 @@ def bench_stream_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     sig = np.ascontiguousarray(p["sigmas"][:N], dtype=np.float32)
 
     def run():
-        n = 0
+        n, marks = 0, []
         for idx, feats in batch.iterVoxelizeTrajectory(src, sig, p["centers"][0], p["boxsize"], p["voxelsize"], box=box, chunk=chunk, ctx=ctx):
             n += len(idx)
             del feats
+            ev = torch.cuda.Event(enable_timing=True)      # behind this call's tile kernel on the consumer's stream
+            ev.record()
+            marks.append(ev)
         torch.cuda.synchronize(dev)
-        return n
+        return n, marks
 
     run()
     n0 = ctx.pipelined_calls()
     t0 = time.perf_counter()
-    n = run()
+    n, marks = run()
     dt = time.perf_counter() - t0
     ms_chunk = dt / (n / chunk) * 1e3
+    # the cadence of the calls once the pipeline is full (first call's pre-pass, the generator's set-up and its final wait aside)
+    steady = marks[0].elapsed_time(marks[-1]) / (len(marks) - 1) if len(marks) > 1 else None
     V = int(np.prod(np.ceil(p["boxsize"] / p["voxelsize"]).astype(int)))
     out = {"frames": n, "frames_per_call": chunk, "frames_per_s": round(n / dt, 1), "ms_per_call": round(ms_chunk, 4),
+           "steady_ms_per_call": round(steady, 4) if steady else None,
            "value": round(n * V * 8 / dt / 1e6, 2), "unit": "Mvoxel-channels/s", "pipelined_calls": ctx.pipelined_calls() - n0,
-           "source": "device-resident [N,3,F] float32 tensor", "driver": "batch.iterVoxelizeTrajectory (promised inputs, include/mkamd_voxel.h)"}
+           "source": "device-resident [N,3,F] float32 tensor", "driver": "batch.iterVoxelizeTrajectory (promised inputs, include/mkamd_voxel.h)",
+           "note": "ms_per_call = the whole pass (generator set-up, the first call's exposed pre-pass, the final wait) / calls; "
+                   "steady_ms_per_call = HIP events behind consecutive calls"}
     if raw_ms_per_step:
         out["raw_pipelined_cfg4_ms_per_step"] = raw_ms_per_step
         out["over_raw_step"] = round(ms_chunk / raw_ms_per_step, 4)
+        if steady:
+            out["steady_over_raw_step"] = round(steady / raw_ms_per_step, 4)
     del src
     torch.cuda.empty_cache()
     return out
 
 
-def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=1024, chunk=256):
+def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     """Secondary leg `xtc_cfg4`: the cfg4 FEEDER -- a synthetic 30 000-atom XTC trajectory (64 frames of the cfg4 random walk
     written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) decoded by
     libmkamd.so's host threads straight into pinned staging and voxelized through batch.iterVoxelizeXTC.  Reports the

@@ -645,7 +645,7 @@ try {
     if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
     if (V == 0 || N == 0) return ctx ? MKAMD_OK : fail(MKAMD_EINVAL, "ctx is NULL");
     if (!results) return fail(MKAMD_EINVAL, "results pointer is NULL");
-    int st0 = check_ctx(ctx, true);
+    int st0 = check_ctx(ctx);
     if (st0) return st0;
     std::vector<float>& tmp = ctx->f32_stage;               // context-owned: no fresh pages to fault in on every call
     // The reference's only caller hands this function a getCenters LATTICE (voxeldescriptors.py:356 via _getOccupancyC):
@@ -787,7 +787,7 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
                                             const int32_t* nvoxels, double voxelsize, const float* box, int32_t max_images)
 {
     MK_HOST_BEGIN();
-    int st = check_ctx(ctx);
+    int st = check_ctx(ctx, true);
     if (st) return st;
     if (ctx->pending.active) {                                      // a begin without its end: that call is abandoned
         (void)hipStreamSynchronize(ctx->stream);

@@ -419,8 +419,16 @@ def test_host_call_halves_are_guarded(hip_ctx):
     with pytest.raises(ValueError, match="no host call was begun"):                      # ... and the call was abandoned
         hip_ctx.voxelize_lattice_host_end(np.empty_like(ref))
     end = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)
-    with pytest.raises(ValueError, match="has not been ended"):
-        batch.voxelize_lattice(*args, ctx=hip_ctx)                                       # would reuse the mapped result buffer
+    assert np.array_equal(batch.voxelize_lattice(*args, ctx=hip_ctx), ref)               # a host call is its own begin: the pending one is
+    with pytest.raises(ValueError, match="no host call was begun"):                      # abandoned (documented), its `end` says so
+        end()
+    end = batch.voxelize_lattice_begin(*args, ctx=hip_ctx)
+    import torch
+    dev = torch.device("cuda", hip_ctx.device)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    with pytest.raises(ValueError, match="has not been ended"):                          # the device entry point shares the workspace
+        batch.voxelize_lattice_torch(t(g["coords"], np.float32), t(args[1], np.int64), t(g["sigmas"], np.float32), t(o[None], np.float64),
+                                     nv, float(g["voxelsize"]), ctx=hip_ctx)
     with pytest.raises(ValueError, match="has not been ended"):
         batch.occupancy_centers(np.zeros((4, 3)), g["coords"], g["sigmas"], ctx=hip_ctx)
     cen = batch.grid_centers(o, nv, float(g["voxelsize"]), ctx=hip_ctx)                  # allowed: touches neither

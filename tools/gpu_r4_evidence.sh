@@ -1,0 +1,50 @@
+# tools/gpu_r4_evidence.sh -- round-4 evidence session on one box, on the FINAL build: parity tests, smoke, the default bench line (as
+# the driver runs it) and its in-order twin, the torchrun 1-rank RCCL path, rocprofv3 kernel-trace stats of every workload the line
+# reports, and PMC passes for EVERY one of them (SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE and WRITE_SIZE in passes of their own,
+# every launch a full batch).  tools/collect_profiles_r4.py copies the summaries into profiles/r4_* and stamps them with the
+# library's source hash (bench.py refuses counters of another build).
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+(timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log)
+(timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log)
+(timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_cfg2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2.log)
+(timeout 400 python bench.py --no-cpu-baseline --no-extra --no-pipeline --min-seconds 1 > gpurun_out/bench_cfg2_nopipe.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2_nopipe.log)
+(timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
+rm -rf gpurun_out/prof_* gpurun_out/pmc_*
+PROF="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
+TRACE="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 40 --warmup 5"
+for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py $TRACE --workload $wl > $R/gpurun_out/rocprof_$wl.log 2>&1)
+done
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py $TRACE --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dist -- python $R/bench.py --workload dist --no-cpu-baseline --steps 20 --warmup 3 > $R/gpurun_out/rocprof_dist.log 2>&1)
+pmc() { name=$1; wl=$2; shift; shift; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${wl}_$name -- python $R/bench.py $PROF --workload $wl $PMC_EXTRA > $R/gpurun_out/pmc_${wl}_$name.log 2>&1); }
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_IFETCH"
+for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
+  PMC_EXTRA=""
+  pmc sq1 $wl $SQ1
+  pmc fetch $wl FETCH_SIZE
+  pmc write $wl WRITE_SIZE
+done
+PMC_EXTRA=""
+pmc sq2 cfg2 $SQ2
+pmc icache cfg2 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
+PMC_EXTRA="--no-pipeline"
+pmc nopipe_fetch cfg2 FETCH_SIZE
+pmc nopipe_write cfg2 WRITE_SIZE
+pmc nopipe_sq1 cfg2 $SQ1
+# the distance leg: one kernel variant per pass (MKAMD_DIST_ONLY), SQ + waits + traffic
+dpmc() { name=$1; mode=$2; shift; shift; (cd /tmp && MKAMD_DIST_ONLY=$mode timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_dist_${mode}_$name -- python $R/bench.py --workload dist --no-cpu-baseline --steps 8 --warmup 2 > $R/gpurun_out/pmc_dist_${mode}_$name.log 2>&1); }
+for mode in periodic nonperiodic; do
+  dpmc sq1 $mode $SQ1
+  dpmc sq2 $mode $SQ2
+  dpmc fetch $mode FETCH_SIZE
+  dpmc write $mode WRITE_SIZE
+done
+# the one-molecule call: latencies, the host side of the drop-in call
+(for i in 1 2 3; do timeout 120 python tools/single_latency.py; done > gpurun_out/single_latency.txt 2>&1)
+(timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
+tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
+python tools/collect_profiles_r4.py
