@@ -868,11 +868,12 @@ def roofline_of(res, workload, B, tile_k):
             sec["valu_insts_per_wave"] = round(entry["SQ_INSTS_VALU"] / entry["SQ_WAVES"], 1)
             if kernel and "k_voxelize_tiles" in kernel and "team" not in kernel:
                 sec["valu_insts_per_tile"] = sec["valu_insts_per_wave"]        # one wave per 512-voxel tile
-            clk = entry.get("GRBM_GUI_ACTIVE") or (entry.get("SQ_BUSY_CYCLES", 0) / 32.0)      # shader cycles of the launch
+            # shader cycles of the launch: GRBM_GUI_ACTIVE is summed over the chip's 8 XCDs, SQ_BUSY_CYCLES over its 32 shader engines
+            clk = (entry["GRBM_GUI_ACTIVE"] / 8.0) if entry.get("GRBM_GUI_ACTIVE") else (entry.get("SQ_BUSY_CYCLES", 0) / 32.0)
             if clk and entry.get("SQ_ACTIVE_INST_VALU") is not None:
                 # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the chip's 1 024 SIMDs
                 sec["valu_busy"] = round(entry["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / clk, 3)
-                sec["valu_busy_of"] = "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / " + ("GRBM_GUI_ACTIVE" if entry.get("GRBM_GUI_ACTIVE") else "(SQ_BUSY_CYCLES / 32 shader engines)")
+                sec["valu_busy_of"] = "SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / " + ("(GRBM_GUI_ACTIVE / 8 XCDs)" if entry.get("GRBM_GUI_ACTIVE") else "(SQ_BUSY_CYCLES / 32 shader engines)")
             sec["counters_source"] = src
         out["secondary"] = sec
     except Exception as e:                             # noqa: BLE001 -- a secondary number

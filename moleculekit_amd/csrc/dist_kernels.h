@@ -51,18 +51,57 @@ MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y
 }
 
 constexpr int DT = 64;                 // tile edge (frames and pairs)
+
+// Which tile a workgroup of a 1-D launch of 8 * ceil(T / 8) blocks takes, T tiles numbered frame slab-major (all pair tiles of
+// slab 0, then slab 1, ...): the dispatcher deals consecutive blocks round-robin to the 8 XCDs, so block b runs on XCD b & 7 as
+// its (b >> 3)-th block; XCD c is given the CONTIGUOUS tile range [c * ceil(T / 8), ...).  Every XCD then works through its
+// own frame slabs: the 256-byte row segments its blocks write one after the other are neighbours in memory and leave its L2
+// as long runs of the same DRAM pages (round 4: dealt tile by tile to all XCDs the result was written at 2.5 TB/s -- a
+// store-only build of the kernel took the same 0.32 ms as the real one -- against 6.9 TB/s for a linear fill), and it reads only
+// its own slabs' coordinates.  Placement is a matter of speed only: any block -> XCD rule gives the same result.
+MK_DEV long long xcd_contiguous_tile(long long T)
+{
+    const long long per_xcd = (T + 7) / 8;
+    const long long g = (long long)(blockIdx.x & 7u) * per_xcd + (long long)(blockIdx.x >> 3);
+    return g < T ? g : -1;
+}
 constexpr int DT_THREADS = 256;
 
 // The second half of every tile kernel here: tile[pair][frame] (lanes ran along frames) goes out with lanes along pairs.
 // A wave owns every fourth frame row; a full tile (the common case, block-uniform) reads its 16 values from LDS at
 // once and stores them behind one another, an edge tile checks every element.
-MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long long p0, long long F, long long P, float* __restrict__ out)
+template <int NW = DT_THREADS / DT /* waves of the block */>
+MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long long p0, long long F, long long p_end /* pairs >= this are not stored */,
+                            long long P /* row pitch of `out` */, float* __restrict__ out)
 {
-    constexpr int NW = DT_THREADS / DT, ROWS = DT / NW;
+    constexpr int ROWS = DT / NW;
     const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
     float* __restrict__ o = out + (size_t)(f0 + fq) * (size_t)P + (size_t)(p0 + pl);
     const size_t step = (size_t)NW * (size_t)P;
-    if (f0 + DT <= F && p0 + DT <= P) {
+#ifndef MK_DIST_NO_V4            // A-B builds
+    if (f0 + DT <= F && p0 + DT <= p_end && ((P | p0) & 3) == 0) {
+        // a full tile whose rows start on 16 bytes: FOUR store instructions of 16 bytes per lane instead of sixteen of 4 (the
+        // memory pipeline takes a wave's store instructions one by one: round-4 PMC showed the kernel at the same 0.30 ms with
+        // and without its image arithmetic and with a third of its loads).  A lane owns four consecutive pairs of one frame;
+        // the lanes are dealt so that the 32 lanes the LDS serves together read 32 different banks:
+        // lane -> (pair quad q = lane & 7 | (lane >> 5) << 3, frame r = (lane >> 3) & 3 of a group of four).
+        const int lane = threadIdx.x & (DT - 1);
+        const int q = (lane & 7) | ((lane >> 5) << 3), r = (lane >> 3) & 3;
+        constexpr int NIT = DT / 4 / NW;                             // groups of four frames per wave
+        float4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int fg = (fq + NW * it) * 4 + r;
+            v[it] = make_float4(tile[4 * q][fg], tile[4 * q + 1][fg], tile[4 * q + 2][fg], tile[4 * q + 3][fg]);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int fg = (fq + NW * it) * 4 + r;
+            *reinterpret_cast<float4*>(out + (size_t)(f0 + fg) * (size_t)P + (size_t)(p0 + 4 * q)) = v[it];
+        }
+    } else
+#endif
+    if (f0 + DT <= F && p0 + DT <= p_end) {
         float v[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) v[i] = tile[pl][fq + i * NW];
@@ -70,7 +109,7 @@ MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long 
         for (int i = 0; i < ROWS; ++i) o[(size_t)i * step] = v[i];
     } else {
         for (int i = 0; i < ROWS; ++i)
-            if (f0 + fq + i * NW < F && p0 + pl < P) o[(size_t)i * step] = tile[pl][fq + i * NW];
+            if (f0 + fq + i * NW < F && p0 + pl < p_end) o[(size_t)i * step] = tile[pl][fq + i * NW];
     }
 }
 
@@ -118,6 +157,7 @@ constexpr int DP_BATCH = MK_DP_BATCH;           // (8 was measured too)
 // d^2 of the DP_RUN consecutive pairs [pw, pw + DP_RUN) for this lane's frame (byte offset fb = 4 f into a coordinate
 // row; the host refuses F >= 2^30): emit(k, d2), k = 0 .. DP_RUN-1, called by all lanes.  Pairs past the end repeat
 // the last pair (valid addresses, no divergence) -- the caller drops what they emit.  Needs pw < P.
+// emit(k0, d2[DP_BATCH]): a batch at a time.
 template <class Emit>
 MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned fb, float bx, float by, float bz,
                          const unsigned* __restrict__ pa, const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
@@ -183,8 +223,7 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
             cur_a = a[DP_BATCH - 1];
             xa = A3[DP_BATCH - 1][0]; ya = A3[DP_BATCH - 1][1]; za = A3[DP_BATCH - 1][2];
         }
-#pragma unroll
-        for (int u = 0; u < DP_BATCH; ++u) emit(k0 + u, d2[u]);
+        emit(k0, d2);                                                // the batch's DP_BATCH values at once: emit(first k, d2[DP_BATCH])
     }
     };
     if (small_rows) { if (run_wraps) run_body(DistFlag<true>{}, DistFlag<true>{}); else run_body(DistFlag<false>{}, DistFlag<true>{}); }
@@ -197,7 +236,9 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
                                         long long P, int squared, float* __restrict__ out)
 {
     __shared__ float tile[DT][DT + 1];
-    const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
+    const long long ptiles = (P + DT - 1) / DT, g = xcd_contiguous_tile(ptiles * ((F + DT - 1) / DT));
+    if (g < 0) return;                                               // (the whole block: the grid is padded to a multiple of 8)
+    const long long f0 = (g / ptiles) * DT, p0 = (g % ptiles) * DT;
     {
         const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
         // frames past the end compute on the last frame (the store phase never reads those tile entries)
@@ -209,11 +250,132 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
 #else
         if (pw < P)
             for_pair_run(coords, F, (unsigned)f * 4u, bx, by, bz, pa, pb, wrap, P, pw,
-                         [&](int k, float d2) { tile[pq * DP_RUN + k][fl] = squared ? d2 : mk_fsqrt_rn(d2); });
+                         [&](int k0, const float (&d2)[DP_BATCH]) {
+                             // the batch's roots behind ONE wave-uniform test (mk_sqrt_ordinary: practically always true)
+                             bool ordinary = true;
+#pragma unroll
+                             for (int u = 0; u < DP_BATCH; ++u) ordinary = ordinary && mk_sqrt_ordinary(d2[u]);
+                             if (squared) {
+#pragma unroll
+                                 for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = d2[u];
+                             } else if (mk_ballot(!ordinary) == 0ull) {
+#pragma unroll
+                                 for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = mk_fsqrt_rn_ordinary(d2[u]);
+                             } else {
+#pragma unroll
+                                 for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = mk_fsqrt_rn(d2[u]);
+                             }
+                         });
 #endif
     }
     mk_block_sync();
-    store_tile_rows(tile, f0, p0, F, P, out);
+    store_tile_rows(tile, f0, p0, F, P, P, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dist_trajectory WITHOUT selfdist (every sel1 atom against every sel2 atom: pair p = i * n2 + j, distance_utils.pyx:144-155
+// with j from 0) -- the common MetricDistance call -- has a rectangular pair table, and k_dist_pairs wastes it: a tile of 64
+// consecutive pairs shares its FIRST atom and loads 64 second atoms x 3 rows per tile, 12 bytes from the L2 for every 4 bytes
+// it stores (2.6 GB per 0.8 GB result on the bench workload; round-4 PMC: with and without the image arithmetic the kernel took
+// the same 0.30 ms -- 92 % and 58 % VALU-busy).  Here a block owns 64 consecutive sel2 atoms x DR_I consecutive sel1 atoms x 64
+// frames: a wave keeps the coordinates of ITS 16 second atoms (lane = frame) in 48 registers and walks the first atoms --
+// three loads per first atom instead of 51 -- transposing one 64-pair row of the result through LDS per first atom, so the
+// stores are k_dist_pairs' (whole 256-byte rows of out[f, i * n2 + j0 ..]).  No pair table is built.  Same arithmetic per
+// pair (dist2_min_image_f32, mk_fsqrt_rn): the same bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int DR_I = 8;                // first atoms per block (the second atoms' loads are amortised over them)
+constexpr int DR_WAVES = 8;            // waves per block: 8 second atoms each -- 24 registers of coordinates, not 48 (sixteen per wave: 129-141
+                                       // VGPRs, three waves per SIMD)
+constexpr int DR_PW = DT / DR_WAVES;   // second atoms (pairs of a row) per wave
+
+template <bool PBC, bool SMALL>
+MK_DEV void dist_rect_block(const float* __restrict__ coords, long long F, const float* __restrict__ box,
+                            const unsigned* __restrict__ sel1, long long n1, const unsigned* __restrict__ sel2, long long n2,
+                            const unsigned* __restrict__ chains, int squared, float* __restrict__ out, float (&tiles)[2][DT][DT + 1],
+                            long long tj /* tile of second atoms */, long long ti /* group of first atoms */, long long tf /* frame slab */)
+{
+    const int fl = threadIdx.x & (DT - 1), wq = threadIdx.x >> 6;
+    const long long f0 = tf * DT, j0 = tj * DT, i0 = ti * DR_I;
+    const long long f = f0 + fl < F ? f0 + fl : F - 1;              // frames past the end compute on the last one (never stored)
+    const unsigned fb = (unsigned)f * 4u, F4 = (unsigned)F * 4u;
+    auto at = [&](unsigned atom, int ax) {
+        if constexpr (SMALL) return mk_load_f32_base_soffset(coords, (atom * 3u + (unsigned)ax) * F4, fb);
+        else return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
+    };
+    // this wave's 16 second atoms (past the end: the last one again -- computed, never stored); lane k holds atom k and its chain
+    const long long jw = j0 + wq * DR_PW;
+    const long long jk = jw + (fl & (DR_PW - 1)) < n2 ? jw + (fl & (DR_PW - 1)) : n2 - 1;
+    const unsigned vb = sel2[jk], vcb = PBC ? chains[vb] : 0u;
+    float B3[DR_PW][3];
+#pragma unroll
+    for (int k = 0; k < DR_PW; ++k) {
+        const unsigned b = mk_readlane(vb, k);
+        B3[k][0] = at(b, 0); B3[k][1] = at(b, 1); B3[k][2] = at(b, 2);
+    }
+    float bx = 0.f, by = 0.f, bz = 0.f, ibx = 0.f, iby = 0.f, ibz = 0.f;
+    if (PBC) {
+        bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+        ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
+    }
+    const long long P = n1 * n2;
+    const long long ni = n1 - i0 < DR_I ? n1 - i0 : DR_I;            // block-uniform, >= 1
+    unsigned a = sel1[i0];
+    float xa = at(a, 0), ya = at(a, 1), za = at(a, 2);
+    for (long long ii = 0; ii < ni; ++ii) {
+        // two tiles alternate: the rows of first atom ii leave tile ii & 1 while ii + 1 is computed into the other one -- ONE
+        // barrier per first atom (what orders the reads of tile ii & 1 before its next writes is the barrier of ii + 1)
+        float (&tile)[DT][DT + 1] = tiles[ii & 1];
+        // the next first atom's coordinates are requested before this one's distances are computed
+        const unsigned a_next = sel1[ii + 1 < ni ? i0 + ii + 1 : i0 + ii];
+        const float xn = at(a_next, 0), yn = at(a_next, 1), zn = at(a_next, 2);
+        const unsigned ca = PBC ? chains[a] : 0u;                    // wave-uniform (scalar load)
+        float d2[DR_PW];
+        bool ordinary = true;
+#pragma unroll
+        for (int k = 0; k < DR_PW; ++k) {
+            const bool wrap = PBC && mk_readlane(vcb, k) != ca;      // distance_utils.pyx:49
+            d2[k] = dist2_min_image_f32(xa, ya, za, B3[k][0], B3[k][1], B3[k][2], bx, by, bz, ibx, iby, ibz, wrap);
+            ordinary = ordinary && mk_sqrt_ordinary(d2[k]);
+        }
+        // the roots of the batch behind ONE wave-uniform test (all values ordinary numbers: practically always)
+        if (squared) {
+#pragma unroll
+            for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = d2[k];
+        } else if (mk_ballot(!ordinary) == 0ull) {
+#pragma unroll
+            for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = mk_fsqrt_rn_ordinary(d2[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = mk_fsqrt_rn(d2[k]);
+        }
+        mk_block_sync();
+        // the row of 64 pairs (i, j0 .. j0 + 63) of every frame of the slab (pairs past the row's end -- j >= n2 -- belong to the
+        // next first atom: the row is clipped at its own end, not at P)
+        store_tile_rows<DR_WAVES>(tile, f0, (i0 + ii) * n2 + j0, F, (i0 + ii) * n2 + (j0 + DT <= n2 ? j0 + DT : n2), P, out);
+        a = a_next; xa = xn; ya = yn; za = zn;
+    }
+}
+
+template <bool PBC>
+MK_KERNEL(DR_WAVES * WAVE) void k_dist_rect(const float* __restrict__ coords, long long F, const float* __restrict__ box,
+                                       const unsigned* __restrict__ sel1, long long n1, const unsigned* __restrict__ sel2, long long n2,
+                                       const unsigned* __restrict__ chains, int squared, float* __restrict__ out)
+{
+    __shared__ float tile[2][DT][DT + 1];
+    // every row this BLOCK touches ends below 4 GiB from the start of the array?  Block-uniform: every wave looks at all 64
+    // second atoms of the tile and at the block's first atoms (lane l: sel2[j0 + l] and sel1[i0 + l mod DR_I])
+    // tiles in the order of the result's memory: slab, then group of first atoms, then tile of second atoms (p = i * n2 + j)
+    const long long gx = (n2 + DT - 1) / DT, gy = (n1 + DR_I - 1) / DR_I;
+    const long long g = xcd_contiguous_tile(gx * gy * ((F + DT - 1) / DT));
+    if (g < 0) return;
+    const long long bx = g % gx, by = (g / gx) % gy, bz = g / (gx * gy);
+    const int l = threadIdx.x & (DT - 1);
+    const long long jl = bx * DT + l, il = by * DR_I + (l & (DR_I - 1));
+    const unsigned hb = sel2[jl < n2 ? jl : n2 - 1], ha = sel1[il < n1 ? il : n1 - 1];
+    const unsigned hi_atom = hb > ha ? hb : ha;
+    const bool small_rows = mk_ballot(((unsigned long long)hi_atom * 3ull + 3ull) * ((unsigned long long)F * 4ull) > 0xffffffffull) == 0ull;
+    if (small_rows) dist_rect_block<PBC, true>(coords, F, box, sel1, n1, sel2, n2, chains, squared, out, tile, bx, by, bz);
+    else dist_rect_block<PBC, false>(coords, F, box, sel1, n1, sel2, n2, chains, squared, out, tile, bx, by, bz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -239,7 +401,10 @@ MK_DEV unsigned contact_mask(const float* __restrict__ coords, long long F, long
     if (p_first >= P) return 0u;                                     // wave-uniform
     unsigned mask = 0u;
     for_pair_run(coords, F, fin ? (unsigned)f * 4u : 0u, bx, by, bz, pa, pb, wrap, P, p_first,
-                 [&](int k, float d2) { mask |= (d2 <= thr2) ? (1u << k) : 0u; });   // distance_utils.pyx:82 / :111 (NaN: no contact)
+                 [&](int k0, const float (&d2)[DP_BATCH]) {                          // distance_utils.pyx:82 / :111 (NaN: no contact)
+#pragma unroll
+                     for (int u = 0; u < DP_BATCH; ++u) mask |= (d2[u] <= thr2) ? (1u << (k0 + u)) : 0u;
+                 });
     const long long left = P - p_first;
     if (left < CT_RUN) mask &= (1u << (unsigned)left) - 1u;
     return fin ? mask : 0u;
@@ -435,7 +600,7 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
         }
     }
     mk_block_sync();
-    store_tile_rows(tile, f0, p0, F, P, out);
+    store_tile_rows(tile, f0, p0, F, P, P, out);
 }
 
 // cdist (distance_utils.pyx:355-383): results[i, j]; any dimension D; lanes along j.

@@ -26,14 +26,26 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     if (F == 0 || P == 0) return ST_OK;
     if (P > 0x7fffffffLL * 32) { err = "too many pairs"; return ST_EINVAL; }
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
-    void *pa = nullptr, *pb = nullptr, *wr = nullptr;
     int st;
+    // every sel1 atom against every sel2 atom (no selfdist: the common MetricDistance call): the rectangular kernel -- no pair
+    // table, the second atoms of a tile stay in registers while the block walks DR_I first atoms (dist_kernels.h)
+    // (both tile kernels: a 1-D grid padded to a multiple of 8, every XCD a contiguous range of tiles -- xcd_contiguous_tile)
+    auto padded8 = [](long long tiles) { return (unsigned)(((tiles + 7) / 8) * 8); };
+    static const bool no_rect = [] { const char* e = std::getenv("MKAMD_NO_RECT"); return e && e[0] == '1'; }();     // A-B knob
+    if (!selfdist && !no_rect) {
+        const long long tiles = ceil_div(n2, DT) * ceil_div(n1, DR_I) * ceil_div(F, DT);
+        if (tiles <= 0x7ffffff0LL)
+            return pbc ? be.launch(k_dist_rect<true>, dim3(padded8(tiles)), dim3(DR_WAVES * WAVE), coords, F, box, sel1, n1, sel2, n2, chains, squared, out)
+                       : be.launch(k_dist_rect<false>, dim3(padded8(tiles)), dim3(DR_WAVES * WAVE), coords, F, box, sel1, n1, sel2, n2, chains, squared, out);
+    }
+    void *pa = nullptr, *pb = nullptr, *wr = nullptr;
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
     if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
     if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
     if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
                         chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
-    return be.launch(k_dist_pairs, dim3((unsigned)ceil_div(P, DT), (unsigned)ceil_div(F, DT)), dim3(DT_THREADS), coords, F, box,
+    if (ceil_div(P, DT) * ceil_div(F, DT) > 0x7ffffff0LL) { err = "too many tiles (pairs x frames / 4096 >= 2^31)"; return ST_EINVAL; }
+    return be.launch(k_dist_pairs, dim3(padded8(ceil_div(P, DT) * ceil_div(F, DT))), dim3(DT_THREADS), coords, F, box,
                      (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
 }
 

@@ -78,6 +78,7 @@ MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
 
 // device-scope fence: this thread's earlier writes are visible to every CU before its later ones (and vice versa for reads)
 MK_DEV void mk_threadfence() { __threadfence(); }
+MK_DEV void mk_sched_fence() { __builtin_amdgcn_sched_barrier(0); }     // the instruction scheduler moves nothing across this point
 MK_DEV void mk_threadfence_system() { __threadfence_system(); }   // release / acquire at system scope (host-visible memory)
 MK_DEV void mk_sleep() { __builtin_amdgcn_s_sleep(8); }
 
@@ -208,6 +209,19 @@ MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // rou
 // is only accurate to 1 ulp -- measured: 15 % of results off in the last bit.)  v_sqrt_f32 is within 1 ulp, so
 // the correctly rounded value is s or one of its neighbours; the sign of the exactly computed (FMA)
 // residuals x - s*s_down and x - s*s_up tells on which side of the two rounding midpoints x lies.
+// The two halves of mk_fsqrt_rn for callers that take MANY roots: `mk_sqrt_ordinary(x)` per value (or-ed over a batch, ONE ballot and
+// ONE wave-uniform branch for the batch), then `mk_fsqrt_rn_ordinary` on every value -- straight-line code the scheduler can
+// interleave across the batch (with a branch per root every pair of the distance kernels was a basic block of its own: a
+// serial chain of ~30 dependent instructions, five s_nop and three branches per distance).
+MK_DEV bool mk_sqrt_ordinary(float x) { return (__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u); }   // in [2^-96, inf)
+MK_DEV float mk_fsqrt_rn_ordinary(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_down = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_down = __builtin_fmaf(-s_down, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    const float y = (r_down <= 0.0f) ? s_down : s;
+    return (r_up > 0.0f) ? s_up : y;
+}
 MK_DEV float mk_fsqrt_rn(float x)
 {
     // every lane of the wave holds an ordinary number in [2^-96, inf) -- practically always: the correction alone

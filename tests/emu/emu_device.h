@@ -212,6 +212,7 @@ MK_DEV float mk_abs(float a) { return fabsf(a); }
 MK_DEV float mk_max(float a, float b) { return fmaxf(a, b); }
 MK_DEV float mk_min3(float m, float a, float b) { return fminf(fminf(a, b), m); }
 MK_DEV void mk_threadfence() {}
+MK_DEV void mk_sched_fence() {}
 MK_DEV void mk_threadfence_system() {}
 MK_DEV void mk_sleep() {}
 MK_DEV unsigned mk_uniform(unsigned v) { return v; }
@@ -288,6 +289,8 @@ MK_DEV float mk_fsub_rn(float a, float b) { volatile float r = a - b; return r; 
 MK_DEV float mk_fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 MK_DEV float mk_fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 MK_DEV float mk_fsqrt_rn(float a) { return sqrtf(a); }
+MK_DEV bool mk_sqrt_ordinary(float x) { return x >= 0x1.0p-96f && x < INFINITY; }
+MK_DEV float mk_fsqrt_rn_ordinary(float a) { return sqrtf(a); }
 MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
 {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_offset);

@@ -146,3 +146,23 @@ def test_image_shift_at_the_half_box_boundary_is_bit_exact():
     c, b, ch, s1, s2 = _half_box_case()
     got = E.dist_trajectory(c, b, s1, s2, ch, False, True)
     assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
+
+
+def test_rectangular_kernel_shapes_and_modes_match_oracle():
+    """Round 4: dist_trajectory without selfdist takes k_dist_rect (a block keeps its 64 second atoms in registers and walks
+    8 first atoms; no pair table).  Shapes around its tile edges -- n2 below / at / above 64 and 128, n1 below / at / above the
+    8 first atoms of a block, frames not a multiple of 64 -- with and without pbc, squared and not, unsorted and repeated
+    atom indices: the kernel source on the host emulator against the oracle, bit for bit."""
+    rng = np.random.default_rng(11)
+    N, F = 260, 67
+    c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(15, 25, size=(3, F)).astype(np.float32)
+    ch = rng.integers(0, 4, size=N).astype(np.uint32)
+    for n1, n2 in ((1, 1), (7, 63), (8, 64), (9, 65), (17, 130), (3, 200)):
+        s1 = rng.integers(0, N, size=n1).astype(np.uint32)
+        s2 = rng.integers(0, N, size=n2).astype(np.uint32)
+        for pbc in (False, True):
+            for sq in (False, True):
+                got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
+                exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
+                assert got.shape == (F, n1 * n2) and np.array_equal(got, exp), (n1, n2, pbc, sq)

@@ -48,7 +48,7 @@ def collect(passes, out_name, items, cmd, note_extra=""):
            "_note": "mean per launch; one rocprofv3 --pmc pass per counter group (tools/gpu_r4_evidence.sh), FETCH_SIZE and WRITE_SIZE in "
                     "passes of their own; KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950: double it (MI355X_MICROARCH.md, HBM). "
                     "--no-single: no single-grid probe launches, every launch of a kernel is one full step. GRBM_GUI_ACTIVE: shader "
-                    "cycles of the launch (the effective clock = it / the kernel's duration)." + note_extra}
+                    "cycles of the launch summed over the 8 XCDs (the effective clock = it / 8 / the kernel's duration)." + note_extra}
     for k in sorted(acc):
         out[k] = {c: round(sum(v) / len(v), 2) for c, v in sorted(acc[k].items())}
         out[k]["_launches"] = max(len(v) for v in acc[k].values())
@@ -62,7 +62,7 @@ def report(out_name, out, alg_mb):
     for k in hot:
         v = out[k]
         if "SQ_INSTS_VALU" in v and v.get("SQ_WAVES"):
-            clk = v.get("GRBM_GUI_ACTIVE") or v.get("SQ_BUSY_CYCLES", 0) / 32.0
+            clk = v["GRBM_GUI_ACTIVE"] / 8.0 if v.get("GRBM_GUI_ACTIVE") else v.get("SQ_BUSY_CYCLES", 0) / 32.0     # (summed over 8 XCDs / 32 SEs)
             busy = v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / clk if clk else float("nan")
             print(f"{out_name}: {k[:52]:52s} VALU/wave {v['SQ_INSTS_VALU'] / v['SQ_WAVES']:8.1f}  SALU/wave {v.get('SQ_INSTS_SALU', 0) / v['SQ_WAVES']:7.1f}  "
                   f"LDS/wave {v.get('SQ_INSTS_LDS', 0) / v['SQ_WAVES']:6.1f}  VALU-busy {busy:.3f}  launches {v['_launches']}")
