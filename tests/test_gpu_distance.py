@@ -203,3 +203,29 @@ def test_more_than_65535_rows_and_groups():
     dist_trajectory_reduction(xyz, box, [[i] for i in range(n1)], [[n1 + j] for j in range(n2)], chains[:n1].copy(),
                               chains[n1:].copy(), False, True, np.ones_like(m), 1, 1, got)
     assert np.array_equal(got, want)
+
+
+def test_rectangular_and_pair_table_kernels_over_many_tiles_match_oracle():
+    """Round 4: dist_trajectory without selfdist runs k_dist_rect (second atoms in registers, 8 first atoms per block), with
+    selfdist the pair-table kernel; both deal their tiles to the XCDs in contiguous ranges of a 1-D grid padded to a multiple
+    of 8.  Shapes with hundreds of tiles whose count is NOT a multiple of 8, ragged edges on every axis (frames, first and
+    second atoms), rows that do and do not start on 16 bytes (16-byte / 4-byte store paths), pbc on and off, squared and
+    not -- against the oracle, bit for bit."""
+    from moleculekit_amd.distance_utils import dist_trajectory
+    rng = np.random.default_rng(23)
+    N, F = 900, 203                                            # 4 frame slabs, the last one ragged
+    c = rng.uniform(-40, 40, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(30, 45, size=(3, F)).astype(np.float32)
+    ch = rng.integers(0, 5, size=N).astype(np.uint32)
+    for n1, n2 in ((19, 132), (8, 64), (37, 203), (1, 500)):
+        s1 = rng.choice(N, n1, replace=False).astype(np.uint32)
+        s2 = rng.choice(N, n2, replace=False).astype(np.uint32)
+        for pbc in (False, True):
+            r = np.full((F, n1 * n2), -3.0, np.float32)
+            dist_trajectory(c, b, s1, s2, ch, False, pbc, r)
+            assert np.array_equal(r, oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc)), (n1, n2, pbc)
+    s = rng.choice(N, 61, replace=False).astype(np.uint32)    # 1 830 pairs: 29 pair tiles x 4 slabs = 116 tiles
+    for pbc in (False, True):
+        r = np.full((F, 61 * 60 // 2), -3.0, np.float32)
+        dist_trajectory(c, b, s, s, ch, True, pbc, r)
+        assert np.array_equal(r, oracle.dist_trajectory(c, b, s, s, ch, True, pbc)), pbc
