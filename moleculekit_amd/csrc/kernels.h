@@ -2404,6 +2404,19 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
             live |= 1u << c;
             const unsigned s0 = mk_uniform(s_gstart[c * NSLOT + cls]) & ~1u, odd = n_in & 1u;
             const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
+#ifdef MK_ITEMS_DIRECT_SINGLE      // round-4 A-B: a group with ONE entry within reach straight through the flush arithmetic (no accumulator set)
+            if (n_in == 1u && wcls <= fast_w_max<K>()) {
+                const float* e1 = sx + s0;
+                const float ex = e1[0], dy = Y - e1[ITEM_STRIDE], dz = Z - e1[2 * ITEM_STRIDE];
+                const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float d2 = plane_d2<K>(k, mk_fma(plane_slope<K>(k), ex, d0));
+                    q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? mk_abs(d2) * wcls : INF);
+                }
+                continue;
+            }
+#endif
             float m[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) { m[k] = INF; mk_keep(m[k]); }
