@@ -140,28 +140,68 @@ inline int index_frames_cached(const Mapped& m, std::shared_ptr<const FrameIndex
 struct BitReader {                       // MSB-first bit stream over [p, end)
     const uint8_t* p;
     const uint8_t* end;
-    uint64_t acc = 0;
-    int nacc = 0;
+    uint64_t acc = 0;                    // the next bits of the stream, left-aligned (bit 63 = next bit); the rest is zero
+    int nacc = 0;                        // how many of them are valid
     bool overrun = false;
-    uint32_t get(int nbits)              // 0 <= nbits <= 32
+    // at least 56 valid bits afterwards (as long as the stream has them): eight bytes at a time, byte-swapped, while they last
+    void refill()
+    {
+        if (p + 8 <= end) {
+            uint64_t v;
+            std::memcpy(&v, p, 8);
+            v = __builtin_bswap64(v);
+            const int take = (63 - nacc) >> 3;          // whole bytes that fit
+            acc |= v >> nacc;
+            p += take;
+            nacc += take * 8;
+            acc &= ~0ull << (64 - nacc);                // (the bits of the byte that did not fit whole come with the next refill)
+        } else {
+            while (nacc <= 56 && p < end) { acc |= (uint64_t)*p++ << (56 - nacc); nacc += 8; }
+        }
+    }
+    uint64_t get64(int nbits)            // 0 <= nbits <= 56
     {
         if (nbits == 0) return 0;
-        while (nacc < nbits) {
-            uint8_t b = 0;
-            if (p < end) b = *p++; else overrun = true;
-            acc = (acc << 8) | b;
-            nacc += 8;
+        if (nacc < nbits) {
+            refill();
+            if (nacc < nbits) { overrun = true; nacc = nbits; }     // past the end: zeros, reported by the caller
         }
+        const uint64_t v = acc >> (64 - nbits);
+        acc <<= nbits;
         nacc -= nbits;
-        return (uint32_t)((acc >> nacc) & ((nbits == 32) ? 0xffffffffull : ((1ull << nbits) - 1ull)));
+        return v;
     }
+    uint32_t get(int nbits) { return (uint32_t)get64(nbits); }     // 0 <= nbits <= 32
     // three values packed as one mixed-radix number of `nbits` bits whose bytes come least-significant first
+    // (the byte-array long division of xdrfile.cpp:545-600 as integer division: 32-bit when the number fits -- every run of
+    //  small differences --, 64-bit for full coordinates of ordinary boxes, 128-bit beyond: three ranges of 2^24)
     void get_triple(int nbits, const uint32_t (&radix)[3], int32_t (&out)[3])
     {
+        const int nfull = (nbits - 1) >> 3, top = nbits - 8 * nfull;      // whole bytes, then the top 1..8 bits (nbits >= 1)
+        if (nbits <= 56) {
+            // the whole bytes arrive most-significant-bit first but are the number's LOW bytes in little-endian order
+            uint64_t x = 0;
+            if (nfull) {
+                const uint64_t be = get64(8 * nfull);                        // byte 0 of the number in the top byte of `be`'s field
+                x = __builtin_bswap64(be << (64 - 8 * nfull));
+            }
+            x |= get64(top) << (8 * nfull);
+            if (nbits <= 32) {
+                uint32_t y = (uint32_t)x;
+                const uint32_t q2 = y / radix[2]; out[2] = (int32_t)(y - q2 * radix[2]); y = q2;
+                const uint32_t q1 = y / radix[1]; out[1] = (int32_t)(y - q1 * radix[1]);
+                out[0] = (int32_t)q1;
+            } else {
+                const uint64_t q2 = x / radix[2]; out[2] = (int32_t)(uint32_t)(x - q2 * radix[2]);
+                const uint64_t q1 = q2 / radix[1]; out[1] = (int32_t)(uint32_t)(q2 - q1 * radix[1]);
+                out[0] = (int32_t)(uint32_t)(q1 & 0xffffffffu);
+            }
+            return;
+        }
         unsigned __int128 x = 0;
-        int shift = 0;
-        while (nbits > 8) { x |= (unsigned __int128)get(8) << shift; shift += 8; nbits -= 8; }
-        if (nbits > 0) x |= (unsigned __int128)get(nbits) << shift;
+        int shift = 0, left = nbits;
+        while (left > 8) { x |= (unsigned __int128)get(8) << shift; shift += 8; left -= 8; }
+        if (left > 0) x |= (unsigned __int128)get(left) << shift;
         out[2] = (int32_t)(uint32_t)(x % radix[2]); x /= radix[2];
         out[1] = (int32_t)(uint32_t)(x % radix[1]); x /= radix[1];
         out[0] = (int32_t)(uint32_t)(x & 0xffffffffu);
@@ -352,17 +392,31 @@ inline int read(const char* path, const int64_t* sel, int64_t nsel, int64_t nato
     //  measured: 82 k -> 44 k frames/s end to end; a caller that wants more threads per chunk asks for bigger chunks)
     constexpr int64_t FB = 16;
     const int64_t nblocks = (nsel + FB - 1) / FB;
+    // (round 4: every frame of a block is decoded into a CONTIGUOUS row of 3 * natoms floats -- the decoder's writes are
+    //  sequential, a 30 000-atom frame stays in the core's L2 -- and the block is transposed into place afterwards, FB
+    //  sequential read streams against one line per row; decoding straight into a [3 * natoms][FB] block touched a cache
+    //  line per value: 5.8 MB per thread and block for such a frame)
     auto work = [&](int t) {
-        std::vector<float> blk((size_t)natoms * 3 * FB);
+        const size_t row = (size_t)natoms * 3;
+        std::vector<float> blk(row * FB);
         for (int64_t bidx = t; bidx < nblocks; bidx += nthreads) {
             const int64_t j0 = bidx * FB, nb = std::min<int64_t>(FB, nsel - j0);
             for (int64_t k = 0; k < nb; ++k) {
                 const int64_t f = sel ? sel[j0 + k] : j0 + k;
-                const int s = decode_frame(m, offs[(size_t)f], natoms, nsel, j0 + k, blk.data(), FB, k, box, time, step);
+                const int s = decode_frame(m, offs[(size_t)f], natoms, nsel, j0 + k, blk.data() + (size_t)k * row, 1, 0, box, time, step);
                 if (s != OK) { status[(size_t)t] = s; return; }
             }
-            for (int64_t r = 0; r < natoms * 3; ++r)
-                std::memcpy(coords + (size_t)r * (size_t)nsel + (size_t)j0, blk.data() + (size_t)r * FB, (size_t)nb * sizeof(float));
+            const float* const b0 = blk.data();
+            if (nb == FB) {
+                for (size_t r = 0; r < row; ++r) {
+                    float* __restrict__ d = coords + r * (size_t)nsel + (size_t)j0;
+#pragma GCC unroll 16
+                    for (int64_t k = 0; k < FB; ++k) d[k] = b0[(size_t)k * row + r];
+                }
+            } else {
+                for (size_t r = 0; r < row; ++r)
+                    for (int64_t k = 0; k < nb; ++k) coords[r * (size_t)nsel + (size_t)j0 + (size_t)k] = b0[(size_t)k * row + r];
+            }
         }
     };
     nthreads = (int)std::min<int64_t>(nthreads, std::max<int64_t>(nblocks, 1));
