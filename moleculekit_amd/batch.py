@@ -181,10 +181,11 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     if ctx is not None and ctx.device != dev_index:
         raise ValueError(f"ctx lives on GPU {ctx.device} but the tensors are on cuda:{dev_index} (kernels run on the context's device)")
     ctx = ctx or _lib.default_context(dev_index)
-    assert coords.dtype == torch.float32 and coords.is_contiguous()
-    assert atom_offsets.dtype == torch.int64 and atom_offsets.is_contiguous()
-    assert sigmas.dtype in (torch.float32, torch.float64) and sigmas.is_contiguous() and sigmas.dim() == 2
-    assert origins.dtype == torch.float64 and origins.is_contiguous()
+    if not (coords.dtype == torch.float32 and coords.is_contiguous() and atom_offsets.dtype == torch.int64 and atom_offsets.is_contiguous()
+            and sigmas.dtype in (torch.float32, torch.float64) and sigmas.is_contiguous() and sigmas.dim() == 2
+            and origins.dtype == torch.float64 and origins.is_contiguous()):
+        ctx.withdraw_promise()            # (see below)
+        raise AssertionError("voxelize_lattice_torch: coords float32, atom_offsets int64, sigmas float32|float64 [n, C], origins float64, all contiguous")
     B = int(origins.shape[0])
     C = int(sigmas.shape[1])
     nv = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
@@ -201,10 +202,14 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     if affine is not None:
         assert affine.dtype == torch.float64 and affine.is_contiguous() and tuple(affine.shape) == (B, 12)
         d_aff = affine.data_ptr()
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    ctx.voxelize_lattice_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]),
-                             sigmas.data_ptr(), sigmas.dtype == torch.float64, C, origins.data_ptr(), nv,
-                             float(voxelsize), d_box, int(max_images), out.data_ptr(), d_aff)
+    try:
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        ctx.voxelize_lattice_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]),
+                                 sigmas.data_ptr(), sigmas.dtype == torch.float64, C, origins.data_ptr(), nv,
+                                 float(voxelsize), d_box, int(max_images), out.data_ptr(), d_aff)
+    except BaseException:
+        ctx.withdraw_promise()            # a promise made for THIS call (Context.promise_inputs) must not reach another one
+        raise
     out = out.view(B, V, C)
     if channel_first:   # what the reference's tutorial builds by hand before nn.Conv3d
         return out.view(B, int(nv[0]), int(nv[1]), int(nv[2]), C).permute(0, 4, 1, 2, 3)

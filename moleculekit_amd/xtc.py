@@ -168,13 +168,19 @@ def write_xtc(filename, coords, box, time, step, precision: float = 1000.0):
             else:
                 prod = int(size[0]) * int(size[1]) * int(size[2])
                 nbits = prod.bit_length()                                # sizeofints(3, sizeint), xdrfile.cpp:425-457
-                V = (rel[:, 0] * np.uint64(size[1]) + rel[:, 1]) * np.uint64(size[2]) + rel[:, 2]        # (three 24-bit ranges: < 2^72 ...
-                if nbits > 63:                                           #  ... this writer folds in 64 bits)
-                    raise ValueError("coordinate range too wide for this writer's 64-bit mixed-radix path")
+                if nbits <= 63:
+                    V = (rel[:, 0] * np.uint64(size[1]) + rel[:, 1]) * np.uint64(size[2]) + rel[:, 2]
+                else:                                                    # three ranges of up to 24 bits: up to 72 bits -- Python integers
+                    V = (rel[:, 0].astype(object) * int(size[1]) + rel[:, 1].astype(object)) * int(size[2]) + rel[:, 2].astype(object)
                 # the number goes out least-significant BYTE first, its top (nbits mod 8, or 8) bits last (sendints, :489-543)
                 nfull, top = (nbits - 1) // 8, nbits - 8 * ((nbits - 1) // 8)
-                fields = [((V >> np.uint64(8 * b)) & np.uint64(0xff), 8) for b in range(nfull)]
-                fields.append(((V >> np.uint64(8 * nfull)) & np.uint64((1 << top) - 1), top))
+                if nbits <= 63:
+                    fields = [((V >> np.uint64(8 * b)) & np.uint64(0xff), 8) for b in range(nfull)]
+                    fields.append(((V >> np.uint64(8 * nfull)) & np.uint64((1 << top) - 1), top))
+                else:
+                    byte = lambda sh, mask: np.array([(int(v) >> sh) & mask for v in V], dtype=np.uint64)
+                    fields = [(byte(8 * b, 0xff), 8) for b in range(nfull)]
+                    fields.append((byte(8 * nfull, (1 << top) - 1), top))
                 fields.append((np.zeros(N, np.uint64), 1))               # ... then the flag bit: 0
                 payload = _pack_bits(*fields)
             fh.write(head + struct.pack(">i", _FIRSTIDX))                # smallidx: any valid index (never used: no small atoms)

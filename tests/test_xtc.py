@@ -137,3 +137,32 @@ def test_write_xtc_is_read_back_like_the_reference_reads_it(name, tmp_path):
     assert np.abs(c - x).max() <= 0.5005e-3 + np.abs(x).max() * 2.0 ** -22
     with pytest.raises(ValueError):
         xtc.write_xtc(fn, x[:, :2], box, t, st)
+
+
+def test_write_then_read_round_trip_property():
+    """Any trajectory written by write_xtc comes back from read_xtc as the quantised coordinates -- int(x * 1000 +- 0.5) / 1000
+    in float32 arithmetic, what the format stores (xdrfile.cpp:606-624 / :975-983) -- for random atom counts around the
+    9-atom switch to plain floats, frame counts, box sizes from a ligand's to beyond 24 bits of range, mixed signs."""
+    hypothesis = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    import tempfile
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 70), st.integers(1, 4), st.sampled_from([0.3, 2.5, 6.69, 40.0, 3000.0, 20000.0]), st.integers(0, 2 ** 31 - 1))
+    def prop(n, f, L, seed):
+        rng = np.random.default_rng(seed)
+        x = (rng.uniform(-0.5, 1.0, size=(n, 3, f)) * L).astype(np.float32)
+        box = np.zeros((3, 3, f), np.float32); box[0, 0] = box[1, 1] = box[2, 2] = L
+        t, s = rng.uniform(0, 100, f).astype(np.float32), rng.integers(0, 10 ** 6, f)
+        with tempfile.TemporaryDirectory() as d:
+            fn = os.path.join(d, "p.xtc")
+            xtc.write_xtc(fn, x, box, t, s)
+            c, b, tt, ss = xtc.read_xtc(fn, nthreads=1)
+            c2 = xtc.read_xtc_frames(fn, np.arange(f)[::-1])[0]
+        lf = x * np.float32(1000)
+        q = np.where(lf >= 0, lf + np.float32(0.5), lf - np.float32(0.5)).astype(np.int64)
+        want = x if n <= 9 else q.astype(np.float32) * np.float32(1.0 / np.float32(1000.0))
+        assert np.array_equal(c, want) and np.array_equal(c2, want[:, :, ::-1])
+        assert np.array_equal(b, box) and np.array_equal(tt, t) and np.array_equal(ss, s.astype(np.int32))
+
+    prop()
