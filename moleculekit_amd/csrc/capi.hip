@@ -1074,15 +1074,11 @@ try {
     if (rows < 0 || n_frames < 0 || src_pitch < n_frames) return fail(MKAMD_EINVAL, "rows / n_frames must be >= 0 and src_pitch >= n_frames");
     if (rows == 0 || n_frames == 0) return MKAMD_OK;
     if (!d_src || !d_dst) return fail(MKAMD_EINVAL, "NULL pointer");
-    const long long gx = (n_frames + 63) / 64, gy = (rows + 63) / 64;
-    if (gy > 65535 * 64LL) return fail(MKAMD_EINVAL, "too many rows");
-    // (rows beyond 65 535 tiles: y-slabs, launched one after the other -- 4 M rows each)
-    for (long long y0 = 0; y0 < gy; y0 += 65535) {
-        const long long ny = gy - y0 < 65535 ? gy - y0 : 65535;
-        hipLaunchKernelGGL(mkamd::k_frames_to_items, dim3((unsigned)gx, (unsigned)ny), dim3(256), 0, (hipStream_t)hip_stream,
-                           d_src + y0 * 64 * src_pitch, rows - y0 * 64, (long long)src_pitch, (long long)n_frames, scale, d_dst + y0 * 64);
-        HIP_TRY(hipGetLastError());
-    }
+    const long long tiles = ((n_frames + 63) / 64) * ((rows + 63) / 64);
+    if (tiles > 0x7ffffff0LL) return fail(MKAMD_EINVAL, "too many tiles (rows x frames / 4096 >= 2^31)");
+    hipLaunchKernelGGL(mkamd::k_frames_to_items, dim3((unsigned)(((tiles + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)hip_stream,
+                       d_src, (long long)rows, (long long)src_pitch, (long long)n_frames, scale, d_dst);
+    HIP_TRY(hipGetLastError());
     return MKAMD_OK;
 } MK_API_CATCH
 

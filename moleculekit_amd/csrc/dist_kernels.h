@@ -551,7 +551,9 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
                                             long long P, float* __restrict__ out)
 {
     __shared__ float tile[DT][DT + 1];
-    const long long f0 = (long long)blockIdx.y * DT, p0 = (long long)blockIdx.x * DT;
+    const long long ptiles = (P + DT - 1) / DT, gt = xcd_contiguous_tile(ptiles * ((F + DT - 1) / DT));   // (as k_dist_pairs)
+    if (gt < 0) return;
+    const long long f0 = (gt / ptiles) * DT, p0 = (gt % ptiles) * DT;
     {
         const int fl = threadIdx.x & (DT - 1);
         const int pq = (int)mk_uniform(threadIdx.x >> 6);            // the wave's index, as a scalar

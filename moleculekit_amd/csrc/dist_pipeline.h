@@ -82,7 +82,8 @@ int run_dist_reduction(BE& be, const float* coords, long long F, const float* bo
                             ng2, masses, (float*)com2))) return st;
         c2 = (const float*)com2;
     }
-    return be.launch(k_dist_reduction, dim3((unsigned)ceil_div(P, DT), (unsigned)ceil_div(F, DT)), dim3(DT_THREADS), c1, c2, F, box,
+    if (ceil_div(P, DT) * ceil_div(F, DT) > 0x7ffffff0LL) { err = "too many tiles (groups pairs x frames / 4096 >= 2^31)"; return ST_EINVAL; }
+    return be.launch(k_dist_reduction, dim3((unsigned)(((ceil_div(P, DT) * ceil_div(F, DT) + 7) / 8) * 8)), dim3(DT_THREADS), c1, c2, F, box,
                      g1_atoms, g1_off, g2_atoms, g2_off, reduction1, reduction2, (const unsigned*)ga, (const unsigned*)gb,
                      (const unsigned*)wr, P, out);
 }

@@ -3093,11 +3093,18 @@ MK_KERNEL(256) void k_sigma_to_w(const SigT* __restrict__ sigmas, long long N, i
 // turns the box lengths ([3][frames]) into [frames][3] (rows = 3).  One float32 multiply per value: torch's
 // `x.mul_(scale)` bits.
 // ------------------------------------------------------------------------------------------------
+// Tiles are dealt to the 8 XCDs in CONTIGUOUS ranges of the destination's memory order (frame tile, then row tile; a 1-D grid
+// padded to a multiple of 8: block b runs on XCD b & 7 as its (b >> 3)-th block) -- the lesson of the distance kernels
+// (dist_kernels.h, xcd_contiguous_tile): neighbouring 256-byte pieces of a row written from different XCDs' L2s at different
+// times reach the HBM at less than half the rate of pieces that leave ONE L2 together.
 MK_KERNEL(256) void k_frames_to_items(const float* __restrict__ src, long long rows, long long src_pitch, long long nframes,
                                       float scale, float* __restrict__ dst)
 {
     __shared__ float tile[64][65];
-    const long long f0 = (long long)blockIdx.x * 64, r0 = (long long)blockIdx.y * 64;
+    const long long rtiles = (rows + 63) / 64, T = rtiles * ((nframes + 63) / 64), per_xcd = (T + 7) / 8;
+    const long long gt = (long long)(blockIdx.x & 7u) * per_xcd + (long long)(blockIdx.x >> 3);
+    if (gt >= T) return;                                             // (the whole block)
+    const long long f0 = (gt / rtiles) * 64, r0 = (gt % rtiles) * 64;
     const int a = threadIdx.x & 63, b = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
