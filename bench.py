@@ -402,14 +402,15 @@ def bench_stream_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     return out
 
 
-def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
+def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=2048):
     """Secondary leg `xtc_cfg4`: the cfg4 FEEDER -- a synthetic 30 000-atom XTC trajectory (64 frames of the cfg4 random walk
-    written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) decoded by
-    libmkamd.so's host threads straight into pinned staging and voxelized through batch.iterVoxelizeXTC.  Reports the
-    decode rate alone, the end-to-end rate and how idle the GPU is (its share of the wall time at the raw cfg4 step)."""
+    written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) voxelized through
+    batch.iterVoxelizeXTC, with the coordinates decompressed ON THE DEVICE (decode="auto": csrc/xtc_gpu.h, large chunks) and,
+    beside it, by libmkamd.so's host threads (decode="host", the round-3 path).  Reports the end-to-end rates, the host
+    decoder's rate alone and how idle the GPU is (the voxelizer's share of the wall time at the raw cfg4 step)."""
     import tempfile
     import torch
-    from moleculekit_amd import batch, xtc
+    from moleculekit_amd import _lib, batch, xtc
     base = 64
     p, _, _ = make_workload("cfg4", base, seed=4001)
     N = int(p["atom_offsets"][1])
@@ -418,42 +419,90 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     bv = np.zeros((3, 3, base), np.float32)
     bv[0, 0] = bv[1, 1] = bv[2, 2] = L * 0.1
     sig = np.ascontiguousarray(p["sigmas"][:N], dtype=np.float32)
+    per_frame_s = raw_ms_per_step * 1e-3 / DEFAULT_BATCH["cfg4"] if raw_ms_per_step else None
     with tempfile.TemporaryDirectory() as d:
         one = os.path.join(d, "one.xtc")
         xtc.write_xtc(one, nm, bv, np.zeros(base, np.float32), np.arange(base))
         blob = open(one, "rb").read()
         fn = os.path.join(d, "cfg4.xtc")
         with open(fn, "wb") as fh:
-            for _ in range(frames // base):
+            for _ in range(max(frames, frames_gpu) // base):
                 fh.write(blob)
-        F = xtc.get_xtc_nframes(fn)
         xtc.read_xtc_frames(fn, np.arange(chunk))                               # warm (page cache, threads)
         t0 = time.perf_counter()
-        xtc.read_xtc(fn)
+        xtc.read_xtc_frames(fn, np.arange(frames))
         t_dec = time.perf_counter() - t0
 
-        def run():
-            n = 0
-            for idx, feats in batch.iterVoxelizeXTC(fn, sig, p["centers"][0], p["boxsize"], p["voxelsize"], pbc=True, chunk=chunk, ctx=ctx):
+        def run(decode, nframes, nchunk):
+            n, marks = 0, []
+            for idx, feats in batch.iterVoxelizeXTC(fn, sig, p["centers"][0], p["boxsize"], p["voxelsize"], pbc=True, chunk=nchunk, ctx=ctx,
+                                                    frames=np.arange(nframes), decode=decode):
                 n += len(idx)
+                ev = torch.cuda.Event(enable_timing=True)                       # when this chunk's features are complete on the device
+                ev.record(torch.cuda.current_stream(dev))
+                marks.append((ev, n))
                 del feats
             torch.cuda.synchronize(dev)
-            return n
+            return n, marks
 
-        run()
-        t0 = time.perf_counter()
-        n = run()
-        dt = time.perf_counter() - t0
-    out = {"atoms": N, "frames": F, "file_MB": round(len(blob) * (frames // base) / 1e6, 1), "bytes_per_atom": round(len(blob) / base / N, 2),
-           "decode_frames_per_s": round(F / t_dec, 1), "decode_Matoms_per_s": round(F * N / t_dec / 1e6, 1), "host_threads": "automatic (<= 64)",
-           "frames_per_s": round(n / dt, 1), "frames_per_call": chunk,
-           "driver": "batch.iterVoxelizeXTC: decode -> pinned staging -> copy stream -> promised voxelize call"}
-    if raw_ms_per_step:
-        gpu_s = n / chunk * raw_ms_per_step * 1e-3
-        out["gpu_busy_fraction"] = round(gpu_s / dt, 4)
-        out["gpu_idle_fraction"] = round(1.0 - gpu_s / dt, 4)
-        out["kernels_alone_frames_per_s"] = round(chunk / (raw_ms_per_step * 1e-3), 1)
-        out["bottleneck"] = "host XTC decode" if F / t_dec < 0.5 * chunk / (raw_ms_per_step * 1e-3) else "GPU"
+        def leg(decode, nframes, nchunk):
+            run(decode, nframes, nchunk)                                        # warm: buffers, pinned staging, the allocator's blocks
+            t0 = time.perf_counter()
+            n, marks = run(decode, nframes, nchunk)
+            dt = time.perf_counter() - t0
+            o = {"frames": n, "frames_per_call": nchunk, "frames_per_s": round(n / dt, 1), "Matoms_per_s": round(n * N / dt / 1e6, 1)}
+            if len(marks) >= 4:                                                 # the feed once it is full: chunk 2's features complete
+                (ea, na), (eb, nb) = marks[1], marks[-1]                        # -> the last chunk's complete (device events)
+                o["steady_frames_per_s"] = round((nb - na) / (ea.elapsed_time(eb) * 1e-3), 1)
+            if per_frame_s:
+                o["gpu_busy_fraction"] = round(n * per_frame_s / dt, 4)         # the voxelizer's share of the wall time
+            return o, dt
+
+        host, _ = leg("host", frames, chunk)
+        torch.cuda.empty_cache()
+        try:
+            gpu, _ = leg("auto", frames_gpu, chunk_gpu)
+            # the decode kernels alone, on resident bytes (what one chunk costs beside the voxelizer)
+            sel = np.arange(chunk_gpu, dtype=np.int64)
+            desc, lo, hi, _, _, _ = xtc.chunk_desc(fn, sel, N)
+            raw = torch.from_numpy(np.fromfile(fn, dtype=np.uint8, count=hi - lo, offset=lo))
+            d_raw = torch.cat([raw, torch.zeros(xtc.XTC_PAD, dtype=torch.uint8)]).to(dev)
+            d_desc = torch.as_tensor(desc, device=dev)
+            d_st = torch.empty(chunk_gpu, dtype=torch.int32, device=dev)
+            xyz = torch.empty((chunk_gpu, N, 3), dtype=torch.float32, device=dev)
+            lib = _lib.load()
+            work = torch.empty(int(lib.mkamd_xtc_decode_work_bytes(chunk_gpu, N)), dtype=torch.uint8, device=dev)
+            st = torch.cuda.current_stream(dev)
+            dec = lambda: _lib._check(lib.mkamd_xtc_decode_dev(ctx._h, st.cuda_stream or None, d_raw.data_ptr(), d_desc.data_ptr(), chunk_gpu, N,
+                                                               10.0, xyz.data_ptr(), d_st.data_ptr(), work.data_ptr(), work.numel()))
+            dec()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st); dec(); dec(); e1.record(st)
+            torch.cuda.synchronize(dev)
+            gpu["decode_kernels_ms_per_call"] = round(e0.elapsed_time(e1) / 2, 3)
+            gpu["decode_kernels_frames_per_s"] = round(chunk_gpu / (e0.elapsed_time(e1) / 2) * 1e3, 1)
+            del d_raw, d_desc, d_st, xyz, work
+        except Exception as e:                     # noqa: BLE001
+            gpu = {"error": f"{type(e).__name__}: {e}"[:300]}
+    out = {"atoms": N, "file_MB": round(len(blob) * (max(frames, frames_gpu) // base) / 1e6, 1), "bytes_per_atom": round(len(blob) / base / N, 2),
+           "frames_per_s": gpu.get("frames_per_s", host["frames_per_s"]), "frames_per_call": gpu.get("frames_per_call", chunk),
+           "decode": "device (k_xtc_scan + k_xtc_expand)" if "frames_per_s" in gpu else "host threads",
+           "device_decode": gpu,
+           "host_decode": dict(host, decode_frames_per_s=round(frames / t_dec, 1), decode_Matoms_per_s=round(frames * N / t_dec / 1e6, 1),
+                               host_threads="automatic (<= 64)"),
+           "driver": "batch.iterVoxelizeXTC: headers + record bytes (device decode) or decoded coordinates (host decode) -> pinned staging -> "
+                     "copy stream -> promised voxelize call"}
+    if per_frame_s:
+        out["kernels_alone_frames_per_s"] = round(1.0 / per_frame_s, 1)
+        fps = out["frames_per_s"]
+        out["gpu_busy_fraction"] = round(fps * per_frame_s, 4)
+        out["gpu_idle_fraction"] = round(1.0 - fps * per_frame_s, 4)
+        out["vs_kernels_alone"] = round(fps * per_frame_s, 4)
+        steady = gpu.get("steady_frames_per_s")
+        if steady:
+            out["steady_vs_kernels_alone"] = round(steady * per_frame_s, 4)
+        out["bottleneck"] = ("GPU (voxelizer)" if (steady or fps) * per_frame_s > 0.9 else
+                             ("device XTC walk (one lane per frame)" if "frames_per_s" in gpu else "host XTC decode"))
     torch.cuda.empty_cache()
     return out
 

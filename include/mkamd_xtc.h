@@ -27,6 +27,35 @@ int mkamd_xtc_info(const char* path, int64_t* n_atoms, int64_t* n_frames);
 int mkamd_xtc_read(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, float* coords, float* box,
                    float* time, int32_t* step, int32_t n_threads);
 
+/* Decoding ON THE DEVICE (round 4; csrc/xtc_gpu.h).  Frames are independent records; inside a frame only the WALK of the bit
+ * stream is serial (where an atom's bits start depends on the flag / run length after every full-precision atom before it:
+ * xdrfile.cpp:749-983).  So a GPU lane walks a frame and records where each group -- a full atom and the run of small atoms
+ * after it -- starts, then a thread per group decodes the numbers; the host only parses the record headers and copies the
+ * records' bytes.
+ *   mkamd_xtc_chunk_desc   headers of the selected frames -> one 64-byte descriptor per frame (desc_out: n_sel x 64 bytes, the
+ *                          layout of mkamd::XtcFrameDesc in csrc/xtc_gpu.h; data offsets relative to *byte_lo), the byte range
+ *                          [*byte_lo, *byte_hi) of the file that holds their records, and what the host path returns besides the
+ *                          coordinates: box vectors f32 [3,3,n_sel] (nm), time f32 [n_sel] (ps), step i32 [n_sel]
+ *   mkamd_xtc_copy_bytes   that byte range into caller memory (pinned staging), by a few host threads
+ *   mkamd_xtc_decode_work_bytes   size of the device work buffer a decode of n_frames x n_atoms needs (8 bytes per atom: the
+ *                          group records)
+ *   mkamd_xtc_decode_dev   (needs mkamd_voxel.h's context) d_bytes / d_desc = device copies of the two, d_bytes
+ *                          MKAMD_XTC_PAD bytes LONGER than the range (the kernels read ahead of what they use) and 4-byte
+ *                          aligned: coordinates float32 [n_frames, n_atoms, 3] -- frame-major, the voxelizer's packed items --
+ *                          times `scale` (10 = nm -> Angstrom), with the float32 operations of the host path ((float)int *
+ *                          (1 / precision), then * scale: the same bits); d_status[f] = 0 ok, 1 corrupt stream, 2 outside what
+ *                          the device path takes (a mixed-radix number of more than 64 bits, a frame of >= 2^21 atoms or
+ *                          >= 512 MB: take the host decoder for such a file; that frame's coordinates are not written).
+ *                          d_work: 8-byte aligned, only used during the call's kernels.  Asynchronous on `hip_stream`. */
+#define MKAMD_XTC_PAD 1024
+int mkamd_xtc_chunk_desc(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, void* desc_out,
+                         int64_t* byte_lo, int64_t* byte_hi, float* box, float* time, int32_t* step);
+int mkamd_xtc_copy_bytes(const char* path, int64_t byte_lo, int64_t byte_hi, void* dst, int32_t n_threads);
+uint64_t mkamd_xtc_decode_work_bytes(int64_t n_frames, int64_t n_atoms);
+struct mkamd_ctx;
+int mkamd_xtc_decode_dev(struct mkamd_ctx* ctx, void* hip_stream, const void* d_bytes, const void* d_desc, int64_t n_frames,
+                         int64_t n_atoms, float scale, float* d_xyz, int32_t* d_status, void* d_work, uint64_t work_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ import time
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libmkamd.so")
-SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h"]
+SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h", "xtc_gpu.h"]
 HEADER = os.path.join(_HERE, "..", "include", "mkamd_voxel.h")
 HEADER2 = os.path.join(_HERE, "..", "include", "mkamd_distance.h")
 HEADER3 = os.path.join(_HERE, "..", "include", "mkamd_xtc.h")

@@ -536,28 +536,53 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
 
 
 def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, frames=None, chunk=1024, device=None,
-                    channel_first=False, ctx=None, nthreads=0, pipelined=True):
-    """``iterVoxelizeTrajectory`` fed straight from an XTC file: chunk k+1 is decoded by host threads (libmkamd.so's
-    decoder, ``moleculekit_amd.xtc``) directly into pinned staging and uploaded while chunk k is voxelized.
-    ``pbc``: use the frames' box (orthorhombic lengths of the box vectors) for the minimum image.  Coordinates are
-    converted from the file's nm to Angstrom on the device, like ``readers.XTCread`` does on the host.
-    ``chunk``: frames per step of the pipeline; the decoder works in blocks of 16 frames, one per host thread, so 1 024
-    frames keep 64 threads busy (tools/bench_xtc.py: 82 k frames/s in chunks of 256, 108 k in chunks of 1 024)."""
+                    channel_first=False, ctx=None, nthreads=0, pipelined=True, decode="auto"):
+    """``iterVoxelizeTrajectory`` fed straight from an XTC file.  ``pbc``: use the frames' box (orthorhombic lengths of the
+    box vectors) for the minimum image.  Coordinates are converted from the file's nm to Angstrom on the device, like
+    ``readers.XTCread`` does on the host.  ``chunk``: frames per step of the pipeline.
+
+    ``decode``: where the coordinates are decompressed --
+      ``"gpu"``   on the device (csrc/xtc_gpu.h): per chunk the host parses the record headers and copies the records' BYTES
+                  (~5 per atom) into pinned staging; a lane walks each frame's bit stream, a thread decodes each group of
+                  atoms, straight into the voxelizer's frame-major items -- the same bits as the host decoder.  The walk
+                  takes the same time for 256 frames as for 4 096 (a wave per 64 frames, most of the chip idle), so LARGE
+                  chunks feed fastest: 2 048 frames of 30 000 atoms decode in 7.7 ms, what their voxelization takes.
+      ``"host"``  by host threads (libmkamd.so's decoder, ``moleculekit_amd.xtc``) into pinned staging, in blocks of 16
+                  frames per thread: bound by the host's cores (28 k frames/s of 30 000 atoms on the 16 an MI355X box grants).
+      ``"auto"``  the device for a contiguous ascending range of frames whose headers it can take (``xtc.device_decodable``:
+                  no coordinate packed into more than 64 bits, < 2^21 atoms), the host otherwise (a sparse selection would
+                  copy the whole span of the file between its first and last frame).
+    A frame the device decoder refuses after all, or a corrupt one, raises -- at the latest when the generator ends (like the
+    voxelizer's own asynchronous errors)."""
     import ctypes
 
     from . import xtc as _xtc
+    if decode not in ("auto", "gpu", "host"):
+        raise ValueError('decode must be "auto", "gpu" or "host"')
     natoms, nframes = _xtc.get_xtc_natoms(filename), _xtc.get_xtc_nframes(filename)
     fr = np.arange(nframes, dtype=np.int64) if frames is None else np.asarray(frames, dtype=np.int64)
     lib, path = _lib.load(), _xtc._path(filename)
     max_images = 1
+    nvoxels = np.ceil(np.array(boxsize, dtype=np.float64) / voxelsize).astype(int)
     if pbc and len(fr):
         _, bv, _, _ = _xtc.read_xtc_frames(filename, fr[:1])     # first guess from the first frame's box; every chunk
                                                                  # recomputes it from its own boxes (_stream_voxelize)
         lengths = np.sqrt((bv[:, :, 0].astype(np.float64) ** 2).sum(axis=1)) * 10.0
         if not np.all(lengths > 0):
             raise ValueError("pbc=True but the XTC frames carry no box")
-        nvoxels = np.ceil(np.array(boxsize, dtype=np.float64) / voxelsize).astype(int)
         max_images = max_images_per_atom(lengths[None, :] * 0.98, nvoxels, voxelsize)    # 2 % slack for box fluctuations
+
+    def box_lengths(bv):                                          # Angstrom, float32 like the reference's conversion
+        bv = bv * np.float32(10.0)                                # (readers.py:1848-1859)
+        return np.sqrt(np.sum(bv * bv, axis=1))                   # [3, n]
+
+    if decode == "auto":
+        contiguous = len(fr) > 0 and np.array_equal(fr, np.arange(fr[0], fr[0] + len(fr)))
+        decode = "gpu" if contiguous and _xtc.device_decodable(_xtc.chunk_desc(filename, fr[:1], natoms)[0], natoms) else "host"
+    if decode == "gpu" and len(fr):
+        yield from _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, bool(pbc), channels, center, boxsize, voxelsize,
+                                 chunk, device, channel_first, ctx, max_images, int(nthreads), pipelined)
+        return
 
     def fill(dst, dst_box, idx):
         n = len(idx)
@@ -567,9 +592,116 @@ def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, 
         st = np.empty(n, dtype=np.int32)
         _lib._check(lib.mkamd_xtc_read(path, _lib._ptr(sel), n, natoms, _lib._ptr(dst), _lib._ptr(bv), _lib._ptr(t),
                                        _lib._ptr(st), int(nthreads)))
-        if dst_box is not None:                                   # box lengths in Angstrom (readers.py:1848-1859)
-            bv *= np.float32(10.0)                                # float32 like the reference's conversion
-            np.copyto(dst_box, np.sqrt(np.sum(bv * bv, axis=1)))
+        if dst_box is not None:
+            np.copyto(dst_box, box_lengths(bv))
 
     yield from _stream_voxelize(natoms, fr, fill, 10.0, bool(pbc), channels, center, boxsize, voxelsize, chunk, device,
                                 channel_first, ctx, max_images, pipelined=pipelined)
+
+
+def _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, has_box, channels, center, boxsize, voxelsize, chunk, device,
+                  channel_first, ctx, max_images, nthreads, pipelined):
+    """``iterVoxelizeXTC(decode="gpu")``: the chunk source of ``_stream_voxelize`` that decodes on the device.  Per chunk, on
+    the host: ``mkamd_xtc_chunk_desc`` (headers -> descriptors, box vectors) and ``mkamd_xtc_copy_bytes`` (the records into
+    one of two pinned byte buffers); on an UPLOAD stream the records' H2D (beside the previous chunk's decode); on the copy
+    stream the descriptors, ``mkamd_xtc_decode_dev`` into the slot's frame-major items, the statuses back into pinned memory.
+
+    The host never waits for a decode it needs soon: a byte buffer is reused when ITS upload is done (the device side orders
+    the upload behind the decode that still reads the device copy), and the small pinned buffers (descriptors, boxes,
+    statuses) rotate over four chunks, so the host blocks on the decode of chunk k-4 at chunk k -- it prepares chunk k while
+    the device still decodes k-1 and k-2 (with a wait on chunk k-2 the feed ran at decode + host + upload per two chunks:
+    10.6 ms per 2 048 frames instead of 9.5).  Statuses are looked at without blocking as chunks complete, and for good at the
+    end."""
+    import torch
+
+    from . import xtc as _xtc
+    lib = _lib.load()
+    run_ctx = ctx or _lib.default_context(None if device is None else torch.device(device).index)
+    dev = torch.device("cuda", run_ctx.device)
+    chunk = int(max(1, min(chunk, len(fr))))
+    NS = 4
+    state = {"k": 0}
+    with torch.cuda.device(dev):
+        h_raw, d_raw = [None, None], [None, None]                # byte buffers, grown as chunks need them (pinning hundreds of
+                                                                 # MB costs 40-80 ms: the pinned ones are kept between calls)
+        for i in range(2):
+            for key in [q for q in _PINNED if q[0] == ("xtcraw", i)]:
+                h_raw[i] = _PINNED.pop(key)
+        h_desc = [torch.empty((chunk, _xtc.DESC_BYTES), dtype=torch.uint8, pin_memory=True) for _ in range(NS)]
+        h_box = [torch.empty((chunk, 3), dtype=torch.float32, pin_memory=True) for _ in range(NS)]
+        h_st = [torch.zeros(chunk, dtype=torch.int32).pin_memory() for _ in range(NS)]
+        d_desc = [torch.empty((chunk, _xtc.DESC_BYTES), dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_st = [torch.empty(chunk, dtype=torch.int32, device=dev) for _ in range(2)]
+        work = torch.empty(int(lib.mkamd_xtc_decode_work_bytes(chunk, natoms)), dtype=torch.uint8, device=dev)  # (decodes are
+        h2d = torch.cuda.Stream(device=dev)                      #  in order on one stream: one work buffer)
+        up = [torch.cuda.Event(), torch.cuda.Event()]            # the upload out of h_raw[slot] is done
+        done = [torch.cuda.Event() for _ in range(NS)]           # chunk k's decode and status copy are done (k % NS)
+    in_flight = [None] * NS                                       # frame indices whose statuses h_st[k % NS] will hold
+
+    def check(ss, block):
+        idx = in_flight[ss]
+        if idx is None or not (block or done[ss].query()):
+            return
+        if block:
+            done[ss].synchronize()
+        in_flight[ss] = None
+        st = h_st[ss][:len(idx)].numpy()
+        if st.any():
+            bad = int(np.flatnonzero(st)[0])
+            raise RuntimeError(f"{filename}: frame {int(idx[bad])} " + ("is corrupt" if st[bad] == 1 else "is outside what the device "
+                               'decoder takes (a number of more than 64 bits): read this file with decode="host"'))
+
+    def fill_dev(copy, xyz, bx, idx):
+        k = state["k"]
+        state["k"] += 1
+        slot, ss = k & 1, k % NS
+        check(ss, True)                                           # chunk k-4: long done; frees the small pinned buffers
+        up[slot].synchronize()                                    # chunk k-2's upload: h_raw[slot] may be overwritten
+        n = len(idx)
+        desc, lo, hi, bv, _, _ = _xtc.chunk_desc(filename, idx, natoms)
+        need = hi - lo + _xtc.XTC_PAD
+        if h_raw[slot] is None or h_raw[slot].numel() < need:
+            h_raw[slot] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+        if d_raw[slot] is None or d_raw[slot].numel() < need:
+            done[(k - 2) % NS].synchronize()                      # (nobody reads the device copy that is let go)
+            with torch.cuda.stream(h2d):
+                d_raw[slot] = torch.empty(h_raw[slot].numel(), dtype=torch.uint8, device=dev)
+        _lib._check(lib.mkamd_xtc_copy_bytes(path, lo, hi, h_raw[slot].data_ptr(), nthreads))
+        h_raw[slot][hi - lo:need].zero_()                         # (the read-ahead pad: never used, but not left to chance)
+        h_desc[ss][:n].numpy()[...] = desc
+        images = max_images
+        if has_box:
+            hb = box_lengths(bv)                                  # [3, n]
+            h_box[ss][:n].numpy()[...] = hb.T
+            images = max(max_images, _chunk_images(hb, nvoxels, voxelsize))
+        with torch.cuda.stream(h2d):
+            if k >= 2:
+                h2d.wait_event(done[(k - 2) % NS])                # the decode that still reads d_raw[slot]
+            d_raw[slot][:need].copy_(h_raw[slot][:need], non_blocking=True)
+            up[slot].record(h2d)
+        copy.wait_event(up[slot])
+        d_desc[slot][:n].copy_(h_desc[ss][:n], non_blocking=True)
+        if has_box:
+            bx.copy_(h_box[ss][:n], non_blocking=True)
+        _lib._check(lib.mkamd_xtc_decode_dev(run_ctx._h, copy.cuda_stream or None, d_raw[slot].data_ptr(), d_desc[slot].data_ptr(), n,
+                                             natoms, 10.0, xyz.data_ptr(), d_st[slot].data_ptr(), work.data_ptr(), work.numel()))
+        h_st[ss][:n].copy_(d_st[slot][:n], non_blocking=True)
+        done[ss].record(copy)
+        in_flight[ss] = np.array(idx, copy=True)
+        return images
+
+    gen = _stream_voxelize(natoms, fr, None, 10.0, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first,
+                           run_ctx, max_images, fill_dev=fill_dev, pipelined=pipelined)
+    try:
+        for item in gen:
+            for ss in range(NS):
+                check(ss, False)
+            yield item
+        for ss in range(NS):
+            check(ss, True)
+    finally:
+        gen.close()                                               # (synchronizes the copy stream, which waited for the uploads)
+        h2d.synchronize()
+        for i in range(2):
+            if h_raw[i] is not None:
+                _pinned_give(("xtcraw", i), h_raw[i])

@@ -9,6 +9,7 @@
 #include <atomic>
 #include "pipeline.h"
 #include "dist_pipeline.h"
+#include "xtc_gpu.h"
 
 #include <algorithm>
 #include <cstring>
@@ -1302,6 +1303,123 @@ try {
     std::string err;
     const int st = mkamd::xtc::read(path, frames, n_sel, n_atoms, coords, box, time, step, (int)n_threads, err);
     if (st) return fail(MKAMD_EINVAL, err);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+// ---- XTC decoding on the device (xtc_gpu.h): the host parses the record headers and copies the records' bytes; a lane walks a frame,
+// a thread decodes a group ----
+extern "C" int mkamd_xtc_chunk_desc(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, void* desc_out,
+                                    int64_t* byte_lo, int64_t* byte_hi, float* box, float* time, int32_t* step)
+try {
+    using namespace mkamd::xtc;
+    if (!path) return fail(MKAMD_EINVAL, "path is NULL");
+    if (n_sel <= 0 || n_atoms < 0) return fail(MKAMD_EINVAL, "n_sel must be > 0 and n_atoms >= 0");
+    if (!desc_out || !byte_lo || !byte_hi || !box || !time || !step) return fail(MKAMD_EINVAL, "NULL pointer");
+    Mapped m;
+    if (!m.open_file(path)) return fail(MKAMD_EINVAL, std::string("cannot open ") + path);
+    std::shared_ptr<const FrameIndex> idx;
+    if (index_frames_cached(m, idx) != OK) return fail(MKAMD_EINVAL, "not an XTC file (bad magic number)");
+    if (idx->natoms != n_atoms) return fail(MKAMD_EINVAL, "atom count of the file differs from the buffers'");
+    mkamd::XtcFrameDesc* D = (mkamd::XtcFrameDesc*)desc_out;
+    size_t lo = (size_t)-1, hi = 0;
+    std::vector<size_t> rec((size_t)n_sel), end((size_t)n_sel);
+    for (int64_t j = 0; j < n_sel; ++j) {
+        const int64_t f = frames ? frames[j] : j;
+        if (f < 0 || f >= (int64_t)idx->offs.size()) return fail(MKAMD_EINVAL, "frame index out of range");
+        const size_t r = idx->offs[(size_t)f];
+        const uint8_t* q = m.p + r;
+        if (be_i32(q) != FRAME_MAGIC || (int64_t)be_i32(q + 4) != n_atoms || (int64_t)be_i32(q + 52) != n_atoms) return fail(MKAMD_EINVAL, "corrupt XTC frame");
+        step[j] = be_i32(q + 8);
+        time[j] = be_f32(q + 12);
+        for (int i = 0; i < 9; ++i) box[(size_t)i * (size_t)n_sel + (size_t)j] = be_f32(q + 16 + 4 * i);
+        mkamd::XtcFrameDesc d{};
+        size_t data = r + 56, e;
+        if (n_atoms <= 9) {
+            d.raw = 1; d.nbytes = (unsigned)(12 * n_atoms);
+            e = data + (size_t)12 * (size_t)n_atoms;
+        } else {
+            const uint8_t* h = m.p + data;
+            const float precision = be_f32(h);
+            int32_t hi3[3];
+            for (int k = 0; k < 3; ++k) { d.lo[k] = be_i32(h + 4 + 4 * k); hi3[k] = be_i32(h + 16 + 4 * k); }
+            d.smallidx = be_i32(h + 28);
+            const int32_t nbytes = be_i32(h + 32);
+            data += 36;
+            if (nbytes < 0 || data + (size_t)nbytes > m.n) return fail(MKAMD_EINVAL, "corrupt XTC frame");
+            d.nbytes = (unsigned)nbytes;
+            for (int k = 0; k < 3; ++k) d.range[k] = (uint32_t)hi3[k] - (uint32_t)d.lo[k] + 1u;
+            if (!d.range[0] || !d.range[1] || !d.range[2]) return fail(MKAMD_EINVAL, "corrupt XTC frame");
+            if ((d.range[0] | d.range[1] | d.range[2]) > 0xffffffu) { d.triple_bits = 0; for (int k = 0; k < 3; ++k) d.field_bits[k] = bits_for(d.range[k]); }
+            else d.triple_bits = bits_for_product(d.range);
+            d.inv_precision = (float)(1.0 / (double)precision);            // as decode_frame
+            e = data + (((size_t)nbytes + 3) / 4) * 4;
+        }
+        rec[(size_t)j] = data; end[(size_t)j] = e;
+        lo = std::min(lo, r); hi = std::max(hi, e);
+        D[j] = d;
+    }
+    if (hi > m.n) hi = m.n;
+    for (int64_t j = 0; j < n_sel; ++j) D[j].data_off = (unsigned long long)(rec[(size_t)j] - lo);
+    *byte_lo = (int64_t)lo; *byte_hi = (int64_t)hi;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+extern "C" int mkamd_xtc_copy_bytes(const char* path, int64_t lo, int64_t hi, void* dst, int32_t n_threads)
+try {
+    using namespace mkamd::xtc;
+    if (!path || !dst) return fail(MKAMD_EINVAL, "NULL pointer");
+    Mapped m;
+    if (!m.open_file(path)) return fail(MKAMD_EINVAL, std::string("cannot open ") + path);
+    if (lo < 0 || hi < lo || (size_t)hi > m.n) return fail(MKAMD_EINVAL, "byte range outside the file");
+    const size_t n = (size_t)(hi - lo);
+    int nt = n_threads > 0 ? n_threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = (int)std::min<size_t>((size_t)nt, std::max<size_t>(n >> 22, 1));         // >= 4 MB per thread
+    auto part = [&](int t) {
+        const size_t a = n / (size_t)nt * (size_t)t, b = t == nt - 1 ? n : n / (size_t)nt * (size_t)(t + 1);
+        std::memcpy((char*)dst + a, m.p + (size_t)lo + a, b - a);
+    };
+    if (nt == 1) part(0);
+    else { std::vector<std::thread> pool; for (int t = 0; t < nt; ++t) pool.emplace_back(part, t); for (auto& th : pool) th.join(); }
+    return MKAMD_OK;
+} MK_API_CATCH
+
+static uint64_t xtc_work_groups_offset(int64_t n_frames) { return ((uint64_t)n_frames * 4u + 255u) & ~(uint64_t)255u; }
+
+extern "C" uint64_t mkamd_xtc_decode_work_bytes(int64_t n_frames, int64_t n_atoms)
+{
+    if (n_frames <= 0 || n_atoms < 0) return 0;
+    return xtc_work_groups_offset(n_frames) + (uint64_t)n_frames * (uint64_t)n_atoms * sizeof(mkamd::XtcGroup);
+}
+
+extern "C" int mkamd_xtc_decode_dev(mkamd_ctx* ctx, void* hip_stream, const void* d_bytes, const void* d_desc, int64_t n_frames,
+                                    int64_t n_atoms, float scale, float* d_xyz, int32_t* d_status, void* d_work, uint64_t work_bytes)
+try {
+    int st = check_ctx(ctx, true);
+    if (st) return st;
+    if (n_frames < 0 || n_atoms < 0) return fail(MKAMD_EINVAL, "n_frames / n_atoms must be >= 0");
+    if (n_frames == 0) return MKAMD_OK;
+    if (!d_bytes || !d_desc || !d_xyz || !d_status || !d_work) return fail(MKAMD_EINVAL, "NULL pointer");
+    if (work_bytes < mkamd_xtc_decode_work_bytes(n_frames, n_atoms))
+        return fail(MKAMD_EINVAL, "work buffer smaller than mkamd_xtc_decode_work_bytes(n_frames, n_atoms)");
+    if (((uintptr_t)d_work & 7u) || ((uintptr_t)d_bytes & 3u)) return fail(MKAMD_EINVAL, "d_work must be 8-byte, d_bytes 4-byte aligned");
+    hipStream_t s = (hipStream_t)hip_stream;
+    int* ngroups = static_cast<int*>(d_work);
+    mkamd::XtcGroup* groups = reinterpret_cast<mkamd::XtcGroup*>(static_cast<unsigned char*>(d_work) + xtc_work_groups_offset(n_frames));
+    const unsigned char* bytes = static_cast<const unsigned char*>(d_bytes);
+    const mkamd::XtcFrameDesc* desc = static_cast<const mkamd::XtcFrameDesc*>(d_desc);
+    hipLaunchKernelGGL(mkamd::k_xtc_scan, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, s, bytes, desc, (long long)n_frames,
+                       (long long)n_atoms, scale, d_xyz, groups, ngroups, d_status);
+    HIP_TRY(hipGetLastError());
+    if (n_atoms >= (1ll << 21)) return MKAMD_OK;                     // (every frame got status 2; nothing to expand)
+    const int64_t bpf = (n_atoms + 255) / 256;
+    if (bpf == 0) return MKAMD_OK;
+    const int64_t per_launch = std::max<int64_t>(1, (int64_t)0x7fffffff / bpf);
+    for (int64_t f0 = 0; f0 < n_frames; f0 += per_launch) {
+        const int64_t nf = std::min(per_launch, n_frames - f0);
+        hipLaunchKernelGGL(mkamd::k_xtc_expand, dim3((unsigned)(nf * bpf)), dim3(256), 0, s, bytes, desc, (long long)f0, (long long)n_atoms,
+                           scale, d_xyz, groups, ngroups, (int)bpf);
+        HIP_TRY(hipGetLastError());
+    }
     return MKAMD_OK;
 } MK_API_CATCH
 

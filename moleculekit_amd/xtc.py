@@ -101,6 +101,77 @@ def XTCread(filename, frame=None, nthreads: int = 0) -> Trajectory:
 
 
 # ------------------------------------------------------------------------------------------------
+# decoding on the device (round 4; include/mkamd_xtc.h, csrc/xtc_gpu.h): a GPU lane decodes a frame
+# ------------------------------------------------------------------------------------------------
+DESC_BYTES = 64        # sizeof(mkamd::XtcFrameDesc)
+XTC_PAD = 1024         # bytes the device copy of a chunk's records extends past them (MKAMD_XTC_PAD, include/mkamd_xtc.h)
+
+
+DESC_DTYPE = np.dtype([("data_off", "<u8"), ("nbytes", "<u4"), ("smallidx", "<i4"), ("lo", "<i4", 3), ("range", "<u4", 3),
+                       ("inv_precision", "<f4"), ("triple_bits", "<i4"), ("field_bits", "<i4", 3), ("raw", "<i4")])
+assert DESC_DTYPE.itemsize == DESC_BYTES
+
+
+def device_decodable(desc, natoms) -> bool:
+    """What the headers tell about ``status 2`` of the device decoder (include/mkamd_xtc.h): no frame of ``desc`` (from
+    ``chunk_desc``) packs a coordinate into more than 64 bits, has >= 2^21 atoms or a stream of >= 512 MB.  (A run of small
+    atoms coded in more than 64 bits is only seen by the device; files with such runs have ranges that fail here.)"""
+    d = np.ascontiguousarray(desc).view(DESC_DTYPE).reshape(-1)
+    return bool(natoms < (1 << 21) and np.all(d["triple_bits"] <= 64) and np.all(d["nbytes"] < (1 << 29) - 4))
+
+
+def chunk_desc(filename, frames, natoms):
+    """Host half of the device decoder for the frames ``frames`` (int64 array): ``(desc uint8 [n, 64], byte_lo, byte_hi,
+    boxvectors f32 [3,3,n] nm, time f32 [n] ps, step i32 [n])`` -- record headers only, no coordinate is decoded."""
+    sel = np.ascontiguousarray(frames, dtype=np.int64).reshape(-1)
+    n = len(sel)
+    desc = np.empty((n, DESC_BYTES), dtype=np.uint8)
+    box = np.empty((3, 3, n), dtype=np.float32)
+    time = np.empty(n, dtype=np.float32)
+    step = np.empty(n, dtype=np.int32)
+    lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib._check(_lib.load().mkamd_xtc_chunk_desc(_path(filename), _lib._ptr(sel), n, int(natoms), _lib._ptr(desc), ctypes.byref(lo),
+                                                 ctypes.byref(hi), _lib._ptr(box), _lib._ptr(time), _lib._ptr(step)))
+    return desc, int(lo.value), int(hi.value), box, time, step
+
+
+def read_xtc_frames_dev(filename, frames=None, scale: float = 1.0, ctx=None):
+    """``read_xtc_frames`` with the coordinates decoded ON THE GPU: returns ``(xyz, boxvectors, time, step)`` with ``xyz`` a
+    float32 CUDA tensor ``[n, natoms, 3]`` (frame-major: the voxelizer's packed items; ``scale`` 10 gives Angstrom) whose
+    values are bit for bit ``read_xtc_frames(...)[0] * scale`` transposed.  Synchronous (tests, one-off reads); the streaming
+    form is ``batch.iterVoxelizeXTC`` (``decode="auto"`` / ``"gpu"``).  Raises for a stream the device decoder refuses (ranges
+    whose mixed-radix number exceeds 64 bits, >= 2^21 atoms: use the host decoder)."""
+    import torch
+
+    ctx = ctx or _lib.default_context()
+    natoms, nframes = _info(filename)
+    sel = np.arange(nframes, dtype=np.int64) if frames is None else np.ascontiguousarray(frames, dtype=np.int64).reshape(-1)
+    dev = torch.device("cuda", ctx.device)
+    n = len(sel)
+    xyz = torch.empty((n, natoms, 3), dtype=torch.float32, device=dev)
+    if n == 0:
+        return xyz, np.zeros((3, 3, 0), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32)
+    desc, lo, hi, box, time, step = chunk_desc(filename, sel, natoms)
+    raw = torch.zeros(hi - lo + XTC_PAD, dtype=torch.uint8).pin_memory()          # (the kernel reads ahead of what it uses)
+    _lib._check(_lib.load().mkamd_xtc_copy_bytes(_path(filename), lo, hi, raw.data_ptr(), 0))
+    with torch.cuda.device(dev):
+        d_raw = raw.to(dev, non_blocking=True)
+        d_desc = torch.as_tensor(desc, device=dev)
+        d_st = torch.empty(n, dtype=torch.int32, device=dev)
+        work = torch.empty(int(_lib.load().mkamd_xtc_decode_work_bytes(n, natoms)), dtype=torch.uint8, device=dev)
+        s = torch.cuda.current_stream(dev)
+        _lib._check(_lib.load().mkamd_xtc_decode_dev(ctx._h, s.cuda_stream or None, d_raw.data_ptr(), d_desc.data_ptr(), n, natoms,
+                                                     float(scale), xyz.data_ptr(), d_st.data_ptr(), work.data_ptr(), work.numel()))
+        st = d_st.cpu().numpy()
+    if st.any():
+        bad = int(np.flatnonzero(st)[0])
+        raise RuntimeError(f"device XTC decoder: frame {int(sel[bad])} " + ("is corrupt" if st[bad] == 1 else
+                           "is outside what the device decoder takes (numbers of more than 64 bits -- a coordinate range beyond ~2 million "
+                           "quanta per axis --, >= 2^21 atoms or >= 512 MB per frame): use the host decoder"))
+    return xyz, box, time, step
+
+
+# ------------------------------------------------------------------------------------------------
 # writing (round 4): enough of an encoder to produce valid trajectories for tests and benchmarks
 # ------------------------------------------------------------------------------------------------
 _MAGIC = 1995

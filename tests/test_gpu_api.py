@@ -230,13 +230,20 @@ def test_xtc_fed_stream_matches_decode_then_voxelize():
     for pbc in (False, True):
         want, _, _ = batch._voxelizeTrajectory_packed(tr.coords, sig, center, [14, 14, 14], 1.0, box=tr.box.astype(np.float32) if pbc else None)
         for chunk in (7, 64):
-            outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=pbc, chunk=chunk)]
-            torch.cuda.synchronize()
-            assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
+            for decode in ("auto", "gpu", "host"):                # (auto = the device decoder for this contiguous range)
+                seen, outs = [], []
+                for idx, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=pbc, chunk=chunk, decode=decode):
+                    seen.append(np.asarray(idx)); outs.append(f)
+                torch.cuda.synchronize()
+                assert np.array_equal(np.concatenate(seen), np.arange(F))
+                assert np.array_equal(torch.cat(outs).cpu().numpy(), want), (pbc, chunk, decode)
     sel = np.array([5, 0, 19])
-    outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=False, frames=sel, chunk=2)]
     want, _, _ = batch._voxelizeTrajectory_packed(tr.coords, sig, center, [14, 14, 14], 1.0, frames=sel)
-    assert np.array_equal(torch.cat(outs).cpu().numpy(), want)
+    for decode in ("auto", "gpu", "host"):                        # (auto = the host decoder for a scattered selection)
+        outs = [f for _, f in batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, pbc=False, frames=sel, chunk=2, decode=decode)]
+        assert np.array_equal(torch.cat(outs).cpu().numpy(), want), decode
+    with pytest.raises(ValueError, match="decode"):
+        next(batch.iterVoxelizeXTC(fn, sig, center, [14, 14, 14], 1.0, decode="fpga"))
 
 
 def test_streaming_paths_raise_on_bad_frames_instead_of_yielding_incomplete_features():
@@ -435,3 +442,91 @@ def test_host_call_halves_are_guarded(hip_ctx):
     hip_ctx.poll_errors()
     assert np.array_equal(end(), ref) and cen.shape == (int(np.prod(nv)), 3)
     assert np.array_equal(batch.voxelize_lattice(*args, ctx=hip_ctx), ref)
+
+
+def test_device_xtc_decoder_is_bit_exact_with_the_host_decoder(hip_ctx, tmp_path):
+    """Round 4 (csrc/xtc_gpu.h): a GPU lane decodes a frame.  Every reference-held trajectory of the test tier (runs of small
+    differences, the water swap, step changes of the small-number table), a synthetic 30 000-atom file, per-axis bit fields,
+    <= 9 atoms as plain floats, frame subsets in any order -- coordinates bit for bit what the host decoder (itself pinned
+    against the REAL reference reader, tests/test_xtc.py) returns, scaled to Angstrom with the same float32 multiply; box
+    vectors, time and step the same; a range beyond 64 bits is refused, not mis-decoded."""
+    import torch
+    from moleculekit_amd import xtc
+    here = os.path.join(os.path.dirname(__file__), "golden", "xtc")
+    files = [os.path.join(here, n + ".xtc") for n in ("mol", "aladipep", "3ptb_traj_head", "4rws_head")]
+    rng = np.random.default_rng(77)
+    for name, N, F, L in (("syn", 30000, 5, 6.69), ("small", 7, 4, 2.0), ("wide", 50, 3, 30000.0), ("tiny_box", 200, 6, 0.8)):
+        x = (rng.uniform(-0.3, 1.0, size=(N, 3, F)) * L).astype(np.float32)
+        bv = np.zeros((3, 3, F), np.float32); bv[0, 0] = bv[1, 1] = bv[2, 2] = L
+        fn = str(tmp_path / (name + ".xtc"))
+        xtc.write_xtc(fn, x, bv, np.arange(F, dtype=np.float32), np.arange(F))
+        files.append(fn)
+    for fn in files:
+        F = xtc.get_xtc_nframes(fn)
+        for sel in (None, np.arange(F)[::-1][: max(1, F // 2)], np.array([F - 1, 0, F - 1])):
+            c, b, t, s = xtc.read_xtc(fn) if sel is None else xtc.read_xtc_frames(fn, sel)
+            for scale in (1.0, 10.0):
+                xyz, b2, t2, s2 = xtc.read_xtc_frames_dev(fn, sel, scale=scale, ctx=hip_ctx)
+                want = np.ascontiguousarray(np.transpose(c, (2, 0, 1))) * np.float32(scale)
+                got = xyz.cpu().numpy()
+                assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (os.path.basename(fn), scale)
+                assert np.array_equal(b2, b) and np.array_equal(t2, t) and np.array_equal(s2, s)
+    x = (rng.uniform(-0.5, 1.0, size=(40, 3, 2)) * 3000.0).astype(np.float32)            # 66..72-bit mixed-radix numbers
+    bv = np.zeros((3, 3, 2), np.float32); bv[0, 0] = bv[1, 1] = bv[2, 2] = 3000.0
+    fn = str(tmp_path / "huge.xtc")
+    xtc.write_xtc(fn, x, bv, np.zeros(2, np.float32), np.arange(2))
+    with pytest.raises(RuntimeError, match="more than 64 bits"):
+        xtc.read_xtc_frames_dev(fn, ctx=hip_ctx)
+    assert not xtc.device_decodable(xtc.chunk_desc(fn, np.arange(2), 40)[0], 40)
+
+
+def test_device_xtc_decoder_many_waves_many_windows_and_bad_streams(hip_ctx, tmp_path):
+    """The two passes of csrc/xtc_gpu.h at sizes where their bookkeeping matters: several hundred frames (a wave walks 64,
+    lanes finish at different positions, the last wave is ragged), streams of tens of LDS windows per frame, chunks of
+    frames that differ in length; the streamed form (``iterVoxelizeXTC(decode="gpu")``: growing byte buffers, two slots,
+    statuses checked as chunks complete) against the host decoder's; a damaged stream raises -- from the one-off reader and
+    from the stream -- instead of yielding coordinates."""
+    import torch
+    from moleculekit_amd import batch, xtc
+    src = os.path.join(os.path.dirname(__file__), "golden", "xtc", "3ptb_traj_head.xtc")
+    blob = open(src, "rb").read()
+    many = str(tmp_path / "many.xtc")
+    with open(many, "wb") as fh:
+        for _ in range(35):
+            fh.write(blob)
+    rng = np.random.default_rng(5)
+    N, F = 3000, 150
+    walk = np.cumsum(rng.normal(0, 0.02, size=(N, 3, 1)), axis=0) + rng.normal(0, 0.01, size=(N, 3, F)) + rng.uniform(0, 4.0, size=(1, 3, F))
+    bv = np.zeros((3, 3, F), np.float32); bv[0, 0] = bv[1, 1] = bv[2, 2] = 5.0
+    syn = str(tmp_path / "walk.xtc")
+    xtc.write_xtc(syn, walk.astype(np.float32), bv, np.arange(F, dtype=np.float32), np.arange(F))
+    for fn in (many, syn):
+        c, b, t, s = xtc.read_xtc(fn)
+        xyz, b2, t2, s2 = xtc.read_xtc_frames_dev(fn, scale=10.0, ctx=hip_ctx)
+        want = np.ascontiguousarray(np.transpose(c, (2, 0, 1))) * np.float32(10.0)
+        assert np.array_equal(xyz.cpu().numpy().view(np.uint32), want.view(np.uint32)), os.path.basename(fn)
+        assert np.array_equal(b2, b) and np.array_equal(t2, t) and np.array_equal(s2, s)
+    # streamed: device decode against host decode, chunk sizes that leave ragged tails and make the byte buffers grow
+    na, nf = xtc.get_xtc_natoms(many), xtc.get_xtc_nframes(many)
+    sig = np.where(rng.random((na, 4)) < 0.3, 1.6, 0.0)
+    center = xtc.read_xtc_frames(many, np.array([0]))[0][:, :, 0].mean(0).astype(np.float64) * 10.0
+    want = torch.cat([f for _, f in batch.iterVoxelizeXTC(many, sig, center, [12, 12, 12], 1.0, pbc=True, chunk=64, decode="host")]).cpu().numpy()
+    for chunk in (50, 128):
+        got = torch.cat([f for _, f in batch.iterVoxelizeXTC(many, sig, center, [12, 12, 12], 1.0, pbc=True, chunk=chunk, decode="gpu")]).cpu().numpy()
+        assert got.shape[0] == nf and np.array_equal(got, want), chunk
+    # a damaged stream: an impossible small-number index in one frame's header (xdrfile.cpp:782 reads it before the stream)
+    desc = xtc.chunk_desc(many, np.arange(3), na)[0].view(xtc.DESC_DTYPE).reshape(-1)
+    bad = bytearray(open(many, "rb").read())
+    # the record's smallidx word sits 8 bytes before the stream's byte count, which is 4 bytes before the stream
+    off = int(desc["data_off"][1]) + xtc.chunk_desc(many, np.arange(3), na)[1] - 8
+    assert int.from_bytes(bad[off:off + 4], "big") == int(desc["smallidx"][1])
+    bad[off:off + 4] = (200).to_bytes(4, "big")
+    badfn = str(tmp_path / "bad.xtc")
+    open(badfn, "wb").write(bytes(bad))
+    with pytest.raises((RuntimeError, ValueError)):
+        xtc.read_xtc_frames(badfn, np.arange(3))
+    with pytest.raises(RuntimeError, match="corrupt"):
+        xtc.read_xtc_frames_dev(badfn, np.arange(3), ctx=hip_ctx)
+    with pytest.raises(RuntimeError, match="corrupt"):
+        for _ in batch.iterVoxelizeXTC(badfn, sig, center, [12, 12, 12], 1.0, pbc=False, frames=np.arange(3), chunk=2, decode="gpu"):
+            pass
