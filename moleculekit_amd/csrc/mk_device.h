@@ -12,6 +12,8 @@
 
 #define MK_DEV __device__ __forceinline__
 #define MK_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define MK_DEVFN __device__                       // a member function of a device-side struct
+#define MK_DEV_CONST __device__ const             // a table in device memory
 
 typedef float v2f __attribute__((ext_vector_type(2)));   // -> v_pk_{add,mul,fma}_f32
 
@@ -139,6 +141,7 @@ MK_DEV void mk_store_result(float4* p, float4 v)
     }
 }
 // value of `v` in lane `lane` (wave-uniform index) -> SGPR (v_readlane_b32)
+MK_DEV void mk_setprio_high() { __builtin_amdgcn_s_setprio(3); }   // this wave first at the issue arbiter of its SIMD
 MK_DEV unsigned mk_readlane(unsigned v, int lane) { return (unsigned)__builtin_amdgcn_readlane((int)v, lane); }
 
 MK_DEV unsigned mk_shfl_up(unsigned v, int delta) { return __shfl_up(v, delta, WAVE); }

@@ -39,7 +39,7 @@ struct XtcFrameDesc {                    // 64 bytes
 };
 static_assert(sizeof(XtcFrameDesc) == 64, "layout shared with the host");
 
-__device__ const int XTC_MAGIC[73] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406,
+MK_DEV_CONST int XTC_MAGIC[73] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 8, 10, 12, 16, 20, 25, 32, 40, 50, 64, 80, 101, 128, 161, 203, 256, 322, 406,
                                       512, 645, 812, 1024, 1290, 1625, 2048, 2580, 3250, 4096, 5060, 6501, 8192, 10321, 13003, 16384, 20642,
                                       26007, 32768, 41285, 52015, 65536, 82570, 104031, 131072, 165140, 208063, 262144, 330280, 416127,
                                       524287, 660561, 832255, 1048576, 1321122, 1664510, 2097152, 2642245, 3329021, 4194304, 5284491,
@@ -53,14 +53,14 @@ struct XtcBits {                         // MSB-first bit reader over 32-bit big
     const unsigned* wp;
     unsigned long long acc;              // next bits, left-aligned
     int nacc;
-    __device__ void start(const unsigned char* base, unsigned bitpos)
+    MK_DEVFN void start(const unsigned char* base, unsigned bitpos)
     {
         wp = reinterpret_cast<const unsigned*>(base) + (bitpos >> 5);
         const int sh = (int)(bitpos & 31u);
         acc = (unsigned long long)__builtin_bswap32(*wp++) << (32 + sh);
         nacc = 32 - sh;
     }
-    __device__ unsigned get(int n)       // 0 <= n <= 32
+    MK_DEVFN unsigned get(int n)       // 0 <= n <= 32
     {
         if (nacc < n) {
             acc |= (unsigned long long)__builtin_bswap32(*wp++) << (32 - nacc);
@@ -76,7 +76,7 @@ struct XtcBits {                         // MSB-first bit reader over 32-bit big
 // x = q * r + rem for r < 2^25 and q < 2^48 (the quotients of the format's mixed-radix numbers): the quotient estimated in
 // double (53 bits: within one of the true one) and corrected -- the 64-bit integer division of this target is a ~100-instruction
 // routine, and there are two per atom
-__device__ inline unsigned long long xtc_divmod(unsigned long long x, unsigned r, double rinv, unsigned& rem)
+MK_DEV unsigned long long xtc_divmod(unsigned long long x, unsigned r, double rinv, unsigned& rem)
 {
     unsigned long long q = (unsigned long long)((double)x * rinv);
     long long d = (long long)(x - q * (unsigned long long)r);
@@ -89,7 +89,7 @@ __device__ inline unsigned long long xtc_divmod(unsigned long long x, unsigned r
 // the same for x < 2^32: the conversions are one instruction each way, the product x * (1/r) is within one of the quotient
 // (x is exact in double, 1/r is off by 2^-53 of itself), and the correction is two selects.  Most of the stream's numbers are
 // the small atoms' (smallidx bits, ~20-30) and the second division of a full one -- this path is what the lane's latency is made of.
-__device__ inline unsigned xtc_divmod32(unsigned x, unsigned r, double rinv, unsigned& rem)
+MK_DEV unsigned xtc_divmod32(unsigned x, unsigned r, double rinv, unsigned& rem)
 {
     unsigned q = (unsigned)((double)x * rinv);
     int d = (int)(x - q * r);
@@ -100,7 +100,7 @@ __device__ inline unsigned xtc_divmod32(unsigned x, unsigned r, double rinv, uns
 }
 
 // three values packed as one mixed-radix number of nbits (<= 64) bits whose bytes come least-significant first
-__device__ inline void xtc_triple(XtcBits& b, int nbits, unsigned r1, unsigned r2, double r1inv, double r2inv, int (&out)[3])
+MK_DEV void xtc_triple(XtcBits& b, int nbits, unsigned r1, unsigned r2, double r1inv, double r2inv, int (&out)[3])
 {
     int nfull = (nbits - 1) >> 3;
     const int top = nbits - 8 * nfull;
@@ -132,7 +132,6 @@ constexpr int XS_ROW = XS_WIN + 8;       // its LDS row (the word after the wind
 constexpr int XS_BATCH = 16;             // rows refilled per batch of loads in flight
 
 struct XtcGroup { unsigned pos, what; }; // what = first output atom (21 bits) | smallidx of the run << 21 | small atoms << 28
-typedef unsigned xtc_u2 __attribute__((ext_vector_type(2), aligned(4)));
 
 MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const XtcFrameDesc* __restrict__ desc, long long nframes,
                               long long natoms, float scale, float* __restrict__ out, XtcGroup* __restrict__ groups,
@@ -141,7 +140,7 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
     __shared__ unsigned win[WAVE * XS_ROW / 4];
     // this wave is a latency chain on a SIMD it usually shares with the voxelizer's waves (the feed decodes chunk k+1 beside
     // chunk k's tile kernel): first in line at the issue arbiter (beside cfg4 steps: 9.5 ms per 2 048 frames without, 7.7 alone)
-    __builtin_amdgcn_s_setprio(3);
+    mk_setprio_high();
     const int lane = (int)(threadIdx.x & (WAVE - 1));
     const long long f = (long long)blockIdx.x * WAVE + lane;
     bool live = f < nframes;
@@ -171,22 +170,23 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
         const unsigned wbase = pos >> 5;
         const unsigned long long src = (unsigned long long)(uintptr_t)(bytes + d.data_off) + 4ull * wbase;
         const unsigned src_lo = (unsigned)src, src_hi = (unsigned)(src >> 32);
-        __syncthreads();                                             // the rows are no longer being read
+        mk_block_sync();                                             // the rows are no longer being read
         for (int l0 = 0; l0 < WAVE; l0 += XS_BATCH) {
-            xtc_u2 v[XS_BATCH];
+            unsigned v[XS_BATCH][2];
 #pragma unroll
             for (int j = 0; j < XS_BATCH; ++j) {
-                const unsigned long long a = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)src_lo, l0 + j) |
-                                             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)src_hi, l0 + j) << 32);
-                v[j] = reinterpret_cast<const xtc_u2*>((uintptr_t)a)[lane];
+                const unsigned long long a = (unsigned long long)mk_readlane(src_lo, l0 + j) | ((unsigned long long)mk_readlane(src_hi, l0 + j) << 32);
+                const unsigned* __restrict__ p = reinterpret_cast<const unsigned*>((uintptr_t)a);
+                v[j][0] = p[2 * lane];
+                v[j][1] = p[2 * lane + 1];
             }
 #pragma unroll
             for (int j = 0; j < XS_BATCH; ++j) {
-                win[(l0 + j) * (XS_ROW / 4) + 2 * lane] = v[j].x;
-                win[(l0 + j) * (XS_ROW / 4) + 2 * lane + 1] = v[j].y;
+                win[(l0 + j) * (XS_ROW / 4) + 2 * lane] = v[j][0];
+                win[(l0 + j) * (XS_ROW / 4) + 2 * lane + 1] = v[j][1];
             }
         }
-        __syncthreads();
+        mk_block_sync();
         // the walk inside the window, straight-line: a wave alone on its SIMD issues an instruction every ~5-8 cycles and pays
         // every divergent branch in exec-mask bookkeeping (the first version of this loop: ~100 instructions, 820 cycles per
         // group), so the checks are accumulated, not branched on, and positions are 32-bit offsets from the window's start

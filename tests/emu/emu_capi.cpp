@@ -5,6 +5,7 @@
 #include "emu_device.h"
 #include "../../moleculekit_amd/csrc/pipeline.h"
 #include "../../moleculekit_amd/csrc/dist_pipeline.h"
+#include "../../moleculekit_amd/csrc/xtc_gpu.h"
 
 #include <string>
 #include <vector>
@@ -220,6 +221,22 @@ int emu_pdist(const float* c, long long n, int D, float* out)
 {
     EmuBackend be;
     return run_pdist(be, c, n, D, out, g_err);
+}
+
+// mirrors mkamd_xtc_decode_dev (csrc/capi.hip): the two passes of xtc_gpu.h on host memory; the work buffer is poisoned first
+int emu_xtc_decode(const unsigned char* bytes, const void* desc, long long n_frames, long long n_atoms, float scale, float* xyz, int* status)
+{
+    if (n_frames <= 0) return 0;
+    std::vector<int> ngroups((size_t)n_frames, -1);
+    std::vector<XtcGroup> groups((size_t)n_frames * (size_t)n_atoms + 1, XtcGroup{0xCDCDCDCDu, 0xCDCDCDCDu});
+    const XtcFrameDesc* D = static_cast<const XtcFrameDesc*>(desc);
+    emu::launch(k_xtc_scan, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), bytes, D, n_frames, n_atoms, scale, xyz, groups.data(), ngroups.data(), status);
+    if (n_atoms >= (1ll << 21)) return 0;
+    const long long bpf = (n_atoms + 255) / 256;
+    if (bpf == 0) return 0;
+    emu::launch(k_xtc_expand, dim3((unsigned)(n_frames * bpf)), dim3(256), bytes, D, 0ll, n_atoms, scale, xyz, (const XtcGroup*)groups.data(),
+                (const int*)ngroups.data(), (int)bpf);
+    return 0;
 }
 
 }  // extern "C"

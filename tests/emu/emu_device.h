@@ -22,6 +22,8 @@
 
 #define MK_DEV static inline
 #define MK_KERNEL(bounds)
+#define MK_DEVFN
+#define MK_DEV_CONST static const
 #define __shared__ static
 #ifndef __restrict__
 #define __restrict__ __restrict
@@ -246,6 +248,7 @@ MK_DEV void mk_tmp_store(float4* p, float4 v) { *p = v; }
 MK_DEV void mk_tmp_store(uint2* p, uint2 v) { *p = v; }
 MK_DEV float4 mk_tmp_load(const float4* p) { return *p; }
 MK_DEV uint2 mk_tmp_load(const uint2* p) { return *p; }
+MK_DEV void mk_setprio_high() {}
 MK_DEV unsigned mk_readlane(unsigned v, int lane)
 {
     const int wv = (int)threadIdx.x >> 6;

@@ -22,7 +22,7 @@ _lib = None
 def build(force=False):
     srcs = [os.path.join(_EMU, "emu_capi.cpp"), os.path.join(_EMU, "emu_device.h"),
             os.path.join(_CSRC, "kernels.h"), os.path.join(_CSRC, "pipeline.h"),
-            os.path.join(_CSRC, "dist_kernels.h"), os.path.join(_CSRC, "dist_pipeline.h")]
+            os.path.join(_CSRC, "dist_kernels.h"), os.path.join(_CSRC, "dist_pipeline.h"), os.path.join(_CSRC, "xtc_gpu.h")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         subprocess.check_call(
@@ -213,3 +213,17 @@ def calculate_occupancy(centers, coords, sigmas, results, inject_lattice_status=
                                        ctypes.c_longlong(coords.shape[0]), _p(sigmas), ctypes.c_int(sigmas.shape[1]),
                                        _p(results), ctypes.c_int(inject_lattice_status), ctypes.byref(route))
     return st, route.value
+
+
+def xtc_decode(raw, desc, natoms, scale=1.0):
+    """The device XTC decoder's two kernels (csrc/xtc_gpu.h) on host memory: ``raw`` uint8 (the records + XTC_PAD bytes),
+    ``desc`` uint8 [n, 64] -> (xyz float32 [n, natoms, 3] (poisoned with NaN first), status int32 [n])."""
+    raw = np.ascontiguousarray(raw, np.uint8)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    n = desc.shape[0]
+    xyz = np.full((n, natoms, 3), np.nan, np.float32)
+    status = np.full(n, -1, np.int32)
+    rc = lib().emu_xtc_decode(_p(raw), _p(desc), ctypes.c_longlong(n), ctypes.c_longlong(natoms), ctypes.c_float(scale), _p(xyz), _p(status))
+    assert rc == 0
+    return xyz, status
+

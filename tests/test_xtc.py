@@ -166,3 +166,77 @@ def test_write_then_read_round_trip_property():
         assert np.array_equal(b, box) and np.array_equal(tt, t) and np.array_equal(ss, s.astype(np.int32))
 
     prop()
+
+
+def _device_decode_emulated(fn, sel=None, scale=10.0):
+    """The host half of the device decoder (headers, record bytes: libmkamd.so, no GPU involved) + the two kernels of
+    csrc/xtc_gpu.h run by the host SIMT emulation (tests/emu): -> (xyz [n, natoms, 3], status [n])."""
+    import ctypes
+    import emu_build
+    from moleculekit_amd import _lib
+    na, nf = xtc.get_xtc_natoms(fn), xtc.get_xtc_nframes(fn)
+    sel = np.arange(nf, dtype=np.int64) if sel is None else np.asarray(sel, dtype=np.int64)
+    desc, lo, hi, box, t, st = xtc.chunk_desc(fn, sel, na)
+    raw = np.zeros(hi - lo + xtc.XTC_PAD, np.uint8)
+    _lib._check(_lib.load().mkamd_xtc_copy_bytes(xtc._path(fn), lo, hi, raw.ctypes.data_as(ctypes.c_void_p), 1))
+    assert np.array_equal(raw[:hi - lo], np.fromfile(fn, np.uint8, count=hi - lo, offset=lo))
+    return emu_build.xtc_decode(raw, desc, na, scale) + (desc,)
+
+
+def test_device_decoder_kernels_emulated_bit_exact_with_the_host_decoder(tmp_path):
+    """csrc/xtc_gpu.h on the CPU tier: the walk (a lane per frame: flag and run bits out of refilled windows, group records)
+    and the expansion (a thread per group) compiled for the host and run lane by lane (tests/emu) -- every reference-held
+    trajectory (runs of small atoms, the water swap, steps of the small-number table), frames in any order, more frames than a
+    wave, per-axis bit fields, <= 9 atoms, streams of many windows: the host decoder's coordinates bit for bit (itself pinned
+    against the real reference reader above), scaled with the same float32 multiply.  Numbers of more than 64 bits and damaged
+    streams come back as statuses, nothing is written out of bounds (the emulator's buffers are exact-size numpy arrays)."""
+    files = [os.path.join(HERE, n + ".xtc") for n in ("mol", "aladipep", "3ptb_traj_head", "4rws_head")]
+    rng = np.random.default_rng(21)
+    for name, N, F, L in (("syn", 1500, 70, 6.69), ("small", 7, 4, 2.0), ("wide", 50, 3, 30000.0), ("tiny_box", 200, 66, 0.8)):
+        x = (rng.uniform(-0.3, 1.0, size=(N, 3, F)) * L).astype(np.float32)
+        bv = np.zeros((3, 3, F), np.float32); bv[0, 0] = bv[1, 1] = bv[2, 2] = L
+        fn = str(tmp_path / (name + ".xtc"))
+        xtc.write_xtc(fn, x, bv, np.arange(F, dtype=np.float32), np.arange(F))
+        files.append(fn)
+    for fn in files:
+        F = xtc.get_xtc_nframes(fn)
+        for sel in (None, np.arange(F)[::-1][: max(1, F // 2)], np.array([F - 1, 0, F - 1])):
+            c = (xtc.read_xtc(fn) if sel is None else xtc.read_xtc_frames(fn, sel))[0]
+            want = np.ascontiguousarray(np.transpose(c, (2, 0, 1))) * np.float32(10.0)
+            got, st, _ = _device_decode_emulated(fn, sel)
+            assert not st.any(), (os.path.basename(fn), st)
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), os.path.basename(fn)
+    # 66..72-bit mixed-radix numbers: refused (status 2), and the headers say so beforehand
+    x = (rng.uniform(-0.5, 1.0, size=(40, 3, 2)) * 3000.0).astype(np.float32)
+    bv = np.zeros((3, 3, 2), np.float32); bv[0, 0] = bv[1, 1] = bv[2, 2] = 3000.0
+    fn = str(tmp_path / "huge.xtc")
+    xtc.write_xtc(fn, x, bv, np.zeros(2, np.float32), np.arange(2))
+    got, st, desc = _device_decode_emulated(fn)
+    assert list(st) == [2, 2] and np.isnan(got).all() and not xtc.device_decodable(desc, 40)
+    assert xtc.device_decodable(_device_decode_emulated(files[2])[2], xtc.get_xtc_natoms(files[2]))
+    # damaged streams: an impossible small-number index; a byte count that ends the stream early; random bit flips never
+    # write outside the frame's rows and either flag the frame or decode like the host decoder does
+    src = files[2]
+    na = xtc.get_xtc_natoms(src)
+    desc0, lo, hi, _, _, _ = xtc.chunk_desc(src, np.arange(3), na)
+    d = desc0.view(xtc.DESC_DTYPE).reshape(-1)
+    blob = bytearray(open(src, "rb").read())
+    off = int(d["data_off"][1]) + lo - 8                                                   # the header's smallidx word
+    assert int.from_bytes(blob[off:off + 4], "big") == int(d["smallidx"][1])
+    bad = bytearray(blob); bad[off:off + 4] = (200).to_bytes(4, "big")
+    fn = str(tmp_path / "bad_idx.xtc"); open(fn, "wb").write(bytes(bad))
+    got, st, _ = _device_decode_emulated(fn, np.arange(3))
+    assert list(st) == [0, 1, 0] and np.isnan(got[1]).all() and not np.isnan(got[0]).any() and not np.isnan(got[2]).any()
+    raw = np.zeros(hi - lo + xtc.XTC_PAD, np.uint8); raw[:hi - lo] = np.frombuffer(bytes(blob[lo:hi]), np.uint8)
+    import emu_build
+    short = desc0.copy(); short.view(xtc.DESC_DTYPE).reshape(-1)["nbytes"][1] //= 2           # the stream "ends" half way
+    got, st = emu_build.xtc_decode(raw, short, na, 10.0)
+    assert list(st) == [0, 1, 0]
+    ok = emu_build.xtc_decode(raw, desc0, na, 10.0)[0]
+    for trial in range(6):
+        r2 = raw.copy()
+        pos = rng.integers(int(d["data_off"][1]), int(d["data_off"][1]) + int(d["nbytes"][1]), size=4)
+        r2[pos] ^= rng.integers(1, 256, size=4).astype(np.uint8)
+        got, st = emu_build.xtc_decode(r2, desc0, na, 10.0)
+        assert st[0] == 0 and st[2] == 0 and np.array_equal(got[0], ok[0]) and np.array_equal(got[2], ok[2])
+        assert st[1] in (0, 1)
