@@ -172,7 +172,7 @@ def _device_decode_emulated(fn, sel=None, scale=10.0):
     """The host half of the device decoder (headers, record bytes: libmkamd.so, no GPU involved) + the two kernels of
     csrc/xtc_gpu.h run by the host SIMT emulation (tests/emu): -> (xyz [n, natoms, 3], status [n])."""
     import ctypes
-    import emu_build
+    from tests import emu_build
     from moleculekit_amd import _lib
     na, nf = xtc.get_xtc_natoms(fn), xtc.get_xtc_nframes(fn)
     sel = np.arange(nf, dtype=np.int64) if sel is None else np.asarray(sel, dtype=np.int64)
@@ -228,7 +228,7 @@ def test_device_decoder_kernels_emulated_bit_exact_with_the_host_decoder(tmp_pat
     got, st, _ = _device_decode_emulated(fn, np.arange(3))
     assert list(st) == [0, 1, 0] and np.isnan(got[1]).all() and not np.isnan(got[0]).any() and not np.isnan(got[2]).any()
     raw = np.zeros(hi - lo + xtc.XTC_PAD, np.uint8); raw[:hi - lo] = np.frombuffer(bytes(blob[lo:hi]), np.uint8)
-    import emu_build
+    from tests import emu_build
     short = desc0.copy(); short.view(xtc.DESC_DTYPE).reshape(-1)["nbytes"][1] //= 2           # the stream "ends" half way
     got, st = emu_build.xtc_decode(raw, short, na, 10.0)
     assert list(st) == [0, 1, 0]
