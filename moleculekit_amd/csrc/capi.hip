@@ -1388,7 +1388,7 @@ static uint64_t xtc_work_groups_offset(int64_t n_frames) { return ((uint64_t)n_f
 extern "C" uint64_t mkamd_xtc_decode_work_bytes(int64_t n_frames, int64_t n_atoms)
 {
     if (n_frames <= 0 || n_atoms < 0) return 0;
-    return xtc_work_groups_offset(n_frames) + (uint64_t)n_frames * (uint64_t)n_atoms * sizeof(mkamd::XtcGroup);
+    return xtc_work_groups_offset(n_frames) + (uint64_t)n_frames * (uint64_t)(n_atoms + mkamd::XS_SPEC) * sizeof(mkamd::XtcGroup);
 }
 
 extern "C" int mkamd_xtc_decode_dev(mkamd_ctx* ctx, void* hip_stream, const void* d_bytes, const void* d_desc, int64_t n_frames,

@@ -127,9 +127,18 @@ MK_DEV void xtc_triple(XtcBits& b, int nbits, unsigned r1, unsigned r2, double r
 }
 
 // ---- pass 1: the walk ----
-constexpr int XS_WIN = 512;              // bytes of a lane's window of its stream
+#ifndef MK_XTC_WIN
+#define MK_XTC_WIN 1024                  // (512: +8 % on a stream without runs, +14 % on 3PTB's -- a refill costs the wave ~3 000 cycles)
+#endif
+#ifndef MK_XTC_SPEC
+#define MK_XTC_SPEC 8
+#endif
+constexpr int XS_WIN = MK_XTC_WIN;       // bytes of a lane's window of its stream
 constexpr int XS_ROW = XS_WIN + 8;       // its LDS row (the word after the window may be read; its bits are never used)
-constexpr int XS_BATCH = 16;             // rows refilled per batch of loads in flight
+constexpr int XS_LW = XS_WIN / 4 / WAVE; // words of a row a lane loads in a refill
+constexpr int XS_BATCH = 32 / XS_LW;     // rows refilled per batch of loads in flight
+constexpr int XS_SPEC = MK_XTC_SPEC;     // groups looked at together (below)
+static_assert(XS_WIN % (4 * WAVE) == 0 && XS_BATCH >= 1 && WAVE % XS_BATCH == 0, "window: whole words per lane");
 
 struct XtcGroup { unsigned pos, what; }; // what = first output atom (21 bits) | smallidx of the run << 21 | small atoms << 28
 
@@ -162,9 +171,10 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
     }
     const unsigned full_bits = d.triple_bits ? (unsigned)d.triple_bits : (unsigned)(d.field_bits[0] + d.field_bits[1] + d.field_bits[2]);
     const unsigned long long total_bits = (unsigned long long)((d.nbytes + 3u) / 4u) * 32ull;
-    XtcGroup* __restrict__ grp = groups + (size_t)(f < nframes ? f : 0) * (size_t)natoms;
+    XtcGroup* __restrict__ grp = groups + (size_t)(f < nframes ? f : 0) * (size_t)(natoms + XS_SPEC);
     unsigned pos = 0u;
     int w = 0, g = 0, run = 0;
+    bool together = false;                                           // wave-uniform: look at XS_SPEC groups together (below)
     while (mk_ballot(live) != 0ull) {
         // the wave refills every lane's window: row l <- XS_WIN bytes of frame l's stream from the word its position is in
         const unsigned wbase = pos >> 5;
@@ -172,34 +182,44 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
         const unsigned src_lo = (unsigned)src, src_hi = (unsigned)(src >> 32);
         mk_block_sync();                                             // the rows are no longer being read
         for (int l0 = 0; l0 < WAVE; l0 += XS_BATCH) {
-            unsigned v[XS_BATCH][2];
+            unsigned v[XS_BATCH][XS_LW];
 #pragma unroll
             for (int j = 0; j < XS_BATCH; ++j) {
                 const unsigned long long a = (unsigned long long)mk_readlane(src_lo, l0 + j) | ((unsigned long long)mk_readlane(src_hi, l0 + j) << 32);
                 const unsigned* __restrict__ p = reinterpret_cast<const unsigned*>((uintptr_t)a);
-                v[j][0] = p[2 * lane];
-                v[j][1] = p[2 * lane + 1];
+#pragma unroll
+                for (int i = 0; i < XS_LW; ++i) v[j][i] = p[XS_LW * lane + i];
             }
 #pragma unroll
-            for (int j = 0; j < XS_BATCH; ++j) {
-                win[(l0 + j) * (XS_ROW / 4) + 2 * lane] = v[j][0];
-                win[(l0 + j) * (XS_ROW / 4) + 2 * lane + 1] = v[j][1];
-            }
+            for (int j = 0; j < XS_BATCH; ++j)
+#pragma unroll
+                for (int i = 0; i < XS_LW; ++i) win[(l0 + j) * (XS_ROW / 4) + XS_LW * lane + i] = v[j][i];
         }
         mk_block_sync();
-        // the walk inside the window, straight-line: a wave alone on its SIMD issues an instruction every ~5-8 cycles and pays
-        // every divergent branch in exec-mask bookkeeping (the first version of this loop: ~100 instructions, 820 cycles per
-        // group), so the checks are accumulated, not branched on, and positions are 32-bit offsets from the window's start
+        // the walk inside the window.  A wave alone on its SIMD issues an instruction every ~5-8 cycles and pays every divergent
+        // branch in exec-mask bookkeeping (the first version of this loop: ~100 instructions and 820 cycles per group), so the
+        // checks are accumulated, not branched on, and positions are 32-bit offsets from the window's start.  And what is
+        // serial is less than it looks: a flag is only SET where the run length or the small-number table changes -- between
+        // two flags every group has the same length (stride below), so the flag bits of the next XS_SPEC groups are read
+        // TOGETHER (independent LDS reads: one latency), the groups before the first set flag are taken in one step, and the
+        // one-group step with all its checks only runs where a flag, the window's end or an error stops them.  That pays where
+        // flags are rare (this package's writer sets none: 6.3 -> 2.9 ms per 30 000-atom frame; 4RWS with its water: 18 % of the
+        // groups) and costs a second LDS round trip per group where they are not -- on a protein the reference's writer
+        // adapts its small-number table at nearly every group (3PTB: 95 %; 0.24 -> 0.69 ms) --, so the wave votes after every
+        // window on what its frames' flags were like.
+        int n_clear = 0, n_set = 0;
         const unsigned* row = &win[lane * (XS_ROW / 4)];
         const unsigned long long wbit = (unsigned long long)wbase << 5;
         const unsigned tot = (unsigned)(total_bits - wbit < 0x7fff0000ull ? total_bits - wbit : 0x7fff0000ull);  // (wbit <= pos <= total_bits)
         unsigned rel = pos & 31u;
-        for (;;) {
+        // one group, whatever it is (the caller has checked that its flag and run bits are inside the window)
+        auto one_group = [&]() {
             const unsigned hdr = rel + full_bits;                                // where the flag bit is
-            if (!(live && hdr + 6u <= XS_WIN * 8u)) break;                       // (not live, or next window)
             const unsigned long long two = ((unsigned long long)__builtin_bswap32(row[hdr >> 5]) << 32) | __builtin_bswap32(row[(hdr >> 5) + 1]);
             const unsigned v = (unsigned)(two >> (58u - (hdr & 31u))) & 63u;     // flag, then the five run bits
             const bool flag = (v & 32u) != 0u;
+            n_set += flag ? 1 : 0;
+            n_clear += flag ? 0 : 1;
             const int r5 = (int)(v & 31u), m3 = r5 - 3 * ((r5 * 171) >> 9);      // r5 % 3
             run = flag ? r5 - m3 : run;                                          // (a run length stays until the next flag)
             const int step = flag ? m3 - 1 : 0;                                  // -1 / 0 / +1
@@ -216,8 +236,50 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
             const bool e_idx = (unsigned)(smallidx - XTC_FIRST) >= (unsigned)(XTC_NMAGIC - XTC_FIRST);
             st = e_end ? 1 : (e_wide ? 2 : ((e_more || e_idx) ? 1 : 0));
             live = st == 0 && w != (int)natoms;
+        };
+        // (two loops, not one with the step above under a condition: with both in one loop the compiler's exec-mask
+        // bookkeeping made the one-by-one walk 80 % slower -- 3PTB 0.23 -> 0.42 ms)
+#ifdef MK_XTC_DIAG_ONE_BY_ONE
+        together = false;
+#endif
+        if (!together) {
+            while (live && rel + full_bits + 6u <= XS_WIN * 8u) one_group();
+        } else {
+            while (live && rel + full_bits + 6u <= XS_WIN * 8u) {
+                const int ns = (run * 171) >> 9;                                 // small atoms per group until a flag says otherwise (run / 3)
+                const unsigned tail = 1u + (unsigned)(ns * smallidx), stride = full_bits + tail;
+                const int per = 1 + ns;
+                // (every word is read before anything is decided, and nothing below branches: eight independent LDS reads, one wait)
+                unsigned wd[XS_SPEC];
+#pragma unroll
+                for (int j = 0; j < XS_SPEC; ++j) {
+                    const unsigned k = (rel + full_bits + (unsigned)j * stride) >> 5;
+                    wd[j] = row[k < (unsigned)(XS_WIN / 4) ? k : (unsigned)(XS_WIN / 4)];
+                }
+                bool open = !(ns != 0 && smallidx > 64);
+                int np = 0;
+#pragma unroll
+                for (int j = 0; j < XS_SPEC; ++j) {
+                    const unsigned h = rel + full_bits + (unsigned)j * stride;   // group j's flag bit, if groups 0..j-1 have none
+                    const bool ok = (h + 6u <= XS_WIN * 8u) & (((__builtin_bswap32(wd[j]) >> (31u - (h & 31u))) & 1u) == 0u) & (h + tail <= tot) &
+                                    (w + (j + 1) * per <= (int)natoms);
+                    open = open & ok;
+                    np += open ? 1 : 0;
+                    // (written whether taken or not: the frame's records have XS_SPEC of slack, and what is not taken is
+                    // overwritten by the next step or lies beyond the frame's count)
+                    grp[g + j] = XtcGroup{(unsigned)wbit + h - full_bits, (unsigned)(w + j * per) | ((unsigned)smallidx << 21) | ((unsigned)ns << 28)};
+                }
+                g += np;
+                n_clear += np;
+                rel += (unsigned)np * stride;
+                w += np * per;
+                if (w == (int)natoms) live = false;
+                if (np < XS_SPEC && live && rel + full_bits + 6u <= XS_WIN * 8u) one_group();
+            }
         }
         pos = (unsigned)wbit + rel;
+        const unsigned long long voters = mk_ballot(live), ayes = mk_ballot(live && n_clear >= 3 * n_set);
+        together = voters != 0ull && 2 * mk_popc64(ayes) >= mk_popc64(voters);
     }
     if (mine) { status[f] = st; ngroups[f] = st ? 0 : g; }
 }
@@ -231,7 +293,7 @@ MK_KERNEL(256) void k_xtc_expand(const unsigned char* __restrict__ bytes, const 
     const int g = (int)(blockIdx.x % (unsigned)blocks_per_frame) * 256 + (int)threadIdx.x;
     if (g >= ngroups[f]) return;
     const XtcFrameDesc& d = desc[f];
-    const XtcGroup rec = groups[(size_t)f * (size_t)natoms + g];
+    const XtcGroup rec = groups[(size_t)f * (size_t)(natoms + XS_SPEC) + g];
     const long long w = (long long)(rec.what & 0x1FFFFFu);
     const int sidx = (int)((rec.what >> 21) & 127u), nsmall = (int)(rec.what >> 28);
     float* __restrict__ o = out + (size_t)f * (size_t)natoms * 3;

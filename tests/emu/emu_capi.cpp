@@ -228,7 +228,7 @@ int emu_xtc_decode(const unsigned char* bytes, const void* desc, long long n_fra
 {
     if (n_frames <= 0) return 0;
     std::vector<int> ngroups((size_t)n_frames, -1);
-    std::vector<XtcGroup> groups((size_t)n_frames * (size_t)n_atoms + 1, XtcGroup{0xCDCDCDCDu, 0xCDCDCDCDu});
+    std::vector<XtcGroup> groups((size_t)n_frames * (size_t)(n_atoms + XS_SPEC), XtcGroup{0xCDCDCDCDu, 0xCDCDCDCDu});
     const XtcFrameDesc* D = static_cast<const XtcFrameDesc*>(desc);
     emu::launch(k_xtc_scan, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), bytes, D, n_frames, n_atoms, scale, xyz, groups.data(), ngroups.data(), status);
     if (n_atoms >= (1ll << 21)) return 0;
