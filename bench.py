@@ -402,7 +402,7 @@ def bench_stream_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     return out
 
 
-def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=2048):
+def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=1024):
     """Secondary leg `xtc_cfg4`: the cfg4 FEEDER -- a synthetic 30 000-atom XTC trajectory (64 frames of the cfg4 random walk
     written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) voxelized through
     batch.iterVoxelizeXTC, with the coordinates decompressed ON THE DEVICE (decode="auto": csrc/xtc_gpu.h, large chunks) and,

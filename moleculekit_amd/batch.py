@@ -545,8 +545,8 @@ def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, 
       ``"gpu"``   on the device (csrc/xtc_gpu.h): per chunk the host parses the record headers and copies the records' BYTES
                   (~5 per atom) into pinned staging; a lane walks each frame's bit stream, a thread decodes each group of
                   atoms, straight into the voxelizer's frame-major items -- the same bits as the host decoder.  The walk
-                  takes the same time for 256 frames as for 4 096 (a wave per 64 frames, most of the chip idle), so LARGE
-                  chunks feed fastest: 2 048 frames of 30 000 atoms decode in 7.7 ms, what their voxelization takes.
+                  takes about the same time for 256 frames as for 4 096 (a wave per 64 frames, most of the chip idle), so
+                  LARGE chunks feed fastest: 1 024 frames of 30 000 atoms decode in 3.1 ms (their voxelization takes 4.3).
       ``"host"``  by host threads (libmkamd.so's decoder, ``moleculekit_amd.xtc``) into pinned staging, in blocks of 16
                   frames per thread: bound by the host's cores (28 k frames/s of 30 000 atoms on the 16 an MI355X box grants).
       ``"auto"``  the device for a contiguous ascending range of frames whose headers it can take (``xtc.device_decodable``:
