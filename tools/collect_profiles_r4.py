@@ -91,7 +91,18 @@ for mode in ("periodic", "nonperiodic"):
                 bench.DEFAULT_BATCH["dist"], f"--workload dist --no-cpu-baseline --steps 8 --warmup 2 (MKAMD_DIST_ONLY={mode})")
     if o:
         report(f"{tag}_dist_{mode}", o, ALG["dist"])
+stats = sorted(glob.glob("gpurun_out/prof_xtc/*/*_kernel_stats.csv"), key=os.path.getmtime)
+if stats:
+    shutil.copy(stats[-1], f"profiles/{tag}_xtc_probe_rocprofv3_kernel_stats.csv")
+if os.path.exists("gpurun_out/xtc_pmc/summary.txt"):
+    with open("gpurun_out/xtc_pmc/summary.txt") as fh:
+        body = fh.read()
+    open(f"profiles/{tag}_xtc_decode_pmc.txt", "w").write(
+        f"# library src {SRC}; tools/gpu_r4_xtc_pmc.sh: rocprofv3 --pmc passes of tools/xtc_gpu_probe.py, one probe file per pass (syn = 30 000 atoms,\n"
+        "# every atom a group, no flag set; real = 3PTB head, 4 507 atoms, reference writer), mean per launch of the kernel at the grid size given\n"
+        "# (k_xtc_scan: 64 lanes = 64 frames per workgroup, so grid / 64 waves; SQ_WAVE_CYCLES and SQ_ACTIVE_* in quad-cycles)\n" + body)
 for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"),
+                 ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("xtc_overlap_probe.txt", "xtc_overlap_probe.txt"),
                  ("r4_tile_ab.txt", "tile_ab_last.txt")):
     f = f"gpurun_out/{src}"
     if os.path.exists(f):

@@ -46,5 +46,10 @@ done
 # the one-molecule call: latencies, the host side of the drop-in call
 (for i in 1 2 3; do timeout 120 python tools/single_latency.py; done > gpurun_out/single_latency.txt 2>&1)
 (timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
+# the device XTC decoder: kernels alone per chunk size, beside the voxelizer, counters, kernel stats
+(timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
+(timeout 200 python tools/xtc_overlap_probe.py > gpurun_out/xtc_overlap_probe.txt 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_xtc -- python $R/tools/xtc_gpu_probe.py > $R/gpurun_out/rocprof_xtc.log 2>&1)
+(bash tools/gpu_r4_xtc_pmc.sh > /dev/null 2>&1)
 tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
 python tools/collect_profiles_r4.py

@@ -21,7 +21,10 @@ real = os.path.join(d, "real.xtc")
 with open(real, "wb") as fh:
     for _ in range(700): fh.write(src)                      # 4200 frames of 4507 atoms
 lib = _lib.load()
+only = os.environ.get("XTC_PROBE_ONLY", "")                  # "syn" / "real": one file (the PMC passes)
 for name, fn in (("synthetic 30000 atoms", syn), ("3ptb head (water runs), 4507 atoms", real)):
+    if only and (only == "syn") != (fn is syn):
+        continue
     na, nf = xtc.get_xtc_natoms(fn), xtc.get_xtc_nframes(fn)
     for n in (256, 1024, 2048, 4096):
         n = min(n, nf)
