@@ -8,8 +8,10 @@
 //
 // Layouts are the reference's: coords float32 [n_atoms, 3, n_frames] (frame fastest, Molecule.coords),
 // box float32 [3, n_frames], results float32 [n_frames, n_pairs].  Frames are the coalescing axis of the
-// inputs and pairs the one of the output, so every kernel computes a 64-frame x 64-pair tile with lanes
-// along frames, transposes it through LDS (65-float pitch: conflict-free) and stores with lanes along pairs.
+// inputs and pairs the one of the output, so the tile kernels compute a 64-frame x 64-pair tile with lanes
+// along frames, transpose it through LDS (65-float pitch: conflict-free) and store with lanes along pairs;
+// rectangular calls with long rows turn the few selected atoms frame-major instead and write rows directly
+// (k_sel_to_frames + k_dist_rows below).
 #pragma once
 #ifndef MK_DEVICE_API_PROVIDED
 #include "mk_device.h"
@@ -376,6 +378,132 @@ MK_KERNEL(DR_WAVES * WAVE) void k_dist_rect(const float* __restrict__ coords, lo
     const bool small_rows = mk_ballot(((unsigned long long)hi_atom * 3ull + 3ull) * ((unsigned long long)F * 4ull) > 0xffffffffull) == 0ull;
     if (small_rows) dist_rect_block<PBC, true>(coords, F, box, sel1, n1, sel2, n2, chains, squared, out, tile, bx, by, bz);
     else dist_rect_block<PBC, false>(coords, F, box, sel1, n1, sel2, n2, chains, squared, out, tile, bx, by, bz);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same rectangular call once more, for rows of the result that are long enough to be written directly (round 4, second
+// half).  k_dist_rect reads the coordinates along frames (their fast axis) and must turn every 64 x 64 tile through LDS to
+// write along pairs: a barrier per first atom, two LDS accesses per distance, and phases of loading, computing and storing
+// that overlap only through other blocks (measured: 0.24-0.28 ms where a store-only build takes 0.157).  But the atoms of
+// the two selections are few (n1 + n2 against n1 * n2 pairs): turning THEM frame-major first costs next to nothing
+// (k_sel_to_frames: [F][3][n] per selection, 17 MB where the result has 819), and then a WAVE owns a frame: a lane keeps ROWS_J
+// second atoms in registers, the first atom of the moment comes in through scalar loads, and the wave writes 256 contiguous
+// bytes of out[f, i * n2 + j..] per store -- no LDS, no barrier, nothing but the pair arithmetic between a load and a store.
+// Same functions per pair (dist2_min_image_f32, mk_fsqrt_rn): the same bits.
+// ------------------------------------------------------------------------------------------------
+constexpr int ROWS_CI = 16;            // first atoms a wave walks for its second atoms (their loads are amortised over them)
+
+// The two selections' coordinates, frame-major: T[f][ax][k] = coords[sel[k], ax, f], k < np (np = n rounded up: the pad repeats the
+// last atom, so that idle lanes compute on something harmless); cs[k] = chains[sel[k]].  ONE launch for both selections and all
+// three axes -- a block turns 64 frames x 64 atoms of one axis through LDS: (F / 64) x (np1 / 64 + np2 / 64) x 3 blocks (as two
+// launches of 64 x 64 x 3-axis blocks the 17 MB of the bench leg took 2 x 14.7 us beside a 170 us row kernel: 128-256 blocks
+// with sixteen dependent rounds of loads each).
+MK_KERNEL(256) void k_sel_to_frames(const float* __restrict__ coords, long long F, const unsigned* __restrict__ sel1, long long n1,
+                                    long long np1, const unsigned* __restrict__ sel2, long long n2, long long np2,
+                                    const unsigned* __restrict__ chains, float* __restrict__ T1, unsigned* __restrict__ cs1,
+                                    float* __restrict__ T2, unsigned* __restrict__ cs2)
+{
+    __shared__ float tile[DT][DT + 1];
+    const int l = threadIdx.x & (DT - 1), wq = threadIdx.x >> 6, ax = (int)blockIdx.z;
+    const long long tiles1 = np1 / DT;
+    const bool second = (long long)blockIdx.y >= tiles1;             // block-uniform: which selection
+    const unsigned* __restrict__ sel = second ? sel2 : sel1;
+    const long long n = second ? n2 : n1, np = second ? np2 : np1;
+    float* __restrict__ T = second ? T2 : T1;
+    const long long f0 = (long long)blockIdx.x * DT, k0 = ((long long)blockIdx.y - (second ? tiles1 : 0)) * DT;
+    const long long f = f0 + l < F ? f0 + l : F - 1;
+    float v[DT / 4];
+#pragma unroll
+    for (int r = 0; r < DT / 4; ++r) {                               // sixteen independent loads per lane, one wait
+        const long long k = k0 + wq + 4 * r < n ? k0 + wq + 4 * r : n - 1;
+        v[r] = coords[((size_t)sel[k] * 3 + (size_t)ax) * (size_t)F + (size_t)f];
+    }
+#pragma unroll
+    for (int r = 0; r < DT / 4; ++r) tile[wq + 4 * r][l] = v[r];
+    if (blockIdx.x == 0 && ax == 0 && chains != nullptr && wq == 0) (second ? cs2 : cs1)[k0 + l] = chains[sel[k0 + l < n ? k0 + l : n - 1]];
+    mk_block_sync();
+#pragma unroll
+    for (int r = 0; r < DT / 4; ++r) {
+        const long long fr = f0 + wq + 4 * r;
+        if (fr < F) T[((size_t)fr * 3 + (size_t)ax) * (size_t)np + (size_t)(k0 + l)] = tile[l][wq + 4 * r];
+    }
+}
+
+// A wave: frame f, first atoms [ic * ROWS_CI, ...), second atoms of block jb: lane-strided (j = jb * 64 * JPL + lane + 64 * k,
+// k < JPL: JPL stores of 256 contiguous bytes per first atom) or, where rows start on 16 bytes (VEC: n2 a multiple of 4, JPL =
+// 4), four neighbours per lane (j = jb * 256 + 4 * lane + k: ONE store of 1 KB per first atom).  Wave tasks are numbered in the
+// result's memory order (frame, then chunk of first atoms, then block of second atoms) and dealt to the XCDs in contiguous
+// ranges, like the tiles of the other kernels.
+template <bool PBC, int JPL, bool VEC>
+MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, const unsigned* __restrict__ c1, const float* __restrict__ T2,
+                                long long np2, const unsigned* __restrict__ c2, const float* __restrict__ box, long long F, long long n1,
+                                long long n2, int squared, float* __restrict__ out)
+{
+    static_assert(!VEC || JPL == 4, "four neighbours per lane");
+    const long long NJ = (n2 + 64 * JPL - 1) / (64 * JPL), NI = (n1 + ROWS_CI - 1) / ROWS_CI;
+    const long long tasks = F * NI * NJ, blocks = (tasks + 3) / 4;
+    const long long gb = xcd_contiguous_tile(blocks);
+    if (gb < 0) return;
+    const long long task = gb * 4 + (long long)mk_uniform(threadIdx.x >> 6);
+    if (task >= tasks) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const long long jb = task % NJ, ic = (task / NJ) % NI, f = task / (NJ * NI);
+    const long long j0 = jb * 64 * JPL + (VEC ? 4 * lane : lane);
+    constexpr int JS = VEC ? 1 : 64;                                // distance between a lane's second atoms
+    float B[JPL][3];
+    unsigned cb[JPL];
+    const float* __restrict__ t2 = T2 + (size_t)f * 3 * (size_t)np2;
+#pragma unroll
+    for (int k = 0; k < JPL; ++k) {
+        const long long j = j0 + JS * k;                            // (< np2: the pad)
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) B[k][ax] = t2[(size_t)ax * (size_t)np2 + (size_t)j];
+        cb[k] = PBC ? c2[j] : 0u;
+    }
+    float bx = 0.f, by = 0.f, bz = 0.f, ibx = 0.f, iby = 0.f, ibz = 0.f;
+    if (PBC) {
+        bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+        ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
+    }
+    const long long P = n1 * n2;
+    const long long i_begin = ic * ROWS_CI, i_end = i_begin + ROWS_CI < n1 ? i_begin + ROWS_CI : n1;
+    const float* __restrict__ t1 = T1 + (size_t)f * 3 * (size_t)np1;
+    float* __restrict__ o = out + (size_t)f * (size_t)P + (size_t)i_begin * (size_t)n2 + (size_t)j0;
+    const bool whole = jb * 64 * JPL + 64 * JPL <= n2;              // wave-uniform: every lane's every pair exists
+    for (long long i = i_begin; i < i_end; ++i, o += n2) {
+        const float xa = t1[i], ya = t1[(size_t)np1 + (size_t)i], za = t1[2 * (size_t)np1 + (size_t)i];   // wave-uniform: scalar loads
+        const unsigned ca = PBC ? c1[i] : 0u;
+        float d[JPL];
+        bool ordinary = true;
+#pragma unroll
+        for (int k = 0; k < JPL; ++k) {
+            d[k] = dist2_min_image_f32(xa, ya, za, B[k][0], B[k][1], B[k][2], bx, by, bz, ibx, iby, ibz, PBC && cb[k] != ca);
+            ordinary = ordinary && mk_sqrt_ordinary(d[k]);
+        }
+        if (!squared) {
+            if (mk_ballot(!ordinary) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < JPL; ++k) d[k] = mk_fsqrt_rn_ordinary(d[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < JPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
+            }
+        }
+        if constexpr (VEC) {
+#ifdef MK_ROWS_NT_STORE            // A-B build
+            if (whole || j0 < n2) mk_tmp_store(reinterpret_cast<float4*>(o), make_float4(d[0], d[1], d[2], d[3]));
+#else
+            if (whole || j0 < n2) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);   // (n2 % 4 == 0: all four or none)
+#endif
+        } else if (whole) {
+#pragma unroll
+            for (int k = 0; k < JPL; ++k) o[64 * k] = d[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < JPL; ++k)
+                if (j0 + 64 * k < n2) o[64 * k] = d[k];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,22 @@ inline long long count_pairs(long long n1, long long n2, int selfdist)
     return s;
 }
 
+// Which rectangular calls (no selfdist) take the row kernel (k_sel_to_frames + k_dist_rows, dist_kernels.h), and with how many
+// second atoms per lane: the largest of 4 / 2 / 1 that keeps >= 80 % of a wave's lanes on real pairs; 0 = the tile kernel
+// (short rows, or selections whose frame-major copy would be more than a quarter of the result).
+inline int dist_rows_jpl(long long n1, long long n2, long long F)
+{
+    int jpl = 0;
+    for (int c : {4, 2, 1})
+        if (!jpl && (double)n2 / (double)(ceil_div(n2, 64 * c) * 64 * c) >= 0.8) jpl = c;
+    if (!jpl) return 0;
+    const long long np1 = ceil_div(n1, DT) * DT, np2 = ceil_div(n2, 64 * jpl) * 64 * jpl;
+    const long long tasks = F * ceil_div(n1, ROWS_CI) * ceil_div(n2, 64 * jpl);
+    const bool fits = (np1 + np2) * 3 * 4 <= n1 * n2 && tasks / 4 + 8 <= 0x7ffffff0LL && (np1 + np2) / DT <= 65535 &&
+                      ceil_div(F, DT) <= 0x7fffffffLL;
+    return fits ? jpl : 0;
+}
+
 // dist_trajectory on device pointers (coords [N,3,F], box [3,F], sel/chains uint32) -> out [F, P]
 template <class BE>
 int run_dist_trajectory(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
@@ -32,6 +48,34 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     // (both tile kernels: a 1-D grid padded to a multiple of 8, every XCD a contiguous range of tiles -- xcd_contiguous_tile)
     auto padded8 = [](long long tiles) { return (unsigned)(((tiles + 7) / 8) * 8); };
     static const bool no_rect = [] { const char* e = std::getenv("MKAMD_NO_RECT"); return e && e[0] == '1'; }();     // A-B knob
+    static const bool no_rows = [] { const char* e = std::getenv("MKAMD_NO_ROWS"); return e && e[0] == '1'; }();     // A-B knob
+    if (!selfdist && !no_rows) {
+        // rows of >= 64 second atoms are written directly by a wave per frame, from selections turned frame-major first
+        const int jpl = dist_rows_jpl(n1, n2, F);
+        if (jpl) {
+            const long long np1 = ceil_div(n1, DT) * DT, np2 = ceil_div(n2, 64 * jpl) * 64 * jpl;
+            const long long tasks = F * ceil_div(n1, ROWS_CI) * ceil_div(n2, 64 * jpl);
+            void *t1 = nullptr, *t2 = nullptr, *cs1 = nullptr, *cs2 = nullptr;
+            if ((st = be.ensure(WS_D_COM1, (size_t)F * 3 * (size_t)np1 * 4, &t1, 0))) return st;
+            if ((st = be.ensure(WS_D_COM2, (size_t)F * 3 * (size_t)np2 * 4, &t2, 0))) return st;
+            if ((st = be.ensure(WS_D_PA, (size_t)np1 * 4, &cs1, 0))) return st;
+            if ((st = be.ensure(WS_D_PB, (size_t)np2 * 4, &cs2, 0))) return st;
+            const unsigned* ch = pbc ? chains : nullptr;
+            if ((st = be.launch(k_sel_to_frames, dim3((unsigned)ceil_div(F, DT), (unsigned)((np1 + np2) / DT), 3u), dim3(256), coords, F, sel1, n1, np1,
+                                sel2, n2, np2, ch, (float*)t1, (unsigned*)cs1, (float*)t2, (unsigned*)cs2))) return st;
+            const dim3 grid(padded8(ceil_div(tasks, 4))), block(256);
+            auto go = [&](auto kernel) {
+                return be.launch(kernel, grid, block, (const float*)t1, np1, (const unsigned*)cs1, (const float*)t2, np2, (const unsigned*)cs2, box, F,
+                                 n1, n2, squared, out);
+            };
+            static const bool no_vec = [] { const char* e = std::getenv("MKAMD_ROWS_NO_VEC"); return e && e[0] == '1'; }();  // A-B knob
+            const bool vec = jpl == 4 && n2 % 4 == 0 && ((uintptr_t)out & 15u) == 0 && !no_vec;      // rows start on 16 bytes
+            if (pbc) return vec ? go(k_dist_rows<true, 4, true>) : jpl == 4 ? go(k_dist_rows<true, 4, false>) : jpl == 2 ? go(k_dist_rows<true, 2, false>)
+                                                                                                                          : go(k_dist_rows<true, 1, false>);
+            return vec ? go(k_dist_rows<false, 4, true>) : jpl == 4 ? go(k_dist_rows<false, 4, false>) : jpl == 2 ? go(k_dist_rows<false, 2, false>)
+                                                                                                                   : go(k_dist_rows<false, 1, false>);
+        }
+    }
     if (!selfdist && !no_rect) {
         const long long tiles = ceil_div(n2, DT) * ceil_div(n1, DR_I) * ceil_div(F, DT);
         if (tiles <= 0x7ffffff0LL)

@@ -239,4 +239,7 @@ int emu_xtc_decode(const unsigned char* bytes, const void* desc, long long n_fra
     return 0;
 }
 
+// which kernel a rectangular dist_trajectory call takes (dist_pipeline.h): second atoms per lane of the row kernel, 0 = the tile kernel
+int emu_dist_rows_jpl(long long n1, long long n2, long long F) { return dist_rows_jpl(n1, n2, F); }
+
 }  // extern "C"

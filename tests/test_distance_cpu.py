@@ -166,3 +166,42 @@ def test_rectangular_kernel_shapes_and_modes_match_oracle():
                 got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
                 exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
                 assert got.shape == (F, n1 * n2) and np.array_equal(got, exp), (n1, n2, pbc, sq)
+
+
+def test_row_kernel_shapes_and_modes_match_oracle():
+    """Round 4: rows of >= 64 second atoms are written by a wave per frame from selections turned frame-major first
+    (k_sel_to_frames + k_dist_rows).  Which (n1, n2) take it and with how many second atoms per lane is decided in
+    run_dist_trajectory (>= 80 % of the lanes busy, the turned selections at most a quarter of the result); shapes on both
+    sides of every decision and around the kernels' edges -- n2 at / around 64, 128, 256 and beyond, first atoms below / at /
+    above a wave's chunk of 16, frames not a multiple of 64 (the turning kernel's tiles), one frame -- with and without pbc,
+    squared and not, unsorted and repeated atom indices; everything against the oracle, bit for bit."""
+    import ctypes
+    jpl = lambda n1, n2, F: E.lib().emu_dist_rows_jpl(ctypes.c_longlong(n1), ctypes.c_longlong(n2), ctypes.c_longlong(F))
+    shapes = ((40, 52), (40, 64), (15, 70), (24, 128), (17, 129), (33, 200), (20, 256), (30, 500), (50, 260), (16, 128))
+    assert [jpl(*s, 67) for s in shapes] == [1, 1, 0, 2, 0, 0, 4, 4, 1, 0]
+    assert jpl(1, 64, 67) == 0 and jpl(200, 500, 2048) == 4 and jpl(300, 30, 100) == 0       # (too few pairs; the bench leg; short rows)
+    rng = np.random.default_rng(12)
+    N = 300
+    ch = rng.integers(0, 4, size=N).astype(np.uint32)
+    for F in (1, 67):
+        c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+        b = rng.uniform(15, 25, size=(3, F)).astype(np.float32)
+        for n1, n2 in shapes:
+            s1 = rng.integers(0, N, size=n1).astype(np.uint32)
+            s2 = rng.integers(0, N, size=n2).astype(np.uint32)
+            for pbc in (False, True):
+                for sq in (False, True):
+                    got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
+                    exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
+                    assert got.shape == (F, n1 * n2) and np.array_equal(got, exp), (F, n1, n2, pbc, sq)
+    # a zero box edge (the reference divides by it: NaN), NaN and huge coordinates: the extraordinary roots' branch
+    F = 5
+    c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+    c[3, 0, 1] = np.nan; c[7, 1, 2] = 3e38; c[9, 2, 0] = -3e38; c[11] = c[12]
+    b = rng.uniform(15, 25, size=(3, F)).astype(np.float32); b[1, 3] = 0.0
+    s1 = np.arange(0, 40, dtype=np.uint32); s2 = np.arange(0, 128, dtype=np.uint32)
+    assert jpl(40, 128, F) == 2
+    for pbc in (False, True):
+        got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc)
+        exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc)
+        assert np.array_equal(got, exp, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(exp))

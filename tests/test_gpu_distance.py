@@ -229,3 +229,27 @@ def test_rectangular_and_pair_table_kernels_over_many_tiles_match_oracle():
         r = np.full((F, 61 * 60 // 2), -3.0, np.float32)
         dist_trajectory(c, b, s, s, ch, True, pbc, r)
         assert np.array_equal(r, oracle.dist_trajectory(c, b, s, s, ch, True, pbc)), pbc
+
+
+def test_row_kernel_over_many_waves_matches_oracle():
+    """Round 4: rectangular calls with rows of >= 64 second atoms take k_sel_to_frames + k_dist_rows (selections turned
+    frame-major, a wave per frame writes whole pieces of a row): shapes for 1, 2 and 4 second atoms per lane, ragged on every
+    axis (frames not a multiple of the turning kernel's 64, first atoms not a multiple of a wave's 16, second atoms not a
+    multiple of 64), wave-task counts that are not multiples of 4 or 32, unsorted and repeated atoms, a zero box edge, pbc on
+    and off (squared distances: the CPU tier's emulated run); and the bench leg's shape (200 x 500) on a slice of frames -- against the oracle, bit for bit,
+    with a sentinel in every element first."""
+    from moleculekit_amd.distance_utils import dist_trajectory
+    rng = np.random.default_rng(29)
+    N, F = 900, 203
+    c = rng.uniform(-40, 40, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(30, 45, size=(3, F)).astype(np.float32)
+    b[2, 77] = 0.0
+    ch = rng.integers(0, 5, size=N).astype(np.uint32)
+    for n1, n2 in ((40, 52), (41, 64), (24, 128), (20, 256), (30, 500), (50, 260), (200, 500), (33, 1000)):
+        s1 = rng.integers(0, N, size=n1).astype(np.uint32)
+        s2 = rng.integers(0, N, size=n2).astype(np.uint32)
+        for pbc in (False, True):
+            r = np.full((F, n1 * n2), -3.0, np.float32)
+            dist_trajectory(c, b, s1, s2, ch, False, pbc, r)
+            exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc)
+            assert np.array_equal(r, exp, equal_nan=True), (n1, n2, pbc)

@@ -46,6 +46,8 @@ done
 # the one-molecule call: latencies, the host side of the drop-in call
 (for i in 1 2 3; do timeout 120 python tools/single_latency.py; done > gpurun_out/single_latency.txt 2>&1)
 (timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
+# the distance leg's shape under every switch: the row kernel (default), the tile kernel it replaced (MKAMD_NO_ROWS=1), fills / copies
+(for v in A=0 MKAMD_NO_ROWS=1 A=0 MKAMD_NO_ROWS=1; do echo "== $v"; env $v timeout 200 python tools/dist_probe.py; done > gpurun_out/dist_probe.txt 2>&1)
 # the device XTC decoder: kernels alone per chunk size, beside the voxelizer, counters, kernel stats
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
 (timeout 200 python tools/xtc_overlap_probe.py > gpurun_out/xtc_overlap_probe.txt 2>&1)
