@@ -29,7 +29,7 @@ for pbc in (False, True):
         for selfd in (False,):
             ms = t(lambda: ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2, chains.data_ptr(), selfd, pbc, sq, out.data_ptr()))
             print(f"pbc={pbc} squared={sq}: {ms:.4f} ms  {out.numel()*4/ms/1e6:.0f} GB/s of result")
-# a square selection with selfdist (the pair-table kernel): 450 x 450 -> 101 025 pairs
+# a square selection with selfdist (MetricSelfDistance; the pair-table kernel): 450 x 450 -> 101 025 pairs
 d3 = torch.as_tensor(np.sort(rng.choice(N, 450, replace=False)).astype(np.int32), device=dev)
 out2 = torch.empty((F, 450 * 449 // 2), device=dev)
 for pbc in (False, True):
