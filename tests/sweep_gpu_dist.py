@@ -1,0 +1,37 @@
+"""One-off wider sweep of dist_trajectory on the GPU (not collected by pytest): random atom counts, frame counts and selection
+shapes -- so that every kernel behind the call is met many times (the row kernel with 1 / 2 / 4 second atoms per lane and its
+16-byte store path, the tile kernel for short rows, the pair-table kernel for selfdist) -- with and without the minimum image,
+boxes down to a few Angstrom (many image shifts, quotients near the rounding boundary), repeated and unsorted atoms.  Every
+result against the oracle, BIT for bit.   python tests/sweep_gpu_dist.py [first_seed] [count]"""
+import os, sys, collections
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle
+from moleculekit_amd.distance_utils import dist_trajectory
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+bad, seen = 0, collections.Counter()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(2, 1500))
+    F = int(rng.choice([1, 2, 7, 63, 64, 65, 130, 200]))
+    L = float(rng.choice([3.0, 11.0, 40.0, 90.0]))
+    c = rng.uniform(-1.5 * L, 1.5 * L, size=(N, 3, F)).astype(np.float32)
+    b = (L * rng.uniform(0.8, 1.2, size=(3, F))).astype(np.float32)
+    ch = rng.integers(0, int(rng.integers(1, 6)), size=N).astype(np.uint32)
+    selfdist = bool(rng.random() < 0.25)
+    n2 = int(rng.choice([1, 5, 52, 63, 64, 65, 100, 128, 200, 256, 260, 500, 1000]))
+    n1 = n2 if selfdist else int(rng.choice([1, 7, 16, 17, 40, 100, 200]))
+    n1, n2 = min(n1, 4 * N), min(n2, 4 * N)
+    s2 = rng.integers(0, N, size=n2).astype(np.uint32)
+    s1 = s2.copy() if selfdist else rng.integers(0, N, size=n1).astype(np.uint32)
+    pbc = bool(rng.random() < 0.6)
+    want = oracle.dist_trajectory(c, b, s1, s2, ch, selfdist, pbc)
+    got = np.full(want.shape, -3.0, np.float32)
+    dist_trajectory(c, b, s1, s2, ch, selfdist, pbc, got)
+    seen[("selfdist" if selfdist else "rect", "pbc" if pbc else "open")] += 1
+    if not np.array_equal(got, want, equal_nan=True):
+        bad += 1
+        print("FAIL seed", seed, dict(N=N, F=F, n1=n1, n2=n2, selfdist=selfdist, pbc=pbc, L=L), "differing elements", int((got != want).sum()))
+print("seeds", first, "..", first + count - 1, ":", bad, "calls differ from the oracle (bit for bit);", dict(seen))

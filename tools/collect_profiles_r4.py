@@ -102,7 +102,7 @@ if os.path.exists("gpurun_out/xtc_pmc/summary.txt"):
         "# every atom a group, no flag set; real = 3PTB head, 4 507 atoms, reference writer), mean per launch of the kernel at the grid size given\n"
         "# (k_xtc_scan: 64 lanes = 64 frames per workgroup, so grid / 64 waves; SQ_WAVE_CYCLES and SQ_ACTIVE_* in quad-cycles)\n" + body)
 for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"),
-                 ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_probe.txt", "dist_probe_rows.txt"), ("xtc_overlap_probe.txt", "xtc_overlap_probe.txt"),
+                 ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_probe.txt", "dist_probe_rows.txt"), ("random_sweeps.txt", "random_sweeps_final.txt"), ("xtc_overlap_probe.txt", "xtc_overlap_probe.txt"),
                  ("r4_tile_ab.txt", "tile_ab_last.txt")):
     f = f"gpurun_out/{src}"
     if os.path.exists(f):

@@ -48,6 +48,8 @@ done
 (timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
 # the distance leg's shape under every switch: the row kernel (default), the tile kernel it replaced (MKAMD_NO_ROWS=1), fills / copies
 (for v in A=0 MKAMD_NO_ROWS=1 A=0 MKAMD_NO_ROWS=1; do echo "== $v"; env $v timeout 200 python tools/dist_probe.py; done > gpurun_out/dist_probe.txt 2>&1)
+# random parity sweeps on this build: the voxelizer (automatic mode and the workgroup-per-item kernel) and dist_trajectory
+(timeout 600 python tests/sweep_gpu_random.py 9000 600; MKAMD_TILE_ITEMS=1 timeout 300 python tests/sweep_gpu_random.py 9600 200; timeout 600 python tests/sweep_gpu_dist.py 0 600) > gpurun_out/random_sweeps.txt 2>&1
 # the device XTC decoder: kernels alone per chunk size, beside the voxelizer, counters, kernel stats
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
 (timeout 200 python tools/xtc_overlap_probe.py > gpurun_out/xtc_overlap_probe.txt 2>&1)
