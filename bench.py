@@ -226,7 +226,7 @@ def cpu_baseline(name):
 
 
 def dist_traffic(F):
-    """HBM bytes per step of the distance leg (k_dist_rows and the two k_sel_to_frames launches before it; k_dist_rect / k_dist_pairs for builds or shapes that take those) from the committed PMC passes of THIS build (profiles/r*_dist_pmc_counters.json, taken
+    """HBM bytes per step of the distance leg (k_dist_rows and the k_sel_to_frames launch before it; k_dist_rect / k_dist_pairs for builds or shapes that take those) from the committed PMC passes of THIS build (profiles/r*_dist_pmc_counters.json, taken
     at the default frame count; stamped and checked like pmc_entry): WRITE_SIZE + 2 x FETCH_SIZE KiB.  -> (bytes | None, file | reason)"""
     import glob
     from moleculekit_amd import _lib
@@ -243,8 +243,8 @@ def dist_traffic(F):
     rows, turn = find("k_dist_rows"), find("k_sel_to_frames")
     if d.get("_items_per_launch") != F:
         return None, f"refused: {rel} was taken at another frame count"
-    if rows is not None and turn is not None:               # the row kernel + the two launches that turn the selections frame-major
-        return int((kib(rows) + 2.0 * kib(turn)) * 1024), rel
+    if rows is not None and turn is not None:               # the row kernel + the launch that turns the selections frame-major
+        return int((kib(rows) + kib(turn)) * 1024), rel
     v = find("k_dist_rect") or find("k_dist_pairs")
     if v is None:
         return None, f"refused: {rel} holds no distance-kernel counters"
@@ -296,7 +296,7 @@ def bench_distances(args, emit=True):
     np_elapsed, np_ms = timed(False) if only != "periodic" else (1.0, 1.0)
     nonperiodic = {"value": round(ndist * args.steps / np_elapsed / 1e6, 1), "unit": "Mdist/s", "ms_per_step": round(np_elapsed / args.steps * 1e3, 4),
                    "roofline": {"bound": "hbm", "achieved": round(alg / np_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": "mkamd::k_dist_rows<false, 4, true>", "timed_region": "the whole call: 2 x k_sel_to_frames + k_dist_rows", "kernel_avg_ms": round(np_ms, 5)}}
+                                "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": "mkamd::k_dist_rows<false, 4, true>", "timed_region": "the whole call: k_sel_to_frames + k_dist_rows", "kernel_avg_ms": round(np_ms, 5)}}
     if not args.no_cpu_baseline and only != "periodic":
         from oracle import oracle
         Fs = min(16, F)
@@ -310,7 +310,7 @@ def bench_distances(args, emit=True):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"},
             "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F)[0], "traffic_source": dist_traffic(F)[1], "kernel": "mkamd::k_dist_rows<true, 4, true>", "timed_region": "the whole call: 2 x k_sel_to_frames + k_dist_rows (HIP events around the steps)",
+                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F)[0], "traffic_source": dist_traffic(F)[1], "kernel": "mkamd::k_dist_rows<true, 4, true>", "timed_region": "the whole call: k_sel_to_frames + k_dist_rows (HIP events around the steps)",
                          "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg},
             "nonperiodic": nonperiodic}
     if not args.no_cpu_baseline:
