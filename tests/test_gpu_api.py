@@ -530,3 +530,59 @@ def test_device_xtc_decoder_many_waves_many_windows_and_bad_streams(hip_ctx, tmp
     with pytest.raises(RuntimeError, match="corrupt"):
         for _ in batch.iterVoxelizeXTC(badfn, sig, center, [12, 12, 12], 1.0, pbc=False, frames=np.arange(3), chunk=2, decode="gpu"):
             pass
+
+
+def test_cfg4_full_count_streamed_from_xtc_device_decode_equals_host_decode(hip_ctx, tmp_path):
+    """BASELINE.json's cfg4 at its full count through the feeder: 10 000 frames of 30 000 atoms in a periodic
+    66.9 A box, read from an XTC file and voxelized onto the 48^3 x 8 grid chunk by chunk -- once with the coordinates
+    decompressed on the device (csrc/xtc_gpu.h) and once by the host decoder (pinned against the real reference reader in
+    tests/test_xtc.py).  3.5 TB of features are not kept: every chunk is reduced on the device to two checksums (the sum of
+    its bit patterns as integers -- any differing bit of any element shows -- and the float64 sum), and the frame indices,
+    the chunk sizes and both checksums of every chunk must agree; a sample of frames is also compared element by element."""
+    import torch
+    from moleculekit_amd import batch, xtc
+    import bench
+    base = 128
+    p, _, _ = bench.make_workload("cfg4", base, seed=4004)
+    N = int(p["atom_offsets"][1])
+    L = float(p["box"][0, 0])
+    nm = np.ascontiguousarray((p["coords"].reshape(base, N, 3) * np.float32(0.1)).transpose(1, 2, 0))
+    bv = np.zeros((3, 3, base), np.float32)
+    bv[0, 0] = bv[1, 1] = bv[2, 2] = L * 0.1
+    one = str(tmp_path / "one.xtc")
+    xtc.write_xtc(one, nm, bv, np.arange(base, dtype=np.float32), np.arange(base))
+    blob = open(one, "rb").read()
+    per = len(blob) // base
+    fn = str(tmp_path / "cfg4_full.xtc")
+    with open(fn, "wb") as fh:
+        for _ in range(10000 // base):
+            fh.write(blob)
+        fh.write(blob[:(10000 % base) * per])                      # (frames are self-contained records of equal size here)
+    assert xtc.get_xtc_nframes(fn) == 10000 and xtc.get_xtc_natoms(fn) == N
+    sig = np.ascontiguousarray(p["sigmas"][:N], dtype=np.float32)
+
+    def run(decode):
+        sums, keep = [], {}
+        for idx, feats in batch.iterVoxelizeXTC(fn, sig, p["centers"][0], p["boxsize"], p["voxelsize"], pbc=True, chunk=1000, ctx=hip_ctx, decode=decode):
+            assert feats.shape == (len(idx), 48 ** 3, 8)
+            sums.append((int(idx[0]), len(idx), int(feats.view(torch.int32).sum(dtype=torch.int64)), float(feats.sum(dtype=torch.float64))))
+            for f in (0, 4999, 9999):
+                if idx[0] <= f <= idx[-1]:
+                    keep[f] = feats[f - int(idx[0])].cpu().numpy()
+            del feats
+        return sums, keep
+
+    dev_sums, dev_keep = run("gpu")
+    host_sums, host_keep = run("host")
+    assert len(dev_sums) == 10 and sum(s[1] for s in dev_sums) == 10000
+    assert dev_sums == host_sums
+    assert all(np.array_equal(dev_keep[f], host_keep[f]) for f in (0, 4999, 9999)) and dev_keep[0].max() > 0.5
+    # frame 9 999 is a copy of base frame 9 999 % 128 = 15 (frames are self-contained): decoded from another place of the stream,
+    # voxelized in another chunk -- the same features as that frame on its own (at the tile depth the big calls take: a small
+    # call's K = 4 rounds the plane sweep differently, ~3e-6; csrc/pipeline.h)
+    hip_ctx.set_tile_k(8)
+    try:
+        alone = next(batch.iterVoxelizeXTC(fn, sig, p["centers"][0], p["boxsize"], p["voxelsize"], pbc=True, frames=np.array([9999 % base]), ctx=hip_ctx))[1]
+    finally:
+        hip_ctx.set_tile_k(0)
+    assert np.array_equal(alone[0].cpu().numpy(), dev_keep[9999])
