@@ -52,6 +52,17 @@ MK_DEV float dist2_min_image_f32(float x1, float y1, float z1, float x2, float y
     return mk_fadd_rn(mk_fadd_rn(mk_fmul_rn(dx, dx), mk_fmul_rn(dy, dy)), mk_fmul_rn(dz, dz));
 }
 
+// Two pairs that share their first atom and take no image shift, in packed arithmetic (v_pk_add_f32 / v_pk_mul_f32: two float32
+// operations per lane and instruction, each rounded on its own like the scalar ones): the row kernel's non-periodic walk,
+// 0.198-0.205 -> 0.193 ms.  (With the image shift packed as well the periodic walk got SLOWER, 0.241-0.247 -> 0.265-0.269 ms:
+// rounding, the test and the per-pair selects work on single components, and moving them in and out of register pairs cost
+// more than the packed multiplies saved.)
+MK_DEV mk_f2 dist2_x2(float x1, float y1, float z1, mk_f2 x2, mk_f2 y2, mk_f2 z2)
+{
+    const mk_f2 dx = mk_f2_sub_rn(mk_f2_splat(x1), x2), dy = mk_f2_sub_rn(mk_f2_splat(y1), y2), dz = mk_f2_sub_rn(mk_f2_splat(z1), z2);
+    return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
+}
+
 constexpr int DT = 64;                 // tile edge (frames and pairs)
 
 // Which tile a workgroup of a 1-D launch of 8 * ceil(T / 8) blocks takes, T tiles numbered frame slab-major (all pair tiles of
@@ -391,7 +402,10 @@ MK_KERNEL(DR_WAVES * WAVE) void k_dist_rect(const float* __restrict__ coords, lo
 // bytes of out[f, i * n2 + j..] per store -- no LDS, no barrier, nothing but the pair arithmetic between a load and a store.
 // Same functions per pair (dist2_min_image_f32, mk_fsqrt_rn): the same bits.
 // ------------------------------------------------------------------------------------------------
-constexpr int ROWS_CI = 16;            // first atoms a wave walks for its second atoms (their loads are amortised over them)
+#ifndef MK_ROWS_CI
+#define MK_ROWS_CI 16
+#endif
+constexpr int ROWS_CI = MK_ROWS_CI;    // first atoms a wave walks for its second atoms (their loads are amortised over them)
 
 // The two selections' coordinates, frame-major: T[f][ax][k] = coords[sel[k], ax, f], k < np (np = n rounded up: the pad repeats the
 // last atom, so that idle lanes compute on something harmless); cs[k] = chains[sel[k]].  ONE launch for both selections and all
@@ -475,10 +489,19 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
         const unsigned ca = PBC ? c1[i] : 0u;
         float d[JPL];
         bool ordinary = true;
+        if constexpr (JPL >= 2 && !PBC) {
 #pragma unroll
-        for (int k = 0; k < JPL; ++k) {
-            d[k] = dist2_min_image_f32(xa, ya, za, B[k][0], B[k][1], B[k][2], bx, by, bz, ibx, iby, ibz, PBC && cb[k] != ca);
-            ordinary = ordinary && mk_sqrt_ordinary(d[k]);
+            for (int k = 0; k < JPL; k += 2) {                       // two pairs per packed operation
+                const mk_f2 d2 = dist2_x2(xa, ya, za, mk_f2{B[k][0], B[k + 1][0]}, mk_f2{B[k][1], B[k + 1][1]}, mk_f2{B[k][2], B[k + 1][2]});
+                d[k] = d2[0]; d[k + 1] = d2[1];
+                ordinary = ordinary && mk_sqrt_ordinary(d[k]) && mk_sqrt_ordinary(d[k + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < JPL; ++k) {
+                d[k] = dist2_min_image_f32(xa, ya, za, B[k][0], B[k][1], B[k][2], bx, by, bz, ibx, iby, ibz, PBC && cb[k] != ca);
+                ordinary = ordinary && mk_sqrt_ordinary(d[k]);
+            }
         }
         if (!squared) {
             if (mk_ballot(!ordinary) == 0ull) {

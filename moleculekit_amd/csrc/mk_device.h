@@ -69,6 +69,23 @@ MK_DEV unsigned mk_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readf
 typedef float mk_f2 __attribute__((ext_vector_type(2)));
 MK_DEV mk_f2 mk_f2_splat(float v) { return mk_f2{v, v}; }
 MK_DEV mk_f2 mk_f2_fma(mk_f2 a, mk_f2 b, mk_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// packed arithmetic with the reference's roundings: a multiply and an add / subtract per component, each rounded on its own --
+// never contracted into an fma (v_pk_mul_f32 / v_pk_add_f32: two float32 operations per lane and instruction)
+MK_DEV mk_f2 mk_f2_mul_rn(mk_f2 a, mk_f2 b)
+{
+#pragma clang fp contract(off)
+    return a * b;
+}
+MK_DEV mk_f2 mk_f2_add_rn(mk_f2 a, mk_f2 b)
+{
+#pragma clang fp contract(off)
+    return a + b;
+}
+MK_DEV mk_f2 mk_f2_sub_rn(mk_f2 a, mk_f2 b)
+{
+#pragma clang fp contract(off)
+    return a - b;
+}
 MK_DEV mk_f2 mk_f2_load(const float* p8) { return *reinterpret_cast<const mk_f2*>(p8); }   // 8-byte aligned
 // running bit-pattern minimum with TWO non-negative floats (v_min3_u32)
 MK_DEV unsigned mk_min3_bits(unsigned m, float a, float b)
