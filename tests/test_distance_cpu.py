@@ -205,3 +205,57 @@ def test_row_kernel_shapes_and_modes_match_oracle():
         got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc)
         exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc)
         assert np.array_equal(got, exp, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(exp))
+
+
+def test_row_kernel_image_shift_is_bit_exact_at_every_boundary():
+    """The image shift d - b * round(d / b) (distance_utils.pyx:49-51) through the ROW kernel (rows of 64 / 128 second atoms):
+    coordinates wrapped into the box (every separation within one box length: the usual trajectory); separations ON half
+    the box edge and one and two ulps either side, on the box edge itself and either side of it, for boxes whose half or
+    reciprocal is inexact in binary; frames with a zero, an infinite, a NaN, a negative, a denormal box edge; signed zeros
+    among the separations; one second atom in the first atoms' chain (never shifted).  Against the oracle, bit for bit.
+    (Written for a shift without the quotient -- d -+ b iff |d| >= b / 2 where |d| <= b -- that was correct on all of this
+    and 3-5 % slower on the GPU: docs/EXPERIMENTS_r4.md.  The cases stay.)"""
+    import ctypes
+    rng = np.random.default_rng(31)
+    jpl = lambda n1, n2, F: E.lib().emu_dist_rows_jpl(ctypes.c_longlong(n1), ctypes.c_longlong(n2), ctypes.c_longlong(F))
+    boxes = np.array([10.0, 33.3, 66.9, 7.123456, 100.0, 3.0e4, 1.1754944e-38 * 3, 1e-3], np.float32)
+    F = len(boxes)
+    b = np.tile(boxes[None, :], (3, 1)).astype(np.float32)
+    # (1) wrapped coordinates, random chains
+    for n1, n2 in ((40, 64), (24, 128)):
+        assert jpl(n1, n2, F) in (1, 2)
+        N = n1 + n2
+        c = (rng.random((N, 3, F)).astype(np.float32) * boxes[None, None, :]).astype(np.float32)
+        ch = rng.integers(0, 3, size=N).astype(np.uint32)
+        s1, s2 = np.arange(n1, dtype=np.uint32), np.arange(n1, N, dtype=np.uint32)
+        got = E.dist_trajectory(c, b, s1, s2, ch, False, True)
+        assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
+    # (2) separations at the boundaries: first atoms at the origin, second atoms at +-k * box (k = 0.5, 1.0) and neighbours
+    n1, n2 = 40, 64
+    ch = np.concatenate([np.zeros(n1, np.uint32), np.ones(n2, np.uint32)])     # every pair across chains: always shifted
+    ch[n1 + 3] = 0                                                             # (but one second atom: never)
+    s1, s2 = np.arange(n1, dtype=np.uint32), np.arange(n1, n1 + n2, dtype=np.uint32)
+    for beyond in (False, True):       # False: every separation <= the box edge; True: some just beyond it
+        seps = []
+        for k in (0.5, 1.0):
+            h = (boxes * np.float32(k)).astype(np.float32)
+            lo1, hi1 = np.nextafter(h, np.float32(0)), np.nextafter(h, np.float32(np.inf))
+            seps += [h, lo1, np.nextafter(lo1, np.float32(0))]
+            if k == 0.5 or beyond:
+                seps += [hi1, np.nextafter(hi1, np.float32(np.inf))]
+        seps += [np.zeros(F, np.float32), (boxes * np.float32(0.25)).astype(np.float32), (boxes * np.float32(0.75)).astype(np.float32)]
+        c = np.zeros((n1 + n2, 3, F), np.float32)
+        c[1:n1:7] = np.float32(-0.0)                                           # first atoms at +0, a few at -0
+        for j in range(n2):
+            s = seps[j % len(seps)] * np.float32(-1.0 if (j // len(seps)) % 2 else 1.0)
+            c[n1 + j, j % 3] = s
+            c[n1 + j, (j + 1) % 3] = seps[(j + 5) % len(seps)] * np.float32(0.5)
+        got = E.dist_trajectory(c, b, s1, s2, ch, False, True)
+        assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True)), beyond
+    # (3) boxes that are not ordinary positive numbers: the general path, NaN where the reference gives NaN
+    b2 = b.copy()
+    b2[0, 0] = 0.0; b2[1, 1] = np.inf; b2[2, 2] = np.nan; b2[0, 3] = -7.0; b2[1, 4] = 1e-42
+    c3 = (rng.random((n1 + n2, 3, F)).astype(np.float32) * np.float32(9.0)).astype(np.float32)
+    got = E.dist_trajectory(c3, b2, s1, s2, ch, False, True)
+    exp = oracle.dist_trajectory(c3, b2, s1, s2, ch, False, True)
+    assert np.array_equal(got, exp, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(exp))
