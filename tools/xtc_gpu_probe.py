@@ -20,13 +20,17 @@ src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 real = os.path.join(d, "real.xtc")
 with open(real, "wb") as fh:
     for _ in range(700): fh.write(src)                      # 4200 frames of 4507 atoms
+src4 = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "xtc", "4rws_head.xtc"), "rb").read()
+real4 = os.path.join(d, "real4.xtc")
+with open(real4, "wb") as fh:
+    for _ in range(2100 // max(1, xtc.get_xtc_nframes(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "xtc", "4rws_head.xtc")))): fh.write(src4)
 lib = _lib.load()
 only = os.environ.get("XTC_PROBE_ONLY", "")                  # "syn" / "real": one file (the PMC passes)
-for name, fn in (("synthetic 30000 atoms", syn), ("3ptb head (water runs), 4507 atoms", real)):
-    if only and (only == "syn") != (fn is syn):
+for name, fn in (("synthetic 30000 atoms", syn), ("3ptb head (water runs), 4507 atoms", real), ("4rws head (reference writer, solvated: 75338 atoms)", real4)):
+    if only and ((only == "syn") != (fn is syn) or fn is real4):
         continue
     na, nf = xtc.get_xtc_natoms(fn), xtc.get_xtc_nframes(fn)
-    for n in (256, 1024, 2048, 4096):
+    for n in ((256, 1024, 2048) if fn is real4 else (256, 1024, 2048, 4096)):
         n = min(n, nf)
         sel = np.arange(n, dtype=np.int64)
         t0 = time.perf_counter(); desc, lo, hi, box, tm, st = xtc.chunk_desc(fn, sel, na); t_desc = time.perf_counter() - t0
