@@ -11,6 +11,9 @@ from tests.synth import grid_origin, synth_config
 
 dev = torch.device("cuda", 0)
 ctx = _lib.default_context(0)
+if os.environ.get("MKAMD_TILE_K"):                     # A/B: force the tile depth (4 / 8) of every call
+    ctx.set_tile_k(int(os.environ["MKAMD_TILE_K"]))
+    _lib.default_context().set_tile_k(int(os.environ["MKAMD_TILE_K"]))
 
 
 def probe(p, reps=300):
@@ -46,4 +49,4 @@ for _ in range(3):
     for _ in range(200):
         getVoxelDescriptors(None, **kw)
     best = min(best, (time.perf_counter() - t0) / 200 * 1e3)
-print(f"{os.environ.get('MKAMD_LIB', 'libmkamd.so'):40s} cfg2 grid {a:6.1f} us   3PTB grid {b:6.1f} us   drop-in 3PTB call {best:.4f} ms", flush=True)
+print(f"{os.environ.get('MKAMD_LIB', 'libmkamd.so') + ' K=' + os.environ.get('MKAMD_TILE_K', 'auto'):40s} cfg2 grid {a:6.1f} us   3PTB grid {b:6.1f} us   drop-in 3PTB call {best:.4f} ms", flush=True)
