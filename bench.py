@@ -720,7 +720,7 @@ def term_reporter():
 def _max_over_ranks(x, world):
     """MAX of a host scalar over the ranks through a CPU tensor (the gloo side of the process group): nothing in or around
     the timed region touches RCCL -- once an RCCL communicator exists in the process every kernel of the step runs 3-7 %
-    slower (measured with one rank, tools/gpu_r3_torchrun_probe2.sh), so it is first created by the gather legs, after
+    slower (measured with one rank, profiles/r3_torchrun_probe.txt), so it is first created by the gather legs, after
     everything that is timed."""
     if world > 1 or "RANK" in os.environ:
         import torch

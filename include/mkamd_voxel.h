@@ -54,6 +54,11 @@ int mkamd_ctx_destroy(mkamd_ctx* ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).  NULL is the legacy
  * default stream (a valid choice); (void*)-1 restores the context's own stream. */
 int mkamd_ctx_set_stream(mkamd_ctx* ctx, void* hip_stream);
+/* Give up a host call that was begun (mkamd_voxelize_lattice_host_begin) and will not be ended -- the caller lost its second
+ * half to an exception, say: the call's kernels are drained, its result is dropped, the context takes every entry point
+ * again.  No-op without a pending call.  (The Python binding calls it when the function `voxelize_lattice_begin` returned is
+ * garbage-collected without having been called, so that a dropped `end` cannot block a shared default context.) */
+int mkamd_ctx_abandon_pending(mkamd_ctx* ctx);
 /* Wait for the stream and report asynchronous errors of "_dev" calls (MKAMD_EOVERFLOW/EBOX). */
 int mkamd_ctx_synchronize(mkamd_ctx* ctx);
 /* Non-blocking form for streaming callers: reports (and clears) an asynchronous error of a "_dev" lattice call that
@@ -132,7 +137,9 @@ int mkamd_ctx_set_pipelining(mkamd_ctx* ctx, int on);
  * are complete already and were not produced by work enqueued on the context's stream after the previous voxelize
  * call, e.g. a resident shard -- and they stay untouched until the call's features have been consumed.  The call's
  * pre-pass waits for the event on whichever stream runs it and may then run beside the previous call's tile kernel.
- * The promise is consumed by that call, pipelined or not (a small call runs in order and still waits for the event). */
+ * The promise is consumed by that call, pipelined or not (a small call runs in order and still waits for the event).  Host
+ * entry points ("_host", mkamd_calculate_occupancy) neither honour nor consume it: a promise made on a shared context
+ * survives another caller's host call made before the device call it is about. */
 int mkamd_ctx_promise_inputs(mkamd_ctx* ctx, void* hip_event);
 /* Drop a promise that no call has consumed (a driver that stops between the promise and its call). */
 int mkamd_ctx_withdraw_promise(mkamd_ctx* ctx);
@@ -158,6 +165,19 @@ int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* laun
 int mkamd_calculate_occupancy(mkamd_ctx* ctx, const double* centers, int64_t n_centers,
                               const float* coords, int64_t n_atoms, const double* sigmas,
                               int32_t n_channels, double* results);
+
+/* (1b) the same contract on the HOST, no context and no GPU (the reference's `method="C"` dispatch,
+ * tools/voxeldescriptors.py:355-360, lands in a CPU loop): the library's own double-precision implementation -- atoms in a
+ * uniform cell list, every centre against the 27 cells around it, the reference's arithmetic per pair (float32 coordinates
+ * promoted, strict d^2 < 25, x^12 as x3*x3*x3*x3, value > old), centres split over host threads.  A maximum does not
+ * depend on the order of its candidates: results are the reference's bit for bit.  EXPLICIT only: no GPU entry point falls
+ * back to it (without a device they fail with MKAMD_ENODEV); the Python package reaches it through method="CPU" /
+ * occupancy_utils.calculate_occupancy_cpu.  `_threads`: n_threads <= 0 = automatic (MKAMD_CPU_THREADS, else one thread for
+ * small calls and up to 32 otherwise). */
+int mkamd_calculate_occupancy_cpu(const double* centers, int64_t n_centers, const float* coords, int64_t n_atoms,
+                                  const double* sigmas, int32_t n_channels, double* results);
+int mkamd_calculate_occupancy_cpu_threads(const double* centers, int64_t n_centers, const float* coords, int64_t n_atoms,
+                                          const double* sigmas, int32_t n_channels, double* results, int32_t n_threads);
 
 /* (2) explicit (arbitrary) centres, float32 output, optional orthorhombic box (double[3], A;
  * NULL = not periodic).  sigmas_are_f64: 1 -> const double*, 0 -> const float*. */
@@ -201,9 +221,10 @@ int mkamd_voxelize_lattice_host_f64(mkamd_ctx* ctx, int32_t n_items, const float
  * ships the inputs and enqueues the kernels (the input arrays must stay valid until `end`); `end` waits and writes the
  * result into ONE of the two arrays (the other NULL) of `n_values` elements -- which must be the n_items * n_voxels *
  * n_channels values the pending call produced (else MKAMD_EINVAL, nothing is written, the call is abandoned).  One call at
- * a time per context; a `begin` that is never ended is abandoned by the next `begin`; between the two halves only queries,
- * mkamd_grid_centers_*, mkamd_copy_to_host and mkamd_frames_to_items_dev are accepted on the context -- any other entry
- * point would regrow or overwrite what `end` hands back and returns MKAMD_EINVAL. */
+ * a time per context; a `begin` that is never ended is abandoned by the next `begin` (or host call) or by
+ * mkamd_ctx_abandon_pending; between the two halves only queries, mkamd_grid_centers_*, mkamd_copy_to_host,
+ * mkamd_frames_to_items_dev and mkamd_xtc_decode_dev are accepted on the context -- any other entry point would regrow or
+ * overwrite what `end` hands back and returns MKAMD_EINVAL (it does not guess whether the pending call is still wanted). */
 int mkamd_voxelize_lattice_host_begin(mkamd_ctx* ctx, int32_t n_items, const float* coords,
                                       const int64_t* atom_offsets, const void* sigmas,
                                       int sigmas_are_f64, int32_t n_channels, const double* origins,

@@ -8,7 +8,7 @@ import time
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libmkamd.so")
-SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h", "xtc_gpu.h"]
+SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "mk_diagnostics.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h", "xtc_gpu.h", "cpu_occupancy.h"]
 HEADER = os.path.join(_HERE, "..", "include", "mkamd_voxel.h")
 HEADER2 = os.path.join(_HERE, "..", "include", "mkamd_distance.h")
 HEADER3 = os.path.join(_HERE, "..", "include", "mkamd_xtc.h")
@@ -59,6 +59,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         tmp = "%s.%d.tmp" % (LIB, os.getpid())
         cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
                "-Wno-unused-function", '-DMKAMD_SRC_HASH="%s"' % source_hash(), os.path.join(CSRC, "capi.hip"), "-o", tmp]
+        # a release build: none of the diagnostics knobs of csrc/mk_diagnostics.h (they compile parts of the kernels out)
+        assert not any(a.startswith("-DMK_") or a.startswith("-DMKAMD_DIAG") for a in cmd), "release builds define no MK_* knobs"
         if verbose:
             print(" ".join(cmd))
         try:

@@ -28,6 +28,7 @@ SIGNATURES = {
     "mkamd_ctx_destroy": (_c_int, [_vp]),
     "mkamd_ctx_set_stream": (_c_int, [_vp, _vp]),
     "mkamd_ctx_synchronize": (_c_int, [_vp]),
+    "mkamd_ctx_abandon_pending": (_c_int, [_vp]),
     "mkamd_ctx_poll_errors": (_c_int, [_vp]),
     "mkamd_ctx_device_info": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(_c_int),
                                        ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.c_size_t]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "mkamd_ctx_enable_kernel_timing": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_read_kernel_timing": (_c_int, [_vp, ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i64)]),
     "mkamd_calculate_occupancy": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
+    "mkamd_calculate_occupancy_cpu": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp]),
+    "mkamd_calculate_occupancy_cpu_threads": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i32, _vp, _c_i32]),
     "mkamd_occupancy_centers_host": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp]),
     "mkamd_occupancy_centers_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp]),
     "mkamd_voxelize_lattice_host": (_c_int, [_vp, _c_i32, _vp, _vp, _vp, _c_int, _c_i32, _vp, _vp, _c_dbl,
@@ -112,6 +115,11 @@ def load() -> ctypes.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(L, name)          # AttributeError if a declared symbol is missing
                 fn.restype, fn.argtypes = res, args
+            # a DIAGNOSTICS build (csrc/mk_diagnostics.h: parts of the kernels compiled out to time them -- wrong values on
+            # purpose -- or cycle counters inside them) is never picked up by accident
+            if b"DIAGNOSTICS" in L.mkamd_version() and os.environ.get("MKAMD_ALLOW_DIAGNOSTICS", "0") != "1":
+                raise RuntimeError(f"moleculekit_amd: {LIB_PATH} is a DIAGNOSTICS build ({L.mkamd_version().decode()}); "
+                                   f"set MKAMD_ALLOW_DIAGNOSTICS=1 to load it for timing experiments")
             _lib = L
     return _lib
 
@@ -191,6 +199,11 @@ class Context:
 
     def synchronize(self):
         _check(load().mkamd_ctx_synchronize(self._h))
+
+    def abandon_pending(self):
+        """Give up a host call that was begun and will not be ended (include/mkamd_voxel.h); no-op without one."""
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _check(load().mkamd_ctx_abandon_pending(self._h))
 
     def poll_errors(self):
         """Non-blocking: raise if an already finished asynchronous lattice call flagged an error (bad / too small
@@ -311,6 +324,8 @@ class Context:
         """First half of voxelize_lattice_host: inputs shipped, kernels enqueued (the arrays must outlive ..._end)."""
         _check(load().mkamd_voxelize_lattice_host_begin(self._h, B, _ptr(coords), _ptr(offsets), _ptr(sigmas), int(sig_f64), C,
                                                         _ptr(origins), _ptr(nvox), float(voxelsize), _ptr(box), int(max_images)))
+        self._begun = getattr(self, "_begun", 0) + 1          # which `begin` is pending (batch.voxelize_lattice_begin's finalizer)
+        return self._begun
 
     def voxelize_lattice_host_end(self, out):
         """Second half: wait, result into `out` (float32 or float64, C-contiguous, B*V*C elements -- checked here and, the

@@ -104,15 +104,40 @@ def voxelize_lattice_begin(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     C = int(sigmas.shape[1])
     V = int(nv[0]) * int(nv[1]) * int(nv[2])
     bx = None if box is None else np.ascontiguousarray(box, dtype=np.float32).reshape(B, 3)
-    ctx.voxelize_lattice_host_begin(B, coords, atom_offsets, sigmas, sig64, C, origins, nv, float(voxelsize), bx, 0)
-    keep = (coords, atom_offsets, sigmas, origins, nv, bx)            # the inputs outlive the call
+    ticket = ctx.voxelize_lattice_host_begin(B, coords, atom_offsets, sigmas, sig64, C, origins, nv, float(voxelsize), bx, 0)
+    return _PendingHostCall(ctx, ticket, (B, V, C), dtype, (coords, atom_offsets, sigmas, origins, nv, bx))
 
-    def end(_keep=keep):
-        out = np.empty((B, V, C), dtype=dtype)
-        ctx.voxelize_lattice_host_end(out)
+
+def _abandon_host_call(ctx_ref, ticket):
+    ctx = ctx_ref()
+    # only the call this object began: a later `begin` (which abandons an unfinished one itself) is somebody else's
+    if ctx is not None and getattr(ctx, "_begun", None) == ticket:
+        try:
+            ctx.abandon_pending()
+        except Exception:
+            pass
+
+
+class _PendingHostCall:
+    """The second half of ``voxelize_lattice_begin``: call it once for the features.  Dropped without having been called
+    (an exception between the halves, a KeyboardInterrupt) it gives the pending call up, so that the context -- often the
+    thread's shared default context -- takes every entry point again (include/mkamd_voxel.h, mkamd_ctx_abandon_pending)."""
+
+    def __init__(self, ctx, ticket, shape, dtype, keep):
+        import weakref
+        self._ctx, self._shape, self._dtype, self._keep = ctx, shape, dtype, keep   # the inputs outlive the call
+        self._finalizer = weakref.finalize(self, _abandon_host_call, weakref.ref(ctx), ticket)
+
+    def __call__(self):
+        self._finalizer.detach()                 # the library ends (or has already abandoned) the call itself from here on
+        out = np.empty(self._shape, dtype=self._dtype)
+        self._ctx.voxelize_lattice_host_end(out)
         return out
 
-    return end
+    def abandon(self):
+        """Give the call up explicitly (what garbage collection does for a dropped object)."""
+        if self._finalizer.alive:
+            self._finalizer()
 
 
 def occupancy_centers(centers, coords, sigmas, box=None, ctx=None):

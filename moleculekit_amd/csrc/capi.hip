@@ -1,7 +1,7 @@
 // capi.hip -- extern "C" boundary of libmkamd.so (see include/mkamd_voxel.h) and the HIP backend
 // that drives the launch sequences of pipeline.h on an MI355X.  One context = one device, one
-// stream, one grow-only workspace.  No CPU compute path exists here: without a GPU every entry
-// point fails with MKAMD_ENODEV / MKAMD_EHIP.
+// stream, one grow-only workspace.  Without a GPU every context entry point fails with MKAMD_ENODEV / MKAMD_EHIP; the one
+// host implementation (mkamd_calculate_occupancy_cpu, cpu_occupancy.h) is a separate, explicit entry point nothing here falls back to.
 #include "../../include/mkamd_voxel.h"
 #include "../../include/mkamd_distance.h"
 #include "../../include/mkamd_xtc.h"
@@ -10,6 +10,7 @@
 #include "pipeline.h"
 #include "dist_pipeline.h"
 #include "xtc_gpu.h"
+#include "cpu_occupancy.h"
 
 #include <algorithm>
 #include <cstring>
@@ -267,7 +268,7 @@ static int check_ctx(mkamd_ctx* ctx, bool pending_ok = false)
 {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     if (!pending_ok && ctx->pending.active)
-        return fail(MKAMD_EINVAL, "a host call begun on this context (mkamd_voxelize_lattice_host_begin) has not been ended: call _end first");
+        return fail(MKAMD_EINVAL, "a host call begun on this context (mkamd_voxelize_lattice_host_begin) has not been ended: call _end (or mkamd_ctx_abandon_pending) first");
     HIP_TRY(hipSetDevice(ctx->device));
     ctx->stream = ctx->main_stream;           // a failed call may have left the side stream selected
     return 0;
@@ -304,7 +305,7 @@ extern "C" {
 #define MKAMD_SRC_HASH "unstamped"
 #endif
 // (the hash is what ties a measurement to a build: profiles/*_pmc_counters.json carry it, bench.py refuses counters of another build)
-const char* mkamd_version(void) { return "moleculekit_amd 0.3.0 (gfx950, HIP) src " MKAMD_SRC_HASH; }
+const char* mkamd_version(void) { return "moleculekit_amd 0.4.0 (gfx950, HIP) src " MKAMD_SRC_HASH MKAMD_BUILD_KIND; }
 
 const char* mkamd_last_error(void) { return g_last_error; }
 
@@ -394,6 +395,18 @@ try {
     ctx->tile_pending[0] = ctx->tile_pending[1] = false;
     ctx->have_pre_tile_event = false;         // the next pipelined pre-pass takes its marker from the NEW stream
     ctx->stream = ctx->main_stream = next;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_abandon_pending(mkamd_ctx* ctx)
+try {
+    int st = check_ctx(ctx, true);
+    if (st) return st;
+    if (!ctx->pending.active) return MKAMD_OK;
+    // the kernels of the abandoned call still write the result buffer and read the workspace: drained before anything reuses them
+    ctx->pending.active = false;
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    HIP_TRY(hipStreamSynchronize(ctx->main_stream));
     return MKAMD_OK;
 } MK_API_CATCH
 
@@ -678,6 +691,25 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+// calculate_occupancy on the HOST: the library's own double-precision implementation (cpu_occupancy.h), no
+// context, no device.  Explicit only: nothing in the library or the package takes it on its own.
+int mkamd_calculate_occupancy_cpu_threads(const double* centers, int64_t V, const float* coords, int64_t N, const double* sigmas,
+                                          int32_t C, double* results, int32_t n_threads)
+try {
+    if (V < 0 || N < 0 || C <= 0) return fail(MKAMD_EINVAL, "n_centers/n_atoms must be >= 0 and n_channels > 0");
+    if (V == 0 || N == 0) return MKAMD_OK;
+    if (!centers || !coords || !sigmas || !results) return fail(MKAMD_EINVAL, "centers/coords/sigmas/results pointer is NULL");
+    if (N > 0xFFFFFFF0LL) return fail(MKAMD_EINVAL, "more than 2^32 atoms");
+    mkamd::cpu::calculate_occupancy(centers, V, coords, N, sigmas, C, results, (int)n_threads);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_calculate_occupancy_cpu(const double* centers, int64_t V, const float* coords, int64_t N, const double* sigmas,
+                                  int32_t C, double* results)
+try {
+    return mkamd_calculate_occupancy_cpu_threads(centers, V, coords, N, sigmas, C, results, 0);
+} MK_API_CATCH
+
 // ---------------------------------------------------------------------------------------------
 // lattice grids (the hot path)
 // ---------------------------------------------------------------------------------------------
@@ -711,6 +743,9 @@ try {
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     std::string err;
+    // a promise (mkamd_ctx_promise_inputs) is about the next call of THIS entry point made from outside the library: a host
+    // call reaches here through voxelize_lattice_host_begin_impl, which has set the promise aside (its inputs were uploaded
+    // on the main stream just now, behind the marker a pipelined pre-pass waits for)
     st = run_lattice(*ctx, P, err);
     ctx->promise = false; ctx->promise_event = nullptr;       // one call's worth
     if (st && !err.empty()) return fail(st, err);
@@ -768,17 +803,6 @@ static void widen(const float* __restrict__ src, double* __restrict__ dst, size_
 
 // `features64` != NULL: the caller wants the reference's float64 [B,V,C] (voxeldescriptors.py:531); the widening is
 // done here, in the pass that takes the results out of the pinned buffer anyway, instead of in a second pass in numpy
-#ifdef MK_HOST_TIMERS   // tools/ build only: where a small synchronous host call spends its time (microseconds, summed)
-#include <chrono>
-static double g_host_us[6];
-static inline double host_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-#define MK_HOST_MARK(i) do { const double n_ = host_now(); g_host_us[i] += n_ - host_t_; host_t_ = n_; } while (0)
-#define MK_HOST_BEGIN() double host_t_ = host_now()
-extern "C" void mkamd_debug_host_timers(double* out6) { for (int i = 0; i < 6; ++i) { out6[i] = g_host_us[i]; g_host_us[i] = 0.0; } }
-#else
-#define MK_HOST_MARK(i) do {} while (0)
-#define MK_HOST_BEGIN() do {} while (0)
-#endif
 
 // A host call in two halves: `begin` checks, ships the inputs and enqueues the kernels; `end` waits and takes the result
 // out.  The one-piece entry points run them back to back; the drop-in getVoxelDescriptors does its own host work (the copy
@@ -787,7 +811,6 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
                                             const void* sigmas, int sigmas_are_f64, int32_t C, const double* origins,
                                             const int32_t* nvoxels, double voxelsize, const float* box, int32_t max_images)
 {
-    MK_HOST_BEGIN();
     int st = check_ctx(ctx, true);
     if (st) return st;
     if (ctx->pending.active) {                                      // a begin without its end: that call is abandoned
@@ -874,7 +897,6 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
     }
     // the per-item pre-pass gives every item ONE workgroup: here the offsets are visible, so a ragged batch whose
     // average is small but which holds a huge item is kept on the kernel chain (automatic mode only)
-    MK_HOST_MARK(0);                                                // checks + inputs packed
     long long biggest = 0;
     for (int b = 0; b < B; ++b) biggest = std::max<long long>(biggest, atom_offsets[b + 1] - atom_offsets[b]);
     const int saved_mode = ctx->prepass_mode;
@@ -885,13 +907,18 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
     if (mapped_out && ctx->fb_host != nullptr) { if (++ctx->seq_counter == 0u) ctx->seq_counter = 1u; seq = ctx->seq_counter; }
     ctx->seq_next = seq;
     ctx->tail_reports = false;
+    // an outstanding promise is about the next DEVICE call of whoever made it, not about this host call (whose inputs went up
+    // on the main stream a moment ago: a pre-pass on the side stream would race the upload): set aside, handed back after
+    const bool saved_promise = ctx->promise;
+    const hipEvent_t saved_promise_event = ctx->promise_event;
+    ctx->promise = false; ctx->promise_event = nullptr;
     st = mkamd_voxelize_lattice_dev(ctx, B, (const float*)dx, (const int64_t*)doff, N, ds, sigmas_are_f64, C,
                                     (const double*)dorg, nvoxels, voxelsize, box ? (const float*)dbox : nullptr,
                                     max_images, (float*)dout);
+    ctx->promise = saved_promise; ctx->promise_event = saved_promise_event;
     ctx->prepass_mode = saved_mode;
     ctx->seq_next = 0u;
     if (st) return st;
-    MK_HOST_MARK(1);                                                // kernels enqueued
     ctx->pending.active = true; ctx->pending.out_bytes = out_bytes; ctx->pending.mapped_out = mapped_out; ctx->pending.seq = seq;
     ctx->pending.dout = dout;
     ctx->pending.done = nullptr;
@@ -905,7 +932,6 @@ static int voxelize_lattice_host_begin_impl(mkamd_ctx* ctx, int32_t B, const flo
 
 static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, double* features64, double* max_into)
 {
-    MK_HOST_BEGIN();
     int st = check_ctx(ctx, true);
     if (st) return st;
     if (!ctx->pending.active) return fail(MKAMD_EINVAL, "no host call was begun on this context");
@@ -953,30 +979,21 @@ static int voxelize_lattice_host_end_impl(mkamd_ctx* ctx, float* features, doubl
             src = ctx->f32_stage.data();
         }
         if (early) {
-            MK_HOST_MARK(2);                                        // waited for the tile kernel
             widen(src, features64, nvals);                          // ... while k_tail runs and the stream signals its completion
-            MK_HOST_MARK(3);
             HIP_TRY(wait_for_small_call(ctx->stream, done));
-#ifndef MK_NO_REPASS   // (tests/: a build without the second pass must FAIL test_host_pass_is_repeated_when_the_tail_changes_values)
             if (((const volatile unsigned*)ctx->fb_host)[FB_TAIL_WROTE] == seq) widen(src, features64, nvals);     // k_tail changed values (rare): once more
-#endif
         } else {
             HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream, done) : hipStreamSynchronize(ctx->stream));
-            MK_HOST_MARK(2);                                        // waited for the stream
             widen(src, features64, nvals);
-            MK_HOST_MARK(3);                                        // float32 -> float64 into the caller's array
         }
         st = collect_async_errors(ctx);
-        MK_HOST_MARK(4);
         return st;
     }
     if (!mapped_out) HIP_TRY(hipMemcpyAsync(features, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (early) {
         memcpy(features, ctx->out_host, out_bytes);
         HIP_TRY(wait_for_small_call(ctx->stream, done));
-#ifndef MK_NO_REPASS
         if (((const volatile unsigned*)ctx->fb_host)[FB_TAIL_WROTE] == seq) memcpy(features, ctx->out_host, out_bytes);
-#endif
         return collect_async_errors(ctx);
     }
     HIP_TRY(mapped_out ? wait_for_small_call(ctx->stream, done) : hipStreamSynchronize(ctx->stream));
@@ -1424,7 +1441,7 @@ try {
 } MK_API_CATCH
 
 #ifdef MK_PHASE_TIMERS
-// profiling build only (tools/gpu_phase_timers.sh): read and clear the per-phase cycle sums of the tile kernel
+// diagnostics build only (mk_diagnostics.h; tools/phase_timers.py): read and clear the per-phase cycle sums of the tile kernel
 extern "C" int mkamd_debug_phase_cycles(unsigned long long* out8)
 {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mkamd::g_phase_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;

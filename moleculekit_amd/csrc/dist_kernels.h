@@ -91,8 +91,7 @@ MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long 
     const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
     float* __restrict__ o = out + (size_t)(f0 + fq) * (size_t)P + (size_t)(p0 + pl);
     const size_t step = (size_t)NW * (size_t)P;
-#ifndef MK_DIST_NO_V4            // A-B builds
-    if (f0 + DT <= F && p0 + DT <= p_end && ((P | p0) & 3) == 0) {
+    if (f0 + DT <= F && p0 + DT <= p_end && ((P | p0) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & (uintptr_t)15) == 0) {   // (any float* is accepted as the result: an offset view is 4-byte aligned only)
         // a full tile whose rows start on 16 bytes: FOUR store instructions of 16 bytes per lane instead of sixteen of 4 (the
         // memory pipeline takes a wave's store instructions one by one: round-4 PMC showed the kernel at the same 0.30 ms with
         // and without its image arithmetic and with a third of its loads).  A lane owns four consecutive pairs of one frame;
@@ -113,7 +112,6 @@ MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long 
             *reinterpret_cast<float4*>(out + (size_t)(f0 + fg) * (size_t)P + (size_t)(p0 + 4 * q)) = v[it];
         }
     } else
-#endif
     if (f0 + DT <= F && p0 + DT <= p_end) {
         float v[ROWS];
 #pragma unroll
@@ -162,10 +160,7 @@ MK_KERNEL(256) void k_build_atom_pairs(const unsigned* __restrict__ sel1, long l
 // trips to L2 per wave, which is what bounded it (0.56 ms for 100 000 pairs x 2 048 frames: 1.5 TB/s of stores).
 constexpr int DP_RUN = DT / (DT_THREADS / DT);   // 16
 template <bool B> struct DistFlag { static constexpr bool value = B; };
-#ifndef MK_DP_BATCH
-#define MK_DP_BATCH 4
-#endif
-constexpr int DP_BATCH = MK_DP_BATCH;           // (8 was measured too)
+constexpr int DP_BATCH = 4;           // (8 was measured too)
 
 // d^2 of the DP_RUN consecutive pairs [pw, pw + DP_RUN) for this lane's frame (byte offset fb = 4 f into a coordinate
 // row; the host refuses F >= 2^30): emit(k, d2), k = 0 .. DP_RUN-1, called by all lanes.  Pairs past the end repeat
@@ -258,9 +253,6 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
         const long long f = f0 + fl < F ? f0 + fl : F - 1;
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
         const long long pw = p0 + pq * DP_RUN;                       // the wave's first pair
-#ifdef MK_DIST_DIAG                                                  // store-only floor (tools): no loads, no arithmetic
-        for (int k = 0; k < DP_RUN; ++k) tile[pq * DP_RUN + k][fl] = bx;
-#else
         if (pw < P)
             for_pair_run(coords, F, (unsigned)f * 4u, bx, by, bz, pa, pb, wrap, P, pw,
                          [&](int k0, const float (&d2)[DP_BATCH]) {
@@ -279,7 +271,6 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
                                  for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = mk_fsqrt_rn(d2[u]);
                              }
                          });
-#endif
     }
     mk_block_sync();
     store_tile_rows(tile, f0, p0, F, P, P, out);
@@ -402,10 +393,7 @@ MK_KERNEL(DR_WAVES * WAVE) void k_dist_rect(const float* __restrict__ coords, lo
 // bytes of out[f, i * n2 + j..] per store -- no LDS, no barrier, nothing but the pair arithmetic between a load and a store.
 // Same functions per pair (dist2_min_image_f32, mk_fsqrt_rn): the same bits.
 // ------------------------------------------------------------------------------------------------
-#ifndef MK_ROWS_CI
-#define MK_ROWS_CI 16
-#endif
-constexpr int ROWS_CI = MK_ROWS_CI;    // first atoms a wave walks for its second atoms (their loads are amortised over them)
+constexpr int ROWS_CI = 16;    // first atoms a wave walks for its second atoms (their loads are amortised over them)
 
 // The two selections' coordinates, frame-major: T[f][ax][k] = coords[sel[k], ax, f], k < np (np = n rounded up: the pad repeats the
 // last atom, so that idle lanes compute on something harmless); cs[k] = chains[sel[k]].  ONE launch for both selections and all
@@ -513,11 +501,7 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
             }
         }
         if constexpr (VEC) {
-#ifdef MK_ROWS_NT_STORE            // A-B build
-            if (whole || j0 < n2) mk_tmp_store(reinterpret_cast<float4*>(o), make_float4(d[0], d[1], d[2], d[3]));
-#else
-            if (whole || j0 < n2) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);   // (n2 % 4 == 0: all four or none)
-#endif
+            if (whole || j0 < n2) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);   // (n2 % 4 == 0: all four or none; non-temporal stores measured: opposite signs for the two modes)
         } else if (whole) {
 #pragma unroll
             for (int k = 0; k < JPL; ++k) o[64 * k] = d[k];

@@ -38,41 +38,14 @@
 #include "mk_device.h"
 #endif
 
-namespace mkamd {
+#include "mk_diagnostics.h"     // MK_DIAG / MK_PHASE_* / MK_BIN_*: all zero / empty in a release build (the only -D knobs of this file)
 
-#ifdef MK_PHASE_TIMERS   // tools/phase_timers build only: wall-clock cycles a tile wave spends in each phase
-__device__ unsigned long long g_phase_cycles[8];
-#endif
-#if defined(MK_PHASE_TIMERS) && !defined(MK_BIN_TIMERS)
-#define MK_PHASE_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
-        if (!DENSE && threadIdx.x == 0) atomicAdd(&g_phase_cycles[i], now_ - phase_t_); phase_t_ = now_; } while (0)
-#define MK_PHASE_BEGIN() unsigned long long phase_t_ = __builtin_readcyclecounter()
-#else
-#define MK_PHASE_MARK(i) do {} while (0)
-#define MK_PHASE_BEGIN() do {} while (0)
-#endif
-#if defined(MK_PHASE_TIMERS) && defined(MK_BIN_TIMERS)      // tools/bin_timers.py build: the same for the sections of k_bin_direct (wave 0 of every 64th block)
-#define MK_BIN_MARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
-        if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) atomicAdd(&g_phase_cycles[i], now_ - bin_t_); bin_t_ = now_; } while (0)   /* a sample: same-address atomics serialise */
-#define MK_BIN_BEGIN() unsigned long long bin_t_ = __builtin_readcyclecounter()
-#else
-#define MK_BIN_MARK(i) do {} while (0)
-#define MK_BIN_BEGIN() do {} while (0)
-#endif
+namespace mkamd {
 
 constexpr int CHG = 8;               // channels per channel-group (one group = one pass of the tile kernel)
 constexpr int NCLS = 15;             // distinct sigma values (classes) the sorted path handles per class table (4-bit ids)
 constexpr int NSLOT = 16;            // bucket stride per channel (slot 15 is never used)
 constexpr int NBUCKET = CHG * NSLOT; // (channel, class) buckets per tile
-#ifndef MK_DIAG           // tools/gpu_diag.sh builds only: compile parts of the tile kernel out to count what they cost
-#define MK_DIAG 0         // 1 pair loops, 2 class flushes, 4 epilogue arithmetic, 8 placement + all class work, 16 histogram traversal
-#endif
-#ifndef MK_SURV_BATCH
-#define MK_SURV_BATCH 2
-#endif
-#ifndef MK_TRAV_BATCH
-#define MK_TRAV_BATCH 4
-#endif
 // LDS entry capacity of a tile (three float arrays, structure of arrays) comes in tiers: LDS per tile is
 // what bounds the tile kernel's occupancy, so the leanest tier is the fastest as long as the tiles fit
 // it; the host moves up when too many tiles of the previous calls did not (pipeline.h, choose_tier).
@@ -83,7 +56,8 @@ constexpr int FEEDBACK_WORDS = NTIER + 4; // host-visible: [t] tiles over tier t
                                           // [NTIER+2] sequence number of the call whose tile kernel has finished (k_tail
                                           // writes it as it starts), [NTIER+3] of the last call whose k_tail changed values
 constexpr int FB_TILES_DONE = NTIER + 2, FB_TAIL_WROTE = NTIER + 3;
-constexpr int TRAV_BATCH = MK_TRAV_BATCH;   // candidate chunks whose loads are in flight together
+constexpr int TRAV_BATCH = 4;       // candidate chunks whose loads are in flight together (6 and 8 measured the same)
+constexpr int SURV_BATCH = 2;       // survivor chunks gathered together (histogram / placement passes)
 constexpr int NXR = 3;               // x-reach sub-buckets: 0 = all K planes, 1 = low half only, 2 = high half only
 constexpr int NBUCKET3 = NBUCKET * NXR;
 constexpr unsigned CLS_EMPTY = 0xffffffffu;   // empty slot of the class table (never a valid w)
@@ -631,7 +605,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
 // -- any of these raises DIRECT_FAILED, and the kernels of the count / scan / fill chain, which are enqueued behind this
 // pass in every call and return at once while the word is clear, do the call the old way (and leave the new class
 // table).  The tile kernels read the word too (find_candidate_runs).  Open boundaries, one channel group.
-// Measured on cfg2 (256 x 50 000 atoms, same box, tools/gpu_r3_direct.sh): 390 us against 338 + 189 + 48 for count + fill +
+// Measured on cfg2 (256 x 50 000 atoms, same box, docs/EXPERIMENTS_r3.md): 390 us against 338 + 189 + 48 for count + fill +
 // reductions (pre-pass traffic 0.9-1.2 GB instead of 1.7); the chain behind it is launched as <= 4 096 workgroups that leave
 // at once (as one workgroup per block it cost 82 us to launch and leave), and the tile kernel reads 27 cell runs instead
 // of 9-16 column runs (+4 %): in-order step 2.41 against 2.55 ms, pipelined 2.28 against 2.27 (nothing).  What bounds the pass
@@ -1381,9 +1355,7 @@ constexpr int SURV_OFF_BITS = 10;
 struct CandRuns {
     unsigned r0, len, pre, N, T;
     bool codable;                     // every run is short enough for the 16-bit survivor codes
-#ifdef MK_PHASE_TIMERS
-    mutable unsigned long long wait_ = 0, proc_ = 0;
-#endif
+    MK_PHASE_FIELDS
 };
 
 template <int K>
@@ -1535,22 +1507,16 @@ MK_DEV void for_each_candidate(const GridDesc& g, const TileGeom& tg, const Cand
     //  per call.  Six or eight in flight instead of four change nothing for a 64^3 grid's 24-chunk tiles)
     CandChunk ch[BATCH];
     for (unsigned t = first_batch; t < T; t += BATCH * batch_stride) {
-#ifdef MK_PHASE_TIMERS
-        const unsigned long long ta_ = __builtin_readcyclecounter();
-#endif
+        MK_PHASE_NOW(ta_);
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) cand_issue<LOAD_CLS>(ld, t + (unsigned)k * batch_stride, ch[k]);
-#ifdef MK_PHASE_TIMERS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long tb_ = __builtin_readcyclecounter();
-#endif
+        MK_PHASE_DRAIN();
+        MK_PHASE_NOW(tb_);
 #pragma unroll
         for (int k = 0; k < BATCH; ++k)
             if (t + (unsigned)k * batch_stride < T) cand_consume<K, F&, LOAD_CODE>(ld, ch[k], f);      // wave-uniform
-#ifdef MK_PHASE_TIMERS
-        const unsigned long long tc_ = __builtin_readcyclecounter();
-        cr.wait_ += tb_ - ta_; cr.proc_ += tc_ - tb_;                 // flushed at the end of the tile
-#endif
+        MK_PHASE_NOW(tc_);
+        MK_PHASE_CAND(cr, ta_, tb_, tc_);                             // (diagnostics builds: flushed at the end of the tile)
     }
 }
 
@@ -1635,23 +1601,15 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     float* const sy = sxyz + ESTRIDE;
     float* const sz = sxyz + 2 * ESTRIDE;
     float4* const ebuf = reinterpret_cast<float4*>(sxyz);   // general path: one chunk's entries of one channel (x,y,z,w)
-#ifdef MK_LDS_PAD                                  // occupancy experiment knob (tools/): waste LDS on purpose
-    __shared__ unsigned lds_pad[MK_LDS_PAD / 4];
-    if (g.nx < 0) lds_pad[threadIdx.x] = 1u, out[0] = (float)lds_pad[(threadIdx.x + 1) & 63];
-#endif
     // per-tile histogram -> placement cursors -> (after placement) sub-bucket starts again; [NBUCKET3] = end
     __shared__ unsigned bucket[NBUCKET3 + 1];
     // a team keeps the placement cursors in an array of their own: the counts, the cursors and the final table of starts then
     // need two workgroup barriers between them, not four (a barrier of four unevenly loaded waves is ~0.3 us of a 28 us call)
     __shared__ unsigned bucket_cur[TEAM > 1 ? NBUCKET3 + 1 : 1];
-#ifdef MK_NO_SURV_LIST                                 // A-B builds (tools/gpu_ab.sh): the two-traversal kernel of round 1
-    constexpr bool SURV_LIST = false;
-#else
     // the hot kernel culls once and keeps the survivors (see SURV_CAP).  The list BORROWS the z array of the entry buffer:
     // it is written by the cull pass, read by the histogram pass, and moved into registers (eight 16-bit codes per lane)
     // before the placement pass starts writing entries -- no LDS of its own, so every tier keeps its occupancy
     constexpr bool SURV_LIST = TEAM == 1 && !DENSE;
-#endif
     // a team's waves share ONE survivor list: every wave culls its share of the candidate chunks once and appends what
     // survives (tile-relative position, class ids, x-reach) -- the placement pass then walks ~450 survivors split over the
     // team instead of re-culling ~1 500 candidates.  The list borrows the LDS of the end-of-tile reduction (s_red).
@@ -1726,16 +1684,10 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     for (int c = 0; c < CHG; ++c)
 #pragma unroll
         for (int k = 0; k < KL; ++k) q[c][k] = INF_BITS;
-    bool q_final = false;                                  // (MK_ROLLED_CHANNELS >= 2 only: q already holds the occupancies; wave-uniform)
 
     // "more sigma classes than the table holds": for a call-wide table (one hot line) this is checked up front; a
     // per-item table is a fresh line per item, so the check waits until the first traversal has hidden the load
-#ifdef MK_DIAG_NO_GENERAL      // A-B build (docs/EXPERIMENTS_r4.md): without the general path the candidate runs need not stay alive across the
-                              // class loops -- what the register-capped instance spills (24 bytes: three dwords stored once per tile)
-    constexpr bool general = false;
-#else
     bool general = !DENSE && (g.force_general || (!g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY));
-#endif
     const unsigned* __restrict__ clsp = rec_cls + (size_t)gq * g.M;
     const float4* __restrict__ w0p = rec_w + (size_t)(gq * 2 + 0) * g.M;
     const float4* __restrict__ w1p = rec_w + (size_t)(gq * 2 + 1) * g.M;
@@ -1786,7 +1738,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         // survivor i of the list: its record again (an L2-hot gather), tile-relative; f(valid, ., x, y, z, class ids)
         auto for_each_survivor = [&](auto from_regs_, auto&& f) {
             constexpr bool FROM_REGS = decltype(from_regs_)::value != 0;
-            constexpr int SB = MK_SURV_BATCH;
+            constexpr int SB = SURV_BATCH;
             static_assert(SURV_REGS % SB == 0, "the batches tile the code registers");
 #pragma unroll
             for (int cb = 0; cb < SURV_REGS; cb += SB) {                 // SB chunks' loads in flight
@@ -1845,13 +1797,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         mk_block_sync();
         const unsigned nsv = TEAM > 1 ? mk_uniform(s_nsv) : 0u;             // the same in every wave of the team
         const bool use_sv = TEAM > 1 && nsv <= (unsigned)SV_CAP;
-#ifdef MK_DIAG_NO_GENERAL
-        {
-#else
         if (!DENSE && g.cls_per_item && mk_readlane(table_word, CLS_OVERFLOW) != CLS_EMPTY) {
             general = true;                      // this item alone has too many classes (its records carry w, not ids)
         } else {
-#endif
         MK_PHASE_MARK(1);                                   // traversal 1 (histogram)
         // ---- bucket starts: lane owns groups 2*lane, 2*lane+1 (3 sub-buckets each); every sub-bucket
         //      is padded to an even count so the pair loop never straddles two of them ----
@@ -1913,30 +1861,6 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 const unsigned* bgp = &bucket[(c * NSLOT + cls) * NXR];                           // uniform reads
                 const uint4 bg = make_uint4(mk_uniform(bgp[0]), mk_uniform(bgp[1]), mk_uniform(bgp[2]), mk_uniform(bgp[3]));
                 const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
-#ifdef MK_DIRECT_SINGLE       // round-4 experiment (docs/EXPERIMENTS_r4.md), OFF: ~200 VALU instructions fewer per cfg2 tile, tile kernel +3.4 % SLOWER
-                // (+13 % code in the eight unrolled copies of this loop).
-                // A group of ONE entry (cfg2: 4.9 of a tile's 27 groups; most groups of a ligand's tile) needs no accumulator set:
-                // its d^2 goes straight through the flush arithmetic into the channel minimum -- min(+inf, g) == g, so the bits are
-                // the loop's; what is saved is the eight +inf moves, the raw minima and the planes its sub-bucket does not reach
-                // (two slots in all = one sub-bucket of one or two entries; the odd flag of the only non-empty one says which)
-                if (TEAM == 1 && (MK_DIAG & 3) == 0 && wcls <= fast_w_max<K>() && (bg.w & ~1u) - (bg.x & ~1u) == 2u && ((bg.x | bg.y | bg.z) & 1u)) {
-                    const float* t = sxyz + (bg.x & ~1u);
-                    const float ex = t[0], dy = Y - t[ESTRIDE], dz = Z - t[2 * ESTRIDE];
-                    const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
-                    auto direct = [&](auto k0_, auto k1_) {
-                        constexpr int K0 = decltype(k0_)::value, K1 = decltype(k1_)::value;
-#pragma unroll
-                        for (int k = K0; k < K1; ++k) {
-                            const float d2 = plane_d2<K>(k, mk_fma(pl_slope(k), ex, d0));
-                            acc[k] = mk_min_bits(acc[k], d2 < R2 ? mk_abs(d2) * wcls : INF);
-                        }
-                    };
-                    if ((bg.y & ~1u) != (bg.x & ~1u)) direct(IntC<0>{}, IntC<K>{});                  // wave-uniform
-                    else if ((bg.z & ~1u) != (bg.y & ~1u)) direct(IntC<0>{}, IntC<K / 2>{});
-                    else direct(IntC<K / 2>{}, IntC<K>{});
-                    continue;
-                }
-#endif
                 // m[k] = min over the class's entries of g_k = d^2 - c_k^2 (c_k = x of plane k relative to the tile centre):
                 // with D0 = ex^2 + dy^2 + dz^2 per (lane, entry), g_k = D0 - 2 c_k ex is ONE fma per (voxel, entry); the
                 // plane constant c_k^2 is added to the class minimum at the flush (rounding is monotone: the same bits as
@@ -1951,11 +1875,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                     if (MK_DIAG & 1) return;
                     constexpr int J0 = K0, J1 = K1;
                     const unsigned s0 = b0 & ~1u, odd = b0 & 1u;
-                    unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
-#ifdef MK_DIAG_TRIPCUT        // TIMING-ONLY build (tools/gpu_r4_tile_ab.sh; wrong values): the pair trips of the big groups (>= 28 slots) scaled
-                              // by MK_DIAG_TRIPCUT / 64 -- the upper bound of what sub-wave candidate lists could save (docs/EXPERIMENTS_r4.md)
-                    if ((bg.w & ~1u) - (bg.x & ~1u) >= 28u) npairs = (npairs * (unsigned)(MK_DIAG_TRIPCUT) + 63u) >> 6;
-#endif
+                    const unsigned npairs = (((b1 & ~1u) - s0) >> 1) - odd;
                     unsigned lo = s0, hi = s0 + 2u * npairs;              // the pairs of the sub-bucket, clamped to this wave's range
                     if (TEAM > 1) { lo = lo > my_b ? lo : my_b; hi = hi < my_e ? hi : my_e; }
                     // (no interleaving: the optimizer would otherwise split m[] into two accumulator sets that
@@ -2085,44 +2005,9 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             MK_PHASE_MARK(2);                               // counts -> starts
             if (!(MK_DIAG & 8)) place(0, CHG, 0u, total);
             MK_PHASE_MARK(3);                               // traversal 2 (placement)
-#ifdef MK_ROLLED_CHANNELS      // round-4 experiment: ONE copy of the class code (pair loops, tails, flush) instead of eight -- the channel is a run-time
-                              // number, a finished channel's minima are moved into their registers behind a scalar branch
-            if (!(MK_DIAG & 8)) {
-#if MK_ROLLED_CHANNELS >= 2
-                if (TEAM == 1 && !(MK_DIAG & 4)) {
-                    q_final = true;                                            // channels without entries: occupancy 0
-#pragma unroll
-                    for (int c = 0; c < CHG; ++c)
-#pragma unroll
-                        for (int k = 0; k < KL; ++k) q[c][k] = 0u;
-                }
-#endif
-#pragma clang loop unroll(disable)
-                for (int c = 0; c < CHG; ++c) {
-                    const unsigned bits = class_bits(c);
-                    if (bits == 0u) continue;                                  // wave-uniform: the channel's minima stay +inf
-                    unsigned acc[KL];
-#pragma unroll
-                    for (int k = 0; k < KL; ++k) acc[k] = INF_BITS;
-                    process_classes(c, bits, acc);
-#if MK_ROLLED_CHANNELS >= 2     // ... and the channel's occupancies computed here, by the loop's one copy of the epilogue arithmetic
-                    if (TEAM == 1 && !(MK_DIAG & 4)) {
-#pragma unroll
-                        for (int k = 0; k < KL; ++k) acc[k] = mk_float_bits(occupancy_from_q(mk_uint_as_float(acc[k])));
-                    }
-#endif
-                    switch (c) {
-#define MK_CH_CASE(CC) case CC: { _Pragma("unroll") for (int k = 0; k < KL; ++k) { q[CC][k] = acc[k]; asm volatile("" : "+v"(q[CC][k])); } } break;
-                        MK_CH_CASE(0) MK_CH_CASE(1) MK_CH_CASE(2) MK_CH_CASE(3) MK_CH_CASE(4) MK_CH_CASE(5) MK_CH_CASE(6) MK_CH_CASE(7)
-#undef MK_CH_CASE
-                    }
-                }
-            }
-#else
             if (!(MK_DIAG & 8))
 #pragma unroll
             for (int c = 0; c < CHG; ++c) process_classes(c, class_bits(c), q[c]);
-#endif
             MK_PHASE_MARK(4);                               // pair loops + class flushes
         } else {
             // ---- dense tile: consecutive channels whose padded entries fit the LDS arrays together are
@@ -2242,13 +2127,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
     for (int k = 0; k < KE; ++k) {
         const int x = tg.x0 + kb + k;
         float f[CHG];
-        if (q_final) {                                      // wave-uniform
 #pragma unroll
-            for (int c = 0; c < CE; ++c) { f[c] = mk_uint_as_float(q[c][k]); mk_keep(f[c]); }
-        } else {
-#pragma unroll
-            for (int c = 0; c < CE; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
-        }
+        for (int c = 0; c < CE; ++c) f[c] = (MK_DIAG & 4) ? mk_uint_as_float(q[c][k]) : occupancy_from_q(mk_uint_as_float(q[c][k]));
         if (yz_in && x < g.nx) {
             const size_t vox = vox0 + (size_t)k * plane_vox;
             if constexpr (CSPLIT > 1) {                      // a big team: this wave stores CE channels of the voxel (16 or 8 bytes)
@@ -2276,9 +2156,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
         }
     }
     MK_PHASE_MARK(5);                                       // epilogue
-#ifdef MK_PHASE_TIMERS
-    if (!DENSE && threadIdx.x == 0) { atomicAdd(&g_phase_cycles[6], runs.wait_); atomicAdd(&g_phase_cycles[7], runs.proc_); }
-#endif
+    MK_PHASE_FLUSH(runs);
 }
 
 template <int K, int ECAP>
@@ -2404,19 +2282,6 @@ MK_DEV void voxelize_item_tile(const GridDesc& g, const int b, const int t, cons
             live |= 1u << c;
             const unsigned s0 = mk_uniform(s_gstart[c * NSLOT + cls]) & ~1u, odd = n_in & 1u;
             const float wcls = mk_uint_as_float(mk_readlane(my_class_w, cls));
-#ifdef MK_ITEMS_DIRECT_SINGLE      // round-4 A-B: a group with ONE entry within reach straight through the flush arithmetic (no accumulator set)
-            if (n_in == 1u && wcls <= fast_w_max<K>()) {
-                const float* e1 = sx + s0;
-                const float ex = e1[0], dy = Y - e1[ITEM_STRIDE], dz = Z - e1[2 * ITEM_STRIDE];
-                const float d0 = mk_fma(ex, ex, mk_fma(dy, dy, dz * dz));
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float d2 = plane_d2<K>(k, mk_fma(plane_slope<K>(k), ex, d0));
-                    q[c][k] = mk_min_bits(q[c][k], d2 < R2 ? mk_abs(d2) * wcls : INF);
-                }
-                continue;
-            }
-#endif
             float m[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) { m[k] = INF; mk_keep(m[k]); }

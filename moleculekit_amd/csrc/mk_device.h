@@ -113,11 +113,7 @@ MK_DEV void mk_wave_sync()
 // workgroup barrier (for the 64-thread tile kernel this is a single-wave s_barrier).
 MK_DEV void mk_block_sync() { __syncthreads(); }
 
-#ifdef MK_DIAG_WG_ATOMICS   // timing experiment only (tools/): the rank atomics at workgroup scope = executed in the XCD's L2
-MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#else
 MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
-#endif
 MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
 MK_DEV void mk_atomic_or(int* p, int v) { atomicOr(p, v); }
 

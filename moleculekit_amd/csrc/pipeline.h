@@ -26,10 +26,9 @@
 #include <string>
 #include <cstdlib>
 
-#ifndef MK_SOLO_CNT_SHIFT
-#define MK_SOLO_CNT_SHIFT 3     // k_bin_solo's cell counters 32 bytes apart (GridDesc::cnt_shift); 16 and 128 bytes measured the same
-#endif
 namespace mkamd {
+
+constexpr int SOLO_CNT_SHIFT = 3;   // k_bin_solo's cell counters 32 bytes apart (GridDesc::cnt_shift); 16 and 128 bytes measured the same
 
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
@@ -371,7 +370,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if (direct) {
             g.cell_cap = direct_cap; g.spill_base = (unsigned)(ncells * (size_t)direct_cap); g.spill_cap = spill;
             mrec = std::max<size_t>(mrec, (size_t)slots);
-            g.cnt_shift = (solo && ncells <= (1u << 16)) ? MK_SOLO_CNT_SHIFT : 0;        // small calls: the counters spread out (see GridDesc)
+            g.cnt_shift = (solo && ncells <= (1u << 16)) ? SOLO_CNT_SHIFT : 0;        // small calls: the counters spread out (see GridDesc)
             dbytes = (((size_t)DIRECT_HEAD + (ncells << g.cnt_shift)) * sizeof(unsigned) + 255) & ~(size_t)255;
             if ((st = be.ensure(WS_DIRECT_COUNT, dbytes, &dcnt, set))) return st;
             if (cs.dptr != dcnt) { cs.dptr = dcnt; cs.dclean = 0; }
@@ -517,11 +516,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     void* dlist = nullptr;
     if ((st = be.ensure(WS_DENSE_LIST, (size_t)total_tiles * g.G * sizeof(unsigned), &dlist, set))) return st;
     const int tier = choose_tier(P.lds_tier, be.feedback_host());
-#ifdef MK_NO_LEAN                                       // A-B builds: the plain kernel also beside the pre-pass
-    const int flavour = team ? TILES_TEAM : TILES_PLAIN;
-#else
     int flavour = team ? TILES_TEAM : (be.set_is_pipelined(set) ? TILES_LEAN : TILES_PLAIN);   // lean: leave registers for the next call's pre-pass
-#endif
     // many ligand-sized items (cfg3, cfg5): a workgroup per item sorts its entries once for all its tiles
     if (P.tile_items != 0 && ((P.tile_items > 0 && !team) || (P.tile_items < 0 && P.tile_team <= 0 && per_item && P.total_atoms <= 96LL * (long long)g.B && g.ntiles <= 512)))
         flavour = TILES_ITEMS;

@@ -127,17 +127,11 @@ MK_DEV void xtc_triple(XtcBits& b, int nbits, unsigned r1, unsigned r2, double r
 }
 
 // ---- pass 1: the walk ----
-#ifndef MK_XTC_WIN
-#define MK_XTC_WIN 1024                  // (512: +8 % on a stream without runs, +14 % on 3PTB's -- a refill costs the wave ~3 000 cycles)
-#endif
-#ifndef MK_XTC_SPEC
-#define MK_XTC_SPEC 8
-#endif
-constexpr int XS_WIN = MK_XTC_WIN;       // bytes of a lane's window of its stream
+constexpr int XS_WIN = 1024;             // bytes of a lane's window of its stream (512: +8 % on a stream without runs, +14 % on 3PTB's -- a refill costs the wave ~3 000 cycles)
 constexpr int XS_ROW = XS_WIN + 8;       // its LDS row (the word after the window may be read; its bits are never used)
 constexpr int XS_LW = XS_WIN / 4 / WAVE; // words of a row a lane loads in a refill
 constexpr int XS_BATCH = 32 / XS_LW;     // rows refilled per batch of loads in flight
-constexpr int XS_SPEC = MK_XTC_SPEC;     // groups looked at together (below)
+constexpr int XS_SPEC = 8;               // groups looked at together (below)
 static_assert(XS_WIN % (4 * WAVE) == 0 && XS_BATCH >= 1 && WAVE % XS_BATCH == 0, "window: whole words per lane");
 
 struct XtcGroup { unsigned pos, what; }; // what = first output atom (21 bits) | smallidx of the run << 21 | small atoms << 28
@@ -239,9 +233,6 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
         };
         // (two loops, not one with the step above under a condition: with both in one loop the compiler's exec-mask
         // bookkeeping made the one-by-one walk 80 % slower -- 3PTB 0.23 -> 0.42 ms)
-#ifdef MK_XTC_DIAG_ONE_BY_ONE
-        together = false;
-#endif
         if (!together) {
             while (live && rel + full_bits + 6u <= XS_WIN * 8u) one_group();
         } else {
@@ -278,6 +269,10 @@ MK_KERNEL(64) void k_xtc_scan(const unsigned char* __restrict__ bytes, const Xtc
             }
         }
         pos = (unsigned)wbit + rel;
+        // a lane that is done -- or dead: a corrupt frame's last step may have put `rel` up to a group's length past the end of
+        // its stream -- keeps taking part in the refills (the wave refills all 64 rows while any lane is live): from the start
+        // of the byte buffer, so that nothing is read beyond the MKAMD_XTC_PAD bytes the header asks for behind the last record
+        if (!live) { pos = 0u; d.data_off = 0ull; }
         const unsigned long long voters = mk_ballot(live), ayes = mk_ballot(live && n_clear >= 3 * n_set);
         together = voters != 0ull && 2 * mk_popc64(ayes) >= mk_popc64(voters);
     }

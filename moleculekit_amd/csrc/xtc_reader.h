@@ -342,7 +342,7 @@ inline int info(const char* path, int64_t& natoms, int64_t& nframes, std::string
 
 // The caller's coordinate array is usually FRESH memory (np.zeros / np.empty: pages nobody has touched).  The decode
 // threads write it a cache line per row at a time -- every thread into every part of the array -- and their first-touch
-// page faults then fight over the same page tables: measured on the 256-core host of an MI355X box (tools/xtc_scaling),
+// page faults then fight over the same page tables: measured on the 256-core host of an MI355X box (round-3 thread-scaling probe, docs/EXPERIMENTS_r3.md),
 // 2 400 frames x 4 507 atoms, 16 threads: 11.9 k frames/s into untouched pages (ONE thread: 18 k) against 241 k once the
 // pages exist.  So before the decode every thread touches a CONTIGUOUS slice of the array, one byte per page (zeros:
 // each element is overwritten by the decode anyway), after asking for transparent huge pages on the 2 MiB-aligned part.

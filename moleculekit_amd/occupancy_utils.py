@@ -1,5 +1,6 @@
 """``calculate_occupancy`` with the exact call contract of the reference's Cython kernel
-(moleculekit/occupancy_utils/occupancy_utils.pyx:34-61), executed on the MI355X.
+(moleculekit/occupancy_utils/occupancy_utils.pyx:34-61), executed on the MI355X; ``calculate_occupancy_cpu``: the same
+contract on the host (the library's own double-precision implementation, explicit only).
 
     calculate_occupancy(centers f64 [V,3], coords f32 [N,3], sigmas f64 [N,C], results f64 [V,C])
 
@@ -22,7 +23,7 @@ def _require(name, a, dtype, ndim=2):
         raise ValueError(f"Buffer has wrong number of dimensions for {name} (expected {ndim}, got {a.ndim})")
 
 
-def calculate_occupancy(centers, coords, sigmas, results, ctx=None):
+def _checked(centers, coords, sigmas, results):
     _require("centers", centers, np.float64)
     _require("coords", coords, np.float32)
     _require("sigmas", sigmas, np.float64)
@@ -30,14 +31,30 @@ def calculate_occupancy(centers, coords, sigmas, results, ctx=None):
     V, N, C = centers.shape[0], coords.shape[0], sigmas.shape[1]
     if centers.shape[1] != 3 or coords.shape[1] != 3 or sigmas.shape[0] != N or results.shape != (V, C):
         raise ValueError("shape mismatch: centers [V,3], coords [N,3], sigmas [N,C], results [V,C]")
+    return np.ascontiguousarray(centers), np.ascontiguousarray(coords), np.ascontiguousarray(sigmas)
+
+
+def calculate_occupancy(centers, coords, sigmas, results, ctx=None):
+    cen, xyz, sig = _checked(centers, coords, sigmas, results)
     ctx = ctx or _lib.default_context()
-    cen = np.ascontiguousarray(centers)
-    xyz = np.ascontiguousarray(coords)
-    sig = np.ascontiguousarray(sigmas)
     if results.flags["C_CONTIGUOUS"]:
         ctx.calculate_occupancy(cen, xyz, sig, results)
     else:  # strided memoryviews are legal in the reference
         tmp = np.ascontiguousarray(results)
         ctx.calculate_occupancy(cen, xyz, sig, tmp)
+        results[...] = tmp
+    return None
+
+
+def calculate_occupancy_cpu(centers, coords, sigmas, results, n_threads=0):
+    """The same contract on the HOST (include/mkamd_voxel.h, mkamd_calculate_occupancy_cpu): the library's own
+    double-precision implementation -- a cell list over the atoms, the reference's arithmetic per pair, bit-identical
+    results -- for hosts without a GPU.  Explicit only: ``calculate_occupancy`` never falls back to it."""
+    cen, xyz, sig = _checked(centers, coords, sigmas, results)
+    V, N, C = cen.shape[0], xyz.shape[0], sig.shape[1]
+    L = _lib.load()
+    tmp = results if results.flags["C_CONTIGUOUS"] else np.ascontiguousarray(results)
+    _lib._check(L.mkamd_calculate_occupancy_cpu_threads(_lib._ptr(cen), V, _lib._ptr(xyz), N, _lib._ptr(sig), C, _lib._ptr(tmp), int(n_threads)))
+    if tmp is not results:
         results[...] = tmp
     return None

@@ -5,7 +5,8 @@ Same function names, arguments, error behaviour and returned ndarray layout as t
 ``rotateCoordinates`` (:78-114), ``_getGridCenters`` (:125-132), ``_getChannelRadii`` (:117-121),
 ``_getOccupancyC`` (:515-533).  The occupancy computation itself runs in hand-written HIP kernels
 behind ``libmkamd.so`` (``method="C"`` -- the reference's only accepted value -- and ``method="HIP"``
-both select them; there is no CPU implementation in this package).
+both select them and fail loudly without a GPU; ``method="CPU"`` explicitly selects the library's host implementation,
+``mkamd_calculate_occupancy_cpu``: double precision, bit-identical to the reference, for hosts without a device).
 
 Return order is the reference's: ``(features, centers)`` with ``usercenters`` else
 ``(features, centers, nvoxels)``; features float64 ``[V, C]`` (float32-accurate values, <= 1e-5
@@ -176,9 +177,15 @@ def getVoxelDescriptors(mol, boxsize=None, voxelsize=1, buffer=0, center=None, u
                 "Make sure your coordinates are either 3D with a last dim of 1 or 2D.")
         coords = coords[:, :, 0]
 
-    if method.upper() not in ("C", "HIP"):
+    if method.upper() not in ("C", "HIP", "CPU"):
         raise RuntimeError("As of moleculekit 0.9.2 we only support C implementation of voxelization")
-    if lattice is not None:
+    if method.upper() == "CPU":
+        # the library's host implementation (explicit only: "C" and "HIP" never fall back to it) -- the reference's own
+        # _getOccupancyC steps (:515-533) around mkamd_calculate_occupancy_cpu
+        if lattice is not None:
+            centers = _centersFromSpec(bb_min, nvoxels, voxelsize)
+        features = _getOccupancyCPU(coords, centers, channels)
+    elif lattice is not None:
         # the grid is ours: the kernels are enqueued first, the centres (a copy of the cached array: 330 KB for a 24^3
         # grid) are made while the device computes, then the features are taken out
         finish = _occupancyLatticeBegin(coords, channels, lattice)
@@ -269,6 +276,21 @@ def _occupancyLatticeBegin(coords, channelsigmas, lattice):
     end = _batch.voxelize_lattice_begin(coords, offs, channelsigmas, np.asarray(bb_min, np.float64)[None, :], nvoxels, voxelsize,
                                         dtype=np.float64)
     return lambda: end()[0]
+
+
+def _getOccupancyCPU(coords, centers, channelsigmas):
+    """``_getOccupancyC`` (voxeldescriptors.py:515-533) on the host: float64 [V, C], bit-identical to the reference."""
+    from .occupancy_utils import calculate_occupancy_cpu
+    coords = np.ascontiguousarray(coords, dtype=np.float32)
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    channelsigmas = np.ascontiguousarray(channelsigmas, dtype=np.float64)
+    if coords.ndim != 2 or coords.shape[1] != 3 or centers.ndim != 2 or centers.shape[1] != 3:
+        raise ValueError("coords and centers must be (n, 3) arrays")
+    if channelsigmas.ndim != 2 or channelsigmas.shape[0] != coords.shape[0]:
+        raise ValueError("channel sigmas must be (natoms, nchannels)")
+    occupancies = np.zeros((centers.shape[0], channelsigmas.shape[1]), dtype=np.float64)
+    calculate_occupancy_cpu(centers, coords, channelsigmas, occupancies)
+    return occupancies
 
 
 _LAST_LATTICE = {}          # number of centres -> (nvoxels, voxelsize) of the last lattice recognised in an array of that length

@@ -1,6 +1,6 @@
 """CPU tier: the C-ABI shared library builds for gfx950, loads without a GPU, and exports every
-symbol include/mkamd_voxel.h declares.  No compute is called here; without a device the library
-must refuse loudly (there is no CPU fallback)."""
+symbol include/mkamd_voxel.h declares.  No GPU compute is called here; without a device the library
+must refuse loudly (there is no CPU fallback: the host entry point is reached by name only)."""
 import ctypes
 import os
 import re
@@ -57,9 +57,14 @@ def test_no_silent_cpu_fallback(lib_path):
         _lib.Context(0)
     import numpy as np
     from moleculekit_amd.voxeldescriptors import getVoxelDescriptors
-    with pytest.raises(RuntimeError):
-        getVoxelDescriptors(None, boxsize=[4, 4, 4], center=[0, 0, 0], usercoords=np.zeros((1, 3), np.float32),
-                            userchannels=np.ones((1, 8)))
+    for method in ("C", "HIP"):
+        with pytest.raises(RuntimeError):
+            getVoxelDescriptors(None, boxsize=[4, 4, 4], center=[0, 0, 0], usercoords=np.zeros((1, 3), np.float32),
+                                userchannels=np.ones((1, 8)), method=method)
+    # the host implementation exists but only by name: nothing above fell back to it
+    feats, _, _ = getVoxelDescriptors(None, boxsize=[4, 4, 4], center=[0, 0, 0], usercoords=np.zeros((1, 3), np.float32),
+                                      userchannels=np.ones((1, 8)), method="CPU")
+    assert feats.shape == (64, 8) and feats.max() > 0
 
 
 def test_product_never_imports_the_oracle():

@@ -2,7 +2,7 @@
 """tools/bench_reduction.py -- dist_trajectory_reduction ("closest" atom between residues, the MetricDistance contact-map
 projection: distance_utils.pyx:211-281) on a synthetic protein-like trajectory: 200 groups of 15 atoms, 512 frames, all
 19 900 group pairs, periodic.  Host arrays in / out (copies included in the wall clock); run it under
-`rocprofv3 --kernel-trace` (tools/gpu_kstats_reduction.sh) for the kernel's own duration.  MKAMD_LIB selects the build."""
+`rocprofv3 --kernel-trace`  for the kernel's own duration.  MKAMD_LIB selects the build."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

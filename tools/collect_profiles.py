@@ -1,65 +1,112 @@
-"""Copy the judged summaries of a GPU session from gpurun_out/ (scratch) into profiles/ (tracked).
+"""Copy the judged summaries of tools/gpu_r4_evidence.sh from gpurun_out/ (scratch) into profiles/r4_* (tracked) and stamp every
+PMC summary with the source hash of the library it was taken on (moleculekit_amd._build.built_hash(): bench.py refuses
+counters of another build).  Runs on the GPU box at the end of the evidence session, and again here (idempotent)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
 
-usage: python tools/collect_profiles.py [round_tag]      (default r1)
-  bench_*.log                 -> profiles/<tag>_bench_<name>.json   (the JSON line only)
-  prof_cfg2*/.../kernel_stats -> profiles/<tag>_cfg2[_nopipe]_rocprofv3_kernel_stats.csv
-  timeline_prof_*.txt         -> profiles/<tag>_cfg2[_nopipe]_timeline.txt
-  pmc_*/counter_collection    -> profiles/<tag>_cfg2_pmc_counters.json (per kernel, mean per launch)
-  ubench_mem.txt, bench_distance.log
-"""
-import collections, csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.getcwd())
+import bench  # noqa: E402
+from moleculekit_amd import _build  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = "r4"
+SRC = _build.built_hash()
 os.makedirs("profiles", exist_ok=True)
-for f in sorted(glob.glob("gpurun_out/bench_*.log")):
-    name = os.path.basename(f)[len("bench_"):-len(".log")]
-    for line in open(f):
-        if line.startswith("{"):
-            json.dump(json.loads(line), open(f"profiles/{tag}_bench_{name}.json", "w"), indent=1)
-            break
-for d, suffix in (("prof_cfg2", ""), ("prof_cfg2_nopipe", "_nopipe")):
-    stats = sorted(glob.glob(f"gpurun_out/{d}/*/*_kernel_stats.csv"), key=os.path.getmtime)    # gpurun merges: keep the newest
+PROF = "--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
+for name in ("cfg2", "cfg2_nopipe", "torchrun1"):
+    f = f"gpurun_out/bench_{name}.log"
+    if os.path.exists(f):
+        for line in open(f):
+            if line.startswith("{"):
+                d = json.loads(line)
+                d["_library_src"] = SRC
+                json.dump(d, open(f"profiles/{tag}_bench_{name}.json", "w"), indent=1)
+                break
+for d in ("cfg2", "cfg2_nopipe", "cfg1", "cfg3", "cfg4", "cfg5", "dist"):
+    stats = sorted(glob.glob(f"gpurun_out/prof_{d}/*/*_kernel_stats.csv"), key=os.path.getmtime)
     if stats:
-        shutil.copy(stats[-1], f"profiles/{tag}_cfg2{suffix}_rocprofv3_kernel_stats.csv")
-    t = f"gpurun_out/timeline_{d}.txt"
-    if os.path.exists(t):
-        shutil.copy(t, f"profiles/{tag}_cfg2{suffix}_timeline.txt")
-for wl in ("cfg1", "cfg3", "cfg4", "cfg5"):                 # rocprofv3 --kernel-trace --stats of the other workloads, when taken
-    stats = sorted(glob.glob(f"gpurun_out/prof_{wl}/*/*_kernel_stats.csv"), key=os.path.getmtime)
-    if stats:
-        shutil.copy(stats[-1], f"profiles/{tag}_{wl}_rocprofv3_kernel_stats.csv")
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in sorted(glob.glob("gpurun_out/pmc_*/")):
-    # gpurun merges every call's output into the same directories: keep the newest pass only
-    fs = sorted(glob.glob(d + "*/*counter_collection.csv"), key=os.path.getmtime)
-    if not fs:
-        continue
-    for r in csv.DictReader(open(fs[-1])):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
-        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-if acc:
-    sys.path.insert(0, os.getcwd())
-    import bench
-    out = {"_items_per_launch": bench.DEFAULT_BATCH["cfg2"],
-           "_note": "mean per launch over the launches of `python bench.py --steps 4 --warmup 1 --no-pipeline` "
-                    "(one rocprofv3 --pmc pass per counter group, tools/gpu_pmc.sh); FETCH_SIZE / WRITE_SIZE in KiB "
-                    "(FETCH_SIZE counts 64 B per 128-B request on gfx950: double it, MI355X_MICROARCH.md HBM section)"}
+        shutil.copy(stats[-1], f"profiles/{tag}_{d}_rocprofv3_kernel_stats.csv")
+
+
+def collect(passes, out_name, items, cmd, note_extra=""):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in passes:
+        fs = sorted(glob.glob(f"gpurun_out/pmc_{d}/*/*counter_collection.csv"), key=os.path.getmtime)
+        if not fs:
+            continue
+        for r in csv.DictReader(open(fs[-1])):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not acc:
+        return None
+    out = {"_library_src": SRC, "_items_per_launch": items, "_full_batch_launches_only": True,
+           "_command": f"rocprofv3 --kernel-trace --pmc <counters of one pass> -- python bench.py {cmd}".strip(),
+           "_note": "mean per launch; one rocprofv3 --pmc pass per counter group (tools/gpu_r4_evidence.sh), FETCH_SIZE and WRITE_SIZE in "
+                    "passes of their own; KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950: double it (MI355X_MICROARCH.md, HBM). "
+                    "--no-single: no single-grid probe launches, every launch of a kernel is one full step. GRBM_GUI_ACTIVE: shader "
+                    "cycles of the launch summed over the 8 XCDs (the effective clock = it / 8 / the kernel's duration)." + note_extra}
     for k in sorted(acc):
         out[k] = {c: round(sum(v) / len(v), 2) for c, v in sorted(acc[k].items())}
         out[k]["_launches"] = max(len(v) for v in acc[k].values())
-    json.dump(out, open(f"profiles/{tag}_cfg2_pmc_counters.json", "w"), indent=1)
-for src, dst in (("ubench_mem.txt", f"{tag}_ubench_mem.txt"),):
-    if os.path.exists("gpurun_out/" + src):
-        shutil.copy("gpurun_out/" + src, "profiles/" + dst)
-for src, dst in (("bench_xtc.txt", f"{tag}_bench_xtc.txt"), ("host_paths.txt", f"{tag}_host_paths.txt"), ("pmc_dist.txt", f"{tag}_dist_pairs_pmc.txt"),
-                 ("kstats_reduction.txt", f"{tag}_dist_reduction_kernel_stats.txt"), ("diag_breakdown.txt", f"{tag}_cfg2_valu_breakdown.txt"),
-                 ("latency_probe.txt", f"{tag}_latency_probe.txt"), ("phase_timers.txt", f"{tag}_phase_timers.txt"),
-                 ("dropin_profile.txt", f"{tag}_dropin_host_profile.txt"), ("pmc_bin.txt", f"{tag}_prepass_instruction_counts.txt")):
-    if os.path.exists("gpurun_out/" + src):
-        shutil.copy("gpurun_out/" + src, "profiles/" + dst)
-for wl in ("cfg1", "cfg3", "cfg4", "cfg5", "dist"):
-    if os.path.exists(f"gpurun_out/{wl}_pmc_counters.json"):
-        shutil.copy(f"gpurun_out/{wl}_pmc_counters.json", f"profiles/{tag}_{wl}_pmc_counters.json")
-if os.path.exists("gpurun_out/single_timeline_cfg2.txt") and os.path.exists("gpurun_out/single_timeline_3ptb.txt"):
-    open(f"profiles/{tag}_single_call_timeline.txt", "w").write(open("gpurun_out/single_timeline_cfg2.txt").read() + open("gpurun_out/single_timeline_3ptb.txt").read())
-print("\n".join(sorted(os.listdir("profiles"))))
+    json.dump(out, open(f"profiles/{out_name}", "w"), indent=1)
+    return out
+
+
+def report(out_name, out, alg_mb):
+    hot = [k for k in out if isinstance(out[k], dict) and ("k_voxelize_tiles" in k or "k_voxelize_items" in k or "k_dist_pairs" in k or "k_dist_rows" in k)]
+    n = max((out[k]["_launches"] for k in hot), default=0)
+    for k in hot:
+        v = out[k]
+        if "SQ_INSTS_VALU" in v and v.get("SQ_WAVES"):
+            clk = v["GRBM_GUI_ACTIVE"] / 8.0 if v.get("GRBM_GUI_ACTIVE") else v.get("SQ_BUSY_CYCLES", 0) / 32.0     # (summed over 8 XCDs / 32 SEs)
+            busy = v["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / clk if clk else float("nan")
+            print(f"{out_name}: {k[:52]:52s} VALU/wave {v['SQ_INSTS_VALU'] / v['SQ_WAVES']:8.1f}  SALU/wave {v.get('SQ_INSTS_SALU', 0) / v['SQ_WAVES']:7.1f}  "
+                  f"LDS/wave {v.get('SQ_INSTS_LDS', 0) / v['SQ_WAVES']:6.1f}  VALU-busy {busy:.3f}  launches {v['_launches']}")
+    step = 0.0
+    for k, v in out.items():
+        if isinstance(v, dict) and k.startswith("mkamd::") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and n:
+            b = (v["WRITE_SIZE"] + 2 * v["FETCH_SIZE"]) * 1024 * v["_launches"] / n
+            step += b
+            print(f"   {k[:52]:52s} {b / 1e6:9.1f} MB per step  (read {2 * v['FETCH_SIZE'] * 1024 * v['_launches'] / n / 1e6:8.1f}, written {v['WRITE_SIZE'] * 1024 * v['_launches'] / n / 1e6:8.1f})")
+    if step:
+        print(f"   step total {step / 1e6:.1f} MB (algorithmic {alg_mb:.1f} MB)")
+
+
+ALG = {"cfg2": 2710.7, "cfg1": 2107.3, "cfg3": 14582.0, "cfg4": 1243.9, "cfg5": 29092.0, "dist": 836.4}
+for wl in ("cfg2", "cfg1", "cfg3", "cfg4", "cfg5"):
+    passes = [f"{wl}_sq1", f"{wl}_fetch", f"{wl}_write"] + ([f"{wl}_sq2", f"{wl}_icache"] if wl == "cfg2" else [])
+    o = collect(passes, f"{tag}_{wl}_pmc_counters.json", bench.DEFAULT_BATCH[wl], f"{PROF} --workload {wl}")
+    if o:
+        report(f"{tag}_{wl}", o, ALG[wl])
+o = collect(("cfg2_nopipe_sq1", "cfg2_nopipe_fetch", "cfg2_nopipe_write"), f"{tag}_cfg2_nopipe_pmc_counters.json", bench.DEFAULT_BATCH["cfg2"], f"{PROF} --no-pipeline")
+if o:
+    report(f"{tag}_cfg2_nopipe", o, ALG["cfg2"])
+for mode in ("periodic", "nonperiodic"):
+    o = collect([f"dist_{mode}_{p}" for p in ("sq1", "sq2", "fetch", "write")],
+                f"{tag}_dist_pmc_counters.json" if mode == "periodic" else f"{tag}_dist_nonperiodic_pmc_counters.json",
+                bench.DEFAULT_BATCH["dist"], f"--workload dist --no-cpu-baseline --steps 8 --warmup 2 (MKAMD_DIST_ONLY={mode})")
+    if o:
+        report(f"{tag}_dist_{mode}", o, ALG["dist"])
+stats = sorted(glob.glob("gpurun_out/prof_xtc/*/*_kernel_stats.csv"), key=os.path.getmtime)
+if stats:
+    shutil.copy(stats[-1], f"profiles/{tag}_xtc_probe_rocprofv3_kernel_stats.csv")
+if os.path.exists("gpurun_out/xtc_pmc/summary.txt"):
+    with open("gpurun_out/xtc_pmc/summary.txt") as fh:
+        body = fh.read()
+    open(f"profiles/{tag}_xtc_decode_pmc.txt", "w").write(
+        f"# library src {SRC}; tools/gpu_r4_xtc_pmc.sh: rocprofv3 --pmc passes of tools/xtc_gpu_probe.py, one probe file per pass (syn = 30 000 atoms,\n"
+        "# every atom a group, no flag set; real = 3PTB head, 4 507 atoms, reference writer), mean per launch of the kernel at the grid size given\n"
+        "# (k_xtc_scan: 64 lanes = 64 frames per workgroup, so grid / 64 waves; SQ_WAVE_CYCLES and SQ_ACTIVE_* in quad-cycles)\n" + body)
+for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"),
+                 ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_probe.txt", "dist_probe_rows.txt"), ("random_sweeps.txt", "random_sweeps_final.txt"), ("xtc_overlap_probe.txt", "xtc_overlap_probe.txt"),
+                 ("r4_tile_ab.txt", "tile_ab_last.txt")):
+    f = f"gpurun_out/{src}"
+    if os.path.exists(f):
+        with open(f) as fh:
+            text = "".join(l for l in fh if "amdgpu.ids" not in l)
+        open(f"profiles/{tag}_{dst}", "w").write(text)
+print("\n".join(sorted(f for f in os.listdir("profiles") if f.startswith(tag))))

@@ -13,7 +13,7 @@
 //      enumeration, the cull and the sort are free here), ds_min_u32 of the bit pattern of d^2 * w per in-range pair,
 //      the tile kernel's epilogue and stores.  Useful pairs / s / CU against the 6.6 G of the round-2 kernel.
 //
-// Prints a report; tools/gpu_r3_study.sh copies it to profiles/r3_formulation_study.txt.
+// Prints a report; round 3 copied it to profiles/r3_formulation_study.txt.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
