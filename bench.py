@@ -204,25 +204,55 @@ def cpu_baseline(name):
     for _ in range(reps):
         oracle.calculate_occupancy(centers, p["coords"][s:e], p["sigmas"][s:e], box=box)
     dt = time.perf_counter() - t0
+    listed, granted = os.cpu_count() or 1, host_cores_granted()
     out = {"value": round(reps * centers.shape[0] * 8 / dt / 1e6, 4), "unit": "Mvoxel-channels/s",
            "cores": 1, "kind": "port", "sample": sample, "seconds": round(dt, 2),
-           "host_cores_available": os.cpu_count()}
-    # the reference is serial (no nogil, OpenMP commented out: setup.py:48); for scale, the same sample split over all
-    # host cores (the C oracle releases the GIL under ctypes): an embarrassingly parallel bound on what a CPU could do
-    ncores = os.cpu_count() or 1
+           "cpu_model": host_cpu_model(), "cores_listed": listed, "cores_granted": granted,
+           "host_cores_available": listed}
+    # the reference is serial (no nogil, OpenMP commented out: setup.py:48); for scale, the same sample split over EVERY core
+    # the box grants this process (its affinity mask; the C oracle releases the GIL under ctypes): an embarrassingly
+    # parallel bound on what this host's CPU could do.  (Fewer threads are timed too: a box may grant logical cores that
+    # share physical ones, and the best figure is the one reported -- with the thread count that gave it.)
     if box is None:
-        best = None
-        for nt in sorted({min(ncores, 16), min(ncores, 64), ncores}):      # the box may grant fewer cores than it lists
+        runs = {}
+        for nt in sorted({granted, max(1, granted // 2), min(granted, 16)}):
             t0 = time.perf_counter()
             par = oracle.calculate_occupancy_threads(centers, p["coords"][s:e], p["sigmas"][s:e], nt)
-            dta = time.perf_counter() - t0
+            runs[nt] = time.perf_counter() - t0
             assert np.isfinite(par).all()
-            if best is None or dta < best[0]:
-                best = (dta, nt)
-        v = centers.shape[0] * 8 / best[0] / 1e6
-        out["all_cores"] = {"value": round(v, 2), "threads": best[1], "cores_listed": ncores,
+        nt_best = min(runs, key=runs.get)
+        v = centers.shape[0] * 8 / runs[nt_best] / 1e6
+        out["all_cores"] = {"value": round(v, 2), "threads": nt_best, "cores_listed": listed, "cores_granted": granted,
+                            "value_at_all_granted_cores": round(centers.shape[0] * 8 / runs[granted] / 1e6, 2),
+                            "seconds_by_threads": {str(k): round(t, 3) for k, t in sorted(runs.items())},
                             "speedup_over_serial": round(v / out["value"], 1)}
     return out
+
+
+def host_cores_granted():
+    """Cores this process may run on (its affinity mask / cgroup), as opposed to the cores /proc lists."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:                                                      # a cgroup v2 CPU quota, when there is one, bounds it further
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def host_cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
 
 
 def dist_traffic(F):
@@ -293,24 +323,33 @@ def bench_distances(args, emit=True):
     ndist = F * n1 * n2
     alg = ndist * 4 + (n1 + n2) * 3 * F * 4 + 3 * F * 4
     only = os.environ.get("MKAMD_DIST_ONLY", "")           # profiling passes: "periodic" / "nonperiodic" = that leg alone (one kernel variant per pass)
-    np_elapsed, np_ms = timed(False) if only != "periodic" else (1.0, 1.0)
-    nonperiodic = {"value": round(ndist * args.steps / np_elapsed / 1e6, 1), "unit": "Mdist/s", "ms_per_step": round(np_elapsed / args.steps * 1e3, 4),
-                   "roofline": {"bound": "hbm", "achieved": round(alg / np_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": "mkamd::k_dist_rows<false, 4, true>", "timed_region": "the whole call: k_sel_to_frames + k_dist_rows", "kernel_avg_ms": round(np_ms, 5)}}
+    nonperiodic = None                                      # (a profiling pass of the periodic leg alone: no numbers are made up for the other)
+    if only != "periodic":
+        np_elapsed, np_ms = timed(False)
+        nonperiodic = {"value": round(ndist * args.steps / np_elapsed / 1e6, 1), "unit": "Mdist/s", "ms_per_step": round(np_elapsed / args.steps * 1e3, 4),
+                       "roofline": {"bound": "hbm", "achieved": round(alg / np_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": ctx.last_dist_kernel(), "timed_region": "the whole call: " + ctx.last_dist_kernel(), "kernel_avg_ms": round(np_ms, 5)}}
     if not args.no_cpu_baseline and only != "periodic":
         from oracle import oracle
         Fs = min(16, F)
         ref = oracle.dist_trajectory(coords[:, :, :Fs].contiguous().cpu().numpy(), box[:, :Fs].contiguous().cpu().numpy(), s1, s2, chains_h, False, False)
         if not np.array_equal(out[:Fs].cpu().numpy(), ref):
             raise SystemExit("dist_trajectory (pbc = False) on the GPU is not bit-exact with the oracle")
-    elapsed, k_ms = timed(True) if only != "nonperiodic" else (np_elapsed, np_ms)
+    if only == "nonperiodic":                               # profiling pass of the non-periodic leg alone: that leg is the line
+        line = {"metric": "Mdist/s (dist_trajectory, pbc = False; MKAMD_DIST_ONLY=nonperiodic)", **nonperiodic, "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"}, "periodic": None}
+        if emit:
+            print(json.dumps(line), flush=True)
+        return line
+    elapsed, k_ms = timed(True)
     line = {"metric": "Mdist/s (dist_trajectory, periodic by chain)", "value": round(ndist * args.steps / elapsed / 1e6, 1),
             "unit": "Mdist/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"},
             "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F)[0], "traffic_source": dist_traffic(F)[1], "kernel": "mkamd::k_dist_rows<true, 4, true>", "timed_region": "the whole call: k_sel_to_frames + k_dist_rows (HIP events around the steps)",
+                         "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F)[0], "traffic_source": dist_traffic(F)[1], "kernel": ctx.last_dist_kernel(), "timed_region": "the whole call: " + ctx.last_dist_kernel() + " (HIP events around the steps)",
                          "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg},
             "nonperiodic": nonperiodic}
     if not args.no_cpu_baseline:
@@ -618,9 +657,13 @@ def dry_run(args):
                   and bool((res[k] == res[k][:, :1, :1]).all()) for k in ("full_plain", "full_overlapped")))
     flags = [None] * world
     dist.all_gather_object(flags, bool(ok))
+    # the device every rank WOULD drive (main(): torch.cuda.set_device(LOCAL_RANK), one process per GPU): what the launcher set
+    places = [None] * world
+    dist.all_gather_object(places, [rank, int(os.environ.get("LOCAL_RANK", "-1"))])
     if rank == 0:
         print(json.dumps({"metric": "dry-run (gloo, stand-in compute)", "dry_run": True, "timed_path": "run_workload", "n_gpus": world,
-                          "ranks_joined": world, "items_per_rank": B, "ok": all(flags), "ms_per_step": round(res["elapsed"] / 2 * 1e3, 3),
+                          "ranks_joined": world, "ranks_alive": ranks_done(world), "scaling": "weak", "rank_to_local_device": places,
+                          "items_per_rank": B, "ok": all(flags), "ms_per_step": round(res["elapsed"] / 2 * 1e3, 3),
                           "gather_ms": res.get("gather_ms"), "gather_error": res.get("gather_error"),
                           "seconds": round(time.perf_counter() - t0, 3)}), flush=True)
     dist.destroy_process_group()

@@ -66,6 +66,11 @@ int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t n_ato
                               const uint32_t* digitized_chains2, int selfdist, int pairs, int pbc,
                               const float* masses, int reduction1, int reduction2, float* results);
 
+/* Names of the kernels the last dist_trajectory call on this context launched, as a profiler prints them (e.g.
+ * "mkamd::k_sel_to_frames + mkamd::k_dist_rows<true, 4, true>"; empty before the first call): what bench.py reports as
+ * the distance leg's `roofline.kernel` -- the choice depends on the shape of the call. */
+int mkamd_ctx_last_dist_kernel(mkamd_ctx* ctx, char* name, size_t name_cap);
+
 /* cdist(coords1 [n1,D], coords2 [n2,D]) -> results [n1,n2];  pdist(coords [n,D]) -> results [n(n-1)/2] */
 int mkamd_cdist_host(mkamd_ctx* ctx, const float* coords1, int64_t n1, const float* coords2, int64_t n2,
                      int32_t dim, float* results);

@@ -85,6 +85,7 @@ SIGNATURES = {
                                                 ctypes.c_float, _vp, ctypes.POINTER(_vp)]),
     "mkamd_dist_reduction_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _vp,
                                            _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp]),
+    "mkamd_ctx_last_dist_kernel": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_cdist_host": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _c_i32, _vp]),
     "mkamd_pdist_host": (_c_int, [_vp, _vp, _c_i64, _c_i32, _vp]),
 }
@@ -274,6 +275,12 @@ class Context:
         """Name of the tile kernel the last lattice call launched, as rocprofv3 prints it ('' before the first call)."""
         buf = ctypes.create_string_buffer(128)
         _check(load().mkamd_ctx_last_tile_kernel(self._h, buf, 128))
+        return buf.value.decode()
+
+    def last_dist_kernel(self) -> str:
+        """Kernels the last dist_trajectory call launched, as rocprofv3 prints them ('' before the first call)."""
+        buf = ctypes.create_string_buffer(128)
+        _check(load().mkamd_ctx_last_dist_kernel(self._h, buf, 128))
         return buf.value.decode()
 
     def pipelined_calls(self) -> int:

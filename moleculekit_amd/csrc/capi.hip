@@ -107,6 +107,8 @@ struct mkamd_ctx {
     unsigned* feedback_dev() const { return fb_dev; }
     void note_error_flag_mirrored(bool yes) { err_mirrored = yes; }
     void note_tail_reports(bool yes) { tail_reports = yes; }
+    char last_dist_kernel[96] = "";        // what the last dist_trajectory call launched (mkamd_ctx_last_dist_kernel)
+    void note_dist_kernel(const char* name) { snprintf(last_dist_kernel, sizeof last_dist_kernel, "%s", name); }
     bool tail_reports = false;             // the last lattice call's k_tail writes FB_TILES_DONE / FB_TAIL_WROTE with seq_next
     unsigned seq_next = 0, seq_counter = 0; // sequence number handed to the next lattice call (0 = none)
     int ensure(int slot, size_t bytes, void** ptr, int set = 0)
@@ -553,6 +555,13 @@ try {
     if (ctx->last_flavour < 0 || ctx->last_flavour > 3) snprintf(name, name_cap, "%s", "");
     else if (ctx->last_flavour == 3) snprintf(name, name_cap, "mkamd::%s<%d>", base[3], ctx->last_K);
     else snprintf(name, name_cap, "mkamd::%s<%d, %d>", base[ctx->last_flavour], ctx->last_K, ctx->last_ecap);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_last_dist_kernel(mkamd_ctx* ctx, char* name, size_t name_cap)
+try {
+    if (!ctx || !name || name_cap == 0) return fail(MKAMD_EINVAL, "ctx / name is NULL");
+    snprintf(name, name_cap, "%s", ctx->last_dist_kernel);
     return MKAMD_OK;
 } MK_API_CATCH
 

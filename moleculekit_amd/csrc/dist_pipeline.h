@@ -70,6 +70,11 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
             };
             static const bool no_vec = [] { const char* e = std::getenv("MKAMD_ROWS_NO_VEC"); return e && e[0] == '1'; }();  // A-B knob
             const bool vec = jpl == 4 && n2 % 4 == 0 && ((uintptr_t)out & 15u) == 0 && !no_vec;      // rows start on 16 bytes
+            {
+                char nm[96];
+                snprintf(nm, sizeof nm, "mkamd::k_sel_to_frames + mkamd::k_dist_rows<%s, %d, %s>", pbc ? "true" : "false", jpl, vec ? "true" : "false");
+                be.note_dist_kernel(nm);
+            }
             if (pbc) return vec ? go(k_dist_rows<true, 4, true>) : jpl == 4 ? go(k_dist_rows<true, 4, false>) : jpl == 2 ? go(k_dist_rows<true, 2, false>)
                                                                                                                           : go(k_dist_rows<true, 1, false>);
             return vec ? go(k_dist_rows<false, 4, true>) : jpl == 4 ? go(k_dist_rows<false, 4, false>) : jpl == 2 ? go(k_dist_rows<false, 2, false>)
@@ -78,6 +83,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     }
     if (!selfdist && !no_rect) {
         const long long tiles = ceil_div(n2, DT) * ceil_div(n1, DR_I) * ceil_div(F, DT);
+        if (tiles <= 0x7ffffff0LL) be.note_dist_kernel(pbc ? "mkamd::k_dist_rect<true>" : "mkamd::k_dist_rect<false>");
         if (tiles <= 0x7ffffff0LL)
             return pbc ? be.launch(k_dist_rect<true>, dim3(padded8(tiles)), dim3(DR_WAVES * WAVE), coords, F, box, sel1, n1, sel2, n2, chains, squared, out)
                        : be.launch(k_dist_rect<false>, dim3(padded8(tiles)), dim3(DR_WAVES * WAVE), coords, F, box, sel1, n1, sel2, n2, chains, squared, out);
@@ -89,6 +95,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
                         chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
     if (ceil_div(P, DT) * ceil_div(F, DT) > 0x7ffffff0LL) { err = "too many tiles (pairs x frames / 4096 >= 2^31)"; return ST_EINVAL; }
+    be.note_dist_kernel("mkamd::k_build_atom_pairs + mkamd::k_dist_pairs");
     return be.launch(k_dist_pairs, dim3(padded8(ceil_div(P, DT) * ceil_div(F, DT))), dim3(DT_THREADS), coords, F, box,
                      (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
 }

@@ -2143,8 +2143,12 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 }
             } else if (g.C == CHG) {
                 float4* o = reinterpret_cast<float4*>(out + vox * CHG);
-                // (the same turned through LDS so that every instruction writes whole lines, as in voxelize_item_tile, was
-                //  measured here too: +1 % on cfg2, nothing on the 3PTB batch and cfg4 -- this kernel is not store-bound)
+                // Two non-temporal 16-byte pieces per lane at a 32-byte stride.  ALONE this pattern writes 2.4 TB/s (a store-only
+                // kernel of this launch shape: 0.91 ms per 2.15 GB; plain stores 6.4 TB/s, the plane turned through LDS into
+                // whole 256-byte rows 5.8 -- tools/store_pattern.hip, profiles/r5_store_pattern.txt), but the kernel needs
+                // 1.0 TB/s, spread over its whole length: same-session A/B (round 5) plain stores +0.6 % on cfg2, +1.7 % on cfg1,
+                // +1.4 % on cfg4, turned +1.3 / +1.6 / +0.4 % -- not store-bound, and the non-temporal form keeps the L2 for the
+                // records its neighbours re-read.  (A kernel with less arithmetic per voxel would want the plain form.)
                 mk_store_result<TEAM == 1>(o, make_float4(f[0], f[1], f[2], f[3]));
                 mk_store_result<TEAM == 1>(o + 1, make_float4(f[4], f[5], f[6], f[7]));
             } else {

@@ -24,6 +24,14 @@
 #ifndef MK_DIAG
 #define MK_DIAG 0
 #endif
+// MK_AB=<bits>: same-box A/B of two CORRECT code paths while an experiment is open (values stay right; the bits and what
+// they select are listed where they are used).  0 in a release build; a diagnostics build like the others.
+#if defined(MK_AB) && !defined(MKAMD_DIAGNOSTICS_BUILD)
+#error "MK_AB selects experimental code paths: diagnostics builds only (-DMKAMD_DIAGNOSTICS_BUILD, tools/build_variant.sh)"
+#endif
+#ifndef MK_AB
+#define MK_AB 0
+#endif
 
 #ifdef MK_PHASE_TIMERS
 namespace mkamd { __device__ unsigned long long g_phase_cycles[8]; }

@@ -23,6 +23,7 @@ struct EmuBackend {
     CounterState& counter_state(int set) { return counters[set & 1]; }
     void note_error_flag_mirrored(bool) {}
     void note_tail_reports(bool) {}
+    void note_dist_kernel(const char*) {}
     const volatile unsigned* feedback_host() const { return feedback; }
     unsigned* feedback_dev() { return feedback; }
     ~EmuBackend() { for (void* p : bufs) free(p); }

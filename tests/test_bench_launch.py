@@ -29,6 +29,21 @@ def test_bench_gpus2_dry_run_spawns_two_ranks():
     assert d["timed_path"] == "run_workload" and d["gather_error"] is None and d["gather_ms"] is not None and d["ms_per_step"] > 0
 
 
+def test_bench_gpus8_dry_run_is_the_drivers_command_shape():
+    """`python bench.py --gpus 8 --dry-run`: the exact command shape the driver uses on the 8-GPU node, eight ranks through
+    run_workload on gloo (the widest rehearsal was four).  Rank 0's line says so: eight ranks joined and
+    finished the timed region, weak scaling, and rank r drives local device r -- one process per GPU, as launch_ranks /
+    torchrun set LOCAL_RANK -- and both gathers returned every rank's rows."""
+    r = _run("--gpus", "8", "--dry-run", "--batch", "3", timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["ranks_joined"] == 8 and d["ranks_alive"] == 8 and d["scaling"] == "weak"
+    assert sorted(d["rank_to_local_device"]) == [[i, i] for i in range(8)]
+    assert d["ok"] is True and d["timed_path"] == "run_workload" and d["gather_error"] is None and d["gather_ms"] is not None
+
+
 def test_bench_refuses_more_gpus_than_devices():
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0

@@ -122,3 +122,68 @@ def test_sharded_voxelization_world4_gloo(B):
     8-GPU run, where gloo runs with two ranks proved little; 11 ragged molecules over 4 ranks (shards of 2-4 items, chunks
     of 0-2), and 3 items over 4 ranks (an empty shard: a rank that only receives)."""
     _run_world(4, B)
+
+
+def _worker8(rank, world, port, q):
+    """world 8: the point-to-point exchange with SEVEN peers per chunk, ragged shards (balanced by atoms) and empty ones."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+
+    from moleculekit_amd import distributed as D
+    from tests.synth import grid_origin, synth_config
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        detail = []
+        for B in (19, 5):                        # 19 ragged molecules over 8 ranks (shards of 1-4); 5 over 8 (three empty shards)
+            p = synth_config(5, B)
+            origins = np.stack([grid_origin(c, p["boxsize"], 1.0)[0] for c in p["centers"]])
+            nv = np.array([6, 5, 4])
+
+            def compute(c, offs, s, o, nvox, vs, bx):
+                # a function of the item alone (its atom count and coordinate sum): a misplaced row shows
+                n = len(offs) - 1
+                csum = np.concatenate([[0.0], np.cumsum(c.astype(np.float64).sum(axis=1))])
+                val = 1.0 + np.diff(offs) + 1e-3 * (csum[offs[1:]] - csum[offs[:-1]])
+                return torch.from_numpy(np.broadcast_to(val[:, None, None], (n, int(np.prod(nvox)), s.shape[1])).astype(np.float32).copy())
+
+            ref = compute(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0, None).numpy()
+            sv = D.ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0,
+                                              balance_by_atoms=(B == 19), compute=compute)
+            lo, hi = int(sv.bounds[rank]), int(sv.bounds[rank + 1])
+            if B == 5:
+                ok = ok and int((np.diff(sv.bounds) == 0).sum()) == 3
+            for nchunks in (1, 4):
+                got = sv.voxelize_gather(nchunks=nchunks, exchange="p2p")
+                ok = ok and sv.last_exchange == "p2p" and np.array_equal(got.numpy(), ref)
+                got = sv.voxelize_gather(nchunks=nchunks, exchange="allgather")
+                ok = ok and np.array_equal(got.numpy(), ref)
+            ok = ok and np.array_equal(sv.voxelize().numpy(), ref[lo:hi])
+            detail.append([int(b) for b in sv.bounds])
+        q.put((rank, bool(ok), detail))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_voxelization_world8_gloo():
+    """Eight ranks: `voxelize_gather(exchange="p2p", nchunks in {1, 4})` with ragged and with empty
+    shards -- every rank posts up to seven sends and seven receives per chunk, the shape of the 8-GPU node's exchange."""
+    import torch.multiprocessing as mp
+
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    for b in res[0][2]:
+        assert b[0] == 0 and len(b) == world + 1
