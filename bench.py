@@ -796,8 +796,11 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     nv = grid_origin(p0["centers"][0], p0["boxsize"], p0["voxelsize"])[1]
     if compute is None:
         # (pipelined steps are the package's own behaviour now: ShardedVoxelizer promises its resident shard to every call)
+        # cfg4 is a trajectory: every item is a frame of ONE molecule, and the package's frame drivers reuse what the pre-pass derives
+        # from its sigmas (a topology handle, include/mkamd_voxel.h (3c)); the other workloads are batches of different molecules
+        shared = name == "cfg4" and not getattr(args, "no_topology", False) and os.environ.get("MKAMD_SPATIAL_ORDER", "0") != "1"
         sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx,
-                                          pipelined=not getattr(args, "no_pipeline", False))
+                                          pipelined=not getattr(args, "no_pipeline", False), shared_sigmas=shared)
     else:
         sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, compute=compute)
     p = cache["p"]
@@ -858,7 +861,8 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     # sanity of what was produced inside the timed region (never a cached / skipped result)
     chk = out[0].double().sum().item()
     assert os.environ.get("MKAMD_DIAG") == "1" or (np.isfinite(chk) and chk > 0), "bench produced an empty grid"
-    res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C), kernel=kernel_name)
+    res = dict(p=p, nv=nv, V=V, C=C, elapsed=elapsed, k_ms=k_ms, k_n=k_n, alg=algorithmic_bytes(p, nv, C), kernel=kernel_name,
+               topology=getattr(sv, "_topo", None) is not None)
     if "out" in keep:
         res["out"] = out
 
@@ -1002,6 +1006,8 @@ def main():
                     help="after the timed K steps, keep stepping until this much wall time has been spent on the same workload and "
                          "report it as `sustained` (the K-step region of a 64^3 workload is tens of milliseconds: too short for a "
                          "utilisation sampler to see, and for the clocks to settle). 0 = skip")
+    ap.add_argument("--no-topology", action="store_true",
+                    help="cfg4 (frames of one molecule): the plain call on the sigma matrix repeated per frame instead of the topology handle (A-B)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-grid latency probe (profiling passes: every launch is a full batch)")
     ap.add_argument("--value-tol", type=float, default=0.0,
                     help="opt into the tolerance-aware reach (mkamd_ctx_set_value_tolerance): atoms are culled where they are "
@@ -1126,6 +1132,7 @@ def main():
             extra[nm] = {"value": round(world * DEFAULT_BATCH[nm] * r2["V"] * r2["C"] * steps2 / r2["elapsed"] / 1e6, 2),
                          "unit": "Mvoxel-channels/s", "items_per_gpu_per_step": DEFAULT_BATCH[nm], "steps": steps2,
                          "ms_per_step": round(r2["elapsed"] / steps2 * 1e3, 4), "grid": [int(v) for v in r2["nv"]],
+                         **({"topology_reuse": "frames of one molecule: sigma classes / class ids built once (mkamd_topology), not per call"} if r2.get("topology") else {}),
                          "roofline": roofline_of(r2, nm, DEFAULT_BATCH[nm], args.tile_k)}
 
     if not args.no_extra and args.workload == "cfg2" and not args.batch and world == 1 and args.value_tol == 0.0:
@@ -1179,7 +1186,7 @@ def main():
                            "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
                            "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
                            "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
-                           "value_tolerance": args.value_tol,
+                           "value_tolerance": args.value_tol, "topology_reuse": bool(res.get("topology")),
                            "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region; "
                                           "fences over gloo, feature gathers over RCCL after everything timed)",
                            "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},

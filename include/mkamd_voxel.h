@@ -248,6 +248,32 @@ int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t n_items, const float*
                                    const float* d_box, int32_t max_images_per_atom,
                                    const double* d_affine, float* d_features);
 
+/* (3c) TOPOLOGY REUSE for trajectory-shaped calls (round 5).  The sigmas depend on the topology only (voxeldescriptors.py:332-335:
+ * vdW radius x channel mask), so for the frames of a trajectory everything the pre-pass derives from them -- an atom's channel
+ * words, the sigma classes and the class table, its class ids, whether any sigma needs the exact cut-off fix-up -- is the same
+ * in every call.  A handle holds it on the device (built once: three small launches and one read-back; the library keeps its
+ * own copy of the sigmas, so the caller's may change or go away); mkamd_voxelize_lattice_topo_dev voxelizes `n_items` sets
+ * of coordinates of that molecule -- atom_offsets[b] = b * n_atoms: every item the topology's atom count long, CHECKED on the
+ * device (an item of another length raises MKAMD_EINVAL at the next mkamd_ctx_synchronize / _poll_errors) -- with 4 bytes of
+ * ids per atom where the plain call reads the sigma row, divides in double and discovers the classes again.  Features are the
+ * plain call's BIT FOR BIT.  The handle is for one voxel size and channel count (the call's must match: MKAMD_EINVAL);
+ * molecules with more than 15 distinct sigma values have no class ids to reuse (creation fails with MKAMD_EINVAL: use the plain
+ * call), and the A-B modes force_general / value tolerance are refused for topology calls.  Promises
+ * (mkamd_ctx_promise_inputs) apply as for the plain call.  What it is for: batch.iterVoxelizeTrajectory / iterVoxelizeXTC /
+ * ShardedVoxelizer(shared_sigmas=True) use it by construction. */
+typedef struct mkamd_topology mkamd_topology;
+int mkamd_topology_create_dev(mkamd_ctx* ctx, const void* d_sigmas, int sigmas_are_f64, int64_t n_atoms, int32_t n_channels,
+                              double voxelsize, mkamd_topology** topology);
+int mkamd_topology_create_host(mkamd_ctx* ctx, const void* sigmas, int sigmas_are_f64, int64_t n_atoms, int32_t n_channels,
+                               double voxelsize, mkamd_topology** topology);
+/* Waits for the context's streams (calls that read the handle), then frees it.  ctx may be NULL (the whole device is drained). */
+int mkamd_topology_destroy(mkamd_ctx* ctx, mkamd_topology* topology);
+int mkamd_topology_info(const mkamd_topology* topology, int64_t* n_atoms, int32_t* n_channels, double* voxelsize, int32_t* has_wide_sigmas);
+int mkamd_voxelize_lattice_topo_dev(mkamd_ctx* ctx, int32_t n_items, const float* d_coords, const int64_t* d_atom_offsets,
+                                    int64_t total_atoms, const mkamd_topology* topology, const double* d_origins,
+                                    const int32_t* nvoxels, double voxelsize, const float* d_box, int32_t max_images_per_atom,
+                                    const double* d_affine, float* d_features);
+
 /* (4) lattice centres (voxeldescriptors.py:125-132 + :245-247), float64 [V,3], bit-exact with the
  * reference's numpy arithmetic: centre = fl64(index*voxelsize) + bb_min. */
 int mkamd_grid_centers_host(mkamd_ctx* ctx, const double* bb_min, const int32_t* nvoxels,

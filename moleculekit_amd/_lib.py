@@ -71,6 +71,11 @@ SIGNATURES = {
                                             _c_dbl, _vp, _c_i32, _vp]),
     "mkamd_voxelize_lattice_aug_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _c_int, _c_i32, _vp, _vp,
                                                 _c_dbl, _vp, _c_i32, _vp, _vp]),
+    "mkamd_topology_create_dev": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_i32, _c_dbl, ctypes.POINTER(_vp)]),
+    "mkamd_topology_create_host": (_c_int, [_vp, _vp, _c_int, _c_i64, _c_i32, _c_dbl, ctypes.POINTER(_vp)]),
+    "mkamd_topology_destroy": (_c_int, [_vp, _vp]),
+    "mkamd_topology_info": (_c_int, [_vp, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i32), ctypes.POINTER(_c_dbl), ctypes.POINTER(_c_i32)]),
+    "mkamd_voxelize_lattice_topo_dev": (_c_int, [_vp, _c_i32, _vp, _vp, _c_i64, _vp, _vp, _vp, _c_dbl, _vp, _c_i32, _vp, _vp]),
     "mkamd_grid_centers_host": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
     "mkamd_grid_centers_dev": (_c_int, [_vp, _vp, _vp, _c_dbl, _vp]),
     "mkamd_lattice_from_centers": (_c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp]),
@@ -246,9 +251,11 @@ class Context:
         """Tolerance-aware reach (include/mkamd_voxel.h): 0 = off (default, the reference's hard 5 A cutoff), else every
         atom is culled per tile where it is worth less than ``eps`` (<= 1e-5): values move by at most ``eps``."""
         _check(load().mkamd_ctx_set_value_tolerance(self._h, float(eps)))
+        self._value_tol = float(eps)
 
     def set_force_general(self, on: bool):
         _check(load().mkamd_ctx_set_force_general(self._h, int(bool(on))))
+        self._force_general = bool(on)
 
     def set_pipelining(self, on: bool):
         """Overlap the pre-pass of a call with the tile kernel of the previous one (see the header for the contract)."""
@@ -351,6 +358,13 @@ class Context:
                                                      float(voxelsize), _ptr(d_box), int(max_images), _ptr(d_affine),
                                                      _ptr(d_out)))
 
+    def voxelize_lattice_topo_dev(self, B, d_coords, d_offsets, total_atoms, topology, d_origins, nvox, voxelsize, d_box, max_images, d_out,
+                                  d_affine=None):
+        """``voxelize_lattice_dev`` for items that are each one set of coordinates of ``topology``'s molecule (include/mkamd_voxel.h)."""
+        _check(load().mkamd_voxelize_lattice_topo_dev(self._h, B, _ptr(d_coords), _ptr(d_offsets), int(total_atoms), topology._h,
+                                                      _ptr(d_origins), _ptr(nvox), float(voxelsize), _ptr(d_box), int(max_images),
+                                                      _ptr(d_affine), _ptr(d_out)))
+
     def grid_centers_host(self, bb_min, nvox, voxelsize, out):
         _check(load().mkamd_grid_centers_host(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(out)))
 
@@ -392,6 +406,55 @@ class Context:
 
     def grid_centers_dev(self, bb_min, nvox, voxelsize, d_out):
         _check(load().mkamd_grid_centers_dev(self._h, _ptr(bb_min), _ptr(nvox), float(voxelsize), _ptr(d_out)))
+
+
+class Topology:
+    """What the voxelizer's pre-pass derives from a molecule's sigmas ALONE, kept on the device for every later call over
+    coordinates of that molecule (include/mkamd_voxel.h, (3c)): ``sigmas`` is the molecule's [n_atoms, C] matrix -- a numpy
+    array (float32 / float64) or a CUDA tensor of the context's device.  The library keeps its own copy."""
+
+    def __init__(self, ctx, sigmas, voxelsize):
+        self._h = _vp(None)
+        self._ctx = ctx
+        h = _vp(None)
+        if isinstance(sigmas, np.ndarray) or not hasattr(sigmas, "data_ptr"):
+            sig = np.ascontiguousarray(sigmas)
+            if sig.dtype not in (np.float32, np.float64):
+                sig = sig.astype(np.float64)
+            if sig.ndim != 2:
+                raise ValueError("sigmas must be (natoms, nchannels)")
+            _check(load().mkamd_topology_create_host(ctx._h, _ptr(sig), int(sig.dtype == np.float64), int(sig.shape[0]), int(sig.shape[1]),
+                                                     float(voxelsize), ctypes.byref(h)))
+            self.n_atoms, self.n_channels = int(sig.shape[0]), int(sig.shape[1])
+        else:
+            import torch
+            if not (sigmas.is_cuda and sigmas.dim() == 2 and sigmas.is_contiguous() and sigmas.dtype in (torch.float32, torch.float64)):
+                raise ValueError("sigmas must be a contiguous float32 / float64 CUDA tensor (natoms, nchannels)")
+            ctx.set_stream(torch.cuda.current_stream(sigmas.device).cuda_stream)
+            _check(load().mkamd_topology_create_dev(ctx._h, int(sigmas.data_ptr()), int(sigmas.dtype == torch.float64), int(sigmas.shape[0]),
+                                                    int(sigmas.shape[1]), float(voxelsize), ctypes.byref(h)))
+            self.n_atoms, self.n_channels = int(sigmas.shape[0]), int(sigmas.shape[1])
+        self._h = h
+        self.voxelsize = float(voxelsize)
+
+    @property
+    def has_wide_sigmas(self) -> bool:
+        w = _c_i32(0)
+        _check(load().mkamd_topology_info(self._h, None, None, None, ctypes.byref(w)))
+        return bool(w.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            ctx = getattr(self, "_ctx", None)
+            alive = ctx is not None and getattr(ctx, "_h", None) is not None and ctx._h.value
+            load().mkamd_topology_destroy(ctx._h if alive else None, self._h)
+            self._h = _vp(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _tls = threading.local()

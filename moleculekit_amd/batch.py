@@ -185,8 +185,12 @@ def rotation_affines(rotations, centers):
 
 
 def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, box=None,
-                           max_images=1, out=None, ctx=None, channel_first=False, affine=None):
+                           max_images=1, out=None, ctx=None, channel_first=False, affine=None, topology=None):
     """Same as ``voxelize_lattice`` on torch CUDA tensors; asynchronous on torch's current stream.
+
+    ``topology`` (``_lib.Topology``, with ``sigmas=None``): every item is one set of coordinates of that molecule -- the frames
+    of a trajectory; what the pre-pass derives from the sigmas is taken from the handle (include/mkamd_voxel.h (3c)): the same
+    features bit for bit, fewer instructions per call.
 
     coords float32 [sumN,3], atom_offsets int64 [B+1], sigmas float32|float64 [sumN,C],
     origins float64 [B,3], box float32 [B,3] or None (pass ``max_images`` from
@@ -206,13 +210,16 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
     if ctx is not None and ctx.device != dev_index:
         raise ValueError(f"ctx lives on GPU {ctx.device} but the tensors are on cuda:{dev_index} (kernels run on the context's device)")
     ctx = ctx or _lib.default_context(dev_index)
+    if (sigmas is None) == (topology is None):
+        ctx.withdraw_promise()
+        raise ValueError("pass the sigmas or a topology (not both)")
     if not (coords.dtype == torch.float32 and coords.is_contiguous() and atom_offsets.dtype == torch.int64 and atom_offsets.is_contiguous()
-            and sigmas.dtype in (torch.float32, torch.float64) and sigmas.is_contiguous() and sigmas.dim() == 2
+            and (sigmas is None or (sigmas.dtype in (torch.float32, torch.float64) and sigmas.is_contiguous() and sigmas.dim() == 2))
             and origins.dtype == torch.float64 and origins.is_contiguous()):
         ctx.withdraw_promise()            # (see below)
         raise AssertionError("voxelize_lattice_torch: coords float32, atom_offsets int64, sigmas float32|float64 [n, C], origins float64, all contiguous")
     B = int(origins.shape[0])
-    C = int(sigmas.shape[1])
+    C = int(sigmas.shape[1]) if topology is None else topology.n_channels
     nv = np.ascontiguousarray(nvoxels, dtype=np.int32).reshape(3)
     V = int(np.prod(nv.astype(np.int64)))
     if out is None:
@@ -229,9 +236,13 @@ def voxelize_lattice_torch(coords, atom_offsets, sigmas, origins, nvoxels, voxel
         d_aff = affine.data_ptr()
     try:
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-        ctx.voxelize_lattice_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]),
-                                 sigmas.data_ptr(), sigmas.dtype == torch.float64, C, origins.data_ptr(), nv,
-                                 float(voxelsize), d_box, int(max_images), out.data_ptr(), d_aff)
+        if topology is not None:
+            ctx.voxelize_lattice_topo_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]), topology, origins.data_ptr(), nv,
+                                          float(voxelsize), d_box, int(max_images), out.data_ptr(), d_aff)
+        else:
+            ctx.voxelize_lattice_dev(B, coords.data_ptr(), atom_offsets.data_ptr(), int(coords.shape[0]),
+                                     sigmas.data_ptr(), sigmas.dtype == torch.float64, C, origins.data_ptr(), nv,
+                                     float(voxelsize), d_box, int(max_images), out.data_ptr(), d_aff)
     except BaseException:
         ctx.withdraw_promise()            # a promise made for THIS call (Context.promise_inputs) must not reach another one
         raise
@@ -333,6 +344,7 @@ def _chunk_images(box3n, nvoxels, voxelsize) -> int:
     return max_images_per_atom(np.ascontiguousarray(np.asarray(box3n).T), nvoxels, voxelsize)
 
 
+USE_TOPOLOGY = True        # the streamed voxelizers build a topology handle for their molecule (tests switch it off for the cross-check)
 _PINNED = {}
 _COPY_THREADS = 8
 _POOL = None
@@ -362,7 +374,7 @@ def _pinned_give(key, t):
 
 
 def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first, ctx,
-                     max_images, fill_dev=None, pipelined=True):
+                     max_images, fill_dev=None, pipelined=True, use_topology=None):
     """Core of the streamed voxelizers.  Host sources: ``fill(coords_np [N,3,n], box_np [3,n] | None, idx)`` produces chunk
     ``idx`` (frame indices) straight into pinned staging; device sources: ``fill_dev(xyz [n,N,3], box [n,3] | None, idx)``
     writes the chunk's frame-major device tensors itself.  Everything a chunk needs on the device -- the upload, the
@@ -402,7 +414,20 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
     copy = torch.cuda.Stream(device=dev)
     host_source = fill_dev is None
     with torch.cuda.device(dev):
-        d_sig = torch.as_tensor(sig, device=dev).repeat(chunk, 1).contiguous()            # [chunk*N, C], shared by the frames
+        # every frame has the molecule's sigmas: what the pre-pass derives from them is built ONCE (a topology handle,
+        # include/mkamd_voxel.h (3c)) instead of per frame and call; molecules the handle does not take (more than 15 distinct
+        # sigmas) -- and use_topology=False, the cross-check of the tests -- get the matrix repeated per frame as before
+        topo = None
+        run_ctx = ctx or _lib.default_context(dev.index)
+        if use_topology is None:
+            use_topology = USE_TOPOLOGY
+        # (the A-B modes of a context -- the general path, a value tolerance -- are not served by topology calls)
+        if use_topology and N > 0 and not getattr(run_ctx, "_force_general", False) and not getattr(run_ctx, "_value_tol", 0.0):
+            try:
+                topo = _lib.Topology(run_ctx, sig, float(voxelsize))
+            except ValueError:
+                topo = None
+        d_sig = None if topo is not None else torch.as_tensor(sig, device=dev).repeat(chunk, 1).contiguous()      # [chunk*N, C]
         d_offs = torch.arange(chunk + 1, dtype=torch.int64, device=dev) * N
         d_org = torch.as_tensor(np.broadcast_to(origin, (chunk, 3)).copy(), device=dev)
         # two slots, each owning its pinned staging (host sources), its device slab and its frame-major inputs
@@ -418,7 +443,6 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
         ready = [torch.cuda.Event(), torch.cuda.Event()]         # the inputs of the chunk in slot i are complete
         consumed = [torch.cuda.Event(), torch.cuda.Event()]      # the call that read slot i's inputs is done (compute stream)
         images = [max_images, max_images]
-        run_ctx = ctx or _lib.default_context(dev.index)
 
         def upload(k, slot):
             idx = fr[k * chunk:(k + 1) * chunk]
@@ -460,9 +484,9 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
                     run_ctx.promise_inputs(ready[slot])           # the library waits for it where the pre-pass runs
                 else:
                     main.wait_event(ready[slot])
-                feats = voxelize_lattice_torch(d_xyz[slot][:n * N], d_offs[:n + 1], d_sig[:n * N], d_org[:n], nvoxels, voxelsize,
-                                               box=d_bx[slot][:n] if has_box else None, max_images=images[slot], ctx=run_ctx,
-                                               channel_first=channel_first)
+                feats = voxelize_lattice_torch(d_xyz[slot][:n * N], d_offs[:n + 1], None if topo is not None else d_sig[:n * N], d_org[:n], nvoxels,
+                                               voxelsize, box=d_bx[slot][:n] if has_box else None, max_images=images[slot], ctx=run_ctx,
+                                               channel_first=channel_first, topology=topo)
                 consumed[slot].record(torch.cuda.current_stream(dev))
                 run_ctx.poll_errors()                             # non-blocking: errors of the chunks already finished
                 yield idx, feats

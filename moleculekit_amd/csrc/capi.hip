@@ -262,6 +262,13 @@ struct mkamd_ctx {
     }
 };
 
+// A molecule's topology on the device (include/mkamd_voxel.h, mkamd_topology_create_*): one allocation, owned here.
+struct mkamd_topology {
+    int device = 0;
+    void* mem = nullptr;                   // sigmas copy | cw | ids | table | flags
+    mkamd::TopologyDev dev;
+};
+
 // `pending_ok`: the entry point may run between the two halves of a host call (mkamd_voxelize_lattice_host_begin / _end): the
 // halves themselves, and what touches neither the pending call's result buffer nor the workspace it reads (queries, the
 // centre generator, copies out).  Every other entry point would regrow or overwrite what `end` is about to hand back --
@@ -286,6 +293,7 @@ static int collect_async_errors(mkamd_ctx* ctx)
     HIP_TRY(hipMemcpy(&flag, ctx->bufs[WS_ERR], sizeof(int), hipMemcpyDeviceToHost));
     if (flag == 0) return 0;
     HIP_TRY(hipMemset(ctx->bufs[WS_ERR], 0, sizeof(int)));
+    if (flag & MK_ERR_TOPOLOGY) return fail(MKAMD_EINVAL, "a topology call was given an item that is not the topology's atom count long; results are incomplete");
     if (flag & MK_ERR_BAD_BOX) return fail(MKAMD_EBOX, "periodic box edges must be > 10 A (2 x cutoff)");
     if (flag & MK_ERR_TOO_MANY_IMAGES) return fail(MKAMD_EBOX, "periodic box much smaller than the grid (too many images)");
     return fail(MKAMD_EOVERFLOW, "more periodic images than max_images_per_atom allowed; results are incomplete");
@@ -732,17 +740,18 @@ try {
                                           d_origins, nvoxels, voxelsize, d_box, max_images, nullptr, d_features);
 } MK_API_CATCH
 
-int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
-                                   const int64_t* d_atom_offsets, int64_t total_atoms, const void* d_sigmas,
-                                   int sigmas_are_f64, int32_t C, const double* d_origins,
-                                   const int32_t* nvoxels, double voxelsize, const float* d_box,
-                                   int32_t max_images, const double* d_affine, float* d_features)
-try {
+static int voxelize_lattice_dev_impl(mkamd_ctx* ctx, int32_t B, const float* d_coords,
+                                     const int64_t* d_atom_offsets, int64_t total_atoms, const void* d_sigmas,
+                                     int sigmas_are_f64, int32_t C, const double* d_origins,
+                                     const int32_t* nvoxels, double voxelsize, const float* d_box,
+                                     int32_t max_images, const double* d_affine, float* d_features, const mkamd_topology* topo)
+{
     int st = check_ctx(ctx);
     if (st) return st;
     if (!nvoxels) return fail(MKAMD_EINVAL, "nvoxels pointer is NULL");
     if (B > 0 && (!d_atom_offsets || !d_origins || !d_features)) return fail(MKAMD_EINVAL, "atom_offsets/origins/features pointer is NULL");
-    if (total_atoms > 0 && (!d_coords || !d_sigmas)) return fail(MKAMD_EINVAL, "coords/sigmas pointer is NULL");
+    if (total_atoms > 0 && (!d_coords || (!d_sigmas && !topo))) return fail(MKAMD_EINVAL, "coords/sigmas pointer is NULL");
+    if (topo && topo->device != ctx->device) return fail(MKAMD_EINVAL, "the topology lives on another device than the context");
     if ((st = ensure_err_flag(ctx))) return st;
     LatticeProblem P;
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
@@ -751,6 +760,7 @@ try {
     P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol; P.direct = ctx->direct; P.seq = ctx->seq_next; ctx->seq_next = 0u;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
+    P.topo = topo ? &topo->dev : nullptr;
     std::string err;
     // a promise (mkamd_ctx_promise_inputs) is about the next call of THIS entry point made from outside the library: a host
     // call reaches here through voxelize_lattice_host_begin_impl, which has set the promise aside (its inputs were uploaded
@@ -759,6 +769,106 @@ try {
     ctx->promise = false; ctx->promise_event = nullptr;       // one call's worth
     if (st && !err.empty()) return fail(st, err);
     return st;
+}
+
+int mkamd_voxelize_lattice_aug_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords,
+                                   const int64_t* d_atom_offsets, int64_t total_atoms, const void* d_sigmas,
+                                   int sigmas_are_f64, int32_t C, const double* d_origins,
+                                   const int32_t* nvoxels, double voxelsize, const float* d_box,
+                                   int32_t max_images, const double* d_affine, float* d_features)
+try {
+    return voxelize_lattice_dev_impl(ctx, B, d_coords, d_atom_offsets, total_atoms, d_sigmas, sigmas_are_f64, C, d_origins, nvoxels, voxelsize,
+                                     d_box, max_images, d_affine, d_features, nullptr);
+} MK_API_CATCH
+
+// ---- topology reuse: the frames of a trajectory share everything the pre-pass derives from the sigmas ----
+int mkamd_topology_create_dev(mkamd_ctx* ctx, const void* d_sigmas, int sigmas_are_f64, int64_t n_atoms, int32_t C, double voxelsize,
+                              mkamd_topology** out)
+try {
+    if (!out) return fail(MKAMD_EINVAL, "topology out-pointer is NULL");
+    *out = nullptr;
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n_atoms <= 0 || C <= 0 || !d_sigmas) return fail(MKAMD_EINVAL, "a topology needs n_atoms > 0, n_channels > 0 and the sigmas");
+    if (n_atoms > 0x7fffffffLL) return fail(MKAMD_EINVAL, "a topology holds at most 2^31 atoms");
+    const int G = ceil_div(C, CHG);
+    const size_t a256 = 255, sig_bytes = (size_t)n_atoms * C * (sigmas_are_f64 ? 8 : 4);
+    const size_t o_cw = (sig_bytes + a256) & ~a256, o_ids = (o_cw + (size_t)n_atoms * G * sizeof(uint2) + a256) & ~a256,
+                 o_tab = (o_ids + (size_t)n_atoms * G * sizeof(unsigned) + a256) & ~a256, o_flags = o_tab + 256, total = o_flags + 256;
+    mkamd_topology* t = new mkamd_topology();
+    t->device = ctx->device;
+    hipError_t e = hipMalloc(&t->mem, total);
+    if (e != hipSuccess) { delete t; return hip_fail(e, "hipMalloc(topology)"); }
+    char* m = (char*)t->mem;
+    auto drop = [&](int code) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(t->mem); delete t; return code; };
+    if ((e = hipMemcpyAsync(m, d_sigmas, sig_bytes, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess) return drop(hip_fail(e, "hipMemcpyAsync(topology sigmas)"));
+    if ((e = hipMemsetAsync(m + o_flags, 0, 256, ctx->stream)) != hipSuccess) return drop(hip_fail(e, "hipMemsetAsync(topology flags)"));
+    std::string err;
+    st = run_topology_build(*ctx, m, sigmas_are_f64, (long long)n_atoms, C, voxelsize, (uint2*)(m + o_cw), (unsigned*)(m + o_ids),
+                            (unsigned*)(m + o_tab), (int*)(m + o_flags), err);
+    if (st) return drop(err.empty() ? st : fail(st, err));
+    unsigned table[CLS_TABLE_WORDS];
+    int flags = 0;
+    if ((e = hipMemcpyAsync(table, m + o_tab, sizeof table, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(&flags, m + o_flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return drop(hip_fail(e, "topology read-back"));
+    if (table[CLS_OVERFLOW] != CLS_EMPTY)
+        return drop(fail(MKAMD_EINVAL, "more than 15 distinct sigma values: no class ids to reuse (use the plain entry point)"));
+    t->dev.n = (long long)n_atoms; t->dev.C = C; t->dev.G = G; t->dev.sigmas_f64 = sigmas_are_f64; t->dev.voxelsize = voxelsize;
+    t->dev.sigmas = m; t->dev.cw = (const uint2*)(m + o_cw); t->dev.ids = (const unsigned*)(m + o_ids); t->dev.table = (const unsigned*)(m + o_tab);
+    t->dev.overflow = false; t->dev.wide = (flags & 1) != 0;
+    *out = t;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_topology_create_host(mkamd_ctx* ctx, const void* sigmas, int sigmas_are_f64, int64_t n_atoms, int32_t C, double voxelsize,
+                               mkamd_topology** out)
+try {
+    if (!out) return fail(MKAMD_EINVAL, "topology out-pointer is NULL");
+    *out = nullptr;
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n_atoms <= 0 || C <= 0 || !sigmas) return fail(MKAMD_EINVAL, "a topology needs n_atoms > 0, n_channels > 0 and the sigmas");
+    void* ds = nullptr;
+    const size_t bytes = (size_t)n_atoms * C * (sigmas_are_f64 ? 8 : 4);
+    if ((st = ctx->ensure(WS_H_SIGMAS, bytes, &ds))) return st;
+    HIP_TRY(hipMemcpyAsync(ds, sigmas, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return mkamd_topology_create_dev(ctx, ds, sigmas_are_f64, n_atoms, C, voxelsize, out);
+} MK_API_CATCH
+
+int mkamd_topology_destroy(mkamd_ctx* ctx, mkamd_topology* topo)
+try {
+    if (!topo) return MKAMD_OK;
+    if (ctx) {                                   // calls that read the handle may still be in flight on the context's streams
+        (void)hipSetDevice(ctx->device);
+        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamSynchronize(ctx->main_stream);
+    } else {
+        (void)hipSetDevice(topo->device);
+        (void)hipDeviceSynchronize();
+    }
+    if (topo->mem) (void)hipFree(topo->mem);
+    delete topo;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_topology_info(const mkamd_topology* topo, int64_t* n_atoms, int32_t* n_channels, double* voxelsize, int32_t* has_wide_sigmas)
+try {
+    if (!topo) return fail(MKAMD_EINVAL, "topology is NULL");
+    if (n_atoms) *n_atoms = (int64_t)topo->dev.n;
+    if (n_channels) *n_channels = topo->dev.C;
+    if (voxelsize) *voxelsize = topo->dev.voxelsize;
+    if (has_wide_sigmas) *has_wide_sigmas = topo->dev.wide ? 1 : 0;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_voxelize_lattice_topo_dev(mkamd_ctx* ctx, int32_t B, const float* d_coords, const int64_t* d_atom_offsets, int64_t total_atoms,
+                                    const mkamd_topology* topo, const double* d_origins, const int32_t* nvoxels, double voxelsize,
+                                    const float* d_box, int32_t max_images, const double* d_affine, float* d_features)
+try {
+    if (!topo) return fail(MKAMD_EINVAL, "topology is NULL");
+    return voxelize_lattice_dev_impl(ctx, B, d_coords, d_atom_offsets, total_atoms, nullptr, topo->dev.sigmas_f64, topo->dev.C, d_origins, nvoxels,
+                                     voxelsize, d_box, max_images, d_affine, d_features, topo);
 } MK_API_CATCH
 
 // End of a small synchronous call (tens of microseconds of GPU work): poll the stream instead of blocking on it -- the

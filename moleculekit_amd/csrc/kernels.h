@@ -105,6 +105,10 @@ struct GridDesc {
     // rank atomics to ~1 000 counters, and device-scope atomics on neighbouring words serialise (packed 4 bytes apart they
     // were 9 us of a 13 us kernel) -- k_bin_solo keeps them 32 bytes apart (cnt_shift = 3; 64 and 128 bytes: the same time)
     int cnt_shift;
+    // topology reuse (round 5; pipeline.h TopologyDev): != 0 -- every item of the call is one set of coordinates of the SAME
+    // molecule of topo_n atoms (the frames of a trajectory), whose per-atom class ids / compact channel words / class table
+    // were built once from its sigmas: sigma-side arrays are indexed by the atom's index INSIDE its item
+    long long topo_n;
 };
 enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4, DIRECT_HEAD = 32 /* words in front of the counters (one 128-byte line) */ };
 constexpr float REACH_STEP = 0.17f;   // levels 0..3: reach 5.00 / 4.56 / 4.06 / 3.50 A at the 5 A cutoff (H at eps = 1e-6: 3.48 A)
@@ -133,7 +137,7 @@ constexpr float MK_W_MAX = 3.0e38f;
 constexpr double CUTOFF2_A = 25.0;   // occupancy_utils.pyx:53, in A^2
 constexpr double CUTOFF_A_KERNEL = 5.0;
 
-enum { MK_ERR_RECORD_OVERFLOW = 1, MK_ERR_BAD_BOX = 2, MK_ERR_TOO_MANY_IMAGES = 4 };
+enum { MK_ERR_RECORD_OVERFLOW = 1, MK_ERR_BAD_BOX = 2, MK_ERR_TOO_MANY_IMAGES = 4, MK_ERR_TOPOLOGY = 8 /* an item is not topo_n atoms long */ };
 
 // w = voxelsize^2 / sigma^2 of one (atom, channel); +inf when the atom is not in the channel
 // (sigma == 0, occupancy_utils.pyx:55-56) or sigma is NaN (the reference never stores NaN).
@@ -408,7 +412,10 @@ MK_DEV void items_of_block(const long long* __restrict__ atom_offsets, int B, lo
 
 // PBC: 0 = open boundaries, 1 = periodic, -1 = decided at run time (g.pbc).  The periodic image loop costs ~20 VGPRs;
 // k_bin_count is compiled for both so that the common open-boundary kernel stays small enough to run beside the tile kernel.
-template <typename SigT, int PBC, class RankOne, class RankWave>
+// TOPO (round 5, GridDesc::topo_n): the call's items are frames of ONE molecule whose class ids were built once
+// (k_topology_ids): `sigmas` then points at those ids (unsigned [topo_n, G]) -- no sigma row, no double-precision division,
+// no class discovery; the ids are parked (tmp_cls as unsigned [atoms, G]) for the fill pass.
+template <typename SigT, int PBC, bool TOPO = false, class RankOne, class RankWave>
 MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_hi, const float* __restrict__ coords,
                      const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
                      const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
@@ -417,10 +424,33 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
                      bool classes, unsigned* s_set, unsigned* s_full, RankOne&& rank_one, RankWave&& rank_wave)
 {
     const bool pbc = PBC < 0 ? (g.pbc != 0) : (PBC != 0);
+    bool any = false;
+    int b = 0;
+    if constexpr (TOPO) {
+        if (act) {
+            int lo = b_lo, hi = b_hi + 1;                        // (nearly always b_lo == b_hi: nothing is searched)
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+            }
+            b = lo;
+            const long long first = atom_offsets[b];
+            if (atom_offsets[b + 1] - first != g.topo_n) {
+                mk_atomic_or(err_flag, MK_ERR_TOPOLOGY);         // not a frame of the molecule the topology was built from
+            } else {
+                const unsigned* __restrict__ ids = reinterpret_cast<const unsigned*>(sigmas) + (size_t)(a - first) * g.G;
+                unsigned* __restrict__ park_ids = reinterpret_cast<unsigned*>(tmp_cls) + (size_t)a * g.G;
+                for (int gq = 0; gq < g.G; ++gq) {
+                    const unsigned v = ids[gq];
+                    any |= v != 0u;
+                    mk_tmp_store(&park_ids[gq], v);
+                }
+            }
+        }
+    }
     // ---- the atom's channels: w bit patterns (one pass over the sigmas serves the drop test AND the class
     //      discovery); registration is wave-cooperative, so every lane takes part ----
-    bool any = false;
-    for (int c0 = 0; c0 < g.C; c0 += CHG) {
+    for (int c0 = 0; !TOPO && c0 < g.C; c0 += CHG) {
         unsigned wb[CHG];
         float w[CHG];
 #pragma unroll
@@ -447,16 +477,17 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
     bool drop = !act || !any;
     double p[3] = {0.0, 0.0, 0.0}, Lv[3] = {0.0, 0.0, 0.0};
     int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
-    int b = 0;
     if (!drop) {
         // item of this atom: the largest b in [b_lo, b_hi] with atom_offsets[b] <= a (the caller narrows the range
         // with wave-uniform look-ups: nearly always b_lo == b_hi and nothing is searched per lane)
-        int lo = b_lo, hi = b_hi + 1;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+        if constexpr (!TOPO) {
+            int lo = b_lo, hi = b_hi + 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (atom_offsets[mid] <= a) lo = mid; else hi = mid;
+            }
+            b = lo;
         }
-        b = lo;
         const int nvox[3] = {g.nx, g.ny, g.nz};
         // fused augmentation (tools/voxeldescriptors.py:78-114 rotateCoordinates, then the astype(float32) of
         // _getOccupancyC :519): x' = M x + t in double, rounded to float32 like the reference pipeline does
@@ -477,8 +508,17 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
                 const double L = (double)box[3 * (size_t)b + ax] * g.inv_res;
                 if (!(L > 2.0 * (g.Rp - 1e-3))) { mk_atomic_or(err_flag, MK_ERR_BAD_BOX); drop = true; }
                 Lv[ax] = L;
-                const double a0 = ceil((-g.Rp - p[ax]) / L);
-                const double a1 = floor(((double)(nvox[ax] - 1) + g.Rp - p[ax]) / L);
+                // the range of images, ceil / floor of two QUOTIENTS by the box length: a quotient's integer part only depends
+                // on how it is rounded within ~1e-16 of a whole number, so the quotients are formed with a single-precision
+                // reciprocal (relative error < 2e-7; |quotient| is a few units) and only a lane within 1e-5 of a whole number
+                // takes the double-precision divisions (2 of ~50 000 atoms) -- the same integers, four f64 divisions per
+                // atom fewer (round 5: they were a quarter of the periodic binning's instructions)
+                const double invL = (double)mk_rcp((float)L);
+                const double n0 = -g.Rp - p[ax], n1 = (double)(nvox[ax] - 1) + g.Rp - p[ax];
+                double q0 = n0 * invL, q1 = n1 * invL;
+                if (!(fabs(q0 - rint(q0)) > 1e-5 * (1.0 + fabs(q0))) || !(fabs(q1 - rint(q1)) > 1e-5 * (1.0 + fabs(q1)))) { q0 = n0 / L; q1 = n1 / L; }
+                const double a0 = ceil(q0);
+                const double a1 = floor(q1);
                 if (a1 - a0 > 64.0) { mk_atomic_or(err_flag, MK_ERR_TOO_MANY_IMAGES); drop = true; }
                 k0[ax] = (int)a0; k1[ax] = (int)a1;              // empty range when a1 < a0
             } else {
@@ -545,7 +585,7 @@ MK_DEV void bin_atom(const GridDesc& g, long long a, bool act, int b_lo, int b_h
         for (int i = used; i < g.img_cap; ++i) tmp_idx[t0 + i] = make_uint2(TMP_UNUSED, 0u);
 }
 
-template <typename SigT, int PBC, bool SHARED = false>
+template <typename SigT, int PBC, bool SHARED = false, bool TOPO = false>
 MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
                                 const long long* __restrict__ atom_offsets, long long total_atoms,
                                 const SigT* __restrict__ sigmas, const double* __restrict__ origins,
@@ -559,7 +599,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     if (g.prepass_hurry) mk_wave_priority_high();
     __shared__ unsigned s_set[CLS_BLOCK_SET];
     __shared__ unsigned s_full;
-    const bool classes = !g.force_general;
+    const bool classes = !TOPO && !g.force_general;           // (a topology call: the classes are the topology's, nothing to discover)
     // One workgroup per 256 atoms -- except behind a direct pass (SHARED), where this kernel is only the fall-back: the
     // launch is then a few thousand workgroups that share the blocks (leaving at once when the pass succeeded costs 5 us,
     // not the 39 us of 50 000 empty workgroups).  A separate instance: as a loop the kernel needs 80 VGPRs, and the one that
@@ -580,7 +620,7 @@ MK_KERNEL(256) void k_bin_count(GridDesc g, const float* __restrict__ coords,
     int b_lo, b_hi;
     items_of_block(atom_offsets, g.B, total_atoms, a_first, a_last, b_lo, b_hi);
     const long long a = a_first + threadIdx.x;
-    bin_atom<SigT, PBC>(g, a, a < total_atoms, b_lo, b_hi, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, tmp_cls, err_flag,
+    bin_atom<SigT, PBC, TOPO>(g, a, a < total_atoms, b_lo, b_hi, coords, atom_offsets, sigmas, origins, box, affine, tmp_pos, tmp_idx, tmp_cls, err_flag,
                    classes, s_set, &s_full, [&](size_t cell) { return mk_atomic_add(&cell_count[cell], 1u); },
                    [&](bool want, size_t cell) { return wave_rank_in_cell(want, (unsigned)cell, cell_count); });
     if (classes) {
@@ -922,7 +962,7 @@ MK_KERNEL(256) void k_bin_solo(GridDesc g, const float* __restrict__ coords, con
 // `tab` = the class table in registers (wave-uniform), so that a lookup is NCLS register compares.
 // The atom's channels come from the compact description the binning parked (w0 bits + nibble mask): one table look-up
 // and one multiply give the 8 class ids; only atoms with several distinct sigmas go back to their sigma row.
-template <typename SigT>
+template <typename SigT, bool TOPO = false>
 MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* __restrict__ sigmas,
                         const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_cls,
                         float4* __restrict__ rec_pos, float4* __restrict__ rec_w,
@@ -930,6 +970,12 @@ MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* 
 {
     float4 pos = mk_tmp_load(&tmp_pos[t]);
     const size_t a = g.img_cap == 1 ? t : t / (size_t)g.img_cap;
+    if constexpr (TOPO) {                                            // the binning parked the topology's class ids: a pure permutation
+        rec_pos[slot] = pos;
+        const unsigned* __restrict__ ids = reinterpret_cast<const unsigned*>(tmp_cls) + a * (size_t)g.G;
+        for (int gq = 0; gq < g.G; ++gq) rec_cls[(size_t)gq * g.M + slot] = mk_tmp_load(&ids[gq]);
+        return;
+    }
     if (g.reach_tau > 0.f) {                                         // tolerance-aware reach (wave-uniform; off by default)
         // the atom's widest sigma -> the largest reach level whose radius still covers tau / w_min (an entry is worth
         // less than the tolerance beyond it); the level rides in the two spare bits of the packed cell word
@@ -985,7 +1031,7 @@ MK_DEV void fill_record(const GridDesc& g, size_t t, unsigned slot, const SigT* 
     }
 }
 
-template <typename SigT, bool SHARED = false>
+template <typename SigT, bool SHARED = false, bool TOPO = false>
 __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, const SigT* __restrict__ sigmas,
                                const unsigned* __restrict__ cell_start,
                                const float4* __restrict__ tmp_pos, const uint2* __restrict__ tmp_idx,
@@ -1009,12 +1055,85 @@ __attribute__((amdgpu_num_vgpr(24))) MK_KERNEL(256) void k_bin_fill(GridDesc g, 
         if (t >= (size_t)g.M) continue;
         const uint2 ix = mk_tmp_load(&tmp_idx[t]);
         if (ix.x == TMP_UNUSED) continue;
-        const bool general = g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY;
+        const bool general = !TOPO && (g.force_general || cls_table[CLS_OVERFLOW] != CLS_EMPTY);
         unsigned tab[NCLS];
 #pragma unroll
-        for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
-        fill_record<SigT>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, tmp_cls, rec_pos, rec_w, rec_cls, tab, general);
+        for (int i = 0; i < NCLS; ++i) tab[i] = TOPO ? 0u : cls_table[i];
+        fill_record<SigT, TOPO>(g, t, cell_start[ix.x] + ix.y, sigmas, tmp_pos, tmp_cls, rec_pos, rec_w, rec_cls, tab, general);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Topology (round 5): what the pre-pass derives from the SIGMAS alone -- an atom's compact channel words,
+// the sigma classes, its class ids, whether any sigma is wide enough for the exact cut-off fix-up -- is the same for every
+// frame of a trajectory (the sigmas depend on the topology only, voxeldescriptors.py:332-335).  Built once per molecule and
+// voxel size by these two kernels (+ k_merge_classes between them); a call that brings the handle (GridDesc::topo_n) bins
+// with k_bin_count<.., TOPO> / k_bin_fill<.., TOPO>: 4 bytes of ids per atom instead of its sigma row, no division, no class
+// discovery, no table look-ups -- the records, and therefore the features, are the plain path's bit for bit (class ids are
+// labels: a minimum over classes does not depend on how they are numbered).
+// ------------------------------------------------------------------------------------------------
+template <typename SigT>
+MK_KERNEL(256) void k_topology_classes(const SigT* __restrict__ sigmas, long long n, int C, int G, double w_scale,
+                                       uint2* __restrict__ cw_out /* [n, G] */, unsigned* __restrict__ block_sets)
+{
+    __shared__ unsigned s_set[CLS_BLOCK_SET];
+    __shared__ unsigned s_full;
+    if (threadIdx.x < CLS_BLOCK_SET) s_set[threadIdx.x] = CLS_EMPTY;
+    if (threadIdx.x == 0) s_full = 0u;
+    mk_block_sync();
+    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = a < n;
+    for (int c0 = 0; c0 < C; c0 += CHG) {                            // (uniform: registration is wave-cooperative)
+        unsigned wb[CHG];
+        float w[CHG];
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) w[j] = mk_inf();
+        uint2 cw = make_uint2(CLS_EMPTY, 0u);
+        if (act) {
+            cw = atom_channel_w(sigmas + (size_t)a * C, c0, C, w_scale, w);
+            cw_out[(size_t)a * G + (c0 / CHG)] = cw;
+        }
+#pragma unroll
+        for (int j = 0; j < CHG; ++j) wb[j] = (w[j] < mk_inf()) ? mk_float_bits(w[j]) : CLS_EMPTY;
+        wave_register_classes(cw.x, cw.y == ATOM_MULTI_SIGMA, wb, s_set, &s_full);
+    }
+    mk_block_sync();
+    if (threadIdx.x < CLS_BLOCK_SET)
+        block_sets[(size_t)blockIdx.x * CLS_BLOCK_SET + threadIdx.x] = s_full ? CLS_TOO_MANY : s_set[threadIdx.x];
+}
+
+template <typename SigT>
+MK_KERNEL(256) void k_topology_ids(const SigT* __restrict__ sigmas, const uint2* __restrict__ cw_in, const unsigned* __restrict__ cls_table,
+                                   long long n, int C, int G, double w_scale, float w_exact_max,
+                                   unsigned* __restrict__ ids_out /* [n, G] */, int* __restrict__ flags /* |= 1: some sigma is wide */)
+{
+    const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    unsigned tab[NCLS];
+#pragma unroll
+    for (int i = 0; i < NCLS; ++i) tab[i] = cls_table[i];
+    auto class_of = [&](unsigned bits) {
+        unsigned id = 0;
+#pragma unroll
+        for (int i = 0; i < NCLS; ++i) id = (tab[i] == bits) ? (unsigned)(i + 1) : id;
+        return id;
+    };
+    bool wide = false;
+    for (int gq = 0; gq < G; ++gq) {
+        const uint2 cw = cw_in[(size_t)a * G + gq];
+        unsigned ids = 0u;
+        if (cw.y != ATOM_MULTI_SIGMA) {
+            ids = class_of(cw.x) * cw.y;                             // ids <= 15: no carry between nibbles (fill_record's rule)
+            wide |= cw.x != CLS_EMPTY && mk_uint_as_float(cw.x) < w_exact_max;
+        } else {
+            float w[CHG];
+            atom_channel_w(sigmas + (size_t)a * C, gq * CHG, C, w_scale, w);
+            for (int c = 0; c < CHG; ++c)
+                if (w[c] < mk_inf()) { ids |= class_of(mk_float_bits(w[c])) << (4 * c); wide |= w[c] < w_exact_max; }
+        }
+        ids_out[(size_t)a * G + gq] = ids;
+    }
+    if (wide) mk_atomic_or(flags, 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1778,7 +1897,7 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
                 use_list = nsurv <= (unsigned)SURV_CAP;
                 mk_block_sync();                              // the list is read by other lanes than wrote it
                 if (use_list) {
-                    for_each_survivor(IntC<0>{}, count_entry);
+                    if (!(MK_DIAG & 32)) for_each_survivor(IntC<0>{}, count_entry);
 #pragma unroll
                     for (int cb = 0; cb < SURV_REGS; ++cb) {              // the codes leave the z array before entries go in
                         const unsigned i = (unsigned)(cb * WAVE + lane);
@@ -1980,7 +2099,8 @@ MK_DEV void voxelize_tile(const GridDesc& g, const unsigned lt, const int gq, co
             auto place_entry = [&](bool surv, unsigned, float ex, float ey, float ez, unsigned ids, int pk) {
                 place_at(surv, ex, ey, ez, ids, x_reach(ex, ey, ez, pk));
             };
-            if (use_list) {
+            if (MK_DIAG & 64) {
+            } else if (use_list) {
                 for_each_survivor(IntC<1>{}, place_entry);
             } else if (use_sv) {
                 for (unsigned i = (unsigned)(wv * WAVE + lane); i < nsv; i += (unsigned)(TEAM * WAVE))     // per-lane trip count: no collectives inside
@@ -2622,8 +2742,9 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, in
     double L[3] = {1.0, 1.0, 1.0};
     if (g.pbc) { L[0] = (double)box[3 * (size_t)b]; L[1] = (double)box[3 * (size_t)b + 1]; L[2] = (double)box[3 * (size_t)b + 2]; }
     double best = 0.0;
+    const long long sshift = g.topo_n ? atom_offsets[b] : 0;              // topology calls: the molecule's one sigma matrix
     for (long long a = atom_offsets[b] + lane; a < atom_offsets[b + 1]; a += WAVE) {
-        const double sg = (double)sigmas[(size_t)a * g.C + c];
+        const double sg = (double)sigmas[(size_t)(a - sshift) * g.C + c];
         if (!(sg != 0.0) || sg != sg) continue;                            // occupancy_utils.pyx:55-56 (a NaN is never stored)
         float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
         if (affine != nullptr) {                                           // rounded to float32 like the binning (bin_atom)
@@ -2677,7 +2798,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
         const int b = (int)blk;
         a_lo = atom_offsets[b]; a_hi = atom_offsets[b + 1];
         if (summary != nullptr) {
-            const unsigned t = lane < CLS_TABLE_WORDS ? summary[(size_t)b * CLS_TABLE_WORDS + lane] : CLS_EMPTY;
+            const unsigned t = lane < CLS_TABLE_WORDS ? summary[(g.topo_n ? (size_t)0 : (size_t)b) * CLS_TABLE_WORDS + lane] : CLS_EMPTY;   // (a topology call: ONE table)
             const bool maybe = lane == CLS_OVERFLOW ? t != CLS_EMPTY : wide_bits(t);   // overflowed table: look at the atoms
             if (mk_ballot(maybe) == 0ull) return;
         }
@@ -2692,15 +2813,17 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
     const double R = CUTOFF_A_KERNEL / g.res, R2 = R * R, band = R2 * EXACT_BAND_REL, Rb = sqrt(R2 + band);
     const int nvox[3] = {g.nx, g.ny, g.nz};
     int b_hint = per_item ? (int)blk : item_of_atom(atom_offsets, g.B, a_lo, 0);
+    // a topology call (always per item): the compact channel words and the sigma rows are the MOLECULE's, indexed inside the item
+    const long long sshift = g.topo_n ? a_lo : 0;
     for (long long base = a_lo; base < a_hi; base += WAVE) {               // wave-uniform
         const long long a_mine = base + lane;
         bool wide = false;
         if (a_mine < a_hi) {
             for (int gq = 0; gq < g.G; ++gq) {
-                const uint2 cw = tmp_cls[(size_t)a_mine * g.G + gq];
+                const uint2 cw = tmp_cls[(size_t)(a_mine - sshift) * g.G + gq];
                 if (cw.y == ATOM_MULTI_SIGMA) {
                     for (int c = gq * CHG; c < g.C && c < gq * CHG + CHG; ++c)
-                        wide |= sigma_to_w(sigmas[(size_t)a_mine * g.C + c], g.w_scale) < wmax;
+                        wide |= sigma_to_w(sigmas[(size_t)(a_mine - sshift) * g.C + c], g.w_scale) < wmax;
                 } else wide |= wide_bits(cw.x);
             }
         }
@@ -2764,7 +2887,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
                             const int vz = (int)mk_readlane((unsigned)(int)iz, hl);
                             if (feedback != nullptr && lane == 0) feedback[FB_TAIL_WROTE] = seq;   // (the host may have read the tile kernel's values already)
                             for (int c = 0; c < g.C; ++c)                  // the atom's wide channels
-                                if (sigma_to_w(sigmas[(size_t)a * g.C + c], g.w_scale) < wmax)
+                                if (sigma_to_w(sigmas[(size_t)(a - sshift) * g.C + c], g.w_scale) < wmax)
                                     exact_recompute<SigT>(g, b, vx, vy, vz, c, coords, atom_offsets, sigmas, origins, box, affine, out, s_best);
                         }
                     }

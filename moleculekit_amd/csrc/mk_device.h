@@ -143,6 +143,8 @@ MK_DEV void mk_tmp_store(float4* p, float4 v) { __builtin_nontemporal_store(mk_v
 MK_DEV void mk_tmp_store(uint2* p, uint2 v) { __builtin_nontemporal_store(mk_v2u_{v.x, v.y}, reinterpret_cast<mk_v2u_*>(p)); }
 MK_DEV float4 mk_tmp_load(const float4* p) { const mk_v4f_ v = __builtin_nontemporal_load(reinterpret_cast<const mk_v4f_*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
 MK_DEV uint2 mk_tmp_load(const uint2* p) { const mk_v2u_ v = __builtin_nontemporal_load(reinterpret_cast<const mk_v2u_*>(p)); return make_uint2(v.x, v.y); }
+MK_DEV void mk_tmp_store(unsigned* p, unsigned v) { __builtin_nontemporal_store(v, p); }
+MK_DEV unsigned mk_tmp_load(const unsigned* p) { return __builtin_nontemporal_load(p); }
 template <bool STREAM>
 MK_DEV void mk_store_result(float4* p, float4 v)
 {

@@ -9,7 +9,8 @@
 //
 //   MK_DIAG=<bits>     compile parts of voxelize_tile OUT to time what they cost (WRONG VALUES by construction):
 //                      1 pair loops, 2 class flushes, 4 epilogue arithmetic, 8 placement + all class work,
-//                      16 cull / histogram traversal                            (profiles/r4_tile_time_map.txt)
+//                      16 cull / histogram traversal, 32 the histogram pass over the survivor list, 64 the placement
+//                      traversal (profiles/r4_tile_time_map.txt, profiles/r5_tile_instruction_map.txt)
 //   MK_PHASE_TIMERS    cycle counters around the phases of a tile wave (tools/phase_timers.py); with MK_BIN_TIMERS the
 //                      sections of k_bin_direct instead (tools/bin_timers.py).  Values stay right, timing does not.
 // Experiments that were measured and ruled out (single-entry groups evaluated directly, the rolled channel loop, the

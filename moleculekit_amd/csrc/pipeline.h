@@ -44,6 +44,21 @@ enum WsSlot {
 
 constexpr double CUTOFF_A = 5.0;            // occupancy_utils.pyx:53 (d^2 < 25)
 
+// A molecule's topology (round 5; kernels.h "Topology"): everything the pre-pass derives from the sigmas alone, on the device.
+// Built once (run_topology_build); a lattice call that brings it voxelizes items that are each ONE set of coordinates of that
+// molecule -- the frames of a trajectory -- without touching sigmas, classes or table look-ups again.
+struct TopologyDev {
+    long long n = 0;                        // atoms of the molecule
+    int C = 0, G = 0, sigmas_f64 = 0;
+    double voxelsize = 0.0;                 // w = voxelsize^2 / sigma^2: the handle is for one voxel size
+    const unsigned* ids = nullptr;          // [n, G] class ids (8 x 4 bits per word)
+    const uint2* cw = nullptr;              // [n, G] compact channel words (what k_tail's fix-up waves look at first)
+    const void* sigmas = nullptr;           // [n, C] the library's own copy (the exact fix-up recomputes from it)
+    const unsigned* table = nullptr;        // [CLS_TABLE_WORDS] the class table
+    bool overflow = false;                  // more than NCLS distinct sigmas: no class ids (creation reports it, calls are refused)
+    bool wide = false;                      // some sigma is wide enough for the exact cut-off fix-up (GridDesc::w_exact_max)
+};
+
 struct LatticeProblem {
     int B = 0;
     long long total_atoms = 0;
@@ -73,6 +88,7 @@ struct LatticeProblem {
     const float* box = nullptr;
     const double* affine = nullptr;        // optional [B,12]: rotation (row-major 3x3) + translation per item
     float* out = nullptr;
+    const TopologyDev* topo = nullptr;      // every item is topo->n atoms of that molecule (checked on the device: MK_ERR_TOPOLOGY)
 };
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -211,6 +227,8 @@ struct TailArgs {
     int team_waves = 0;                     // waves per tile of the team kernel (0 = by the number of tiles; 4, 8, 16: K = 4 only)
     unsigned* solo_counts = nullptr;        // a call binned by k_bin_solo: its counters (+ control words), zeroed by k_tail
     unsigned solo_n = 0;
+    const void* sigmas = nullptr;           // != nullptr: the sigma matrix k_tail recomputes from (a topology call: the handle's copy)
+    int sigmas_f64 = 0;
 };
 
 template <int K, int T, class BE>
@@ -265,7 +283,9 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
                              P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls, ta.solo_counts, ta.solo_n,
                              (unsigned*)ctab, g.force_general ? 0u : P.seq, ta.fix_jobs);
         };
-        st = P.sigmas_f64 ? tail(k_tail<K, E, double>, (const double*)P.sigmas) : tail(k_tail<K, E, float>, (const float*)P.sigmas);
+        const void* sig = ta.sigmas ? ta.sigmas : P.sigmas;
+        const int sig64 = ta.sigmas ? ta.sigmas_f64 : P.sigmas_f64;
+        st = sig64 ? tail(k_tail<K, E, double>, (const double*)sig) : tail(k_tail<K, E, float>, (const float*)sig);
     }
     return st;
 }
@@ -308,6 +328,20 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     // (when the call can be pipelined -- the caller opted in and the batch is big -- items of more than ~1 000 atoms go to
     //  the kernel chain: its pre-pass then hides behind the previous call's tile kernel, the one-launch one never does;
     //  cfg1 x 4096 = 1 639 atoms per item: 2.00 -> 1.93 ms per step; 60-atom items lose 4 % that way)
+    // a topology call (P.topo): the chain with the TOPO binning kernels; what they do not cover -- the general path, the
+    // tolerance-aware reach (it needs every atom's smallest w at fill time) -- is refused, not approximated
+    const bool topo = P.topo != nullptr;
+    if (topo) {
+        if (P.topo->overflow || g.force_general || g.reach_tau > 0.f) {
+            err = "a topology call takes the class-sorted path only: not with more than 15 distinct sigmas, force_general or a value tolerance (use the plain entry point)";
+            return ST_EINVAL;
+        }
+        if (P.topo->C != P.C || P.topo->voxelsize != P.voxelsize || P.topo->n <= 0 || P.total_atoms != (long long)P.B * P.topo->n) {
+            err = "the topology was built for another channel count / voxel size, or the call is not n_items x its atom count long";
+            return ST_EINVAL;
+        }
+    }
+    g.topo_n = topo ? P.topo->n : 0;
     const bool chain_pays = be.pipelining_possible() && P.total_atoms >= 200000 && P.total_atoms > 1024LL * (long long)g.B;
     const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
@@ -329,9 +363,9 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     // chose a pre-pass (prepass_mode) or it is a ligand-sized call of the workgroup-per-item tile kernel; direct == 2
     // forces it for any size (tests)
     const bool items_sized = P.tile_items != 0 && P.total_atoms <= 96LL * (long long)g.B && g.ntiles <= 512;
-    const bool solo = direct_geom && (unsigned long long)P.total_atoms * (unsigned)g.B <= (1ull << 22) &&
+    const bool solo = !topo && direct_geom && (unsigned long long)P.total_atoms * (unsigned)g.B <= (1ull << 22) &&
                       (P.direct == 2 || (P.direct != 0 && P.prepass_mode < 0 && team && !(items_sized && P.tile_team <= 0 && g.ncell + 1 <= ITEM_HIST)));
-    const bool per_item = !solo && (g.ncell + 1 <= ITEM_HIST) && P.prepass_mode != 0 &&
+    const bool per_item = !topo && !solo && (g.ncell + 1 <= ITEM_HIST) && P.prepass_mode != 0 &&
                           (P.prepass_mode == 1 || (P.total_atoms <= 4096LL * (long long)g.B && !chain_pays));
     g.cls_per_item = per_item ? 1 : 0;
     const int set = be.acquire_set(P.total_atoms >= 200000 && !per_item && !solo);
@@ -364,7 +398,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         // k_bin_direct for a big call: whenever asked for (1), and by itself (-1) when the call is NOT pipelined -- in order
         // the one-pass form is 3 % faster (the class table of the previous call on the workspace serves; the chain behind
         // it leaves at once), beside the previous call's tile kernel it gains nothing
-        const bool direct_big = !per_item && direct_geom && (P.direct == 1 || (P.direct < 0 && !be.set_is_pipelined(set) && P.total_atoms >= 200000));
+        const bool direct_big = !topo && !per_item && direct_geom && (P.direct == 1 || (P.direct < 0 && !be.set_is_pipelined(set) && P.total_atoms >= 200000));
         const bool direct = (solo || direct_big) && slots <= 0xFFFF0000ull;
         if (solo && !direct) { err = "internal: the one-launch pre-pass does not fit its record slots"; return ST_EINVAL; }
         if (direct) {
@@ -395,6 +429,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
             if ((st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;
         }
     }
+    void* const table_before = cs.tptr;
     cs.tptr = nullptr;                              // (a call that fails half-way leaves no table behind)
     if (cs.ptr != count) { cs.ptr = count; cs.clean = 0; }
     size_t clean_after = cs.clean;
@@ -449,6 +484,10 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
         fix_summary = g.force_general ? nullptr : (const unsigned*)bsets;
         fix_waves = P.total_atoms > 0 ? nblk : 0u;
+        if (topo) {                                 // fix-up jobs per ITEM, all looking at the one table first -- or none at all
+            fix_summary = P.topo->table;
+            fix_waves = P.topo->wide ? (unsigned)g.B : 0u;
+        }
         const unsigned* dfail = g.direct_words ? g.direct_words + DIRECT_FAILED : nullptr;
         if (solo) {
             st = P.sigmas_f64 ? be.launch(k_bin_solo<double>, agrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const double*)P.sigmas, P.origins,
@@ -470,15 +509,21 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                 return be.launch(kern, cgrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine,
                                  (unsigned*)count, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (unsigned*)bsets, (int*)eflag, nblk);
             };
-            if (fallback_only) {                             // (open boundaries: the direct layouts have no periodic form)
+            if (topo) {                                      // (the ids stand where the sigmas would: bin_atom<.., TOPO>)
+                auto tbin = [&](auto kern) {
+                    return be.launch(kern, cgrid, ablk, g, P.coords, P.atom_offsets, P.total_atoms, (const float*)P.topo->ids, P.origins, P.box, P.affine,
+                                     (unsigned*)count, (float4*)tpos, (uint2*)tidx, (uint2*)tcls, (unsigned*)bsets, (int*)eflag, nblk);
+                };
+                st = g.pbc ? tbin(k_bin_count<float, 1, false, true>) : tbin(k_bin_count<float, 0, false, true>);
+            } else if (fallback_only) {                             // (open boundaries: the direct layouts have no periodic form)
                 st = P.sigmas_f64 ? bin(k_bin_count<double, 0, true>, (const double*)P.sigmas) : bin(k_bin_count<float, 0, true>, (const float*)P.sigmas);
             } else if (P.sigmas_f64) st = g.pbc ? bin(k_bin_count<double, 1>, (const double*)P.sigmas) : bin(k_bin_count<double, 0>, (const double*)P.sigmas);
             else              st = g.pbc ? bin(k_bin_count<float, 1>, (const float*)P.sigmas) : bin(k_bin_count<float, 0>, (const float*)P.sigmas);
             if (st) return st;
         }
         // sigma classes (per-block sets -> class table) and the scan of the cell counts, fused two launches deep
-        const bool do_classes = P.total_atoms > 0 && !g.force_general;
-        if (!do_classes && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
+        const bool do_classes = P.total_atoms > 0 && !g.force_general && !topo;
+        if (!do_classes && !topo && (st = be.fill(ctab, 0xff, CLS_TABLE_WORDS * sizeof(unsigned)))) return st;   // nothing to register
         if (!g.direct_words && ncells <= SMALL_PREPASS_MAX_CELLS && nblk <= SMALL_PREPASS_MAX_BLOCKS) {
             // a small call (one grid): one launch instead of three dependent ones
             if ((st = be.launch(k_prepass_small, dim3(1), dim3(SMALL_PREPASS_THREADS), (const unsigned*)bsets, do_classes ? nblk : 0u,
@@ -503,7 +548,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
                 return be.launch(kern, fgrid, ablk, g, sig, (const unsigned*)start, (const float4*)tpos, (const uint2*)tidx, (const uint2*)tcls,
                                  (float4*)rpos, (float4*)rw, (unsigned*)rcls, (const unsigned*)ctab, nfblk);
             };
-            if (fallback_only) st = P.sigmas_f64 ? fill(k_bin_fill<double, true>, (const double*)P.sigmas) : fill(k_bin_fill<float, true>, (const float*)P.sigmas);
+            if (topo) st = fill(k_bin_fill<float, false, true>, (const float*)nullptr);
+            else if (fallback_only) st = P.sigmas_f64 ? fill(k_bin_fill<double, true>, (const double*)P.sigmas) : fill(k_bin_fill<float, true>, (const float*)P.sigmas);
             else               st = P.sigmas_f64 ? fill(k_bin_fill<double>, (const double*)P.sigmas) : fill(k_bin_fill<float>, (const float*)P.sigmas);
             if (st) return st;
         }
@@ -525,7 +571,8 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
     ta.fix_jobs = fix_waves;
     ta.fix_waves = fix_waves < 8192u ? fix_waves : 8192u;         // (the fix-up waves share the jobs: see k_tail)
-    ta.other_words = dother; ta.per_item = per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = tcls;
+    ta.other_words = dother; ta.per_item = (per_item || topo) ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = topo ? (const void*)P.topo->cw : tcls;
+    if (topo) { ctab = const_cast<unsigned*>(P.topo->table); ta.sigmas = P.topo->sigmas; ta.sigmas_f64 = P.topo->sigmas_f64; }
     ta.team_waves = (P.tile_team == 4 || P.tile_team == 8 || P.tile_team == 16) ? P.tile_team : 0;
     if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(DIRECT_HEAD + (ncells << g.cnt_shift)); }
     be.hot_begin(flavour, g.K, ECAP_TIER[tier]);
@@ -535,7 +582,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (!st) {
         cs.clean = clean_after;
         cs.wclean = true;
-        cs.tptr = ctab;                             // every pre-pass leaves a whole table in the buffer
+        cs.tptr = topo ? table_before : ctab;       // every pre-pass leaves a whole table in the buffer (a topology call: untouched)
         if (solo) cs.dclean = dbytes;               // k_tail has zeroed them
         if (ta.dense_wgs + ta.fix_waves != 0u) cs.parity ^= 1u;       // k_tail has cleared the other copy: the next call's
     }
@@ -543,6 +590,35 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     be.note_tail_reports(!st && !g.force_general && ta.dense_wgs + ta.fix_waves != 0u && be.feedback_dev() != nullptr && P.seq != 0u);
     be.tile_done(set);
     return st;
+}
+
+// Build a molecule's topology into caller-provided device buffers (cw [n, G] uint2, ids [n, G], table [CLS_TABLE_WORDS],
+// flags [1] int, zeroed by the caller); `d_sigmas` is the library's own copy.  The caller reads table[CLS_OVERFLOW] and
+// flags[0] back once the stream has drained.  Workspace: the class-set slots of set 0.
+template <class BE>
+int run_topology_build(BE& be, const void* d_sigmas, int sigmas_f64, long long n, int C, double voxelsize, uint2* cw, unsigned* ids,
+                       unsigned* table, int* flags, std::string& err)
+{
+    if (n <= 0 || C <= 0) { err = "a topology needs n_atoms > 0 and n_channels > 0"; return ST_EINVAL; }
+    if (!(voxelsize > 0.0) || !std::isfinite(voxelsize)) { err = "voxelsize must be a positive finite number"; return ST_EINVAL; }
+    const int G = ceil_div(C, CHG);
+    const double w_scale = voxelsize * voxelsize, R = CUTOFF_A / voxelsize;
+    const float w_exact_max = (float)(7.647 / (R * R));                     // plan_lattice's rule
+    const unsigned nblk = (unsigned)ceil_div(n, 256), rows_per_block = 128, nl1 = (nblk + rows_per_block - 1) / rows_per_block;
+    void *bsets = nullptr, *l1sets = nullptr;
+    int st;
+    if ((st = be.ensure(WS_CLS_BLOCKS, (size_t)nblk * CLS_BLOCK_SET * sizeof(unsigned), &bsets, 0))) return st;
+    if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, 0))) return st;
+    st = sigmas_f64 ? be.launch(k_topology_classes<double>, dim3(nblk), dim3(256), (const double*)d_sigmas, n, C, G, w_scale, cw, (unsigned*)bsets)
+                    : be.launch(k_topology_classes<float>, dim3(nblk), dim3(256), (const float*)d_sigmas, n, C, G, w_scale, cw, (unsigned*)bsets);
+    if (st) return st;
+    if ((st = be.launch(k_merge_classes, dim3(nl1), dim3(256), (const unsigned*)bsets, nblk, (unsigned)CLS_BLOCK_SET, rows_per_block,
+                        (unsigned*)l1sets, (unsigned*)nullptr))) return st;
+    if ((st = be.launch(k_merge_classes, dim3(1), dim3(256), (const unsigned*)l1sets, nl1, (unsigned)MERGE_SET, nl1, (unsigned*)nullptr, table))) return st;
+    return sigmas_f64 ? be.launch(k_topology_ids<double>, dim3(nblk), dim3(256), (const double*)d_sigmas, (const uint2*)cw, (const unsigned*)table, n, C, G,
+                                  w_scale, w_exact_max, ids, flags)
+                      : be.launch(k_topology_ids<float>, dim3(nblk), dim3(256), (const float*)d_sigmas, (const uint2*)cw, (const unsigned*)table, n, C, G,
+                                  w_scale, w_exact_max, ids, flags);
 }
 
 // Explicit centres: sigma -> w, then the brute-force double-precision kernel.

@@ -125,8 +125,12 @@ class ShardedVoxelizer:
     """
 
     def __init__(self, n_items, bounds, shard, nvoxels, voxelsize, device=None, compute=None, group=None, ctx=None,
-                 pipelined=True):
+                 pipelined=True, shared_sigmas=False):
         import torch
+
+        # shared_sigmas: the items are sets of coordinates of ONE molecule -- the frames of a trajectory (cfg4) --, so everything the
+        # pre-pass derives from the sigmas is built once (a topology handle, include/mkamd_voxel.h (3c)) and only the molecule's own
+        # sigma matrix lives on the device.  Checked here, on the host: every item the same length, every item's rows identical.
 
         # The shard's buffers belong to this object and never change after the upload below has completed: every voxelize
         # call over them is made with the library's per-call promise (Context.promise_inputs, include/mkamd_voxel.h), so
@@ -162,10 +166,38 @@ class ShardedVoxelizer:
             self.device = torch.device("cpu" if device is None else device)
         sig = np.asarray(sigmas)
         sig_dt = np.float64 if sig.dtype == np.float64 else np.float32
+        self._topo = None
+        self._shared = False
+        if shared_sigmas and compute is None and self.n_local > 0:
+            sizes = np.diff(self._offs_host)
+            n0 = int(sizes[0])
+            if n0 > 0 and np.all(sizes == n0):
+                if sig.shape[0] == n0 * self.n_local:                  # the matrix repeated per item: it has to BE a repeat
+                    rows = sig.reshape(self.n_local, n0, -1)
+                    if not all(np.array_equal(rows[0], r) for r in rows[1:]):
+                        raise ValueError("shared_sigmas: the items' sigma rows differ (not frames of one molecule)")
+                    sig = np.ascontiguousarray(rows[0])
+                elif sig.shape[0] != n0:
+                    raise ValueError("shared_sigmas: pass the molecule's [n, C] matrix or its repeat per item")
+                self._shared = True
+            else:
+                raise ValueError("shared_sigmas: every item must have the molecule's atom count")
         self._d = self._upload(dict(coords=(coords, np.float32), offs=(self._offs_host, np.int64), sigmas=(sig, sig_dt),
                                     origins=(np.asarray(origins, dtype=np.float64).reshape(-1, 3), np.float64),
                                     box=(box, np.float32)))
         self._chunk_offs = {}
+        if self._shared:
+            from . import _lib
+            tctx = self._ctx or _lib.default_context(self.device.index if self.device.index is not None else 0)
+            if not getattr(tctx, "_force_general", False) and not getattr(tctx, "_value_tol", 0.0):
+                torch.cuda.current_stream(self.device).synchronize()
+                try:
+                    self._topo = _lib.Topology(tctx, self._d["sigmas"], self.voxelsize)
+                except ValueError:                                     # more than 15 distinct sigmas: the plain call on the repeated matrix
+                    self._topo = None
+            if self._topo is None:
+                self._d["sigmas"] = self._d["sigmas"].repeat(self.n_local, 1).contiguous()
+                self._shared = False
 
     # ---- construction -------------------------------------------------------------------------------------
     @classmethod
@@ -233,8 +265,8 @@ class ShardedVoxelizer:
         ctx = self._ctx or _lib.default_context(self.device.index if self.device.index is not None else 0)
         if self.pipelined:
             ctx.promise_inputs(None)          # resident since _upload's host-side wait: complete, and nobody writes them
-        return batch.voxelize_lattice_torch(coords, offs, sigmas, origins, self.nvoxels, self.voxelsize, box=box,
-                                            max_images=self.max_images, out=out, ctx=ctx)
+        return batch.voxelize_lattice_torch(coords, offs, None if self._topo is not None else sigmas, origins, self.nvoxels, self.voxelsize,
+                                            box=box, max_images=self.max_images, out=out, ctx=ctx, topology=self._topo)
 
     def _items(self, lo, hi):
         """Views of the resident shard for local items [lo, hi) (the rebased offsets are built once per range)."""
@@ -249,7 +281,8 @@ class ShardedVoxelizer:
             if offs is None:
                 offs = torch.as_tensor(self._offs_host[lo:hi + 1] - a0, device=self.device)
                 self._chunk_offs[(lo, hi)] = offs
-        return d["coords"][a0:a1], offs, d["sigmas"][a0:a1], d["origins"][lo:hi], None if d["box"] is None else d["box"][lo:hi]
+        sig = d["sigmas"] if self._shared else d["sigmas"][a0:a1]       # (shared: the molecule's one matrix, the topology stands in for it)
+        return d["coords"][a0:a1], offs, sig, d["origins"][lo:hi], None if d["box"] is None else d["box"][lo:hi]
 
     def voxelize(self, out=None):
         """This rank's shard -> float32 [B_local, V, C] on its device; asynchronous, no collective."""

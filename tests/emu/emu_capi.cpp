@@ -106,6 +106,46 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
     return st;
 }
 
+// mirrors mkamd_topology_create_host + mkamd_voxelize_lattice_topo_dev (capi.hip): the topology of ONE molecule (sigmas [n, C]) built
+// by the product's kernels, then B sets of coordinates of it through run_lattice with P.topo.  *wide_out: the handle's wide flag.
+int emu_voxelize_lattice_topo(int B, const float* coords, const long long* atom_offsets, const void* sigmas, int sigmas_f64, long long n, int C,
+                              const double* origins, const int* nvox, double voxelsize, const float* box, int max_images, int tile_k,
+                              const double* affine, float* features, int* err_flag_out, int* wide_out, int repeat)
+{
+    EmuBackend be;
+    void* eflag = nullptr;
+    be.ensure(WS_ERR, sizeof(int), &eflag);
+    *(int*)eflag = 0;
+    const int G = ceil_div(C, CHG);
+    std::vector<uint2> cw((size_t)n * G);
+    std::vector<unsigned> ids((size_t)n * G, 0xCDCDCDCDu), table(CLS_TABLE_WORDS, 0xCDCDCDCDu);
+    int flags = 0;
+    int st = run_topology_build(be, sigmas, sigmas_f64, n, C, voxelsize, cw.data(), ids.data(), table.data(), &flags, g_err);
+    if (st) return st;
+    TopologyDev T;
+    T.n = n; T.C = C; T.G = G; T.sigmas_f64 = sigmas_f64; T.voxelsize = voxelsize; T.ids = ids.data(); T.cw = cw.data(); T.sigmas = sigmas;
+    T.table = table.data(); T.overflow = table[CLS_OVERFLOW] != CLS_EMPTY; T.wide = (flags & 1) != 0;
+    if (wide_out) *wide_out = T.wide ? 1 : 0;
+    LatticeProblem P;
+    P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;
+    P.nvox[0] = nvox[0]; P.nvox[1] = nvox[1]; P.nvox[2] = nvox[2];
+    P.voxelsize = voxelsize; P.pbc = box ? 1 : 0; P.tile_k = tile_k;
+    if (box && max_images <= 0) {
+        max_images = max_images_from_boxes(box, B, nvox, voxelsize, g_err);
+        if (max_images < 0) return ST_EBOX;
+    }
+    P.max_images = box ? max_images : 1;
+    P.coords = coords; P.atom_offsets = atom_offsets; P.sigmas = nullptr; P.origins = origins;
+    P.box = box; P.affine = affine; P.out = features; P.topo = &T;
+    const size_t nout = (size_t)B * nvox[0] * nvox[1] * nvox[2] * C;
+    for (int r = 0; r < (repeat > 0 ? repeat : 1) && !st; ++r) {
+        for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;
+        st = run_lattice(be, P, g_err);
+    }
+    if (err_flag_out) *err_flag_out = *(int*)be.bufs[WS_ERR];
+    return st;
+}
+
 int emu_occupancy_centers(const double* centers, long long V, const float* coords, long long N,
                           const void* sigmas, int sigmas_f64, int C, const double* box, float* features)
 {

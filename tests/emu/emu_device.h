@@ -251,6 +251,8 @@ MK_DEV void mk_tmp_store(float4* p, float4 v) { *p = v; }
 MK_DEV void mk_tmp_store(uint2* p, uint2 v) { *p = v; }
 MK_DEV float4 mk_tmp_load(const float4* p) { return *p; }
 MK_DEV uint2 mk_tmp_load(const uint2* p) { return *p; }
+MK_DEV void mk_tmp_store(unsigned* p, unsigned v) { *p = v; }
+MK_DEV unsigned mk_tmp_load(const unsigned* p) { return *p; }
 MK_DEV void mk_setprio_high() {}
 MK_DEV unsigned mk_readlane(unsigned v, int lane)
 {

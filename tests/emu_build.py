@@ -78,6 +78,30 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
     return out, err.value
 
 
+def voxelize_lattice_topo(coords, sigmas_one, n_items, origins, nvox, voxelsize, box=None, max_images=0, tile_k=0, affine=None, repeat=1,
+                          atom_offsets=None):
+    """B sets of coordinates of ONE molecule (sigmas_one [n, C]) through the topology path (run_topology_build + run_lattice with
+    P.topo) on the emulated kernels -> (features [B, V, C], device error flag, the handle's wide flag)."""
+    coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
+    sig64 = sigmas_one.dtype == np.float64
+    sigmas_one = np.ascontiguousarray(sigmas_one, np.float64 if sig64 else np.float32)
+    n, C = sigmas_one.shape
+    B = int(n_items)
+    offs = np.ascontiguousarray(np.arange(B + 1, dtype=np.int64) * n if atom_offsets is None else atom_offsets, np.int64)
+    origins = np.ascontiguousarray(origins, np.float64).reshape(B, 3)
+    nvox = np.ascontiguousarray(nvox, np.int32)
+    out = np.empty((B, int(np.prod(nvox)), C), np.float32)
+    bx = None if box is None else np.ascontiguousarray(box, np.float32).reshape(B, 3)
+    err, wide = ctypes.c_int(0), ctypes.c_int(0)
+    st = lib().emu_voxelize_lattice_topo(ctypes.c_int(B), _p(coords), _p(offs), _p(sigmas_one), ctypes.c_int(int(sig64)), ctypes.c_longlong(n),
+                                         ctypes.c_int(C), _p(origins), _p(nvox), ctypes.c_double(voxelsize), _p(bx), ctypes.c_int(max_images),
+                                         ctypes.c_int(tile_k), _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out),
+                                         ctypes.byref(err), ctypes.byref(wide), ctypes.c_int(int(repeat)))
+    if st != 0:
+        raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
+    return out, err.value, bool(wide.value)
+
+
 def choose_tier(forced, feedback):
     return int(lib().emu_choose_tier(ctypes.c_int(forced), _p(np.ascontiguousarray(feedback, np.uint32))))
 

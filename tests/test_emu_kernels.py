@@ -597,3 +597,83 @@ def test_small_calls_take_the_solo_prepass_by_default():
     out, err = E.voxelize_lattice(case["coords"], case["atom_offsets"], case["sigmas"], case["origins"], case["nvoxels"],
                                   case["voxelsize"], direct_words=words, prepass_mode=1)
     assert words[0] == 0xffffffff and np.array_equal(out, _chain(case))        # the caller chose a pre-pass: no direct pass
+
+
+def _frames_of_one_molecule(seed, n, F, C=8, pbc=False, wide=False, multi=False):
+    """F sets of coordinates of one n-atom molecule (a jittering trajectory) + its sigma matrix."""
+    from tests.synth import synth_sigmas
+    rng = np.random.default_rng(seed)
+    sig = synth_sigmas(rng, n).astype(np.float64)
+    if C != 8:
+        sig = np.concatenate([sig, sig[:, : C - 8] * 0.9], axis=1) if C > 8 else sig[:, :C]
+    if wide:
+        sig[::7, 0] = 2.27            # Na: wide enough for the exact cut-off fix-up
+    if multi:
+        sig[::5, 1] = 1.3             # atoms with several distinct sigmas
+        sig[::5, 3] = 1.9
+    base = rng.uniform(-9.0, 9.0, size=(n, 3))
+    frames = np.stack([base + rng.normal(0, 0.4, size=(n, 3)) for _ in range(F)]).astype(np.float32)
+    box = np.tile(np.array([[21.0, 23.0, 22.0]], np.float32), (F, 1)) if pbc else None
+    return frames.reshape(F * n, 3), sig, box
+
+
+@pytest.mark.parametrize("kind", ["plain", "pbc", "wide", "multi", "channels11", "f32"])
+@pytest.mark.parametrize("tile_k", [8, 4])
+def test_topology_calls_are_bit_identical_with_plain_calls(kind, tile_k):
+    """Round 5: frames of ONE molecule voxelized with its topology handle (class ids, channel words, class table
+    and the wide flag built once by k_topology_classes / k_topology_ids; binning by k_bin_count<.., TOPO> / k_bin_fill<.., TOPO>)
+    against the plain call with the sigma matrix repeated per frame: the same records, the same features, bit for bit -- open
+    and periodic frames, wide sigmas (the exact fix-up reads the molecule's sigmas by the index inside the item), atoms with
+    several sigmas, two channel groups, float32 sigmas; repeated calls on one workspace."""
+    if tile_k == 4 and kind in ("multi", "channels11", "f32"):
+        pytest.skip("covered with K=8 (emulation time)")
+    n, F = 230, 3
+    coords, sig, box = _frames_of_one_molecule(11, n, F, C=11 if kind == "channels11" else 8, pbc=kind == "pbc", wide=kind == "wide",
+                                               multi=kind == "multi")
+    if kind == "f32":
+        sig = sig.astype(np.float32)
+    origins = np.tile([[-10.0, -11.0, -9.5]], (F, 1))
+    nv = [20, 22, 19]
+    offs = np.arange(F + 1) * n
+    plain, e0 = E.voxelize_lattice(coords, offs, np.tile(sig, (F, 1)), origins, nv, 1.0, box=box, tile_k=tile_k, prepass_mode=0)
+    topo, e1, wide = E.voxelize_lattice_topo(coords, sig, F, origins, nv, 1.0, box=box, tile_k=tile_k, repeat=2)
+    assert e0 == 0 and e1 == 0 and wide == (kind in ("wide", "multi"))        # (1.9 A and 2.27 A are wider than 1.81 A)
+    assert np.array_equal(plain, topo)
+    if kind == "wide":                       # and the fix-up really ran on this case: values differ from a run without the wide atoms' exactness
+        assert np.abs(plain.astype(np.float64) - oracle_lattice(coords, offs, np.tile(sig, (F, 1)), origins, np.array(nv), 1.0, box)).max() <= TOL
+
+
+def test_topology_call_with_an_item_of_another_length_is_flagged():
+    """every item must be the topology's atom count long: checked on the device (MK_ERR_TOPOLOGY = 8), not assumed"""
+    n, F = 100, 3
+    coords, sig, _ = _frames_of_one_molecule(3, n, F)
+    offs = np.array([0, n, 2 * n - 10, 3 * n])          # the right total, the wrong split
+    origins = np.tile([[-10.0, -10.0, -10.0]], (F, 1))
+    _, err, _ = E.voxelize_lattice_topo(coords, sig, F, origins, [20, 20, 20], 1.0, atom_offsets=offs)
+    assert err & 8
+
+
+def test_periodic_image_ranges_without_divisions_are_the_quotients():
+    """bin_atom forms the image range from a single-precision reciprocal of the box length and falls back to the double-precision
+    quotient within 1e-5 of a whole number: atoms placed so that (position + reach) / L is a whole number +- 1e-7 ... 1e-3 must bin
+    exactly like the reference composition says (the features of the periodic call == the oracle's minimum image)."""
+    rng = np.random.default_rng(8)
+    L = np.array([24.0, 26.0, 25.0], np.float32)
+    nv = np.array([30, 30, 30])                          # a grid wider than the box: several images per atom
+    origin = np.array([[0.0, 0.0, 0.0]])
+    Rp = 5.001
+    pos = []
+    for k in range(-1, 2):
+        for eps in (0.0, 1e-7, -1e-7, 1e-5, -1e-5, 1e-3, -1e-3):
+            for ax in range(3):
+                p = rng.uniform(2.0, 20.0, 3)
+                p[ax] = -Rp - (k + eps) * float(L[ax])                       # (-Rp - p) / L = k + eps
+                pos.append(p.copy())
+                p[ax] = (nv[ax] - 1) + Rp - (k + eps) * float(L[ax])         # (n - 1 + Rp - p) / L = k + eps
+                pos.append(p.copy())
+    coords = np.array(pos, np.float32)
+    sig = np.zeros((len(coords), 8)); sig[:, 7] = 1.7; sig[::2, 0] = 1.55
+    got, err = E.voxelize_lattice(coords, [0, len(coords)], sig, origin, nv, 1.0, box=L[None], prepass_mode=0)
+    assert err == 0
+    exp = oracle_lattice(coords, np.array([0, len(coords)]), sig, origin, nv, 1.0, L[None])
+    assert np.abs(got.astype(np.float64) - exp).max() <= TOL

@@ -642,3 +642,107 @@ def test_cfg4_full_count_streamed_from_xtc_device_decode_equals_host_decode(hip_
     finally:
         hip_ctx.set_tile_k(0)
     assert np.array_equal(alone[0].cpu().numpy(), dev_keep[9999])
+
+
+def test_topology_calls_are_bitwise_the_plain_calls_and_refuse_what_they_cannot_serve(hip_ctx):
+    """Round 5: frames of one molecule through a topology handle (include/mkamd_voxel.h (3c)) against the plain
+    call on the sigma matrix repeated per frame -- cfg4's shape at a reduced count (periodic, 30 000 atoms, 48^3), open frames, a
+    molecule with wide sigmas (the exact fix-up reads the handle's sigmas) and two channel groups: every bit the same; pipelined by
+    promise like the plain call; an item of the wrong length is detected on the device; sigmas that the caller changes after the
+    handle was built do not matter (the library keeps its own copy); what a topology call cannot serve is refused."""
+    import torch
+    from moleculekit_amd import _lib, batch
+    from tests.synth import synth_config, synth_sigmas
+    dev = torch.device("cuda", hip_ctx.device)
+    t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+    cases = []
+    p = synth_config(4, 12)                                            # twelve cfg4 frames
+    n = int(p["atom_offsets"][1])
+    cases.append(("cfg4", p["coords"], p["sigmas"][:n], 12, grid_origin(p["centers"][0], p["boxsize"], 1.0), p["box"], np.float64))
+    rng = np.random.default_rng(15)
+    n2, F2 = 4000, 7
+    sig = synth_sigmas(rng, n2)
+    sig[::9, 6] = 2.27
+    sig = np.concatenate([sig, sig[:, :3] * 0.8], axis=1)              # 11 channels, wide sigmas, atoms with several sigmas
+    base = rng.uniform(-14, 14, size=(n2, 3))
+    xyz = np.concatenate([base + rng.normal(0, 0.5, size=(n2, 3)) for _ in range(F2)]).astype(np.float32)
+    cases.append(("wide11", xyz, sig, F2, (np.array([-13.0, -12.0, -13.5]), np.array([26, 25, 27])), None, np.float32))
+    for name, coords, sig1, F, (o, nv), box, sdt in cases:
+        n = sig1.shape[0]
+        d_xyz, d_offs = t(coords, np.float32), t(np.arange(F + 1) * n, np.int64)
+        d_org = t(np.tile(o, (F, 1)), np.float64)
+        d_box = None if box is None else t(box, np.float32)
+        d_sig1 = t(sig1, sdt)
+        plain = batch.voxelize_lattice_torch(d_xyz, d_offs, d_sig1.repeat(F, 1).contiguous(), d_org, nv, 1.0, box=d_box, ctx=hip_ctx)
+        topo = _lib.Topology(hip_ctx, d_sig1, 1.0)
+        assert topo.has_wide_sigmas == (name == "wide11") and topo.n_atoms == n
+        d_sig1.zero_()                                                 # the caller's sigmas may change or go away: the handle has its own
+        got = batch.voxelize_lattice_torch(d_xyz, d_offs, None, d_org, nv, 1.0, box=d_box, ctx=hip_ctx, topology=topo)
+        assert torch.equal(plain, got), name
+        # promised (pipelined) calls, back to back, and from a host-side handle
+        topo_h = _lib.Topology(hip_ctx, np.asarray(sig1, dtype=sdt), 1.0)
+        before = hip_ctx.pipelined_calls()
+        outs = []
+        for _ in range(3):
+            hip_ctx.promise_inputs(None)
+            outs.append(batch.voxelize_lattice_torch(d_xyz, d_offs, None, d_org, nv, 1.0, box=d_box, ctx=hip_ctx, topology=topo_h))
+        assert all(torch.equal(plain, x) for x in outs), name
+        if coords.shape[0] >= 200000:
+            assert hip_ctx.pipelined_calls() > before
+        # the wrong split of the right total: flagged by the device, reported at the next synchronize
+        bad = np.arange(F + 1) * n
+        bad[1] -= 5
+        batch.voxelize_lattice_torch(d_xyz, t(bad, np.int64), None, d_org, nv, 1.0, box=d_box, ctx=hip_ctx, topology=topo)
+        with pytest.raises(ValueError, match="topology"):
+            hip_ctx.synchronize()
+        with pytest.raises(ValueError, match="atom count"):             # ... and the wrong total on the host already
+            batch.voxelize_lattice_torch(d_xyz[:-3], d_offs, None, d_org, nv, 1.0, box=d_box, ctx=hip_ctx, topology=topo)
+        with pytest.raises(ValueError, match="voxel size"):
+            batch.voxelize_lattice_torch(d_xyz, d_offs, None, d_org, nv, 0.5, box=d_box, ctx=hip_ctx, topology=topo)
+        hip_ctx.set_force_general(True)
+        try:
+            with pytest.raises(ValueError, match="class-sorted path only"):
+                batch.voxelize_lattice_torch(d_xyz, d_offs, None, d_org, nv, 1.0, box=d_box, ctx=hip_ctx, topology=topo)
+        finally:
+            hip_ctx.set_force_general(False)
+        assert torch.equal(batch.voxelize_lattice_torch(d_xyz, d_offs, None, d_org, nv, 1.0, box=d_box, ctx=hip_ctx, topology=topo), plain)
+        topo.close(); topo_h.close()
+    with pytest.raises(ValueError, match="15 distinct"):               # no class ids to reuse
+        _lib.Topology(hip_ctx, np.tile(np.linspace(1.0, 2.9, 20)[:, None], (1, 8)), 1.0)
+
+
+def test_streamed_and_sharded_frame_drivers_use_the_topology_and_stay_bitwise(hip_ctx):
+    """iterVoxelizeTrajectory and ShardedVoxelizer(shared_sigmas=True) build a topology handle for their molecule by construction:
+    the same features as with the handle switched off (the sigma matrix repeated per frame), bit for bit."""
+    import torch
+    from moleculekit_amd import batch
+    from moleculekit_amd.distributed import ShardedVoxelizer
+    from tests.synth import synth_config
+    p = synth_config(4, 10)
+    n = int(p["atom_offsets"][1])
+    coords = np.ascontiguousarray(np.transpose(p["coords"].reshape(10, n, 3), (1, 2, 0)))          # Molecule.coords layout [N, 3, F]
+    box = np.ascontiguousarray(p["box"].T)
+    kw = dict(box=box, chunk=4, ctx=hip_ctx)
+    center, boxsize = p["centers"][0], p["boxsize"]
+    with_topo = torch.cat([f for _, f in batch.iterVoxelizeTrajectory(coords, p["sigmas"][:n], center, boxsize, 1.0, **kw)])
+    batch.USE_TOPOLOGY = False
+    try:
+        without = torch.cat([f for _, f in batch.iterVoxelizeTrajectory(coords, p["sigmas"][:n], center, boxsize, 1.0, **kw)])
+    finally:
+        batch.USE_TOPOLOGY = True
+    assert torch.equal(with_topo, without) and float(with_topo.max()) > 0.5
+    o, nv = grid_origin(center, boxsize, 1.0)
+    origins = np.tile(o, (10, 1))
+    dev = torch.device("cuda", hip_ctx.device)
+    sv = ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0, box=p["box"], device=dev, ctx=hip_ctx,
+                                    shared_sigmas=True)
+    assert sv._topo is not None and tuple(sv._d["sigmas"].shape) == (n, 8)
+    plain = ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], p["sigmas"], origins, nv, 1.0, box=p["box"], device=dev, ctx=hip_ctx)
+    assert plain._topo is None
+    a, b = sv.voxelize(), plain.voxelize()
+    assert torch.equal(a, b)
+    # (ten frames in one call take the depth-8 tiles, the streamed chunks of four the depth-4 ones: same values to float32 noise, DESIGN.md section 1)
+    assert float((a - with_topo).abs().max()) <= 1e-5
+    with pytest.raises(ValueError, match="sigma rows differ"):
+        sg = p["sigmas"].copy(); sg[n + 3, 7] = 1.23
+        ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], sg, origins, nv, 1.0, box=p["box"], device=dev, ctx=hip_ctx, shared_sigmas=True)

@@ -16,8 +16,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGETS = {
     "k_voxelize_tiles_leanILi8ELi640E": (104, 64),     # 4 waves per SIMD leave 96 registers for the pre-pass
     "k_voxelize_tilesILi8ELi640E": (128, 0),           # 4 waves per SIMD
-    "k_bin_countIfLi0ELb0EE": (48, 0),                 # two pre-pass waves per SIMD beside four lean tile waves (the shared-loop instance: free)
-    "k_bin_fillIfLb0EE": (48, 0),
+    "k_bin_countIfLi0ELb0ELb0EE": (48, 0),             # two pre-pass waves per SIMD beside four lean tile waves (the shared-loop instance: free)
+    "k_bin_fillIfLb0ELb0EE": (48, 0),
+    "k_bin_countIfLi0ELb0ELb1EE": (48, 0),             # the topology instances (round 5) run beside the tile kernel like the plain ones
+    "k_bin_fillIfLb0ELb1EE": (48, 0),
     "k_voxelize_itemsILi8E": (128, 0),                 # 4 waves per SIMD
 }
 
