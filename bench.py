@@ -363,6 +363,44 @@ def bench_distances(args, emit=True):
             raise SystemExit("dist_trajectory on the GPU is not bit-exact with the oracle")
         line["cpu_baseline"] = {"value": round(Fs * n1 * n2 / cpu_s / 1e6, 2), "unit": "Mdist/s", "cores": 1, "kind": "port",
                                 "sample": f"first {Fs} frames of the same workload (also checked bit-exact)"}
+    # ---- the other shapes the projections send (round 5): MetricSelfDistance's triangular list, and the small call MetricDistance
+    #      usually makes (protein C-alphas x ligand atoms); each checked bit-exact on its first frames before it is timed ----
+    if only == "":
+        def shape_leg(sb, sa, selfd, check):                         # sb: first atoms, sa: second atoms
+            n1s, n2s = len(sb), len(sa)
+            da, db = torch.as_tensor(sb.astype(np.int32), device=dev), torch.as_tensor(sa.astype(np.int32), device=dev)
+            Pn = int(lib_count(n1s, n2s, selfd))
+            o2 = torch.empty((F, Pn), device=dev, dtype=torch.float32)
+            algn = F * Pn * 4 + ((n2s if selfd else n1s + n2s)) * 3 * F * 4 + 3 * F * 4
+            res = {}
+            for pbc in (False, True):
+                call = lambda: ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), da.data_ptr(), n1s, db.data_ptr(), n2s, chains.data_ptr(),
+                                                       selfd, pbc, False, o2.data_ptr())
+                for _ in range(max(3, args.warmup)):
+                    call()
+                torch.cuda.synchronize(dev)
+                if check:
+                    from oracle import oracle
+                    Fs = min(8, F)
+                    ref = oracle.dist_trajectory(coords[:, :, :Fs].contiguous().cpu().numpy(), box[:, :Fs].contiguous().cpu().numpy(), sb, sa, chains_h, selfd, pbc)
+                    if not np.array_equal(o2[:Fs].cpu().numpy(), ref):
+                        raise SystemExit(f"dist_trajectory {n1s} x {n2s} selfdist={selfd} pbc={pbc} on the GPU is not bit-exact with the oracle")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.steps):
+                    call()
+                e1.record()
+                torch.cuda.synchronize(dev)
+                ms = e0.elapsed_time(e1) / args.steps
+                res["periodic" if pbc else "nonperiodic"] = {"us_per_call": round(ms * 1e3, 2), "frac": round(algn / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                             "achieved_GBs": round(algn / ms / 1e6, 1), "kernel": ctx.last_dist_kernel()}
+            res["shape"] = f"{n1s} x {n2s}{' selfdist' if selfd else ''}: {Pn} pairs x {F} frames ({F * Pn * 4 / 1e6:.0f} MB of result)"
+            del o2
+            return res
+        lib_count = lambda a, b, sd: _lib.load().mkamd_dist_count_pairs(a, b, int(sd))
+        check = not args.no_cpu_baseline
+        line["selfdist"] = shape_leg(s2[:450].copy(), s2[:450].copy(), True, check)
+        line["small_call"] = shape_leg(s2[:300].copy(), s1[:30].copy(), False, check)
     del coords, out
     torch.cuda.empty_cache()
     if emit:
@@ -798,7 +836,8 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         # (pipelined steps are the package's own behaviour now: ShardedVoxelizer promises its resident shard to every call)
         # cfg4 is a trajectory: every item is a frame of ONE molecule, and the package's frame drivers reuse what the pre-pass derives
         # from its sigmas (a topology handle, include/mkamd_voxel.h (3c)); the other workloads are batches of different molecules
-        shared = name == "cfg4" and not getattr(args, "no_topology", False) and os.environ.get("MKAMD_SPATIAL_ORDER", "0") != "1"
+        # (cfg1 x 4096 is the augmentation loop: 4 096 rotated copies of ONE pocket -- the same molecule too)
+        shared = name in ("cfg1", "cfg4") and not getattr(args, "no_topology", False) and os.environ.get("MKAMD_SPATIAL_ORDER", "0") != "1"
         sv = ShardedVoxelizer.from_loader(world * B, loader, nv, p0["voxelsize"], device=dev, ctx=ctx,
                                           pipelined=not getattr(args, "no_pipeline", False), shared_sigmas=shared)
     else:
@@ -1007,7 +1046,7 @@ def main():
                          "report it as `sustained` (the K-step region of a 64^3 workload is tens of milliseconds: too short for a "
                          "utilisation sampler to see, and for the clocks to settle). 0 = skip")
     ap.add_argument("--no-topology", action="store_true",
-                    help="cfg4 (frames of one molecule): the plain call on the sigma matrix repeated per frame instead of the topology handle (A-B)")
+                    help="cfg1 / cfg4 (rotated copies / frames of one molecule): the plain call on the sigma matrix repeated per frame instead of the topology handle (A-B)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-grid latency probe (profiling passes: every launch is a full batch)")
     ap.add_argument("--value-tol", type=float, default=0.0,
                     help="opt into the tolerance-aware reach (mkamd_ctx_set_value_tolerance): atoms are culled where they are "

@@ -66,6 +66,20 @@ int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t n_ato
                               const uint32_t* digitized_chains2, int selfdist, int pairs, int pbc,
                               const float* masses, int reduction1, int reduction2, float* results);
 
+/* Self-test of the kernels' float32 square root.  The reference's sqrtf is correctly rounded; the kernels take roots with
+ * one exact-residual correction of x * rsq(x) (8 issue slots; the provable form, v_sqrt_f32 + Tuckerman's test, takes 12 and
+ * the kernels are bound by instruction issue).  That this is the correctly rounded root is a property of gfx950's v_rsq_f32,
+ * checked rather than proved: this call compares the two forms on the device over EVERY float in [2^-96, inf) -- 1.9e9 values,
+ * a few milliseconds -- and returns the number of mismatches (0 on the hardware this library is built for) and the bit pattern
+ * of the first one.  Run by the GPU test tier. */
+int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_bad_bits);
+
+/* Which kernels dist_trajectory may take (default 0: all; the choice depends on the shape of the call): bits of `avoid_mask` --
+ * 1 the block-per-frame kernel (rectangular calls with short rows -- the small calls MetricDistance makes: one launch), 2 the row
+ * kernel (rectangular calls with rows of >= 64 second atoms), 4 the rectangular tile kernel, 8 the row kernel's 16-byte stores
+ * (selfdist always takes the pair-table kernel).  Every kernel produces the same
+ * bits; for tests (every kernel over the same shapes) and same-box A-B timing. */
+int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask);
 /* Names of the kernels the last dist_trajectory call on this context launched, as a profiler prints them (e.g.
  * "mkamd::k_sel_to_frames + mkamd::k_dist_rows<true, 4, true>"; empty before the first call): what bench.py reports as
  * the distance leg's `roofline.kernel` -- the choice depends on the shape of the call. */

@@ -90,6 +90,8 @@ SIGNATURES = {
                                                 ctypes.c_float, _vp, ctypes.POINTER(_vp)]),
     "mkamd_dist_reduction_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _vp,
                                            _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp]),
+    "mkamd_selftest_sqrt": (_c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
+    "mkamd_ctx_set_dist_kernels": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_last_dist_kernel": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
     "mkamd_cdist_host": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _c_i32, _vp]),
     "mkamd_pdist_host": (_c_int, [_vp, _vp, _c_i64, _c_i32, _vp]),
@@ -283,6 +285,18 @@ class Context:
         buf = ctypes.create_string_buffer(128)
         _check(load().mkamd_ctx_last_tile_kernel(self._h, buf, 128))
         return buf.value.decode()
+
+    def selftest_sqrt(self):
+        """(mismatches, first bad bit pattern) of the distance kernels' short square root against the provable form over every
+        float in [2^-96, inf) (include/mkamd_distance.h): (0, 0) on gfx950."""
+        n, first = ctypes.c_uint64(0), ctypes.c_uint32(0)
+        _check(load().mkamd_selftest_sqrt(self._h, ctypes.byref(n), ctypes.byref(first)))
+        return int(n.value), int(first.value)
+
+    def set_dist_kernels(self, avoid_mask: int = 0):
+        """Kernels dist_trajectory must NOT take (include/mkamd_distance.h): 1 block-per-frame, 2 rows, 4 rectangular tiles, 8 the
+        row kernel's 16-byte stores; 0 = free choice.  Same bits whichever runs (tests, A-B timing)."""
+        _check(load().mkamd_ctx_set_dist_kernels(self._h, int(avoid_mask)))
 
     def last_dist_kernel(self) -> str:
         """Kernels the last dist_trajectory call launched, as rocprofv3 prints them ('' before the first call)."""

@@ -107,6 +107,7 @@ struct mkamd_ctx {
     unsigned* feedback_dev() const { return fb_dev; }
     void note_error_flag_mirrored(bool yes) { err_mirrored = yes; }
     void note_tail_reports(bool yes) { tail_reports = yes; }
+    int dist_avoid = 0;                    // kernels dist_trajectory must not take (mkamd_ctx_set_dist_kernels: tests, A-B timing)
     char last_dist_kernel[96] = "";        // what the last dist_trajectory call launched (mkamd_ctx_last_dist_kernel)
     void note_dist_kernel(const char* name) { snprintf(last_dist_kernel, sizeof last_dist_kernel, "%s", name); }
     bool tail_reports = false;             // the last lattice call's k_tail writes FB_TILES_DONE / FB_TAIL_WROTE with seq_next
@@ -563,6 +564,34 @@ try {
     if (ctx->last_flavour < 0 || ctx->last_flavour > 3) snprintf(name, name_cap, "%s", "");
     else if (ctx->last_flavour == 3) snprintf(name, name_cap, "mkamd::%s<%d>", base[3], ctx->last_K);
     else snprintf(name, name_cap, "mkamd::%s<%d, %d>", base[ctx->last_flavour], ctx->last_K, ctx->last_ecap);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+// the short correctly-rounded square root of the distance kernels against the provable form, over every float it is used for
+int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_bad_bits)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (!mismatches) return fail(MKAMD_EINVAL, "mismatches pointer is NULL");
+    void* w = nullptr;
+    if ((st = ctx->ensure(WS_D_TOT, 16, &w, 0))) return st;
+    HIP_TRY(hipMemsetAsync(w, 0, 16, ctx->stream));
+    const unsigned lo = 0x0F800000u;                                // 2^-96: below it mk_fsqrt_rn takes its scaled branch
+    const unsigned long long n = 0x7F800000ull - lo;
+    if ((st = ctx->launch(k_selftest_sqrt, dim3(65536), dim3(256), lo, n, (unsigned long long*)w, (unsigned*)((char*)w + 8)))) return st;
+    unsigned long long host[2] = {0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(host, w, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mismatches = (uint64_t)host[0];
+    if (first_bad_bits) *first_bad_bits = (uint32_t)(host[1] & 0xffffffffull);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask)
+try {
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (avoid_mask < 0 || avoid_mask > 15) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores)");
+    ctx->dist_avoid = avoid_mask;
     return MKAMD_OK;
 } MK_API_CATCH
 
@@ -1266,7 +1295,7 @@ try {
     int st = check_ctx(ctx);
     if (st) return st;
     std::string err;
-    st = run_dist_trajectory(*ctx, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_results, err);
+    st = run_dist_trajectory(*ctx, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_results, err, ctx->dist_avoid);
     if (st && !err.empty()) return fail(st, err);
     return st;
 } MK_API_CATCH

@@ -29,6 +29,10 @@ namespace mkamd {
 // the comparison false -- take the correctly rounded divisions.  (A NaN q is ignored by the maxima; then r is NaN and so
 // is the reference's result: 0 / 0, inf / inf or a NaN operand.)
 // `ib` = fl(1 / b), computed once per (lane, frame) instead of three IEEE divisions per pair.
+// (Round 5 tried the test on the SHIFTED separation instead -- |d - b r| < b (1/2 - 2^-12) per axis and |q| < 512: three compares
+//  against per-frame constants, a max3 and a compare where this takes seven instructions; same results, emulator and GPU tests
+//  green -- and every periodic kernel ran 10-15 % SLOWER in a same-session probe (200 x 500: 245 us against 213; the open calls
+//  beside them unchanged): three compares into scalar pairs and their s_and chain wait on each other, the max3 / fma form does not.)
 MK_DEV float round_quotient_exact(float d, float b) { return roundf(mk_fdiv_rn(d, b)); }
 
 // distance_utils.pyx:34-54 (_dist) / :188-206 (_dist2)
@@ -61,6 +65,21 @@ MK_DEV mk_f2 dist2_x2(float x1, float y1, float z1, mk_f2 x2, mk_f2 y2, mk_f2 z2
 {
     const mk_f2 dx = mk_f2_sub_rn(mk_f2_splat(x1), x2), dy = mk_f2_sub_rn(mk_f2_splat(y1), y2), dz = mk_f2_sub_rn(mk_f2_splat(z1), z2);
     return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
+}
+
+// Self-test of mk_fsqrt_rn_ordinary (mk_device.h: the short correctly-rounded root) against the provable form, over the float bit
+// patterns [lo, lo + n): mismatches counted, the first one kept (mkamd_selftest_sqrt).
+MK_KERNEL(256) void k_selftest_sqrt(unsigned lo, unsigned long long n, unsigned long long* __restrict__ bad, unsigned* __restrict__ first)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long mine = 0ull;
+    unsigned where = 0u;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const unsigned bits = lo + (unsigned)k;
+        const float x = mk_uint_as_float(bits);
+        if (mk_float_bits(mk_fsqrt_rn_ordinary(x)) != mk_float_bits(mk_fsqrt_rn_tuckerman(x))) { if (!mine) where = bits; ++mine; }
+    }
+    if (mine) { if (mk_atomic_add64(bad, mine) == 0ull) *first = where; }
 }
 
 constexpr int DT = 64;                 // tile edge (frames and pairs)
@@ -510,6 +529,94 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
             for (int k = 0; k < JPL; ++k)
                 if (j0 + 64 * k < n2) o[64 * k] = d[k];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One launch for rectangular calls with SHORT rows (round 5): a BLOCK per frame (or per slice of a frame's pairs).  The atoms of both
+// selections are few, so the block stages the frame's copy of them in LDS -- (n1 + n2) x {x, y, z, chain}: strided gathers from the
+// reference layout, no turning launch in front -- and then walks the frame's pair list in its MEMORY order, four consecutive pairs
+// per lane: the wave writes 1 KB of out[f, p..] per store instruction however short the rows are (the calls MetricDistance usually
+// makes, protein C-alphas x ligand atoms: 300 x 30 pairs x 2 048 frames took the rectangular tile kernel 43 us open / 62 us periodic,
+// this 34 / 40; 1 000 x 30: 126 / 167 against 127 / 162; profiles/r5_dist_shapes_probe.txt).  No pair table: a lane finds the
+// (i, j) of its first pair by one division and steps.  Same functions per pair (dist2_min_image_f32, mk_fsqrt_rn): the same bits
+// as every other kernel here.  (The triangular list of selfdist through the same walk -- rows found by a square root and stepping --
+// was measured too: 450 x 450 318 us against 235 for the pair-table kernel, 60 x 60 23 us against 12: finding the rows costs more
+// than the table's two loads; selfdist keeps the pair-table kernel.)
+// ------------------------------------------------------------------------------------------------
+constexpr int DF_THREADS = 256, DF_PPL = 4;                  // pairs per lane and step
+constexpr int DF_STEP = DF_THREADS * DF_PPL;                 // pairs a block takes per step
+
+// I: the type pair numbers are computed in -- unsigned while the frame's list is shorter than 2^30 pairs (64-bit multiplies and
+// divisions are a dozen instructions each), long long beyond
+template <bool PBC, int CAP /* atoms of both selections the LDS copy holds */, typename I>
+MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long long F, const float* __restrict__ box,
+                                        const unsigned* __restrict__ sel1, long long n1_, const unsigned* __restrict__ sel2, long long n2_,
+                                        const unsigned* __restrict__ chains, int squared, long long slices, float* __restrict__ out)
+{
+    __shared__ float4 s_at[CAP];                                     // {x, y, z, chain id bits}: sel1's atoms, then sel2's
+    const long long g = xcd_contiguous_tile(F * slices);             // (frame, slice) in the result's memory order, XCD-contiguous
+    if (g < 0) return;
+    const long long f = g / slices, sl = g - f * slices;
+    const int tid = threadIdx.x;
+    const I n1 = (I)n1_, n2 = (I)n2_;
+    const long long P_ = n1_ * n2_;
+    const int na = (int)(n1_ + n2_);
+    for (int k = tid; k < na; k += DF_THREADS) {
+        const unsigned a = k < (int)n1_ ? sel1[k] : sel2[k - (int)n1_];
+        const float* __restrict__ c = coords + (size_t)a * 3 * (size_t)F + (size_t)f;
+        s_at[k] = make_float4(c[0], c[(size_t)F], c[2 * (size_t)F], mk_uint_as_float(PBC ? chains[a] : 0u));
+    }
+    float bx = 0.f, by = 0.f, bz = 0.f, ibx = 0.f, iby = 0.f, ibz = 0.f;
+    if (PBC) {
+        bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+        ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
+    }
+    mk_block_sync();
+    // this slice's pairs [p_lo, p_hi): whole steps of the block, so that a lane's four pairs start on a multiple of four
+    const long long steps = (P_ + DF_STEP - 1) / DF_STEP, per = (steps + slices - 1) / slices;
+    const long long p_lo_ = sl * per * DF_STEP, p_end_ = (sl + 1) * per * DF_STEP;
+    const I p_lo = (I)(p_lo_ < P_ ? p_lo_ : P_), p_hi = (I)(p_end_ < P_ ? p_end_ : P_);
+    float* __restrict__ row = out + (size_t)f * (size_t)P_;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(row) & (uintptr_t)15) == 0);      // block-uniform: the frame's row starts on 16 bytes
+    const float4* __restrict__ s2 = s_at + n1_;
+    // the step from a lane's last pair + 1 to its next first pair, in whole rows and a rest (block-uniform)
+    const I adv = (I)(DF_STEP - DF_PPL), adv_rows = adv / n2, adv_rest = adv - adv_rows * n2;
+    I p = p_lo + (I)tid * (I)DF_PPL;
+    I i = p / n2, j = p - i * n2;
+    // (the trip count is the BLOCK's: the roots' ballot inside is taken by whole waves; a lane past the end of the list computes on
+    //  clamped atoms and stores nothing)
+    for (I base = p_lo; base < p_hi; base += (I)DF_STEP, p += (I)DF_STEP) {
+        float d[DF_PPL];
+        bool ordinary = true;
+#pragma unroll
+        for (int k = 0; k < DF_PPL; ++k) {
+            const I ic = i < n1 ? i : n1 - 1;                                             // (pairs past the end of the list: the last atom again, never stored)
+            const float4 A = s_at[ic], B = s2[j];
+            const bool wrap = PBC && mk_float_bits(A.w) != mk_float_bits(B.w);           // distance_utils.pyx:49
+            d[k] = dist2_min_image_f32(A.x, A.y, A.z, B.x, B.y, B.z, bx, by, bz, ibx, iby, ibz, wrap);
+            ordinary = ordinary && mk_sqrt_ordinary(d[k]);
+            if (++j >= n2) { ++i; j = 0; }
+        }
+        if (!squared) {
+            if (mk_ballot(!ordinary) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn_ordinary(d[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
+            }
+        }
+        if (aligned && p + (I)DF_PPL <= p_hi) {
+            *reinterpret_cast<float4*>(row + p) = make_float4(d[0], d[1], d[2], d[3]);
+        } else if (p < p_hi) {
+#pragma unroll
+            for (int k = 0; k < DF_PPL; ++k)
+                if (p + (I)k < p_hi) row[p + (I)k] = d[k];
+        }
+        // on to pair p + DF_STEP: (i, j) stands at pair p + DF_PPL
+        i += adv_rows; j += adv_rest;
+        if (j >= n2) { j -= n2; ++i; }
     }
 }
 

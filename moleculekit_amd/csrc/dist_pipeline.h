@@ -32,10 +32,12 @@ inline int dist_rows_jpl(long long n1, long long n2, long long F)
 }
 
 // dist_trajectory on device pointers (coords [N,3,F], box [3,F], sel/chains uint32) -> out [F, P]
+// `avoid`: kernels NOT to take (tests walk every kernel over the same shapes; A-B timing) -- the choice below is made among the rest
+enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8 };
 template <class BE>
 int run_dist_trajectory(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                         const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
-                        float* out, std::string& err)
+                        float* out, std::string& err, int avoid = 0)
 {
     if (F < 0 || n1 < 0 || n2 < 0) { err = "negative size"; return ST_EINVAL; }
     const long long P = count_pairs(n1, n2, selfdist);
@@ -47,8 +49,28 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     // table, the second atoms of a tile stay in registers while the block walks DR_I first atoms (dist_kernels.h)
     // (both tile kernels: a 1-D grid padded to a multiple of 8, every XCD a contiguous range of tiles -- xcd_contiguous_tile)
     auto padded8 = [](long long tiles) { return (unsigned)(((tiles + 7) / 8) * 8); };
-    static const bool no_rect = [] { const char* e = std::getenv("MKAMD_NO_RECT"); return e && e[0] == '1'; }();     // A-B knob
-    static const bool no_rows = [] { const char* e = std::getenv("MKAMD_NO_ROWS"); return e && e[0] == '1'; }();     // A-B knob
+    const bool no_frame = (avoid & DIST_AVOID_FRAME) != 0, no_rows = (avoid & DIST_AVOID_ROWS) != 0, no_rect = (avoid & DIST_AVOID_RECT) != 0;
+    // One launch for rectangular calls whose rows are too short for the row kernel (k_dist_frame: a block per frame stages both
+    // selections in LDS and walks the pair list in memory order).  (selfdist keeps the pair-table kernel: dist_kernels.h)
+    const int rows_jpl = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
+    if (!no_frame && !selfdist && rows_jpl == 0 && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
+        long long slices = (4096 + F - 1) / F;                              // enough blocks to fill the chip ...
+        const long long most = (P + 4 * DF_STEP - 1) / (4 * DF_STEP);       // ... of at least four steps each
+        slices = slices < 1 ? 1 : (slices > most ? most : slices);
+        if (slices > 64) slices = 64;
+        const dim3 grid(padded8(F * slices)), block(DF_THREADS);
+        auto go = [&](auto kern) { return be.launch(kern, grid, block, coords, F, box, sel1, n1, sel2, n2, chains, squared, slices, out); };
+        const bool small = n1 + n2 <= 1024, big_p = P > 0x3fffffffLL;
+        char nm[96];
+        snprintf(nm, sizeof nm, "mkamd::k_dist_frame<%s, %d, %s>", pbc ? "true" : "false", small ? 1024 : 4096, big_p ? "long long" : "unsigned int");
+        be.note_dist_kernel(nm);
+        if (pbc) {
+            if (big_p) return small ? go(k_dist_frame<true, 1024, long long>) : go(k_dist_frame<true, 4096, long long>);
+            return small ? go(k_dist_frame<true, 1024, unsigned>) : go(k_dist_frame<true, 4096, unsigned>);
+        }
+        if (big_p) return small ? go(k_dist_frame<false, 1024, long long>) : go(k_dist_frame<false, 4096, long long>);
+        return small ? go(k_dist_frame<false, 1024, unsigned>) : go(k_dist_frame<false, 4096, unsigned>);
+    }
     if (!selfdist && !no_rows) {
         // rows of >= 64 second atoms are written directly by a wave per frame, from selections turned frame-major first
         const int jpl = dist_rows_jpl(n1, n2, F);
@@ -68,7 +90,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
                 return be.launch(kernel, grid, block, (const float*)t1, np1, (const unsigned*)cs1, (const float*)t2, np2, (const unsigned*)cs2, box, F,
                                  n1, n2, squared, out);
             };
-            static const bool no_vec = [] { const char* e = std::getenv("MKAMD_ROWS_NO_VEC"); return e && e[0] == '1'; }();  // A-B knob
+            const bool no_vec = (avoid & DIST_AVOID_VEC) != 0;
             const bool vec = jpl == 4 && n2 % 4 == 0 && ((uintptr_t)out & 15u) == 0 && !no_vec;      // rows start on 16 bytes
             {
                 char nm[96];

@@ -114,6 +114,7 @@ MK_DEV void mk_wave_sync()
 MK_DEV void mk_block_sync() { __syncthreads(); }
 
 MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { return atomicAdd(p, v); }
+MK_DEV unsigned long long mk_atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { return atomicSub(p, v); }
 MK_DEV void mk_atomic_or(int* p, int v) { atomicOr(p, v); }
 
@@ -232,7 +233,8 @@ MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // rou
 // interleave across the batch (with a branch per root every pair of the distance kernels was a basic block of its own: a
 // serial chain of ~30 dependent instructions, five s_nop and three branches per distance).
 MK_DEV bool mk_sqrt_ordinary(float x) { return (__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u); }   // in [2^-96, inf)
-MK_DEV float mk_fsqrt_rn_ordinary(float x)
+// (the provable form: v_sqrt_f32 + the Tuckerman correction, 12 issue slots; what the fast form below is verified against)
+MK_DEV float mk_fsqrt_rn_tuckerman(float x)
 {
     const float s = __builtin_amdgcn_sqrtf(x);
     const float s_down = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
@@ -240,16 +242,25 @@ MK_DEV float mk_fsqrt_rn_ordinary(float x)
     const float y = (r_down <= 0.0f) ? s_down : s;
     return (r_up > 0.0f) ? s_up : y;
 }
+// Round 5: the distance kernels are bound by VALU issue and a third of their instructions per pair was this root.  One
+// Newton-style correction of x * rsq(x) with the EXACT residual -- y0 = v_rsq_f32(x), s = x y0, r = fma(-s, s, x),
+// root = fma(r, y0 / 2, s) -- costs 8 issue slots instead of 12, and on gfx950 it returns the correctly rounded root for EVERY
+// float in [2^-96, inf): compared with the form above over all 1 879 048 192 of them (tools/sqrt_exact.hip,
+// profiles/r5_sqrt_exact.txt; the library repeats the comparison on demand: mkamd_selftest_sqrt, run by the GPU test tier).
+// It is a property of this chip's v_rsq_f32, not a theorem: the error of the correction term (~2^-46 of the root) is larger
+// than the closest a root can come to a rounding boundary (2^-50) -- hence the exhaustive check.
+MK_DEV float mk_fsqrt_rn_ordinary(float x)
+{
+    const float y0 = __builtin_amdgcn_rsqf(x);
+    const float s = x * y0;
+    const float r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, 0.5f * y0, s);
+}
 MK_DEV float mk_fsqrt_rn(float x)
 {
-    // every lane of the wave holds an ordinary number in [2^-96, inf) -- practically always: the correction alone
-    if (__builtin_amdgcn_ballot_w64(!((__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u))) == 0ull) {
-        const float s = __builtin_amdgcn_sqrtf(x);
-        const float s_down = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
-        const float r_down = __builtin_fmaf(-s_down, s, x), r_up = __builtin_fmaf(-s_up, s, x);
-        const float y = (r_down <= 0.0f) ? s_down : s;
-        return (r_up > 0.0f) ? s_up : y;
-    }
+    // every lane of the wave holds an ordinary number in [2^-96, inf) -- practically always: the short form alone
+    if (__builtin_amdgcn_ballot_w64(!((__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u))) == 0ull)
+        return mk_fsqrt_rn_ordinary(x);
     // keep v_sqrt_f32 away from denormal inputs / results: scale tiny x by 2^64 (exact), result by 2^-32
     const bool tiny = x < 0x1.0p-96f;
     const float xs = tiny ? x * 0x1.0p+64f : x;

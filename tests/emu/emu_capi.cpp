@@ -224,10 +224,10 @@ int emu_plan(int B, long long total_atoms, int C, const int* nvox, double voxels
 // ---- distance_utils row: same launch sequences on host memory ----
 int emu_dist_trajectory(const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                         const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
-                        float* out)
+                        float* out, int avoid /* DIST_AVOID_* bits: kernels not to take */)
 {
     EmuBackend be;
-    return run_dist_trajectory(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, squared, out, g_err);
+    return run_dist_trajectory(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, squared, out, g_err, avoid);
 }
 
 int emu_dist_reduction(const float* coords, long long F, const float* box, const int* g1a, const long long* g1o, long long ng1,

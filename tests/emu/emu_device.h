@@ -236,6 +236,7 @@ MK_DEV float mk_uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f
 MK_DEV void mk_block_sync() { emu::rendezvous(16, emu::g_blk.nthreads); }
 MK_DEV void mk_wave_sync() { emu::rendezvous((int)threadIdx.x >> 6, 64); }
 MK_DEV unsigned mk_atomic_add(unsigned* p, unsigned v) { const unsigned o = *p; *p = o + v; return o; }
+MK_DEV unsigned long long mk_atomic_add64(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
 MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; *p = o - v; return o; }
 MK_DEV void mk_atomic_or(int* p, int v) { *p |= v; }
 MK_DEV unsigned mk_atomic_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
@@ -299,6 +300,7 @@ MK_DEV float mk_fdiv_rn(float a, float b) { volatile float r = a / b; return r; 
 MK_DEV float mk_fsqrt_rn(float a) { return sqrtf(a); }
 MK_DEV bool mk_sqrt_ordinary(float x) { return x >= 0x1.0p-96f && x < INFINITY; }
 MK_DEV float mk_fsqrt_rn_ordinary(float a) { return sqrtf(a); }
+MK_DEV float mk_fsqrt_rn_tuckerman(float a) { return sqrtf(a); }
 MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
 {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_offset);

@@ -161,7 +161,9 @@ def _npairs(n1, n2, selfdist):
     return sum(max(n2 - 1 - i, 0) for i in range(n1)) if selfdist else n1 * n2
 
 
-def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=False):
+def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=False, avoid=0):
+    """avoid: DIST_AVOID_* bits of dist_pipeline.h (1 the block-per-frame kernel, 2 the row kernel, 4 the rectangular tile kernel,
+    8 the row kernel's 16-byte stores): the call takes the best kernel among the rest"""
     coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
     sel1 = np.ascontiguousarray(sel1, np.uint32); sel2 = np.ascontiguousarray(sel2, np.uint32)
     chains = np.ascontiguousarray(chains, np.uint32)
@@ -169,7 +171,7 @@ def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=Fals
     out = np.full((F, _npairs(len(sel1), len(sel2), selfdist)), -7.0, np.float32)
     st = lib().emu_dist_trajectory(_p(coords), ctypes.c_longlong(F), _p(box), _p(sel1), ctypes.c_longlong(len(sel1)), _p(sel2),
                                    ctypes.c_longlong(len(sel2)), _p(chains), ctypes.c_int(int(selfdist)), ctypes.c_int(int(pbc)),
-                                   ctypes.c_int(int(squared)), _p(out))
+                                   ctypes.c_int(int(squared)), _p(out), ctypes.c_int(int(avoid)))
     assert st == 0, lib().emu_last_error()
     return out
 

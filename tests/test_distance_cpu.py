@@ -114,9 +114,10 @@ def test_emu_larger_random_case_matches_oracle():
     ch = rng.integers(0, 3, size=N).astype(np.uint32)
     s1 = np.arange(0, 90, dtype=np.uint32); s2 = np.arange(40, 150, dtype=np.uint32)
     for selfd, a, bb in ((False, s1, s2), (True, s2, s2), (True, s1[:7], s2[:20])):
-        got = E.dist_trajectory(c, b, a, bb, ch, selfd, True)
         exp = oracle.dist_trajectory(c, b, a, bb, ch, selfd, True)
-        assert np.array_equal(got, exp, equal_nan=True)
+        for avoid in (0, 1):                                # the block-per-frame kernel (round 5), then the tile kernels it stands in front of
+            got = E.dist_trajectory(c, b, a, bb, ch, selfd, True, avoid=avoid)
+            assert np.array_equal(got, exp, equal_nan=True), (selfd, avoid)
         assert np.isnan(exp[5]).any()
 
 
@@ -163,9 +164,42 @@ def test_rectangular_kernel_shapes_and_modes_match_oracle():
         s2 = rng.integers(0, N, size=n2).astype(np.uint32)
         for pbc in (False, True):
             for sq in (False, True):
-                got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
+                got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq, avoid=3)       # neither the frame nor the row kernel: k_dist_rect
                 exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
                 assert got.shape == (F, n1 * n2) and np.array_equal(got, exp), (n1, n2, pbc, sq)
+
+
+def test_block_per_frame_kernel_shapes_and_modes_match_oracle():
+    """Round 5: k_dist_frame -- a block per frame (or slice of a frame's pairs) stages both selections in LDS and walks the
+    rectangular pair list in memory order, four consecutive pairs per lane: rows shorter and longer than a lane's four pairs and
+    than a block's step of 1 024, lists that end inside a lane's four pairs, frame rows that do and do not start on 16 bytes, one
+    frame and several slices per frame, more than 1 024 atoms (the big LDS tier), pbc on and off, squared and not, a zero box
+    edge and NaN coordinates -- the kernel source on the host emulator against the oracle, bit for bit.  (Triangular lists ride
+    along: they keep the pair-table kernel whatever is avoided.)"""
+    rng = np.random.default_rng(41)
+    N = 1500
+    ch = rng.integers(0, 4, size=N).astype(np.uint32)
+    for F in (1, 5):
+        c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+        b = rng.uniform(15, 25, size=(3, F)).astype(np.float32)
+        if F > 1:
+            b[1, 3] = 0.0
+            c[3, 0, 1] = np.nan; c[7, 1, 2] = 3e38
+        cases = [(False, 1, 1), (False, 7, 3), (False, 30, 30), (False, 300, 30), (False, 5, 1030), (False, 3, 4100 // 3), (False, 41, 101),
+                 (False, 1030, 2), (True, 5, 5), (True, 61, 61), (True, 12, 90)]
+        for selfd, n1, n2 in cases:
+            s2 = rng.integers(0, N, size=n2).astype(np.uint32)
+            s1 = s2[:n1].copy() if (selfd and n1 <= n2) else rng.integers(0, N, size=n1).astype(np.uint32)
+            for pbc in (False, True):
+                for sq in ((False, True) if n1 * n2 < 2000 else (False,)):
+                    exp = oracle.dist_trajectory(c, b, s1, s2, ch, selfd, pbc, squared=sq)
+                    got = E.dist_trajectory(c, b, s1, s2, ch, selfd, pbc, squared=sq, avoid=2)     # (never the row kernel: the frame kernel)
+                    assert got.shape == exp.shape and np.array_equal(got, exp, equal_nan=True), (F, selfd, n1, n2, pbc, sq)
+    # more atoms than the small LDS tier holds; a list that the row kernel would take, through the frame kernel
+    c = rng.uniform(-30, 30, size=(N, 3, 2)).astype(np.float32)
+    b = rng.uniform(15, 25, size=(3, 2)).astype(np.float32)
+    s1, s2 = np.arange(0, 40, dtype=np.uint32), np.arange(100, 1400, dtype=np.uint32)
+    assert np.array_equal(E.dist_trajectory(c, b, s1, s2, ch, False, True, avoid=2), oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
 
 
 def test_row_kernel_shapes_and_modes_match_oracle():

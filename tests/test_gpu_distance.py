@@ -253,3 +253,58 @@ def test_row_kernel_over_many_waves_matches_oracle():
             dist_trajectory(c, b, s1, s2, ch, False, pbc, r)
             exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc)
             assert np.array_equal(r, exp, equal_nan=True), (n1, n2, pbc)
+
+
+def test_block_per_frame_kernel_over_many_blocks_and_every_kernel_on_the_same_shapes():
+    """Round 5: k_dist_frame (a block per frame / slice stages both selections in LDS and walks the pair list in memory order) at
+    sizes where its bookkeeping matters -- thousands of blocks whose count is not a multiple of 8, several slices per frame, short
+    rectangular rows (MetricDistance's protein x ligand shape), frame rows that do not start on 16 bytes, more than 1 024 atoms (the
+    big LDS tier), a zero box edge; triangular lists (MetricSelfDistance's shape: the pair-table kernel) beside them -- and every
+    kernel that can take a shape on that shape (``Context.set_dist_kernels``): all against the oracle, bit for bit,
+    with a sentinel in every element first."""
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import dist_trajectory
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(31)
+    N, F = 2500, 203
+    c = rng.uniform(-40, 40, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(30, 45, size=(3, F)).astype(np.float32)
+    b[2, 77] = 0.0
+    ch = rng.integers(0, 5, size=N).astype(np.uint32)
+    shapes = [(False, 300, 30), (False, 30, 300), (False, 41, 101), (False, 7, 3), (False, 5, 1031), (True, 61, 61), (True, 450, 450), (True, 12, 90),
+              (True, 90, 12), (True, 2, 2), (False, 20, 1300)]
+    seen = set()
+    try:
+        for selfd, n1, n2 in shapes:
+            s2 = rng.choice(N, n2, replace=False).astype(np.uint32)
+            s1 = s2[:n1].copy() if (selfd and n1 <= n2) else rng.choice(N, n1, replace=False).astype(np.uint32)
+            for pbc in (False, True):
+                exp = oracle.dist_trajectory(c, b, s1, s2, ch, selfd, pbc)
+                for avoid in (0, 1, 2, 3):
+                    ctx.set_dist_kernels(avoid)
+                    r = np.full(exp.shape, -3.0, np.float32)
+                    dist_trajectory(c, b, s1, s2, ch, selfd, pbc, r)
+                    seen.add(ctx.last_dist_kernel().split("<")[0])
+                    assert np.array_equal(r, exp, equal_nan=True), (selfd, n1, n2, pbc, avoid, ctx.last_dist_kernel())
+    finally:
+        ctx.set_dist_kernels(0)
+    assert {"mkamd::k_dist_frame", "mkamd::k_dist_rect", "mkamd::k_build_atom_pairs + mkamd::k_dist_pairs", "mkamd::k_sel_to_frames + mkamd::k_dist_rows"} <= seen, seen
+
+
+def test_the_short_square_root_is_the_correctly_rounded_one_for_every_float():
+    """Round 5: the kernels' root is one exact-residual correction of x * rsq(x) (csrc/mk_device.h, mk_fsqrt_rn_ordinary) -- 8 issue slots
+    instead of the provable form's 12 in kernels bound by instruction issue.  Correct rounding is a property of this chip's
+    v_rsq_f32: the library checks it on the device over all 1 879 048 192 floats in [2^-96, inf) against v_sqrt_f32 + Tuckerman's
+    test (mkamd_selftest_sqrt); and a sample of the same range against the host's correctly rounded sqrtf through the product's
+    own API (cdist of 1-D points: sqrt((x - 0)^2) = |x| would prove nothing; squared distances of 3-D points do)."""
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import cdist
+    assert _lib.default_context().selftest_sqrt() == (0, 0)
+    rng = np.random.default_rng(7)
+    a = (rng.uniform(-1, 1, size=(3000, 3)) * np.exp(rng.uniform(-40, 40, size=(3000, 1)))).astype(np.float32)
+    b = (rng.uniform(-1, 1, size=(700, 3)) * np.exp(rng.uniform(-40, 40, size=(700, 1)))).astype(np.float32)
+    got = np.zeros((3000, 700), np.float32)
+    cdist(a, b, got)
+    d = a[:, None, :] - b[None, :, :]                                  # float32, one rounding per operation, the reference's order
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    assert d2.dtype == np.float32 and np.array_equal(got, np.sqrt(d2))

@@ -22,12 +22,18 @@ def t(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for n1, n2, selfd in ((300, 30, False), (30, 300, False), (300, 60, False), (1000, 30, False), (300, 300, True), (1000, 1000, True), (300, 300, False)):
+for n1, n2, selfd in ((300, 30, False), (30, 300, False), (300, 60, False), (1000, 30, False), (300, 300, True), (450, 450, True), (1000, 1000, True), (300, 300, False),
+                      (200, 500, False)):
     s2 = np.sort(rng.choice(N, n2, replace=False)).astype(np.int32)
     s1 = s2 if selfd else np.sort(rng.choice(N, n1, replace=False)).astype(np.int32)
     d1, d2 = torch.as_tensor(s1, device=dev), torch.as_tensor(s2, device=dev)
     P = int(lib.mkamd_dist_count_pairs(n1, n2, int(selfd)))
     out = torch.empty((F, P), device=dev)
     for pbc in (False, True):
-        ms = t(lambda: ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2, chains.data_ptr(), selfd, pbc, False, out.data_ptr()))
-        print(f"{n1:5d} x {n2:5d} {'selfdist' if selfd else '        '} pbc={pbc!s:5}: {ms * 1e3:8.1f} us  {out.numel() * 4 / ms / 1e6:6.0f} GB/s of result ({out.numel() * 4 / 1e6:.0f} MB)")
+        for avoid in (0, 1, 3):                  # free choice; without the block-per-frame kernel (round 4's choice); the tile kernels only
+            ctx.set_dist_kernels(avoid)
+            ms = t(lambda: ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2, chains.data_ptr(), selfd, pbc, False, out.data_ptr()))
+            alg = out.numel() * 4 + (n1 + n2) * 3 * F * 4
+            print(f"{n1:5d} x {n2:5d} {'selfdist' if selfd else '        '} pbc={pbc!s:5} avoid={avoid}: {ms * 1e3:8.1f} us  {alg / ms / 1e6:6.0f} GB/s algorithmic "
+                  f"({out.numel() * 4 / 1e6:.0f} MB)  {ctx.last_dist_kernel()}")
+ctx.set_dist_kernels(0)
