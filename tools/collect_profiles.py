@@ -1,4 +1,4 @@
-"""Copy the judged summaries of tools/gpu_r4_evidence.sh from gpurun_out/ (scratch) into profiles/r4_* (tracked) and stamp every
+"""Copy the judged summaries of tools/gpu_evidence.sh from gpurun_out/ (scratch) into profiles/<tag>_* (tracked; tag = argv[1], default r5) and stamp every
 PMC summary with the source hash of the library it was taken on (moleculekit_amd._build.built_hash(): bench.py refuses
 counters of another build).  Runs on the GPU box at the end of the evidence session, and again here (idempotent)."""
 import collections
@@ -13,11 +13,11 @@ sys.path.insert(0, os.getcwd())
 import bench  # noqa: E402
 from moleculekit_amd import _build  # noqa: E402
 
-tag = "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
 SRC = _build.built_hash()
 os.makedirs("profiles", exist_ok=True)
 PROF = "--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
-for name in ("cfg2", "cfg2_nopipe", "torchrun1"):
+for name in ("cfg2", "cfg2_nopipe", "torchrun1", "dist"):
     f = f"gpurun_out/bench_{name}.log"
     if os.path.exists(f):
         for line in open(f):
@@ -26,7 +26,7 @@ for name in ("cfg2", "cfg2_nopipe", "torchrun1"):
                 d["_library_src"] = SRC
                 json.dump(d, open(f"profiles/{tag}_bench_{name}.json", "w"), indent=1)
                 break
-for d in ("cfg2", "cfg2_nopipe", "cfg1", "cfg3", "cfg4", "cfg5", "dist"):
+for d in ("cfg2", "cfg2_nopipe", "cfg1", "cfg3", "cfg4", "cfg4_plain", "cfg5", "dist"):
     stats = sorted(glob.glob(f"gpurun_out/prof_{d}/*/*_kernel_stats.csv"), key=os.path.getmtime)
     if stats:
         shutil.copy(stats[-1], f"profiles/{tag}_{d}_rocprofv3_kernel_stats.csv")
@@ -45,7 +45,7 @@ def collect(passes, out_name, items, cmd, note_extra=""):
         return None
     out = {"_library_src": SRC, "_items_per_launch": items, "_full_batch_launches_only": True,
            "_command": f"rocprofv3 --kernel-trace --pmc <counters of one pass> -- python bench.py {cmd}".strip(),
-           "_note": "mean per launch; one rocprofv3 --pmc pass per counter group (tools/gpu_r4_evidence.sh), FETCH_SIZE and WRITE_SIZE in "
+           "_note": "mean per launch; one rocprofv3 --pmc pass per counter group (tools/gpu_evidence.sh), FETCH_SIZE and WRITE_SIZE in "
                     "passes of their own; KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950: double it (MI355X_MICROARCH.md, HBM). "
                     "--no-single: no single-grid probe launches, every launch of a kernel is one full step. GRBM_GUI_ACTIVE: shader "
                     "cycles of the launch summed over the 8 XCDs (the effective clock = it / 8 / the kernel's duration)." + note_extra}
@@ -57,7 +57,7 @@ def collect(passes, out_name, items, cmd, note_extra=""):
 
 
 def report(out_name, out, alg_mb):
-    hot = [k for k in out if isinstance(out[k], dict) and ("k_voxelize_tiles" in k or "k_voxelize_items" in k or "k_dist_pairs" in k or "k_dist_rows" in k)]
+    hot = [k for k in out if isinstance(out[k], dict) and ("k_voxelize_tiles" in k or "k_voxelize_items" in k or "k_dist_pairs" in k or "k_dist_rows" in k or "k_dist_frame" in k)]
     n = max((out[k]["_launches"] for k in hot), default=0)
     for k in hot:
         v = out[k]
@@ -78,7 +78,7 @@ def report(out_name, out, alg_mb):
 
 ALG = {"cfg2": 2710.7, "cfg1": 2107.3, "cfg3": 14582.0, "cfg4": 1243.9, "cfg5": 29092.0, "dist": 836.4}
 for wl in ("cfg2", "cfg1", "cfg3", "cfg4", "cfg5"):
-    passes = [f"{wl}_sq1", f"{wl}_fetch", f"{wl}_write"] + ([f"{wl}_sq2", f"{wl}_icache"] if wl == "cfg2" else [])
+    passes = [f"{wl}_sq1", f"{wl}_fetch", f"{wl}_write"] + ([f"{wl}_sq2"] if wl == "cfg2" else [])
     o = collect(passes, f"{tag}_{wl}_pmc_counters.json", bench.DEFAULT_BATCH[wl], f"{PROF} --workload {wl}")
     if o:
         report(f"{tag}_{wl}", o, ALG[wl])
@@ -86,24 +86,14 @@ o = collect(("cfg2_nopipe_sq1", "cfg2_nopipe_fetch", "cfg2_nopipe_write"), f"{ta
 if o:
     report(f"{tag}_cfg2_nopipe", o, ALG["cfg2"])
 for mode in ("periodic", "nonperiodic"):
-    o = collect([f"dist_{mode}_{p}" for p in ("sq1", "sq2", "fetch", "write")],
+    o = collect([f"dist_{mode}_{p}" for p in ("sq1", "fetch", "write")],
                 f"{tag}_dist_pmc_counters.json" if mode == "periodic" else f"{tag}_dist_nonperiodic_pmc_counters.json",
                 bench.DEFAULT_BATCH["dist"], f"--workload dist --no-cpu-baseline --steps 8 --warmup 2 (MKAMD_DIST_ONLY={mode})")
     if o:
         report(f"{tag}_dist_{mode}", o, ALG["dist"])
-stats = sorted(glob.glob("gpurun_out/prof_xtc/*/*_kernel_stats.csv"), key=os.path.getmtime)
-if stats:
-    shutil.copy(stats[-1], f"profiles/{tag}_xtc_probe_rocprofv3_kernel_stats.csv")
-if os.path.exists("gpurun_out/xtc_pmc/summary.txt"):
-    with open("gpurun_out/xtc_pmc/summary.txt") as fh:
-        body = fh.read()
-    open(f"profiles/{tag}_xtc_decode_pmc.txt", "w").write(
-        f"# library src {SRC}; tools/gpu_r4_xtc_pmc.sh: rocprofv3 --pmc passes of tools/xtc_gpu_probe.py, one probe file per pass (syn = 30 000 atoms,\n"
-        "# every atom a group, no flag set; real = 3PTB head, 4 507 atoms, reference writer), mean per launch of the kernel at the grid size given\n"
-        "# (k_xtc_scan: 64 lanes = 64 frames per workgroup, so grid / 64 waves; SQ_WAVE_CYCLES and SQ_ACTIVE_* in quad-cycles)\n" + body)
 for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"),
-                 ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_probe.txt", "dist_probe_rows.txt"), ("random_sweeps.txt", "random_sweeps_final.txt"), ("xtc_overlap_probe.txt", "xtc_overlap_probe.txt"),
-                 ("r4_tile_ab.txt", "tile_ab_last.txt")):
+                 ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_shapes_probe.txt", "dist_shapes_probe.txt"), ("random_sweeps.txt", "random_sweeps_final.txt"),
+                 ("sqrt_exact.txt", "sqrt_exact.txt")):
     f = f"gpurun_out/{src}"
     if os.path.exists(f):
         with open(f) as fh:

@@ -1,16 +1,18 @@
-# tools/gpu_r4_evidence.sh -- round-4 evidence session on one box, on the FINAL build: parity tests, smoke, the default bench line (as
-# the driver runs it) and its in-order twin, the torchrun 1-rank RCCL path, rocprofv3 kernel-trace stats of every workload the line
-# reports, and PMC passes for EVERY one of them (SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE and WRITE_SIZE in passes of their own,
-# every launch a full batch).  tools/collect_profiles_r4.py copies the summaries into profiles/r4_* and stamps them with the
-# library's source hash (bench.py refuses counters of another build).
+# tools/gpu_evidence.sh -- the evidence session of a round on ONE box, on the FINAL build: parity tests, smoke, the default bench line (as the
+# driver runs it) and its in-order twin, the torchrun 1-rank RCCL path, rocprofv3 kernel-trace stats of every workload the line reports, and PMC
+# passes for EVERY one of them (SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE and WRITE_SIZE in passes of their own, every launch a full batch).
+# tools/collect_profiles.py copies the summaries into profiles/<tag>_* and stamps them with the library's source hash (bench.py refuses
+# counters of another build).   usage: bash tools/gpu_evidence.sh r5
+TAG=${1:-r5}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log)
+(timeout 900 python -m pytest tests -m gpu -q -s > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log)
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log)
 (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_cfg2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2.log)
 (timeout 400 python bench.py --no-cpu-baseline --no-extra --no-pipeline --min-seconds 1 > gpurun_out/bench_cfg2_nopipe.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2_nopipe.log)
 (timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
+(timeout 400 python bench.py --workload dist --steps 20 --warmup 3 > gpurun_out/bench_dist.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist.log)
 rm -rf gpurun_out/prof_* gpurun_out/pmc_*
 PROF="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
 TRACE="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 40 --warmup 5"
@@ -18,6 +20,7 @@ for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py $TRACE --workload $wl > $R/gpurun_out/rocprof_$wl.log 2>&1)
 done
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py $TRACE --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg4_plain -- python $R/bench.py $TRACE --workload cfg4 --no-topology > $R/gpurun_out/rocprof_cfg4_plain.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dist -- python $R/bench.py --workload dist --no-cpu-baseline --steps 20 --warmup 3 > $R/gpurun_out/rocprof_dist.log 2>&1)
 pmc() { name=$1; wl=$2; shift; shift; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${wl}_$name -- python $R/bench.py $PROF --workload $wl $PMC_EXTRA > $R/gpurun_out/pmc_${wl}_$name.log 2>&1); }
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
@@ -30,7 +33,6 @@ for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
 done
 PMC_EXTRA=""
 pmc sq2 cfg2 $SQ2
-pmc icache cfg2 SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE
 PMC_EXTRA="--no-pipeline"
 pmc nopipe_fetch cfg2 FETCH_SIZE
 pmc nopipe_write cfg2 WRITE_SIZE
@@ -39,21 +41,19 @@ pmc nopipe_sq1 cfg2 $SQ1
 dpmc() { name=$1; mode=$2; shift; shift; (cd /tmp && MKAMD_DIST_ONLY=$mode timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_dist_${mode}_$name -- python $R/bench.py --workload dist --no-cpu-baseline --steps 8 --warmup 2 > $R/gpurun_out/pmc_dist_${mode}_$name.log 2>&1); }
 for mode in periodic nonperiodic; do
   dpmc sq1 $mode $SQ1
-  dpmc sq2 $mode $SQ2
   dpmc fetch $mode FETCH_SIZE
   dpmc write $mode WRITE_SIZE
 done
 # the one-molecule call: latencies, the host side of the drop-in call
 (for i in 1 2 3; do timeout 120 python tools/single_latency.py; done > gpurun_out/single_latency.txt 2>&1)
 (timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
-# the distance leg's shape under every switch: the row kernel (default), the tile kernel it replaced (MKAMD_NO_ROWS=1), fills / copies
-(for v in A=0 MKAMD_NO_ROWS=1 A=0 MKAMD_NO_ROWS=1; do echo "== $v"; env $v timeout 200 python tools/dist_probe.py; done > gpurun_out/dist_probe.txt 2>&1)
+# dist_trajectory at the shapes the projections call it with, under every kernel choice
+(timeout 300 python tools/dist_shapes_probe.py > gpurun_out/dist_shapes_probe.txt 2>&1)
 # random parity sweeps on this build: the voxelizer (automatic mode and the workgroup-per-item kernel) and dist_trajectory
 (timeout 600 python tests/sweep_gpu_random.py 9000 600; MKAMD_TILE_ITEMS=1 timeout 300 python tests/sweep_gpu_random.py 9600 200; timeout 600 python tests/sweep_gpu_dist.py 0 600) > gpurun_out/random_sweeps.txt 2>&1
-# the device XTC decoder: kernels alone per chunk size, beside the voxelizer, counters, kernel stats
+# the device XTC decoder: kernels alone per chunk size
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
-(timeout 200 python tools/xtc_overlap_probe.py > gpurun_out/xtc_overlap_probe.txt 2>&1)
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_xtc -- python $R/tools/xtc_gpu_probe.py > $R/gpurun_out/rocprof_xtc.log 2>&1)
-(bash tools/gpu_r4_xtc_pmc.sh > /dev/null 2>&1)
-tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
-python tools/collect_profiles_r4.py
+(timeout 120 tools/store_pattern > gpurun_out/store_pattern.txt 2>&1)
+(timeout 60 tools/sqrt_exact > gpurun_out/sqrt_exact.txt 2>&1)
+grep -a "cutoff shell" gpurun_out/pytest_gpu.log | sort -u; tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
+python tools/collect_profiles.py $TAG
