@@ -547,93 +547,124 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
 constexpr int DF_THREADS = 256, DF_PPL = 4;                  // pairs per lane and step
 constexpr int DF_STEP = DF_THREADS * DF_PPL;                 // pairs a block takes per step
 
+// A block takes FR CONSECUTIVE frames (and a slice of their pairs).  The reference layout is frame-fastest, so the FR frames of one
+// (atom, axis) are 4 FR contiguous bytes: staged with ONE 16-byte load where FR = 4 and the rows are aligned (F a multiple of four) --
+// a quarter of the cache lines a block per single frame asks for (4 096 blocks x 990 lines for the 300 x 30 x 2 048 call).  Measured:
+// the staging with four work items in flight per thread took the 1 000 x 30 call from 127 to 112 us (periodic 162 -> 145); the four
+// frames per block changed nothing measurable at 300 x 30 (33.4 -> 33.6 us in the probe): what is left of that kernel's 34 us is its
+// ~26 instructions per pair (a third of them index arithmetic and LDS addresses), not the lines it fetches.
 // I: the type pair numbers are computed in -- unsigned while the frame's list is shorter than 2^30 pairs (64-bit multiplies and
 // divisions are a dozen instructions each), long long beyond
-template <bool PBC, int CAP /* atoms of both selections the LDS copy holds */, typename I>
+template <bool PBC, int CAP /* atoms of both selections the LDS copy holds */, int FR /* frames per block */, typename I>
 MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long long F, const float* __restrict__ box,
                                         const unsigned* __restrict__ sel1, long long n1_, const unsigned* __restrict__ sel2, long long n2_,
                                         const unsigned* __restrict__ chains, int squared, long long slices, float* __restrict__ out)
 {
-    __shared__ float4 s_at[CAP];                                     // {x, y, z, chain id bits}: sel1's atoms, then sel2's
-    const long long g = xcd_contiguous_tile(F * slices);             // (frame, slice) in the result's memory order, XCD-contiguous
+    static_assert(FR == 1 || FR == 4, "one frame, or four with 16-byte loads");
+    __shared__ float4 s_at[FR][CAP];                                 // {x, y, z, chain id bits} per frame: sel1's atoms, then sel2's
+    const long long groups = (F + FR - 1) / FR;
+    const long long g = xcd_contiguous_tile(groups * slices);        // (frame group, slice) in the result's memory order, XCD-contiguous
     if (g < 0) return;
-    const long long f = g / slices, sl = g - f * slices;
+    const long long fg = g / slices, sl = g - fg * slices, f0 = fg * FR;
     const int tid = threadIdx.x;
     const I n1 = (I)n1_, n2 = (I)n2_;
     const long long P_ = n1_ * n2_;
     const int na = (int)(n1_ + n2_);
-    // staging: FOUR atoms per thread in flight -- their indices in one round trip, then their 12 coordinates (+ chains) in another:
-    // a block's time before its first pair is a chain of round trips, and a small call is little more than that (atom by atom the
-    // 300 x 30 call read 35 us)
-    for (int k0 = 0; k0 < na; k0 += 4 * DF_THREADS) {                // block-uniform
+    // staging: work items (atom, axis), FOUR per thread in flight -- the atom indices in one round trip, then the coordinates (and, with
+    // the x axis, the chain) in another: a block's time before its first pair is a chain of round trips
+    const bool vec = FR == 4 && (F & 3) == 0 && (reinterpret_cast<uintptr_t>(coords) & (uintptr_t)15) == 0;     // block-uniform
+    for (int w0 = 0; w0 < 3 * na; w0 += 4 * DF_THREADS) {           // block-uniform
         unsigned a[4];
-        float4 v[4];
+        float v[4][FR];
+        unsigned ch[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DF_THREADS + tid, kc = k < na ? k : na - 1;
-            a[u] = kc < (int)n1_ ? sel1[kc] : sel2[kc - (int)n1_];
+            const int w = w0 + u * DF_THREADS + tid, wc = w < 3 * na ? w : 3 * na - 1, k = wc / 3;
+            a[u] = k < (int)n1_ ? sel1[k] : sel2[k - (int)n1_];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* __restrict__ c = coords + (size_t)a[u] * 3 * (size_t)F + (size_t)f;
-            v[u] = make_float4(c[0], c[(size_t)F], c[2 * (size_t)F], mk_uint_as_float(PBC ? chains[a[u]] : 0u));
+            const int w = w0 + u * DF_THREADS + tid, wc = w < 3 * na ? w : 3 * na - 1, ax = wc - (wc / 3) * 3;
+            const float* __restrict__ c = coords + ((size_t)a[u] * 3 + (size_t)ax) * (size_t)F + (size_t)f0;
+            if (FR == 4 && vec) {
+                const float4 q = *reinterpret_cast<const float4*>(c);
+                v[u][0] = q.x; v[u][FR > 1 ? 1 : 0] = q.y; v[u][FR > 2 ? 2 : 0] = q.z; v[u][FR > 3 ? 3 : 0] = q.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < FR; ++r) v[u][r] = c[f0 + r < F ? r : 0];
+            }
+            ch[u] = (PBC && ax == 0) ? chains[a[u]] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int k = k0 + u * DF_THREADS + tid;
-            if (k < na) s_at[k] = v[u];
+            const int w = w0 + u * DF_THREADS + tid;
+            if (w < 3 * na) {
+                const int k = w / 3, ax = w - k * 3;
+#pragma unroll
+                for (int r = 0; r < FR; ++r) {
+                    float* dst = reinterpret_cast<float*>(&s_at[r][k]);
+                    dst[ax] = v[u][r];
+                    if (ax == 0) dst[3] = mk_uint_as_float(ch[u]);
+                }
+            }
         }
-    }
-    float bx = 0.f, by = 0.f, bz = 0.f, ibx = 0.f, iby = 0.f, ibz = 0.f;
-    if (PBC) {
-        bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
-        ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
     }
     mk_block_sync();
     // this slice's pairs [p_lo, p_hi): whole steps of the block, so that a lane's four pairs start on a multiple of four
     const long long steps = (P_ + DF_STEP - 1) / DF_STEP, per = (steps + slices - 1) / slices;
     const long long p_lo_ = sl * per * DF_STEP, p_end_ = (sl + 1) * per * DF_STEP;
     const I p_lo = (I)(p_lo_ < P_ ? p_lo_ : P_), p_hi = (I)(p_end_ < P_ ? p_end_ : P_);
-    float* __restrict__ row = out + (size_t)f * (size_t)P_;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(row) & (uintptr_t)15) == 0);      // block-uniform: the frame's row starts on 16 bytes
-    const float4* __restrict__ s2 = s_at + n1_;
     // the step from a lane's last pair + 1 to its next first pair, in whole rows and a rest (block-uniform)
     const I adv = (I)(DF_STEP - DF_PPL), adv_rows = adv / n2, adv_rest = adv - adv_rows * n2;
-    I p = p_lo + (I)tid * (I)DF_PPL;
-    I i = p / n2, j = p - i * n2;
-    // (the trip count is the BLOCK's: the roots' ballot inside is taken by whole waves; a lane past the end of the list computes on
-    //  clamped atoms and stores nothing)
-    for (I base = p_lo; base < p_hi; base += (I)DF_STEP, p += (I)DF_STEP) {
-        float d[DF_PPL];
-        bool ordinary = true;
-#pragma unroll
-        for (int k = 0; k < DF_PPL; ++k) {
-            const I ic = i < n1 ? i : n1 - 1;                                             // (pairs past the end of the list: the last atom again, never stored)
-            const float4 A = s_at[ic], B = s2[j];
-            const bool wrap = PBC && mk_float_bits(A.w) != mk_float_bits(B.w);           // distance_utils.pyx:49
-            d[k] = dist2_min_image_f32(A.x, A.y, A.z, B.x, B.y, B.z, bx, by, bz, ibx, iby, ibz, wrap);
-            ordinary = ordinary && mk_sqrt_ordinary(d[k]);
-            if (++j >= n2) { ++i; j = 0; }
+    const I p_first = p_lo + (I)tid * (I)DF_PPL;
+    const I i_first = p_first / n2, j_first = p_first - i_first * n2;
+    for (int r = 0; r < FR; ++r) {                                   // block-uniform
+        const long long f = f0 + r;
+        if (f >= F) break;
+        float bx = 0.f, by = 0.f, bz = 0.f, ibx = 0.f, iby = 0.f, ibz = 0.f;
+        if (PBC) {
+            bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+            ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
         }
-        if (!squared) {
-            if (mk_ballot(!ordinary) == 0ull) {
+        float* __restrict__ row = out + (size_t)f * (size_t)P_;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(row) & (uintptr_t)15) == 0);  // block-uniform: the frame's row starts on 16 bytes
+        const float4* __restrict__ s1 = s_at[r];
+        const float4* __restrict__ s2 = s_at[r] + n1_;
+        I p = p_first, i = i_first, j = j_first;
+        // (the trip count is the BLOCK's: the roots' ballot inside is taken by whole waves; a lane past the end of the list computes
+        //  on clamped atoms and stores nothing)
+        for (I base = p_lo; base < p_hi; base += (I)DF_STEP, p += (I)DF_STEP) {
+            float d[DF_PPL];
+            bool ordinary = true;
 #pragma unroll
-                for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn_ordinary(d[k]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
+            for (int k = 0; k < DF_PPL; ++k) {
+                const I ic = i < n1 ? i : n1 - 1;                                         // (pairs past the end of the list: the last atom again, never stored)
+                const float4 A = s1[ic], B = s2[j];
+                const bool wrap = PBC && mk_float_bits(A.w) != mk_float_bits(B.w);       // distance_utils.pyx:49
+                d[k] = dist2_min_image_f32(A.x, A.y, A.z, B.x, B.y, B.z, bx, by, bz, ibx, iby, ibz, wrap);
+                ordinary = ordinary && mk_sqrt_ordinary(d[k]);
+                if (++j >= n2) { ++i; j = 0; }
             }
-        }
-        if (aligned && p + (I)DF_PPL <= p_hi) {
-            *reinterpret_cast<float4*>(row + p) = make_float4(d[0], d[1], d[2], d[3]);
-        } else if (p < p_hi) {
+            if (!squared) {
+                if (mk_ballot(!ordinary) == 0ull) {
 #pragma unroll
-            for (int k = 0; k < DF_PPL; ++k)
-                if (p + (I)k < p_hi) row[p + (I)k] = d[k];
+                    for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn_ordinary(d[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
+                }
+            }
+            if (aligned && p + (I)DF_PPL <= p_hi) {
+                *reinterpret_cast<float4*>(row + p) = make_float4(d[0], d[1], d[2], d[3]);
+            } else if (p < p_hi) {
+#pragma unroll
+                for (int k = 0; k < DF_PPL; ++k)
+                    if (p + (I)k < p_hi) row[p + (I)k] = d[k];
+            }
+            // on to pair p + DF_STEP: (i, j) stands at pair p + DF_PPL
+            i += adv_rows; j += adv_rest;
+            if (j >= n2) { j -= n2; ++i; }
         }
-        // on to pair p + DF_STEP: (i, j) stands at pair p + DF_PPL
-        i += adv_rows; j += adv_rest;
-        if (j >= n2) { j -= n2; ++i; }
     }
 }
 

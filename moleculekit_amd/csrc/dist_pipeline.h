@@ -54,22 +54,26 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     // selections in LDS and walks the pair list in memory order).  (selfdist keeps the pair-table kernel: dist_kernels.h)
     const int rows_jpl = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
     if (!no_frame && !selfdist && rows_jpl == 0 && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
-        long long slices = (4096 + F - 1) / F;                              // enough blocks to fill the chip ...
-        const long long most = (P + 4 * DF_STEP - 1) / (4 * DF_STEP);       // ... of at least four steps each
+        // four consecutive frames per block while both selections fit 32 KB of LDS (they share the cache lines of their atoms' rows),
+        // one beyond; slices of the pair list so that ~2 000 blocks exist, of at least four steps each
+        const bool four = n1 + n2 <= 512;
+        const long long groups = four ? ceil_div(F, 4) : F;
+        long long slices = ceil_div(2048, groups);
+        const long long most = (P + 4 * DF_STEP - 1) / (4 * DF_STEP);
         slices = slices < 1 ? 1 : (slices > most ? most : slices);
         if (slices > 64) slices = 64;
-        const dim3 grid(padded8(F * slices)), block(DF_THREADS);
+        const dim3 grid(padded8(groups * slices)), block(DF_THREADS);
         auto go = [&](auto kern) { return be.launch(kern, grid, block, coords, F, box, sel1, n1, sel2, n2, chains, squared, slices, out); };
-        const bool small = n1 + n2 <= 1024, big_p = P > 0x3fffffffLL;
+        const bool big_p = P > 0x3fffffffLL;
         char nm[96];
-        snprintf(nm, sizeof nm, "mkamd::k_dist_frame<%s, %d, %s>", pbc ? "true" : "false", small ? 1024 : 4096, big_p ? "long long" : "unsigned int");
+        snprintf(nm, sizeof nm, "mkamd::k_dist_frame<%s, %d, %d, %s>", pbc ? "true" : "false", four ? 512 : 4096, four ? 4 : 1, big_p ? "long long" : "unsigned int");
         be.note_dist_kernel(nm);
         if (pbc) {
-            if (big_p) return small ? go(k_dist_frame<true, 1024, long long>) : go(k_dist_frame<true, 4096, long long>);
-            return small ? go(k_dist_frame<true, 1024, unsigned>) : go(k_dist_frame<true, 4096, unsigned>);
+            if (big_p) return four ? go(k_dist_frame<true, 512, 4, long long>) : go(k_dist_frame<true, 4096, 1, long long>);
+            return four ? go(k_dist_frame<true, 512, 4, unsigned>) : go(k_dist_frame<true, 4096, 1, unsigned>);
         }
-        if (big_p) return small ? go(k_dist_frame<false, 1024, long long>) : go(k_dist_frame<false, 4096, long long>);
-        return small ? go(k_dist_frame<false, 1024, unsigned>) : go(k_dist_frame<false, 4096, unsigned>);
+        if (big_p) return four ? go(k_dist_frame<false, 512, 4, long long>) : go(k_dist_frame<false, 4096, 1, long long>);
+        return four ? go(k_dist_frame<false, 512, 4, unsigned>) : go(k_dist_frame<false, 4096, 1, unsigned>);
     }
     if (!selfdist && !no_rows) {
         // rows of >= 64 second atoms are written directly by a wave per frame, from selections turned frame-major first

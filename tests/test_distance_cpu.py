@@ -171,7 +171,8 @@ def test_rectangular_kernel_shapes_and_modes_match_oracle():
 
 def test_block_per_frame_kernel_shapes_and_modes_match_oracle():
     """Round 5: k_dist_frame -- a block per frame (or slice of a frame's pairs) stages both selections in LDS and walks the
-    rectangular pair list in memory order, four consecutive pairs per lane: rows shorter and longer than a lane's four pairs and
+    rectangular pair list in memory order, four consecutive pairs per lane: four consecutive frames per block where both selections fit 32 KB of LDS (one 16-byte load per atom and axis when the
+    frame count is a multiple of four), rows shorter and longer than a lane's four pairs and
     than a block's step of 1 024, lists that end inside a lane's four pairs, frame rows that do and do not start on 16 bytes, one
     frame and several slices per frame, more than 1 024 atoms (the big LDS tier), pbc on and off, squared and not, a zero box
     edge and NaN coordinates -- the kernel source on the host emulator against the oracle, bit for bit.  (Triangular lists ride
@@ -179,7 +180,7 @@ def test_block_per_frame_kernel_shapes_and_modes_match_oracle():
     rng = np.random.default_rng(41)
     N = 1500
     ch = rng.integers(0, 4, size=N).astype(np.uint32)
-    for F in (1, 5):
+    for F in (1, 5, 8):                                       # (8: four frames per block through 16-byte loads; 5: a ragged last group)
         c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
         b = rng.uniform(15, 25, size=(3, F)).astype(np.float32)
         if F > 1:
@@ -198,7 +199,7 @@ def test_block_per_frame_kernel_shapes_and_modes_match_oracle():
     # more atoms than the small LDS tier holds; a list that the row kernel would take, through the frame kernel
     c = rng.uniform(-30, 30, size=(N, 3, 2)).astype(np.float32)
     b = rng.uniform(15, 25, size=(3, 2)).astype(np.float32)
-    s1, s2 = np.arange(0, 40, dtype=np.uint32), np.arange(100, 1400, dtype=np.uint32)
+    s1, s2 = np.arange(0, 40, dtype=np.uint32), np.arange(100, 1400, dtype=np.uint32)     # 1 340 atoms: one frame per block
     assert np.array_equal(E.dist_trajectory(c, b, s1, s2, ch, False, True, avoid=2), oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
 
 

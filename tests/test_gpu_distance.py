@@ -286,6 +286,15 @@ def test_block_per_frame_kernel_over_many_blocks_and_every_kernel_on_the_same_sh
                     dist_trajectory(c, b, s1, s2, ch, selfd, pbc, r)
                     seen.add(ctx.last_dist_kernel().split("<")[0])
                     assert np.array_equal(r, exp, equal_nan=True), (selfd, n1, n2, pbc, avoid, ctx.last_dist_kernel())
+        # a frame count that is a multiple of four: the frame kernel's 16-byte staging loads
+        c4, b4 = np.ascontiguousarray(c[:, :, :200]), np.ascontiguousarray(b[:, :200])
+        s1, s2 = rng.choice(N, 300, replace=False).astype(np.uint32), rng.choice(N, 30, replace=False).astype(np.uint32)
+        ctx.set_dist_kernels(0)
+        for pbc in (False, True):
+            r = np.full((200, 9000), -3.0, np.float32)
+            dist_trajectory(c4, b4, s1, s2, ch, False, pbc, r)
+            assert "k_dist_frame" in ctx.last_dist_kernel() and ", 4," in ctx.last_dist_kernel()
+            assert np.array_equal(r, oracle.dist_trajectory(c4, b4, s1, s2, ch, False, pbc), equal_nan=True), pbc
     finally:
         ctx.set_dist_kernels(0)
     assert {"mkamd::k_dist_frame", "mkamd::k_dist_rect", "mkamd::k_build_atom_pairs + mkamd::k_dist_pairs", "mkamd::k_sel_to_frames + mkamd::k_dist_rows"} <= seen, seen
