@@ -890,6 +890,17 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
     for _ in range(2):
         step()
     ctx.synchronize()
+    # set-up too: let the clocks settle under this workload before anything is counted.  A GPU that has been idle (loading, host-side
+    # workload generation) takes its first tens of milliseconds of kernels at lower clocks -- the 20 timed steps of the default run
+    # are 43 ms: they read 2.158 ms per step where 6 s of the same steps read 2.105 (profiles/r5_bench_cfg2.json, `sustained`), and the
+    # few-millisecond distance legs read 20 % low (bench_distances).  Untimed, reported as `clock_settle_s`; the W warm-up steps follow.
+    settle = float(getattr(args, "settle_seconds", 0.0) or 0.0) if compute is None else 0.0
+    if settle > 0:
+        t_end = time.perf_counter() + settle
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step()
+            ctx.synchronize()
     for _ in range(warmup):
         step()
     ctx.synchronize()                     # also surfaces asynchronous errors of the warm-up
@@ -955,11 +966,11 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
             if "full_plain" in keep:
                 res["full_plain"] = full
             del full
-            full = sv.voxelize_gather(nchunks=4, loopback=world == 1)  # (the first point-to-point exchange sets its channels up)
+            full = sv.voxelize_gather(nchunks=4, loopback=world == 1 and compute is None)  # (the first point-to-point exchange sets its channels up)
             del full
             fence()
             g0 = time.perf_counter()
-            full = sv.voxelize_gather(nchunks=4, loopback=world == 1)
+            full = sv.voxelize_gather(nchunks=4, loopback=world == 1 and compute is None)
             fence()
             res["gather_exchange"] = getattr(sv, "last_exchange", "?") + (" (one rank: batched send / receive to itself)" if world == 1 else "")
             both = (time.perf_counter() - g0) * 1e3
@@ -1057,6 +1068,8 @@ def main():
                     help="after the timed K steps, keep stepping until this much wall time has been spent on the same workload and "
                          "report it as `sustained` (the K-step region of a 64^3 workload is tens of milliseconds: too short for a "
                          "utilisation sampler to see, and for the clocks to settle). 0 = skip")
+    ap.add_argument("--settle-seconds", type=float, default=1.0,
+                    help="untimed steps of the workload before the warm-up steps, so that the timed steps run at settled clocks (0 = none)")
     ap.add_argument("--no-topology", action="store_true",
                     help="cfg1 / cfg4 (rotated copies / frames of one molecule): the plain call on the sigma matrix repeated per frame instead of the topology handle (A-B)")
     ap.add_argument("--no-single", action="store_true", help="skip the single-grid latency probe (profiling passes: every launch is a full batch)")
@@ -1237,7 +1250,7 @@ def main():
                            "items_per_gpu_per_step": B, "grid": [int(v) for v in nv], "channels": C,
                            "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
                            "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
-                           "value_tolerance": args.value_tol, "topology_reuse": bool(res.get("topology")),
+                           "value_tolerance": args.value_tol, "topology_reuse": bool(res.get("topology")), "clock_settle_s": args.settle_seconds,
                            "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region; "
                                           "fences over gloo, feature gathers over RCCL after everything timed)",
                            "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},
