@@ -32,7 +32,10 @@ namespace mkamd {
 // (Round 5 tried the test on the SHIFTED separation instead -- |d - b r| < b (1/2 - 2^-12) per axis and |q| < 512: three compares
 //  against per-frame constants, a max3 and a compare where this takes seven instructions; same results, emulator and GPU tests
 //  green -- and every periodic kernel ran 10-15 % SLOWER in a same-session probe (200 x 500: 245 us against 213; the open calls
-//  beside them unchanged): three compares into scalar pairs and their s_and chain wait on each other, the max3 / fma form does not.)
+//  beside them unchanged): three compares into scalar pairs and their s_and chain wait on each other, the max3 / fma form does not.
+//  Also tried: the shift as ONE fma per axis where |r| <= 2 on every axis -- b r is exact then, so d - b r rounds once either way --
+//  for one more compare (`qm < 2.5`) on the test: 3 instructions fewer of ~27, bit-identical (GPU tests green), and within +-1.5 % of
+//  this form on every periodic shape of tools/dist_shapes_probe.py, three alternating runs each: not adopted.)
 MK_DEV float round_quotient_exact(float d, float b) { return roundf(mk_fdiv_rn(d, b)); }
 
 // distance_utils.pyx:34-54 (_dist) / :188-206 (_dist2)

@@ -30,7 +30,7 @@ for n1, n2, selfd in ((300, 30, False), (30, 300, False), (300, 60, False), (100
     P = int(lib.mkamd_dist_count_pairs(n1, n2, int(selfd)))
     out = torch.empty((F, P), device=dev)
     for pbc in (False, True):
-        for avoid in (0, 1, 3):                  # free choice; without the block-per-frame kernel (round 4's choice); the tile kernels only
+        for avoid in tuple(int(a) for a in os.environ.get('PROBE_AVOID', '0,1,3').split(',')):                  # free choice; without the block-per-frame kernel (round 4's choice); the tile kernels only
             ctx.set_dist_kernels(avoid)
             ms = t(lambda: ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2, chains.data_ptr(), selfd, pbc, False, out.data_ptr()))
             alg = out.numel() * 4 + (n1 + n2) * 3 * F * 4
