@@ -9,10 +9,6 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests -m gpu -q -s > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log)
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log)
-(timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_cfg2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2.log)
-(timeout 400 python bench.py --no-cpu-baseline --no-extra --no-pipeline --min-seconds 1 > gpurun_out/bench_cfg2_nopipe.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2_nopipe.log)
-(timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
-(timeout 400 python bench.py --workload dist --steps 20 --warmup 3 > gpurun_out/bench_dist.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist.log)
 rm -rf gpurun_out/prof_* gpurun_out/pmc_*
 PROF="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
 TRACE="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 40 --warmup 5"
@@ -56,4 +52,10 @@ done
 (timeout 120 tools/store_pattern > gpurun_out/store_pattern.txt 2>&1)
 (timeout 60 tools/sqrt_exact > gpurun_out/sqrt_exact.txt 2>&1)
 grep -a "cutoff shell" gpurun_out/pytest_gpu.log | sort -u; tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
+python tools/collect_profiles.py $TAG > /dev/null      # the PMC summaries of THIS build first: the bench lines below then carry roofline.traffic
+# the bench lines proper (the default one exactly as the driver runs it), after the counters so that they can quote them
+(timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_cfg2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2.log)
+(timeout 400 python bench.py --no-cpu-baseline --no-extra --no-pipeline --min-seconds 1 > gpurun_out/bench_cfg2_nopipe.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2_nopipe.log)
+(timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
+(timeout 400 python bench.py --workload dist --steps 20 --warmup 3 > gpurun_out/bench_dist.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist.log)
 python tools/collect_profiles.py $TAG
