@@ -306,6 +306,8 @@ def bench_distances(args, emit=True):
         """Calls back to back for `seconds` before a timed leg: a leg of a few milliseconds on an idle GPU is timed at the clocks
         it finds (the stand-alone `--workload dist` run read 0.39 / 0.55 of the roofline where the same legs read 0.44 / 0.68 at
         the end of the default run, behind seconds of other work)."""
+        if not getattr(args, "settle_seconds", 1.0):   # (--settle-seconds 0: profiling passes, where every launch is a row of the trace)
+            return
         t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end:
             for _ in range(16):

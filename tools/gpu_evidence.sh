@@ -10,14 +10,14 @@ R=$GRAFT_REPO_ROOT
 (timeout 900 python -m pytest tests -m gpu -q -s > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log)
 (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log)
 rm -rf gpurun_out/prof_* gpurun_out/pmc_*
-PROF="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
-TRACE="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 40 --warmup 5"
+PROF="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --settle-seconds 0 --steps 8 --warmup 2"
+TRACE="--no-cpu-baseline --no-extra --no-single --min-seconds 0 --settle-seconds 0 --steps 40 --warmup 5"
 for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$wl -- python $R/bench.py $TRACE --workload $wl > $R/gpurun_out/rocprof_$wl.log 2>&1)
 done
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py $TRACE --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg4_plain -- python $R/bench.py $TRACE --workload cfg4 --no-topology > $R/gpurun_out/rocprof_cfg4_plain.log 2>&1)
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dist -- python $R/bench.py --workload dist --no-cpu-baseline --steps 20 --warmup 3 > $R/gpurun_out/rocprof_dist.log 2>&1)
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dist -- python $R/bench.py --workload dist --no-cpu-baseline --settle-seconds 0 --steps 20 --warmup 3 > $R/gpurun_out/rocprof_dist.log 2>&1)
 pmc() { name=$1; wl=$2; shift; shift; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${wl}_$name -- python $R/bench.py $PROF --workload $wl $PMC_EXTRA > $R/gpurun_out/pmc_${wl}_$name.log 2>&1); }
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_IFETCH"
@@ -34,7 +34,7 @@ pmc nopipe_fetch cfg2 FETCH_SIZE
 pmc nopipe_write cfg2 WRITE_SIZE
 pmc nopipe_sq1 cfg2 $SQ1
 # the distance leg: one kernel variant per pass (MKAMD_DIST_ONLY), SQ + waits + traffic
-dpmc() { name=$1; mode=$2; shift; shift; (cd /tmp && MKAMD_DIST_ONLY=$mode timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_dist_${mode}_$name -- python $R/bench.py --workload dist --no-cpu-baseline --steps 8 --warmup 2 > $R/gpurun_out/pmc_dist_${mode}_$name.log 2>&1); }
+dpmc() { name=$1; mode=$2; shift; shift; (cd /tmp && MKAMD_DIST_ONLY=$mode timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_dist_${mode}_$name -- python $R/bench.py --workload dist --no-cpu-baseline --settle-seconds 0 --steps 8 --warmup 2 > $R/gpurun_out/pmc_dist_${mode}_$name.log 2>&1); }
 for mode in periodic nonperiodic; do
   dpmc sq1 $mode $SQ1
   dpmc fetch $mode FETCH_SIZE
@@ -59,3 +59,9 @@ python tools/collect_profiles.py $TAG > /dev/null      # the PMC summaries of TH
 (timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
 (timeout 400 python bench.py --workload dist --steps 20 --warmup 3 > gpurun_out/bench_dist.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist.log)
 python tools/collect_profiles.py $TAG
+# gpurun merges at most 64 MiB back: the per-launch traces are not needed once the stats / counter tables exist
+find gpurun_out -name "*_kernel_trace.csv" -size +1M -delete; du -sh gpurun_out | tail -1
+# the summaries as collected HERE travel too (profiles/ itself is not merged back): cp gpurun_out/profiles_out/* profiles/ at home
+rm -rf gpurun_out/profiles_out; mkdir -p gpurun_out/profiles_out; cp profiles/${TAG}_* gpurun_out/profiles_out/
+if [ $(du -sm gpurun_out | cut -f1) -gt 55 ]; then rm -rf gpurun_out/prof_* gpurun_out/pmc_*; echo "raw rocprofv3 tables dropped (over the merge limit)"; fi
+du -sh gpurun_out | tail -1
