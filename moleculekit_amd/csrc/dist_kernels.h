@@ -113,8 +113,10 @@ MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long 
     const int pl = threadIdx.x & (DT - 1), fq = threadIdx.x >> 6;
     float* __restrict__ o = out + (size_t)(f0 + fq) * (size_t)P + (size_t)(p0 + pl);
     const size_t step = (size_t)NW * (size_t)P;
-    if (f0 + DT <= F && p0 + DT <= p_end && ((P | p0) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & (uintptr_t)15) == 0) {   // (any float* is accepted as the result: an offset view is 4-byte aligned only)
-        // a full tile whose rows start on 16 bytes: FOUR store instructions of 16 bytes per lane instead of sixteen of 4 (the
+    if (f0 + DT <= F && p0 + DT <= p_end) {
+        // a full tile: FOUR store instructions of 16 bytes per lane instead of sixteen of 4, whatever the alignment of its rows
+        // (mk_store_f4_dword_aligned: the triangular list of 450 atoms has 101 025 pairs per row -- an odd pitch; any float* is
+        // accepted as the result, an offset view is 4-byte aligned only) (the
         // memory pipeline takes a wave's store instructions one by one: round-4 PMC showed the kernel at the same 0.30 ms with
         // and without its image arithmetic and with a third of its loads).  A lane owns four consecutive pairs of one frame;
         // the lanes are dealt so that the 32 lanes the LDS serves together read 32 different banks:
@@ -131,15 +133,8 @@ MK_DEV void store_tile_rows(const float (&tile)[DT][DT + 1], long long f0, long 
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int fg = (fq + NW * it) * 4 + r;
-            *reinterpret_cast<float4*>(out + (size_t)(f0 + fg) * (size_t)P + (size_t)(p0 + 4 * q)) = v[it];
+            mk_store_f4_dword_aligned(out + (size_t)(f0 + fg) * (size_t)P + (size_t)(p0 + 4 * q), v[it]);
         }
-    } else
-    if (f0 + DT <= F && p0 + DT <= p_end) {
-        float v[ROWS];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) v[i] = tile[pl][fq + i * NW];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) o[(size_t)i * step] = v[i];
     } else {
         for (int i = 0; i < ROWS; ++i)
             if (f0 + fq + i * NW < F && p0 + pl < p_end) o[(size_t)i * step] = tile[pl][fq + i * NW];
@@ -260,6 +255,10 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
     else { if (run_wraps) run_body(DistFlag<true>{}, DistFlag<false>{}); else run_body(DistFlag<false>{}, DistFlag<false>{}); }
 }
 
+// (Round 5 tried the kernel WITHOUT the turn through LDS: a lane stores the four roots of a batch -- four consecutive pairs of its
+//  frame -- as 16 bytes of out[f, p ..], a store instruction touches 64 rows whose lines fill up over the wave's four batches.  No
+//  LDS, no barrier, the same bits -- and 35-55 % SLOWER on every triangular shape (450 x 450: 400 us against 292, 2.1 TB/s; 100 x 100:
+//  23.8 against 19.7): sixty-four quarter-lines per store instruction are what the memory pipeline is slowest at.)
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
                                         const float* __restrict__ box, const unsigned* __restrict__ pa,
                                         const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
@@ -454,8 +453,8 @@ MK_KERNEL(256) void k_sel_to_frames(const float* __restrict__ coords, long long 
 }
 
 // A wave: frame f, first atoms [ic * ROWS_CI, ...), second atoms of block jb: lane-strided (j = jb * 64 * JPL + lane + 64 * k,
-// k < JPL: JPL stores of 256 contiguous bytes per first atom) or, where rows start on 16 bytes (VEC: n2 a multiple of 4, JPL =
-// 4), four neighbours per lane (j = jb * 256 + 4 * lane + k: ONE store of 1 KB per first atom).  Wave tasks are numbered in the
+// k < JPL: JPL stores of 256 contiguous bytes per first atom) or (VEC, JPL = 4) four neighbours per lane (j = jb * 256 + 4 * lane
+// + k: ONE store of 1 KB per first atom, 16 bytes per lane at whatever alignment the row has).  Wave tasks are numbered in the
 // result's memory order (frame, then chunk of first atoms, then block of second atoms) and dealt to the XCDs in contiguous
 // ranges, like the tiles of the other kernels.
 template <bool PBC, int JPL, bool VEC>
@@ -523,7 +522,14 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
             }
         }
         if constexpr (VEC) {
-            if (whole || j0 < n2) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);   // (n2 % 4 == 0: all four or none; non-temporal stores measured: opposite signs for the two modes)
+            // (rows of any length and any float* result: a row starts on 4 bytes only when n2 is not a multiple of four;
+            //  non-temporal stores measured: opposite signs for the two modes)
+            if (whole || j0 + 3 < n2) mk_store_f4_dword_aligned(o, make_float4(d[0], d[1], d[2], d[3]));
+            else {
+#pragma unroll
+                for (int k = 0; k < JPL; ++k)
+                    if (j0 + k < n2) o[k] = d[k];
+            }
         } else if (whole) {
 #pragma unroll
             for (int k = 0; k < JPL; ++k) o[64 * k] = d[k];
@@ -630,7 +636,6 @@ MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long l
             ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
         }
         float* __restrict__ row = out + (size_t)f * (size_t)P_;
-        const bool aligned = ((reinterpret_cast<uintptr_t>(row) & (uintptr_t)15) == 0);  // block-uniform: the frame's row starts on 16 bytes
         const float4* __restrict__ s1 = s_at[r];
         const float4* __restrict__ s2 = s_at[r] + n1_;
         I p = p_first, i = i_first, j = j_first;
@@ -657,8 +662,8 @@ MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long l
                     for (int k = 0; k < DF_PPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
                 }
             }
-            if (aligned && p + (I)DF_PPL <= p_hi) {
-                *reinterpret_cast<float4*>(row + p) = make_float4(d[0], d[1], d[2], d[3]);
+            if (p + (I)DF_PPL <= p_hi) {
+                mk_store_f4_dword_aligned(row + p, make_float4(d[0], d[1], d[2], d[3]));   // (rows of an odd pitch start on 4 bytes only)
             } else if (p < p_hi) {
 #pragma unroll
                 for (int k = 0; k < DF_PPL; ++k)

@@ -95,7 +95,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
                                  n1, n2, squared, out);
             };
             const bool no_vec = (avoid & DIST_AVOID_VEC) != 0;
-            const bool vec = jpl == 4 && n2 % 4 == 0 && ((uintptr_t)out & 15u) == 0 && !no_vec;      // rows start on 16 bytes
+            const bool vec = jpl == 4 && !no_vec;      // (16-byte stores at 4-byte alignment: rows of any length, any float* result)
             {
                 char nm[96];
                 snprintf(nm, sizeof nm, "mkamd::k_sel_to_frames + mkamd::k_dist_rows<%s, %d, %s>", pbc ? "true" : "false", jpl, vec ? "true" : "false");

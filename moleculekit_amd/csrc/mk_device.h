@@ -140,6 +140,10 @@ MK_DEV void mk_wave_priority_high() { __builtin_amdgcn_s_setprio(3); }
 // the in-order pre-pass gains 1 % (step 2.50 -> 2.47 ms), the overlapped one nothing.
 typedef float mk_v4f_ __attribute__((ext_vector_type(4)));
 typedef unsigned mk_v2u_ __attribute__((ext_vector_type(2)));
+// Sixteen bytes to an address that is only known to be 4-byte aligned (a result row whose pitch is an odd number of floats, an
+// offset view): ONE global_store_dwordx4 -- the compiler emits it for a 4-byte-aligned 16-byte copy on amdhsa targets, where the
+// kernel driver runs every queue in the unaligned access mode (SH_MEM_CONFIG.ALIGNMENT_MODE) -- instead of four dword stores.
+MK_DEV void mk_store_f4_dword_aligned(float* p, float4 v) { __builtin_memcpy(p, &v, 16); }
 MK_DEV void mk_tmp_store(float4* p, float4 v) { __builtin_nontemporal_store(mk_v4f_{v.x, v.y, v.z, v.w}, reinterpret_cast<mk_v4f_*>(p)); }
 MK_DEV void mk_tmp_store(uint2* p, uint2 v) { __builtin_nontemporal_store(mk_v2u_{v.x, v.y}, reinterpret_cast<mk_v2u_*>(p)); }
 MK_DEV float4 mk_tmp_load(const float4* p) { const mk_v4f_ v = __builtin_nontemporal_load(reinterpret_cast<const mk_v4f_*>(p)); return make_float4(v.x, v.y, v.z, v.w); }

@@ -248,6 +248,7 @@ MK_DEV unsigned mk_lds_add(unsigned* p, unsigned v) { const unsigned o = *p; *p 
 MK_DEV void mk_lds_min(unsigned* p, unsigned v) { if (v < *p) *p = v; }
 MK_DEV void mk_wave_priority_high() {}
 template <bool STREAM> MK_DEV void mk_store_result(float4* p, float4 v) { *p = v; }
+MK_DEV void mk_store_f4_dword_aligned(float* p, float4 v) { memcpy(p, &v, 16); }
 MK_DEV void mk_tmp_store(float4* p, float4 v) { *p = v; }
 MK_DEV void mk_tmp_store(uint2* p, uint2 v) { *p = v; }
 MK_DEV float4 mk_tmp_load(const float4* p) { return *p; }

@@ -212,8 +212,11 @@ def test_row_kernel_shapes_and_modes_match_oracle():
     squared and not, unsorted and repeated atom indices; everything against the oracle, bit for bit."""
     import ctypes
     jpl = lambda n1, n2, F: E.lib().emu_dist_rows_jpl(ctypes.c_longlong(n1), ctypes.c_longlong(n2), ctypes.c_longlong(F))
-    shapes = ((40, 52), (40, 64), (15, 70), (24, 128), (17, 129), (33, 200), (20, 256), (30, 500), (50, 260), (16, 128))
-    assert [jpl(*s, 67) for s in shapes] == [1, 1, 0, 2, 0, 0, 4, 4, 1, 0]
+    # (the last three: four second atoms per lane with rows that are NOT a multiple of four long -- 16-byte stores at 4-byte
+    #  alignment and a lane whose four straddle the end of the row, round 5)
+    shapes = ((40, 52), (40, 64), (15, 70), (24, 128), (17, 129), (33, 200), (20, 256), (30, 500), (50, 260), (16, 128),
+              (20, 254), (20, 511), (25, 253))
+    assert [jpl(*s, 67) for s in shapes] == [1, 1, 0, 2, 0, 0, 4, 4, 1, 0, 4, 4, 4]
     assert jpl(1, 64, 67) == 0 and jpl(200, 500, 2048) == 4 and jpl(300, 30, 100) == 0       # (too few pairs; the bench leg; short rows)
     rng = np.random.default_rng(12)
     N = 300

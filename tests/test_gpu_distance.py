@@ -300,6 +300,44 @@ def test_block_per_frame_kernel_over_many_blocks_and_every_kernel_on_the_same_sh
     assert {"mkamd::k_dist_frame", "mkamd::k_dist_rect", "mkamd::k_build_atom_pairs + mkamd::k_dist_pairs", "mkamd::k_sel_to_frames + mkamd::k_dist_rows"} <= seen, seen
 
 
+def test_results_at_four_byte_alignment_take_the_sixteen_byte_stores():
+    """Round 5: every kernel stores 16 bytes per lane at whatever alignment a result row has (rows of an odd pitch -- the triangular
+    list of 450 atoms has 101 025 pairs --, a result pointer that is an offset view: 4-byte aligned only).  The same calls into an
+    aligned buffer and into one that starts 4, 8 and 12 bytes behind a 16-byte boundary, with a sentinel in front of and behind the
+    result: bit for bit the oracle's, nothing written outside."""
+    import torch
+    from moleculekit_amd import _lib
+    dev = torch.device("cuda", 0)
+    ctx = _lib.default_context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    rng = np.random.default_rng(77)
+    N, F = 1200, 130
+    c = rng.uniform(-40, 40, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(30, 45, size=(3, F)).astype(np.float32)
+    ch = rng.integers(0, 5, size=N).astype(np.uint32)
+    dc, db = torch.as_tensor(c, device=dev), torch.as_tensor(b, device=dev)
+    dch = torch.as_tensor(ch.astype(np.int32), device=dev)
+    seen = set()
+    for selfd, n1, n2 in ((False, 20, 254), (False, 20, 256), (True, 131, 131), (False, 300, 30), (False, 301, 31), (False, 70, 70)):
+        s2 = rng.choice(N, n2, replace=False).astype(np.uint32)
+        s1 = s2.copy() if selfd else rng.choice(N, n1, replace=False).astype(np.uint32)
+        d1, d2 = torch.as_tensor(s1.astype(np.int32), device=dev), torch.as_tensor(s2.astype(np.int32), device=dev)
+        for pbc in (False, True):
+            exp = oracle.dist_trajectory(c, b, s1, s2, ch, selfd, pbc)
+            P = exp.shape[1]
+            for off in (0, 1, 2, 3):
+                buf = torch.full((F * P + 8,), -3.0, device=dev, dtype=torch.float32)
+                out = buf[4 + off: 4 + off + F * P]
+                assert out.data_ptr() % 16 == (4 * off) % 16
+                ctx.dist_trajectory_dev(dc.data_ptr(), F, db.data_ptr(), d1.data_ptr(), n1, d2.data_ptr(), n2, dch.data_ptr(), selfd, pbc, False, out.data_ptr())
+                torch.cuda.synchronize(dev)
+                seen.add(ctx.last_dist_kernel().split("<")[0])
+                h = buf.cpu().numpy()
+                assert np.array_equal(h[4 + off: 4 + off + F * P].reshape(F, P), exp, equal_nan=True), (selfd, n1, n2, pbc, off, ctx.last_dist_kernel())
+                assert (h[:4 + off] == -3.0).all() and (h[4 + off + F * P:] == -3.0).all(), (selfd, n1, n2, pbc, off)
+    assert {"mkamd::k_dist_frame", "mkamd::k_build_atom_pairs + mkamd::k_dist_pairs", "mkamd::k_sel_to_frames + mkamd::k_dist_rows"} <= seen, seen
+
+
 def test_the_short_square_root_is_the_correctly_rounded_one_for_every_float():
     """Round 5: the kernels' root is one exact-residual correction of x * rsq(x) (csrc/mk_device.h, mk_fsqrt_rn_ordinary) -- 8 issue slots
     instead of the provable form's 12 in kernels bound by instruction issue.  Correct rounding is a property of this chip's
