@@ -278,9 +278,7 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
             for_pair_run(coords, F, (unsigned)f * 4u, bx, by, bz, pa, pb, wrap, P, pw,
                          [&](int k0, const float (&d2)[DP_BATCH]) {
                              // the batch's roots behind ONE wave-uniform test (mk_sqrt_ordinary: practically always true)
-                             bool ordinary = true;
-#pragma unroll
-                             for (int u = 0; u < DP_BATCH; ++u) ordinary = ordinary && mk_sqrt_ordinary(d2[u]);
+                             const bool ordinary = mk_sqrt_ordinary_all(d2);
                              if (squared) {
 #pragma unroll
                                  for (int u = 0; u < DP_BATCH; ++u) tile[pq * DP_RUN + k0 + u][fl] = d2[u];
@@ -355,13 +353,12 @@ MK_DEV void dist_rect_block(const float* __restrict__ coords, long long F, const
         const float xn = at(a_next, 0), yn = at(a_next, 1), zn = at(a_next, 2);
         const unsigned ca = PBC ? chains[a] : 0u;                    // wave-uniform (scalar load)
         float d2[DR_PW];
-        bool ordinary = true;
 #pragma unroll
         for (int k = 0; k < DR_PW; ++k) {
             const bool wrap = PBC && mk_readlane(vcb, k) != ca;      // distance_utils.pyx:49
             d2[k] = dist2_min_image_f32(xa, ya, za, B3[k][0], B3[k][1], B3[k][2], bx, by, bz, ibx, iby, ibz, wrap);
-            ordinary = ordinary && mk_sqrt_ordinary(d2[k]);
         }
+        const bool ordinary = mk_sqrt_ordinary_all(d2);
         // the roots of the batch behind ONE wave-uniform test (all values ordinary numbers: practically always)
         if (squared) {
 #pragma unroll
@@ -497,21 +494,18 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
         const float xa = t1[i], ya = t1[(size_t)np1 + (size_t)i], za = t1[2 * (size_t)np1 + (size_t)i];   // wave-uniform: scalar loads
         const unsigned ca = PBC ? c1[i] : 0u;
         float d[JPL];
-        bool ordinary = true;
         if constexpr (JPL >= 2 && !PBC) {
 #pragma unroll
             for (int k = 0; k < JPL; k += 2) {                       // two pairs per packed operation
                 const mk_f2 d2 = dist2_x2(xa, ya, za, mk_f2{B[k][0], B[k + 1][0]}, mk_f2{B[k][1], B[k + 1][1]}, mk_f2{B[k][2], B[k + 1][2]});
                 d[k] = d2[0]; d[k + 1] = d2[1];
-                ordinary = ordinary && mk_sqrt_ordinary(d[k]) && mk_sqrt_ordinary(d[k + 1]);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < JPL; ++k) {
+            for (int k = 0; k < JPL; ++k)
                 d[k] = dist2_min_image_f32(xa, ya, za, B[k][0], B[k][1], B[k][2], bx, by, bz, ibx, iby, ibz, PBC && cb[k] != ca);
-                ordinary = ordinary && mk_sqrt_ordinary(d[k]);
-            }
         }
+        const bool ordinary = mk_sqrt_ordinary_all(d);
         if (!squared) {
             if (mk_ballot(!ordinary) == 0ull) {
 #pragma unroll
@@ -643,16 +637,15 @@ MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long l
         //  on clamped atoms and stores nothing)
         for (I base = p_lo; base < p_hi; base += (I)DF_STEP, p += (I)DF_STEP) {
             float d[DF_PPL];
-            bool ordinary = true;
 #pragma unroll
             for (int k = 0; k < DF_PPL; ++k) {
                 const I ic = i < n1 ? i : n1 - 1;                                         // (pairs past the end of the list: the last atom again, never stored)
                 const float4 A = s1[ic], B = s2[j];
                 const bool wrap = PBC && mk_float_bits(A.w) != mk_float_bits(B.w);       // distance_utils.pyx:49
                 d[k] = dist2_min_image_f32(A.x, A.y, A.z, B.x, B.y, B.z, bx, by, bz, ibx, iby, ibz, wrap);
-                ordinary = ordinary && mk_sqrt_ordinary(d[k]);
                 if (++j >= n2) { ++i; j = 0; }
             }
+            const bool ordinary = mk_sqrt_ordinary_all(d);
             if (!squared) {
                 if (mk_ballot(!ordinary) == 0ull) {
 #pragma unroll

@@ -55,10 +55,12 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     const int rows_jpl = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
     if (!no_frame && !selfdist && rows_jpl == 0 && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
         // four consecutive frames per block while both selections fit 32 KB of LDS (they share the cache lines of their atoms' rows),
-        // one beyond; slices of the pair list so that ~2 000 blocks exist, of at least four steps each
+        // one beyond; slices of the pair list so that ~1 280 blocks exist, of at least four steps each (measured with 512 ... 4 096:
+        // 300 x 30 x 2 048 is flat, 300 x 60 64-65 -> 59-60 us against 2 048 blocks, 1 000 x 30 +25 % beyond 2 048;
+        // profiles/r5_dist_frame_blocks.txt)
         const bool four = n1 + n2 <= 512;
         const long long groups = four ? ceil_div(F, 4) : F;
-        long long slices = ceil_div(2048, groups);
+        long long slices = ceil_div(1280, groups);                   // (32 KB of LDS per block: 5 blocks per CU x 256 CUs are resident together)
         const long long most = (P + 4 * DF_STEP - 1) / (4 * DF_STEP);
         slices = slices < 1 ? 1 : (slices > most ? most : slices);
         if (slices > 64) slices = 64;

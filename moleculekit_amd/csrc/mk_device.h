@@ -237,6 +237,22 @@ MK_DEV float mk_rint(float a) { return __builtin_rintf(a); }              // rou
 // interleave across the batch (with a branch per root every pair of the distance kernels was a basic block of its own: a
 // serial chain of ~30 dependent instructions, five s_nop and three branches per distance).
 MK_DEV bool mk_sqrt_ordinary(float x) { return (__float_as_uint(x) - 0x0F800000u) < (0x7F800000u - 0x0F800000u); }   // in [2^-96, inf)
+// ... and of a whole batch at once: bit patterns of non-negative floats order like the values, everything else (a sign bit, NaN) is
+// a LARGER unsigned number than +inf -- so "all in [2^-96, inf)" is the smallest pattern >= 2^-96's and the largest < inf's: a
+// v_min3_u32 / v_max3_u32 tree and two compares (round 5: and-ing four single tests cost the compiler ~20 instructions per batch of
+// four -- compare, 0/1, shift, or --, a fifth of a non-periodic pair's instructions in the block-per-frame kernel).
+template <int N>
+MK_DEV bool mk_sqrt_ordinary_all(const float (&x)[N])
+{
+    unsigned lo = __float_as_uint(x[0]), hi = lo;
+#pragma unroll
+    for (int i = 1; i < N; ++i) {
+        const unsigned b = __float_as_uint(x[i]);
+        lo = b < lo ? b : lo;
+        hi = b > hi ? b : hi;
+    }
+    return lo >= 0x0F800000u && hi < 0x7F800000u;
+}
 // (the provable form: v_sqrt_f32 + the Tuckerman correction, 12 issue slots; what the fast form below is verified against)
 MK_DEV float mk_fsqrt_rn_tuckerman(float x)
 {

@@ -300,6 +300,13 @@ MK_DEV float mk_fmul_rn(float a, float b) { volatile float r = a * b; return r; 
 MK_DEV float mk_fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 MK_DEV float mk_fsqrt_rn(float a) { return sqrtf(a); }
 MK_DEV bool mk_sqrt_ordinary(float x) { return x >= 0x1.0p-96f && x < INFINITY; }
+template <int N>
+MK_DEV bool mk_sqrt_ordinary_all(const float (&x)[N])
+{
+    bool all = true;
+    for (int i = 0; i < N; ++i) all = all && mk_sqrt_ordinary(x[i]);
+    return all;
+}
 MK_DEV float mk_fsqrt_rn_ordinary(float a) { return sqrtf(a); }
 MK_DEV float mk_fsqrt_rn_tuckerman(float a) { return sqrtf(a); }
 MK_DEV float mk_load_f32_uniform_base(const float* base, unsigned byte_offset)
