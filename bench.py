@@ -615,6 +615,16 @@ def _free_port():
     return port
 
 
+def _json_only_stdout():
+    """The contract is ONE JSON line on stdout, and libraries write there too (gloo: "[Gloo] Rank n is connected to ..." from every
+    rank; RCCL with NCCL_DEBUG set).  From here on file descriptor 1 IS stderr for everything below Python; `print` keeps the real
+    stdout through a duplicate.  (Rank processes only: the launcher's children inherit its descriptors.)"""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(keep, "w", buffering=1)
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves -- one process per
     GPU under torch.distributed.run on this node (rendezvous on 127.0.0.1) -- and let rank 0 print the line."""
@@ -1087,6 +1097,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         # not under torchrun: become the launcher (one rank per GPU, RCCL), the line comes from rank 0 of the children
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
+    _json_only_stdout()
     if args.dry_run:
         return dry_run(args)
     if args.workload == "dropin":
