@@ -202,7 +202,7 @@ def cpu_baseline(name):
     oracle.calculate_occupancy(centers[:64], p["coords"][s:e], p["sigmas"][s:e], box=box)   # warm
     t0 = time.perf_counter()
     for _ in range(reps):
-        oracle.calculate_occupancy(centers, p["coords"][s:e], p["sigmas"][s:e], box=box)
+        ref = oracle.calculate_occupancy(centers, p["coords"][s:e], p["sigmas"][s:e], box=box)
     dt = time.perf_counter() - t0
     listed, granted = os.cpu_count() or 1, host_cores_granted()
     out = {"value": round(reps * centers.shape[0] * 8 / dt / 1e6, 4), "unit": "Mvoxel-channels/s",
@@ -226,6 +226,28 @@ def cpu_baseline(name):
                             "value_at_all_granted_cores": round(centers.shape[0] * 8 / runs[granted] / 1e6, 2),
                             "seconds_by_threads": {str(k): round(t, 3) for k, t in sorted(runs.items())},
                             "speedup_over_serial": round(v / out["value"], 1)}
+        # beside the baseline, NOT part of it: the library's own host entry point (mkamd_calculate_occupancy_cpu, SURVEY 8b(2): the
+        # same contract through a cell list over the atoms) on the same sample -- product code, checked here against the port's result
+        try:
+            from moleculekit_amd.occupancy_utils import calculate_occupancy_cpu
+            c32 = np.ascontiguousarray(p["coords"][s:e], np.float32)
+            s64 = np.ascontiguousarray(p["sigmas"][s:e], np.float64)
+            c64 = np.ascontiguousarray(centers, np.float64)
+            calculate_occupancy_cpu(c64[:64], c32, s64, np.zeros((64, 8), np.float64), n_threads=1)      # (loads the library)
+            ent = {}
+            for nt in sorted({1, granted}):
+                res = np.zeros((c64.shape[0], 8), np.float64)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    calculate_occupancy_cpu(c64, c32, s64, res, n_threads=nt)
+                ent[nt] = time.perf_counter() - t0
+                same = bool(np.array_equal(res, np.asarray(ref).reshape(res.shape)))
+            out["library_host_entry"] = {"what": "mkamd_calculate_occupancy_cpu (product code: cell list over the atoms; not the baseline)",
+                                         "value_1_thread": round(reps * c64.shape[0] * 8 / ent[1] / 1e6, 2),
+                                         "value_all_granted": round(reps * c64.shape[0] * 8 / ent[granted] / 1e6, 2), "threads": granted,
+                                         "unit": "Mvoxel-channels/s", "equal_to_the_port_bit_for_bit": same}
+        except Exception as ex:                     # noqa: BLE001  (a reported extra: never the reason the line is missing)
+            out["library_host_entry"] = {"error": f"{type(ex).__name__}: {ex}"[:200]}
     return out
 
 
