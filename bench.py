@@ -970,14 +970,33 @@ def run_workload(name, B, steps, warmup, ctx, dev, rank, world, args, fence, wan
         # the same steps again, long enough to be seen from outside (same fences, max over ranks): every rank runs the
         # same number of steps, fixed up front from rank-independent numbers
         n2 = int(min(max(steps, np.ceil(min_s / (elapsed / steps))), 200000))
+        # ... and, beside them, the shader clock the device sustains under THIS load: one wave on a stream of its own counts shader
+        # clock ticks against the fixed 100 MHz reference for half a second (mkamd_clock_probe_dev).  Boxes differ here -- the tile
+        # kernel takes the same 4.50 M cycles on every one of them, and four of them differed by 7 % in step time (docs/EXPERIMENTS_r5.md).
+        ticks = probe_stream = None
+        if compute is None and hasattr(ctx, "clock_probe_dev"):
+            import torch
+            probe_stream = torch.cuda.Stream(dev)
+            ticks = torch.zeros(2, dtype=torch.int64, device=dev)
         fence()
         t0 = time.perf_counter()
-        for _ in range(n2):
+        for i in range(n2):
             step()
+            if ticks is not None and i == n2 // 4:
+                try:
+                    ctx.clock_probe_dev(probe_stream.cuda_stream, 500000, ticks.data_ptr())
+                except Exception:                 # noqa: BLE001  (a reported extra)
+                    ticks = None
         fence()
         e2 = _max_over_ranks(time.perf_counter() - t0, world)
         res["sustained"] = {"steps": n2, "seconds": round(e2, 4), "ms_per_step": round(e2 / n2 * 1e3, 4),
                             "value": round(world * B * V * C * n2 / e2 / 1e6, 2), "unit": "Mvoxel-channels/s"}
+        if ticks is not None:
+            probe_stream.synchronize()
+            t_sh, t_ref = (int(v) for v in ticks.cpu().tolist())
+            if t_ref > 0:
+                res["sustained"]["shader_clock_ghz_under_load"] = round(t_sh / t_ref * 0.1, 4)
+                res["sustained"]["shader_clock_source"] = "s_memtime ticks / s_memrealtime ticks (100 MHz) of one wave spinning 0.5 s beside the steps"
 
     def gather_legs():
         # (a secondary measurement: a failure in it -- RCCL, memory for the world x B result -- is reported on the line,

@@ -153,6 +153,12 @@ int mkamd_ctx_last_tile_kernel(mkamd_ctx* ctx, char* name, size_t name_cap);
  * roofline leg): enable, run, then read back the accumulated time and launch count (resets). */
 int mkamd_ctx_enable_kernel_timing(mkamd_ctx* ctx, int enable);
 int mkamd_ctx_read_kernel_timing(mkamd_ctx* ctx, double* total_ms, int64_t* launches);
+/* The shader clock the device sustains UNDER a given load (bench.py reports it next to the roofline: boxes run the same kernel
+ * -- the same cycle count -- at 2.0 to 2.2 GHz).  Enqueues ONE wave on `hip_stream` (the caller's: a stream other than the one
+ * the load runs on) that spins for `microseconds` of the fixed 100 MHz reference counter (s_memrealtime) and stores
+ * d_ticks2[0] = shader clock ticks (s_memtime) and d_ticks2[1] = reference ticks that passed meanwhile (device memory, two
+ * uint64): clock = d_ticks2[0] / d_ticks2[1] x 100 MHz.  Asynchronous; nothing of the context is touched. */
+int mkamd_clock_probe_dev(mkamd_ctx* ctx, void* hip_stream, int64_t microseconds, uint64_t* d_ticks2);
 
 /* (1) calculate_occupancy, exact reference contract -------------------------------------------
  * Replaces occupancy_utils.pyx:34-61: for every centre/channel

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mkamd_ctx_withdraw_promise": (_c_int, [_vp]),
     "mkamd_ctx_pipelined_calls": (_c_int, [_vp, ctypes.POINTER(_c_i64)]),
     "mkamd_ctx_last_tile_kernel": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
+    "mkamd_clock_probe_dev": (_c_int, [_vp, _vp, _c_i64, _vp]),
     "mkamd_frames_to_items_dev": (_c_int, [_vp, _vp, _vp, _c_i64, _c_i64, _c_i64, ctypes.c_float, _vp]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
@@ -274,6 +275,11 @@ class Context:
     def withdraw_promise(self):
         """Drop a promise no call has consumed."""
         _check(load().mkamd_ctx_withdraw_promise(self._h))
+
+    def clock_probe_dev(self, stream, microseconds, d_ticks2):
+        """One wave on `stream` that spins for `microseconds` and stores {shader clock ticks, 100 MHz reference ticks} (uint64 x 2)
+        at the device address `d_ticks2`: the clock the device sustains under whatever runs beside it (include/mkamd_voxel.h)."""
+        _check(load().mkamd_clock_probe_dev(self._h, int(stream) or None, int(microseconds), int(d_ticks2)))
 
     def frames_to_items_dev(self, stream, d_src, rows, src_pitch, n_frames, scale, d_dst):
         """[rows][frames] (frame fastest, pitch ``src_pitch``) -> [frames][rows] * scale on ``stream`` (include/mkamd_voxel.h)."""

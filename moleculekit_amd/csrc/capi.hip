@@ -310,6 +310,20 @@ static int ensure_err_flag(mkamd_ctx* ctx)
     return 0;
 }
 
+// One wave that spins for `ref_ticks` of the fixed-frequency reference counter (s_memrealtime) and reports how far the SHADER clock
+// counter (s_memtime) got meanwhile: launched on a stream of the caller's beside the work whose clock is asked for.
+__global__ void k_clock_probe(unsigned long long ref_ticks, unsigned long long* __restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_readcyclecounter();
+    unsigned long long r;
+    do { __builtin_amdgcn_s_sleep(16); r = __builtin_amdgcn_s_memrealtime(); } while (r - r0 < ref_ticks);
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    out[0] = t1 - t0;
+    out[1] = r - r0;
+}
+
+
 extern "C" {
 
 #ifndef MKAMD_SRC_HASH            // _build.py: sha256 over the sources this library was compiled from (first 16 hex digits)
@@ -584,6 +598,17 @@ try {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *mismatches = (uint64_t)host[0];
     if (first_bad_bits) *first_bad_bits = (uint32_t)(host[1] & 0xffffffffull);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_clock_probe_dev(mkamd_ctx* ctx, void* hip_stream, int64_t microseconds, uint64_t* d_ticks2)
+try {
+    if (!ctx || !d_ticks2) return fail(MKAMD_EINVAL, "ctx / result pointer is NULL");
+    if (microseconds < 1 || microseconds > 5000000) return fail(MKAMD_EINVAL, "clock probe: 1 us .. 5 s");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, (unsigned long long)microseconds * 100ull,
+                       (unsigned long long*)d_ticks2);
+    HIP_TRY(hipGetLastError());
     return MKAMD_OK;
 } MK_API_CATCH
 

@@ -746,3 +746,24 @@ def test_streamed_and_sharded_frame_drivers_use_the_topology_and_stay_bitwise(hi
     with pytest.raises(ValueError, match="sigma rows differ"):
         sg = p["sigmas"].copy(); sg[n + 3, 7] = 1.23
         ShardedVoxelizer.from_host(p["coords"], p["atom_offsets"], sg, origins, nv, 1.0, box=p["box"], device=dev, ctx=hip_ctx, shared_sigmas=True)
+
+
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """mkamd_clock_probe_dev: one wave counts shader clock ticks against the 100 MHz reference counter on a stream of the caller's
+    (bench.py reports the clock the device sustains under the headline load).  Idle device, 20 ms: the reference ticks are what was
+    asked for, the clock is a number an MI355X can have."""
+    import torch
+    from moleculekit_amd import _lib
+    dev = torch.device("cuda", 0)
+    ctx = _lib.default_context(0)
+    st = torch.cuda.Stream(dev)
+    ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+    ctx.clock_probe_dev(st.cuda_stream, 20000, ticks.data_ptr())
+    st.synchronize()
+    t_sh, t_ref = (int(v) for v in ticks.cpu().tolist())
+    assert 2_000_000 <= t_ref < 2_200_000, t_ref                      # 20 ms of a 100 MHz counter
+    ghz = t_sh / t_ref * 0.1
+    assert 0.3 < ghz < 3.0, ghz
+    with pytest.raises(Exception):
+        ctx.clock_probe_dev(st.cuda_stream, 0, ticks.data_ptr())
+

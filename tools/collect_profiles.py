@@ -48,7 +48,7 @@ def collect(passes, out_name, items, cmd, note_extra=""):
            "_note": "mean per launch; one rocprofv3 --pmc pass per counter group (tools/gpu_evidence.sh), FETCH_SIZE and WRITE_SIZE in "
                     "passes of their own; KiB; FETCH_SIZE counts 64 B per 128-B request on gfx950: double it (MI355X_MICROARCH.md, HBM). "
                     "--no-single: no single-grid probe launches, every launch of a kernel is one full step. GRBM_GUI_ACTIVE: shader "
-                    "cycles of the launch summed over the 8 XCDs (the effective clock = it / 8 / the kernel's duration)." + note_extra}
+                    "cycles of the launch summed over the 8 XCDs (counter passes run every kernel ALONE: divide by a duration of the same pass, not of a trace run in which kernels overlap)." + note_extra}
     for k in sorted(acc):
         out[k] = {c: round(sum(v) / len(v), 2) for c, v in sorted(acc[k].items())}
         out[k]["_launches"] = max(len(v) for v in acc[k].values())

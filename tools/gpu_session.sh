@@ -1,20 +1,11 @@
 # tools/gpu_session.sh -- the commands of the CURRENT gpurun session
-# round 5, session 16: k_frames_to_items with non-temporal loads / stores (read once, written once: it runs beside the tile kernel, whose records
-# live in the L2) against the committed build, alternating: the streamed trajectory driver's steady ms per call
+# round 5, session 17: the clock probe (mkamd_clock_probe_dev): its test, and the default bench line with `sustained.shader_clock_ghz_under_load`
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-V=$PWD/.variants/libmkamd_base.so
-cat > /tmp/stream_once.py <<'PY'
-import sys, os, json
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-import torch, bench
-from moleculekit_amd import _lib
-ctx = _lib.default_context(0); dev = torch.device("cuda", 0)
-for i in range(2):
-    r = bench.bench_stream_cfg4(ctx, dev, 0.914, frames=8192, chunk=256)
-print(os.environ.get("TAGX"), r["steady_ms_per_call"], r["ms_per_call"], r["frames_per_s"])
+(timeout 600 python -m pytest tests/test_gpu_api.py -m gpu -q -x -k "clock_probe" 2>&1 | tail -3)
+(timeout 600 python bench.py --no-extra --no-cpu-baseline > gpurun_out/bench_probe.log 2>&1); python - <<'PY'
+import json
+for l in open("gpurun_out/bench_probe.log"):
+    if l.startswith("{"):
+        d = json.loads(l); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["sustained"])
 PY
-for r in 1 2 3; do
-  TAGX=base MKAMD_LIB=$V MKAMD_ALLOW_DIAGNOSTICS=1 timeout 200 python /tmp/stream_once.py 2>&1 | tail -1
-  TAGX=new timeout 200 python /tmp/stream_once.py 2>&1 | tail -1
-done
