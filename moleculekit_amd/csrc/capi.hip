@@ -317,7 +317,8 @@ __global__ void k_clock_probe(unsigned long long ref_ticks, unsigned long long* 
     if (threadIdx.x != 0) return;
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_readcyclecounter();
     unsigned long long r;
-    do { __builtin_amdgcn_s_sleep(16); r = __builtin_amdgcn_s_memrealtime(); } while (r - r0 < ref_ticks);
+    unsigned spins = 0u;                                             // (bounded whatever the counter does: a probe must not be able to hang a queue)
+    do { __builtin_amdgcn_s_sleep(16); r = __builtin_amdgcn_s_memrealtime(); } while (r - r0 < ref_ticks && ++spins < (1u << 25));
     const unsigned long long t1 = __builtin_readcyclecounter();
     out[0] = t1 - t0;
     out[1] = r - r0;
