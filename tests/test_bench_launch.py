@@ -22,6 +22,9 @@ def test_bench_gpus2_dry_run_spawns_two_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
+    # the contract is ONE JSON line on stdout: what libraries print to descriptor 1 ("[Gloo] Rank 0 is connected to ...", from
+    # every rank) goes to stderr in the rank processes
+    assert r.stdout.strip() == lines[0].strip(), r.stdout[:400]
     d = json.loads(lines[0])
     assert d["dry_run"] is True and d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["ok"] is True
     # the ranks went through bench.run_workload itself (sharded loader, timed loop, fences, max over ranks, the plain
