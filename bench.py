@@ -654,7 +654,7 @@ def launch_ranks(args, argv):
     if not args.dry_run:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        if have < args.gpus and not (os.environ.get("MKAMD_BENCH_SHARE_DEVICES", "0") == "1" and have > 0):
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} HIP device(s) visible on this node")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
@@ -1160,6 +1160,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    # REHEARSAL of the multi-process path on a box with fewer GPUs than ranks (MKAMD_BENCH_SHARE_DEVICES=1): ranks share devices
+    # round-robin.  Everything between the processes is real -- torchrun, the rendezvous, the gloo fences, the max over ranks,
+    # RCCL's answer to two ranks on one device in the gather legs -- the numbers are not a scaling measurement and the line says so.
+    shared_devices = os.environ.get("MKAMD_BENCH_SHARE_DEVICES", "0") == "1" and torch.cuda.device_count() > 0
+    if shared_devices:
+        local = local % torch.cuda.device_count()
     if torch.cuda.device_count() <= local:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local)
@@ -1305,6 +1311,7 @@ def main():
                            "voxelsize": p["voxelsize"], "atoms_per_gpu": int(p["atom_offsets"][-1]),
                            "periodic": p["box"] is not None, "tile_k": args.tile_k, "pipelined_steps": not args.no_pipeline,
                            "value_tolerance": args.value_tol, "topology_reuse": bool(res.get("topology")), "clock_settle_s": args.settle_seconds,
+                           **({"rehearsal": "ranks SHARE devices (MKAMD_BENCH_SHARE_DEVICES=1): the multi-process path on fewer GPUs than ranks, not a scaling measurement"} if shared_devices else {}),
                            "parallelism": f"dp{world} (items sharded: every rank loads, stages and keeps only its own shard; no collective in the timed region; "
                                           "fences over gloo, feature gathers over RCCL after everything timed)",
                            "device": info["name"], "arch": info["arch"], "compute_units": info["compute_units"]},

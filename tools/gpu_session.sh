@@ -1,7 +1,13 @@
 # tools/gpu_session.sh -- the commands of the CURRENT gpurun session
-# round 5, session 21: more random parity on the final build: 3 000 further voxelizer configurations (automatic mode), 600 through the
-# workgroup-per-item kernel, 2 000 further dist_trajectory shapes
+# round 5, session 22: the multi-process bench path on REAL processes with a GPU under them -- two and four ranks sharing the box's one device
+# (MKAMD_BENCH_SHARE_DEVICES=1: a rehearsal, not a scaling measurement): (a) without the gather legs, (b) with them -- RCCL is asked for a
+# communicator of ranks that sit on one device and must be survived: rank 0's line has to print either way
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 1500 python tests/sweep_gpu_random.py 20000 3000; MKAMD_TILE_ITEMS=1 timeout 600 python tests/sweep_gpu_random.py 30000 600; timeout 1200 python tests/sweep_gpu_dist.py 1000 2000) > gpurun_out/random_sweeps_extra.txt 2>&1
-grep -h "worst\|differ" gpurun_out/random_sweeps_extra.txt | cut -c1-200
+export MKAMD_BENCH_SHARE_DEVICES=1
+(timeout 400 python bench.py --gpus 2 --no-extra --no-cpu-baseline --no-single --steps 10 --warmup 3 --min-seconds 1 --no-gather > gpurun_out/rehearsal_2_nogather.log 2>gpurun_out/rehearsal_2_nogather.err; echo "rc=$?" >> gpurun_out/rehearsal_2_nogather.log)
+tail -c 1500 gpurun_out/rehearsal_2_nogather.log; echo
+(timeout 400 python bench.py --gpus 4 --no-extra --no-cpu-baseline --no-single --steps 10 --warmup 3 --min-seconds 1 --no-gather --batch 64 > gpurun_out/rehearsal_4_nogather.log 2>gpurun_out/rehearsal_4_nogather.err; echo "rc=$?" >> gpurun_out/rehearsal_4_nogather.log)
+tail -c 700 gpurun_out/rehearsal_4_nogather.log; echo
+(timeout 500 python bench.py --gpus 2 --no-extra --no-cpu-baseline --no-single --steps 10 --warmup 3 --min-seconds 1 --gather-timeout 60 > gpurun_out/rehearsal_2_gather.log 2>gpurun_out/rehearsal_2_gather.err; echo "rc=$?" >> gpurun_out/rehearsal_2_gather.log)
+tail -c 1200 gpurun_out/rehearsal_2_gather.log; echo; tail -5 gpurun_out/rehearsal_2_gather.err | cut -c1-300
