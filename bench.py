@@ -17,12 +17,16 @@ feature tensors is timed separately: `gather_ms` (one padded all-gather after th
 `gather_overlapped_extra_ms` (chunks gathered on a communication stream while the next chunk is computed).
 The headline workload is the same at every N (the driver divides the per-N values); north_star's "batched
 molecules" case (cfg3) runs through the same sharded path as a secondary leg (`batched_molecules`).
-`--dry-run` exercises the launch / rendezvous / shard / gather plumbing on CPU (gloo, stand-in compute).
+`--dry-run` exercises the launch / rendezvous / shard / gather plumbing on CPU (gloo, stand-in compute);
+MKAMD_BENCH_SHARE_DEVICES=1 rehearses the real multi-process path on a box with fewer GPUs than ranks (ranks share
+devices; the line carries `config.rehearsal` and is not a scaling measurement).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded around the tile
 kernel on the stream it runs on; at N = 1 `other_workloads` carries the same measurement for the other
 BASELINE configs; `cpu_baseline` times the oracle (oracle/liboracle.so, a port of the reference's serial
-Cython kernel) on a bounded sample of the same workload on 1 host core.
+Cython kernel) on a bounded sample of the same workload on 1 host core.  Before the W warm-up steps the workload runs
+untimed for `--settle-seconds` (clocks; `config.clock_settle_s`); `sustained` repeats the steps for seconds and
+reports the shader clock the device held meanwhile.  stdout carries the JSON line only.
 """
 from __future__ import annotations
 
