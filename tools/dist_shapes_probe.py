@@ -22,7 +22,7 @@ def t(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-SHAPES_ODD = ((300, 30, False), (1000, 30, False), (100, 30, False), (300, 31, False)) if os.environ.get("PROBE_ODD") else None
+SHAPES_ODD = ((450, 450, True), (300, 300, True), (1000, 1000, True), (17, 130, False)) if os.environ.get("PROBE_ODD") else None
 for n1, n2, selfd in SHAPES_ODD or ((300, 30, False), (30, 300, False), (300, 60, False), (1000, 30, False), (300, 300, True), (450, 450, True), (1000, 1000, True), (300, 300, False),
                       (200, 500, False)):
     s2 = np.sort(rng.choice(N, n2, replace=False)).astype(np.int32)
