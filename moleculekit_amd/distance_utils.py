@@ -188,3 +188,40 @@ def squareform(distances):
     out[iu] = d[: len(iu[0])]
     out[(iu[1], iu[0])] = d[: len(iu[0])]
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# The drop-in hook for this row.  The reference reaches its compiled ``moleculekit.distance_utils`` only through
+# function-local imports -- projections/util.py:22 (pp_calcDistances) and :100 (get_reduced_distances) behind MetricDistance,
+# distance.py:242 / :278 / :308 / :360 (cdist, pdist, squareform, calculate_contacts), molecule.py:3731 (_detectCollisions) --
+# so swapping the attributes of that module makes every one of those callers run on the GPU unchanged.
+# ------------------------------------------------------------------------------------------------
+HOOKED = ("dist_trajectory", "contacts_trajectory", "get_collisions", "dist_trajectory_reduction",
+          "dist_trajectory_reduction_pairs", "cdist", "pdist", "squareform")
+
+
+def install():
+    """Swap the eight functions of an installed ``moleculekit.distance_utils`` for this module's (same positional
+    signatures, in-place ``results``).  Returns ``{name: original}``; idempotent; ``uninstall()`` puts them back."""
+    import moleculekit.distance_utils as ref
+
+    saved = getattr(ref, "_mkamd_reference", None)
+    if saved is not None:
+        return saved
+    mine = globals()
+    saved = {name: getattr(ref, name) for name in HOOKED if hasattr(ref, name)}
+    for name in saved:
+        setattr(ref, name, mine[name])
+    ref._mkamd_reference = saved
+    return saved
+
+
+def uninstall():
+    """Undo ``install()``."""
+    import moleculekit.distance_utils as ref
+
+    saved = getattr(ref, "_mkamd_reference", None)
+    if saved is not None:
+        for name, fn in saved.items():
+            setattr(ref, name, fn)
+        ref._mkamd_reference = None

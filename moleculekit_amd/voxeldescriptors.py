@@ -377,12 +377,23 @@ def _getOccupancyC(coords, centers, channelsigmas, _lattice=None):
     return feats.astype(np.float64)
 
 
-def install():
+def install(distances: bool = True):
     """Make an installed moleculekit use the MI355X kernels: swaps
     ``moleculekit.tools.voxeldescriptors._getOccupancyC`` (the sole caller of the Cython kernel,
-    voxeldescriptors.py:356) for this module's.  Returns the original function; ``uninstall()`` puts it back."""
+    voxeldescriptors.py:356) for this module's and -- unless ``distances=False`` -- the functions of
+    ``moleculekit.distance_utils`` for ``moleculekit_amd.distance_utils``' (what MetricDistance, ``calculate_contacts``,
+    ``cdist`` / ``pdist`` and ``_detectCollisions`` import at call time).  Returns the original ``_getOccupancyC``;
+    ``uninstall()`` puts everything back."""
     import moleculekit.tools.voxeldescriptors as ref
 
+    if distances:
+        try:
+            import moleculekit.distance_utils  # noqa: F401
+        except ImportError:                                             # (an installation without the compiled module)
+            pass
+        else:
+            from . import distance_utils as _du
+            _du.install()
     if getattr(ref, "_getOccupancyC_reference", None) is not None:      # already installed
         return ref._getOccupancyC_reference
     original = ref._getOccupancyC
@@ -393,9 +404,13 @@ def install():
 
 def uninstall():
     """Undo ``install()``."""
+    import sys
     import moleculekit.tools.voxeldescriptors as ref
 
     original = getattr(ref, "_getOccupancyC_reference", None)
     if original is not None:
         ref._getOccupancyC = original
         ref._getOccupancyC_reference = None
+    if "moleculekit.distance_utils" in sys.modules:
+        from . import distance_utils as _du
+        _du.uninstall()

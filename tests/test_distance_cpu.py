@@ -297,3 +297,33 @@ def test_row_kernel_image_shift_is_bit_exact_at_every_boundary():
     got = E.dist_trajectory(c3, b2, s1, s2, ch, False, True)
     exp = oracle.dist_trajectory(c3, b2, s1, s2, ch, False, True)
     assert np.array_equal(got, exp, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(exp))
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's own MetricDistance projections on its real trajectory (tests/metricdistance_real.py)
+# ------------------------------------------------------------------------------------------------
+class _OracleFns:
+    @staticmethod
+    def dist_trajectory(coords, box, s1, s2, chains, selfdist, pbc, res):
+        res[...] = oracle.dist_trajectory(coords, box, s1, s2, chains, selfdist, pbc)
+
+    @staticmethod
+    def dist_trajectory_reduction(coords, box, g1, g2, c1, c2, selfdist, pbc, masses, r1, r2, res):
+        res[...] = oracle.dist_trajectory_reduction(coords, box, g1, g2, c1, c2, selfdist, pbc, masses, r1, r2)
+
+
+def test_oracle_on_the_reference_held_metricdistance_projections():
+    """Host XTC reader -> oracle == the compiled reference bit for bit, and within the reference's own 1e-3 of the arrays the
+    reference holds (they were written by an older build: 7.6e-6 / 3.8e-6 away from today's reference too)."""
+    from tests import metricdistance_real as M
+    g = M.load()
+    coords, box = M.read_trajectory(g)
+    for key in M.KEYS:
+        exact, worst = M.check(M.run_projection(_OracleFns, coords, box, g, key), g, key)
+        assert exact, key
+        assert worst is None or worst < 1e-5, (key, worst)
+    # the held contact matrix (contacts.npy beside distances.npy; no test of the reference reads it any more, and it is in the
+    # pair order of an older build: ligand atom-major): the `metric="contacts"` post-processing of the drivers, threshold 8
+    d = M.run_projection(_OracleFns, coords, box, g, "distances")
+    n1, n2 = len(g["distances_sel1"]), len(g["distances_sel2"])
+    assert np.array_equal((d <= 8).reshape(-1, n1, n2).transpose(0, 2, 1).reshape(d.shape[0], -1), g["contacts_held"])

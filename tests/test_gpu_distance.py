@@ -355,3 +355,35 @@ def test_the_short_square_root_is_the_correctly_rounded_one_for_every_float():
     d = a[:, None, :] - b[None, :, :]                                  # float32, one rounding per operation, the reference's order
     d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
     assert d2.dtype == np.float32 and np.array_equal(got, np.sqrt(d2))
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's OWN answers on its real trajectory (tests/metricdistance_real.py): own XTC reader ->
+# own kernels, the calls MetricDistance makes (arguments as the reference's drivers built them)
+# ------------------------------------------------------------------------------------------------
+def test_reference_held_metricdistance_projections_on_the_gpu():
+    from moleculekit_amd import distance_utils as du
+    from tests import metricdistance_real as M
+    g = M.load()
+    coords, box = M.read_trajectory(g)
+    report = {}
+    for key in M.KEYS:
+        res = M.run_projection(du, coords, box, g, key)
+        exact, worst = M.check(res, g, key)                      # allclose(atol=1e-3) with the held arrays, as the reference asserts
+        report[key] = (exact, worst)
+        assert exact, f"{key}: not bit-exact with the compiled reference"
+    print("metricdistance_real:", report)
+    # ... and the device XTC decoder feeds the same bits to the same kernels (coords frame-major on the device -> [N,3,F])
+    import torch
+    from moleculekit_amd.xtc import read_xtc_frames_dev
+    xyz, _, _, _ = read_xtc_frames_dev(M.TRAJ, scale=10.0)
+    assert np.array_equal(xyz.permute(1, 2, 0).contiguous().cpu().numpy(), coords)
+    # contacts through the device-side compaction == threshold on the held distances' own pair order
+    s1, s2 = g["distances_sel1"], g["distances_sel2"]
+    lists = du.contacts_trajectory(coords, box, s1, s2, g["distances_chains"], False, True, 8.0)
+    d = M.run_projection(du, coords, box, g, "distances")
+    for f in (0, 57, 199):
+        hit = np.nonzero(d[f] <= np.float32(8.0))[0]
+        i, j = np.divmod(hit, len(s2))
+        # (dist2 <= 64 and sqrt(dist2) <= 8 agree: the root is correctly rounded and 8 is exact)
+        assert lists[f] == np.stack([s1[i], s2[j]], 1).ravel().tolist()
