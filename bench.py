@@ -441,11 +441,175 @@ def bench_distances(args, emit=True):
         check = not args.no_cpu_baseline
         line["selfdist"] = shape_leg(s2[:450].copy(), s2[:450].copy(), True, check)
         line["small_call"] = shape_leg(s2[:300].copy(), s1[:30].copy(), False, check)
+        # ---- round 6: the group reductions (MetricDistance's residue contact maps) and the device-side contact lists ----
+        line["reduction"] = bench_reductions(args, ctx, dev, busy, check)
+        line["contacts"] = bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s1, s2, d1, d2, F)
     del coords, out
     torch.cuda.empty_cache()
     if emit:
         print(json.dumps(line), flush=True)
     return line
+
+
+def _clock_ghz(ctx, dev, call, us=30000):
+    """Shader clock the device holds while `call` runs back to back: one wave on a stream of its own counts shader clock ticks against
+    the fixed 100 MHz reference for `us` microseconds (mkamd_clock_probe_dev) beside the calls.  GHz, or None."""
+    try:
+        import torch
+        ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+        ps = torch.cuda.Stream(dev)
+        torch.cuda.synchronize(dev)
+        ctx.clock_probe_dev(ps.cuda_stream, us, ticks.data_ptr())
+        t_end = time.perf_counter() + us * 1.3e-6
+        while time.perf_counter() < t_end:
+            call()
+            torch.cuda.current_stream(dev).synchronize()
+        ps.synchronize()
+        sh, ref = (int(v) for v in ticks.cpu().tolist())
+        return round(sh / ref * 0.1, 3) if ref > 0 else None
+    except Exception:                                   # noqa: BLE001  (a reported extra)
+        return None
+
+
+def reduction_workload(G=200, A=15, F=512, L=60.0, seed=5):
+    """tools/bench_reduction.py's protein-like trajectory (the shape the 2.9 ms of round 2 were measured on): G residues of A
+    atoms (centres uniform in an L^3 box, atoms N(0, 1.5 A) around them, N(0, 0.3 A) per frame), 4 chains of G/4 residues."""
+    rng = np.random.default_rng(seed)
+    N = G * A
+    centres = rng.uniform(0, L, size=(G, 3))
+    c0 = (np.repeat(centres, A, axis=0) + rng.normal(0, 1.5, size=(N, 3))).astype(np.float32)
+    coords = np.ascontiguousarray((c0[:, :, None] + rng.normal(0, 0.3, size=(N, 3, F))).astype(np.float32))
+    box = np.full((3, F), L, dtype=np.float32)
+    atoms = np.arange(N, dtype=np.int32)
+    offs = (np.arange(G + 1, dtype=np.int64) * A)
+    chains = (np.arange(G) // max(1, G // 4)).astype(np.uint32)
+    return coords, box, atoms, offs, chains, np.ones(N, np.float32)
+
+
+def bench_reductions(args, ctx, dev, busy, check):
+    """dist_trajectory_reduction (distance_utils.pyx:211-281) on device pointers: all 19 900 pairs of 200 residues of 15 atoms,
+    512 frames -- 2.29 G atom-pair distances per call.  The path is bound by instruction issue, not by memory (59 MB of
+    algorithmic traffic per call): `roofline` is the HBM line the contract asks for, `valu` the one that bounds it
+    (atom pairs per second; issue slots the chip had per atom pair at the measured clock; instructions per pair from the
+    committed PMC pass of this build when there is one)."""
+    import torch
+    from moleculekit_amd import _lib
+    G, A, F = 200, 15, 512
+    coords, box, atoms, offs, chains, masses = reduction_workload(G, A, F)
+    N = coords.shape[0]
+    t = lambda a: torch.as_tensor(a, device=dev)
+    d_c, d_b, d_a, d_o, d_m = t(coords), t(box), t(atoms), t(offs), t(masses)
+    d_ch = t(chains.astype(np.int32))
+    P = G * (G - 1) // 2
+    out = torch.empty((F, P), device=dev, dtype=torch.float32)
+    groups = [atoms[offs[g]:offs[g + 1]].tolist() for g in range(G)]
+    res = {"shape": f"{G} groups x {A} atoms, {F} frames, all {P} group pairs (selfdist): {P * A * A * F / 1e9:.2f} G atom pairs per call"}
+    alg = N * 3 * F * 4 + 3 * F * 4 + F * P * 4
+
+    def leg(pbc, r1, r2, pairs=False, block=0):
+        ctx.set_reduction_block(block)
+        n_out = G if pairs else P
+        o = out if not pairs else torch.empty((F, G), device=dev, dtype=torch.float32)
+        call = lambda: ctx.dist_reduction_dev(d_c, N, F, d_b, d_a, d_o, G, N, d_a, d_o, G, d_ch, d_ch, not pairs, pairs, pbc, d_m, r1, r2, o)
+        busy(call, 0.3)
+        for _ in range(max(3, args.warmup)):
+            call()
+        torch.cuda.synchronize(dev)
+        if check:
+            from oracle import oracle
+            Fs = 4
+            ref = oracle.dist_trajectory_reduction(coords[:, :, :Fs].copy(), box[:, :Fs].copy(), groups, groups, chains, chains, not pairs, pbc, masses,
+                                                   r1, r2, pairs=pairs)
+            if not np.array_equal(o[:Fs].cpu().numpy(), ref, equal_nan=True):
+                raise SystemExit(f"dist_trajectory_reduction pbc={pbc} r=({r1},{r2}) pairs={pairs} block={block} on the GPU is not bit-exact with the oracle")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            call()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ctx.set_reduction_block(0)
+        if want_clock:
+            clock[0] = _clock_ghz(ctx, dev, call)
+        return e0.elapsed_time(e1) / args.steps
+
+    info = ctx.device_info()
+    lanes = info["compute_units"] * 4 * 16
+    clock, want_clock = [None], True
+    for name, pbc in (("periodic", True), ("nonperiodic", False)):
+        ms = leg(pbc, 0, 0)
+        clk = clock[0]
+        npairs = P * A * A * F
+        entry = {"ms_per_call": round(ms, 4), "kernel": "mkamd::k_dist_reduction_closest",
+                 "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 5),
+                              "algorithmic_bytes_per_launch": alg, "note": "instruction-bound: see valu"},
+                 "valu": {"atom_pairs_per_s_G": round(npairs / ms / 1e6, 1),
+                          "issue_slots_per_atom_pair": None if not clk else round(lanes * clk * 1e9 * ms * 1e-3 / npairs, 2),
+                          "shader_clock_ghz": clk}}
+        res[name] = entry
+    want_clock = False
+    # same-box A-B: the block sizes of the new kernel and the generic kernel it replaces (round 2-5: 2.9 ms on record)
+    res["ab_periodic_ms"] = {"block4": round(leg(True, 0, 0, block=4), 4), "block8": round(leg(True, 0, 0, block=8), 4),
+                             "generic_kernel": round(leg(True, 0, 0, block=-1), 4)}
+    res["com_com_periodic_ms"] = round(leg(True, 1, 1), 4)
+    res["pairs_closest_periodic_ms"] = round(leg(True, 0, 0, pairs=True), 4)
+    pmc = reduction_pmc()
+    if pmc:
+        res["periodic"]["valu"].update(pmc)
+    return res
+
+
+def reduction_pmc():
+    """VALU instructions per atom pair of the periodic leg from the committed PMC pass of THIS build (profiles/r*_reduction_pmc_counters.json)."""
+    import glob
+    from moleculekit_amd import _lib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reduction_pmc_counters.json")), key=lambda f: int(os.path.basename(f)[1:].split("_")[0]))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    if d.get("_library_src") != _lib.source_hash():
+        return {"pmc": f"refused: {os.path.relpath(files[-1], ROOT)} was taken on build {d.get('_library_src')}, this is {_lib.source_hash()}"}
+    v = next((x for k, x in d.items() if isinstance(x, dict) and "k_dist_reduction_closest" in k and "SQ_INSTS_VALU" in x), None)
+    if v is None:
+        return None
+    pairs = 200 * 199 // 2 * 225 * 512
+    return {"valu_wave_instructions_per_call": v["SQ_INSTS_VALU"], "lane_instructions_per_atom_pair": round(v["SQ_INSTS_VALU"] * 64 / pairs, 2),
+            "pmc_source": os.path.relpath(files[-1], ROOT)}
+
+
+def bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s1, s2, d1, d2, F):
+    """contacts_trajectory (distance_utils.pyx:59-93) on device pointers: the dist leg's 200 x 500 pairs over its F frames,
+    threshold 8 A, periodic by chain -- counted, scanned and compacted on the device (two passes over the pairs), the list
+    stays in HBM.  Algorithmic bytes: the selected atoms' coordinates once + 8 B per contact + the frame offsets."""
+    import torch
+    n1, n2 = len(s1), len(s2)
+    thr = 8.0
+    state = {}
+
+    def call():
+        state["r"] = ctx.contacts_trajectory_dev(coords, F, box, d1, n1, d2, n2, chains, False, True, thr)
+    busy(call, 0.2)
+    for _ in range(max(2, args.warmup)):
+        call()
+    offs, ptr, n = state["r"]
+    if check:
+        from oracle import oracle
+        Fs = min(8, F)
+        ref = oracle.dist_trajectory(coords[:, :, :Fs].contiguous().cpu().numpy(), box[:, :Fs].contiguous().cpu().numpy(), s1, s2, chains_h, False, True, squared=True)
+        want = [int((ref[f] <= np.float32(thr) * np.float32(thr)).sum()) for f in range(Fs)]
+        if want != np.diff(offs[:Fs + 1]).tolist():
+            raise SystemExit("contacts_trajectory on the GPU does not count what the oracle counts")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        call()
+    torch.cuda.synchronize(dev)                      # (every call ends with its own wait for the counts: wall clock = device time + read-backs)
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    alg = (n1 + n2) * 3 * F * 4 + 3 * F * 4 + n * 8 + (F + 1) * 8
+    return {"shape": f"{n1} x {n2} pairs x {F} frames, threshold {thr} A, periodic: {n} contacts", "ms_per_call": round(ms, 4),
+            "pair_tests_per_s_G": round(n1 * n2 * F / ms / 1e6, 1),
+            "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 5),
+                         "algorithmic_bytes_per_launch": alg, "note": "instruction-bound: every pair is computed twice (count, fill); wall clock incl. the count read-back"},
+            "kernel": "mkamd::k_contacts_count + k_contacts_scan + k_contacts_fill"}
 
 
 def bench_dropin(args):

@@ -2,13 +2,13 @@
  * mkamd_distance.h -- C ABI of libmkamd.so, distance_utils row.
  *
  * GPU replacements for moleculekit/distance_utils/distance_utils.pyx:
- *   dist_trajectory                  :126-155     -> mkamd_dist_trajectory_host
- *   contacts_trajectory              :59-93  }    -> mkamd_contacts_trajectory_host (thresholded and compacted on the GPU,
+ *   dist_trajectory                  :126-155     -> mkamd_dist_trajectory_host / _dev
+ *   contacts_trajectory              :59-93  }    -> mkamd_contacts_trajectory_host / _dev (thresholded and compacted on the GPU,
  *   get_collisions                   :98-121 }       the reference's (frame, i, j) order; no [frames x pairs] matrix anywhere)
- *   dist_trajectory_reduction        :211-281 }   -> mkamd_dist_reduction_host (pairs = 0 / 1)
+ *   dist_trajectory_reduction        :211-281 }   -> mkamd_dist_reduction_host / _dev (pairs = 0 / 1)
  *   dist_trajectory_reduction_pairs  :286-350 }
- *   cdist                            :355-383     -> mkamd_cdist_host
- *   pdist                            :388-416     -> mkamd_pdist_host
+ *   cdist                            :355-383     -> mkamd_cdist_host / _dev
+ *   pdist                            :388-416     -> mkamd_pdist_host / _dev
  * All float32, BIT-EXACT with the reference (same operation order, one rounding per operation).
  *
  * Layouts (C-contiguous, the reference's):  coords float32 [n_atoms, 3, n_frames] (Molecule.coords),
@@ -66,6 +66,30 @@ int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t n_ato
                               const uint32_t* digitized_chains2, int selfdist, int pairs, int pbc,
                               const float* masses, int reduction1, int reduction2, float* results);
 
+/* ---- device-resident forms (round 6): device pointers in, device results out, on the context's stream (mkamd_ctx_set_stream)
+ * -- for callers that keep the trajectory on the GPU (a decoded XTC chunk, an ML / analysis loop).  Same kernels, same bits as the
+ * "_host" forms.  Asynchronous like mkamd_dist_trajectory_dev, except the contact list (its size has to reach the host). ---- */
+
+/* contacts_trajectory (distance_utils.pyx:59-93) on device pointers: frame_offsets is a HOST array int64 [n_frames + 1] (out);
+ * *d_pairs (out) points at 2 * frame_offsets[n_frames] uint32 (a0, b0, a1, b1, ...) in DEVICE memory owned by the context, valid
+ * until the next contacts call on it (NULL when there is no contact).  The call returns when the list is complete. */
+int mkamd_contacts_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t n_frames, const float* d_box,
+                                  const uint32_t* d_sel1, int64_t n1, const uint32_t* d_sel2, int64_t n2,
+                                  const uint32_t* d_digitized_chains, int selfdist, int pbc, float dist_threshold,
+                                  int64_t* frame_offsets, const uint32_t** d_pairs);
+/* dist_trajectory_reduction[_pairs] (:211-350) on device pointers.  n_atoms (rows of d_coords) and n_g1_atoms (length of
+ * d_g1_atoms = the value of d_g1_offsets[n_groups1]) are what the host knows about the device arrays: they choose the kernel
+ * variant (32-bit row offsets, first-group atoms per wave), never the result.  Indices are NOT range-checked on the device. */
+int mkamd_dist_reduction_dev(mkamd_ctx* ctx, const float* d_coords, int64_t n_atoms, int64_t n_frames, const float* d_box,
+                             const int32_t* d_g1_atoms, const int64_t* d_g1_offsets, int64_t n_groups1, int64_t n_g1_atoms,
+                             const int32_t* d_g2_atoms, const int64_t* d_g2_offsets, int64_t n_groups2,
+                             const uint32_t* d_digitized_chains1, const uint32_t* d_digitized_chains2, int selfdist, int pairs,
+                             int pbc, const float* d_masses, int reduction1, int reduction2, float* d_results);
+/* cdist (:355-383) / pdist (:388-416) on device pointers */
+int mkamd_cdist_dev(mkamd_ctx* ctx, const float* d_coords1, int64_t n1, const float* d_coords2, int64_t n2, int32_t dim,
+                    float* d_results);
+int mkamd_pdist_dev(mkamd_ctx* ctx, const float* d_coords, int64_t n, int32_t dim, float* d_results);
+
 /* Self-test of the kernels' float32 square root.  The reference's sqrtf is correctly rounded; the kernels take roots with
  * one exact-residual correction of x * rsq(x) (8 issue slots; the provable form, v_sqrt_f32 + Tuckerman's test, takes 12 and
  * the kernels are bound by instruction issue).  That this is the correctly rounded root is a property of gfx950's v_rsq_f32,
@@ -80,6 +104,10 @@ int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_ba
  * (selfdist always takes the pair-table kernel).  Every kernel produces the same
  * bits; for tests (every kernel over the same shapes) and same-box A-B timing. */
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask);
+/* Which kernel the "closest"/"closest" group reductions take (default 0: k_dist_reduction_closest with 4 or 8 first-group atoms in
+ * registers, chosen from the mean size of the first groups; 4 / 8: that many; -1: the generic kernel the centre-of-mass modes
+ * use).  Every choice produces the same bits; for tests and same-box A-B timing. */
+int mkamd_ctx_set_reduction_block(mkamd_ctx* ctx, int block);
 /* Names of the kernels the last dist_trajectory call on this context launched, as a profiler prints them (e.g.
  * "mkamd::k_sel_to_frames + mkamd::k_dist_rows<true, 4, true>"; empty before the first call): what bench.py reports as
  * the distance leg's `roofline.kernel` -- the choice depends on the shape of the call. */

@@ -91,6 +91,13 @@ SIGNATURES = {
                                                 ctypes.c_float, _vp, ctypes.POINTER(_vp)]),
     "mkamd_dist_reduction_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _vp,
                                            _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp]),
+    "mkamd_contacts_trajectory_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int, ctypes.c_float, _vp,
+                                               ctypes.POINTER(_vp)]),
+    "mkamd_dist_reduction_dev": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _c_i64, _vp, _vp,
+                                          _c_int, _c_int, _c_int, _vp, _c_int, _c_int, _vp]),
+    "mkamd_cdist_dev": (_c_int, [_vp, _vp, _c_i64, _vp, _c_i64, _c_i32, _vp]),
+    "mkamd_pdist_dev": (_c_int, [_vp, _vp, _c_i64, _c_i32, _vp]),
+    "mkamd_ctx_set_reduction_block": (_c_int, [_vp, _c_int]),
     "mkamd_selftest_sqrt": (_c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
     "mkamd_ctx_set_dist_kernels": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_last_dist_kernel": (_c_int, [_vp, ctypes.c_char_p, ctypes.c_size_t]),
@@ -169,9 +176,11 @@ def device_count() -> int:
 
 
 def _ptr(a):
-    """void* of a numpy array / int address / None."""
+    """void* of a numpy array / an object with data_ptr() (a torch tensor) / int address / None."""
     if a is None:
         return None
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
     if isinstance(a, np.ndarray):
         return a.ctypes.data          # plain address: every pointer parameter is declared c_void_p (SIGNATURES); the
                                       # caller's frame keeps the array alive for the duration of the call
@@ -304,6 +313,10 @@ class Context:
         row kernel's 16-byte stores; 0 = free choice.  Same bits whichever runs (tests, A-B timing)."""
         _check(load().mkamd_ctx_set_dist_kernels(self._h, int(avoid_mask)))
 
+    def set_reduction_block(self, block: int = 0):
+        """0: choose; 4 / 8: first-group atoms a wave of the closest-atom group reduction keeps in registers; -1: the generic kernel."""
+        _check(load().mkamd_ctx_set_reduction_block(self._h, int(block)))
+
     def last_dist_kernel(self) -> str:
         """Kernels the last dist_trajectory call launched, as rocprofv3 prints them ('' before the first call)."""
         buf = ctypes.create_string_buffer(128)
@@ -417,6 +430,29 @@ class Context:
         _check(load().mkamd_dist_reduction_host(self._h, _ptr(coords), N, F, _ptr(box), _ptr(g1a), _ptr(g1o), g1o.shape[0] - 1,
                                                 _ptr(g2a), _ptr(g2o), g2o.shape[0] - 1, _ptr(ch1), _ptr(ch2), int(selfdist),
                                                 int(pairs), int(pbc), _ptr(masses), int(r1), int(r2), _ptr(out)))
+
+    # device-resident forms: arguments are torch CUDA tensors / objects with data_ptr() (or raw addresses); asynchronous on the
+    # context's stream except the contact list
+    def contacts_trajectory_dev(self, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, threshold):
+        """-> (frame_offsets int64 [F+1] host, address of the device list of 2 * n uint32 (context-owned until the next contacts
+        call; 0 when empty), n)."""
+        offs = np.zeros(F + 1, dtype=np.int64)
+        ptr = _vp(None)
+        _check(load().mkamd_contacts_trajectory_dev(self._h, _ptr(d_coords), F, _ptr(d_box), _ptr(d_sel1), n1, _ptr(d_sel2), n2, _ptr(d_chains),
+                                                    int(selfdist), int(pbc), float(threshold), _ptr(offs), ctypes.byref(ptr)))
+        return offs, int(ptr.value or 0), int(offs[-1])
+
+    def dist_reduction_dev(self, d_coords, N, F, d_box, d_g1a, d_g1o, ng1, n_g1_atoms, d_g2a, d_g2o, ng2, d_ch1, d_ch2, selfdist, pairs, pbc,
+                           d_masses, r1, r2, d_out):
+        _check(load().mkamd_dist_reduction_dev(self._h, _ptr(d_coords), N, F, _ptr(d_box), _ptr(d_g1a), _ptr(d_g1o), ng1, n_g1_atoms, _ptr(d_g2a),
+                                               _ptr(d_g2o), ng2, _ptr(d_ch1), _ptr(d_ch2), int(selfdist), int(pairs), int(pbc), _ptr(d_masses),
+                                               int(r1), int(r2), _ptr(d_out)))
+
+    def cdist_dev(self, d_c1, n1, d_c2, n2, dim, d_out):
+        _check(load().mkamd_cdist_dev(self._h, _ptr(d_c1), n1, _ptr(d_c2), n2, dim, _ptr(d_out)))
+
+    def pdist_dev(self, d_c, n, dim, d_out):
+        _check(load().mkamd_pdist_dev(self._h, _ptr(d_c), n, dim, _ptr(d_out)))
 
     def cdist_host(self, c1, c2, out):
         _check(load().mkamd_cdist_host(self._h, _ptr(c1), c1.shape[0], _ptr(c2), c2.shape[0], c1.shape[1], _ptr(out)))

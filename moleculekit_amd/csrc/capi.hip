@@ -108,6 +108,7 @@ struct mkamd_ctx {
     void note_error_flag_mirrored(bool yes) { err_mirrored = yes; }
     void note_tail_reports(bool yes) { tail_reports = yes; }
     int dist_avoid = 0;                    // kernels dist_trajectory must not take (mkamd_ctx_set_dist_kernels: tests, A-B timing)
+    int reduction_block = 0;               // k_dist_reduction_closest's first-group atoms in registers (mkamd_ctx_set_reduction_block)
     char last_dist_kernel[96] = "";        // what the last dist_trajectory call launched (mkamd_ctx_last_dist_kernel)
     void note_dist_kernel(const char* name) { snprintf(last_dist_kernel, sizeof last_dist_kernel, "%s", name); }
     bool tail_reports = false;             // the last lattice call's k_tail writes FB_TILES_DONE / FB_TAIL_WROTE with seq_next
@@ -127,6 +128,28 @@ struct mkamd_ctx {
             hipError_t e = hipMalloc(&bufs[slot], want);
             if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)");
             caps[slot] = want;
+        }
+        *ptr = bufs[slot];
+        return 0;
+    }
+    // a workspace buffer that grows WITH its first keep_bytes (the device-resident contact list: chunks are appended)
+    int grow_keep(int slot, size_t bytes, size_t keep_bytes, void** ptr)
+    {
+        if (bytes == 0) bytes = 16;
+        if (caps[slot] < bytes) {
+            void* fresh = nullptr;
+            const size_t want = bytes + bytes / 2 + 256;
+            hipError_t e = hipMalloc(&fresh, want);
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(contact list)");
+            if (bufs[slot] && keep_bytes) {
+                e = hipMemcpyAsync(fresh, bufs[slot], keep_bytes, hipMemcpyDeviceToDevice, stream);
+                if (e != hipSuccess) { (void)hipFree(fresh); return hip_fail(e, "hipMemcpyAsync(contact list)"); }
+            }
+            if (bufs[slot]) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipFree(bufs[slot]));
+            }
+            bufs[slot] = fresh; caps[slot] = want;
         }
         *ptr = bufs[slot];
         return 0;
@@ -618,6 +641,14 @@ try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
     if (avoid_mask < 0 || avoid_mask > 15) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores)");
     ctx->dist_avoid = avoid_mask;
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_ctx_set_reduction_block(mkamd_ctx* ctx, int block)
+try {
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (block != 0 && block != 4 && block != 8 && block != -1) return fail(MKAMD_EINVAL, "reduction block: 0 (choose), 4, 8, or -1 (the generic kernel)");
+    ctx->reduction_block = block;
     return MKAMD_OK;
 } MK_API_CATCH
 
@@ -1382,7 +1413,7 @@ try {
     static_assert(sizeof(long long) == sizeof(int64_t), "frame offsets are int64");
     st = run_contacts(*ctx, (const float*)dc, (long long)F, (const float*)db, (const unsigned*)d1, (long long)n1, (const unsigned*)d2,
                       (long long)n2, (const unsigned*)dch, selfdist, pbc, dist_threshold, (size_t)256 << 20,
-                      (long long*)frame_offsets, ctx->contacts_host, err);
+                      (long long*)frame_offsets, HostPairSink<mkamd_ctx>{*ctx, ctx->contacts_host}, err);
     if (st) return err.empty() ? st : fail(st, err);
     if (ctx->contacts_host.empty()) return MKAMD_OK;
     *pairs = ctx->contacts_host.data();
@@ -1419,13 +1450,86 @@ try {
     if (masses && (st = upload(ctx, WS_D_MASS, masses, (size_t)N * 4, &dm))) return st;
     if ((st = ctx->ensure(WS_H_OUT, (size_t)F * P * 4, &dout, 0))) return st;
     std::string err;
-    st = run_dist_reduction(*ctx, (const float*)dc, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, (const int*)a2,
+    st = run_dist_reduction(*ctx, (const float*)dc, N, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, g1_off[ng1], (const int*)a2,
                             (const long long*)o2, ng2, (const unsigned*)c1, (const unsigned*)c2, selfdist, pairs, pbc,
-                            (const float*)dm, reduction1, reduction2, (float*)dout, err);
+                            (const float*)dm, reduction1, reduction2, (float*)dout, err, ctx->reduction_block);
     if (st) return err.empty() ? st : fail(st, err);
     prefault_big_result(results, (size_t)F * P * 4);
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MKAMD_OK;
+} MK_API_CATCH
+
+// ---- device-resident forms (round 6): coordinates, selections / groups and results stay on the GPU; asynchronous on the
+// context's stream except for the contact list, whose size has to reach the host ----
+int mkamd_contacts_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t F, const float* d_box, const uint32_t* d_sel1,
+                                  int64_t n1, const uint32_t* d_sel2, int64_t n2, const uint32_t* d_chains, int selfdist, int pbc,
+                                  float dist_threshold, int64_t* frame_offsets, const uint32_t** d_pairs)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (!frame_offsets || !d_pairs) return fail(MKAMD_EINVAL, "frame_offsets/d_pairs pointer is NULL");
+    *d_pairs = nullptr;
+    for (int64_t f = 0; f <= F; ++f) frame_offsets[f] = 0;
+    if (F == 0 || count_pairs(n1, n2, selfdist) == 0) return MKAMD_OK;
+    if (!d_coords || !d_box || !d_sel1 || !d_sel2 || !d_chains) return fail(MKAMD_EINVAL, "NULL pointer");
+    std::string err;
+    DevicePairSink<mkamd_ctx> sink{*ctx};
+    st = run_contacts(*ctx, d_coords, (long long)F, d_box, d_sel1, (long long)n1, d_sel2, (long long)n2, d_chains, selfdist, pbc,
+                      dist_threshold, (size_t)256 << 20, (long long*)frame_offsets, sink, err);
+    if (st) return err.empty() ? st : fail(st, err);
+    if (sink.size) *d_pairs = static_cast<const uint32_t*>(sink.base);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_dist_reduction_dev(mkamd_ctx* ctx, const float* d_coords, int64_t N, int64_t F, const float* d_box,
+                             const int32_t* d_g1_atoms, const int64_t* d_g1_off, int64_t ng1, int64_t n_g1_atoms,
+                             const int32_t* d_g2_atoms, const int64_t* d_g2_off, int64_t ng2, const uint32_t* d_chains1,
+                             const uint32_t* d_chains2, int selfdist, int pairs, int pbc, const float* d_masses, int reduction1,
+                             int reduction2, float* d_results)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (N < 0 || F < 0 || ng1 < 0 || ng2 < 0 || n_g1_atoms < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (pairs && ng1 != ng2) return fail(MKAMD_EINVAL, "pairs mode needs the same number of groups on both sides");
+    const int64_t P = pairs ? ng1 : count_pairs(ng1, ng2, selfdist);
+    if (F == 0 || P == 0) return MKAMD_OK;
+    if (!d_coords || !d_box || !d_g1_atoms || !d_g1_off || !d_g2_atoms || !d_g2_off || !d_chains1 || !d_chains2 || !d_results)
+        return fail(MKAMD_EINVAL, "NULL pointer");
+    if ((reduction1 == 1 || reduction2 == 1) && !d_masses) return fail(MKAMD_EINVAL, "masses are required for the com reduction");
+    std::string err;
+    static_assert(sizeof(long long) == sizeof(int64_t), "group offsets are int64");
+    st = run_dist_reduction(*ctx, d_coords, N, F, d_box, (const int*)d_g1_atoms, (const long long*)d_g1_off, ng1, n_g1_atoms,
+                            (const int*)d_g2_atoms, (const long long*)d_g2_off, ng2, d_chains1, d_chains2, selfdist, pairs, pbc, d_masses,
+                            reduction1, reduction2, d_results, err, ctx->reduction_block);
+    if (st) return err.empty() ? st : fail(st, err);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_cdist_dev(mkamd_ctx* ctx, const float* d_c1, int64_t n1, const float* d_c2, int64_t n2, int32_t D, float* d_results)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n1 < 0 || n2 < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (n1 == 0 || n2 == 0) return MKAMD_OK;
+    if (!d_c1 || !d_c2 || !d_results) return fail(MKAMD_EINVAL, "NULL pointer");
+    std::string err;
+    st = run_cdist(*ctx, d_c1, n1, d_c2, n2, D, d_results, err);
+    if (st) return err.empty() ? st : fail(st, err);
+    return MKAMD_OK;
+} MK_API_CATCH
+
+int mkamd_pdist_dev(mkamd_ctx* ctx, const float* d_c, int64_t n, int32_t D, float* d_results)
+try {
+    int st = check_ctx(ctx);
+    if (st) return st;
+    if (n < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
+    if (n < 2) return MKAMD_OK;
+    if (!d_c || !d_results) return fail(MKAMD_EINVAL, "NULL pointer");
+    std::string err;
+    st = run_pdist(*ctx, d_c, n, D, d_results, err);
+    if (st) return err.empty() ? st : fail(st, err);
     return MKAMD_OK;
 } MK_API_CATCH
 

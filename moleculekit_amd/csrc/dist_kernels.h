@@ -896,6 +896,182 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
     store_tile_rows(tile, f0, p0, F, P, P, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// dist_trajectory_reduction[_pairs] with the "closest" reduction on BOTH sides (distance_utils.pyx:211-281, :286-350 with
+// reduction1 = reduction2 = 0): the residue-contact maps of MetricDistance -- for every (frame, group pair) the smallest d^2
+// over |g1| x |g2| atom pairs, then ONE root.  Round 6.  (The kernel above re-loaded every atom of every atom pair -- three
+// loads and ~50 instructions per pair, 2.9 ms for 200 groups of 15 atoms x 512 frames; it stays for the centre-of-mass modes,
+// whose group pairs are one or |g| atom pairs.)
+//
+//  * Lanes run along frames; a wave takes DRC_RUN CONSECUTIVE group pairs of its tile (the kernel above: every fourth), which
+//    in the reference's g1-major order share their first group.  I atoms of that group stay in registers as I/2 packed pairs
+//    (mk_f2: x, y, z of two atoms side by side) for the whole stretch; the atoms of the second groups stream past them, one
+//    load per (atom, axis) for I atom pairs, a coalesced 256-byte row segment each (frames are the fastest axis of `coords`).
+//  * The arithmetic is packed (v_pk_add_f32 / v_pk_mul_f32: two separately rounded float32 operations per lane and
+//    instruction -- the reference's roundings): separation, quotient, image shift, squares: 13 packed instructions per TWO
+//    pairs, plus three v_rndne_f32 per pair.  Nothing is selected per pair: whether a group pair wraps (pbc and different
+//    chains, :225-229) is wave-uniform.
+//  * The exactness test of the image integers (round_quotient_exact above) is ACCUMULATED: risk = max over the pairs of
+//    (largest |q - rndne(q)| + 3e-7 largest |q|) -- two v_max3 with |x| modifiers, an fma and half a v_max3 per pair, no branch.
+//    One wave-uniform test per (block of first atoms, second group); a stretch that fails it (a separation within 3e-7 of half
+//    a box length, an infinite quotient) is redone pair by pair with dist2_min_image_f32 and its correctly rounded divisions.
+//  * The reference's update `if dist2 < mindist or mindist < 0` (mindist = -1 at first) keeps the FIRST pair's d^2 whatever it
+//    is and then every smaller one: the result is NaN when the first pair's is, else the minimum over the pairs that are not
+//    NaN.  That is v_min3_f32 (NaN operands are ignored) over all pairs in any order plus the first pair's NaN-ness -- which is
+//    component 0 of the first packed pair of the first second atom; the order of the pairs is free, and so is their grouping.
+//    Padding slots (a group whose size is not a multiple of I) repeat the group's last atom: the same d^2 once more.
+//  * A group with more than I atoms takes several passes over its second groups; the partial minima wait in the wave's own
+//    column of the LDS tile (-1 = nothing yet, as the reference starts), where the root is taken at the end.
+// ------------------------------------------------------------------------------------------------
+constexpr int DRC_RUN = DT / (DT_THREADS / DT);      // consecutive group pairs per wave (16)
+constexpr float DRC_RISK = 0.4999998f;               // risk below this: every rndne(d * fl(1/b)) is the reference's round(d / b)
+                                                     // (the per-pair test is tm < 0.5 - 3e-7 qm, proven bound 1.8e-7 qm; here
+                                                     //  tm + 3e-7 qm is rounded once more: 2e-7 of slack)
+
+// d^2 of two atom pairs (first atoms ax/ay/az[0..1], second atom (x2, y2, z2)) -- distance_utils.pyx:188-206
+template <bool WR>
+MK_DEV mk_f2 dist2_pk(mk_f2 ax, mk_f2 ay, mk_f2 az, float x2, float y2, float z2, float bx, float by, float bz,
+                      float ibx, float iby, float ibz, float& risk)
+{
+    mk_f2 dx = mk_f2_sub_rn(ax, mk_f2_splat(x2)), dy = mk_f2_sub_rn(ay, mk_f2_splat(y2)), dz = mk_f2_sub_rn(az, mk_f2_splat(z2));
+    if constexpr (WR) {
+        const mk_f2 qx = mk_f2_mul_rn(dx, mk_f2_splat(ibx)), qy = mk_f2_mul_rn(dy, mk_f2_splat(iby)), qz = mk_f2_mul_rn(dz, mk_f2_splat(ibz));
+        const mk_f2 rx = mk_f2{mk_rint(qx[0]), mk_rint(qx[1])}, ry = mk_f2{mk_rint(qy[0]), mk_rint(qy[1])}, rz = mk_f2{mk_rint(qz[0]), mk_rint(qz[1])};
+        const mk_f2 tx = mk_f2_sub_rn(qx, rx), ty = mk_f2_sub_rn(qy, ry), tz = mk_f2_sub_rn(qz, rz);       // (exact)
+        const float s0 = mk_fma(3e-7f, mk_max3_abs_raw(qx[0], qy[0], qz[0]), mk_max3_abs_raw(tx[0], ty[0], tz[0]));
+        const float s1 = mk_fma(3e-7f, mk_max3_abs_raw(qx[1], qy[1], qz[1]), mk_max3_abs_raw(tx[1], ty[1], tz[1]));
+        risk = mk_max3_raw(risk, s0, s1);
+        dx = mk_f2_sub_rn(dx, mk_f2_mul_rn(mk_f2_splat(bx), rx));
+        dy = mk_f2_sub_rn(dy, mk_f2_mul_rn(mk_f2_splat(by), ry));
+        dz = mk_f2_sub_rn(dz, mk_f2_mul_rn(mk_f2_splat(bz), rz));
+    }
+    return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
+}
+
+template <int I /* first-group atoms in registers: 4 or 8 */, bool SMALL /* every coordinate row ends below 4 GiB: one descriptor */>
+MK_KERNEL(DT_THREADS) void k_dist_reduction_closest(const float* __restrict__ coords, long long F, const float* __restrict__ box,
+                                                    const int* __restrict__ g1_atoms, const long long* __restrict__ g1_off,
+                                                    const int* __restrict__ g2_atoms, const long long* __restrict__ g2_off,
+                                                    const unsigned* __restrict__ ga, const unsigned* __restrict__ gb,
+                                                    const unsigned* __restrict__ wrap, long long P, float* __restrict__ out)
+{
+    static_assert(I == 4 || I == 8, "packed pairs of first atoms");
+    constexpr int H = I / 2;
+    __shared__ float tile[DT][DT + 1];
+    const long long ptiles = (P + DT - 1) / DT, gt = xcd_contiguous_tile(ptiles * ((F + DT - 1) / DT));   // (as k_dist_pairs)
+    if (gt < 0) return;
+    const long long f0 = (gt / ptiles) * DT, p0 = (gt % ptiles) * DT;
+    {
+        const int fl = threadIdx.x & (DT - 1);
+        const int pq = (int)mk_uniform(threadIdx.x >> 6);            // the wave's index, as a scalar
+        const long long f = f0 + fl < F ? f0 + fl : F - 1;           // frames past the end compute on the last frame (never stored)
+        const unsigned fb = (unsigned)f * 4u;                        // (the host refuses F >= 2^30)
+        const unsigned F4 = (unsigned)F * 4u;
+        const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
+        float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
+        mk_keep(ibx); mk_keep(iby); mk_keep(ibz);
+        auto at = [&](unsigned atom, int ax) {
+            if constexpr (SMALL) return mk_load_f32_base_soffset(coords, (atom * 3u + (unsigned)ax) * F4, fb);
+            else return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
+        };
+        const long long pw = p0 + (long long)pq * DRC_RUN;           // the wave's first group pair
+        const int nrun = pw >= P ? 0 : (P - pw < DRC_RUN ? (int)(P - pw) : DRC_RUN);
+        for (int k = 0; k < nrun;) {
+            // a stretch [k, ke) of group pairs that share their first group
+            const unsigned a = ga[pw + k];
+            int ke = k + 1;
+            while (ke < nrun && ga[pw + ke] == a) ++ke;
+            const long long i0 = g1_off[a], i1 = g1_off[a + 1];
+            for (int kk = k; kk < ke; ++kk) tile[pq * DRC_RUN + kk][fl] = -1.f;      // the reference's `mindist = -1` (:252)
+            for (long long ib = i0; ib < i1; ib += I) {
+                mk_f2 ax[H], ay[H], az[H];
+#pragma unroll
+                for (int u = 0; u < H; ++u) {
+                    const long long e0 = ib + 2 * u < i1 ? ib + 2 * u : i1 - 1, e1 = ib + 2 * u + 1 < i1 ? ib + 2 * u + 1 : i1 - 1;
+                    const unsigned a0 = (unsigned)g1_atoms[e0], a1 = (unsigned)g1_atoms[e1];
+                    ax[u] = mk_f2{at(a0, 0), at(a1, 0)}; ay[u] = mk_f2{at(a0, 1), at(a1, 1)}; az[u] = mk_f2{at(a0, 2), at(a1, 2)};
+                }
+                const int valid = i1 - ib < I ? (int)(i1 - ib) : I;   // first atoms of this block that are not padding
+                for (int kk = k; kk < ke; ++kk) {
+                    const unsigned b = gb[pw + kk];
+                    const bool w = wrap[pw + kk] != 0u;
+                    const long long j0 = g2_off[b], j1 = g2_off[b + 1];
+                    if (j1 <= j0) continue;                          // an empty second group: -1 stays (sqrt(-1), as the reference)
+                    float m[H], first = 0.f, risk = 0.f;
+#pragma unroll
+                    for (int u = 0; u < H; ++u) m[u] = mk_inf();
+                    auto sweep = [&](auto wraps_) {
+                        constexpr bool WR = decltype(wraps_)::value;
+                        long long j = j0;
+                        {   // the first second atom alone: component 0 of its first packed pair is the reference's first pair
+                            const unsigned c = (unsigned)g2_atoms[j];
+                            const float x2 = at(c, 0), y2 = at(c, 1), z2 = at(c, 2);
+#pragma unroll
+                            for (int u = 0; u < H; ++u) {
+                                const mk_f2 d2 = dist2_pk<WR>(ax[u], ay[u], az[u], x2, y2, z2, bx, by, bz, ibx, iby, ibz, risk);
+                                if (u == 0) first = d2[0];
+                                m[u] = mk_min3_raw(m[u], d2[0], d2[1]);
+                            }
+                            ++j;
+                        }
+                        for (; j + 2 <= j1; j += 2) {                // two second atoms: six loads in flight
+                            const unsigned c0 = (unsigned)g2_atoms[j], c1 = (unsigned)g2_atoms[j + 1];
+                            const float x2 = at(c0, 0), y2 = at(c0, 1), z2 = at(c0, 2), x3 = at(c1, 0), y3 = at(c1, 1), z3 = at(c1, 2);
+#pragma unroll
+                            for (int u = 0; u < H; ++u) {
+                                const mk_f2 d2 = dist2_pk<WR>(ax[u], ay[u], az[u], x2, y2, z2, bx, by, bz, ibx, iby, ibz, risk);
+                                const mk_f2 e2 = dist2_pk<WR>(ax[u], ay[u], az[u], x3, y3, z3, bx, by, bz, ibx, iby, ibz, risk);
+                                m[u] = mk_min3_raw(m[u], d2[0], d2[1]);
+                                m[u] = mk_min3_raw(m[u], e2[0], e2[1]);
+                            }
+                        }
+                        if (j < j1) {
+                            const unsigned c = (unsigned)g2_atoms[j];
+                            const float x2 = at(c, 0), y2 = at(c, 1), z2 = at(c, 2);
+#pragma unroll
+                            for (int u = 0; u < H; ++u) {
+                                const mk_f2 d2 = dist2_pk<WR>(ax[u], ay[u], az[u], x2, y2, z2, bx, by, bz, ibx, iby, ibz, risk);
+                                m[u] = mk_min3_raw(m[u], d2[0], d2[1]);
+                            }
+                        }
+                    };
+                    if (w) sweep(DistFlag<true>{}); else sweep(DistFlag<false>{});
+                    float mm = m[0];
+#pragma unroll
+                    for (int u = 1; u < H; ++u) mm = mk_min_raw(mm, m[u]);
+                    if (w && mk_ballot(!(risk < DRC_RISK)) != 0ull) {
+                        // an image integer of this stretch may differ from the reference's round(d / b): once more, pair by pair,
+                        // with the per-pair test and the correctly rounded divisions behind it (wave-uniform, rare)
+                        mk_stay_in_branch();
+                        mm = mk_inf();
+                        for (int u = 0; u < valid; ++u) {
+                            const unsigned a1 = (unsigned)g1_atoms[ib + u];                // (loaded again: no dynamic register index)
+                            const float x1 = at(a1, 0), y1 = at(a1, 1), z1 = at(a1, 2);
+                            for (long long j = j0; j < j1; ++j) {
+                                const unsigned c = (unsigned)g2_atoms[j];
+                                const float d2 = dist2_min_image_f32(x1, y1, z1, at(c, 0), at(c, 1), at(c, 2), bx, by, bz, ibx, iby, ibz, true);
+                                if (u == 0 && j == j0) first = d2;
+                                mm = mk_min_raw(mm, d2);
+                            }
+                        }
+                    }
+                    float& acc = tile[pq * DRC_RUN + kk][fl];
+                    const float old = acc;
+                    if (old < 0.f) acc = (first != first) ? first : mm;          // the first block: the first pair decides about NaN
+                    else if (old == old) acc = mk_min_raw(old, mm);              // (a NaN stays: `dist2 < NaN` never holds)
+                }
+            }
+            for (int kk = k; kk < ke; ++kk) {
+                float& acc = tile[pq * DRC_RUN + kk][fl];
+                acc = mk_fsqrt_rn(acc);                                           // ONE root per (frame, group pair) (:276)
+            }
+            k = ke;
+        }
+    }
+    mk_block_sync();
+    store_tile_rows(tile, f0, p0, F, P, P, out);
+}
+
 // cdist (distance_utils.pyx:355-383): results[i, j]; any dimension D; lanes along j.
 MK_KERNEL(256) void k_cdist(const float* __restrict__ c1, long long n1, const float* __restrict__ c2,
                             long long n2, int D, float* __restrict__ out)

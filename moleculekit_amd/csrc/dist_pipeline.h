@@ -129,11 +129,14 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
 }
 
 // dist_trajectory_reduction[_pairs] on device pointers; groups as CSR (atoms int32, offsets int64)
+// `n_atoms` (rows of coords) and `n_g1_atoms` (length of g1_atoms) are what the HOST knows about arrays that live on the device:
+// they choose the kernel variant (32-bit row offsets; how many first-group atoms a wave keeps in registers), never the result.
+// `closest_block`: 0 = choose, 4 / 8 = that many first-group atoms in registers (tests, A-B timing), -1 = the generic kernel.
 template <class BE>
-int run_dist_reduction(BE& be, const float* coords, long long F, const float* box, const int* g1_atoms,
-                       const long long* g1_off, long long ng1, const int* g2_atoms, const long long* g2_off,
+int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long F, const float* box, const int* g1_atoms,
+                       const long long* g1_off, long long ng1, long long n_g1_atoms, const int* g2_atoms, const long long* g2_off,
                        long long ng2, const unsigned* chains1, const unsigned* chains2, int selfdist, int pairs, int pbc,
-                       const float* masses, int reduction1, int reduction2, float* out, std::string& err)
+                       const float* masses, int reduction1, int reduction2, float* out, std::string& err, int closest_block = 0)
 {
     if (F < 0 || ng1 < 0 || ng2 < 0) { err = "negative size"; return ST_EINVAL; }
     if (pairs && ng1 != ng2) { err = "pairs mode needs the same number of groups on both sides"; return ST_EINVAL; }
@@ -162,7 +165,20 @@ int run_dist_reduction(BE& be, const float* coords, long long F, const float* bo
         c2 = (const float*)com2;
     }
     if (ceil_div(P, DT) * ceil_div(F, DT) > 0x7ffffff0LL) { err = "too many tiles (groups pairs x frames / 4096 >= 2^31)"; return ST_EINVAL; }
-    return be.launch(k_dist_reduction, dim3((unsigned)(((ceil_div(P, DT) * ceil_div(F, DT) + 7) / 8) * 8)), dim3(DT_THREADS), c1, c2, F, box,
+    const dim3 grid((unsigned)(((ceil_div(P, DT) * ceil_div(F, DT) + 7) / 8) * 8));
+    if (reduction1 == 0 && reduction2 == 0 && closest_block >= 0) {
+        // closest atom pair of two atom lists -- the residue-contact maps: first-group atoms in registers, packed arithmetic
+        // (k_dist_reduction_closest).  Eight atoms per pass when the first groups are large enough to fill them.
+        const bool eight = closest_block ? closest_block == 8 : n_g1_atoms * 10 >= ng1 * 130;
+        const bool small_rows = (unsigned long long)n_atoms * 3ull * (unsigned long long)F * 4ull <= 0xffffffffull;
+        auto go = [&](auto kern) {
+            return be.launch(kern, grid, dim3(DT_THREADS), coords, F, box, g1_atoms, g1_off, g2_atoms, g2_off, (const unsigned*)ga,
+                             (const unsigned*)gb, (const unsigned*)wr, P, out);
+        };
+        if (eight) return small_rows ? go(k_dist_reduction_closest<8, true>) : go(k_dist_reduction_closest<8, false>);
+        return small_rows ? go(k_dist_reduction_closest<4, true>) : go(k_dist_reduction_closest<4, false>);
+    }
+    return be.launch(k_dist_reduction, grid, dim3(DT_THREADS), c1, c2, F, box,
                      g1_atoms, g1_off, g2_atoms, g2_off, reduction1, reduction2, (const unsigned*)ga, (const unsigned*)gb,
                      (const unsigned*)wr, P, out);
 }
@@ -172,13 +188,42 @@ int run_dist_reduction(BE& be, const float* coords, long long F, const float* bo
 //   int to_host(void* dst, const void* src_dev, size_t bytes)     copy out and wait for it (and for the kernels before it)
 //   int to_device(void* dst_dev, const void* src, size_t bytes)   copy in (stream-ordered)
 // `budget_bytes` bounds the per-(pair tile, frame) counters: it decides how many frames go in one chunk.
-// frame_offsets [F+1] and `pairs` (2 x uint32 per contact, frames concatenated) are host-side results.
+// frame_offsets [F+1] is a host-side result (the counts have to reach the host to size the list); the (a, b) pairs of a chunk are
+// written by the fill kernel where `sink.reserve(n, &dst)` says and then handed over with `sink.commit(dst, n)`:
+//   HostPairSink    a chunk lands in the WS_H_OUT workspace and is copied behind the host vector (the "_host" entry point)
+//   DevicePairSink  chunks are written behind one another in ONE device buffer that grows by copying (the "_dev" entry point:
+//                   the list never leaves the device; one chunk -- a 256 MB counter budget covers 42 000 frames of 100 000
+//                   pairs -- is written in place).  The backend provides grow_keep(slot, bytes, keep_bytes, &ptr).
 template <class BE>
+struct HostPairSink {
+    BE& be;
+    std::vector<unsigned>& pairs;
+    int reserve(size_t n, void** dst) { return be.ensure(WS_H_OUT, n * 8, dst, 0); }
+    int commit(void* dst, size_t n)
+    {
+        const size_t old = pairs.size();
+        pairs.resize(old + n * 2);
+        return be.to_host(pairs.data() + old, dst, n * 8);
+    }
+};
+template <class BE>
+struct DevicePairSink {
+    BE& be;
+    size_t size = 0;                       // pairs written so far
+    void* base = nullptr;
+    int reserve(size_t n, void** dst)
+    {
+        const int st = be.grow_keep(WS_D_CONTACTS, (size + n) * 8, size * 8, &base);
+        *dst = static_cast<char*>(base) + size * 8;
+        return st;
+    }
+    int commit(void*, size_t n) { size += n; return 0; }
+};
+template <class BE, class Sink>
 int run_contacts(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                  const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, float dist_threshold,
-                 size_t budget_bytes, long long* frame_offsets, std::vector<unsigned>& pairs, std::string& err)
+                 size_t budget_bytes, long long* frame_offsets, Sink&& sink, std::string& err)
 {
-    pairs.clear();
     for (long long f = 0; f <= F; ++f) frame_offsets[f] = 0;
     if (F < 0 || n1 < 0 || n2 < 0) { err = "negative size"; return ST_EINVAL; }
     const long long P = count_pairs(n1, n2, selfdist);
@@ -214,13 +259,11 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         for (long long i = 0; i < fc_pad; ++i) { bases[(size_t)i] = run; run += i < fc ? totals[(size_t)i] : 0ull; }
         for (long long i = 0; i < fc; ++i) frame_offsets[f0 + i + 1] = frame_offsets[f0 + i] + (long long)totals[(size_t)i];
         if (run == 0) continue;
-        if ((st = be.ensure(WS_H_OUT, (size_t)run * 8, &dout, 0))) return st;
+        if ((st = sink.reserve((size_t)run, &dout))) return st;
         if ((st = be.to_device(base, bases.data(), (size_t)fc_pad * 8))) return st;
         if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
                             (const unsigned*)wr, P, thr2, (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
-        const size_t old = pairs.size();
-        pairs.resize(old + (size_t)run * 2);
-        if ((st = be.to_host(pairs.data() + old, dout, (size_t)run * 8))) return st;
+        if ((st = sink.commit(dout, (size_t)run))) return st;
     }
     return ST_OK;
 }

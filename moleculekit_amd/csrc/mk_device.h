@@ -46,6 +46,11 @@ MK_DEV float mk_abs(float a) { return __builtin_fabsf(a); }             // |x| s
 // v_min_f32 as the hardware does it, without the canonicalising v_max_f32 x, x, x the compiler puts in front of fminf when it
 // cannot see where an operand comes from (a running minimum carried through a loop): the operands here are never signalling NaNs
 MK_DEV float mk_min_raw(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// ... and v_min3_f32 / v_max3_f32 the same way (round 6: the running minima / maxima of the group-reduction kernel's inner loop)
+MK_DEV float mk_min3_raw(float m, float a, float b) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
+MK_DEV float mk_max3_raw(float m, float a, float b) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b)); return r; }
+// max3 of the ABSOLUTE values (the |x| source modifiers of a VOP3 instruction: no separate v_and)
+MK_DEV float mk_max3_abs_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // keeps what follows inside its (wave-uniform) branch: a volatile asm is never speculated, so the branch is not if-converted
 MK_DEV void mk_stay_in_branch() { asm volatile(""); }
 // the value stays in its register from here on: the compiler forgets that it is a constant it could build again (it

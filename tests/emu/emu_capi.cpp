@@ -39,6 +39,19 @@ struct EmuBackend {
         *ptr = bufs[slot];
         return 0;
     }
+    int grow_keep(int slot, size_t bytes, size_t keep_bytes, void** ptr)       // (as mkamd_ctx::grow_keep: exact sizes here, so that every chunk grows)
+    {
+        if (bytes == 0) bytes = 16;
+        if (caps[slot] < bytes) {
+            void* fresh = malloc(bytes);
+            memset(fresh, 0xCD, bytes);
+            if (bufs[slot] && keep_bytes) memcpy(fresh, bufs[slot], keep_bytes);
+            free(bufs[slot]);
+            bufs[slot] = fresh; caps[slot] = bytes;
+        }
+        *ptr = bufs[slot];
+        return 0;
+    }
     int fill(void* p, int byte, size_t bytes) { memset(p, byte, bytes); ++fills; return 0; }
     int to_host(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
     int to_device(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); return 0; }
@@ -232,21 +245,31 @@ int emu_dist_trajectory(const float* coords, long long F, const float* box, cons
 
 int emu_dist_reduction(const float* coords, long long F, const float* box, const int* g1a, const long long* g1o, long long ng1,
                        const int* g2a, const long long* g2o, long long ng2, const unsigned* ch1, const unsigned* ch2,
-                       int selfdist, int pairs, int pbc, const float* masses, int r1, int r2, float* out)
+                       int selfdist, int pairs, int pbc, const float* masses, int r1, int r2, float* out, long long n_atoms,
+                       int closest_block /* 0 choose, 4 / 8, -1 the generic kernel */)
 {
     EmuBackend be;
-    return run_dist_reduction(be, coords, F, box, g1a, g1o, ng1, g2a, g2o, ng2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out, g_err);
+    return run_dist_reduction(be, coords, n_atoms, F, box, g1a, g1o, ng1, g1o[ng1], g2a, g2o, ng2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out,
+                              g_err, closest_block);
 }
 
 // contacts_trajectory: frame_offsets [F+1]; pairs_out (capacity 2*cap uint32) gets the (a, b) pairs; returns the count in *n_out
 int emu_contacts(const float* coords, long long F, const float* box, const unsigned* sel1, long long n1, const unsigned* sel2,
                  long long n2, const unsigned* chains, int selfdist, int pbc, float threshold, long long budget_bytes,
-                 long long* frame_offsets, unsigned* pairs_out, long long cap, long long* n_out)
+                 long long* frame_offsets, unsigned* pairs_out, long long cap, long long* n_out, int device_sink)
 {
     EmuBackend be;
+    if (device_sink) {                                               // the "_dev" entry point's sink: one buffer that grows by copying
+        DevicePairSink<EmuBackend> sink{be};
+        const int st = run_contacts(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, threshold, (size_t)budget_bytes,
+                                    frame_offsets, sink, g_err);
+        *n_out = (long long)sink.size;
+        if (!st && (long long)sink.size <= cap && sink.size) memcpy(pairs_out, sink.base, sink.size * 2 * sizeof(unsigned));
+        return st;
+    }
     std::vector<unsigned> pairs;
     const int st = run_contacts(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, threshold, (size_t)budget_bytes,
-                                frame_offsets, pairs, g_err);
+                                frame_offsets, HostPairSink<EmuBackend>{be, pairs}, g_err);
     *n_out = (long long)(pairs.size() / 2);
     if (!st && (long long)(pairs.size() / 2) <= cap) memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(unsigned));
     return st;

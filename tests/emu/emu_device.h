@@ -207,6 +207,9 @@ MK_DEV float mk_rcp(float x) { return 1.0f / x; }
 MK_DEV float mk_exp2(float x) { return exp2f(x); }
 MK_DEV float mk_min(float a, float b) { return fminf(a, b); }
 MK_DEV float mk_min_raw(float a, float b) { return fminf(a, b); }
+MK_DEV float mk_min3_raw(float m, float a, float b) { return fminf(fminf(a, b), m); }
+MK_DEV float mk_max3_raw(float m, float a, float b) { return fmaxf(fmaxf(a, b), m); }
+MK_DEV float mk_max3_abs_raw(float a, float b, float c) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)); }
 MK_DEV void mk_keep(float&) {}
 MK_DEV void mk_stay_in_branch() {}
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }

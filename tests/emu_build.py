@@ -176,7 +176,9 @@ def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=Fals
     return out
 
 
-def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masses, r1, r2, pairs=False):
+def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masses, r1, r2, pairs=False, block=0, n_atoms=None):
+    """block: 0 = the library's choice, 4 / 8 = first-group atoms in registers (closest / closest only), -1 = the generic kernel;
+    n_atoms: what the host believes the number of coordinate rows is (decides 32-bit row offsets: a huge value forces the 64-bit form)."""
     coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
     a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)
     ch1 = np.ascontiguousarray(ch1, np.uint32); ch2 = np.ascontiguousarray(ch2, np.uint32)
@@ -186,14 +188,16 @@ def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masse
     out = np.full((F, nout), -7.0, np.float32)
     st = lib().emu_dist_reduction(_p(coords), ctypes.c_longlong(F), _p(box), _p(a1), _p(o1), ctypes.c_longlong(len(groups1)),
                                   _p(a2), _p(o2), ctypes.c_longlong(len(groups2)), _p(ch1), _p(ch2), ctypes.c_int(int(selfdist)),
-                                  ctypes.c_int(int(pairs)), ctypes.c_int(int(pbc)), _p(masses), ctypes.c_int(r1), ctypes.c_int(r2), _p(out))
+                                  ctypes.c_int(int(pairs)), ctypes.c_int(int(pbc)), _p(masses), ctypes.c_int(r1), ctypes.c_int(r2), _p(out),
+                                  ctypes.c_longlong(coords.shape[0] if n_atoms is None else n_atoms), ctypes.c_int(int(block)))
     assert st == 0, lib().emu_last_error()
     return out
 
 
-def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshold, budget_bytes=256 << 20):
+def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshold, budget_bytes=256 << 20, device_sink=False):
     """-> per-frame list of flat [a0, b0, a1, b1, ...] lists (the reference's return shape), through the device-side
-    count / scan / fill kernels; a tiny `budget_bytes` forces several chunks of frames."""
+    count / scan / fill kernels; a tiny `budget_bytes` forces several chunks of frames; `device_sink`: the list is kept in ONE
+    growing 'device' buffer as mkamd_contacts_trajectory_dev keeps it (else chunk by chunk to the host, the "_host" form)."""
     coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
     sel1 = np.ascontiguousarray(sel1, np.uint32); sel2 = np.ascontiguousarray(sel2, np.uint32)
     chains = np.ascontiguousarray(chains, np.uint32)
@@ -205,7 +209,7 @@ def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshol
     st = lib().emu_contacts(_p(coords), ctypes.c_longlong(F), _p(box), _p(sel1), ctypes.c_longlong(len(sel1)), _p(sel2),
                             ctypes.c_longlong(len(sel2)), _p(chains), ctypes.c_int(int(selfdist)), ctypes.c_int(int(pbc)),
                             ctypes.c_float(threshold), ctypes.c_longlong(budget_bytes), _p(offs), _p(pairs), ctypes.c_longlong(cap),
-                            ctypes.byref(n))
+                            ctypes.byref(n), ctypes.c_int(int(device_sink)))
     assert st == 0, lib().emu_last_error()
     flat = pairs[:2 * n.value].astype(np.int64)
     return [flat[2 * offs[f]:2 * offs[f + 1]].tolist() for f in range(F)]

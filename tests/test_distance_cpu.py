@@ -72,9 +72,10 @@ def test_device_side_contact_lists_match_reference_lists(g):
     also when a tiny counter budget cuts the frames into several chunks, and for self pairs."""
     c, b, ch = g["coords"], g["box"], g["chains"]
     for budget in (256 << 20, 1):
-        res = E.contacts_trajectory(c, b, g["sel1"], g["sel2"], ch, False, True, 12.0, budget_bytes=budget)
-        assert np.array_equal([len(x) // 2 for x in res], g["contacts_counts"])
-        assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_flat"])
+        for device_sink in (False, True):       # (round 6: the "_dev" form's list stays in one buffer that grows chunk by chunk)
+            res = E.contacts_trajectory(c, b, g["sel1"], g["sel2"], ch, False, True, 12.0, budget_bytes=budget, device_sink=device_sink)
+            assert np.array_equal([len(x) // 2 for x in res], g["contacts_counts"])
+            assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_flat"])
     res = E.contacts_trajectory(c, b, g["sel2"], g["sel2"], ch, True, False, 15.0)
     assert np.array_equal([len(x) // 2 for x in res], g["contacts_self_counts"])
     assert np.array_equal(np.concatenate([np.asarray(x, np.int64) for x in res]), g["contacts_self_flat"])
@@ -327,3 +328,106 @@ def test_oracle_on_the_reference_held_metricdistance_projections():
     d = M.run_projection(_OracleFns, coords, box, g, "distances")
     n1, n2 = len(g["distances_sel1"]), len(g["distances_sel2"])
     assert np.array_equal((d <= 8).reshape(-1, n1, n2).transpose(0, 2, 1).reshape(d.shape[0], -1), g["contacts_held"])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: k_dist_reduction_closest (first-group atoms in registers, packed arithmetic, accumulated exactness test)
+# ------------------------------------------------------------------------------------------------
+def _ragged_groups(rng, n_atoms, ng, lo, hi):
+    return [rng.choice(n_atoms, int(rng.integers(lo, hi + 1)), replace=False).tolist() for _ in range(ng)]
+
+
+@pytest.mark.parametrize("selfdist,pairs", [(False, False), (True, False), (False, True)])
+def test_closest_reduction_kernel_every_block_size_is_the_oracle(selfdist, pairs):
+    """Ragged groups of 1 ... 19 atoms (padding slots, several passes per first group), 70 frames (a frame tile and a ragged
+    one), enough group pairs for several tiles and for waves whose stretch crosses first groups: 4 and 8 first atoms in
+    registers, the generic kernel and the oracle agree bit for bit, periodic with mixed chains and open."""
+    rng = np.random.default_rng(601 + 2 * selfdist + pairs)
+    N, F = 150, 70
+    coords = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
+    box = rng.uniform(22, 31, size=(3, F)).astype(np.float32)
+    masses = np.ones(N, np.float32)
+    g1 = _ragged_groups(rng, N, 13, 1, 19)
+    g2 = g1 if selfdist else _ragged_groups(rng, N, 13 if pairs else 11, 1, 12)
+    ch1 = rng.integers(0, 3, len(g1)).astype(np.uint32)
+    ch2 = ch1 if selfdist else rng.integers(0, 3, len(g2)).astype(np.uint32)
+    for pbc in (True, False):
+        want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs)
+        for block in (4, 8, -1, 0):
+            got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs, block=block)
+            assert np.array_equal(got, want), (pbc, block)
+    # 64-bit row addressing (what a trajectory of more than 4 GiB takes): same bits
+    got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, selfdist, True, masses, 0, 0, pairs=pairs, block=4, n_atoms=1 << 40)
+    assert np.array_equal(got, oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, True, masses, 0, 0, pairs=pairs))
+
+
+def _image_integer_traps(rng, n):
+    """(box length b, separation d) float32 pairs for which rndne(fl(d * fl(1/b))) -- the kernels' fast image integer -- is NOT
+    the reference's round(fl(d / b)) AND the shifted separations differ: quotients on or within an ulp of a half-integer."""
+    f32, out = np.float32, []
+    while len(out) < n:
+        b = f32(rng.uniform(15, 40)); k = int(rng.integers(-3, 3))
+        d = f32((k + 0.5) * float(b))
+        for _ in range(int(rng.integers(0, 3))):
+            d = np.nextafter(d, f32(np.inf if rng.integers(2) else -np.inf), dtype=np.float32)
+        q_fast = f32(d * (f32(1) / b)); r_fast = np.rint(q_fast)
+        q_ref = float(f32(d / b)); r_ref = np.sign(q_ref) * np.floor(abs(q_ref) + 0.5)             # C round(): half away from zero
+        if r_fast != r_ref and abs(f32(d - f32(b * f32(r_fast)))) != abs(f32(d - f32(b * f32(r_ref)))):
+            out.append((b, d))
+    return out
+
+
+def test_closest_reduction_kernel_redoes_stretches_near_half_a_box_exactly():
+    """Separations for which the fast image integer differs from the reference's round(d / b) (found by search: quotients on
+    half-integers, where round-half-even and round-half-away part, or an ulp beside them): the accumulated risk sends those
+    stretches through the pair-by-pair path with its correctly rounded divisions; bit for bit the oracle.  Single-atom groups,
+    so that the trapped pair IS the minimum (tests/test_distance_cpu.py was mutation-checked: without the redo this fails)."""
+    rng = np.random.default_rng(77)
+    F = 64
+    traps = _image_integer_traps(rng, F)
+    N = 24
+    coords = rng.uniform(0, 12, size=(N, 3, F)).astype(np.float32)
+    box = np.empty((3, F), np.float32)
+    for f, (b, d) in enumerate(traps):
+        ax = f % 3
+        box[:, f] = [np.float32(41.3), np.float32(37.9), np.float32(44.1)]
+        box[ax, f] = b
+        coords[1, :, f] = coords[0, :, f]                      # atom 1 = atom 0 shifted by the trap along one axis
+        coords[1, ax, f] = np.float32(coords[0, ax, f] - d)
+    g1 = [[0], [2, 3, 4, 5, 6]]
+    g2 = [[1], [7, 8, 9]]
+    ch1, ch2 = np.zeros(2, np.uint32), np.ones(2, np.uint32)
+    masses = np.ones(N, np.float32)
+    want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, 0, 0)
+    fast = []                                                  # what the fast integer alone would give for the trapped pair
+    for f, (b, d) in enumerate(traps):
+        ax = f % 3
+        dd = np.float32(coords[0, ax, f] - coords[1, ax, f])
+        fast.append(dd == d)
+    assert sum(fast) > F // 2                                  # (the subtraction reproduces the trap's separation in most frames)
+    for block in (4, 8):
+        assert np.array_equal(E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, 0, 0, block=block), want)
+
+
+def test_closest_reduction_kernel_nan_and_infinite_semantics():
+    """The reference's `if dist2 < mindist or mindist < 0` keeps a NaN only when the FIRST atom pair produced it
+    (distance_utils.pyx:268-274); an infinite coordinate gives inf or NaN like the reference; a zero box with pbc too."""
+    rng = np.random.default_rng(5)
+    N, F = 30, 64
+    coords = rng.uniform(0, 15, size=(N, 3, F)).astype(np.float32)
+    box = np.full((3, F), 25.0, np.float32)
+    coords[4, 1, ::3] = np.nan            # first atom of group 0 of side 1: every result of that row is NaN in those frames
+    coords[9, 2, ::5] = np.nan            # a LATER atom of a group: ignored by the minimum
+    coords[12, 0, ::7] = np.inf
+    box[:, 10] = 0.0                      # pbc with a zero box: the reference divides by zero
+    g1 = [[4, 5, 6], [7, 8, 9, 10, 11], [12, 13]]
+    g2 = [[14, 15, 16, 17], [18, 9], [20, 21, 22, 23, 24, 25, 26, 27, 28]]
+    ch1, ch2 = np.zeros(3, np.uint32), np.ones(3, np.uint32)
+    masses = np.ones(N, np.float32)
+    with np.errstate(all="ignore"):
+        for pbc in (True, False):
+            want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0)
+            assert np.isnan(want).any() and np.isfinite(want).any()
+            for block in (4, 8, -1):
+                got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0, block=block)
+                assert np.array_equal(got, want, equal_nan=True), (pbc, block)

@@ -387,3 +387,176 @@ def test_reference_held_metricdistance_projections_on_the_gpu():
         i, j = np.divmod(hit, len(s2))
         # (dist2 <= 64 and sqrt(dist2) <= 8 agree: the root is correctly rounded and 8 is exact)
         assert lists[f] == np.stack([s1[i], s2[j]], 1).ravel().tolist()
+
+
+# ------------------------------------------------------------------------------------------------
+# round 6: k_dist_reduction_closest on the hardware, and the device-resident entry points
+# ------------------------------------------------------------------------------------------------
+def _ragged(rng, n_atoms, ng, lo, hi):
+    return [rng.choice(n_atoms, int(rng.integers(lo, hi + 1)), replace=False).tolist() for _ in range(ng)]
+
+
+@pytest.mark.parametrize("selfdist,pairs", [(False, False), (True, False), (False, True)])
+def test_closest_reduction_many_tiles_every_block_size_bit_exact(selfdist, pairs):
+    """Hundreds of (group pair, frame) tiles, ragged groups of 1 ... 21 atoms, 200 frames (a ragged frame tile): 4 / 8 first
+    atoms in registers, the generic kernel and the default choice all give the oracle's bits."""
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import dist_trajectory_reduction, dist_trajectory_reduction_pairs
+    rng = np.random.default_rng(91 + 2 * selfdist + pairs)
+    N, F = 900, 200
+    coords = rng.uniform(-40, 40, size=(N, 3, F)).astype(np.float32)
+    box = rng.uniform(35, 47, size=(3, F)).astype(np.float32)
+    masses = rng.uniform(1, 32, N).astype(np.float32)
+    g1 = _ragged(rng, N, 61, 1, 21)
+    g2 = g1 if selfdist else _ragged(rng, N, 61 if pairs else 37, 1, 16)
+    ch1 = rng.integers(0, 3, len(g1)).astype(np.uint32)
+    ch2 = ch1 if selfdist else rng.integers(0, 3, len(g2)).astype(np.uint32)
+    ctx = _lib.default_context()
+    try:
+        for pbc in (True, False):
+            want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs)
+            for block in (0, 4, 8, -1):
+                ctx.set_reduction_block(block)
+                r = np.zeros_like(want)
+                if pairs:
+                    dist_trajectory_reduction_pairs(coords, box, g1, g2, ch1, ch2, pbc, masses, 0, 0, r)
+                else:
+                    dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, r)
+                assert np.array_equal(r, want), (pbc, block)
+    finally:
+        ctx.set_reduction_block(0)
+
+
+def test_closest_reduction_redo_path_and_nan_rules_on_the_hardware():
+    """Image integers where rndne(d * fl(1/b)) is not the reference's round(d / b) (the redo path), NaN / inf coordinates and a
+    zero box: the same cases as the emulated tier (tests/test_distance_cpu.py), on the real v_rndne / v_min3 / v_max3."""
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import dist_trajectory_reduction
+    from tests.test_distance_cpu import _image_integer_traps
+    rng = np.random.default_rng(77)
+    F, N = 64, 24
+    traps = _image_integer_traps(rng, F)
+    coords = rng.uniform(0, 12, size=(N, 3, F)).astype(np.float32)
+    box = np.empty((3, F), np.float32)
+    for f, (b, d) in enumerate(traps):
+        ax = f % 3
+        box[:, f] = [np.float32(41.3), np.float32(37.9), np.float32(44.1)]
+        box[ax, f] = b
+        coords[1, :, f] = coords[0, :, f]
+        coords[1, ax, f] = np.float32(coords[0, ax, f] - d)
+    g1, g2 = [[0], [2, 3, 4, 5, 6]], [[1], [7, 8, 9]]
+    ch1, ch2 = np.zeros(2, np.uint32), np.ones(2, np.uint32)
+    masses = np.ones(N, np.float32)
+    ctx = _lib.default_context()
+    try:
+        want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, 0, 0)
+        for block in (4, 8):
+            ctx.set_reduction_block(block)
+            r = np.zeros_like(want)
+            dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, 0, 0, r)
+            assert np.array_equal(r, want), block
+        # NaN / inf / zero box
+        coords = rng.uniform(0, 15, size=(30, 3, F)).astype(np.float32)
+        box = np.full((3, F), 25.0, np.float32)
+        coords[4, 1, ::3] = np.nan; coords[9, 2, ::5] = np.nan; coords[12, 0, ::7] = np.inf
+        box[:, 10] = 0.0
+        g1 = [[4, 5, 6], [7, 8, 9, 10, 11], [12, 13]]
+        g2 = [[14, 15, 16, 17], [18, 9], [20, 21, 22, 23, 24, 25, 26, 27, 28]]
+        ch1, ch2 = np.zeros(3, np.uint32), np.ones(3, np.uint32)
+        masses = np.ones(30, np.float32)
+        with np.errstate(all="ignore"):
+            for pbc in (True, False):
+                want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0)
+                for block in (4, 8, -1):
+                    ctx.set_reduction_block(block)
+                    r = np.zeros_like(want)
+                    dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0, r)
+                    assert np.array_equal(r, want, equal_nan=True), (pbc, block)
+    finally:
+        ctx.set_reduction_block(0)
+
+
+def test_device_resident_entry_points_bit_exact(g):
+    """mkamd_dist_reduction_dev / mkamd_contacts_trajectory_dev / mkamd_cdist_dev / mkamd_pdist_dev: device tensors in, device
+    results out on the caller's stream -- the bits of the host forms (and so the reference's)."""
+    import torch
+    from moleculekit_amd import _lib
+    dev = torch.device("cuda", 0)
+    ctx = _lib.default_context(0)
+    stream = torch.cuda.Stream(dev)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    c, b, m = g["coords"], g["box"], g["masses"]
+    N, F = c.shape[0], c.shape[2]
+    g1 = [list(map(int, x)) for x in g["groups1"]]; g2 = [list(map(int, x)) for x in g["groups2"]]
+    csr = lambda gs: (np.concatenate([np.asarray(x, np.int32) for x in gs]), np.concatenate([[0], np.cumsum([len(x) for x in gs])]).astype(np.int64))
+    a1, o1 = csr(g1); a2, o2 = csr(g2)
+    d_c, d_b, d_m = t(c), t(b), t(m)
+    d_a1, d_o1, d_a2, d_o2 = t(a1), t(o1), t(a2), t(o2)
+    d_ch1, d_ch2 = t(g["gchains1"].astype(np.int32)), t(g["gchains2"].astype(np.int32))
+    with torch.cuda.stream(stream):
+        ctx.set_stream(stream.cuda_stream)
+        try:
+            for r1 in (0, 1):
+                for r2 in (0, 1):
+                    for pbc in (0, 1):
+                        want = g[f"red_{r1}{r2}_pbc{pbc}"]
+                        out = torch.full(want.shape, -3.0, device=dev, dtype=torch.float32)
+                        ctx.dist_reduction_dev(d_c, N, F, d_b, d_a1, d_o1, len(g1), len(a1), d_a2, d_o2, len(g2), d_ch1, d_ch2, False, False, bool(pbc),
+                                               d_m, r1, r2, out)
+                        stream.synchronize()
+                        assert np.array_equal(out.cpu().numpy(), want), (r1, r2, pbc)
+            want = g["red_self"]
+            out = torch.empty(want.shape, device=dev, dtype=torch.float32)
+            ctx.dist_reduction_dev(d_c, N, F, d_b, d_a2, d_o2, len(g2), len(a2), d_a2, d_o2, len(g2), d_ch2, d_ch2, True, False, True, d_m, 0, 0, out)
+            stream.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+            # contact lists: the device list == the reference's lists
+            s1, s2 = t(g["sel1"].astype(np.int32)), t(g["sel2"].astype(np.int32))
+            d_ch = t(g["chains"].astype(np.int32))
+            offs, ptr, n = ctx.contacts_trajectory_dev(d_c, F, d_b, s1, len(g["sel1"]), s2, len(g["sel2"]), d_ch, False, True, 12.0)
+            assert np.array_equal(np.diff(offs), g["contacts_counts"]) and n == int(g["contacts_counts"].sum()) and ptr
+            flat = np.empty(2 * n, np.uint32)
+            _lib._check(_lib.load().mkamd_copy_to_host(ctx._h, flat.ctypes.data, ptr, flat.nbytes))
+            assert np.array_equal(flat.astype(np.int64), g["contacts_flat"])
+            offs, ptr, n = ctx.contacts_trajectory_dev(d_c, F, d_b, s2, len(g["sel2"]), s2, len(g["sel2"]), d_ch, True, False, 15.0)
+            flat = np.empty(2 * n, np.uint32)
+            _lib._check(_lib.load().mkamd_copy_to_host(ctx._h, flat.ctypes.data, ptr, flat.nbytes))
+            assert np.array_equal(np.diff(offs), g["contacts_self_counts"]) and np.array_equal(flat.astype(np.int64), g["contacts_self_flat"])
+            offs, ptr, n = ctx.contacts_trajectory_dev(d_c, F, d_b, s1, len(g["sel1"]), s2, len(g["sel2"]), d_ch, False, True, 0.001)
+            assert n == 0 and ptr == 0 and not offs.any()
+            for D in (1, 2, 3, 5):
+                ca, cb = t(g[f"cdist_a{D}"]), t(g[f"cdist_b{D}"])
+                out = torch.empty(g[f"cdist_r{D}"].shape, device=dev, dtype=torch.float32)
+                ctx.cdist_dev(ca, ca.shape[0], cb, cb.shape[0], D, out)
+                po = torch.empty(g[f"pdist_r{D}"].shape, device=dev, dtype=torch.float32)
+                ctx.pdist_dev(cb, cb.shape[0], D, po)
+                stream.synchronize()
+                assert np.array_equal(out.cpu().numpy(), g[f"cdist_r{D}"]) and np.array_equal(po.cpu().numpy(), g[f"pdist_r{D}"])
+        finally:
+            ctx.set_stream(None)
+
+
+def test_device_contact_list_equals_the_host_form_on_a_larger_call():
+    """37 500 pairs x 300 frames, thousands of contacts: the device-resident list of mkamd_contacts_trajectory_dev read back ==
+    the lists of the host form.  (Growth of the device list across several chunks of frames needs a counter budget below the
+    library's 256 MB: covered on the emulated tier, tests/test_distance_cpu.py, with a one-byte budget.)"""
+    import torch
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import contacts_trajectory
+    rng = np.random.default_rng(12)
+    N, F = 400, 300
+    coords = rng.uniform(0, 30, size=(N, 3, F)).astype(np.float32)
+    box = np.full((3, F), 30.0, np.float32)
+    chains = (np.arange(N) // 100).astype(np.uint32)
+    sel = np.arange(N, dtype=np.uint32)
+    want = contacts_trajectory(coords, box, sel[:150], sel[150:], chains, False, True, 4.0)
+    dev = torch.device("cuda", 0)
+    ctx = _lib.default_context(0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    d_c, d_b = t(coords), t(box)
+    offs, ptr, n = ctx.contacts_trajectory_dev(d_c, F, d_b, t(sel[:150].astype(np.int32)), 150, t(sel[150:].astype(np.int32)), 250,
+                                               t(chains.astype(np.int32)), False, True, 4.0)
+    flat = np.empty(2 * n, np.uint32)
+    _lib._check(_lib.load().mkamd_copy_to_host(ctx._h, flat.ctypes.data, ptr, flat.nbytes))
+    got = [flat[2 * offs[f]:2 * offs[f + 1]].astype(np.int64).tolist() for f in range(F)]
+    assert got == want and n > 1000

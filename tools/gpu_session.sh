@@ -1,13 +1,11 @@
 # tools/gpu_session.sh -- the commands of the CURRENT gpurun session
-# round 5, session 24: the exactness test's slope in a scalar register (one v_mov per periodic pair fewer in the tile kernels) against the
-# committed build, alternating; GPU distance tests with the new build first
+# round 6, session 1: the new closest-atom group reduction kernel, the device-resident entry points and the reference-held
+# MetricDistance projections on the hardware; then the whole GPU tier; then the dist bench line with its new legs
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-V=$PWD/.variants/libmkamd_base.so
-(timeout 900 python -m pytest tests/test_gpu_distance.py -m gpu -q -x 2>&1 | tail -2)
-rm -f gpurun_out/dist_ab7.txt
-for r in 1 2 3; do
-  (PROBE_AVOID=0,3 PROBE_ODD=1 MKAMD_LIB=$V MKAMD_ALLOW_DIAGNOSTICS=1 timeout 300 python tools/dist_shapes_probe.py 2>&1 | grep "pbc=True" | sed 's/^/base /') >> gpurun_out/dist_ab7.txt
-  (PROBE_AVOID=0,3 PROBE_ODD=1 timeout 300 python tools/dist_shapes_probe.py 2>&1 | grep "pbc=True" | sed 's/^/new  /') >> gpurun_out/dist_ab7.txt
-done
-sort -k2,2n -k4,4n -k7,7 -s gpurun_out/dist_ab7.txt | cut -c1-112
+(timeout 900 python -m pytest tests/test_gpu_distance.py -m gpu -q -x -s 2>&1 | tail -15) > gpurun_out/s1_dist_tests.txt 2>&1
+cat gpurun_out/s1_dist_tests.txt
+(timeout 600 python bench.py --workload dist --steps 20 --warmup 3 > gpurun_out/s1_bench_dist.log 2>&1; echo "rc=$?" >> gpurun_out/s1_bench_dist.log)
+tail -c 6000 gpurun_out/s1_bench_dist.log
+(timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -5) > gpurun_out/s1_all_tests.txt 2>&1
+cat gpurun_out/s1_all_tests.txt
