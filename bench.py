@@ -355,19 +355,33 @@ def bench_distances(args, emit=True):
             step()
         e1.record()
         torch.cuda.synchronize(dev)
-        return time.perf_counter() - t0, e0.elapsed_time(e1) / args.steps
+        elapsed, ms = time.perf_counter() - t0, e0.elapsed_time(e1) / args.steps
+        clocks[pbc] = _clock_ghz(ctx, dev, step)     # the shader clock the device holds under THIS leg (beside the roofline fraction it explains)
+        return elapsed, ms
 
+    clocks = {}
+    only = os.environ.get("MKAMD_DIST_ONLY", "")           # profiling passes: "periodic" / "nonperiodic" / "reduction" = that leg alone (one kernel variant per pass)
+    if only == "reduction":                                 # the group-reduction leg alone (periodic, the default block): its PMC / trace passes
+        line = {"metric": "G atom pairs/s (dist_trajectory_reduction, closest, periodic; MKAMD_DIST_ONLY=reduction)", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "reduction": bench_reductions(args, ctx, dev, busy, False, only_periodic=True)}
+        line["value"], line["unit"] = line["reduction"]["periodic"]["valu"]["atom_pairs_per_s_G"], "G atom pairs/s"
+        line["ms_per_step"] = line["reduction"]["periodic"]["ms_per_call"]
+        line["config"] = {"workload": line["reduction"]["shape"]}
+        if emit:
+            print(json.dumps(line), flush=True)
+        return line
     # the common MetricDistance call first (pbc = False: no pair wraps; projections/util.py:30-37), then the headline of this
     # leg, periodic by chain -- whose result stays in `out` for the bit-exactness check below
     ndist = F * n1 * n2
     alg = ndist * 4 + (n1 + n2) * 3 * F * 4 + 3 * F * 4
-    only = os.environ.get("MKAMD_DIST_ONLY", "")           # profiling passes: "periodic" / "nonperiodic" = that leg alone (one kernel variant per pass)
     nonperiodic = None                                      # (a profiling pass of the periodic leg alone: no numbers are made up for the other)
     if only != "periodic":
         np_elapsed, np_ms = timed(False)
         nonperiodic = {"value": round(ndist * args.steps / np_elapsed / 1e6, 1), "unit": "Mdist/s", "ms_per_step": round(np_elapsed / args.steps * 1e3, 4),
                        "roofline": {"bound": "hbm", "achieved": round(alg / np_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": ctx.last_dist_kernel(), "timed_region": "the whole call: " + ctx.last_dist_kernel(), "kernel_avg_ms": round(np_ms, 5)}}
+                                    "frac": round(alg / np_ms / 1e6 / HBM_PEAK_GBS, 4), "kernel": ctx.last_dist_kernel(), "timed_region": "the whole call: " + ctx.last_dist_kernel(), "kernel_avg_ms": round(np_ms, 5),
+                                    "shader_clock_ghz": clocks.get(False)}}
     if not args.no_cpu_baseline and only != "periodic":
         from oracle import oracle
         Fs = min(16, F)
@@ -389,7 +403,7 @@ def bench_distances(args, emit=True):
             "config": {"workload": f"dist: {N} atoms x {F} frames, {n1} x {n2} pairs (SURVEY.md 8f-1)"},
             "roofline": {"bound": "hbm", "achieved": round(alg / k_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / k_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": dist_traffic(F)[0], "traffic_source": dist_traffic(F)[1], "kernel": ctx.last_dist_kernel(), "timed_region": "the whole call: " + ctx.last_dist_kernel() + " (HIP events around the steps)",
-                         "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg},
+                         "kernel_avg_ms": round(k_ms, 5), "algorithmic_bytes_per_launch": alg, "shader_clock_ghz": clocks.get(True)},
             "nonperiodic": nonperiodic}
     if not args.no_cpu_baseline:
         from oracle import oracle
@@ -433,7 +447,8 @@ def bench_distances(args, emit=True):
                 torch.cuda.synchronize(dev)
                 ms = e0.elapsed_time(e1) / args.steps
                 res["periodic" if pbc else "nonperiodic"] = {"us_per_call": round(ms * 1e3, 2), "frac": round(algn / ms / 1e6 / HBM_PEAK_GBS, 4),
-                                                             "achieved_GBs": round(algn / ms / 1e6, 1), "kernel": ctx.last_dist_kernel()}
+                                                             "achieved_GBs": round(algn / ms / 1e6, 1), "kernel": ctx.last_dist_kernel(),
+                                                             "algorithmic_bytes_per_launch": algn, "shader_clock_ghz": _clock_ghz(ctx, dev, call)}
             res["shape"] = f"{n1s} x {n2s}{' selfdist' if selfd else ''}: {Pn} pairs x {F} frames ({F * Pn * 4 / 1e6:.0f} MB of result)"
             del o2
             return res
@@ -486,7 +501,7 @@ def reduction_workload(G=200, A=15, F=512, L=60.0, seed=5):
     return coords, box, atoms, offs, chains, np.ones(N, np.float32)
 
 
-def bench_reductions(args, ctx, dev, busy, check):
+def bench_reductions(args, ctx, dev, busy, check, only_periodic=False):
     """dist_trajectory_reduction (distance_utils.pyx:211-281) on device pointers: all 19 900 pairs of 200 residues of 15 atoms,
     512 frames -- 2.29 G atom-pair distances per call.  The path is bound by instruction issue, not by memory (59 MB of
     algorithmic traffic per call): `roofline` is the HBM line the contract asks for, `valu` the one that bounds it
@@ -536,7 +551,7 @@ def bench_reductions(args, ctx, dev, busy, check):
     info = ctx.device_info()
     lanes = info["compute_units"] * 4 * 16
     clock, want_clock = [None], True
-    for name, pbc in (("periodic", True), ("nonperiodic", False)):
+    for name, pbc in (("periodic", True), ("nonperiodic", False))[:1 if only_periodic else 2]:
         ms = leg(pbc, 0, 0)
         clk = clock[0]
         npairs = P * A * A * F
@@ -547,10 +562,12 @@ def bench_reductions(args, ctx, dev, busy, check):
                           "issue_slots_per_atom_pair": None if not clk else round(lanes * clk * 1e9 * ms * 1e-3 / npairs, 2),
                           "shader_clock_ghz": clk}}
         res[name] = entry
+    if only_periodic:
+        return res
     want_clock = False
     # same-box A-B: the block sizes of the new kernel and the generic kernel it replaces (round 2-5: 2.9 ms on record)
     res["ab_periodic_ms"] = {"block4": round(leg(True, 0, 0, block=4), 4), "block8": round(leg(True, 0, 0, block=8), 4),
-                             "generic_kernel": round(leg(True, 0, 0, block=-1), 4)}
+                             "block8_four_waves": round(leg(True, 0, 0, block=108), 4), "generic_kernel": round(leg(True, 0, 0, block=-1), 4)}
     res["com_com_periodic_ms"] = round(leg(True, 1, 1), 4)
     res["pairs_closest_periodic_ms"] = round(leg(True, 0, 0, pairs=True), 4)
     pmc = reduction_pmc()

@@ -647,7 +647,8 @@ try {
 int mkamd_ctx_set_reduction_block(mkamd_ctx* ctx, int block)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (block != 0 && block != 4 && block != 8 && block != -1) return fail(MKAMD_EINVAL, "reduction block: 0 (choose), 4, 8, or -1 (the generic kernel)");
+    if (block != 0 && block != 4 && block != 8 && block != -1 && block != 104 && block != 108)
+        return fail(MKAMD_EINVAL, "reduction block: 0 (choose), 4, 8 (+ 100: blocks of four waves), or -1 (the generic kernel)");
     ctx->reduction_block = block;
     return MKAMD_OK;
 } MK_API_CATCH

@@ -183,7 +183,7 @@ constexpr int DP_BATCH = 4;           // (8 was measured too)
 // row; the host refuses F >= 2^30): emit(k, d2), k = 0 .. DP_RUN-1, called by all lanes.  Pairs past the end repeat
 // the last pair (valid addresses, no divergence) -- the caller drops what they emit.  Needs pw < P.
 // emit(k0, d2[DP_BATCH]): a batch at a time.
-template <class Emit>
+template <bool MAYWRAP = true /* false: a call with pbc = 0 -- no pair wraps, the flags are not even looked at */, class Emit>
 MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned fb, float bx, float by, float bz,
                          const unsigned* __restrict__ pa, const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
                          long long P, long long pw, Emit&& emit)
@@ -192,7 +192,9 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
     const long long left = P - pw;                                   // wave-uniform, > 0
     const long long pi = pw + (lane & (DP_RUN - 1)) < P ? pw + (lane & (DP_RUN - 1)) : P - 1;
     // lane k: first atom of pair k, and its second atom with the wrap flag in bit 31 (atom indices are int32)
-    const unsigned va = pa[pi], vb = pb[pi] | (wrap[pi] != 0u ? 0x80000000u : 0u);
+    unsigned vb_ = pb[pi];
+    if constexpr (MAYWRAP) vb_ |= wrap[pi] != 0u ? 0x80000000u : 0u;
+    const unsigned va = pa[pi], vb = vb_;
     const unsigned a_first = mk_readlane(va, 0);
     const bool one_a = mk_ballot(va != a_first) == 0ull;              // the usual case in i-major order: one first atom for the run
     // a coordinate row is a wave-uniform base (the atom index sits in a scalar register) plus this lane's frame as a
@@ -207,7 +209,7 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
     // a body that holds no image arithmetic at all; the reciprocals of the box are only formed (three IEEE divisions: 30
     // vector instructions) for runs that wrap, ONCE per run: left to itself the optimizer sinks them into every batch
     // (round 4: 99 v_rcp_f32 in the kernel, 7.5 instructions per distance).
-    const bool run_wraps = mk_ballot((vb & 0x80000000u) != 0u) != 0ull;
+    const bool run_wraps = MAYWRAP && mk_ballot((vb & 0x80000000u) != 0u) != 0ull;
     float ibx = 0.f, iby = 0.f, ibz = 0.f;
     if (run_wraps) { ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz); }
     mk_keep(ibx); mk_keep(iby); mk_keep(ibz);
@@ -259,6 +261,9 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
 //  frame -- as 16 bytes of out[f, p ..], a store instruction touches 64 rows whose lines fill up over the wave's four batches.  No
 //  LDS, no barrier, the same bits -- and 35-55 % SLOWER on every triangular shape (450 x 450: 400 us against 292, 2.1 TB/s; 100 x 100:
 //  23.8 against 19.7): sixty-four quarter-lines per store instruction are what the memory pipeline is slowest at.)
+// (round 6: PBC is a template parameter -- the periodic and the open call are different kernels to a profiler, as the row and
+//  frame kernels' are: `mkamd::k_dist_pairs<true>` / `<false>`; the open one never reads the wrap flags)
+template <bool PBC>
 MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long long F,
                                         const float* __restrict__ box, const unsigned* __restrict__ pa,
                                         const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap,
@@ -275,7 +280,7 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
         const long long pw = p0 + pq * DP_RUN;                       // the wave's first pair
         if (pw < P)
-            for_pair_run(coords, F, (unsigned)f * 4u, bx, by, bz, pa, pb, wrap, P, pw,
+            for_pair_run<PBC>(coords, F, (unsigned)f * 4u, bx, by, bz, pa, pb, wrap, P, pw,
                          [&](int k0, const float (&d2)[DP_BATCH]) {
                              // the batch's roots behind ONE wave-uniform test (mk_sqrt_ordinary: practically always true)
                              const bool ordinary = mk_sqrt_ordinary_all(d2);
@@ -678,6 +683,7 @@ MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long l
 //   k_contacts_scan  : per frame, exclusive prefix of the counts over the pair tiles (+ the frame's total)
 //   k_contacts_fill  : the same tiles again; a lane keeps its 16 hits as a bit mask, ranks them behind the tile's
 //                      prefix and the lower waves of its block, and writes (a, b) at frame_base + rank: (i, j) order
+//                      (round 6: from the 16-bit masks the count pass left -- no distance is computed twice)
 // Frames are processed in chunks (host loop, capi.hip) so that the counters stay within a fixed memory budget.
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_RUN = DT / (DT_THREADS / DT);        // consecutive pairs per wave of a tile (16)
@@ -701,11 +707,13 @@ MK_DEV unsigned contact_mask(const float* __restrict__ coords, long long F, long
     return fin ? mask : 0u;
 }
 
-// blockIdx.x = pair tile, blockIdx.y = 64-frame slab of the chunk [f_begin, f_begin + fc); cnt is [tiles][fc_pad]
+// blockIdx.x = pair tile, blockIdx.y = 64-frame slab of the chunk [f_begin, f_begin + fc); cnt is [tiles][fc_pad];
+// masks is [tiles * 4 runs][fc_pad] (round 6): the 16 contact bits of every (run of 16 pairs, frame), kept for the fill pass --
+// which then computes no distance at all (before: every pair twice, 0.56 ms for 200 x 500 pairs x 2 048 frames)
 MK_KERNEL(DT_THREADS) void k_contacts_count(const float* __restrict__ coords, long long F, long long f_begin, long long fc,
                                             long long fc_pad, const float* __restrict__ box, const unsigned* __restrict__ pa,
                                             const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap, long long P,
-                                            float thr2, unsigned* __restrict__ cnt)
+                                            float thr2, unsigned* __restrict__ cnt, unsigned short* __restrict__ masks)
 {
     __shared__ unsigned s_c[DT_THREADS / DT][DT];
     const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
@@ -713,6 +721,7 @@ MK_KERNEL(DT_THREADS) void k_contacts_count(const float* __restrict__ coords, lo
     const bool fin = lf < fc;
     const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
     const unsigned m = contact_mask(coords, F, f, fin, bx, by, bz, pa, pb, wrap, P, (long long)blockIdx.x * DT + pq * CT_RUN, thr2);
+    masks[((size_t)blockIdx.x * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf] = (unsigned short)m;
     s_c[pq][fl] = (unsigned)__builtin_popcount(m);
     mk_block_sync();
     if (pq == 0) {
@@ -748,19 +757,16 @@ MK_KERNEL(DT_THREADS) void k_contacts_scan(unsigned* __restrict__ cnt, long long
     if (w == 0) totals[lf] = total;
 }
 
-MK_KERNEL(DT_THREADS) void k_contacts_fill(const float* __restrict__ coords, long long F, long long f_begin, long long fc,
-                                           long long fc_pad, const float* __restrict__ box, const unsigned* __restrict__ pa,
-                                           const unsigned* __restrict__ pb, const unsigned* __restrict__ wrap, long long P,
-                                           float thr2, const unsigned* __restrict__ prefix,
+MK_KERNEL(DT_THREADS) void k_contacts_fill(long long fc, long long fc_pad, const unsigned* __restrict__ pa, const unsigned* __restrict__ pb,
+                                           const unsigned short* __restrict__ masks, const unsigned* __restrict__ prefix,
                                            const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
 {
     __shared__ unsigned s_c[DT_THREADS / DT][DT];
     const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
-    const long long lf = (long long)blockIdx.y * DT + fl, f = f_begin + lf;
+    const long long lf = (long long)blockIdx.y * DT + fl;
     const bool fin = lf < fc;
-    const float bx = fin ? box[0 * F + f] : 1.f, by = fin ? box[1 * F + f] : 1.f, bz = fin ? box[2 * F + f] : 1.f;
     const long long p_first = (long long)blockIdx.x * DT + pq * CT_RUN;
-    unsigned m = contact_mask(coords, F, f, fin, bx, by, bz, pa, pb, wrap, P, p_first, thr2);
+    unsigned m = masks[((size_t)blockIdx.x * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf];   // (0 for padded frames and pairs past the end)
     s_c[pq][fl] = (unsigned)__builtin_popcount(m);
     mk_block_sync();
     if (!fin || m == 0u) return;
@@ -903,7 +909,7 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
 // loads and ~50 instructions per pair, 2.9 ms for 200 groups of 15 atoms x 512 frames; it stays for the centre-of-mass modes,
 // whose group pairs are one or |g| atom pairs.)
 //
-//  * Lanes run along frames; a wave takes DRC_RUN CONSECUTIVE group pairs of its tile (the kernel above: every fourth), which
+//  * Lanes run along frames; a wave takes DT / NW CONSECUTIVE group pairs of its tile (the kernel above: every fourth), which
 //    in the reference's g1-major order share their first group.  I atoms of that group stay in registers as I/2 packed pairs
 //    (mk_f2: x, y, z of two atoms side by side) for the whole stretch; the atoms of the second groups stream past them, one
 //    load per (atom, axis) for I atom pairs, a coalesced 256-byte row segment each (frames are the fastest axis of `coords`).
@@ -923,7 +929,8 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
 //  * A group with more than I atoms takes several passes over its second groups; the partial minima wait in the wave's own
 //    column of the LDS tile (-1 = nothing yet, as the reference starts), where the root is taken at the end.
 // ------------------------------------------------------------------------------------------------
-constexpr int DRC_RUN = DT / (DT_THREADS / DT);      // consecutive group pairs per wave (16)
+constexpr int DRC_WAVES = 8;                         // waves per block: 8 consecutive group pairs each (round 6, measured: 4 waves x 16 pairs
+                                                     // left the chip's last round of blocks 43 % full on 19 900 pairs x 512 frames)
 constexpr float DRC_RISK = 0.4999998f;               // risk below this: every rndne(d * fl(1/b)) is the reference's round(d / b)
                                                      // (the per-pair test is tm < 0.5 - 3e-7 qm, proven bound 1.8e-7 qm; here
                                                      //  tm + 3e-7 qm is rounded once more: 2e-7 of slack)
@@ -948,15 +955,17 @@ MK_DEV mk_f2 dist2_pk(mk_f2 ax, mk_f2 ay, mk_f2 az, float x2, float y2, float z2
     return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
 }
 
-template <int I /* first-group atoms in registers: 4 or 8 */, bool SMALL /* every coordinate row ends below 4 GiB: one descriptor */>
-MK_KERNEL(DT_THREADS) void k_dist_reduction_closest(const float* __restrict__ coords, long long F, const float* __restrict__ box,
+template <int I /* first-group atoms in registers: 4 or 8 */, bool SMALL /* every coordinate row ends below 4 GiB: one descriptor */,
+          int NW = DRC_WAVES /* waves per block; DT / NW consecutive group pairs per wave */>
+MK_KERNEL(NW * WAVE) void k_dist_reduction_closest(const float* __restrict__ coords, long long F, const float* __restrict__ box,
                                                     const int* __restrict__ g1_atoms, const long long* __restrict__ g1_off,
                                                     const int* __restrict__ g2_atoms, const long long* __restrict__ g2_off,
                                                     const unsigned* __restrict__ ga, const unsigned* __restrict__ gb,
                                                     const unsigned* __restrict__ wrap, long long P, float* __restrict__ out)
 {
     static_assert(I == 4 || I == 8, "packed pairs of first atoms");
-    constexpr int H = I / 2;
+    static_assert(NW == 4 || NW == 8, "waves per block");
+    constexpr int H = I / 2, DRC_RUN = DT / NW;
     __shared__ float tile[DT][DT + 1];
     const long long ptiles = (P + DT - 1) / DT, gt = xcd_contiguous_tile(ptiles * ((F + DT - 1) / DT));   // (as k_dist_pairs)
     if (gt < 0) return;
@@ -1069,7 +1078,7 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction_closest(const float* __restrict__ co
         }
     }
     mk_block_sync();
-    store_tile_rows(tile, f0, p0, F, P, P, out);
+    store_tile_rows<NW>(tile, f0, p0, F, P, P, out);
 }
 
 // cdist (distance_utils.pyx:355-383): results[i, j]; any dimension D; lanes along j.

@@ -123,15 +123,16 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
                         chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
     if (ceil_div(P, DT) * ceil_div(F, DT) > 0x7ffffff0LL) { err = "too many tiles (pairs x frames / 4096 >= 2^31)"; return ST_EINVAL; }
-    be.note_dist_kernel("mkamd::k_build_atom_pairs + mkamd::k_dist_pairs");
-    return be.launch(k_dist_pairs, dim3(padded8(ceil_div(P, DT) * ceil_div(F, DT))), dim3(DT_THREADS), coords, F, box,
-                     (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
+    be.note_dist_kernel(pbc ? "mkamd::k_build_atom_pairs + mkamd::k_dist_pairs<true>" : "mkamd::k_build_atom_pairs + mkamd::k_dist_pairs<false>");
+    const dim3 pgrid(padded8(ceil_div(P, DT) * ceil_div(F, DT)));
+    return pbc ? be.launch(k_dist_pairs<true>, pgrid, dim3(DT_THREADS), coords, F, box, (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out)
+               : be.launch(k_dist_pairs<false>, pgrid, dim3(DT_THREADS), coords, F, box, (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
 }
 
 // dist_trajectory_reduction[_pairs] on device pointers; groups as CSR (atoms int32, offsets int64)
 // `n_atoms` (rows of coords) and `n_g1_atoms` (length of g1_atoms) are what the HOST knows about arrays that live on the device:
 // they choose the kernel variant (32-bit row offsets; how many first-group atoms a wave keeps in registers), never the result.
-// `closest_block`: 0 = choose, 4 / 8 = that many first-group atoms in registers (tests, A-B timing), -1 = the generic kernel.
+// `closest_block`: 0 = choose, 4 / 8 = that many first-group atoms in registers (tests, A-B timing; + 100: blocks of four waves), -1 = the generic kernel.
 template <class BE>
 int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long F, const float* box, const int* g1_atoms,
                        const long long* g1_off, long long ng1, long long n_g1_atoms, const int* g2_atoms, const long long* g2_off,
@@ -169,14 +170,20 @@ int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long
     if (reduction1 == 0 && reduction2 == 0 && closest_block >= 0) {
         // closest atom pair of two atom lists -- the residue-contact maps: first-group atoms in registers, packed arithmetic
         // (k_dist_reduction_closest).  Eight atoms per pass when the first groups are large enough to fill them.
-        const bool eight = closest_block ? closest_block == 8 : n_g1_atoms * 10 >= ng1 * 130;
+        const int blk = closest_block % 100;                         // (+100: four waves of 16 pairs per block -- A-B timing)
+        const bool eight = blk ? blk == 8 : n_g1_atoms * 10 >= ng1 * 130;
+        const bool four_waves = closest_block >= 100;
         const bool small_rows = (unsigned long long)n_atoms * 3ull * (unsigned long long)F * 4ull <= 0xffffffffull;
-        auto go = [&](auto kern) {
-            return be.launch(kern, grid, dim3(DT_THREADS), coords, F, box, g1_atoms, g1_off, g2_atoms, g2_off, (const unsigned*)ga,
+        auto go = [&](auto kern, int nw) {
+            return be.launch(kern, grid, dim3((unsigned)(nw * WAVE)), coords, F, box, g1_atoms, g1_off, g2_atoms, g2_off, (const unsigned*)ga,
                              (const unsigned*)gb, (const unsigned*)wr, P, out);
         };
-        if (eight) return small_rows ? go(k_dist_reduction_closest<8, true>) : go(k_dist_reduction_closest<8, false>);
-        return small_rows ? go(k_dist_reduction_closest<4, true>) : go(k_dist_reduction_closest<4, false>);
+        if (four_waves) {
+            if (eight) return small_rows ? go(k_dist_reduction_closest<8, true, 4>, 4) : go(k_dist_reduction_closest<8, false, 4>, 4);
+            return small_rows ? go(k_dist_reduction_closest<4, true, 4>, 4) : go(k_dist_reduction_closest<4, false, 4>, 4);
+        }
+        if (eight) return small_rows ? go(k_dist_reduction_closest<8, true>, DRC_WAVES) : go(k_dist_reduction_closest<8, false>, DRC_WAVES);
+        return small_rows ? go(k_dist_reduction_closest<4, true>, DRC_WAVES) : go(k_dist_reduction_closest<4, false>, DRC_WAVES);
     }
     return be.launch(k_dist_reduction, grid, dim3(DT_THREADS), c1, c2, F, box,
                      g1_atoms, g1_off, g2_atoms, g2_off, reduction1, reduction2, (const unsigned*)ga, (const unsigned*)gb,
@@ -230,7 +237,7 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     if (F == 0 || P == 0) return ST_OK;
     if (P >= 0xffffffffLL) { err = "too many atom pairs (>= 2^32); split the selections"; return ST_EINVAL; }
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
-    void *pa = nullptr, *pb = nullptr, *wr = nullptr, *cnt = nullptr, *tot = nullptr, *base = nullptr, *dout = nullptr;
+    void *pa = nullptr, *pb = nullptr, *wr = nullptr, *cnt = nullptr, *tot = nullptr, *base = nullptr, *dout = nullptr, *msk = nullptr;
     int st;
     if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
     if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
@@ -239,11 +246,12 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
                         chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
     // frames per chunk: the per-(tile, frame) counters stay within the budget whatever the number of pairs
     const long long tiles = ceil_div(P, DT);
-    long long chunk = ((long long)budget_bytes / (tiles * 4)) / DT * DT;
+    long long chunk = ((long long)budget_bytes / (tiles * 12)) / DT * DT;     // 4 B of counter + 4 x 2 B of contact masks per (tile, frame)
     chunk = std::max<long long>(DT, std::min<long long>(chunk, (F + DT - 1) / DT * DT));
     chunk = std::min<long long>(chunk, 65535LL * DT);
     const float thr2 = dist_threshold * dist_threshold;              // `float dist_threshold` squared in float (:73)
     if ((st = be.ensure(WS_D_CNT, (size_t)tiles * chunk * 4, &cnt, 0))) return st;
+    if ((st = be.ensure(WS_D_MASK, (size_t)tiles * (DT_THREADS / DT) * chunk * 2, &msk, 0))) return st;
     if ((st = be.ensure(WS_D_TOT, (size_t)chunk * 8, &tot, 0))) return st;
     if ((st = be.ensure(WS_D_BASE, (size_t)chunk * 8, &base, 0))) return st;
     std::vector<unsigned long long> totals((size_t)chunk), bases((size_t)chunk);
@@ -251,7 +259,7 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
         const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
         if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
-                            (const unsigned*)wr, P, thr2, (unsigned*)cnt))) return st;
+                            (const unsigned*)wr, P, thr2, (unsigned*)cnt, (unsigned short*)msk))) return st;
         if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(DT_THREADS), (unsigned*)cnt, tiles, fc_pad,
                             (unsigned long long*)tot))) return st;
         if ((st = be.to_host(totals.data(), tot, (size_t)fc_pad * 8))) return st;
@@ -261,8 +269,8 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         if (run == 0) continue;
         if ((st = sink.reserve((size_t)run, &dout))) return st;
         if ((st = be.to_device(base, bases.data(), (size_t)fc_pad * 8))) return st;
-        if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
-                            (const unsigned*)wr, P, thr2, (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
+        if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), fc, fc_pad, (const unsigned*)pa, (const unsigned*)pb, (const unsigned short*)msk,
+                            (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
         if ((st = sink.commit(dout, (size_t)run))) return st;
     }
     return ST_OK;

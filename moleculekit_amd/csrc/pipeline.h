@@ -38,7 +38,7 @@ enum WsSlot {
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS, WS_H_STAGE,
     // distance_utils row (dist_pipeline.h)
     WS_D_PA, WS_D_PB, WS_D_WRAP, WS_D_COM1, WS_D_COM2, WS_D_SEL1, WS_D_SEL2, WS_D_CHAINS, WS_D_CHAINS2, WS_D_G1A, WS_D_G1O,
-    WS_D_G2A, WS_D_G2O, WS_D_MASS, WS_D_CNT, WS_D_TOT, WS_D_BASE, WS_D_CONTACTS,
+    WS_D_G2A, WS_D_G2O, WS_D_MASS, WS_D_CNT, WS_D_TOT, WS_D_BASE, WS_D_CONTACTS, WS_D_MASK,
     WS_NSLOTS
 };
 

@@ -353,7 +353,7 @@ def test_closest_reduction_kernel_every_block_size_is_the_oracle(selfdist, pairs
     ch2 = ch1 if selfdist else rng.integers(0, 3, len(g2)).astype(np.uint32)
     for pbc in (True, False):
         want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs)
-        for block in (4, 8, -1, 0):
+        for block in (4, 8, -1, 0, 104, 108):       # (+ 100: blocks of four waves)
             got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs, block=block)
             assert np.array_equal(got, want), (pbc, block)
     # 64-bit row addressing (what a trajectory of more than 4 GiB takes): same bits

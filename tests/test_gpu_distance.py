@@ -415,7 +415,7 @@ def test_closest_reduction_many_tiles_every_block_size_bit_exact(selfdist, pairs
     try:
         for pbc in (True, False):
             want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs)
-            for block in (0, 4, 8, -1):
+            for block in (0, 4, 8, -1, 104, 108):
                 ctx.set_reduction_block(block)
                 r = np.zeros_like(want)
                 if pairs:
@@ -522,7 +522,8 @@ def test_device_resident_entry_points_bit_exact(g):
             flat = np.empty(2 * n, np.uint32)
             _lib._check(_lib.load().mkamd_copy_to_host(ctx._h, flat.ctypes.data, ptr, flat.nbytes))
             assert np.array_equal(np.diff(offs), g["contacts_self_counts"]) and np.array_equal(flat.astype(np.int64), g["contacts_self_flat"])
-            offs, ptr, n = ctx.contacts_trajectory_dev(d_c, F, d_b, s1, len(g["sel1"]), s2, len(g["sel2"]), d_ch, False, True, 0.001)
+            only1 = np.setdiff1d(g["sel1"], g["sel2"]).astype(np.int32)          # (an atom in both selections is 0 A from itself)
+            offs, ptr, n = ctx.contacts_trajectory_dev(d_c, F, d_b, t(only1), len(only1), s2, len(g["sel2"]), d_ch, False, True, 0.001)
             assert n == 0 and ptr == 0 and not offs.any()
             for D in (1, 2, 3, 5):
                 ca, cb = t(g[f"cdist_a{D}"]), t(g[f"cdist_b{D}"])
