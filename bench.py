@@ -940,6 +940,143 @@ def dry_run(args):
         raise SystemExit("dry run: sharding / gather mismatch")
 
 
+def _standin_distances(kind, coords, box, sel1, sel2, chains, selfdist, pbc):
+    """Stand-in for the distance kernels (dry run only): every pair of a frame = 1 + the frame's coordinate sum -- a function of
+    the FRAME alone, so a misplaced or missing row of the sharded / gathered result shows."""
+    P = len(sel1) * len(sel2)
+    val = 1.0 + coords.astype(np.float64).sum(axis=(0, 1))
+    return np.broadcast_to(val[:, None], (coords.shape[2], P)).astype(np.float32).copy()
+
+
+def bench_distances_sharded(args, dry=False):
+    """`--workload dist --gpus N`: dist_trajectory with the FRAMES sharded over the ranks (moleculekit_amd.distributed.ShardedDistances,
+    SURVEY.md section 8f-1: "frames shard across GPUs exactly like cfg4").  Weak scaling: F frames per rank, each rank generates and keeps
+    only its own; selections replicated; the timed region has no collective; results stay sharded [F_rank, n_pairs].  The gather of the
+    rows is a leg of its own after everything timed.  `dry`: gloo + a stand-in compute on CPU tensors (tests/test_bench_launch.py)."""
+    import torch
+    import torch.distributed as dist
+    from moleculekit_amd.distributed import ShardedDistances
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    use_dist = world > 1 or "RANK" in os.environ
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if dry:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dev, N, F, n1, n2 = torch.device("cpu"), 50, args.batch or 5, 4, 6
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+        shared = os.environ.get("MKAMD_BENCH_SHARE_DEVICES", "0") == "1" and torch.cuda.device_count() > 0
+        if shared:
+            local = local % torch.cuda.device_count()
+        if torch.cuda.device_count() <= local:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} HIP device(s) visible")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if use_dist:
+            import datetime
+            dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=120))
+        N, F, n1, n2 = 30000, args.batch or DEFAULT_BATCH["dist"], 200, 500
+
+    def fence():
+        if not dry:
+            torch.cuda.synchronize(dev)
+        if use_dist:
+            _collective(lambda: dist.all_reduce(torch.zeros(1)))
+        if not dry:
+            torch.cuda.synchronize(dev)
+
+    once = threading.Lock()
+
+    def degraded_line():
+        if once.acquire(blocking=False):
+            print(json.dumps({"metric": "Mdist/s (dist_trajectory, periodic by chain; frames sharded)", "value": None, "unit": "Mdist/s", "n_gpus": world,
+                              "dry_run": dry, "ok": False, "ranks_alive": ranks_done(world), "degraded": _RANKS["broken"]}), flush=True)
+
+    if use_dist and rank == 0:
+        _RANKS["emit"] = degraded_line
+        term_reporter()
+    rng = np.random.default_rng(4)                             # the selections: the same on every rank
+    chains_h = (np.arange(N) // max(1, N // 30)).astype(np.uint32)
+    s1 = np.sort(rng.choice(N, n1, replace=False)).astype(np.uint32)
+    s2 = np.sort(rng.choice(N, n2, replace=False)).astype(np.uint32)
+
+    def loader(lo, hi):                                        # this rank's frames (their own seed): nobody builds the whole trajectory
+        assert (lo, hi) == (rank * F, (rank + 1) * F)
+        r = np.random.default_rng(9000 + rank)
+        return (r.random((N, 3, F), dtype=np.float32) * np.float32(66.9)), np.full((3, F), 66.9, np.float32)
+
+    kw = dict(compute=_standin_distances) if dry else dict(device=dev)
+    sd = ShardedDistances.from_loader(world * F, loader, **kw)
+    out = torch.empty((F, n1 * n2), dtype=torch.float32, device=dev)
+    step = lambda: sd.dist_trajectory(s1, s2, chains_h, False, True, out=out)
+    steps, warm = (2, 1) if dry else (args.steps, args.warmup)
+    if not dry and getattr(args, "settle_seconds", 1.0):
+        t_end = time.perf_counter() + 0.4
+        while time.perf_counter() < t_end:
+            for _ in range(16):
+                step()
+            torch.cuda.synchronize(dev)
+    for _ in range(warm):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    if not dry:
+        torch.cuda.synchronize(dev)
+    mark_done(rank)
+    fence()
+    elapsed = _max_over_ranks(time.perf_counter() - t0, world)
+    if _RANKS["broken"]:
+        if rank == 0:
+            degraded_line()
+        os._exit(1)
+    line = {"metric": "Mdist/s (dist_trajectory, periodic by chain; frames sharded over the ranks)", "value": round(world * F * n1 * n2 * steps / elapsed / 1e6, 1),
+            "unit": "Mdist/s", "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": dry,
+            "config": {"workload": f"dist: {N} atoms x {F} frames per rank, {n1} x {n2} pairs (SURVEY.md 8f-1)", "sharding": "contiguous frame ranges, no collective on the compute path"},
+            "ranks_alive": ranks_done(world) if use_dist else 1}
+    # the gather of the rows (after everything timed: the first RCCL collective of the process builds the communicator)
+    if use_dist and not args.no_gather:
+        def legs():
+            fence()
+            g0 = time.perf_counter()
+            full = sd.gather(out)
+            fence()
+            line["gather_ms"] = round((time.perf_counter() - g0) * 1e3, 3)
+            root = sd.gather(out, dst=0)
+            fence()
+            return full, root
+        try:
+            full, root = guarded(legs, args.gather_timeout, lambda: (degraded_line(), os._exit(1)) if rank == 0 else os._exit(1))
+            ok = tuple(full.shape) == (world * F, n1 * n2) and torch.equal(full[rank * F:(rank + 1) * F], out)
+            ok = ok and ((root is None) if rank else torch.equal(root, full))
+            if dry:                                            # every rank's rows are worth what that rank says they are
+                mine = out[:, 0].tolist()
+                everyone = [None] * world
+                dist.all_gather_object(everyone, mine)
+                ok = ok and torch.equal(full[:, 0], torch.tensor([v for part in everyone for v in part], dtype=torch.float32)) and bool((full == full[:, :1]).all())
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(ok))
+            line["gather_ok"] = all(flags)
+        except Exception as e:                                 # noqa: BLE001 -- a secondary leg
+            line["gather_error"] = f"{type(e).__name__}: {e}"[:300]
+    line["ok"] = bool(line.get("gather_ok", True)) and "gather_error" not in line
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        try:
+            dist.destroy_process_group()
+        except Exception:                                      # noqa: BLE001
+            pass
+    if dry and not line["ok"]:
+        raise SystemExit("dry run: frame sharding / gather mismatch")
+    return line
+
+
 def guarded(fn, seconds, on_timeout):
     """fn() under a watchdog: when it has not returned after `seconds`, on_timeout() is called from another thread (fn
     itself keeps running: a collective that hangs cannot be cancelled, only left behind)."""
@@ -1325,12 +1462,13 @@ def main():
         raise SystemExit(launch_ranks(args, sys.argv[1:]))
     _json_only_stdout()
     if args.dry_run:
-        return dry_run(args)
+        return bench_distances_sharded(args, dry=True) if args.workload == "dist" else dry_run(args)
     if args.workload == "dropin":
         return bench_dropin(args)
     if args.workload == "dist":
-        if args.gpus != 1:
-            raise SystemExit("--workload dist is a single-GPU secondary bench")
+        # one GPU, not under torchrun: the leg-by-leg distance line; N ranks (or one under torchrun): the frames-sharded path
+        if args.gpus != 1 or "RANK" in os.environ:
+            return bench_distances_sharded(args)
         return bench_distances(args)
 
     import torch

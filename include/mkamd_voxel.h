@@ -294,6 +294,9 @@ int mkamd_prefault(void* buffer, uint64_t bytes);
 /* Synchronous device -> host copy on the context's stream (hipMemcpyAsync + wait): what the _host entry points use for
  * their results, for callers of the _dev entry points that collect chunks into a host array. */
 int mkamd_copy_to_host(mkamd_ctx* ctx, void* host_dst, const void* device_src, uint64_t bytes);
+/* Asynchronous device -> device copy on the context's stream: how a caller keeps a context-owned device result (the contact
+ * list of mkamd_contacts_trajectory_dev) past the next call that reuses its memory. */
+int mkamd_copy_dev(mkamd_ctx* ctx, void* device_dst, const void* device_src, uint64_t bytes);
 /* Trajectory slab -> packed items, on the device, on a stream of the CALLER's choice (a copy stream: batch._stream_voxelize
  * prepares chunk k+1 there while chunk k is voxelized): `d_src` holds `rows` rows (atoms x 3 of Molecule.coords, or the 3 box
  * lengths) of `src_pitch` floats each, frame fastest; frames [0, n_frames) of it are written frame-major,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "mkamd_lattice_from_centers": (_c_int, [_vp, ctypes.c_int64, _vp, _vp, _vp]),
     "mkamd_prefault": (_c_int, [_vp, ctypes.c_uint64]),
     "mkamd_copy_to_host": (_c_int, [_vp, _vp, _vp, ctypes.c_uint64]),
+    "mkamd_copy_dev": (_c_int, [_vp, _vp, _vp, ctypes.c_uint64]),
     # include/mkamd_distance.h
     "mkamd_dist_count_pairs": (_c_i64, [_c_i64, _c_i64, _c_int]),
     "mkamd_dist_trajectory_host": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_int, _c_int,

@@ -1317,6 +1317,16 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+extern "C" int mkamd_copy_dev(mkamd_ctx* ctx, void* device_dst, const void* device_src, uint64_t bytes)
+try {
+    int st = check_ctx(ctx, true);
+    if (st) return st;
+    if (bytes == 0) return MKAMD_OK;
+    if (!device_dst || !device_src) return fail(MKAMD_EINVAL, "NULL pointer");
+    HIP_TRY(hipMemcpyAsync(device_dst, device_src, (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MKAMD_OK;
+} MK_API_CATCH
+
 extern "C" int mkamd_prefault(void* buffer, uint64_t bytes)
 try {
     if (!buffer) return MKAMD_OK;

@@ -1023,16 +1023,30 @@ MK_KERNEL(NW * WAVE) void k_dist_reduction_closest(const float* __restrict__ coo
                             }
                             ++j;
                         }
-                        for (; j + 2 <= j1; j += 2) {                // two second atoms: six loads in flight
+                        // two second atoms per step, the NEXT step's six loads issued before this step's arithmetic (round 6, PMC: with
+                        // the loads waited for where they were issued a third of the wave cycles were spent in s_waitcnt, 82 % VALU-busy)
+                        // (the two atoms' coordinates side by side in register PAIRS, X = {x of the first, x of the second}: a packed
+                        //  instruction broadcasts either half; with six single registers the compiler paired a current value with a
+                        //  NEXT one and every use of the pair waited for the next step's load)
+                        mk_f2 X = mk_f2_splat(0.f), Y = X, Z = X;
+                        if (j + 2 <= j1) {
                             const unsigned c0 = (unsigned)g2_atoms[j], c1 = (unsigned)g2_atoms[j + 1];
-                            const float x2 = at(c0, 0), y2 = at(c0, 1), z2 = at(c0, 2), x3 = at(c1, 0), y3 = at(c1, 1), z3 = at(c1, 2);
+                            X = mk_f2{at(c0, 0), at(c1, 0)}; Y = mk_f2{at(c0, 1), at(c1, 1)}; Z = mk_f2{at(c0, 2), at(c1, 2)};
+                        }
+                        for (; j + 2 <= j1; j += 2) {
+                            mk_keep(X); mk_keep(Y); mk_keep(Z);      // (pairs of the SAME step, complete here: see above)
+                            // (past the end: the last two atoms once more -- valid addresses, the values are not used)
+                            const long long jn = j + 4 <= j1 ? j + 2 : j;
+                            const unsigned n0 = (unsigned)g2_atoms[jn], n1 = (unsigned)g2_atoms[jn + 1];
+                            const mk_f2 nX = mk_f2{at(n0, 0), at(n1, 0)}, nY = mk_f2{at(n0, 1), at(n1, 1)}, nZ = mk_f2{at(n0, 2), at(n1, 2)};
 #pragma unroll
                             for (int u = 0; u < H; ++u) {
-                                const mk_f2 d2 = dist2_pk<WR>(ax[u], ay[u], az[u], x2, y2, z2, bx, by, bz, ibx, iby, ibz, risk);
-                                const mk_f2 e2 = dist2_pk<WR>(ax[u], ay[u], az[u], x3, y3, z3, bx, by, bz, ibx, iby, ibz, risk);
+                                const mk_f2 d2 = dist2_pk<WR>(ax[u], ay[u], az[u], X[0], Y[0], Z[0], bx, by, bz, ibx, iby, ibz, risk);
+                                const mk_f2 e2 = dist2_pk<WR>(ax[u], ay[u], az[u], X[1], Y[1], Z[1], bx, by, bz, ibx, iby, ibz, risk);
                                 m[u] = mk_min3_raw(m[u], d2[0], d2[1]);
                                 m[u] = mk_min3_raw(m[u], e2[0], e2[1]);
                             }
+                            X = nX; Y = nY; Z = nZ;
                         }
                         if (j < j1) {
                             const unsigned c = (unsigned)g2_atoms[j];

@@ -73,6 +73,9 @@ MK_DEV unsigned mk_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readf
 // identical to the scalar ops)
 typedef float mk_f2 __attribute__((ext_vector_type(2)));
 MK_DEV mk_f2 mk_f2_splat(float v) { return mk_f2{v, v}; }
+// the two components sit in ONE aligned register pair from here on (the register allocator otherwise splits a pair whose halves it
+// can track separately and re-pairs the halves as it likes -- e.g. a value in use with one that is still being loaded)
+MK_DEV void mk_keep(mk_f2& x) { asm("" : "+v"(x)); }
 MK_DEV mk_f2 mk_f2_fma(mk_f2 a, mk_f2 b, mk_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // packed arithmetic with the reference's roundings: a multiply and an add / subtract per component, each rounded on its own --
 // never contracted into an fma (v_pk_mul_f32 / v_pk_add_f32: two float32 operations per lane and instruction)

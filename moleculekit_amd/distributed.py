@@ -444,3 +444,210 @@ def voxelize_sharded(coords, atom_offsets, sigmas, origins, nvoxels, voxelsize, 
     if nchunks > 0:
         return sv.voxelize_gather(nchunks=nchunks, dst=dst), sv.bounds
     return sv.gather(sv.voxelize(), dst=dst), sv.bounds
+
+
+# ------------------------------------------------------------------------------------------------
+# Frames-sharded distances ("frames shard across GPUs exactly like cfg4").  The reference's frame
+# loop is the OUTER loop of every distance_utils function (distance_utils.pyx:149, :244, :316, :76): frames are
+# independent, selections / groups are the same for all of them.  So: contiguous frame ranges per rank, the selections
+# replicated (a few kilobytes), the trajectory shard resident in HBM in the reference's [N, 3, F_rank] layout, results left
+# sharded [F_rank, n_pairs] -- no collective on the compute path -- with the same optional gathers as the voxel path.
+# ------------------------------------------------------------------------------------------------
+def shard_frames(coords, box, lo, hi):
+    """Frames [lo, hi) of a trajectory in the reference's layout: coords [N, 3, F] -> C-contiguous [N, 3, hi - lo], box [3, F] ->
+    [3, hi - lo] (frames are the fastest axis, so a frame range is a strided view: this makes the copy a rank uploads)."""
+    c = np.ascontiguousarray(np.asarray(coords)[:, :, lo:hi], dtype=np.float32)
+    b = None if box is None else np.ascontiguousarray(np.asarray(box)[:, lo:hi], dtype=np.float32)
+    return c, b
+
+
+class ShardedDistances:
+    """This rank's frames of a trajectory, resident on its device, and the distance_utils functions over them.
+
+    ``from_host(coords [N,3,F], box [3,F])`` (every rank passes the same arrays; only this rank's frames are copied) or
+    ``from_loader(n_frames, loader)`` with ``loader(lo, hi) -> (coords [N,3,hi-lo], box [3,hi-lo] | None)`` (no rank holds the
+    whole trajectory: e.g. a rank decodes its own frames of an XTC file).  ``weights`` (per frame) balance ragged costs.
+    Every method returns this rank's rows ``[F_rank, n_pairs]`` as a float32 tensor on its device, asynchronously, with NO
+    collective; ``gather(local)`` / ``gather(local, dst=0)`` collect the rows of all ranks in frame order (one padded RCCL
+    all-gather / gather-to-root over xGMI, as for the features).  The kernels are those of ``moleculekit_amd.distance_utils``
+    (same bits).  ``compute(kind, coords, box, *args) -> ndarray``: CPU test-suite only (the sharding / gather logic under
+    ``gloo``); the product never injects it.
+    """
+
+    def __init__(self, n_frames, bounds, shard, device=None, compute=None, group=None, ctx=None):
+        import torch
+
+        self.group = group
+        self.rank, self.world = world(group)
+        self.n_frames = int(n_frames)
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.n_frames:
+            raise ValueError("bounds must partition range(n_frames) over the ranks")
+        self.lo, self.hi = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        coords, box = shard
+        coords = np.asarray(coords)
+        if coords.ndim != 3 or coords.shape[1] != 3 or coords.shape[2] != self.hi - self.lo:
+            raise ValueError(f"this rank's shard must be coords [N, 3, {self.hi - self.lo}], got {coords.shape}")
+        self.n_atoms, self.n_local = int(coords.shape[0]), int(coords.shape[2])
+        if box is None:                                              # (what the reference's drivers pass for periodic=None)
+            box = np.zeros((3, self.n_local), dtype=np.float32)
+        if np.asarray(box).shape != (3, self.n_local):
+            raise ValueError(f"box must be [3, {self.n_local}] for this rank's frames")
+        self._compute = compute
+        self._ctx = ctx
+        if compute is None:
+            if device is None:
+                device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", self.rank)) % max(torch.cuda.device_count(), 1))
+            self.device = torch.device(device)
+            if self.device.type != "cuda":
+                raise RuntimeError("ShardedDistances needs a HIP device (there is no CPU path); tests inject `compute`")
+            # pinned staging -> one H2D copy per array (the trajectory shard is the only big thing a rank ever uploads)
+            self._coords = self._to_device(np.ascontiguousarray(coords, dtype=np.float32))
+            self._box = self._to_device(np.ascontiguousarray(box, dtype=np.float32))
+        else:
+            self.device = torch.device("cpu" if device is None else device)
+            self._coords = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.float32))
+            self._box = torch.from_numpy(np.ascontiguousarray(box, dtype=np.float32))
+        self._cache = {}
+
+    # ---- construction -------------------------------------------------------------------------------------
+    @classmethod
+    def from_host(cls, coords, box=None, weights=None, **kw):
+        rank, ws = world(kw.get("group"))
+        F = int(np.asarray(coords).shape[2])
+        bounds = shard_bounds(F, ws, weights)
+        return cls(F, bounds, shard_frames(coords, box, int(bounds[rank]), int(bounds[rank + 1])), **kw)
+
+    @classmethod
+    def from_loader(cls, n_frames, loader, weights=None, **kw):
+        rank, ws = world(kw.get("group"))
+        bounds = shard_bounds(int(n_frames), ws, weights)
+        return cls(n_frames, bounds, tuple(loader(int(bounds[rank]), int(bounds[rank + 1]))), **kw)
+
+    def _to_device(self, a):
+        import torch
+        pinned = torch.empty(a.shape, dtype=getattr(torch, a.dtype.name), pin_memory=True)
+        np.copyto(pinned.numpy(), a)
+        t = pinned.to(self.device, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()          # (set-up: the staging buffer is released here)
+        return t
+
+    def _dev(self, key, a, dtype):
+        """Replicated small inputs (selections, groups, chain ids, masses): uploaded once per distinct array."""
+        import torch
+        a = np.ascontiguousarray(a, dtype=dtype)
+        k = (key, a.shape, a.tobytes() if a.nbytes <= 1 << 16 else hash(a.tobytes()))
+        t = self._cache.get(k)
+        if t is None:
+            # (uint32 has no torch dtype everywhere: the bit patterns travel as int32 / int64)
+            view = a.view(np.int32) if a.dtype == np.uint32 else a
+            t = torch.as_tensor(view, device=self.device)
+            if len(self._cache) > 64:
+                self._cache.clear()
+            self._cache[k] = t
+        return t
+
+    def _context(self):
+        from . import _lib
+        ctx = self._ctx or _lib.default_context(self.device.index if self.device.index is not None else 0)
+        return ctx
+
+    # ---- the distance_utils functions over this rank's frames ---------------------------------------------------------
+    def dist_trajectory(self, sel1, sel2, digitized_chains, selfdist, pbc, out=None, squared=False):
+        """distance_utils.pyx:126-155 over frames [lo, hi): float32 [F_rank, n_pairs]."""
+        import torch
+        sel1, sel2 = np.ascontiguousarray(sel1, np.uint32), np.ascontiguousarray(sel2, np.uint32)
+        chains = np.ascontiguousarray(digitized_chains, np.uint32)
+        n1, n2 = len(sel1), len(sel2)
+        P = n1 * n2 if not selfdist else sum(max(n2 - 1 - i, 0) for i in range(n1))
+        if self._compute is not None:
+            res = torch.from_numpy(np.asarray(self._compute("dist_trajectory", self._coords.numpy(), self._box.numpy(), sel1, sel2, chains,
+                                                           bool(selfdist), bool(pbc)), dtype=np.float32).reshape(self.n_local, P))
+            return res if out is None else out.copy_(res)
+        for name, s in (("sel1", sel1), ("sel2", sel2)):
+            if len(s) and int(s.max()) >= self.n_atoms:
+                raise ValueError(f"{name} index out of range")
+        if len(chains) < self.n_atoms:
+            raise ValueError(f"digitized_chains has {len(chains)} entries for {self.n_atoms} atoms")
+        if out is None:
+            out = torch.empty((self.n_local, P), dtype=torch.float32, device=self.device)
+        if self.n_local and P:
+            ctx = self._context()
+            ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            try:
+                ctx.dist_trajectory_dev(self._coords, self.n_local, self._box, self._dev("s1", sel1, np.uint32), n1, self._dev("s2", sel2, np.uint32), n2,
+                                        self._dev("ch", chains, np.uint32), bool(selfdist), bool(pbc), bool(squared), out)
+            finally:
+                ctx.set_stream(None)
+        return out
+
+    def dist_trajectory_reduction(self, groups1, groups2, digitized_chains1, digitized_chains2, selfdist, pbc, masses, reduction1, reduction2,
+                                  pairs=False, out=None):
+        """distance_utils.pyx:211-350 (``pairs``: the ``_pairs`` form) over frames [lo, hi): float32 [F_rank, n_group_pairs]."""
+        import torch
+        from .distance_utils import _csr
+        a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)
+        ng1, ng2 = len(groups1), len(groups2)
+        if pairs and ng1 != ng2:
+            raise ValueError("pairs mode needs the same number of groups on both sides")
+        P = ng1 if pairs else (ng1 * ng2 if not selfdist else sum(max(ng2 - 1 - i, 0) for i in range(ng1)))
+        ch1, ch2 = np.ascontiguousarray(digitized_chains1, np.uint32), np.ascontiguousarray(digitized_chains2, np.uint32)
+        masses = np.ascontiguousarray(masses, np.float32)
+        if self._compute is not None:
+            res = torch.from_numpy(np.asarray(self._compute("dist_trajectory_reduction", self._coords.numpy(), self._box.numpy(), groups1, groups2, ch1, ch2,
+                                                           bool(selfdist), bool(pbc), masses, int(reduction1), int(reduction2), bool(pairs)),
+                                              dtype=np.float32).reshape(self.n_local, P))
+            return res if out is None else out.copy_(res)
+        if (a1.size and (a1.min() < 0 or a1.max() >= self.n_atoms)) or (a2.size and (a2.min() < 0 or a2.max() >= self.n_atoms)):
+            raise ValueError("group atom index out of range")
+        if min((len(g) for g in groups1), default=1) == 0 or min((len(g) for g in groups2), default=1) == 0:
+            raise ValueError("empty group")
+        if len(ch1) < ng1 or len(ch2) < ng2 or len(masses) < self.n_atoms:
+            raise ValueError("digitized_chains1/2 need one entry per group, masses one per atom")
+        if out is None:
+            out = torch.empty((self.n_local, P), dtype=torch.float32, device=self.device)
+        if self.n_local and P:
+            ctx = self._context()
+            ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+            try:
+                ctx.dist_reduction_dev(self._coords, self.n_atoms, self.n_local, self._box, self._dev("a1", a1, np.int32), self._dev("o1", o1, np.int64), ng1,
+                                       len(a1), self._dev("a2", a2, np.int32), self._dev("o2", o2, np.int64), ng2, self._dev("c1", ch1, np.uint32),
+                                       self._dev("c2", ch2, np.uint32), bool(selfdist), bool(pairs), bool(pbc), self._dev("m", masses, np.float32),
+                                       int(reduction1), int(reduction2), out)
+            finally:
+                ctx.set_stream(None)
+        return out
+
+    def contacts_trajectory(self, sel1, sel2, digitized_chains, selfdist, pbc, dist_threshold=5):
+        """distance_utils.pyx:59-93 over frames [lo, hi): ``(frame_offsets int64 [F_rank + 1] (host), pairs uint32 [n, 2] tensor on the
+        device)`` -- frame f of this rank owns rows ``frame_offsets[f] : frame_offsets[f + 1]``; thresholded and compacted on the GPU."""
+        import torch
+        sel1, sel2 = np.ascontiguousarray(sel1, np.uint32), np.ascontiguousarray(sel2, np.uint32)
+        chains = np.ascontiguousarray(digitized_chains, np.uint32)
+        if self._compute is not None:
+            offs, pairs = self._compute("contacts_trajectory", self._coords.numpy(), self._box.numpy(), sel1, sel2, chains, bool(selfdist), bool(pbc),
+                                        float(dist_threshold))
+            return np.asarray(offs, np.int64), torch.from_numpy(np.asarray(pairs, np.int64).reshape(-1, 2))
+        if not self.n_local:
+            return np.zeros(1, np.int64), torch.zeros((0, 2), dtype=torch.int64, device=self.device)
+        ctx = self._context()
+        ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        try:
+            offs, ptr, n = ctx.contacts_trajectory_dev(self._coords, self.n_local, self._box, self._dev("s1", sel1, np.uint32), len(sel1),
+                                                       self._dev("s2", sel2, np.uint32), len(sel2), self._dev("ch", chains, np.uint32),
+                                                       bool(selfdist), bool(pbc), float(dist_threshold))
+            pairs = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+            if n:                                   # the list is context-owned until the next contacts call: a device-to-device copy keeps it
+                from . import _lib
+                _lib._check(_lib.load().mkamd_copy_dev(ctx._h, pairs.data_ptr(), ptr, n * 8))
+        finally:
+            ctx.set_stream(None)
+        return offs, pairs
+
+    # ---- the optional collectives (after the compute) ----------------------------------------------------------------
+    def _collectives(self):
+        return ShardedVoxelizer._collectives(self)
+
+    def gather(self, local, dst=None):
+        """Rows of every rank in frame order: [F, n_pairs] on every rank (``dst=None``: one padded all-gather) or on ``dst`` only."""
+        return gather_features(local, self.bounds, group=self.group, dst=dst) if self._collectives() else local

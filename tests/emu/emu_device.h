@@ -223,6 +223,7 @@ MK_DEV void mk_sleep() {}
 MK_DEV unsigned mk_uniform(unsigned v) { return v; }
 typedef float mk_f2 __attribute__((vector_size(8)));
 MK_DEV mk_f2 mk_f2_splat(float v) { return mk_f2{v, v}; }
+MK_DEV void mk_keep(mk_f2&) {}
 MK_DEV mk_f2 mk_f2_fma(mk_f2 a, mk_f2 b, mk_f2 c) { return mk_f2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
 MK_DEV mk_f2 mk_f2_mul_rn(mk_f2 a, mk_f2 b) { volatile float x = a[0] * b[0], y = a[1] * b[1]; return mk_f2{x, y}; }
 MK_DEV mk_f2 mk_f2_add_rn(mk_f2 a, mk_f2 b) { volatile float x = a[0] + b[0], y = a[1] + b[1]; return mk_f2{x, y}; }

@@ -110,3 +110,18 @@ def test_rank_0_prints_its_line_when_another_rank_dies():
     assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
     d = lines[0]
     assert d["ok"] is False and d["n_gpus"] == 2 and d["ranks_alive"] == 1 and d["degraded"]
+
+
+def test_bench_dist_workload_shards_frames_over_the_ranks_dry_run():
+    """`python bench.py --workload dist --gpus N --dry-run`: N ranks, each with its own frames of the
+    trajectory in a moleculekit_amd.distributed.ShardedDistances, the timed loop without a collective, rows left sharded, then
+    both gathers checked row by row (a stand-in compute whose rows are a function of the frame alone)."""
+    for n in (2, 8):
+        r = _run("--workload", "dist", "--gpus", str(n), "--dry-run", "--batch", "3", timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1 and r.stdout.strip() == lines[0].strip(), r.stdout[:400]
+        d = json.loads(lines[0])
+        assert d["dry_run"] is True and d["n_gpus"] == n and d["ranks_alive"] == n and d["scaling"] == "weak"
+        assert d["ok"] is True and d["gather_ok"] is True and d["gather_ms"] is not None and d["value"] > 0
+        assert "frames per rank" in d["config"]["workload"] and "no collective" in d["config"]["sharding"]

@@ -187,3 +187,132 @@ def test_sharded_voxelization_world8_gloo():
     assert all(ok for _, ok, _ in res), res
     for b in res[0][2]:
         assert b[0] == 0 and len(b) == world + 1
+
+
+# ------------------------------------------------------------------------------------------------
+# frames-sharded distances (moleculekit_amd.distributed.ShardedDistances): the oracle stands in for the
+# kernels, what is under test is the frame partition (ragged, empty shards), the replicated selections, results left sharded
+# [F_rank, n_pairs] and the two gathers.
+# ------------------------------------------------------------------------------------------------
+def _dist_compute(kind, coords, box, *a):
+    from oracle import oracle
+    if kind == "dist_trajectory":
+        sel1, sel2, chains, selfdist, pbc = a
+        return oracle.dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc)
+    if kind == "dist_trajectory_reduction":
+        g1, g2, c1, c2, selfdist, pbc, masses, r1, r2, pairs = a
+        return oracle.dist_trajectory_reduction(coords, box, g1, g2, c1, c2, selfdist, pbc, masses, r1, r2, pairs=pairs)
+    sel1, sel2, chains, selfdist, pbc, thr = a
+    d2 = oracle.dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=True)
+    ii, jj = (np.triu_indices(len(sel1), 1) if selfdist else [x.ravel() for x in np.indices((len(sel1), len(sel2)))])
+    offs, rows = [0], []
+    for f in range(d2.shape[0]):
+        hit = np.nonzero(d2[f] <= np.float32(thr) * np.float32(thr))[0]
+        rows.append(np.stack([sel1[ii[hit]], sel2[jj[hit]]], 1).astype(np.int64))
+        offs.append(offs[-1] + len(hit))
+    return np.asarray(offs, np.int64), (np.concatenate(rows) if rows else np.zeros((0, 2), np.int64))
+
+
+def _worker_dist(rank, world, port, F, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from moleculekit_amd import distributed as D
+    from oracle import oracle
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(31)
+        N = 40
+        coords = rng.uniform(-20, 20, size=(N, 3, F)).astype(np.float32)
+        box = rng.uniform(25, 33, size=(3, F)).astype(np.float32)
+        chains = rng.integers(0, 3, N).astype(np.uint32)
+        masses = rng.uniform(1, 16, N).astype(np.float32)
+        sel1 = np.sort(rng.choice(N, 7, replace=False)).astype(np.uint32)
+        sel2 = np.sort(rng.choice(N, 9, replace=False)).astype(np.uint32)
+        g1 = [rng.choice(N, int(rng.integers(1, 6)), replace=False).tolist() for _ in range(5)]
+        g2 = [rng.choice(N, int(rng.integers(1, 6)), replace=False).tolist() for _ in range(4)]
+        ch1, ch2 = rng.integers(0, 2, 5).astype(np.uint32), rng.integers(0, 2, 4).astype(np.uint32)
+        seen = []
+
+        def loader(lo, hi):                                    # a rank that only ever sees its own frames
+            seen.append((lo, hi))
+            return D.shard_frames(coords, box, lo, hi)
+
+        ok = True
+        for sd in (D.ShardedDistances.from_host(coords, box, compute=_dist_compute),
+                   D.ShardedDistances.from_loader(F, loader, compute=_dist_compute)):
+            lo, hi = sd.lo, sd.hi
+            ok = ok and (lo, hi) == (int(sd.bounds[rank]), int(sd.bounds[rank + 1])) and sd.n_local == hi - lo
+            # dist_trajectory: rows of this rank, then both gathers in frame order
+            want = oracle.dist_trajectory(coords, box, sel1, sel2, chains, False, True)
+            local = sd.dist_trajectory(sel1, sel2, chains, False, True)
+            ok = ok and tuple(local.shape) == (hi - lo, want.shape[1]) and np.array_equal(local.numpy(), want[lo:hi])
+            ok = ok and np.array_equal(sd.gather(local).numpy(), want)
+            root = sd.gather(local, dst=0)
+            ok = ok and ((root is None) if rank else np.array_equal(root.numpy(), want))
+            want = oracle.dist_trajectory(coords, box, sel2, sel2, chains, True, False)
+            ok = ok and np.array_equal(sd.gather(sd.dist_trajectory(sel2, sel2, chains, True, False)).numpy(), want)
+            # group reductions (closest and centre of mass, all-vs-all and pairs)
+            want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, 0, 0)
+            ok = ok and np.array_equal(sd.gather(sd.dist_trajectory_reduction(g1, g2, ch1, ch2, False, True, masses, 0, 0)).numpy(), want)
+            want = oracle.dist_trajectory_reduction(coords, box, g1[:4], g2, ch1[:4], ch2, False, True, masses, 1, 0, pairs=True)
+            ok = ok and np.array_equal(sd.gather(sd.dist_trajectory_reduction(g1[:4], g2, ch1[:4], ch2, False, True, masses, 1, 0, pairs=True)).numpy(), want)
+            # contact lists: per-rank offsets and rows; stitched together over the ranks they are the whole trajectory's lists
+            offs, pairs = sd.contacts_trajectory(sel1, sel2, chains, False, True, 14.0)
+            woffs, wpairs = _dist_compute("contacts_trajectory", coords, box, sel1, sel2, chains, False, True, 14.0)
+            ok = ok and len(offs) == hi - lo + 1 and np.array_equal(np.diff(offs), np.diff(woffs[lo:hi + 1]))
+            ok = ok and np.array_equal(pairs.numpy(), wpairs[woffs[lo]:woffs[hi]])
+        ok = ok and seen == [(int(sd.bounds[rank]), int(sd.bounds[rank + 1]))]
+        # per-frame weights balance a ragged cost (e.g. frames of different system sizes do not exist here; the partition follows them anyway)
+        w = np.ones(F); w[: F // 2] = 3.0
+        sdw = D.ShardedDistances.from_host(coords, box, weights=w, compute=_dist_compute)
+        want = oracle.dist_trajectory(coords, box, sel1, sel2, chains, False, False)
+        ok = ok and np.array_equal(sdw.gather(sdw.dist_trajectory(sel1, sel2, chains, False, False)).numpy(), want)
+        q.put((rank, bool(ok), [int(b) for b in sd.bounds]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world_dist(world, F):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dist, args=(r, world, port, F, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    b = res[0][2]
+    assert b[0] == 0 and b[-1] == F and len(b) == world + 1
+
+
+@pytest.mark.parametrize("F", [9, 2, 1])
+def test_sharded_distances_world2_gloo(F):
+    """Frames-sharded distance_utils under gloo, two ranks: 9 frames (5 + 4), 2 (1 + 1), 1 (an empty shard)."""
+    _run_world_dist(2, F)
+
+
+def test_sharded_distances_world8_gloo():
+    """Eight ranks, 19 frames (shards of 2-3 frames) -- the 8-GPU node's shape -- and the padded collectives over ragged shards."""
+    _run_world_dist(8, 19)
+
+
+def test_sharded_distances_single_process_without_a_group():
+    """No process group: everything is local, gather() is the identity."""
+    from moleculekit_amd import distributed as D
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    coords = rng.uniform(-10, 10, size=(12, 3, 5)).astype(np.float32)
+    sd = D.ShardedDistances.from_host(coords, None, compute=_dist_compute)
+    sel = np.arange(4, dtype=np.uint32)
+    got = sd.dist_trajectory(sel, sel + 4, np.zeros(12, np.uint32), False, False)
+    assert np.array_equal(sd.gather(got).numpy(), oracle.dist_trajectory(coords, np.zeros((3, 5), np.float32), sel, sel + 4, np.zeros(12, np.uint32), False, False))
+    with pytest.raises(ValueError):
+        D.ShardedDistances(5, [0, 4], (coords, None), compute=_dist_compute)
