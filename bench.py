@@ -1581,6 +1581,16 @@ def main():
                          "ms_per_step": round(r2["elapsed"] / steps2 * 1e3, 4), "grid": [int(v) for v in r2["nv"]],
                          **({"topology_reuse": "frames of one molecule: sigma classes / class ids built once (mkamd_topology), not per call"} if r2.get("topology") else {}),
                          "roofline": roofline_of(r2, nm, DEFAULT_BATCH[nm], args.tile_k)}
+            if r2.get("topology"):
+                # ... and the same leg WITHOUT the handle (the plain call, class discovery inside the timed region: what rounds 1-4 timed),
+                # so that the two are never mistaken for each other
+                try:
+                    plain_args = argparse.Namespace(**{**vars(args), "no_topology": True})
+                    r2p = run_workload(nm, DEFAULT_BATCH[nm], steps2, max(2, args.warmup), ctx, dev, rank, world, plain_args, fence)
+                    extra[nm]["plain_call"] = {"ms_per_step": round(r2p["elapsed"] / steps2 * 1e3, 4),
+                                               "value": round(world * DEFAULT_BATCH[nm] * r2p["V"] * r2p["C"] * steps2 / r2p["elapsed"] / 1e6, 2)}
+                except Exception as e:             # noqa: BLE001
+                    extra[nm]["plain_call"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     if not args.no_extra and args.workload == "cfg2" and not args.batch and world == 1 and args.value_tol == 0.0:
         # the opt-in tolerance-aware reach (mkamd_ctx_set_value_tolerance, eps = 1e-6) on the headline workload: atoms

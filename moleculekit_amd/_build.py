@@ -8,6 +8,7 @@ import time
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libmkamd.so")
+HOST_LIB = os.path.join(CSRC, "libmkamd_host.so")          # the host entry point alone, plain C++ (no ROCm): build_host()
 SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "mk_diagnostics.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h", "xtc_gpu.h", "cpu_occupancy.h"]
 HEADER = os.path.join(_HERE, "..", "include", "mkamd_voxel.h")
 HEADER2 = os.path.join(_HERE, "..", "include", "mkamd_distance.h")
@@ -73,5 +74,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """libmkamd_host.so: mkamd_calculate_occupancy_cpu[_threads] by the plain C++ compiler ($CXX, g++, c++ or clang++ -- no hipcc,
+    nothing of ROCm linked), with -ffp-contract=off: what `occupancy_utils.calculate_occupancy_cpu` / method="CPU" load."""
+    import shutil
+    deps = [os.path.join(CSRC, "host_capi.cpp"), os.path.join(CSRC, "cpu_occupancy.h")]
+    stale = (not os.path.exists(HOST_LIB)) or any(os.path.getmtime(d) > os.path.getmtime(HOST_LIB) for d in deps)
+    if force or stale:
+        cxx = next((c for c in (os.environ.get("CXX"), "g++", "c++", "clang++") if c and shutil.which(c)), None)
+        if cxx is None:
+            raise RuntimeError("moleculekit_amd: no C++ compiler found for libmkamd_host.so (set CXX)")
+        tmp = "%s.%d.tmp" % (HOST_LIB, os.getpid())
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wall", deps[0], "-o", tmp]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, HOST_LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return HOST_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

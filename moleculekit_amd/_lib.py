@@ -141,6 +141,25 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+_host_lib = None
+
+
+def load_host() -> ctypes.CDLL:
+    """libmkamd_host.so: the HOST implementation of calculate_occupancy alone (csrc/host_capi.cpp), built on first use by the plain
+    C++ compiler -- no hipcc, no HIP runtime: what a machine without ROCm can still load."""
+    global _host_lib
+    with _lock:
+        if _host_lib is None:
+            from . import _build
+            L = ctypes.CDLL(_build.build_host())
+            for name in ("mkamd_calculate_occupancy_cpu", "mkamd_calculate_occupancy_cpu_threads"):
+                fn = getattr(L, name)
+                fn.restype, fn.argtypes = SIGNATURES[name]
+            L.mkamd_host_last_error.restype = ctypes.c_char_p
+            _host_lib = L
+        return _host_lib
+
+
 def version() -> str:
     """``mkamd_version()`` of the loaded library: name, version, and the hash of the sources it was built from."""
     return load().mkamd_version().decode()

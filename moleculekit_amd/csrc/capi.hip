@@ -625,6 +625,36 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+// Every distance kernel takes its roots with mk_fsqrt_rn_ordinary, whose correct rounding is a PROPERTY OF THIS CHIP's v_rsq_f32 (checked
+// exhaustively, not proved: mk_device.h).  So the exhaustive comparison runs once per process and device, in front of the first
+// distance call (a few milliseconds), and a device -- another stepping, firmware or compiler lowering of the reciprocal square root --
+// on which it finds a mismatch gets no distances at all rather than wrong last bits.  -1 unknown, 1 good, 0 bad.
+static std::atomic<int> g_sqrt_verdict[64];
+static struct SqrtVerdictInit { SqrtVerdictInit() { for (auto& v : g_sqrt_verdict) v.store(-1); } } g_sqrt_verdict_init;
+
+static int dist_entry(mkamd_ctx* ctx)
+{
+    int st = check_ctx(ctx);
+    if (st) return st;
+    const int d = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    int v = g_sqrt_verdict[d].load();
+    if (v < 0) {
+        uint64_t bad = 0;
+        uint32_t first = 0;
+        if ((st = mkamd_selftest_sqrt(ctx, &bad, &first))) return st;
+        v = bad == 0 ? 1 : 0;
+        g_sqrt_verdict[d].store(v);
+        if (!v) {
+            char msg[200];
+            snprintf(msg, sizeof msg, "float32 square-root self-test failed on this device (%llu mismatches, first at bits 0x%08x): "
+                     "the distance kernels would not be bit-exact here", (unsigned long long)bad, first);
+            return fail(MKAMD_EHIP, msg);
+        }
+    }
+    if (!v) return fail(MKAMD_EHIP, "float32 square-root self-test failed on this device: the distance kernels would not be bit-exact here");
+    return MKAMD_OK;
+}
+
 int mkamd_clock_probe_dev(mkamd_ctx* ctx, void* hip_stream, int64_t microseconds, uint64_t* d_ticks2)
 try {
     if (!ctx || !d_ticks2) return fail(MKAMD_EINVAL, "ctx / result pointer is NULL");
@@ -881,7 +911,8 @@ try {
     const int G = ceil_div(C, CHG);
     const size_t a256 = 255, sig_bytes = (size_t)n_atoms * C * (sigmas_are_f64 ? 8 : 4);
     const size_t o_cw = (sig_bytes + a256) & ~a256, o_ids = (o_cw + (size_t)n_atoms * G * sizeof(uint2) + a256) & ~a256,
-                 o_tab = (o_ids + (size_t)n_atoms * G * sizeof(unsigned) + a256) & ~a256, o_flags = o_tab + 256, total = o_flags + 256;
+                 o_tab = (o_ids + (size_t)n_atoms * G * sizeof(unsigned) + a256) & ~a256, o_flags = o_tab + 256, o_wide = o_flags + 256,
+                 total = o_wide + (size_t)n_atoms * sizeof(unsigned);
     mkamd_topology* t = new mkamd_topology();
     t->device = ctx->device;
     hipError_t e = hipMalloc(&t->mem, total);
@@ -892,18 +923,30 @@ try {
     if ((e = hipMemsetAsync(m + o_flags, 0, 256, ctx->stream)) != hipSuccess) return drop(hip_fail(e, "hipMemsetAsync(topology flags)"));
     std::string err;
     st = run_topology_build(*ctx, m, sigmas_are_f64, (long long)n_atoms, C, voxelsize, (uint2*)(m + o_cw), (unsigned*)(m + o_ids),
-                            (unsigned*)(m + o_tab), (int*)(m + o_flags), err);
+                            (unsigned*)(m + o_tab), (int*)(m + o_flags), (unsigned*)(m + o_wide), err);
     if (st) return drop(err.empty() ? st : fail(st, err));
     unsigned table[CLS_TABLE_WORDS];
-    int flags = 0;
+    int flags2[2] = {0, 0};
     if ((e = hipMemcpyAsync(table, m + o_tab, sizeof table, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
-        (e = hipMemcpyAsync(&flags, m + o_flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+        (e = hipMemcpyAsync(flags2, m + o_flags, sizeof flags2, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return drop(hip_fail(e, "topology read-back"));
+    const int flags = flags2[0];
+    const unsigned n_wide = (unsigned)flags2[1];
+    if (n_wide > 1u) {
+        // the list arrives in the order the lanes' atomics did: sorted here, once, so that a handle is the same whenever it is built
+        std::vector<unsigned> wl(n_wide);
+        if ((e = hipMemcpyAsync(wl.data(), m + o_wide, (size_t)n_wide * 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return drop(hip_fail(e, "topology read-back (wide atoms)"));
+        std::sort(wl.begin(), wl.end());
+        if ((e = hipMemcpyAsync(m + o_wide, wl.data(), (size_t)n_wide * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return drop(hip_fail(e, "topology write-back (wide atoms)"));
+    }
     if (table[CLS_OVERFLOW] != CLS_EMPTY)
         return drop(fail(MKAMD_EINVAL, "more than 15 distinct sigma values: no class ids to reuse (use the plain entry point)"));
     t->dev.n = (long long)n_atoms; t->dev.C = C; t->dev.G = G; t->dev.sigmas_f64 = sigmas_are_f64; t->dev.voxelsize = voxelsize;
     t->dev.sigmas = m; t->dev.cw = (const uint2*)(m + o_cw); t->dev.ids = (const unsigned*)(m + o_ids); t->dev.table = (const unsigned*)(m + o_tab);
     t->dev.overflow = false; t->dev.wide = (flags & 1) != 0;
+    t->dev.wide_list = (const unsigned*)(m + o_wide); t->dev.n_wide = n_wide;
     *out = t;
     return MKAMD_OK;
 } MK_API_CATCH
@@ -1360,7 +1403,7 @@ int mkamd_dist_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t F, 
                               const uint32_t* d_sel1, int64_t n1, const uint32_t* d_sel2, int64_t n2,
                               const uint32_t* d_chains, int selfdist, int pbc, int squared, float* d_results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     std::string err;
     st = run_dist_trajectory(*ctx, d_coords, F, d_box, d_sel1, n1, d_sel2, n2, d_chains, selfdist, pbc, squared, d_results, err, ctx->dist_avoid);
@@ -1372,7 +1415,7 @@ int mkamd_dist_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t N, i
                                const uint32_t* sel1, int64_t n1, const uint32_t* sel2, int64_t n2,
                                const uint32_t* chains, int selfdist, int pbc, int squared, float* results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (N < 0 || F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
     const int64_t P = count_pairs(n1, n2, selfdist);
@@ -1402,7 +1445,7 @@ int mkamd_contacts_trajectory_host(mkamd_ctx* ctx, const float* coords, int64_t 
                                    const uint32_t* chains, int selfdist, int pbc, float dist_threshold,
                                    int64_t* frame_offsets, const uint32_t** pairs)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (N < 0 || F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
     if (!frame_offsets || !pairs) return fail(MKAMD_EINVAL, "frame_offsets/pairs pointer is NULL");
@@ -1437,7 +1480,7 @@ int mkamd_dist_reduction_host(mkamd_ctx* ctx, const float* coords, int64_t N, in
                               int selfdist, int pairs, int pbc, const float* masses, int reduction1, int reduction2,
                               float* results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (N < 0 || F < 0 || ng1 < 0 || ng2 < 0) return fail(MKAMD_EINVAL, "negative size");
     if (pairs && ng1 != ng2) return fail(MKAMD_EINVAL, "pairs mode needs the same number of groups on both sides");
@@ -1477,7 +1520,7 @@ int mkamd_contacts_trajectory_dev(mkamd_ctx* ctx, const float* d_coords, int64_t
                                   int64_t n1, const uint32_t* d_sel2, int64_t n2, const uint32_t* d_chains, int selfdist, int pbc,
                                   float dist_threshold, int64_t* frame_offsets, const uint32_t** d_pairs)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (F < 0 || n1 < 0 || n2 < 0) return fail(MKAMD_EINVAL, "negative size");
     if (!frame_offsets || !d_pairs) return fail(MKAMD_EINVAL, "frame_offsets/d_pairs pointer is NULL");
@@ -1500,7 +1543,7 @@ int mkamd_dist_reduction_dev(mkamd_ctx* ctx, const float* d_coords, int64_t N, i
                              const uint32_t* d_chains2, int selfdist, int pairs, int pbc, const float* d_masses, int reduction1,
                              int reduction2, float* d_results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (N < 0 || F < 0 || ng1 < 0 || ng2 < 0 || n_g1_atoms < 0) return fail(MKAMD_EINVAL, "negative size");
     if (pairs && ng1 != ng2) return fail(MKAMD_EINVAL, "pairs mode needs the same number of groups on both sides");
@@ -1520,7 +1563,7 @@ try {
 
 int mkamd_cdist_dev(mkamd_ctx* ctx, const float* d_c1, int64_t n1, const float* d_c2, int64_t n2, int32_t D, float* d_results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (n1 < 0 || n2 < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
     if (n1 == 0 || n2 == 0) return MKAMD_OK;
@@ -1533,7 +1576,7 @@ try {
 
 int mkamd_pdist_dev(mkamd_ctx* ctx, const float* d_c, int64_t n, int32_t D, float* d_results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (n < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
     if (n < 2) return MKAMD_OK;
@@ -1546,7 +1589,7 @@ try {
 
 int mkamd_cdist_host(mkamd_ctx* ctx, const float* c1, int64_t n1, const float* c2, int64_t n2, int32_t D, float* results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (n1 < 0 || n2 < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
     if (n1 == 0 || n2 == 0) return MKAMD_OK;
@@ -1566,7 +1609,7 @@ try {
 
 int mkamd_pdist_host(mkamd_ctx* ctx, const float* c, int64_t n, int32_t D, float* results)
 try {
-    int st = check_ctx(ctx);
+    int st = dist_entry(ctx);
     if (st) return st;
     if (n < 0 || D < 0) return fail(MKAMD_EINVAL, "negative size");
     if (n < 2) return MKAMD_OK;

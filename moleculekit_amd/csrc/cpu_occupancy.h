@@ -1,5 +1,6 @@
 // cpu_occupancy.h -- the library's HOST implementation of calculate_occupancy ("a CPU function with
-// a1's exact contract"), for the GPU-less hosts on which moleculekit users prepare data.  Product code: it shares nothing
+// a1's exact contract"), for the GPU-less hosts on which moleculekit users prepare data (built twice: into libmkamd.so, and by
+// the plain C++ compiler into libmkamd_host.so -- host_capi.cpp -- which needs no ROCm at all).  Product code: it shares nothing
 // with the test suite's checker (which restates the reference's N x V loop) and is never taken silently -- only
 // mkamd_calculate_occupancy_cpu / method="CPU" reach it; every GPU entry point still fails loudly without a device.
 //
@@ -82,10 +83,14 @@ inline bool build_cells(const float* coords, int64_t N, const double* sigmas, in
     return true;
 }
 
-// centres [v0, v1): every atom of the 27 cells around a centre, the reference's arithmetic per pair
-#pragma clang fp contract(off)
+// centres [v0, v1): every atom of the 27 cells around a centre, the reference's arithmetic per pair -- one rounding per
+// operation, never contracted into an fma: the pragma below covers THIS function's body only (clang: libmkamd.so, where this
+// header sits in the middle of capi.hip); the stand-alone host library (host_capi.cpp, g++) is built with -ffp-contract=off
 inline void centres_slice(const AtomCells& cl, const double* centers, int64_t v0, int64_t v1, const double* sigmas, int32_t C, double* results)
 {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     for (int64_t v = v0; v < v1; ++v) {
         const double cx = centers[3 * v], cy = centers[3 * v + 1], cz = centers[3 * v + 2];
         const double c3[3] = {cx, cy, cz};

@@ -109,6 +109,7 @@ struct GridDesc {
     // molecule of topo_n atoms (the frames of a trajectory), whose per-atom class ids / compact channel words / class table
     // were built once from its sigmas: sigma-side arrays are indexed by the atom's index INSIDE its item
     long long topo_n;
+    unsigned topo_wide;         // atoms of that molecule with a sigma wide enough for the exact cut-off fix-up (the handle lists them)
 };
 enum { DIRECT_FAILED = 0, DIRECT_SPILLED = 1, DIRECT_WORDS = 4, DIRECT_HEAD = 32 /* words in front of the counters (one 128-byte line) */ };
 constexpr float REACH_STEP = 0.17f;   // levels 0..3: reach 5.00 / 4.56 / 4.06 / 3.50 A at the 5 A cutoff (H at eps = 1e-6: 3.48 A)
@@ -1105,7 +1106,8 @@ MK_KERNEL(256) void k_topology_classes(const SigT* __restrict__ sigmas, long lon
 template <typename SigT>
 MK_KERNEL(256) void k_topology_ids(const SigT* __restrict__ sigmas, const uint2* __restrict__ cw_in, const unsigned* __restrict__ cls_table,
                                    long long n, int C, int G, double w_scale, float w_exact_max,
-                                   unsigned* __restrict__ ids_out /* [n, G] */, int* __restrict__ flags /* |= 1: some sigma is wide */)
+                                   unsigned* __restrict__ ids_out /* [n, G] */, int* __restrict__ flags /* [0] |= 1: some sigma is wide; [1]: how many atoms */,
+                                   unsigned* __restrict__ wide_list /* [n]: the atoms with a wide sigma, in the order they arrive (the host sorts) */)
 {
     const long long a = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n) return;
@@ -1133,7 +1135,10 @@ MK_KERNEL(256) void k_topology_ids(const SigT* __restrict__ sigmas, const uint2*
         }
         ids_out[(size_t)a * G + gq] = ids;
     }
-    if (wide) mk_atomic_or(flags, 1);
+    if (wide) {
+        mk_atomic_or(flags, 1);
+        wide_list[mk_atomic_add(reinterpret_cast<unsigned*>(flags) + 1, 1u)] = (unsigned)a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2779,8 +2784,86 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, in
     mk_block_sync();
 }
 
+// The cut-off shell of ONE wide atom `a` of item `b` (all 64 lanes): every (voxel, wide channel) the shell passes is recomputed
+// exactly.  `srow` = the atom's row in `sigmas` (a topology call: its index inside the molecule).
+template <typename SigT>
+MK_DEV void exact_fixup_atom(const GridDesc& g, const int b, const long long a, const long long srow, const float* __restrict__ coords,
+                             const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
+                             const float* __restrict__ box, const double* __restrict__ affine, float* __restrict__ out, double* s_best,
+                             unsigned* __restrict__ feedback, unsigned seq)
+{
+    const int lane = threadIdx.x;
+    const float wmax = g.w_exact_max;
+    const double R = CUTOFF_A_KERNEL / g.res, R2 = R * R, band = R2 * EXACT_BAND_REL, Rb = sqrt(R2 + band);
+    const int nvox[3] = {g.nx, g.ny, g.nz};
+    // position in voxel units, as the binning sees it
+    float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
+    if (affine != nullptr) {
+        const double* A = affine + 12 * (size_t)b;
+        const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+        xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+        xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+        xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+    }
+    double p[3], Lv[3] = {0.0, 0.0, 0.0};
+    int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
+    bool skip = false;
+    for (int ax = 0; ax < 3; ++ax) {
+        p[ax] = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
+        if (g.pbc) {
+            const double Lx = (double)box[3 * (size_t)b + ax] * g.inv_res;
+            if (!(Lx > 2.0 * (g.Rp - 1e-3))) skip = true;          // bad box: the binning has raised the error flag
+            Lv[ax] = Lx;
+            const double i0 = ceil((-Rb - p[ax]) / Lx), i1 = floor(((double)(nvox[ax] - 1) + Rb - p[ax]) / Lx);
+            if (!(i1 - i0 <= 64.0)) skip = true;
+            k0[ax] = (int)i0; k1[ax] = (int)i1;
+        }
+        if (!(p[ax] == p[ax])) skip = true;                        // NaN coordinate
+    }
+    if (skip) return;
+    for (int kx = k0[0]; kx <= k1[0]; ++kx)
+    for (int ky = k0[1]; ky <= k1[1]; ++ky)
+    for (int kz = k0[2]; kz <= k1[2]; ++kz) {                      // wave-uniform: the periodic images
+        const double qx = p[0] + kx * Lv[0], qy = p[1] + ky * Lv[1], qz = p[2] + kz * Lv[2];
+        const double fx0 = ceil(qx - Rb), fx1 = floor(qx + Rb), fy0 = ceil(qy - Rb), fy1 = floor(qy + Rb);
+        const int x_lo = fx0 > 0.0 ? (int)fx0 : 0, x_hi = fx1 < (double)(g.nx - 1) ? (int)fx1 : g.nx - 1;
+        const int y_lo = fy0 > 0.0 ? (int)fy0 : 0, y_hi = fy1 < (double)(g.ny - 1) ? (int)fy1 : g.ny - 1;
+        if (x_hi < x_lo || y_hi < y_lo) continue;
+        const int nyr = y_hi - y_lo + 1, ncol = (x_hi - x_lo + 1) * nyr;
+        for (int cb = 0; cb < ncol; cb += WAVE) {                  // wave-uniform: 64 voxel columns at a time
+            const int col = cb + lane;
+            const int ix = x_lo + (col < ncol ? col / nyr : 0), iy = y_lo + (col < ncol ? col % nyr : 0);
+            const double dx = (double)ix - qx, dy = (double)iy - qy, r2 = R2 - dx * dx - dy * dy;
+            const double zr = sqrt(r2 > 0.0 ? r2 : 0.0);
+            const long long ia = (long long)floor(qz - zr + 0.5), ib = (long long)floor(qz + zr + 0.5);
+            for (int s = 0; s < 6; ++s) {                          // the voxels next to the two crossings
+                const long long iz = s < 3 ? ia - 1 + s : ib - 1 + (s - 3);
+                const double dz = (double)iz - qz, d2 = dx * dx + dy * dy + dz * dz;
+                const bool hit = col < ncol && r2 >= -band && iz >= 0 && iz < (long long)g.nz && (s < 3 || iz > ia + 1) &&
+                                 fabs(d2 - R2) <= band;
+                unsigned long long hits = mk_ballot(hit);
+                while (hits) {                                     // wave-uniform: rare
+                    const int hl = mk_ctz64(hits);
+                    hits &= hits - 1ull;
+                    const int vx = (int)mk_readlane((unsigned)ix, hl), vy = (int)mk_readlane((unsigned)iy, hl);
+                    const int vz = (int)mk_readlane((unsigned)(int)iz, hl);
+                    if (feedback != nullptr && lane == 0) feedback[FB_TAIL_WROTE] = seq;   // (the host may have read the tile kernel's values already)
+                    for (int c = 0; c < g.C; ++c)                  // the atom's wide channels
+                        if (sigma_to_w(sigmas[(size_t)srow * g.C + c], g.w_scale) < wmax)
+                            exact_recompute<SigT>(g, b, vx, vy, vz, c, coords, atom_offsets, sigmas, origins, box, affine, out, s_best);
+                }
+            }
+        }
+    }
+}
+
 // One wave per 256 atoms of the binning (per_item == 0: `summary` = the blocks' sigma sets, CLS_BLOCK_SET words each;
-// nullptr = no summary, look at every atom) or per item (per_item == 1: `summary` = the items' class tables).
+// nullptr = no summary, look at every atom), per item (per_item == 1: `summary` = the items' class tables), or -- a topology
+// call, per_item == 2 -- per (item, wide atom of the molecule): `summary` = the handle's list of the g.topo_wide atoms that have
+// a wide sigma, job = item * g.topo_wide + position in the list.  (Round 5 gave a topology call ONE job per item: a single wave
+// walked all of the item's atoms 64 at a time and took its wide atoms one after the other -- for 30 000-atom frames with a
+// few ions ~470 dependent load / ballot rounds on B waves; now the B x n_wide shells are spread over all fix-up waves and
+// nobody looks at an atom that is not wide.)
 template <typename SigT>
 MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_item, const unsigned* __restrict__ summary,
                               const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
@@ -2792,13 +2875,23 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
     const int lane = threadIdx.x;
     const float wmax = g.w_exact_max;
     auto wide_bits = [&](unsigned bits) { return bits != CLS_EMPTY && mk_uint_as_float(bits) < wmax; };   // NaN: false
+    if (per_item == 2) {
+        const int b = (int)(blk / g.topo_wide);
+        const long long k = (long long)summary[blk % g.topo_wide];         // the atom's index inside the molecule
+        const long long a_lo = atom_offsets[b], a_hi = atom_offsets[b + 1];
+        // an item that is not the topology's atom count long: the binning has raised MK_ERR_TOPOLOGY; nothing of the handle's
+        // is indexed with it (the C API promises a clean MKAMD_EINVAL at the next synchronize, not a read past the handle)
+        if (a_hi - a_lo != (long long)g.topo_n || k >= (long long)g.topo_n) return;
+        exact_fixup_atom<SigT>(g, b, a_lo + k, k, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, feedback, seq);
+        return;
+    }
     // ---- the summary: is there anything wide among this wave's atoms at all? ----
     long long a_lo, a_hi;
     if (per_item) {
         const int b = (int)blk;
         a_lo = atom_offsets[b]; a_hi = atom_offsets[b + 1];
         if (summary != nullptr) {
-            const unsigned t = lane < CLS_TABLE_WORDS ? summary[(g.topo_n ? (size_t)0 : (size_t)b) * CLS_TABLE_WORDS + lane] : CLS_EMPTY;   // (a topology call: ONE table)
+            const unsigned t = lane < CLS_TABLE_WORDS ? summary[(size_t)b * CLS_TABLE_WORDS + lane] : CLS_EMPTY;
             const bool maybe = lane == CLS_OVERFLOW ? t != CLS_EMPTY : wide_bits(t);   // overflowed table: look at the atoms
             if (mk_ballot(maybe) == 0ull) return;
         }
@@ -2810,20 +2903,16 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
             if (mk_ballot(t == CLS_TOO_MANY || wide_bits(t)) == 0ull) return;
         }
     }
-    const double R = CUTOFF_A_KERNEL / g.res, R2 = R * R, band = R2 * EXACT_BAND_REL, Rb = sqrt(R2 + band);
-    const int nvox[3] = {g.nx, g.ny, g.nz};
     int b_hint = per_item ? (int)blk : item_of_atom(atom_offsets, g.B, a_lo, 0);
-    // a topology call (always per item): the compact channel words and the sigma rows are the MOLECULE's, indexed inside the item
-    const long long sshift = g.topo_n ? a_lo : 0;
     for (long long base = a_lo; base < a_hi; base += WAVE) {               // wave-uniform
         const long long a_mine = base + lane;
         bool wide = false;
         if (a_mine < a_hi) {
             for (int gq = 0; gq < g.G; ++gq) {
-                const uint2 cw = tmp_cls[(size_t)(a_mine - sshift) * g.G + gq];
+                const uint2 cw = tmp_cls[(size_t)a_mine * g.G + gq];
                 if (cw.y == ATOM_MULTI_SIGMA) {
                     for (int c = gq * CHG; c < g.C && c < gq * CHG + CHG; ++c)
-                        wide |= sigma_to_w(sigmas[(size_t)(a_mine - sshift) * g.C + c], g.w_scale) < wmax;
+                        wide |= sigma_to_w(sigmas[(size_t)a_mine * g.C + c], g.w_scale) < wmax;
                 } else wide |= wide_bits(cw.x);
             }
         }
@@ -2834,65 +2923,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
             const long long a = base + l;
             const int b = per_item ? (int)blk : item_of_atom(atom_offsets, g.B, a, b_hint);
             b_hint = b;
-            // position in voxel units, as the binning sees it
-            float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
-            if (affine != nullptr) {
-                const double* A = affine + 12 * (size_t)b;
-                const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
-                xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
-                xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
-                xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
-            }
-            double p[3], Lv[3] = {0.0, 0.0, 0.0};
-            int k0[3] = {0, 0, 0}, k1[3] = {0, 0, 0};
-            bool skip = false;
-            for (int ax = 0; ax < 3; ++ax) {
-                p[ax] = ((double)xyz[ax] - origins[3 * (size_t)b + ax]) * g.inv_res;
-                if (g.pbc) {
-                    const double Lx = (double)box[3 * (size_t)b + ax] * g.inv_res;
-                    if (!(Lx > 2.0 * (g.Rp - 1e-3))) skip = true;          // bad box: the binning has raised the error flag
-                    Lv[ax] = Lx;
-                    const double i0 = ceil((-Rb - p[ax]) / Lx), i1 = floor(((double)(nvox[ax] - 1) + Rb - p[ax]) / Lx);
-                    if (!(i1 - i0 <= 64.0)) skip = true;
-                    k0[ax] = (int)i0; k1[ax] = (int)i1;
-                }
-                if (!(p[ax] == p[ax])) skip = true;                        // NaN coordinate
-            }
-            if (skip) continue;
-            for (int kx = k0[0]; kx <= k1[0]; ++kx)
-            for (int ky = k0[1]; ky <= k1[1]; ++ky)
-            for (int kz = k0[2]; kz <= k1[2]; ++kz) {                      // wave-uniform: the periodic images
-                const double qx = p[0] + kx * Lv[0], qy = p[1] + ky * Lv[1], qz = p[2] + kz * Lv[2];
-                const double fx0 = ceil(qx - Rb), fx1 = floor(qx + Rb), fy0 = ceil(qy - Rb), fy1 = floor(qy + Rb);
-                const int x_lo = fx0 > 0.0 ? (int)fx0 : 0, x_hi = fx1 < (double)(g.nx - 1) ? (int)fx1 : g.nx - 1;
-                const int y_lo = fy0 > 0.0 ? (int)fy0 : 0, y_hi = fy1 < (double)(g.ny - 1) ? (int)fy1 : g.ny - 1;
-                if (x_hi < x_lo || y_hi < y_lo) continue;
-                const int nyr = y_hi - y_lo + 1, ncol = (x_hi - x_lo + 1) * nyr;
-                for (int cb = 0; cb < ncol; cb += WAVE) {                  // wave-uniform: 64 voxel columns at a time
-                    const int col = cb + lane;
-                    const int ix = x_lo + (col < ncol ? col / nyr : 0), iy = y_lo + (col < ncol ? col % nyr : 0);
-                    const double dx = (double)ix - qx, dy = (double)iy - qy, r2 = R2 - dx * dx - dy * dy;
-                    const double zr = sqrt(r2 > 0.0 ? r2 : 0.0);
-                    const long long ia = (long long)floor(qz - zr + 0.5), ib = (long long)floor(qz + zr + 0.5);
-                    for (int s = 0; s < 6; ++s) {                          // the voxels next to the two crossings
-                        const long long iz = s < 3 ? ia - 1 + s : ib - 1 + (s - 3);
-                        const double dz = (double)iz - qz, d2 = dx * dx + dy * dy + dz * dz;
-                        const bool hit = col < ncol && r2 >= -band && iz >= 0 && iz < (long long)g.nz && (s < 3 || iz > ia + 1) &&
-                                         fabs(d2 - R2) <= band;
-                        unsigned long long hits = mk_ballot(hit);
-                        while (hits) {                                     // wave-uniform: rare
-                            const int hl = mk_ctz64(hits);
-                            hits &= hits - 1ull;
-                            const int vx = (int)mk_readlane((unsigned)ix, hl), vy = (int)mk_readlane((unsigned)iy, hl);
-                            const int vz = (int)mk_readlane((unsigned)(int)iz, hl);
-                            if (feedback != nullptr && lane == 0) feedback[FB_TAIL_WROTE] = seq;   // (the host may have read the tile kernel's values already)
-                            for (int c = 0; c < g.C; ++c)                  // the atom's wide channels
-                                if (sigma_to_w(sigmas[(size_t)(a - sshift) * g.C + c], g.w_scale) < wmax)
-                                    exact_recompute<SigT>(g, b, vx, vy, vz, c, coords, atom_offsets, sigmas, origins, box, affine, out, s_best);
-                        }
-                    }
-                }
-            }
+            exact_fixup_atom<SigT>(g, b, a, a, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, feedback, seq);
         }
     }
 }

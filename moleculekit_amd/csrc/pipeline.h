@@ -57,6 +57,8 @@ struct TopologyDev {
     const unsigned* table = nullptr;        // [CLS_TABLE_WORDS] the class table
     bool overflow = false;                  // more than NCLS distinct sigmas: no class ids (creation reports it, calls are refused)
     bool wide = false;                      // some sigma is wide enough for the exact cut-off fix-up (GridDesc::w_exact_max)
+    const unsigned* wide_list = nullptr;    // [n_wide] the atoms that have one, ascending (k_tail's fix-up jobs of a topology call: item x wide atom)
+    unsigned n_wide = 0;
 };
 
 struct LatticeProblem {
@@ -342,6 +344,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         }
     }
     g.topo_n = topo ? P.topo->n : 0;
+    g.topo_wide = topo ? P.topo->n_wide : 0u;
     const bool chain_pays = be.pipelining_possible() && P.total_atoms >= 200000 && P.total_atoms > 1024LL * (long long)g.B;
     const unsigned total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     // fewer tile waves than the chip has SIMDs (one or two 64^3 grids, a pocket): a team of waves per tile
@@ -484,9 +487,13 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
         if ((st = be.ensure(WS_CLS_L1, (size_t)nl1 * MERGE_SET * sizeof(unsigned), &l1sets, set))) return st;
         fix_summary = g.force_general ? nullptr : (const unsigned*)bsets;
         fix_waves = P.total_atoms > 0 ? nblk : 0u;
-        if (topo) {                                 // fix-up jobs per ITEM, all looking at the one table first -- or none at all
-            fix_summary = P.topo->table;
-            fix_waves = P.topo->wide ? (unsigned)g.B : 0u;
+        if (topo) {
+            // fix-up jobs per (item, WIDE atom of the molecule) -- the handle lists them -- or none at all.  (Round 5: one job per item;
+            // a wave then walked all of a 30 000-atom frame 64 atoms at a time and took its wide atoms one after the other.)
+            fix_summary = P.topo->wide_list;
+            const unsigned long long jobs = (unsigned long long)g.B * P.topo->n_wide;
+            if (jobs > 0xffffffffull) { err = "too many (item, wide atom) fix-up jobs (>= 2^32): split the batch"; return ST_EINVAL; }
+            fix_waves = (unsigned)jobs;
         }
         const unsigned* dfail = g.direct_words ? g.direct_words + DIRECT_FAILED : nullptr;
         if (solo) {
@@ -571,7 +578,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     ta.dense_wgs = g.force_general ? 0u : (total_tiles * (unsigned)g.G < 4096u ? total_tiles * (unsigned)g.G : 4096u);
     ta.fix_jobs = fix_waves;
     ta.fix_waves = fix_waves < 8192u ? fix_waves : 8192u;         // (the fix-up waves share the jobs: see k_tail)
-    ta.other_words = dother; ta.per_item = (per_item || topo) ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = topo ? (const void*)P.topo->cw : tcls;
+    ta.other_words = dother; ta.per_item = topo ? 2 : per_item ? 1 : 0; ta.summary = fix_summary; ta.P = &P; ta.tcls = topo ? (const void*)P.topo->cw : tcls;
     if (topo) { ctab = const_cast<unsigned*>(P.topo->table); ta.sigmas = P.topo->sigmas; ta.sigmas_f64 = P.topo->sigmas_f64; }
     ta.team_waves = (P.tile_team == 4 || P.tile_team == 8 || P.tile_team == 16) ? P.tile_team : 0;
     if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(DIRECT_HEAD + (ncells << g.cnt_shift)); }
@@ -597,7 +604,7 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
 // flags[0] back once the stream has drained.  Workspace: the class-set slots of set 0.
 template <class BE>
 int run_topology_build(BE& be, const void* d_sigmas, int sigmas_f64, long long n, int C, double voxelsize, uint2* cw, unsigned* ids,
-                       unsigned* table, int* flags, std::string& err)
+                       unsigned* table, int* flags /* 2 words, zeroed */, unsigned* wide_list /* [n] */, std::string& err)
 {
     if (n <= 0 || C <= 0) { err = "a topology needs n_atoms > 0 and n_channels > 0"; return ST_EINVAL; }
     if (!(voxelsize > 0.0) || !std::isfinite(voxelsize)) { err = "voxelsize must be a positive finite number"; return ST_EINVAL; }
@@ -616,9 +623,9 @@ int run_topology_build(BE& be, const void* d_sigmas, int sigmas_f64, long long n
                         (unsigned*)l1sets, (unsigned*)nullptr))) return st;
     if ((st = be.launch(k_merge_classes, dim3(1), dim3(256), (const unsigned*)l1sets, nl1, (unsigned)MERGE_SET, nl1, (unsigned*)nullptr, table))) return st;
     return sigmas_f64 ? be.launch(k_topology_ids<double>, dim3(nblk), dim3(256), (const double*)d_sigmas, (const uint2*)cw, (const unsigned*)table, n, C, G,
-                                  w_scale, w_exact_max, ids, flags)
+                                  w_scale, w_exact_max, ids, flags, wide_list)
                       : be.launch(k_topology_ids<float>, dim3(nblk), dim3(256), (const float*)d_sigmas, (const uint2*)cw, (const unsigned*)table, n, C, G,
-                                  w_scale, w_exact_max, ids, flags);
+                                  w_scale, w_exact_max, ids, flags, wide_list);
 }
 
 // Explicit centres: sigma -> w, then the brute-force double-precision kernel.

@@ -168,7 +168,9 @@ class ShardedVoxelizer:
         sig_dt = np.float64 if sig.dtype == np.float64 else np.float32
         self._topo = None
         self._shared = False
-        if shared_sigmas and compute is None and self.n_local > 0:
+        if shared_sigmas and self.n_local > 0:
+            # (checked whoever computes: an injected `compute` -- the CPU test path -- gets the matrix repeated per item, as it
+            #  slices rows by atom; round 5 skipped the check there and would have sliced a molecule's [n, C] matrix wrongly)
             sizes = np.diff(self._offs_host)
             n0 = int(sizes[0])
             if n0 > 0 and np.all(sizes == n0):
@@ -179,7 +181,10 @@ class ShardedVoxelizer:
                     sig = np.ascontiguousarray(rows[0])
                 elif sig.shape[0] != n0:
                     raise ValueError("shared_sigmas: pass the molecule's [n, C] matrix or its repeat per item")
-                self._shared = True
+                if compute is None:
+                    self._shared = True
+                else:
+                    sig = np.tile(sig, (self.n_local, 1))
             else:
                 raise ValueError("shared_sigmas: every item must have the molecule's atom count")
         self._d = self._upload(dict(coords=(coords, np.float32), offs=(self._offs_host, np.int64), sigmas=(sig, sig_dt),

@@ -52,9 +52,12 @@ def calculate_occupancy_cpu(centers, coords, sigmas, results, n_threads=0):
     results -- for hosts without a GPU.  Explicit only: ``calculate_occupancy`` never falls back to it."""
     cen, xyz, sig = _checked(centers, coords, sigmas, results)
     V, N, C = cen.shape[0], xyz.shape[0], sig.shape[1]
-    L = _lib.load()
+    L = _lib.load_host()                     # libmkamd_host.so: plain C++, no ROCm needed (the copy inside libmkamd.so is for C callers)
     tmp = results if results.flags["C_CONTIGUOUS"] else np.ascontiguousarray(results)
-    _lib._check(L.mkamd_calculate_occupancy_cpu_threads(_lib._ptr(cen), V, _lib._ptr(xyz), N, _lib._ptr(sig), C, _lib._ptr(tmp), int(n_threads)))
+    st = L.mkamd_calculate_occupancy_cpu_threads(_lib._ptr(cen), V, _lib._ptr(xyz), N, _lib._ptr(sig), C, _lib._ptr(tmp), int(n_threads))
+    if st:
+        msg = L.mkamd_host_last_error().decode(errors="replace")
+        raise (ValueError if st == 1 else MemoryError if st == 6 else RuntimeError)(f"libmkamd_host: {msg}")
     if tmp is not results:
         results[...] = tmp
     return None

@@ -8,6 +8,7 @@
 #include "../../moleculekit_amd/csrc/xtc_gpu.h"
 
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace mkamd;
@@ -132,12 +133,16 @@ int emu_voxelize_lattice_topo(int B, const float* coords, const long long* atom_
     const int G = ceil_div(C, CHG);
     std::vector<uint2> cw((size_t)n * G);
     std::vector<unsigned> ids((size_t)n * G, 0xCDCDCDCDu), table(CLS_TABLE_WORDS, 0xCDCDCDCDu);
-    int flags = 0;
-    int st = run_topology_build(be, sigmas, sigmas_f64, n, C, voxelsize, cw.data(), ids.data(), table.data(), &flags, g_err);
+    int flags2[2] = {0, 0};
+    std::vector<unsigned> wide_list((size_t)n, 0xCDCDCDCDu);
+    int st = run_topology_build(be, sigmas, sigmas_f64, n, C, voxelsize, cw.data(), ids.data(), table.data(), flags2, wide_list.data(), g_err);
     if (st) return st;
+    const int flags = flags2[0];
+    std::sort(wide_list.begin(), wide_list.begin() + flags2[1]);     // (as mkamd_topology_create_dev does)
     TopologyDev T;
     T.n = n; T.C = C; T.G = G; T.sigmas_f64 = sigmas_f64; T.voxelsize = voxelsize; T.ids = ids.data(); T.cw = cw.data(); T.sigmas = sigmas;
     T.table = table.data(); T.overflow = table[CLS_OVERFLOW] != CLS_EMPTY; T.wide = (flags & 1) != 0;
+    T.wide_list = wide_list.data(); T.n_wide = (unsigned)flags2[1];
     if (wide_out) *wide_out = T.wide ? 1 : 0;
     LatticeProblem P;
     P.B = B; P.total_atoms = B > 0 ? atom_offsets[B] : 0; P.C = C; P.sigmas_f64 = sigmas_f64;

@@ -106,3 +106,26 @@ def test_random_configurations_against_the_checker():
         centers = rng.normal(0, rng.uniform(2, 20), (V, 3))
         sig = rng.choice([0.0, 1.1, 1.7, 1.55, 2.27, 0.3], (N, C))
         assert np.array_equal(_cpu(centers, coords, sig, int(rng.integers(0, 5))), oracle.calculate_occupancy(centers, coords, sig))
+
+
+def test_host_library_stands_alone_and_equals_the_copy_inside_libmkamd():
+    """libmkamd_host.so (csrc/host_capi.cpp) is built by the plain C++ compiler and needs nothing of ROCm: no HIP runtime among
+    its dependencies; the two entry points it exports give the bits of the copies inside libmkamd.so (clang, fp-contract off per
+    function) -- and so the reference's."""
+    import ctypes
+    import subprocess
+    from moleculekit_amd import _build, _lib
+    path = _build.build_host()
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "libamdhip64" not in needed and "libhsa" not in needed, needed
+    g = golden("cfg1_3ptb.npz")
+    cen, xyz, sig = (np.ascontiguousarray(g["centers"], np.float64), np.ascontiguousarray(g["coords"], np.float32),
+                     np.ascontiguousarray(g["sigmas"], np.float64))
+    a = np.zeros_like(g["features"]); b = np.zeros_like(g["features"])
+    H, L = _lib.load_host(), _lib.load()
+    args = lambda out: (cen.ctypes.data, cen.shape[0], xyz.ctypes.data, xyz.shape[0], sig.ctypes.data, sig.shape[1], out.ctypes.data)
+    assert H.mkamd_calculate_occupancy_cpu(*args(a)) == 0 and L.mkamd_calculate_occupancy_cpu(*args(b)) == 0
+    assert np.array_equal(a, b) and np.array_equal(a, g["features"])
+    assert H.mkamd_calculate_occupancy_cpu_threads(None, 5, None, 5, None, 8, None, 1) == 1 and b"NULL" in H.mkamd_host_last_error()
+    with pytest.raises(ValueError):
+        occupancy_utils.calculate_occupancy_cpu(cen, xyz, sig.astype(np.float32), a)

@@ -316,3 +316,31 @@ def test_sharded_distances_single_process_without_a_group():
     assert np.array_equal(sd.gather(got).numpy(), oracle.dist_trajectory(coords, np.zeros((3, 5), np.float32), sel, sel + 4, np.zeros(12, np.uint32), False, False))
     with pytest.raises(ValueError):
         D.ShardedDistances(5, [0, 4], (coords, None), compute=_dist_compute)
+
+
+def test_shared_sigmas_is_validated_with_an_injected_compute_too():
+    """`shared_sigmas=True` used to be ignored silently when `compute` was injected.  Now: the molecule's [n, C] matrix is
+    accepted and repeated for the stand-in, a repeated matrix has to BE a repeat, ragged items are refused."""
+    import torch
+    from moleculekit_amd import distributed as D
+    n, F = 5, 3
+    rng = np.random.default_rng(0)
+    coords = rng.normal(size=(n * F, 3)).astype(np.float32)
+    offs = np.arange(F + 1) * n
+    sig1 = rng.uniform(1, 2, size=(n, 8))
+    origins = np.zeros((F, 3))
+    seen = {}
+
+    def compute(c, o, s, org, nv, vs, bx):
+        seen["sig"] = s.copy()
+        return torch.zeros((len(o) - 1, int(np.prod(nv)), s.shape[1]))
+
+    for sig in (sig1, np.tile(sig1, (F, 1))):
+        sv = D.ShardedVoxelizer.from_host(coords, offs, sig, origins, [2, 2, 2], 1.0, compute=compute, shared_sigmas=True)
+        sv.voxelize()
+        assert seen["sig"].shape == (n * F, 8) and np.array_equal(seen["sig"], np.tile(sig1, (F, 1)))
+    bad = np.tile(sig1, (F, 1)); bad[-1, 0] += 1
+    with pytest.raises(ValueError):
+        D.ShardedVoxelizer.from_host(coords, offs, bad, origins, [2, 2, 2], 1.0, compute=compute, shared_sigmas=True)
+    with pytest.raises(ValueError):
+        D.ShardedVoxelizer.from_host(coords, np.array([0, 4, 10, 15]), np.tile(sig1, (F, 1)), origins, [2, 2, 2], 1.0, compute=compute, shared_sigmas=True)

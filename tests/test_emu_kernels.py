@@ -677,3 +677,42 @@ def test_periodic_image_ranges_without_divisions_are_the_quotients():
     assert err == 0
     exp = oracle_lattice(coords, np.array([0, len(coords)]), sig, origin, nv, 1.0, L[None])
     assert np.abs(got.astype(np.float64) - exp).max() <= TOL
+
+
+def test_topology_fixup_jobs_are_per_wide_atom_and_decide_the_shell_exactly():
+    """Round 6: a topology call's exact cut-off fix-up runs one job per (item, WIDE atom of the molecule) from
+    the handle's list (round 5: one wave per item walked every atom).  Atoms on lattice points nudged by float32 ulps put 30 voxels
+    each within ~1e-6 A of the 5 A shell; sigma 1.81 A (channel 1) is re-decided in double: after the topology call NO value of
+    that channel is on the other side of the cutoff than the reference's -- which only holds if the fix-up found every wide
+    atom of every frame -- and the topology call is bit for bit the plain call."""
+    rng = np.random.default_rng(4)
+    base = np.stack(np.meshgrid(*[6.0 + 12.0 * np.arange(2)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    frames = []
+    for _ in range(3):
+        c = base.copy()
+        for k in range(len(c)):
+            for ax in range(3):
+                steps = int(rng.integers(-3, 4))
+                for _ in range(abs(steps)):
+                    c[k, ax] = np.nextafter(c[k, ax], np.float32(np.inf if steps > 0 else -np.inf))
+        frames.append(c)
+    n, F = len(base), len(frames)
+    coords = np.concatenate(frames)
+    sig = np.zeros((n, 8))
+    sig[:, 0] = 1.80
+    sig[1::2, 1] = 1.81                       # wide atoms: every second atom of the molecule
+    sig[::3, 7] = 2.27
+    offs = np.arange(F + 1) * n
+    origins = np.zeros((F, 3))
+    nv = [24, 24, 24]
+    topo, err, wide = E.voxelize_lattice_topo(coords, sig, F, origins, nv, 1.0)
+    plain, e0 = E.voxelize_lattice(coords, offs, np.tile(sig, (F, 1)), origins, nv, 1.0, prepass_mode=0)
+    assert err == 0 and e0 == 0 and wide and np.array_equal(topo, plain)
+    exp = oracle_lattice(coords, offs, np.tile(sig, (F, 1)), origins, np.array(nv), 1.0)
+    assert np.abs(topo - exp).max() <= TOL
+    for c in (1, 7):
+        assert not ((topo[:, :, c] == 0) != (exp[:, :, c] == 0)).any(), c
+    # ragged offsets with wide atoms: flagged on the device, and the fix-up jobs do not index the handle with them
+    bad = np.array([0, n - 2, 2 * n + 1, 3 * n])
+    _, err, _ = E.voxelize_lattice_topo(coords, sig, F, origins, nv, 1.0, atom_offsets=bad)
+    assert err & 8
