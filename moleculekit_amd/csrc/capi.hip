@@ -1506,7 +1506,8 @@ try {
     std::string err;
     st = run_dist_reduction(*ctx, (const float*)dc, N, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, g1_off[ng1], (const int*)a2,
                             (const long long*)o2, ng2, (const unsigned*)c1, (const unsigned*)c2, selfdist, pairs, pbc,
-                            (const float*)dm, reduction1, reduction2, (float*)dout, err, ctx->reduction_block);
+                            (const float*)dm, reduction1, reduction2, (float*)dout, err,
+                            ctx->reduction_block ? ctx->reduction_block : reduction_block_for((const long long*)g1_off, ng1));
     if (st) return err.empty() ? st : fail(st, err);
     prefault_big_result(results, (size_t)F * P * 4);
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));

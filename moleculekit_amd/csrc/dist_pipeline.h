@@ -129,6 +129,18 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
                : be.launch(k_dist_pairs<false>, pgrid, dim3(DT_THREADS), coords, F, box, (const unsigned*)pa, (const unsigned*)pb, (const unsigned*)wr, P, squared, out);
 }
 
+// 4 or 8 first-group atoms per pass of k_dist_reduction_closest from the group sizes themselves (host offsets): the padded slot
+// totals, 8 unless it pads more than 6 % worse
+inline int reduction_block_for(const long long* g1_off, long long ng1)
+{
+    long long s4 = 0, s8 = 0;
+    for (long long g = 0; g < ng1; ++g) {
+        const long long n = g1_off[g + 1] - g1_off[g];
+        s4 += (n + 3) / 4 * 4; s8 += (n + 7) / 8 * 8;
+    }
+    return s8 * 100 <= s4 * 106 ? 8 : 4;
+}
+
 // dist_trajectory_reduction[_pairs] on device pointers; groups as CSR (atoms int32, offsets int64)
 // `n_atoms` (rows of coords) and `n_g1_atoms` (length of g1_atoms) are what the HOST knows about arrays that live on the device:
 // they choose the kernel variant (32-bit row offsets; how many first-group atoms a wave keeps in registers), never the result.
@@ -171,8 +183,13 @@ int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long
         // closest atom pair of two atom lists -- the residue-contact maps: first-group atoms in registers, packed arithmetic
         // (k_dist_reduction_closest).  Eight atoms per pass when the first groups are large enough to fill them.
         const int blk = closest_block % 100;                         // (+100: four waves of 16 pairs per block -- A-B timing)
-        const bool eight = blk ? blk == 8 : n_g1_atoms * 10 >= ng1 * 130;
-        const bool four_waves = closest_block >= 100;
+        // 4 or 8 first-group atoms per pass: whichever pads the first groups less, 8 on a tie (fewer loads per atom pair: measured
+        // 0.42 against 0.54 ms on open pairs, 1.12 against 1.18 ms on periodic ones, 200 groups of 15; groups of 9: 0.56 against 0.67 ms
+        // for 4 -- profiles/r6_reduction_probe.txt).  Only the MEAN group size is known here (the offsets live on the device); a
+        // caller that has the sizes passes its choice (mkamd_dist_reduction_host does: reduction_block_for).
+        const long long mean = ng1 > 0 ? (n_g1_atoms + ng1 - 1) / ng1 : 1;
+        const bool eight = blk ? blk == 8 : ceil_div(mean, 8) * 8 * 100 <= ceil_div(mean, 4) * 4 * 106;
+        const bool four_waves = closest_block >= 100;       // (sixteen waves of 4 pairs were measured too: 1.31 against 1.12 ms)
         const bool small_rows = (unsigned long long)n_atoms * 3ull * (unsigned long long)F * 4ull <= 0xffffffffull;
         auto go = [&](auto kern, int nw) {
             return be.launch(kern, grid, dim3((unsigned)(nw * WAVE)), coords, F, box, g1_atoms, g1_off, g2_atoms, g2_off, (const unsigned*)ga,

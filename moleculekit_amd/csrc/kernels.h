@@ -2733,12 +2733,24 @@ MK_KERNEL(TILE_TEAM * 64) void k_voxelize_items(GridDesc g, const unsigned* __re
 // ------------------------------------------------------------------------------------------------
 constexpr double EXACT_BAND_REL = 8e-6;      // band = R^2 x this (2e-4 A^2)
 
-// the occupancy of (voxel ix,iy,iz of item b, channel c) exactly as the reference computes it; all 64 lanes take part
+// the occupancy of (voxel ix,iy,iz of item b) in nch <= EXACT_CH channels (wave-uniform; their indices packed 16 bits each into `chs`:
+// no register array is indexed dynamically) exactly as the reference computes it; all 64 lanes take part.
+// Round 6 (profiles/r6_topology_wide_ab.txt): this used to be ONE channel per pass, one atom per lane and round trip to memory -- a
+// loop whose `continue`s keep the compiler from overlapping the loads: 469 dependent round trips for a 30 000-atom frame, ~60 us per
+// (voxel, channel) on one wave, and k_tail lasts as long as its unluckiest wave: 0.41-0.5 ms per cfg4-sized step for a molecule with
+// eight ions.  Now (a) EXACT_BATCH atoms per lane are loaded together (24 loads in flight: 59 round trips per 30 000-atom frame), (b) a float32
+// pre-test -- d^2 > 25.5 A^2 leaves at once: an error of 1e-3 A^2 at most against a margin of 0.5, whichever image the float32 rounding
+// picks at half a box length, where both images are beyond the cutoff -- puts the ~50 atoms near the voxel on a list in LDS, and only
+// those take the double-precision arithmetic with its divisions and read their (strided) sigma row -- one copy of that code, a lane
+// per listed atom, (c) all the wide channels of the shell's atom share the pass.
+constexpr int EXACT_BATCH = 8, EXACT_CH = 4, EXACT_LIST = 2 * WAVE * EXACT_BATCH;   // (the list holds two whole batches: it is emptied BETWEEN batches)
+template <bool B> struct ExactFull { static constexpr bool value = B; };
 template <typename SigT>
-MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, int c, const float* __restrict__ coords,
+MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, unsigned long long chs /* 16 bits per channel index */, int nch,
+                            const float* __restrict__ coords,
                             const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
                             const double* __restrict__ origins, const float* __restrict__ box,
-                            const double* __restrict__ affine, float* __restrict__ out, double* s_best)
+                            const double* __restrict__ affine, float* __restrict__ out, double* s_best, unsigned* s_near /* [EXACT_LIST] */)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const double cx = mk_dadd_rn(mk_dmul_rn((double)ix, g.res), origins[3 * (size_t)b + 0]);
@@ -2746,42 +2758,102 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, in
     const double cz = mk_dadd_rn(mk_dmul_rn((double)iz, g.res), origins[3 * (size_t)b + 2]);
     double L[3] = {1.0, 1.0, 1.0};
     if (g.pbc) { L[0] = (double)box[3 * (size_t)b]; L[1] = (double)box[3 * (size_t)b + 1]; L[2] = (double)box[3 * (size_t)b + 2]; }
-    double best = 0.0;
-    const long long sshift = g.topo_n ? atom_offsets[b] : 0;              // topology calls: the molecule's one sigma matrix
-    for (long long a = atom_offsets[b] + lane; a < atom_offsets[b + 1]; a += WAVE) {
-        const double sg = (double)sigmas[(size_t)(a - sshift) * g.C + c];
-        if (!(sg != 0.0) || sg != sg) continue;                            // occupancy_utils.pyx:55-56 (a NaN is never stored)
-        float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
-        if (affine != nullptr) {                                           // rounded to float32 like the binning (bin_atom)
-            const double* A = affine + 12 * (size_t)b;
-            const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
-            xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
-            xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
-            xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+    const long long a_lo = atom_offsets[b], a_hi = atom_offsets[b + 1];
+    const long long sshift = g.topo_n ? a_lo : 0;                         // topology calls: the molecule's one sigma matrix
+    const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;
+    const float fL[3] = {(float)L[0], (float)L[1], (float)L[2]};
+    const float fiL[3] = {1.0f / fL[0], 1.0f / fL[1], 1.0f / fL[2]};
+    double best[EXACT_CH];
+#pragma unroll
+    for (int k = 0; k < EXACT_CH; ++k) best[k] = 0.0;
+    unsigned cnt = 0;                                                      // wave-uniform: atoms waiting in s_near
+    // the reference's arithmetic for the atoms of the list (a lane each) -- ONE copy of the double-precision code, outside the unrolled scan
+    auto flush = [&]() {
+        mk_wave_sync();
+        for (unsigned i0 = 0; i0 < cnt; i0 += WAVE) {                      // wave-uniform
+            const unsigned i = i0 + (unsigned)lane;
+            if (i >= cnt) continue;
+            const long long a = a_lo + (long long)s_near[i];
+            float xyz[3] = {coords[3 * a + 0], coords[3 * a + 1], coords[3 * a + 2]};
+            if (affine != nullptr) {                                       // rounded to float32 like the binning (bin_atom)
+                const double* A = affine + 12 * (size_t)b;
+                const double x = (double)xyz[0], y = (double)xyz[1], z = (double)xyz[2];
+                xyz[0] = (float)(A[0] * x + A[1] * y + A[2] * z + A[9]);
+                xyz[1] = (float)(A[3] * x + A[4] * y + A[5] * z + A[10]);
+                xyz[2] = (float)(A[6] * x + A[7] * y + A[8] * z + A[11]);
+            }
+            double dx = (double)xyz[0] - cx, dy = (double)xyz[1] - cy, dz = (double)xyz[2] - cz;
+            if (g.pbc) {
+                dx -= L[0] * round(dx / L[0]);
+                dy -= L[1] * round(dy / L[1]);
+                dz -= L[2] * round(dz / L[2]);
+            }
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < CUTOFF2_A) {
+                const double root = sqrt(d2);
+#pragma unroll
+                for (int k = 0; k < EXACT_CH; ++k) {
+                    if (k >= nch) break;
+                    const double sg = (double)sigmas[(size_t)(a - sshift) * g.C + (size_t)((chs >> (16 * k)) & 0xffffull)];
+                    if (!(sg != 0.0) || sg != sg) continue;                // occupancy_utils.pyx:55-56 (a NaN is never stored)
+                    const double x = sg / root;
+                    const double x3 = x * x * x;
+                    const double val = 1.0 - exp(-(x3 * x3 * x3 * x3));
+                    if (val > best[k]) best[k] = val;
+                }
+            }
         }
-        double dx = (double)xyz[0] - cx, dy = (double)xyz[1] - cy, dz = (double)xyz[2] - cz;
-        if (g.pbc) {
-            dx -= L[0] * round(dx / L[0]);
-            dy -= L[1] * round(dy / L[1]);
-            dz -= L[2] * round(dz / L[2]);
+        mk_wave_sync();
+        cnt = 0;
+    };
+    // a batch of WAVE x EXACT_BATCH atoms from `base` on.  FULL: all of them exist -- the loads are ONE address per lane plus constant
+    // offsets (no clamp, no 64-bit arithmetic per load: with it the 48 addresses of a batch alone took ~100 registers)
+    auto scan = [&](long long base, auto full_) {
+        constexpr bool FULL = decltype(full_)::value;
+        float X[EXACT_BATCH], Y[EXACT_BATCH], Z[EXACT_BATCH];
+        const float* __restrict__ p0 = coords + 3 * (base + lane);
+#pragma unroll
+        for (int u = 0; u < EXACT_BATCH; ++u) {                            // every load of the batch before the first use
+            if constexpr (FULL) {
+                X[u] = p0[3 * WAVE * u + 0]; Y[u] = p0[3 * WAVE * u + 1]; Z[u] = p0[3 * WAVE * u + 2];
+            } else {
+                const long long a = base + (long long)u * WAVE + lane, ai = a < a_hi ? a : a_hi - 1;
+                X[u] = coords[3 * ai + 0]; Y[u] = coords[3 * ai + 1]; Z[u] = coords[3 * ai + 2];
+            }
         }
-        const double d2 = dx * dx + dy * dy + dz * dz;
-        if (d2 < CUTOFF2_A) {
-            const double x = sg / sqrt(d2);
-            const double x3 = x * x * x;
-            const double val = 1.0 - exp(-(x3 * x3 * x3 * x3));
-            if (val > best) best = val;
+#pragma unroll
+        for (int u = 0; u < EXACT_BATCH; ++u) {
+            const long long a = base + (long long)u * WAVE + lane;
+            bool near = FULL || a < a_hi;
+            if (affine == nullptr) {                                       // (an augmented call: every atom takes the exact path)
+                float fx = X[u] - fcx, fy = Y[u] - fcy, fz = Z[u] - fcz;
+                if (g.pbc) { fx -= fL[0] * mk_rint(fx * fiL[0]); fy -= fL[1] * mk_rint(fy * fiL[1]); fz -= fL[2] * mk_rint(fz * fiL[2]); }
+                near = near && (fx * fx + fy * fy + fz * fz <= 25.5f);     // far (or NaN: the reference's `d2 < 25` is false too)
+            }
+            const unsigned long long m = mk_ballot(near);
+            if (m == 0ull) continue;                                       // wave-uniform
+            if (near) s_near[cnt + (unsigned)mk_rank_in_mask(m)] = (unsigned)(a - a_lo);
+            cnt += (unsigned)mk_popc64(m);
         }
+        if (cnt > (unsigned)(EXACT_LIST - WAVE * EXACT_BATCH)) flush();   // (not inside the unrolled scan: the batch's 24 registers would live across it)
+    };
+    long long base = a_lo;
+    for (; base + (long long)WAVE * EXACT_BATCH <= a_hi; base += (long long)WAVE * EXACT_BATCH) scan(base, ExactFull<true>{});   // wave-uniform
+    for (; base < a_hi; base += (long long)WAVE * EXACT_BATCH) scan(base, ExactFull<false>{});
+    flush();
+#pragma unroll
+    for (int k = 0; k < EXACT_CH; ++k) {                                   // wave-uniform
+        if (k >= nch) break;
+        s_best[lane] = best[k];
+        mk_block_sync();
+        if (lane == 0) {
+            double m = s_best[0];
+            for (int j = 1; j < WAVE; ++j) m = s_best[j] > m ? s_best[j] : m;
+            const size_t vox = (size_t)b * (size_t)g.V + ((size_t)ix * g.ny + iy) * g.nz + iz;
+            out[vox * (size_t)g.C + (size_t)((chs >> (16 * k)) & 0xffffull)] = (float)m;
+        }
+        mk_block_sync();
     }
-    s_best[lane] = best;
-    mk_block_sync();
-    if (lane == 0) {
-        double m = s_best[0];
-        for (int j = 1; j < WAVE; ++j) m = s_best[j] > m ? s_best[j] : m;
-        const size_t vox = (size_t)b * (size_t)g.V + ((size_t)ix * g.ny + iy) * g.nz + iz;
-        out[vox * (size_t)g.C + (size_t)c] = (float)m;
-    }
-    mk_block_sync();
 }
 
 // The cut-off shell of ONE wide atom `a` of item `b` (all 64 lanes): every (voxel, wide channel) the shell passes is recomputed
@@ -2790,7 +2862,7 @@ template <typename SigT>
 MK_DEV void exact_fixup_atom(const GridDesc& g, const int b, const long long a, const long long srow, const float* __restrict__ coords,
                              const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                              const float* __restrict__ box, const double* __restrict__ affine, float* __restrict__ out, double* s_best,
-                             unsigned* __restrict__ feedback, unsigned seq)
+                             unsigned* s_near, unsigned* __restrict__ feedback, unsigned seq)
 {
     const int lane = threadIdx.x;
     const float wmax = g.w_exact_max;
@@ -2848,9 +2920,15 @@ MK_DEV void exact_fixup_atom(const GridDesc& g, const int b, const long long a, 
                     const int vx = (int)mk_readlane((unsigned)ix, hl), vy = (int)mk_readlane((unsigned)iy, hl);
                     const int vz = (int)mk_readlane((unsigned)(int)iz, hl);
                     if (feedback != nullptr && lane == 0) feedback[FB_TAIL_WROTE] = seq;   // (the host may have read the tile kernel's values already)
-                    for (int c = 0; c < g.C; ++c)                  // the atom's wide channels
-                        if (sigma_to_w(sigmas[(size_t)srow * g.C + c], g.w_scale) < wmax)
-                            exact_recompute<SigT>(g, b, vx, vy, vz, c, coords, atom_offsets, sigmas, origins, box, affine, out, s_best);
+                    unsigned long long chs = 0ull;                 // the atom's wide channels, EXACT_CH of them per pass over the item's atoms
+                    int nch = 0;
+                    for (int c = 0; c < g.C; ++c) {
+                        if (sigma_to_w(sigmas[(size_t)srow * g.C + c], g.w_scale) < wmax) { chs |= (unsigned long long)(c & 0xffff) << (16 * nch); ++nch; }
+                        if (nch == EXACT_CH || (c == g.C - 1 && nch)) {
+                            exact_recompute<SigT>(g, b, vx, vy, vz, chs, nch, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near);
+                            chs = 0ull; nch = 0;
+                        }
+                    }
                 }
             }
         }
@@ -2869,7 +2947,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
                               const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
                               long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                               const float* __restrict__ box, const double* __restrict__ affine,
-                              const uint2* __restrict__ tmp_cls, float* __restrict__ out, double* s_best,
+                              const uint2* __restrict__ tmp_cls, float* __restrict__ out, double* s_best, unsigned* s_near,
                               unsigned* __restrict__ feedback = nullptr, unsigned seq = 0u)
 {
     const int lane = threadIdx.x;
@@ -2882,7 +2960,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
         // an item that is not the topology's atom count long: the binning has raised MK_ERR_TOPOLOGY; nothing of the handle's
         // is indexed with it (the C API promises a clean MKAMD_EINVAL at the next synchronize, not a read past the handle)
         if (a_hi - a_lo != (long long)g.topo_n || k >= (long long)g.topo_n) return;
-        exact_fixup_atom<SigT>(g, b, a_lo + k, k, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, feedback, seq);
+        exact_fixup_atom<SigT>(g, b, a_lo + k, k, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near, feedback, seq);
         return;
     }
     // ---- the summary: is there anything wide among this wave's atoms at all? ----
@@ -2923,7 +3001,7 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
             const long long a = base + l;
             const int b = per_item ? (int)blk : item_of_atom(atom_offsets, g.B, a, b_hint);
             b_hint = b;
-            exact_fixup_atom<SigT>(g, b, a, a, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, feedback, seq);
+            exact_fixup_atom<SigT>(g, b, a, a, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near, feedback, seq);
         }
     }
 }
@@ -2953,6 +3031,7 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
                           unsigned fix_jobs /* fix-up jobs (256-atom blocks, or items): the fix-up waves share them */)
 {
     __shared__ double s_best[WAVE];
+    __shared__ unsigned s_near[EXACT_LIST];
     const unsigned n = dense_words[0], total_tiles = (unsigned)g.B * (unsigned)g.ntiles;
     if (blockIdx.x == 0) {
         if (threadIdx.x <= (unsigned)DENSE_WORDS + 1u) other_words[threadIdx.x] = 0u;  // (+ the done counter and the role tickets)
@@ -3008,7 +3087,7 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
     //  take several each start and drain faster than one wave per job -- 18 -> ~6 us per 256-grid step)
     for (unsigned job = role - dense_wgs; job < fix_jobs; job += gridDim.x - dense_wgs)
         exact_fixup_block<SigT>(g, job, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
-                                tmp_cls, out, s_best, feedback, seq);
+                                tmp_cls, out, s_best, s_near, feedback, seq);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ dev = torch.device("cuda", 0)
 ctx = _lib.default_context(0)
 ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 blocks = [int(b) for b in os.environ.get("PROBE_BLOCKS", "0,4,8,108,-1").split(",")]
-shapes = [(200, 15, 512), (200, 15, 2048), (100, 15, 512), (200, 8, 512), (200, 9, 512), (200, 24, 512), (400, 7, 512), (50, 15, 200)]
+shapes = [(200, 15, 512), (200, 15, 2048), (100, 15, 512), (200, 9, 512), (400, 7, 512), (50, 15, 200)]
 t = lambda a: torch.as_tensor(a, device=dev)
 for G, A, F in shapes:
     coords, box, atoms, offs, chains, masses = reduction_workload(G, A, F)
