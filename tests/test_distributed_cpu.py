@@ -135,6 +135,21 @@ def _worker8(rank, world, port, q):
     from tests.synth import grid_origin, synth_config
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # which lines of voxelize_gather this rank executes (the world-8 run has to ENTER every branch the 8-GPU line takes)
+    code = D.ShardedVoxelizer.voxelize_gather.__code__
+    lines = set()
+
+    def tracer(frame, event, arg):
+        if frame.f_code is not code:
+            return None
+
+        def local(fr, ev, a):
+            if ev == "line":
+                lines.add(fr.f_lineno)
+            return local
+        return local
+
+    sys.settrace(tracer)
     try:
         ok = True
         detail = []
@@ -161,10 +176,14 @@ def _worker8(rank, world, port, q):
                 ok = ok and sv.last_exchange == "p2p" and np.array_equal(got.numpy(), ref)
                 got = sv.voxelize_gather(nchunks=nchunks, exchange="allgather")
                 ok = ok and np.array_equal(got.numpy(), ref)
+                got = sv.voxelize_gather(nchunks=nchunks, dst=0)                # gather-to-root (padded collectives)
+                ok = ok and ((got is None) if rank else np.array_equal(got.numpy(), ref))
             ok = ok and np.array_equal(sv.voxelize().numpy(), ref[lo:hi])
             detail.append([int(b) for b in sv.bounds])
-        q.put((rank, bool(ok), detail))
+        sys.settrace(None)
+        q.put((rank, bool(ok), detail, sorted(lines)))
     finally:
+        sys.settrace(None)
         dist.destroy_process_group()
 
 
@@ -184,9 +203,36 @@ def test_sharded_voxelization_world8_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(ok for _, ok, _ in res), res
+    assert all(r[1] for r in res), [r[:3] for r in res]
     for b in res[0][2]:
         assert b[0] == 0 and len(b) == world + 1
+    # branch coverage of voxelize_gather over the eight ranks: every executable line was entered by some rank, except the ones that
+    # cannot run in this setting BY THEIR OWN TEXT (no process group, one rank's loopback, the CUDA-only stream plumbing, the argument check)
+    import inspect
+    from moleculekit_amd import distributed as D
+    fn = D.ShardedVoxelizer.voxelize_gather
+    src, first = inspect.getsourcelines(fn)
+    executable = {ln for _, _, ln in fn.__code__.co_lines() if ln is not None and ln > first}
+    hit = set().union(*[set(r[3]) for r in res])
+    allowed = ("return self.voxelize()", "ws == 1", "loopback", "check", "raise ValueError", "if cuda", "comm.wait_event", "torch.cuda.Event()", "ev.record(main)",
+               "main.wait_stream(comm)", "record_stream(comm)", "import torch")
+    missing = {ln: src[ln - first].strip() for ln in sorted(executable - hit)}
+
+    def explained(ln):
+        """the line itself, or the statement that controls it (the nearest line above with a smaller indentation), says why"""
+        i = ln - first
+        if any(a in src[i] for a in allowed):
+            return True
+        ind = len(src[i]) - len(src[i].lstrip())
+        for j in range(i - 1, 0, -1):
+            t = src[j]
+            if t.strip() and len(t) - len(t.lstrip()) < ind:
+                return any(a in t for a in allowed)
+        return False
+
+    unexplained = {ln: t for ln, t in missing.items() if not explained(ln)}
+    assert not unexplained, unexplained
+    assert len(hit) > 40, len(hit)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -597,7 +597,7 @@ def test_cfg4_full_count_streamed_from_xtc_device_decode_equals_host_decode(hip_
     the chunk sizes and both checksums of every chunk must agree; a sample of frames is also compared element by element."""
     import torch
     from moleculekit_amd import batch, xtc
-    import bench
+    from tools.benchlib import workloads as bench            # (the workload generators; bench.py itself is not needed)
     base = 128
     p, _, _ = bench.make_workload("cfg4", base, seed=4004)
     N = int(p["atom_offsets"][1])

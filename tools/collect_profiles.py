@@ -13,19 +13,34 @@ sys.path.insert(0, os.getcwd())
 import bench  # noqa: E402
 from moleculekit_amd import _build  # noqa: E402
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 SRC = _build.built_hash()
 os.makedirs("profiles", exist_ok=True)
 PROF = "--no-cpu-baseline --no-extra --no-single --min-seconds 0 --steps 8 --warmup 2"
-for name in ("cfg2", "cfg2_nopipe", "torchrun1", "dist"):
+for name in ("cfg2", "cfg2_nopipe", "torchrun1", "dist", "dist_torchrun1"):
     f = f"gpurun_out/bench_{name}.log"
     if os.path.exists(f):
         for line in open(f):
             if line.startswith("{"):
                 d = json.loads(line)
                 d["_library_src"] = SRC
+                err = f"gpurun_out/bench_{name}.err"
+                if os.path.exists(err):                      # the torchrun passes run with NCCL_DEBUG=WARN: what RCCL had to say
+                    warn = [l.strip()[:300] for l in open(err, errors="replace") if "NCCL WARN" in l or "NCCL ERROR" in l]
+                    d["_nccl_debug_warn_lines"] = warn[:20]
+                    d["_nccl_debug_warn_count"] = len(warn)
                 json.dump(d, open(f"profiles/{tag}_bench_{name}.json", "w"), indent=1)
                 break
+# the distance line of the TRACED pass (rocprofv3 --kernel-trace --stats with the burns): the fractions and clocks the stats file is compared with
+f = "gpurun_out/rocprof_dist.log"
+if os.path.exists(f):
+    for line in open(f, errors="replace"):
+        if line.startswith("{"):
+            d = json.loads(line)
+            d["_library_src"] = SRC
+            d["_note"] = "the bench line printed by the pass that profiles/%s_dist_rocprofv3_kernel_stats.csv was taken on" % tag
+            json.dump(d, open(f"profiles/{tag}_bench_dist_traced_pass.json", "w"), indent=1)
+            break
 for d in ("cfg2", "cfg2_nopipe", "cfg1", "cfg3", "cfg4", "cfg4_plain", "cfg5", "dist"):
     stats = sorted(glob.glob(f"gpurun_out/prof_{d}/*/*_kernel_stats.csv"), key=os.path.getmtime)
     if stats:
@@ -91,7 +106,18 @@ for mode in ("periodic", "nonperiodic"):
                 bench.DEFAULT_BATCH["dist"], f"--workload dist --no-cpu-baseline --steps 8 --warmup 2 (MKAMD_DIST_ONLY={mode})")
     if o:
         report(f"{tag}_dist_{mode}", o, ALG["dist"])
-for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"),
+o = collect(("reduction_sq1", "reduction_sq2"), f"{tag}_reduction_pmc_counters.json", 512,
+            "--workload dist --no-cpu-baseline --settle-seconds 0 --steps 4 --warmup 1 (MKAMD_DIST_ONLY=reduction)",
+            note_extra="  The group-reduction leg: 200 groups x 15 atoms x 512 frames, all 19 900 group pairs, periodic (tools/benchlib/distances.py::bench_reductions).")
+if o:
+    for k, v in o.items():
+        if isinstance(v, dict) and "k_dist_reduction_closest" in k and "SQ_INSTS_VALU" in v:
+            pairs = 200 * 199 // 2 * 225 * 512
+            clk = v["GRBM_GUI_ACTIVE"] / 8.0
+            print(f"{tag}_reduction: {k[:60]} VALU wave-instructions {v['SQ_INSTS_VALU']:.0f} = {v['SQ_INSTS_VALU'] * 64 / pairs:.2f} lane-instructions per atom pair; "
+                  f"VALU-busy {v['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / clk:.3f}")
+for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"), ("graph_latency.txt", "graph_latency.txt"),
+                 ("reduction_probe.txt", "reduction_probe.txt"),
                  ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_shapes_probe.txt", "dist_shapes_probe.txt"), ("random_sweeps.txt", "random_sweeps_final.txt"),
                  ("sqrt_exact.txt", "sqrt_exact.txt")):
     f = f"gpurun_out/{src}"

@@ -2,8 +2,8 @@
 # driver runs it) and its in-order twin, the torchrun 1-rank RCCL path, rocprofv3 kernel-trace stats of every workload the line reports, and PMC
 # passes for EVERY one of them (SQ counters + GRBM_GUI_ACTIVE, FETCH_SIZE and WRITE_SIZE in passes of their own, every launch a full batch).
 # tools/collect_profiles.py copies the summaries into profiles/<tag>_* and stamps them with the library's source hash (bench.py refuses
-# counters of another build).   usage: bash tools/gpu_evidence.sh r5
-TAG=${1:-r5}
+# counters of another build).   usage: bash tools/gpu_evidence.sh r6
+TAG=${1:-r6}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -17,7 +17,10 @@ for wl in cfg2 cfg1 cfg3 cfg4 cfg5; do
 done
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg2_nopipe -- python $R/bench.py $TRACE --no-pipeline > $R/gpurun_out/rocprof_cfg2_nopipe.log 2>&1)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg4_plain -- python $R/bench.py $TRACE --workload cfg4 --no-topology > $R/gpurun_out/rocprof_cfg4_plain.log 2>&1)
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dist -- python $R/bench.py --workload dist --no-cpu-baseline --settle-seconds 0 --steps 20 --warmup 3 > $R/gpurun_out/rocprof_dist.log 2>&1)
+# the distance trace WITH the untimed burns in front of every leg (round 6, VERDICT r5 item 3: a cold trace read 0.42 / 0.55 where the line says 0.52 / 0.68;
+# the burns are a few thousand warm launches of the same kernels, so the per-kernel averages of the stats file are the warm figures; the log holds the line of THIS
+# pass with the shader clock of every leg beside its roofline fraction)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dist -- python $R/bench.py --workload dist --no-cpu-baseline --steps 40 --warmup 5 > $R/gpurun_out/rocprof_dist.log 2>&1)
 pmc() { name=$1; wl=$2; shift; shift; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_${wl}_$name -- python $R/bench.py $PROF --workload $wl $PMC_EXTRA > $R/gpurun_out/pmc_${wl}_$name.log 2>&1); }
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_IFETCH"
@@ -40,7 +43,12 @@ for mode in periodic nonperiodic; do
   dpmc fetch $mode FETCH_SIZE
   dpmc write $mode WRITE_SIZE
 done
-# the one-molecule call: latencies, the host side of the drop-in call
+# the group-reduction leg alone (k_dist_reduction_closest): SQ counters in two passes
+rpmc() { name=$1; shift; (cd /tmp && MKAMD_DIST_ONLY=reduction timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_reduction_$name -- python $R/bench.py --workload dist --no-cpu-baseline --settle-seconds 0 --steps 4 --warmup 1 > $R/gpurun_out/pmc_reduction_$name.log 2>&1); }
+rpmc sq1 $SQ1
+rpmc sq2 $SQ2
+# the one-molecule call: latencies, the host side of the drop-in call, and the gated HIP-graph experiment
+(timeout 300 python tools/graph_latency.py > gpurun_out/graph_latency.txt 2>&1)
 (for i in 1 2 3; do timeout 120 python tools/single_latency.py; done > gpurun_out/single_latency.txt 2>&1)
 (timeout 200 python tools/dropin_profile.py > gpurun_out/dropin_profile.txt 2>&1)
 # dist_trajectory at the shapes the projections call it with, under every kernel choice
@@ -49,14 +57,15 @@ done
 (timeout 600 python tests/sweep_gpu_random.py 9000 600; MKAMD_TILE_ITEMS=1 timeout 300 python tests/sweep_gpu_random.py 9600 200; timeout 600 python tests/sweep_gpu_dist.py 0 600) > gpurun_out/random_sweeps.txt 2>&1
 # the device XTC decoder: kernels alone per chunk size
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
-(timeout 120 tools/store_pattern > gpurun_out/store_pattern.txt 2>&1)
-(timeout 60 tools/sqrt_exact > gpurun_out/sqrt_exact.txt 2>&1)
+(timeout 600 python tools/reduction_probe.py > gpurun_out/reduction_probe.txt 2>&1)
 grep -a "cutoff shell" gpurun_out/pytest_gpu.log | sort -u; tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
 python tools/collect_profiles.py $TAG > /dev/null      # the PMC summaries of THIS build first: the bench lines below then carry roofline.traffic
 # the bench lines proper (the default one exactly as the driver runs it), after the counters so that they can quote them
 (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_cfg2.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2.log)
 (timeout 400 python bench.py --no-cpu-baseline --no-extra --no-pipeline --min-seconds 1 > gpurun_out/bench_cfg2_nopipe.log 2>&1; echo "rc=$?" >> gpurun_out/bench_cfg2_nopipe.log)
-(timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2>&1; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
+# one rank under torchrun: every collective an N-rank run issues runs on RCCL once (bench.py: collectives_exercised), RCCL's warnings captured
+(NCCL_DEBUG=WARN timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/bench_torchrun1.log 2> gpurun_out/bench_torchrun1.err; echo "rc=$?" >> gpurun_out/bench_torchrun1.log)
+(NCCL_DEBUG=WARN timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --workload dist --gpus 1 --steps 10 --warmup 3 > gpurun_out/bench_dist_torchrun1.log 2> gpurun_out/bench_dist_torchrun1.err; echo "rc=$?" >> gpurun_out/bench_dist_torchrun1.log)
 (timeout 400 python bench.py --workload dist --steps 20 --warmup 3 > gpurun_out/bench_dist.log 2>&1; echo "rc=$?" >> gpurun_out/bench_dist.log)
 python tools/collect_profiles.py $TAG
 # gpurun merges at most 64 MiB back: the per-launch traces are not needed once the stats / counter tables exist

@@ -1,18 +1,17 @@
-# round 6, session 7: k_tail with the batched, listed exact_recompute (8 ions: 0.41-0.5 ms at first, 0.30 with the pre-test alone)
+# round 6, session 8: the HIP-graph experiment, the RCCL collectives under torchrun with one rank (NCCL_DEBUG=WARN), the split bench.py
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-(timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_api.py tests/test_gpu_random.py -m gpu -q -x 2>&1 | tail -3)
-(timeout 900 python tools/topology_wide_ab.py > gpurun_out/s7_topology_wide_ab.txt 2>&1); cat gpurun_out/s7_topology_wide_ab.txt
-for only in 8 300; do
-rm -rf gpurun_out/prof_topo_wide_$only
-(cd /tmp && AB_ONLY=$only timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_topo_wide_$only -- python $R/tools/topology_wide_ab.py > $R/gpurun_out/s7_rocprof_topo_wide_$only.log 2>&1)
-python - <<PY
-import csv, glob
-for f in glob.glob("gpurun_out/prof_topo_wide_$only/*/*kernel_stats.csv"):
-    for r in csv.DictReader(open(f)):
-        if "k_tail" in r["Name"]:
-            print("$only wide atoms:", r["Name"][:40], r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"])
+(timeout 300 python tools/graph_latency.py > gpurun_out/s8_graph_latency.txt 2>&1); grep -v amdgpu.ids gpurun_out/s8_graph_latency.txt | tail -8
+(NCCL_DEBUG=WARN timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 > gpurun_out/s8_bench_torchrun1.log 2> gpurun_out/s8_bench_torchrun1.err; echo "rc=$?" >> gpurun_out/s8_bench_torchrun1.log)
+python - <<'PY'
+import json
+for l in open("gpurun_out/s8_bench_torchrun1.log"):
+    if l.startswith("{"):
+        d = json.loads(l)
+        print({k: d.get(k) for k in ("value", "ms_per_step", "gather_ms", "gather_overlapped_extra_ms", "gather_exchange", "gather_error", "collectives_exercised", "ranks_alive")})
 PY
-done
-find gpurun_out -name "*_kernel_trace.csv" -size +1M -delete
+tail -1 gpurun_out/s8_bench_torchrun1.log; grep -c "NCCL WARN" gpurun_out/s8_bench_torchrun1.err; grep "NCCL WARN" gpurun_out/s8_bench_torchrun1.err | head -5
+(NCCL_DEBUG=WARN timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --workload dist --gpus 1 --steps 10 --warmup 3 > gpurun_out/s8_bench_dist_torchrun1.log 2> gpurun_out/s8_bench_dist_torchrun1.err; echo "rc=$?" >> gpurun_out/s8_bench_dist_torchrun1.log)
+tail -2 gpurun_out/s8_bench_dist_torchrun1.log | cut -c1-1200; grep -c "NCCL WARN" gpurun_out/s8_bench_dist_torchrun1.err
+(timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra > gpurun_out/s8_bench_cfg2.log 2>&1; echo "rc=$?" >> gpurun_out/s8_bench_cfg2.log); tail -2 gpurun_out/s8_bench_cfg2.log | cut -c1-900

@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from moleculekit_amd import _lib
-from bench import reduction_workload
+from tools.benchlib.workloads import reduction_workload
 
 dev = torch.device("cuda", 0)
 ctx = _lib.default_context(0)
