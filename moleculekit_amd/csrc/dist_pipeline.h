@@ -298,6 +298,10 @@ int run_cdist(BE& be, const float* c1, long long n1, const float* c2, long long 
 {
     if (n1 < 0 || n2 < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
     if (n1 == 0 || n2 == 0) return ST_OK;
+    if ((D == 2 || D == 3) && ceil_div(n1, CD_ROWS) <= 65535) {     // coordinates: four second points per lane in registers, 16-byte stores
+        const dim3 grid((unsigned)ceil_div(n2, 256 * CD_JPL), (unsigned)ceil_div(n1, CD_ROWS));
+        return D == 3 ? be.launch(k_cdist_rows<3>, grid, dim3(256), c1, n1, c2, n2, out) : be.launch(k_cdist_rows<2>, grid, dim3(256), c1, n1, c2, n2, out);
+    }
     return be.launch(k_cdist, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), c1, n1, c2, n2, D, out);
 }
 
@@ -306,6 +310,10 @@ int run_pdist(BE& be, const float* c, long long n, int D, float* out, std::strin
 {
     if (n < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
     if (n < 2) return ST_OK;
+    if ((D == 2 || D == 3) && ceil_div(n, CD_ROWS) <= 65535) {
+        const dim3 grid((unsigned)ceil_div(n, 256 * CD_JPL), (unsigned)ceil_div(n, CD_ROWS));
+        return D == 3 ? be.launch(k_pdist_rows<3>, grid, dim3(256), c, n, out) : be.launch(k_pdist_rows<2>, grid, dim3(256), c, n, out);
+    }
     return be.launch(k_pdist, dim3((unsigned)ceil_div(n, 256), (unsigned)std::min<long long>(n, 65535)), dim3(256), c, n, D, out);
 }
 

@@ -28,6 +28,9 @@ import os
 import numpy as np
 
 
+P2P_MAX_BYTES = 1 << 30        # largest single point-to-point message voxelize_gather posts (see there)
+
+
 def world(group=None):
     """(rank, world_size) from torch.distributed if initialised, else from the torchrun env."""
     try:
@@ -342,6 +345,13 @@ class ShardedVoxelizer:
             # transfer know its size from the partition, an empty chunk is skipped by both)
             full = torch.empty((self.n_items,) + tail, dtype=torch.float32, device=self.device)
             row = lambda r, c: int(self.bounds[r] + cb[r][c])
+            # one message holds at most P2P_MAX_BYTES: a 2 GiB send (256 cfg2 grids in ONE chunk) came back different from RCCL's
+            # one-rank loopback (round 6, profiles/r6_bench_torchrun1.json) -- a byte count that no longer fits 31 bits.  Both ends
+            # of a transfer cut the same rows the same way.
+            rows_per_msg = max(1, P2P_MAX_BYTES // max(1, self.V * self.C * 4))
+
+            def pieces(r0, r1):
+                return [(a, min(a + rows_per_msg, r1)) for a in range(r0, r1, rows_per_msg)]
             for c in range(len(cb[rank]) - 1):
                 lo, hi = int(cb[rank][c]), int(cb[rank][c + 1])
                 if hi > lo:
@@ -359,15 +369,19 @@ class ShardedVoxelizer:
                     for k in range(1, ws):                                # staggered peers: rank r starts with r + 1
                         to, frm = (rank + k) % ws, (rank - k) % ws
                         if hi > lo:
-                            ops.append(dist.P2POp(dist.isend, full[row(rank, c):row(rank, c + 1)], self._global_rank(to), group=self.group))
+                            for a, b in pieces(row(rank, c), row(rank, c + 1)):
+                                ops.append(dist.P2POp(dist.isend, full[a:b], self._global_rank(to), group=self.group))
                         if cb[frm][c + 1] > cb[frm][c]:
-                            ops.append(dist.P2POp(dist.irecv, full[row(frm, c):row(frm, c + 1)], self._global_rank(frm), group=self.group))
+                            for a, b in pieces(row(frm, c), row(frm, c + 1)):
+                                ops.append(dist.P2POp(dist.irecv, full[a:b], self._global_rank(frm), group=self.group))
                     if ws == 1 and hi > lo:
                         # one rank (a 1-GPU box under torchrun): the same batched send / receive, to itself, into a scratch
                         # tensor that must come back equal -- the exchange code touches the communicator at least once
                         check = torch.empty_like(full[row(rank, c):row(rank, c + 1)])
-                        ops = [dist.P2POp(dist.isend, full[row(rank, c):row(rank, c + 1)], self._global_rank(rank), group=self.group),
-                               dist.P2POp(dist.irecv, check, self._global_rank(rank), group=self.group)]
+                        ops = []
+                        for a, b in pieces(row(rank, c), row(rank, c + 1)):
+                            ops.append(dist.P2POp(dist.isend, full[a:b], self._global_rank(rank), group=self.group))
+                            ops.append(dist.P2POp(dist.irecv, check[a - row(rank, c):b - row(rank, c)], self._global_rank(rank), group=self.group))
                     if ops:
                         for req in dist.batch_isend_irecv(ops):
                             req.wait()

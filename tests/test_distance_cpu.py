@@ -431,3 +431,19 @@ def test_closest_reduction_kernel_nan_and_infinite_semantics():
             for block in (4, 8, -1):
                 got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0, block=block)
                 assert np.array_equal(got, want, equal_nan=True), (pbc, block)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_cdist_pdist_row_kernels_ragged_edges_bit_exact(D):
+    """Round 6: k_cdist_rows / k_pdist_rows (four second points per lane, 16-byte stores at any alignment): several blocks along both
+    axes, row lengths that are not multiples of four, blocks that the diagonal of the condensed triangle crosses; the oracle's bits."""
+    rng = np.random.default_rng(40 + D)
+    a = rng.normal(0, 15, size=(37, D)).astype(np.float32)
+    b = rng.normal(0, 15, size=(1031, D)).astype(np.float32)
+    assert np.array_equal(E.cdist(a, b), oracle.cdist(a, b))
+    assert np.array_equal(E.cdist(b[:5], a[:3]), oracle.cdist(b[:5], a[:3]))
+    c = rng.normal(0, 15, size=(1100, D)).astype(np.float32)
+    c[7] = c[3]                                                  # a zero distance
+    assert np.array_equal(E.pdist(c), oracle.pdist(c))
+    for n in (2, 3, 5, 1025):
+        assert np.array_equal(E.pdist(c[:n]), oracle.pdist(c[:n])), n

@@ -561,3 +561,20 @@ def test_device_contact_list_equals_the_host_form_on_a_larger_call():
     _lib._check(_lib.load().mkamd_copy_to_host(ctx._h, flat.ctypes.data, ptr, flat.nbytes))
     got = [flat[2 * offs[f]:2 * offs[f + 1]].astype(np.int64).tolist() for f in range(F)]
     assert got == want and n > 1000
+
+
+@pytest.mark.parametrize("D", [2, 3, 4])
+def test_cdist_pdist_at_size_bit_exact(D):
+    """cdist / pdist at sizes that take thousands of blocks of the row kernels (D = 2, 3) and the generic kernels (D = 4): the oracle's
+    bits, odd row lengths (16-byte stores at 4-byte alignment), through the host forms."""
+    from moleculekit_amd.distance_utils import cdist, pdist
+    rng = np.random.default_rng(50 + D)
+    a = rng.normal(0, 25, size=(300, D)).astype(np.float32)
+    b = rng.normal(0, 25, size=(4099, D)).astype(np.float32)
+    r = np.zeros((300, 4099), np.float32)
+    cdist(a, b, r)
+    assert np.array_equal(r, oracle.cdist(a, b))
+    c = rng.normal(0, 25, size=(3001, D)).astype(np.float32)
+    r = np.zeros(3001 * 3000 // 2, np.float32)
+    pdist(c, r)
+    assert np.array_equal(r, oracle.pdist(c))

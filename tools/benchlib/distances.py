@@ -184,6 +184,7 @@ def bench_distances(args, emit=True):
         line["selfdist"] = shape_leg(s2[:450].copy(), s2[:450].copy(), True, check)
         line["small_call"] = shape_leg(s2[:300].copy(), s1[:30].copy(), False, check)
         # ---- round 6: the group reductions (MetricDistance's residue contact maps) and the device-side contact lists ----
+        line["cdist_pdist"] = bench_cdist_pdist(args, ctx, dev, busy, check)
         line["reduction"] = bench_reductions(args, ctx, dev, busy, check)
         line["contacts"] = bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s1, s2, d1, d2, F)
     del coords, out
@@ -265,6 +266,47 @@ def bench_reductions(args, ctx, dev, busy, check, only_periodic=False):
     pmc = reduction_pmc()
     if pmc:
         res["periodic"]["valu"].update(pmc)
+    return res
+
+
+def bench_cdist_pdist(args, ctx, dev, busy, check):
+    """cdist / pdist (distance_utils.pyx:355-416) on device pointers: 8 192 x 8 192 points in 3-D (268 MB of result) and the condensed
+    upper triangle of 16 384 points (537 MB) -- store-bound: algorithmic bytes = the result once + the points once."""
+    import torch
+    rng = np.random.default_rng(12)
+    n1 = n2 = 8192
+    a = rng.normal(0, 20, size=(n1, 3)).astype(np.float32)
+    b = rng.normal(0, 20, size=(n2, 3)).astype(np.float32)
+    np_ = 16384
+    c = rng.normal(0, 20, size=(np_, 3)).astype(np.float32)
+    d_a, d_b, d_c = (torch.as_tensor(x, device=dev) for x in (a, b, c))
+    out_c = torch.empty((n1, n2), device=dev, dtype=torch.float32)
+    out_p = torch.empty((np_ * (np_ - 1) // 2,), device=dev, dtype=torch.float32)
+    res = {}
+    for name, call, alg, out in (("cdist", lambda: ctx.cdist_dev(d_a, n1, d_b, n2, 3, out_c), n1 * n2 * 4 + (n1 + n2) * 12, out_c),
+                                 ("pdist", lambda: ctx.pdist_dev(d_c, np_, 3, out_p), np_ * (np_ - 1) // 2 * 4 + np_ * 12, out_p)):
+        busy(call, 0.2)
+        for _ in range(max(3, args.warmup)):
+            call()
+        torch.cuda.synchronize(dev)
+        if check:
+            from oracle import oracle
+            if name == "cdist":
+                ok = np.array_equal(out[:64].cpu().numpy(), oracle.cdist(a[:64], b))
+            else:
+                ok = np.array_equal(out[:np_ - 1].cpu().numpy(), oracle.cdist(c[:1], c[1:])[0])      # row 0 of the triangle
+            if not ok:
+                raise SystemExit(f"{name} on the GPU is not bit-exact with the oracle")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            call()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / args.steps
+        res[name] = {"shape": f"{n1} x {n2} x 3" if name == "cdist" else f"{np_} points x 3", "us_per_call": round(ms * 1e3, 2),
+                     "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                  "algorithmic_bytes_per_launch": alg}, "kernel": "mkamd::k_" + name}
     return res
 
 
@@ -405,6 +447,8 @@ def bench_distances_sharded(args, dry=False):
     # the gather of the rows (after everything timed: the first RCCL collective of the process builds the communicator)
     if use_dist and not args.no_gather:
         def legs():
+            fence()
+            full = sd.gather(out)                  # (the first collective of a process also builds the communicator)
             fence()
             g0 = time.perf_counter()
             full = sd.gather(out)
