@@ -306,7 +306,7 @@ def bench_cdist_pdist(args, ctx, dev, busy, check):
         ms = e0.elapsed_time(e1) / args.steps
         res[name] = {"shape": f"{n1} x {n2} x 3" if name == "cdist" else f"{np_} points x 3", "us_per_call": round(ms * 1e3, 2),
                      "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
-                                  "algorithmic_bytes_per_launch": alg}, "kernel": "mkamd::k_" + name}
+                                  "algorithmic_bytes_per_launch": alg}, "kernel": "mkamd::k_" + name + "_rows<3>"}
     return res
 
 
