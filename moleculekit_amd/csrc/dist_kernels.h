@@ -1188,23 +1188,52 @@ MK_KERNEL(256) void k_cdist_rows(const float* __restrict__ c1, long long n1, con
     }
 }
 
-// the condensed upper triangle: row i holds the n - 1 - i pairs (i, j > i) from offset i (n - 1) - i (i - 1) / 2 on
+// the condensed upper triangle: row i holds the n - 1 - i pairs (i, j > i) from offset i (n - 1) - i (i - 1) / 2 on.
+// A row starts wherever the rows before it end, so four consecutive pairs of a lane would be stored at any 4-byte offset (first version:
+// 0.41 of the roofline against cdist's 0.73 -- every store instruction of a wave straddles one line more and leaves two of them partly
+// written).  Here a lane's four pairs are chosen PER ROW so that their 16 bytes are 16-byte aligned in the result: with s = (row offset)
+// mod 4 -- the same for the whole block -- lane q takes the second points 4 q - s .. 4 q - s + 3; it keeps the seven points
+// 4 q - 3 .. 4 q + 3 in registers and a block-uniform switch picks the four.
+template <int D, int S>
+MK_DEV void pd_row_shifted(const float* __restrict__ a, const float (&p7)[CD_JPL + 3][D], float (&r)[CD_JPL])
+{
+    float p[CD_JPL][D];
+#pragma unroll
+    for (int u = 0; u < CD_JPL; ++u)
+#pragma unroll
+        for (int k = 0; k < D; ++k) p[u][k] = p7[u + 3 - S][k];
+    cd_row<D>(a, p, r);
+}
+
 template <int D>
 MK_KERNEL(256) void k_pdist_rows(const float* __restrict__ c, long long n, float* __restrict__ out)
 {
-    const long long jb = (long long)blockIdx.x * blockDim.x * CD_JPL;                                  // the block's first second point
+    const long long qb = (long long)blockIdx.x * blockDim.x;                                           // the block's first quad of second points
     const long long i0 = (long long)blockIdx.y * CD_ROWS, i1 = i0 + CD_ROWS < n ? i0 + CD_ROWS : n;
-    if (jb + (long long)blockDim.x * CD_JPL - 1 <= i0) return;       // block-uniform: entirely on or below the diagonal
-    const long long j0 = jb + (long long)threadIdx.x * CD_JPL;
-    const long long jw = jb + (long long)(threadIdx.x & ~(WAVE - 1)) * CD_JPL;                         // the wave's first second point
-    if (jw >= n) return;                                             // wave-uniform
-    float p[CD_JPL][D];
-    cd_load_points<D>(c, n, j0 < n ? j0 : n - 1, p);
+    if ((qb + blockDim.x) * CD_JPL - 1 <= i0) return;                // block-uniform: entirely on or below the diagonal
+    const long long qw = qb + (long long)(threadIdx.x & ~(WAVE - 1));                                  // the wave's first quad
+    if (qw * CD_JPL - 3 >= n) return;                                // wave-uniform
+    const long long q = qb + threadIdx.x;
+    float p7[CD_JPL + 3][D];
+#pragma unroll
+    for (int u = 0; u < CD_JPL + 3; ++u) {
+        long long j = q * CD_JPL - 3 + u;
+        j = j < 0 ? 0 : (j < n ? j : n - 1);                          // (outside the list: a valid point, never stored)
+#pragma unroll
+        for (int k = 0; k < D; ++k) p7[u][k] = c[j * D + k];
+    }
     for (long long i = i0; i < i1; ++i) {                            // block-uniform
-        float r[CD_JPL];
-        cd_row<D>(c + i * D, p, r);
         const long long row = i * (n - 1) - i * (i - 1) / 2 - i - 1; // out[row + j] is the pair (i, j)
-        if (j0 > i && j0 + CD_JPL <= n) mk_store_f4_dword_aligned(out + row + j0, make_float4(r[0], r[1], r[2], r[3]));
+        const int s = (int)(((row % 4) + 4) % 4);                    // block-uniform: (row + 4 q - s) is a multiple of 4
+        const long long j0 = q * CD_JPL - s;
+        float r[CD_JPL];
+        switch (s) {
+        case 0: pd_row_shifted<D, 0>(c + i * D, p7, r); break;
+        case 1: pd_row_shifted<D, 1>(c + i * D, p7, r); break;
+        case 2: pd_row_shifted<D, 2>(c + i * D, p7, r); break;
+        default: pd_row_shifted<D, 3>(c + i * D, p7, r); break;
+        }
+        if (j0 > i && j0 + CD_JPL <= n) *reinterpret_cast<float4*>(out + row + j0) = make_float4(r[0], r[1], r[2], r[3]);   // (16-byte aligned when `out` is)
         else
 #pragma unroll
             for (int u = 0; u < CD_JPL; ++u) if (j0 + u > i && j0 + u < n) out[row + j0 + u] = r[u];

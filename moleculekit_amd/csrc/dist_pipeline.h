@@ -310,8 +310,8 @@ int run_pdist(BE& be, const float* c, long long n, int D, float* out, std::strin
 {
     if (n < 0 || D < 0) { err = "negative size"; return ST_EINVAL; }
     if (n < 2) return ST_OK;
-    if ((D == 2 || D == 3) && ceil_div(n, CD_ROWS) <= 65535) {
-        const dim3 grid((unsigned)ceil_div(n, 256 * CD_JPL), (unsigned)ceil_div(n, CD_ROWS));
+    if ((D == 2 || D == 3) && ceil_div(n, CD_ROWS) <= 65535 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {   // (a result that is 16-byte aligned: the row kernel's stores are)
+        const dim3 grid((unsigned)ceil_div(n + 3, 256 * CD_JPL), (unsigned)ceil_div(n, CD_ROWS));
         return D == 3 ? be.launch(k_pdist_rows<3>, grid, dim3(256), c, n, out) : be.launch(k_pdist_rows<2>, grid, dim3(256), c, n, out);
     }
     return be.launch(k_pdist, dim3((unsigned)ceil_div(n, 256), (unsigned)std::min<long long>(n, 65535)), dim3(256), c, n, D, out);

@@ -15,7 +15,6 @@ REF_BUILD = os.environ.get("MOLECULEKIT_REF_BUILD", "/tmp/mkbuild")
 OUT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REF_BUILD)
 from moleculekit import distance_utils as du  # noqa: E402
-from moleculekit.periodictable import periodictable  # noqa: E402
 import json  # noqa: E402
 
 
@@ -91,8 +90,6 @@ def main():
     out["squareform"] = np.array(du.squareform(out["pdist_r3"]))
     np.savez_compressed(os.path.join(OUT, "distance_cases.npz"), **out)
     print("wrote distance_cases.npz", os.path.getsize(os.path.join(OUT, "distance_cases.npz")) // 1024, "KiB")
-    with open(os.path.join(OUT, "element_masses.json"), "w") as f:
-        json.dump({k: v.mass for k, v in periodictable.items()}, f, indent=0, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -124,36 +124,35 @@ def test_ragged_runs_zero_box_and_contact_lists_against_oracle():
             assert lists[f] == [int(v) for k in hits for v in table[k]]
 
 
-def test_metricdistance_style_drivers():
-    """pp_calcDistances / get_reduced_distances / calculate_contacts (projections/util.py, distance.py) on a duck-typed
-    molecule, incl. the analytic 2 A-box case in the spirit of tests/test_metricdistance.py:99-135."""
-    from moleculekit_amd.distance import calculate_contacts, get_reduced_distances, pp_calcDistances
-
-    class M:
-        pass
-    m = M()
-    m.coords = np.zeros((4, 3, 2), np.float32)
-    m.coords[1, 0, :] = 1.5; m.coords[2, 1, :] = 0.5; m.coords[3, 2, 1] = 1.75
-    m.box = np.full((3, 2), 2.0, np.float32)
-    m.chain = np.array(["A", "B", "B", "C"]); m.element = np.array(["C", "N", "O", "C"])
-    m.numAtoms, m.numFrames = 4, 2
-    s1 = np.array([True, False, False, False]); s2 = np.array([False, True, True, True])
-    d = pp_calcDistances(m, s1, s2, None)
+def test_analytic_two_angstrom_box_case():
+    """The analytic 2 A-box case in the spirit of tests/test_metricdistance.py:99-135, through the distance_utils functions themselves
+    with the arguments the reference's drivers build (projections/util.py:24-70: chains digitized by chain or by selection, a zero box
+    and pbc = False for periodic=None): wrapped and unwrapped distances, the closest-atom and centre-of-mass reductions, contact lists."""
+    from moleculekit_amd import distance_utils as du
+    coords = np.zeros((4, 3, 2), np.float32)
+    coords[1, 0, :] = 1.5; coords[2, 1, :] = 0.5; coords[3, 2, 1] = 1.75
+    box = np.full((3, 2), 2.0, np.float32)
+    by_chain = np.array([0, 1, 1, 2], np.uint32)                       # chains A, B, B, C
+    s1, s2 = np.array([0], np.uint32), np.array([1, 2, 3], np.uint32)
+    d = np.zeros((2, 3), np.float32)
+    du.dist_trajectory(coords, np.zeros_like(box), s1, s2, np.zeros(4, np.uint32), False, False, d)           # periodic=None
     assert np.allclose(d, [[1.5, 0.5, 0.0], [1.5, 0.5, 1.75]])
-    d = pp_calcDistances(m, s1, s2, "chains")
+    du.dist_trajectory(coords, box, s1, s2, by_chain, False, True, d)                                         # periodic="chains"
     assert np.allclose(d, [[0.5, 0.5, 0.0], [0.5, 0.5, 0.25]])
-    assert pp_calcDistances(m, s1, s2, "selections", metric="contacts", threshold=0.4).tolist() == [[False, False, True], [False, False, True]]
-    red = get_reduced_distances(m, s1, np.array([[False, True, True, False], [False, False, False, True]]), "chains")
+    by_sel = np.array([1, 2, 2, 2], np.uint32)                          # periodic="selections"
+    du.dist_trajectory(coords, box, s1, s2, by_sel, False, True, d)
+    assert (d <= 0.4).tolist() == [[False, False, True], [False, False, True]]
+    masses = np.array([12.011, 14.0067, 15.9994, 12.011], np.float32)
+    red = np.zeros((2, 2), np.float32)
+    du.dist_trajectory_reduction(coords, box, [[0]], [[1, 2], [3]], np.array([0], np.uint32), np.array([1, 2], np.uint32), False, True, masses, 0, 0, red)
     assert np.allclose(red, [[0.5, 0.0], [0.5, 0.25]])
-    com = get_reduced_distances(m, s1, np.array([[False, True, True, False]]), None, reduction2="com")
-    w = np.array([14.0067, 15.9994], np.float32)
+    com = np.zeros((2, 1), np.float32)
+    du.dist_trajectory_reduction(coords, np.zeros_like(box), [[0]], [[1, 2]], np.zeros(1, np.uint32), np.zeros(1, np.uint32), False, False, masses, 0, 1, com)
+    w = masses[1:3]
     cx, cy = 1.5 * w[0] / w.sum(), 0.5 * w[1] / w.sum()
     assert np.allclose(com, np.sqrt(cx * cx + cy * cy), atol=1e-6)
-    con = calculate_contacts(m, s1, s2, "chains", threshold=0.3)
-    assert [c.tolist() for c in con] == [[[0, 3]], [[0, 3]]]
-    with pytest.raises(RuntimeError):
-        m.box = np.zeros((3, 2), np.float32)
-        pp_calcDistances(m, s1, s2, "chains")
+    con = du.contacts_trajectory(coords, box, s1, s2, by_chain, False, True, 0.3)
+    assert con == [[0, 3], [0, 3]]
 
 
 def test_image_shift_at_the_half_box_boundary_is_bit_exact():
