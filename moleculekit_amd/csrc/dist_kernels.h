@@ -732,16 +732,18 @@ MK_KERNEL(DT_THREADS) void k_contacts_count(const float* __restrict__ coords, lo
     }
 }
 
-// one block per 64-frame slab: lanes = frames, the 4 waves split the tile range; in-place exclusive prefix over the
-// tiles of every frame, totals[frame] = its number of contacts
-MK_KERNEL(DT_THREADS) void k_contacts_scan(unsigned* __restrict__ cnt, long long tiles, long long fc_pad,
-                                           unsigned long long* __restrict__ totals)
+// one block per 64-frame slab: lanes = frames, the block's CS_WAVES waves split the tile range; in-place exclusive prefix over the
+// tiles of every frame, totals[frame] = its number of contacts.  (Round 6: sixteen waves instead of four -- with 1 563 tiles a wave
+// walked 390 of them twice, one dependent load after the other: 134 us of a 370-us contacts call, profiles/r6_dist_rocprofv3_kernel_stats.csv.)
+constexpr int CS_WAVES = 16;
+MK_KERNEL(CS_WAVES * WAVE) void k_contacts_scan(unsigned* __restrict__ cnt, long long tiles, long long fc_pad,
+                                                unsigned long long* __restrict__ totals)
 {
-    __shared__ unsigned long long s_seg[DT_THREADS / DT][DT];
+    __shared__ unsigned long long s_seg[CS_WAVES][DT];
     const int fl = threadIdx.x & (DT - 1), w = threadIdx.x >> 6;
-    constexpr int NW = DT_THREADS / DT;
+    constexpr int NW = CS_WAVES;
     const long long lf = (long long)blockIdx.x * DT + fl;
-    const long long per = (tiles + NW - 1) / NW, t0 = w * per, t1 = t0 + per < tiles ? t0 + per : tiles;
+    const long long per = (tiles + NW - 1) / NW, t0 = w * per < tiles ? w * per : tiles, t1 = t0 + per < tiles ? t0 + per : tiles;
     unsigned long long sum = 0;
     for (long long t = t0; t < t1; ++t) sum += cnt[(size_t)t * fc_pad + lf];
     s_seg[w][fl] = sum;

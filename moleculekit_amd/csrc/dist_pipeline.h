@@ -277,7 +277,7 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
         if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
                             (const unsigned*)wr, P, thr2, (unsigned*)cnt, (unsigned short*)msk))) return st;
-        if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(DT_THREADS), (unsigned*)cnt, tiles, fc_pad,
+        if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(CS_WAVES * WAVE), (unsigned*)cnt, tiles, fc_pad,
                             (unsigned long long*)tot))) return st;
         if ((st = be.to_host(totals.data(), tot, (size_t)fc_pad * 8))) return st;
         unsigned long long run = 0;

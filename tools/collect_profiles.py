@@ -31,17 +31,18 @@ for name in ("cfg2", "cfg2_nopipe", "torchrun1", "dist", "dist_torchrun1"):
                     d["_nccl_debug_warn_count"] = len(warn)
                 json.dump(d, open(f"profiles/{tag}_bench_{name}.json", "w"), indent=1)
                 break
-# the distance line of the TRACED pass (rocprofv3 --kernel-trace --stats with the burns): the fractions and clocks the stats file is compared with
-f = "gpurun_out/rocprof_dist.log"
-if os.path.exists(f):
-    for line in open(f, errors="replace"):
-        if line.startswith("{"):
-            d = json.loads(line)
-            d["_library_src"] = SRC
-            d["_note"] = "the bench line printed by the pass that profiles/%s_dist_rocprofv3_kernel_stats.csv was taken on" % tag
-            json.dump(d, open(f"profiles/{tag}_bench_dist_traced_pass.json", "w"), indent=1)
-            break
-for d in ("cfg2", "cfg2_nopipe", "cfg1", "cfg3", "cfg4", "cfg4_plain", "cfg5", "dist"):
+# the distance lines of the TRACED passes (rocprofv3 --kernel-trace --stats with the burns): the fractions and clocks the stats files are compared with
+for log, what in (("rocprof_dist.log", "dist"), ("rocprof_reduction.log", "reduction")):
+    f = "gpurun_out/" + log
+    if os.path.exists(f):
+        for line in open(f, errors="replace"):
+            if line.startswith("{"):
+                d = json.loads(line)
+                d["_library_src"] = SRC
+                d["_note"] = "the bench line printed by the pass that profiles/%s_%s_rocprofv3_kernel_stats.csv was taken on" % (tag, what)
+                json.dump(d, open(f"profiles/{tag}_bench_{what}_traced_pass.json", "w"), indent=1)
+                break
+for d in ("cfg2", "cfg2_nopipe", "cfg1", "cfg3", "cfg4", "cfg4_plain", "cfg5", "dist", "reduction"):
     stats = sorted(glob.glob(f"gpurun_out/prof_{d}/*/*_kernel_stats.csv"), key=os.path.getmtime)
     if stats:
         shutil.copy(stats[-1], f"profiles/{tag}_{d}_rocprofv3_kernel_stats.csv")

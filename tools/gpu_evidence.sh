@@ -43,7 +43,9 @@ for mode in periodic nonperiodic; do
   dpmc fetch $mode FETCH_SIZE
   dpmc write $mode WRITE_SIZE
 done
-# the group-reduction leg alone (k_dist_reduction_closest): SQ counters in two passes
+# the group-reduction leg alone (k_dist_reduction_closest, periodic, the default block): a trace WITH its burn -- every launch of the pass is the same call, so the
+# stats file's average is the leg's kernel time -- and SQ counters in two passes
+(cd /tmp && MKAMD_DIST_ONLY=reduction timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_reduction -- python $R/bench.py --workload dist --no-cpu-baseline --steps 40 --warmup 5 > $R/gpurun_out/rocprof_reduction.log 2>&1)
 rpmc() { name=$1; shift; (cd /tmp && MKAMD_DIST_ONLY=reduction timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmc_reduction_$name -- python $R/bench.py --workload dist --no-cpu-baseline --settle-seconds 0 --steps 4 --warmup 1 > $R/gpurun_out/pmc_reduction_$name.log 2>&1); }
 rpmc sq1 $SQ1
 rpmc sq2 $SQ2
