@@ -447,3 +447,45 @@ def test_cdist_pdist_row_kernels_ragged_edges_bit_exact(D):
     assert np.array_equal(E.pdist(c), oracle.pdist(c))
     for n in (2, 3, 5, 1025):
         assert np.array_equal(E.pdist(c[:n]), oracle.pdist(c[:n])), n
+
+
+def _row_kernel_trap_case(mixed, seed=9):
+    """16 x 250 pairs x 6 frames -- rows long enough for the row kernel -- in which second atoms sit at image-integer traps from first
+    atoms (rndne(d * fl(1/b)) != round(d / b)), one frame has a zero box, one coordinate is inf and one NaN; `mixed`: chain ids vary among
+    the second atoms (per-pair wrap flags), else the reference's periodic="selections" ids (1 / 2)."""
+    rng = np.random.default_rng(seed)
+    n1, n2, F = 16, 250, 6                                     # (250 of 256 lanes x 4: the row kernel with four second atoms per lane)
+    N = n1 + n2
+    c = rng.uniform(0, 14, size=(N, 3, F)).astype(np.float32)
+    b = np.empty((3, F), np.float32)
+    traps = _image_integer_traps(rng, 15)
+    for f in range(F):
+        b[:, f] = [np.float32(43.7), np.float32(39.1), np.float32(47.3)]
+    for t, (bl, d) in enumerate(traps):                          # one trap per (frame, axis): its box length is that trap's
+        f, ax, i, j = (0, 1, 2, 3, 5)[t // 3], t % 3, t % n1, n1 + (17 * t) % n2
+        b[ax, f] = bl
+        c[i, ax, f] = 0.0                                        # (so that first - second is EXACTLY the trap's separation)
+        c[j, :, f] = c[i, :, f]
+        c[j, ax, f] = -d
+    b[:, 4] = 0.0                                                # pbc with a zero box: NaN / inf like the reference
+    c[n1 + 5, 0, 2] = np.inf
+    c[n1 + 9, 1, 3] = np.nan
+    ch = np.ones(N, np.uint32); ch[n1:] = 2
+    if mixed:
+        ch = rng.integers(0, 3, N).astype(np.uint32)
+    return c, b, ch, np.arange(n1, dtype=np.uint32), np.arange(n1, N, dtype=np.uint32)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_periodic_row_kernel_image_integers_are_the_references(mixed):
+    """k_dist_rows' periodic rows (four second atoms per lane): image integers at traps (the reciprocal-multiply shortcut alone would get
+    them wrong: mutation-checked in round 6 against a packed variant of the kernel whose redo path was switched off), one chain id among
+    the second atoms and mixed ids, a zero box, inf / NaN coordinates; with and without the 16-byte stores; squared distances too."""
+    c, b, ch, s1, s2 = _row_kernel_trap_case(mixed)
+    with np.errstate(all="ignore"):
+        for sq in (False, True):
+            want = oracle.dist_trajectory(c, b, s1, s2, ch, False, True, squared=sq)
+            for avoid in (1, 1 | 8):                             # (not the block-per-frame kernel: the row kernel, with / without 16-byte stores)
+                got = E.dist_trajectory(c, b, s1, s2, ch, False, True, squared=sq, avoid=avoid)
+                assert np.array_equal(got, want, equal_nan=True), (sq, avoid)
+        assert np.isnan(want).any()                              # (the zero box, the NaN coordinate; an inf coordinate wraps to NaN as well)

@@ -577,3 +577,39 @@ def test_cdist_pdist_at_size_bit_exact(D):
     r = np.zeros(3001 * 3000 // 2, np.float32)
     pdist(c, r)
     assert np.array_equal(r, oracle.pdist(c))
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_periodic_row_kernel_image_integers_on_the_hardware(mixed):
+    """k_dist_rows' periodic rows on the hardware: the emulated tier's trap case (image integers where rndne(d * fl(1/b)) != round(d / b), a
+    zero box, inf / NaN coordinates), one chain id among the second atoms and mixed ids, with and without 16-byte stores -- and a bigger
+    random call with unwrapped coordinates (quotients up to +-2.5) against the oracle."""
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import dist_trajectory
+    from tests.test_distance_cpu import _row_kernel_trap_case
+    ctx = _lib.default_context()
+    c, b, ch, s1, s2 = _row_kernel_trap_case(mixed)
+    try:
+        with np.errstate(all="ignore"):
+            want = oracle.dist_trajectory(c, b, s1, s2, ch, False, True)
+            for avoid in (1, 1 | 8):
+                ctx.set_dist_kernels(avoid)
+                r = np.zeros_like(want)
+                dist_trajectory(c, b, s1, s2, ch, False, True, r)
+                assert "k_dist_rows<true" in ctx.last_dist_kernel(), ctx.last_dist_kernel()
+                assert np.array_equal(r, want, equal_nan=True), avoid
+        ctx.set_dist_kernels(0)
+        rng = np.random.default_rng(70 + mixed)
+        N, F = 3000, 130
+        c = rng.uniform(-40, 40, size=(N, 3, F)).astype(np.float32)             # unwrapped: quotients up to +-2.5
+        b = rng.uniform(30, 40, size=(3, F)).astype(np.float32)
+        s1 = np.sort(rng.choice(N, 70, replace=False)).astype(np.uint32)
+        s2 = np.sort(rng.choice(N, 700, replace=False)).astype(np.uint32)
+        ch = (np.arange(N) // 100).astype(np.uint32) if mixed else np.isin(np.arange(N), s2).astype(np.uint32) + 1
+        want = oracle.dist_trajectory(c, b, s1, s2, ch, False, True)
+        r = np.zeros_like(want)
+        dist_trajectory(c, b, s1, s2, ch, False, True, r)
+        assert "k_dist_rows<true, 4" in ctx.last_dist_kernel()
+        assert np.array_equal(r, want)
+    finally:
+        ctx.set_dist_kernels(0)
