@@ -613,3 +613,48 @@ def test_periodic_row_kernel_image_integers_on_the_hardware(mixed):
         assert np.array_equal(r, want)
     finally:
         ctx.set_dist_kernels(0)
+
+
+def test_sharded_distances_on_the_device_single_rank():
+    """distributed.ShardedDistances on the GPU (one process, no group: the whole trajectory is this rank's shard): the trajectory resident
+    in HBM, selections / groups replicated once, every method against the oracle bit for bit; results stay on the device."""
+    import torch
+    from moleculekit_amd.distributed import ShardedDistances
+    rng = np.random.default_rng(23)
+    N, F = 500, 90
+    coords = rng.uniform(-25, 25, size=(N, 3, F)).astype(np.float32)
+    box = rng.uniform(28, 36, size=(3, F)).astype(np.float32)
+    chains = (np.arange(N) // 60).astype(np.uint32)
+    masses = rng.uniform(1, 32, N).astype(np.float32)
+    sd = ShardedDistances.from_host(coords, box)
+    assert (sd.lo, sd.hi, sd.n_local) == (0, F, F) and sd.device.type == "cuda"
+    s1 = np.sort(rng.choice(N, 40, replace=False)).astype(np.uint32)
+    s2 = np.sort(rng.choice(N, 230, replace=False)).astype(np.uint32)
+    for selfd, a, b in ((False, s1, s2), (True, s2, s2)):
+        for pbc in (True, False):
+            got = sd.dist_trajectory(a, b, chains, selfd, pbc)
+            assert got.is_cuda and np.array_equal(sd.gather(got).cpu().numpy(), oracle.dist_trajectory(coords, box, a, b, chains, selfd, pbc))
+    g1 = [rng.choice(N, int(rng.integers(1, 18)), replace=False).tolist() for _ in range(23)]
+    g2 = [rng.choice(N, int(rng.integers(1, 12)), replace=False).tolist() for _ in range(17)]
+    ch1, ch2 = rng.integers(0, 3, 23).astype(np.uint32), rng.integers(0, 3, 17).astype(np.uint32)
+    for r1, r2 in ((0, 0), (1, 0), (1, 1)):
+        got = sd.dist_trajectory_reduction(g1, g2, ch1, ch2, False, True, masses, r1, r2)
+        assert np.array_equal(got.cpu().numpy(), oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, r1, r2)), (r1, r2)
+    got = sd.dist_trajectory_reduction(g1, g1, ch1, ch1, True, False, masses, 0, 0)
+    assert np.array_equal(got.cpu().numpy(), oracle.dist_trajectory_reduction(coords, box, g1, g1, ch1, ch1, True, False, masses, 0, 0))
+    got = sd.dist_trajectory_reduction(g1[:17], g2, ch1[:17], ch2, False, True, masses, 0, 0, pairs=True)
+    assert np.array_equal(got.cpu().numpy(), oracle.dist_trajectory_reduction(coords, box, g1[:17], g2, ch1[:17], ch2, False, True, masses, 0, 0, pairs=True))
+    offs, pairs = sd.contacts_trajectory(s1, s2, chains, False, True, 9.0)
+    d2 = oracle.dist_trajectory(coords, box, s1, s2, chains, False, True, squared=True)
+    assert pairs.is_cuda and len(offs) == F + 1
+    flat = pairs.cpu().numpy().astype(np.int64)
+    for f in (0, 41, F - 1):
+        hit = np.nonzero(d2[f] <= np.float32(81.0))[0]
+        i, j = np.divmod(hit, len(s2))
+        assert np.array_equal(flat[offs[f]:offs[f + 1]], np.stack([s1[i], s2[j]], 1))
+    # a second contacts call reuses the context's list: the first result was copied out of it and is still what it was
+    keep = flat.copy()
+    sd.contacts_trajectory(s2[:50], s2[50:120], chains, False, False, 30.0)
+    assert np.array_equal(pairs.cpu().numpy().astype(np.int64), keep)
+    with pytest.raises(ValueError):
+        sd.dist_trajectory(np.array([N], np.uint32), s2, chains, False, True)
