@@ -317,7 +317,23 @@ from moleculekit.projections.metricdistance import MetricDistance, MetricSelfDis
 ctx = _OracleCtx(); _lib.default_context = lambda device=None: ctx
 d = "/root/reference/tests/test_projections"
 mol = Molecule(os.path.join(d, "trajectory", "filtered.pdb")); mol.read(os.path.join(d, "trajectory", "traj.xtc"))
+# the reference's other callers of distance_utils, first on its own compiled functions ...
+from moleculekit.distance import calculate_contacts, cdist, pdist, squareform
+from moleculekit.molecule import _detectCollisions
+few = mol.copy(); few.dropFrames(keep=[0, 7, 199])
+s1, s2 = few.atomselect("protein and name CA"), few.atomselect("resname MOL and noh")
+a, b = few.coords[s1, :, 0].copy(), few.coords[s2, :, 0].copy()
+def others():
+    con = calculate_contacts(few, s1, s2, "selections", threshold=30)
+    return ([c.tolist() for c in con], cdist(a, b), pdist(b), squareform(pdist(b)), _detectCollisions(a, b, 40.0, np.arange(len(b))).tolist())
+before = others()
 moleculekit_amd.install()
+# ... then through the hook: the same lists, the same bits
+after = others()
+assert before[0] == after[0] and before[4] == after[4] and sum(len(c) for c in before[0]) > 0 and len(before[4]) > 0
+assert all(np.array_equal(x, y) for x, y in zip(before[1:4], after[1:4]))
+assert ctx.calls == ["contacts_trajectory", "cdist", "pdist", "pdist", "contacts_trajectory"], ctx.calls
+ctx.calls.clear()
 r = MetricDistance("protein and name CA", "resname MOL and noh", metric="distances", periodic="selections").project(mol)
 assert np.allclose(r, np.load(os.path.join(d, "metricdistance", "distances.npy")), atol=1e-3)
 r = MetricDistance("protein and noh", "resname MOL and noh", periodic="selections", groupsel1="residue", groupsel2="all").project(mol)
