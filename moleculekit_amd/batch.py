@@ -373,8 +373,23 @@ def _pinned_give(key, t):
     _PINNED[(key, tuple(t.shape))] = t
 
 
+def chunk_plan(n_frames, chunk, ramp=0):
+    """Boundaries of the chunks a streamed driver takes: equal chunks of ``chunk`` frames, or -- ``ramp`` > 0 -- a first chunk of
+    ``ramp`` frames and every next one twice the size until ``chunk`` is reached.  A pipeline's first chunk is exposed (nothing
+    runs beside its upload and decode) and its stages only overlap once several chunks are in flight, so a long trajectory is
+    fed fastest by LARGE chunks that are approached through small ones (the device XTC walk takes ~10 ms beside the tile kernel
+    whatever the chunk holds: below ~3 000 cfg4-sized frames per chunk it, not the voxelizer, sets the pace --
+    docs/EXPERIMENTS_r6.md section 12)."""
+    n_frames, chunk = int(n_frames), int(max(1, chunk))
+    b, size = [0], int(ramp) if ramp and 0 < int(ramp) < chunk else chunk
+    while b[-1] < n_frames:
+        b.append(min(n_frames, b[-1] + size))
+        size = min(chunk, 2 * size)
+    return b
+
+
 def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first, ctx,
-                     max_images, fill_dev=None, pipelined=True, use_topology=None):
+                     max_images, fill_dev=None, pipelined=True, use_topology=None, ramp=0):
     """Core of the streamed voxelizers.  Host sources: ``fill(coords_np [N,3,n], box_np [3,n] | None, idx)`` produces chunk
     ``idx`` (frame indices) straight into pinned staging; device sources: ``fill_dev(xyz [n,N,3], box [n,3] | None, idx)``
     writes the chunk's frame-major device tensors itself.  Everything a chunk needs on the device -- the upload, the
@@ -444,8 +459,10 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
         consumed = [torch.cuda.Event(), torch.cuda.Event()]      # the call that read slot i's inputs is done (compute stream)
         images = [max_images, max_images]
 
+        plan = chunk_plan(len(fr), chunk, ramp)
+
         def upload(k, slot):
-            idx = fr[k * chunk:(k + 1) * chunk]
+            idx = fr[plan[k]:plan[k + 1]]
             n = len(idx)
             xyz = d_xyz[slot][:n * N].view(n, N, 3)
             if host_source:
@@ -472,7 +489,7 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
             return idx
 
         try:
-            nchunks = (len(fr) + chunk - 1) // chunk
+            nchunks = len(plan) - 1
             pending = upload(0, 0) if nchunks else None
             for k in range(nchunks):
                 slot = k & 1
@@ -585,10 +602,12 @@ def iterVoxelizeTrajectory(coords, channels, center, boxsize, voxelsize=1, box=N
 
 
 def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, frames=None, chunk=1024, device=None,
-                    channel_first=False, ctx=None, nthreads=0, pipelined=True, decode="auto"):
+                    channel_first=False, ctx=None, nthreads=0, pipelined=True, decode="auto", ramp=0):
     """``iterVoxelizeTrajectory`` fed straight from an XTC file.  ``pbc``: use the frames' box (orthorhombic lengths of the
     box vectors) for the minimum image.  Coordinates are converted from the file's nm to Angstrom on the device, like
-    ``readers.XTCread`` does on the host.  ``chunk``: frames per step of the pipeline.
+    ``readers.XTCread`` does on the host.  ``chunk``: frames per step of the pipeline; ``ramp`` > 0: the first step takes
+    ``ramp`` frames and every next one twice as many until ``chunk`` is reached (``chunk_plan``: for long trajectories
+    ``chunk=4096, ramp=512`` feeds fastest -- the yielded batches then differ in size).
 
     ``decode``: where the coordinates are decompressed --
       ``"gpu"``   on the device (csrc/xtc_gpu.h): per chunk the host parses the record headers and copies the records' BYTES
@@ -630,7 +649,7 @@ def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, 
         decode = "gpu" if contiguous and _xtc.device_decodable(_xtc.chunk_desc(filename, fr[:1], natoms)[0], natoms) else "host"
     if decode == "gpu" and len(fr):
         yield from _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, bool(pbc), channels, center, boxsize, voxelsize,
-                                 chunk, device, channel_first, ctx, max_images, int(nthreads), pipelined)
+                                 chunk, device, channel_first, ctx, max_images, int(nthreads), pipelined, ramp)
         return
 
     def fill(dst, dst_box, idx):
@@ -645,11 +664,11 @@ def iterVoxelizeXTC(filename, channels, center, boxsize, voxelsize=1, pbc=True, 
             np.copyto(dst_box, box_lengths(bv))
 
     yield from _stream_voxelize(natoms, fr, fill, 10.0, bool(pbc), channels, center, boxsize, voxelsize, chunk, device,
-                                channel_first, ctx, max_images, pipelined=pipelined)
+                                channel_first, ctx, max_images, pipelined=pipelined, ramp=ramp)
 
 
 def _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, has_box, channels, center, boxsize, voxelsize, chunk, device,
-                  channel_first, ctx, max_images, nthreads, pipelined):
+                  channel_first, ctx, max_images, nthreads, pipelined, ramp=0):
     """``iterVoxelizeXTC(decode="gpu")``: the chunk source of ``_stream_voxelize`` that decodes on the device.  Per chunk, on
     the host: ``mkamd_xtc_chunk_desc`` (headers -> descriptors, box vectors) and ``mkamd_xtc_copy_bytes`` (the records into
     one of two pinned byte buffers); on an UPLOAD stream the records' H2D (beside the previous chunk's decode); on the copy
@@ -740,7 +759,7 @@ def _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, has_box, cha
         return images
 
     gen = _stream_voxelize(natoms, fr, None, 10.0, has_box, channels, center, boxsize, voxelsize, chunk, device, channel_first,
-                           run_ctx, max_images, fill_dev=fill_dev, pipelined=pipelined)
+                           run_ctx, max_images, fill_dev=fill_dev, pipelined=pipelined, ramp=ramp)
     try:
         for item in gen:
             for ss in range(NS):

@@ -570,6 +570,12 @@ def test_device_xtc_decoder_many_waves_many_windows_and_bad_streams(hip_ctx, tmp
     for chunk in (50, 128):
         got = torch.cat([f for _, f in batch.iterVoxelizeXTC(many, sig, center, [12, 12, 12], 1.0, pbc=True, chunk=chunk, decode="gpu")]).cpu().numpy()
         assert got.shape[0] == nf and np.array_equal(got, want), chunk
+    # (round 6) chunks approached through a ramp -- 8, 16, 32, 64, 64, ... frames: the plan's sizes, every frame once and in order, the same features
+    for decode in ("gpu", "host"):
+        parts = list(batch.iterVoxelizeXTC(many, sig, center, [12, 12, 12], 1.0, pbc=True, chunk=64, ramp=8, decode=decode))
+        assert [len(i) for i, _ in parts] == list(np.diff(batch.chunk_plan(nf, 64, 8))) and [len(i) for i, _ in parts][:4] == [8, 16, 32, 64]
+        assert np.array_equal(np.concatenate([i for i, _ in parts]), np.arange(nf))
+        assert np.array_equal(torch.cat([f for _, f in parts]).cpu().numpy(), want), decode
     # a damaged stream: an impossible small-number index in one frame's header (xdrfile.cpp:782 reads it before the stream)
     desc = xtc.chunk_desc(many, np.arange(3), na)[0].view(xtc.DESC_DTYPE).reshape(-1)
     bad = bytearray(open(many, "rb").read())

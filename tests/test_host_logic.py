@@ -249,3 +249,16 @@ def test_centres_cache_survives_concurrent_eviction():
     ts = [threading.Thread(target=churn, args=(s,)) for s in range(8)]
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errors and len(vd._CENTERS_CACHE) <= 4
+
+
+def test_chunk_plan_of_the_streamed_drivers():
+    """batch.chunk_plan: equal chunks, or a first chunk of `ramp` frames doubling up to `chunk`; the boundaries always cover the frames
+    exactly once."""
+    from moleculekit_amd.batch import chunk_plan
+    assert chunk_plan(10, 4) == [0, 4, 8, 10] and chunk_plan(0, 4) == [0] and chunk_plan(3, 8) == [0, 3]
+    assert chunk_plan(16384, 4096, 512) == [0, 512, 1536, 3584, 7680, 11776, 15872, 16384]
+    assert chunk_plan(10, 4, 1) == [0, 1, 3, 7, 10] and chunk_plan(5, 8, 2) == [0, 2, 5]
+    assert chunk_plan(10, 4, 4) == [0, 4, 8, 10] and chunk_plan(10, 4, 9) == [0, 4, 8, 10]       # a ramp that is no ramp
+    for n, c, r in ((1000, 64, 8), (77, 13, 5), (5, 1, 3)):
+        b = chunk_plan(n, c, r)
+        assert b[0] == 0 and b[-1] == n and all(0 < y - x <= c for x, y in zip(b, b[1:]))

@@ -90,12 +90,14 @@ def bench_stream_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     return out
 
 
-def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=1024):
+def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=4096, ramp_gpu=512):
     """Secondary leg `xtc_cfg4`: the cfg4 FEEDER -- a synthetic 30 000-atom XTC trajectory (64 frames of the cfg4 random walk
     written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) voxelized through
     batch.iterVoxelizeXTC, with the coordinates decompressed ON THE DEVICE (decode="auto": csrc/xtc_gpu.h, large chunks) and,
     beside it, by libmkamd.so's host threads (decode="host", the round-3 path).  Reports the end-to-end rates, the host
-    decoder's rate alone and how idle the GPU is (the voxelizer's share of the wall time at the raw cfg4 step)."""
+    decoder's rate alone and how idle the GPU is (the voxelizer's share of the wall time at the raw cfg4 step).
+    Round 6: the device-decoded feed takes chunks of 4 096 frames approached through 512, 1 024, 2 048 (`ramp`): the device walk takes
+    ~10 ms beside the tile kernel whatever the chunk holds, so below ~3 000 frames per chunk IT sets the pace (docs/EXPERIMENTS_r6.md section 12)."""
     import tempfile
     import torch
     from moleculekit_amd import _lib, batch, xtc
@@ -121,10 +123,10 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu
         xtc.read_xtc_frames(fn, np.arange(frames))
         t_dec = time.perf_counter() - t0
 
-        def run(decode, nframes, nchunk):
+        def run(decode, nframes, nchunk, ramp=0):
             n, marks = 0, []
             for idx, feats in batch.iterVoxelizeXTC(fn, sig, p["centers"][0], p["boxsize"], p["voxelsize"], pbc=True, chunk=nchunk, ctx=ctx,
-                                                    frames=np.arange(nframes), decode=decode):
+                                                    frames=np.arange(nframes), decode=decode, ramp=ramp):
                 n += len(idx)
                 ev = torch.cuda.Event(enable_timing=True)                       # when this chunk's features are complete on the device
                 ev.record(torch.cuda.current_stream(dev))
@@ -133,15 +135,20 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu
             torch.cuda.synchronize(dev)
             return n, marks
 
-        def leg(decode, nframes, nchunk):
-            run(decode, nframes, nchunk)                                        # warm: buffers, pinned staging, the allocator's blocks
+        def leg(decode, nframes, nchunk, ramp=0):
+            run(decode, nframes, nchunk, ramp)                                  # warm: buffers, pinned staging, the allocator's blocks
             t0 = time.perf_counter()
-            n, marks = run(decode, nframes, nchunk)
+            n, marks = run(decode, nframes, nchunk, ramp)
             dt = time.perf_counter() - t0
             o = {"frames": n, "frames_per_call": nchunk, "frames_per_s": round(n / dt, 1), "Matoms_per_s": round(n * N / dt / 1e6, 1)}
-            if len(marks) >= 4:                                                 # the feed once it is full: chunk 2's features complete
-                (ea, na), (eb, nb) = marks[1], marks[-1]                        # -> the last chunk's complete (device events)
-                o["steady_frames_per_s"] = round((nb - na) / (ea.elapsed_time(eb) * 1e-3), 1)
+            if ramp:
+                o["first_call_frames"] = ramp
+            if len(marks) >= 4:                                                 # the feed once it is full: from the first chunk of the FULL size
+                full = [i for i in range(1, len(marks)) if marks[i][1] - marks[i - 1][1] == nchunk]
+                i0 = full[0] if ramp and len(full) >= 2 else 1                  # (no ramp: chunk 2's features complete -> the last chunk's)
+                (ea, na), (eb, nb) = marks[i0], marks[full[-1] if ramp and len(full) >= 2 else -1]
+                if nb > na:
+                    o["steady_frames_per_s"] = round((nb - na) / (ea.elapsed_time(eb) * 1e-3), 1)
             if per_frame_s:
                 o["gpu_busy_fraction"] = round(n * per_frame_s / dt, 4)         # the voxelizer's share of the wall time
             return o, dt
@@ -149,7 +156,7 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu
         host, _ = leg("host", frames, chunk)
         torch.cuda.empty_cache()
         try:
-            gpu, _ = leg("auto", frames_gpu, chunk_gpu)
+            gpu, _ = leg("auto", frames_gpu, chunk_gpu, ramp_gpu)
             # the decode kernels alone, on resident bytes (what one chunk costs beside the voxelizer)
             sel = np.arange(chunk_gpu, dtype=np.int64)
             desc, lo, hi, _, _, _ = xtc.chunk_desc(fn, sel, N)
