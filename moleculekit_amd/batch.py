@@ -426,7 +426,12 @@ def _stream_voxelize(N, fr, fill, scale, has_box, channels, center, boxsize, vox
     nvoxels = np.ceil(boxsize / voxelsize).astype(int)
     origin = np.asarray(center, dtype=np.float64) - boxsize / 2
     main = torch.cuda.current_stream(dev)
-    copy = torch.cuda.Stream(device=dev)
+    # A HIGH-PRIORITY stream: what runs on it -- uploads, the transposing kernel, the device XTC decoder -- has to run BESIDE the
+    # voxelizer.  Streams of one priority share a handful of hardware queues round-robin by creation order; when this stream landed on
+    # the queue of the context's main or side stream, chunk k+1's decode and chunk k's tile kernel took turns instead of overlapping
+    # (round 6: the XTC-fed leg flipped between 139 k and 193 k frames/s from one run to the next in ONE process).  High-priority
+    # streams have queues of their own -- and a latency chain like the XTC walk wants to be dispatched first anyway.
+    copy = torch.cuda.Stream(device=dev, priority=-1)
     host_source = fill_dev is None
     with torch.cuda.device(dev):
         # every frame has the molecule's sigmas: what the pre-pass derives from them is built ONCE (a topology handle,

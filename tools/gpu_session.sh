@@ -1,16 +1,16 @@
-# round 6, session 20: the XTC-fed leg with chunks of 4 096 frames approached through a ramp; the xtc GPU tests
+# round 6, session 22: the XTC-fed leg, chunk plans side by side on one box, twice
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 900 python -m pytest tests/test_gpu_api.py -m gpu -q -x -k "xtc" 2>&1 | tail -3)
 cat > /tmp/xtcchunks.py <<'PY'
 import sys, os, json
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 import torch, bench
 from moleculekit_amd import _lib
 ctx = _lib.default_context(0); dev = torch.device("cuda", 0)
-for chunk, ramp in ((1024, 0), (4096, 512), (4096, 0), (4096, 1024), (8192, 512)):
-    r = bench.bench_xtc_cfg4(ctx, dev, 0.92, frames_gpu=16384, chunk_gpu=chunk, ramp_gpu=ramp)
-    x = r["device_decode"]
-    print("chunk", x["frames_per_call"], "ramp", ramp, "frames/s", x["frames_per_s"], "steady", x.get("steady_frames_per_s"), "busy", x["gpu_busy_fraction"], r["bottleneck"], flush=True)
+for rep in range(2):
+    for chunk, ramp in ((1024, 0), (2048, 0), (4096, 0), (4096, 512), (4096, 2048)):
+        r = bench.bench_xtc_cfg4(ctx, dev, 0.92, frames_gpu=16384, chunk_gpu=chunk, ramp_gpu=ramp)
+        x = r["device_decode"]
+        print("chunk", x["frames_per_call"], "ramp", ramp, "frames/s", x["frames_per_s"], "steady", x.get("steady_frames_per_s"), "busy", x["gpu_busy_fraction"], flush=True)
 PY
-timeout 900 python /tmp/xtcchunks.py 2>&1 | grep -v amdgpu | tail -6
+timeout 900 python /tmp/xtcchunks.py 2>&1 | grep -v amdgpu | tail -10
