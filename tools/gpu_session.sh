@@ -1,16 +1,7 @@
-# round 6, session 22: the XTC-fed leg, chunk plans side by side on one box, twice
+# round 6, session 25: timeline of the XTC-fed leg (2 048 frames per chunk) with the copy/decode stream on a high-priority queue
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-cat > /tmp/xtcchunks.py <<'PY'
-import sys, os, json
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-import torch, bench
-from moleculekit_amd import _lib
-ctx = _lib.default_context(0); dev = torch.device("cuda", 0)
-for rep in range(2):
-    for chunk, ramp in ((1024, 0), (2048, 0), (4096, 0), (4096, 512), (4096, 2048)):
-        r = bench.bench_xtc_cfg4(ctx, dev, 0.92, frames_gpu=16384, chunk_gpu=chunk, ramp_gpu=ramp)
-        x = r["device_decode"]
-        print("chunk", x["frames_per_call"], "ramp", ramp, "frames/s", x["frames_per_s"], "steady", x.get("steady_frames_per_s"), "busy", x["gpu_busy_fraction"], flush=True)
-PY
-timeout 900 python /tmp/xtcchunks.py 2>&1 | grep -v amdgpu | tail -10
+rm -rf gpurun_out/prof_xtc_tl
+(cd /tmp && XTC_LEG_ONE=2048 timeout 600 rocprofv3 --kernel-trace --memory-copy-trace -d $GRAFT_REPO_ROOT/gpurun_out/prof_xtc_tl -o tl --output-format csv -- python $GRAFT_REPO_ROOT/tools/xtc_leg.py 0.92 2>&1 | grep -v amdgpu | tail -25 | cut -c1-300)
+python tools/xtc_timeline.py gpurun_out/prof_xtc_tl | tail -40 | tee gpurun_out/xtc_timeline.txt
+rm -rf gpurun_out/prof_xtc_tl

@@ -4,13 +4,13 @@ upload, its decode (k_xtc_scan / k_xtc_expand) and its voxelization ran, and the
 import csv, glob, sys
 d = sys.argv[1]
 ev = []
-for f in glob.glob(d + "/*/*kernel_trace.csv"):
+for f in glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
         kind = "scan" if "k_xtc_scan" in n else "expand" if "k_xtc_expand" in n else "tile" if "k_voxelize_tiles" in n else "bin" if "k_bin_count" in n else None
         if kind:
             ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), kind))
-for f in glob.glob(d + "/*/*memory_copy_trace.csv"):
+for f in glob.glob(d + "/*/*memory_copy_trace.csv") + glob.glob(d + "/*memory_copy_trace.csv"):
     for r in csv.DictReader(open(f)):
         b = int(r.get("Bytes", r.get("Size", 0)) or 0)
         if b > (8 << 20):
