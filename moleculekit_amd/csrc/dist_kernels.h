@@ -70,6 +70,33 @@ MK_DEV mk_f2 dist2_x2(float x1, float y1, float z1, mk_f2 x2, mk_f2 y2, mk_f2 z2
     return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
 }
 
+// The image integers of SEVERAL pairs behind one wave-uniform test (round 6; the group reductions first, then the pair-table walk):
+// risk = max over the pairs of (largest |q - rndne(q)| + 3e-7 largest |q|), accumulated without a branch; a stretch whose risk
+// reaches DRC_RISK in any lane is computed once more pair by pair (dist2_min_image_f32: the per-pair test, the divisions).
+constexpr float DRC_RISK = 0.4999998f;               // risk below this: every rndne(d * fl(1/b)) is the reference's round(d / b)
+                                                     // (the per-pair test is tm < 0.5 - 3e-7 qm, proven bound 1.8e-7 qm; here
+                                                     //  tm + 3e-7 qm is rounded once more: 2e-7 of slack)
+
+// d^2 of two atom pairs (first atoms ax/ay/az[0..1], second atom (x2, y2, z2)) -- distance_utils.pyx:188-206
+template <bool WR>
+MK_DEV mk_f2 dist2_pk(mk_f2 ax, mk_f2 ay, mk_f2 az, float x2, float y2, float z2, float bx, float by, float bz,
+                      float ibx, float iby, float ibz, float& risk)
+{
+    mk_f2 dx = mk_f2_sub_rn(ax, mk_f2_splat(x2)), dy = mk_f2_sub_rn(ay, mk_f2_splat(y2)), dz = mk_f2_sub_rn(az, mk_f2_splat(z2));
+    if constexpr (WR) {
+        const mk_f2 qx = mk_f2_mul_rn(dx, mk_f2_splat(ibx)), qy = mk_f2_mul_rn(dy, mk_f2_splat(iby)), qz = mk_f2_mul_rn(dz, mk_f2_splat(ibz));
+        const mk_f2 rx = mk_f2{mk_rint(qx[0]), mk_rint(qx[1])}, ry = mk_f2{mk_rint(qy[0]), mk_rint(qy[1])}, rz = mk_f2{mk_rint(qz[0]), mk_rint(qz[1])};
+        const mk_f2 tx = mk_f2_sub_rn(qx, rx), ty = mk_f2_sub_rn(qy, ry), tz = mk_f2_sub_rn(qz, rz);       // (exact)
+        const float s0 = mk_fma(3e-7f, mk_max3_abs_raw(qx[0], qy[0], qz[0]), mk_max3_abs_raw(tx[0], ty[0], tz[0]));
+        const float s1 = mk_fma(3e-7f, mk_max3_abs_raw(qx[1], qy[1], qz[1]), mk_max3_abs_raw(tx[1], ty[1], tz[1]));
+        risk = mk_max3_raw(risk, s0, s1);
+        dx = mk_f2_sub_rn(dx, mk_f2_mul_rn(mk_f2_splat(bx), rx));
+        dy = mk_f2_sub_rn(dy, mk_f2_mul_rn(mk_f2_splat(by), ry));
+        dz = mk_f2_sub_rn(dz, mk_f2_mul_rn(mk_f2_splat(bz), rz));
+    }
+    return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
+}
+
 // Self-test of mk_fsqrt_rn_ordinary (mk_device.h: the short correctly-rounded root) against the provable form, over the float bit
 // patterns [lo, lo + n): mismatches counted, the first one kept (mkamd_selftest_sqrt).
 MK_KERNEL(256) void k_selftest_sqrt(unsigned lo, unsigned long long n, unsigned long long* __restrict__ bad, unsigned* __restrict__ first)
@@ -236,10 +263,38 @@ MK_DEV void for_pair_run(const float* __restrict__ coords, long long F, unsigned
         float B3[DP_BATCH][3], d2[DP_BATCH];
 #pragma unroll
         for (int u = 0; u < DP_BATCH; ++u) { B3[u][0] = at(b[u], 0); B3[u][1] = at(b[u], 1); B3[u][2] = at(b[u], 2); }
-        if (same) {
+        if (!same) {
+            // a batch with ONE first atom that is not the cached one (the first batch of a run, the first after a row of the pair list
+            // ended): that atom is fetched once and the batch goes the way of the cached ones (round 6: it used to load it four times)
+            bool one = true;
 #pragma unroll
-            for (int u = 0; u < DP_BATCH; ++u)
-                d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, WR && w[u] != 0u);
+            for (int u = 1; u < DP_BATCH; ++u) one &= a[u] == a[0];
+            if (one) { cur_a = a[0]; xa = at(a[0], 0); ya = at(a[0], 1); za = at(a[0], 2); same = true; }
+        }
+        if (same) {
+            // (round 6) a batch whose four pairs ALL wrap (wave-uniform: the flags sit in scalar registers) in packed arithmetic, two
+            // pairs per instruction, their image integers behind ONE accumulated test (dist2_pk; b - a instead of a - b: every
+            // operation on the way to d^2 is odd or even in the separation, rndne included).  A batch that fails it in any lane
+            // -- a separation within 3e-7 of half a box length, an infinite quotient -- and mixed batches go pair by pair.
+            bool packed = false;
+            if constexpr (WR) {
+                static_assert(DP_BATCH == 4, "two packed pairs of second atoms");
+                if ((w[0] & w[1] & w[2] & w[3]) != 0u) {
+                    float risk = 0.f;
+                    const mk_f2 e01 = dist2_pk<true>(mk_f2{B3[0][0], B3[1][0]}, mk_f2{B3[0][1], B3[1][1]}, mk_f2{B3[0][2], B3[1][2]}, xa, ya, za,
+                                                     bx, by, bz, ibx, iby, ibz, risk);
+                    const mk_f2 e23 = dist2_pk<true>(mk_f2{B3[2][0], B3[3][0]}, mk_f2{B3[2][1], B3[3][1]}, mk_f2{B3[2][2], B3[3][2]}, xa, ya, za,
+                                                     bx, by, bz, ibx, iby, ibz, risk);
+                    packed = mk_ballot(!(risk < DRC_RISK)) == 0ull;
+                    d2[0] = e01[0]; d2[1] = e01[1]; d2[2] = e23[0]; d2[3] = e23[1];
+                }
+            }
+            if (!packed) {
+                if constexpr (WR) mk_stay_in_branch();
+#pragma unroll
+                for (int u = 0; u < DP_BATCH; ++u)
+                    d2[u] = dist2_min_image_f32(xa, ya, za, B3[u][0], B3[u][1], B3[u][2], bx, by, bz, ibx, iby, ibz, WR && w[u] != 0u);
+            }
         } else {
             float A3[DP_BATCH][3];
 #pragma unroll
@@ -781,6 +836,166 @@ MK_KERNEL(DT_THREADS) void k_contacts_fill(long long fc, long long fc_pad, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The contact lists of a RECTANGULAR call (no selfdist: every sel1 atom against every sel2 atom), round 6.  The pair-table walk
+// above loads the second atom of EVERY pair (three 256-byte loads per 64 pair-frames: 2.5 GB through the L1 for 200 x 500 pairs x
+// 2 048 frames) and k_contacts_count took 186 us of a 0.30-ms call with a third of its issue slots used.  Here -- as in k_dist_rect
+// -- a wave keeps ITS sixteen second atoms in 48 registers (as eight packed pairs: lane = frame) and walks the block's CR_I first
+// atoms: 0.6 loads per pair; the sixteen d^2 of a first atom come from eight packed calls (dist2_pk), their image integers behind
+// ONE accumulated test.  Nothing goes through LDS but the per-(row tile, frame) counts.
+// A "row tile" is (first atom i, 64 consecutive second atoms jt): tile t = i * JT + jt, JT = ceil(n2 / 64); its four runs of 16 are
+// the four waves' second atoms.  Tiles ascend in the reference's (i, j) order, so scan and fill work as for the pair tiles -- with
+// masks past a row's end (j >= n2) zero.  No pair table is built: a pair is (sel1[t / JT], sel2[(t % JT) * 64 + 16 run + k]).
+// ------------------------------------------------------------------------------------------------
+constexpr int CR_I = 8;                // first atoms per block (the second atoms' 48 loads per wave are amortised over them)
+
+template <bool PBC, bool SMALL>
+MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, long long f_begin, long long fc, long long fc_pad,
+                                const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
+                                const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains, float thr2,
+                                unsigned* __restrict__ cnt, unsigned short* __restrict__ masks, unsigned (&s_c)[CR_I][DT_THREADS / DT][DT],
+                                long long ig, long long jt, long long JT)
+{
+    const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
+    const long long lf = (long long)blockIdx.y * DT + fl;
+    const bool fin = lf < fc;
+    const long long f = fin ? f_begin + lf : f_begin;                // a padded frame computes on the chunk's first one and reports nothing
+    const unsigned fb = (unsigned)f * 4u, F4 = (unsigned)F * 4u;
+    auto at = [&](unsigned atom, int ax) {
+        if constexpr (SMALL) return mk_load_f32_base_soffset(coords, (atom * 3u + (unsigned)ax) * F4, fb);
+        else return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
+    };
+    const long long i0 = ig * CR_I, ni = n1 - i0 < CR_I ? n1 - i0 : CR_I;       // block-uniform, >= 1
+    const long long jw = jt * DT + (long long)pq * CT_RUN;           // the wave's first second atom
+    const int nv = n2 - jw >= CT_RUN ? CT_RUN : (n2 - jw > 0 ? (int)(n2 - jw) : 0);     // wave-uniform: how many of its 16 exist
+    if (nv > 0) {
+        // lane k holds second atom k and its chain (past the row's end: the last one again -- computed, masked out)
+        const long long jk = jw + (fl & (CT_RUN - 1)) < n2 ? jw + (fl & (CT_RUN - 1)) : n2 - 1;
+        const unsigned vb = sel2[jk], vcb = PBC ? chains[vb] : 0u;
+        constexpr int H = CT_RUN / 2;
+        mk_f2 BX[H], BY[H], BZ[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const unsigned b0 = mk_readlane(vb, 2 * h), b1 = mk_readlane(vb, 2 * h + 1);
+            BX[h] = mk_f2{at(b0, 0), at(b1, 0)}; BY[h] = mk_f2{at(b0, 1), at(b1, 1)}; BZ[h] = mk_f2{at(b0, 2), at(b1, 2)};
+        }
+        float bx = 1.f, by = 1.f, bz = 1.f, ibx = 1.f, iby = 1.f, ibz = 1.f;
+        if (PBC) {
+            bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+            ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
+        }
+        const unsigned valid = nv >= CT_RUN ? 0xffffu : (1u << (unsigned)nv) - 1u;
+        unsigned a = sel1[i0];
+        float xa = at(a, 0), ya = at(a, 1), za = at(a, 2);
+        for (long long ii = 0; ii < ni; ++ii) {
+            // the next first atom's coordinates are requested before this one's distances are computed
+            const unsigned a_next = sel1[ii + 1 < ni ? i0 + ii + 1 : i0 + ii];
+            const float xn = at(a_next, 0), yn = at(a_next, 1), zn = at(a_next, 2);
+            // which of the 16 second atoms wrap against this first atom (pbc and different chains, distance_utils.pyx:49): wave-uniform bits
+            unsigned wm = 0u;
+            if (PBC) { const unsigned ca = chains[a]; wm = (unsigned)(mk_ballot(vcb != ca) & 0xffffull); }
+            unsigned m = 0u;
+            bool redo = false;
+            if (PBC && wm != 0u) {
+                // every pair in packed arithmetic WITH the image shift; where only some of the sixteen wrap (wave-uniform bits) the
+                // others are computed without it as well and chosen per pair -- no branch, four packed instructions more per two pairs
+                const bool all = wm == 0xffffu;
+                float risk = 0.f, none = 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    mk_f2 d2 = dist2_pk<true>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, risk);
+                    if (!all) {
+                        const mk_f2 o2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
+                        d2 = mk_f2{((wm >> (2 * h)) & 1u) ? d2[0] : o2[0], ((wm >> (2 * h + 1)) & 1u) ? d2[1] : o2[1]};
+                    }
+                    m |= (d2[0] <= thr2 ? 1u << (2 * h) : 0u) | (d2[1] <= thr2 ? 2u << (2 * h) : 0u);     // distance_utils.pyx:82 (NaN: no contact)
+                }
+                redo = mk_ballot(!(risk < DRC_RISK)) != 0ull;        // an image integer may differ from round(d / b) (rare)
+            } else {
+                float none = 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const mk_f2 d2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
+                    m |= (d2[0] <= thr2 ? 1u << (2 * h) : 0u) | (d2[1] <= thr2 ? 2u << (2 * h) : 0u);
+                }
+            }
+            if (redo) {
+                // pair by pair with the per-pair test and the correctly rounded divisions behind it; the second atoms are loaded again
+                // (a loop, not sixteen inlined copies: with those the kernel held 182 registers -- two waves per SIMD)
+                mk_stay_in_branch();
+                m = 0u;
+#pragma unroll 1
+                for (int k = 0; k < CT_RUN; ++k) {
+                    const unsigned bk = mk_readlane(vb, k);
+                    const float d = dist2_min_image_f32(xa, ya, za, at(bk, 0), at(bk, 1), at(bk, 2), bx, by, bz, ibx, iby, ibz, ((wm >> k) & 1u) != 0u);
+                    m |= d <= thr2 ? 1u << k : 0u;
+                }
+            }
+            m = fin ? m & valid : 0u;
+            masks[(((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf] = (unsigned short)m;
+            s_c[ii][pq][fl] = (unsigned)__builtin_popcount(m);
+            a = a_next; xa = xn; ya = yn; za = zn;
+        }
+    } else {
+        for (long long ii = 0; ii < ni; ++ii) {                      // a run past the row's end: nothing, said explicitly (the fill pass reads it)
+            masks[(((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf] = 0;
+            s_c[ii][pq][fl] = 0u;
+        }
+    }
+    mk_block_sync();
+    for (long long ii = pq; ii < ni; ii += DT_THREADS / DT) {        // ONE count per (row tile, frame)
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < DT_THREADS / DT; ++w) t += s_c[ii][w][fl];
+        cnt[((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (size_t)fc_pad + (size_t)lf] = t;
+    }
+}
+
+// blockIdx.x = (group of CR_I first atoms) * JT + tile of 64 second atoms, blockIdx.y = 64-frame slab of the chunk; cnt is
+// [n1 * JT][fc_pad], masks [n1 * JT * 4 runs][fc_pad] -- the layouts of k_contacts_count with row tiles for pair tiles
+template <bool PBC>
+MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coords, long long F, long long f_begin, long long fc, long long fc_pad,
+                                                 const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
+                                                 const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains,
+                                                 float thr2, unsigned* __restrict__ cnt, unsigned short* __restrict__ masks)
+{
+    __shared__ unsigned s_c[CR_I][DT_THREADS / DT][DT];
+    const long long JT = (n2 + DT - 1) / DT, ig = (long long)blockIdx.x / JT, jt = (long long)blockIdx.x % JT;
+    // every row this BLOCK touches ends below 4 GiB from the start of the array?  (block-uniform: every wave looks at the tile's 64
+    // second atoms and the block's first atoms)
+    const int l = threadIdx.x & (DT - 1);
+    const long long jl = jt * DT + l, il = ig * CR_I + (l & (CR_I - 1));
+    const unsigned hb = sel2[jl < n2 ? jl : n2 - 1], ha = sel1[il < n1 ? il : n1 - 1];
+    const unsigned hi_atom = hb > ha ? hb : ha;
+    const bool small_rows = mk_ballot(((unsigned long long)hi_atom * 3ull + 3ull) * ((unsigned long long)F * 4ull) > 0xffffffffull) == 0ull;
+    if (small_rows) contacts_rect_block<PBC, true>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, cnt, masks, s_c, ig, jt, JT);
+    else contacts_rect_block<PBC, false>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, cnt, masks, s_c, ig, jt, JT);
+}
+
+// k_contacts_fill for row tiles: the pair behind bit k of run pq of tile t is (sel1[t / JT], sel2[(t % JT) * 64 + 16 pq + k])
+MK_KERNEL(DT_THREADS) void k_contacts_fill_rect(long long fc, long long fc_pad, const unsigned* __restrict__ sel1, const unsigned* __restrict__ sel2,
+                                                long long n2, const unsigned short* __restrict__ masks, const unsigned* __restrict__ prefix,
+                                                const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
+{
+    __shared__ unsigned s_c[DT_THREADS / DT][DT];
+    const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
+    const long long lf = (long long)blockIdx.y * DT + fl;
+    const bool fin = lf < fc;
+    const long long JT = (n2 + DT - 1) / DT, i = (long long)blockIdx.x / JT, j_first = ((long long)blockIdx.x % JT) * DT + pq * CT_RUN;
+    unsigned m = masks[((size_t)blockIdx.x * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf];   // (0 for padded frames and past a row's end)
+    s_c[pq][fl] = (unsigned)__builtin_popcount(m);
+    mk_block_sync();
+    if (!fin || m == 0u) return;
+    unsigned long long pos = frame_base[lf] + prefix[(size_t)blockIdx.x * fc_pad + lf];
+    for (int w = 0; w < pq; ++w) pos += s_c[w][fl];
+    const unsigned a = sel1[i];
+    while (m) {                                                    // ascending j = the reference's (i, j) order
+        const int k = __builtin_ctz(m);
+        m &= m - 1u;
+        out[pos++] = make_uint2(a, sel2[j_first + k]);
+    }
+}
+
 // Centre of mass of every group in every frame (distance_utils.pyx:160-183): sequential float32
 // accumulation in group order.  com has the coords layout [n_groups, 3, F]; lanes along frames.
 MK_KERNEL(256) void k_group_com(const float* __restrict__ coords, long long F,
@@ -933,30 +1148,6 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
 // ------------------------------------------------------------------------------------------------
 constexpr int DRC_WAVES = 8;                         // waves per block: 8 consecutive group pairs each (round 6, measured: 4 waves x 16 pairs
                                                      // left the chip's last round of blocks 43 % full on 19 900 pairs x 512 frames)
-constexpr float DRC_RISK = 0.4999998f;               // risk below this: every rndne(d * fl(1/b)) is the reference's round(d / b)
-                                                     // (the per-pair test is tm < 0.5 - 3e-7 qm, proven bound 1.8e-7 qm; here
-                                                     //  tm + 3e-7 qm is rounded once more: 2e-7 of slack)
-
-// d^2 of two atom pairs (first atoms ax/ay/az[0..1], second atom (x2, y2, z2)) -- distance_utils.pyx:188-206
-template <bool WR>
-MK_DEV mk_f2 dist2_pk(mk_f2 ax, mk_f2 ay, mk_f2 az, float x2, float y2, float z2, float bx, float by, float bz,
-                      float ibx, float iby, float ibz, float& risk)
-{
-    mk_f2 dx = mk_f2_sub_rn(ax, mk_f2_splat(x2)), dy = mk_f2_sub_rn(ay, mk_f2_splat(y2)), dz = mk_f2_sub_rn(az, mk_f2_splat(z2));
-    if constexpr (WR) {
-        const mk_f2 qx = mk_f2_mul_rn(dx, mk_f2_splat(ibx)), qy = mk_f2_mul_rn(dy, mk_f2_splat(iby)), qz = mk_f2_mul_rn(dz, mk_f2_splat(ibz));
-        const mk_f2 rx = mk_f2{mk_rint(qx[0]), mk_rint(qx[1])}, ry = mk_f2{mk_rint(qy[0]), mk_rint(qy[1])}, rz = mk_f2{mk_rint(qz[0]), mk_rint(qz[1])};
-        const mk_f2 tx = mk_f2_sub_rn(qx, rx), ty = mk_f2_sub_rn(qy, ry), tz = mk_f2_sub_rn(qz, rz);       // (exact)
-        const float s0 = mk_fma(3e-7f, mk_max3_abs_raw(qx[0], qy[0], qz[0]), mk_max3_abs_raw(tx[0], ty[0], tz[0]));
-        const float s1 = mk_fma(3e-7f, mk_max3_abs_raw(qx[1], qy[1], qz[1]), mk_max3_abs_raw(tx[1], ty[1], tz[1]));
-        risk = mk_max3_raw(risk, s0, s1);
-        dx = mk_f2_sub_rn(dx, mk_f2_mul_rn(mk_f2_splat(bx), rx));
-        dy = mk_f2_sub_rn(dy, mk_f2_mul_rn(mk_f2_splat(by), ry));
-        dz = mk_f2_sub_rn(dz, mk_f2_mul_rn(mk_f2_splat(bz), rz));
-    }
-    return mk_f2_add_rn(mk_f2_add_rn(mk_f2_mul_rn(dx, dx), mk_f2_mul_rn(dy, dy)), mk_f2_mul_rn(dz, dz));
-}
-
 template <int I /* first-group atoms in registers: 4 or 8 */, bool SMALL /* every coordinate row ends below 4 GiB: one descriptor */,
           int NW = DRC_WAVES /* waves per block; DT / NW consecutive group pairs per wave */>
 MK_KERNEL(NW * WAVE) void k_dist_reduction_closest(const float* __restrict__ coords, long long F, const float* __restrict__ box,

@@ -243,10 +243,11 @@ struct DevicePairSink {
     }
     int commit(void*, size_t n) { size += n; return 0; }
 };
+enum { CONTACTS_AVOID_RECT = 1 };      // `avoid`: the tests walk both walks over the same shapes
 template <class BE, class Sink>
 int run_contacts(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                  const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, float dist_threshold,
-                 size_t budget_bytes, long long* frame_offsets, Sink&& sink, std::string& err)
+                 size_t budget_bytes, long long* frame_offsets, Sink&& sink, std::string& err, int avoid = 0)
 {
     for (long long f = 0; f <= F; ++f) frame_offsets[f] = 0;
     if (F < 0 || n1 < 0 || n2 < 0) { err = "negative size"; return ST_EINVAL; }
@@ -256,13 +257,19 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     void *pa = nullptr, *pb = nullptr, *wr = nullptr, *cnt = nullptr, *tot = nullptr, *base = nullptr, *dout = nullptr, *msk = nullptr;
     int st;
-    if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
-    if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
-    if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
-    if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
-                        chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
+    // A rectangular call (no selfdist) whose rows fill at least three eighths of their 64-wide row tiles: second atoms in registers,
+    // no pair table (k_contacts_count_rect; a 30-atom ligand: 30 of 64, a single ion: the pair-table walk)
+    const long long JT = ceil_div(n2, DT);
+    const bool rect = !selfdist && !(avoid & CONTACTS_AVOID_RECT) && n2 * 8 >= JT * DT * 3 && n1 * JT <= 0x7ffffff0LL;
+    if (!rect) {
+        if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
+        if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
+        if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
+        if ((st = be.launch(k_build_atom_pairs, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535)), dim3(256), sel1, n1, sel2, n2,
+                            chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
+    }
     // frames per chunk: the per-(tile, frame) counters stay within the budget whatever the number of pairs
-    const long long tiles = ceil_div(P, DT);
+    const long long tiles = rect ? n1 * JT : ceil_div(P, DT);
     long long chunk = ((long long)budget_bytes / (tiles * 12)) / DT * DT;     // 4 B of counter + 4 x 2 B of contact masks per (tile, frame)
     chunk = std::max<long long>(DT, std::min<long long>(chunk, (F + DT - 1) / DT * DT));
     chunk = std::min<long long>(chunk, 65535LL * DT);
@@ -275,8 +282,15 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     for (long long f0 = 0; f0 < F; f0 += chunk) {
         const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
         const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
-        if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
-                            (const unsigned*)wr, P, thr2, (unsigned*)cnt, (unsigned short*)msk))) return st;
+        if (rect) {
+            const dim3 cgrid((unsigned)(ceil_div(n1, CR_I) * JT), (unsigned)(fc_pad / DT));
+            st = pbc ? be.launch(k_contacts_count_rect<true>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2,
+                                 (unsigned*)cnt, (unsigned short*)msk)
+                     : be.launch(k_contacts_count_rect<false>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2,
+                                 (unsigned*)cnt, (unsigned short*)msk);
+            if (st) return st;
+        } else if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
+                                   (const unsigned*)wr, P, thr2, (unsigned*)cnt, (unsigned short*)msk))) return st;
         if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(CS_WAVES * WAVE), (unsigned*)cnt, tiles, fc_pad,
                             (unsigned long long*)tot))) return st;
         if ((st = be.to_host(totals.data(), tot, (size_t)fc_pad * 8))) return st;
@@ -286,8 +300,11 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         if (run == 0) continue;
         if ((st = sink.reserve((size_t)run, &dout))) return st;
         if ((st = be.to_device(base, bases.data(), (size_t)fc_pad * 8))) return st;
-        if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), fc, fc_pad, (const unsigned*)pa, (const unsigned*)pb, (const unsigned short*)msk,
-                            (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
+        if (rect) {
+            if ((st = be.launch(k_contacts_fill_rect, grid, dim3(DT_THREADS), fc, fc_pad, sel1, sel2, n2, (const unsigned short*)msk, (const unsigned*)cnt,
+                                (const unsigned long long*)base, (uint2*)dout))) return st;
+        } else if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), fc, fc_pad, (const unsigned*)pa, (const unsigned*)pb, (const unsigned short*)msk,
+                                   (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
         if ((st = sink.commit(dout, (size_t)run))) return st;
     }
     return ST_OK;

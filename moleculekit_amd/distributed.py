@@ -336,7 +336,9 @@ class ShardedVoxelizer:
         cb = [chunk_bounds(int(s), nchunks) for s in sizes]               # per rank: its chunk boundaries (same count)
         tail = (self.V, self.C)
         cuda = self.device.type == "cuda"
-        comm = torch.cuda.Stream(device=self.device) if cuda else None
+        # a high-priority stream: the exchange of chunk c has to run BESIDE the voxelization of chunk c + 1; streams of one priority share
+        # hardware queues, and on the main stream's queue the two would take turns (batch._stream_voxelize, round 6)
+        comm = torch.cuda.Stream(device=self.device, priority=-1) if cuda else None
         main = torch.cuda.current_stream(self.device) if cuda else None
 
         if exchange == "p2p":

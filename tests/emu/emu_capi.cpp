@@ -261,20 +261,20 @@ int emu_dist_reduction(const float* coords, long long F, const float* box, const
 // contacts_trajectory: frame_offsets [F+1]; pairs_out (capacity 2*cap uint32) gets the (a, b) pairs; returns the count in *n_out
 int emu_contacts(const float* coords, long long F, const float* box, const unsigned* sel1, long long n1, const unsigned* sel2,
                  long long n2, const unsigned* chains, int selfdist, int pbc, float threshold, long long budget_bytes,
-                 long long* frame_offsets, unsigned* pairs_out, long long cap, long long* n_out, int device_sink)
+                 long long* frame_offsets, unsigned* pairs_out, long long cap, long long* n_out, int device_sink, int avoid /* CONTACTS_AVOID_* */)
 {
     EmuBackend be;
     if (device_sink) {                                               // the "_dev" entry point's sink: one buffer that grows by copying
         DevicePairSink<EmuBackend> sink{be};
         const int st = run_contacts(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, threshold, (size_t)budget_bytes,
-                                    frame_offsets, sink, g_err);
+                                    frame_offsets, sink, g_err, avoid);
         *n_out = (long long)sink.size;
         if (!st && (long long)sink.size <= cap && sink.size) memcpy(pairs_out, sink.base, sink.size * 2 * sizeof(unsigned));
         return st;
     }
     std::vector<unsigned> pairs;
     const int st = run_contacts(be, coords, F, box, sel1, n1, sel2, n2, chains, selfdist, pbc, threshold, (size_t)budget_bytes,
-                                frame_offsets, HostPairSink<EmuBackend>{be, pairs}, g_err);
+                                frame_offsets, HostPairSink<EmuBackend>{be, pairs}, g_err, avoid);
     *n_out = (long long)(pairs.size() / 2);
     if (!st && (long long)(pairs.size() / 2) <= cap) memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(unsigned));
     return st;

@@ -194,10 +194,11 @@ def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masse
     return out
 
 
-def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshold, budget_bytes=256 << 20, device_sink=False):
+def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshold, budget_bytes=256 << 20, device_sink=False, avoid=0):
     """-> per-frame list of flat [a0, b0, a1, b1, ...] lists (the reference's return shape), through the device-side
     count / scan / fill kernels; a tiny `budget_bytes` forces several chunks of frames; `device_sink`: the list is kept in ONE
-    growing 'device' buffer as mkamd_contacts_trajectory_dev keeps it (else chunk by chunk to the host, the "_host" form)."""
+    growing 'device' buffer as mkamd_contacts_trajectory_dev keeps it (else chunk by chunk to the host, the "_host" form);
+    `avoid` = 1: a rectangular call takes the pair-table walk as well (CONTACTS_AVOID_RECT)."""
     coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
     sel1 = np.ascontiguousarray(sel1, np.uint32); sel2 = np.ascontiguousarray(sel2, np.uint32)
     chains = np.ascontiguousarray(chains, np.uint32)
@@ -209,7 +210,7 @@ def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshol
     st = lib().emu_contacts(_p(coords), ctypes.c_longlong(F), _p(box), _p(sel1), ctypes.c_longlong(len(sel1)), _p(sel2),
                             ctypes.c_longlong(len(sel2)), _p(chains), ctypes.c_int(int(selfdist)), ctypes.c_int(int(pbc)),
                             ctypes.c_float(threshold), ctypes.c_longlong(budget_bytes), _p(offs), _p(pairs), ctypes.c_longlong(cap),
-                            ctypes.byref(n), ctypes.c_int(int(device_sink)))
+                            ctypes.byref(n), ctypes.c_int(int(device_sink)), ctypes.c_int(int(avoid)))
     assert st == 0, lib().emu_last_error()
     flat = pairs[:2 * n.value].astype(np.int64)
     return [flat[2 * offs[f]:2 * offs[f + 1]].tolist() for f in range(F)]

@@ -489,3 +489,155 @@ def test_periodic_row_kernel_image_integers_are_the_references(mixed):
                 got = E.dist_trajectory(c, b, s1, s2, ch, False, True, squared=sq, avoid=avoid)
                 assert np.array_equal(got, want, equal_nan=True), (sq, avoid)
         assert np.isnan(want).any()                              # (the zero box, the NaN coordinate; an inf coordinate wraps to NaN as well)
+
+
+def _pair_table_trap_case(mixed, seed=21):
+    """40 atoms x 70 frames for the PAIR-TABLE walk (selfdist: k_dist_pairs, and the contact kernels on the same walk): in every frame one
+    pair sits at an image-integer trap (rndne(d * fl(1/b)) != round(d / b)), one frame has a zero box, one coordinate is inf and one NaN;
+    every atom its own chain (all pairs wrap: the packed batches), or -- `mixed` -- three chains (batches in which some pairs wrap)."""
+    rng = np.random.default_rng(seed)
+    N, F = 40, 70
+    c = rng.uniform(0, 14, size=(N, 3, F)).astype(np.float32)
+    b = np.empty((3, F), np.float32)
+    traps = _image_integer_traps(rng, F)
+    where = []
+    for f, (bl, d) in enumerate(traps):
+        b[:, f] = [np.float32(43.7), np.float32(39.1), np.float32(47.3)]
+        ax, i = f % 3, int(rng.integers(0, N - 1))
+        j = int(rng.integers(i + 1, N))
+        if mixed:                                                # (a pair of different chains: it wraps)
+            while (i % 3) == (j % 3):
+                j = j + 1 if j + 1 < N else i + 1
+        b[ax, f] = bl
+        c[i, ax, f] = 0.0                                        # (so that first - second is EXACTLY the trap's separation)
+        c[j, :, f] = c[i, :, f]
+        c[j, ax, f] = -d
+        where.append((i, j))
+    b[:, 11] = 0.0
+    c[7, 0, 12] = np.inf
+    c[9, 1, 13] = np.nan
+    ch = (np.arange(N) % 3 if mixed else np.arange(N)).astype(np.uint32)
+    return c, b, ch, np.arange(N, dtype=np.uint32), where
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_pair_table_walk_packed_batches_redo_image_integer_traps(mixed):
+    """for_pair_run (round 6): batches of four wrapping pairs run in packed arithmetic behind one accumulated test of their image
+    integers; a batch holding a trap must be redone pair by pair (mutation-checked: with the redo switched off this fails in most frames),
+    batches with pairs of one chain among them never take the packed form.  selfdist (the pair table), distances and squares, and the
+    contact lists of the same walk."""
+    c, b, ch, sel, where = _pair_table_trap_case(mixed)
+    with np.errstate(all="ignore"):
+        for sq in (False, True):
+            want = oracle.dist_trajectory(c, b, sel, sel, ch, True, True, squared=sq)
+            got = E.dist_trajectory(c, b, sel, sel, ch, True, True, squared=sq)
+            assert np.array_equal(got, want, equal_nan=True), sq
+        assert np.isnan(want).any()
+        # what the fast integer alone would have given differs from the reference at the trapped pair of most frames
+        f32, differ = np.float32, 0
+        for f, (i, j) in enumerate(where):
+            if f in (11, 12, 13):
+                continue
+            ax = f % 3
+            d, bl = f32(c[i, ax, f] - c[j, ax, f]), b[ax, f]
+            r_fast = np.rint(f32(d * (f32(1) / bl)))
+            q = float(f32(d / bl)); r_ref = np.sign(q) * np.floor(abs(q) + 0.5)
+            differ += r_fast != r_ref
+        assert differ > 40
+        d2 = oracle.dist_trajectory(c, b, sel, sel, ch, True, True, squared=True)
+        res = E.contacts_trajectory(c, b, sel, sel, ch, True, True, 9.0)
+        iu, ju = np.triu_indices(len(sel), 1)
+        for f in range(c.shape[2]):
+            hit = np.nonzero(d2[f] <= f32(81.0))[0]
+            assert res[f] == np.stack([sel[iu[hit]], sel[ju[hit]]], 1).astype(np.int64).ravel().tolist(), f
+
+
+def _contact_lists(d2, s1, s2, thr):
+    out = []
+    for f in range(d2.shape[0]):
+        hit = np.nonzero(d2[f] <= np.float32(thr) * np.float32(thr))[0]
+        i, j = np.divmod(hit, len(s2))
+        out.append(np.stack([s1[i], s2[j]], 1).astype(np.int64).ravel().tolist())
+    return out
+
+
+def _rect_contact_case(ids, n2, n1=21, F=70, seed=31):
+    """n1 x n2 atoms x F frames for the rectangular contact kernel: an image-integer trap in every frame (rndne(d * fl(1/b)) !=
+    round(d / b)), a zero box, inf / NaN coordinates; chain ids that make every pair wrap ("selections": 1 / 2), some ("chains"), none ("one")."""
+    rng = np.random.default_rng(seed)
+    N = n1 + n2
+    c = rng.uniform(0, 14, size=(N, 3, F)).astype(np.float32)
+    b = np.empty((3, F), np.float32)
+    traps = _image_integer_traps(rng, F)
+    for f, (bl, d) in enumerate(traps):
+        b[:, f] = [np.float32(43.7), np.float32(39.1), np.float32(47.3)]
+        ax, i, j = f % 3, f % n1, n1 + (17 * f) % n2
+        b[ax, f] = bl
+        c[i, ax, f] = 0.0
+        c[j, :, f] = c[i, :, f]                                  # (a trapped pair is a contact at half a box length only through the image)
+        c[j, ax, f] = -d
+    b[:, 11] = 0.0
+    c[n1 + 5, 0, 12] = np.inf
+    c[n1 + 9, 1, 13] = np.nan
+    ch = np.ones(N, np.uint32); ch[n1:] = 2
+    if ids == "chains":
+        ch = rng.integers(0, 3, N).astype(np.uint32)
+    elif ids == "one":
+        ch[:] = 0
+    return c, b, ch, np.arange(n1, dtype=np.uint32), np.arange(n1, N, dtype=np.uint32)
+
+
+def _trapped_threshold_cases(seed=5, n1=8, n2=64, F=64):
+    """Frames whose pair (first atom 0, first second atom) sits at an image-integer trap, with the float32 threshold whose square is EXACTLY the
+    oracle's d^2 of that pair (frames for which no float32 squares to it are left out): `d^2 <= thr^2` holds for the reference and fails for a
+    kernel whose image integer gave a larger |d - b r| -- the contact list itself tells whether the trapped batch was redone pair by pair."""
+    rng = np.random.default_rng(seed)
+    N = n1 + n2
+    c = rng.uniform(0, 10, size=(N, 3, F)).astype(np.float32)
+    b = np.full((3, F), 40.0, np.float32)
+    s1, s2 = np.arange(n1, dtype=np.uint32), np.arange(n1, N, dtype=np.uint32)
+    ch = np.ones(N, np.uint32); ch[n1:] = 2
+    for f, (bl, d) in enumerate(_image_integer_traps(rng, F)):
+        b[0, f] = bl
+        c[0, 0, f] = 0.0
+        c[n1, :, f] = c[0, :, f]
+        c[n1, 0, f] = -d
+    d2 = oracle.dist_trajectory(c, b, s1, s2, ch, False, True, squared=True)
+    cases = []
+    for f in range(F):
+        thr = np.float32(np.sqrt(np.float64(d2[f, 0])))
+        if np.float32(thr * thr) == d2[f, 0]:
+            cases.append((c[:, :, f:f + 1].copy(), b[:, f:f + 1].copy(), float(thr), _contact_lists(d2[f:f + 1], s1, s2, thr)))
+    assert len(cases) >= 5
+    return cases, ch, s1, s2
+
+
+@pytest.mark.parametrize("ids", ["selections", "chains", "one"])
+def test_rectangular_contact_kernel_is_the_reference_order_and_image(ids):
+    """k_contacts_count_rect / k_contacts_fill_rect (round 6: second atoms in registers, row tiles, packed arithmetic): rows that end inside a
+    run of 16 and inside a tile of 64 (n2 = 70, 150), first atoms not a multiple of 8, frames not a multiple of 64, several chunks of
+    frames, traps, a zero box, inf / NaN.  Against the oracle's squared distances in the reference's (frame, i, j) order, and equal to the
+    pair-table walk's lists."""
+    for n2 in (70, 150):
+        c, b, ch, s1, s2 = _rect_contact_case(ids, n2)
+        with np.errstate(all="ignore"):
+            d2 = oracle.dist_trajectory(c, b, s1, s2, ch, False, True, squared=True)
+            # a threshold around half a box length catches the trapped pairs (their image decides), 6 A the ordinary ones
+            for thr in (6.0, 21.5):
+                want = _contact_lists(d2, s1, s2, thr)
+                assert sum(len(x) for x in want) > 0
+                for budget, sink in ((256 << 20, False), (12 * 64 * 8, True)):
+                    got = E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr, budget_bytes=budget, device_sink=sink)
+                    assert got == want, (n2, thr, budget)
+                assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr, avoid=1) == want
+            # pbc = False: no image at all
+            d2o = oracle.dist_trajectory(c, b, s1, s2, ch, False, False, squared=True)
+            assert E.contacts_trajectory(c, b, s1, s2, ch, False, False, 6.0) == _contact_lists(d2o, s1, s2, 6.0)
+
+
+def test_rectangular_contact_kernel_trapped_pairs_decide_contacts():
+    """A threshold whose square is exactly the reference's d^2 of a trapped pair: the pair is a contact only if the batch it sits in was
+    redone with the correctly rounded divisions (mutation-checked: with the accumulated test switched off this fails)."""
+    cases, ch, s1, s2 = _trapped_threshold_cases()
+    for c, b, thr, want in cases:
+        assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr) == want

@@ -562,6 +562,64 @@ def test_device_contact_list_equals_the_host_form_on_a_larger_call():
     assert got == want and n > 1000
 
 
+@pytest.mark.parametrize("ids", ["selections", "chains", "one"])
+def test_rectangular_contact_kernel_on_the_device(ids):
+    """k_contacts_count_rect / k_contacts_fill_rect (round 6): the cases of tests/test_distance_cpu.py on the hardware -- rows ending inside a
+    run of 16 and inside a tile of 64, ragged first atoms and frames, image-integer traps, a zero box, inf / NaN, every / some / no pair
+    wrapping -- against the oracle's squared distances in the reference's (frame, i, j) order; host form and device-resident form."""
+    import torch
+    from moleculekit_amd import _lib
+    from moleculekit_amd.distance_utils import contacts_trajectory
+    from tests.test_distance_cpu import _contact_lists, _rect_contact_case
+    dev = torch.device("cuda", 0)
+    ctx = _lib.default_context(0)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=dev)
+    for n2 in (70, 150):
+        c, b, ch, s1, s2 = _rect_contact_case(ids, n2)
+        F = c.shape[2]
+        with np.errstate(all="ignore"):
+            for pbc in (True, False):
+                d2 = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=True)
+                for thr in (6.0, 21.5):
+                    want = _contact_lists(d2, s1, s2, thr)
+                    assert contacts_trajectory(c, b, s1, s2, ch, False, pbc, thr) == want, (n2, pbc, thr)
+                    offs, ptr, n = ctx.contacts_trajectory_dev(t(c), F, t(b), t(s1.astype(np.int32)), len(s1), t(s2.astype(np.int32)), len(s2),
+                                                               t(ch.astype(np.int32)), False, pbc, thr)
+                    flat = np.empty(2 * n, np.uint32)
+                    if n:
+                        _lib._check(_lib.load().mkamd_copy_to_host(ctx._h, flat.ctypes.data, ptr, flat.nbytes))
+                    assert [flat[2 * offs[f]:2 * offs[f + 1]].astype(np.int64).tolist() for f in range(F)] == want
+
+
+def test_rectangular_contact_kernel_redoes_trapped_batches_on_the_device():
+    """A threshold whose square is exactly the reference's d^2 of a trapped pair: a contact only if its batch was redone pair by pair."""
+    from moleculekit_amd.distance_utils import contacts_trajectory
+    from tests.test_distance_cpu import _trapped_threshold_cases
+    cases, ch, s1, s2 = _trapped_threshold_cases()
+    for c, b, thr, want in cases:
+        assert contacts_trajectory(c, b, s1, s2, ch, False, True, thr) == want
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_pair_table_walk_packed_batches_on_the_device(mixed):
+    """for_pair_run's packed batches (round 6) on the hardware: selfdist with an image-integer trap in every frame, a zero box, inf / NaN;
+    every atom its own chain, and three chains (mixed batches); distances and the contact lists of the same walk."""
+    from moleculekit_amd.distance_utils import contacts_trajectory, dist_trajectory
+    from tests.test_distance_cpu import _pair_table_trap_case
+    c, b, ch, sel, _ = _pair_table_trap_case(mixed)
+    with np.errstate(all="ignore"):
+        want = oracle.dist_trajectory(c, b, sel, sel, ch, True, True)
+        got = np.zeros_like(want)
+        dist_trajectory(c, b, sel, sel, ch, True, True, got)
+        assert np.array_equal(got, want, equal_nan=True)
+        d2 = oracle.dist_trajectory(c, b, sel, sel, ch, True, True, squared=True)
+        res = contacts_trajectory(c, b, sel, sel, ch, True, True, 9.0)
+        iu, ju = np.triu_indices(len(sel), 1)
+        for f in range(c.shape[2]):
+            hit = np.nonzero(d2[f] <= np.float32(81.0))[0]
+            assert res[f] == np.stack([sel[iu[hit]], sel[ju[hit]]], 1).astype(np.int64).ravel().tolist(), f
+
+
 @pytest.mark.parametrize("D", [2, 3, 4])
 def test_cdist_pdist_at_size_bit_exact(D):
     """cdist / pdist at sizes that take thousands of blocks of the row kernels (D = 2, 3) and the generic kernels (D = 4): the oracle's
