@@ -838,23 +838,24 @@ MK_KERNEL(DT_THREADS) void k_contacts_fill(long long fc, long long fc_pad, const
 
 // ------------------------------------------------------------------------------------------------
 // The contact lists of a RECTANGULAR call (no selfdist: every sel1 atom against every sel2 atom), round 6.  The pair-table walk
-// above loads the second atom of EVERY pair (three 256-byte loads per 64 pair-frames: 2.5 GB through the L1 for 200 x 500 pairs x
-// 2 048 frames) and k_contacts_count took 186 us of a 0.30-ms call with a third of its issue slots used.  Here -- as in k_dist_rect
-// -- a wave keeps ITS sixteen second atoms in 48 registers (as eight packed pairs: lane = frame) and walks the block's CR_I first
-// atoms: 0.6 loads per pair; the sixteen d^2 of a first atom come from eight packed calls (dist2_pk), their image integers behind
-// ONE accumulated test.  Nothing goes through LDS but the per-(row tile, frame) counts.
-// A "row tile" is (first atom i, 64 consecutive second atoms jt): tile t = i * JT + jt, JT = ceil(n2 / 64); its four runs of 16 are
-// the four waves' second atoms.  Tiles ascend in the reference's (i, j) order, so scan and fill work as for the pair tiles -- with
-// masks past a row's end (j >= n2) zero.  No pair table is built: a pair is (sel1[t / JT], sel2[(t % JT) * 64 + 16 run + k]).
+// above loads the second atom of EVERY pair (three 256-byte loads per 64 pair-frames) and spends 33 instructions on a periodic
+// pair; its counters are per 64-pair tile, so a scan over 1 600 tiles and a fill pass of as many blocks follow (43 + 46 us of a
+// 0.30-ms call for 200 x 500 pairs x 2 048 frames).  Here -- as in k_dist_rect -- a wave keeps ITS sixteen second atoms in 48
+// registers (as eight packed pairs: lane = frame) and walks a GROUP of first atoms: the sixteen d^2 of a first atom come from
+// eight packed calls (dist2_pk), their image integers behind ONE accumulated test; rows of which only some pairs wrap compute
+// both forms and choose per pair.  Nothing goes through LDS, there is no barrier.
+//   masks  [(i * JT + jt) * 4 + run][frame]   the 16 contact bits of (first atom i, second atoms jt * 64 + 16 run ..), JT = ceil(n2 / 64);
+//                                             zero past a row's end and for padded frames
+//   cntg   [group][frame]                     contacts of the group's rows (groups of `ni` consecutive first atoms: contiguous in the
+//                                             reference's (i, j) order) -- added up by the waves with atomics; k_contacts_scan then runs over
+//                                             the GROUPS (25 instead of 1 600 tiles) and k_contacts_fill_rect finds a mask's place inside
+//                                             its group itself.  No pair table is built.
 // ------------------------------------------------------------------------------------------------
-constexpr int CR_I = 8;                // first atoms per block (the second atoms' 48 loads per wave are amortised over them)
-
 template <bool PBC, bool SMALL>
 MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, long long f_begin, long long fc, long long fc_pad,
                                 const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
-                                const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains, float thr2,
-                                unsigned* __restrict__ cnt, unsigned short* __restrict__ masks, unsigned (&s_c)[CR_I][DT_THREADS / DT][DT],
-                                long long ig, long long jt, long long JT)
+                                const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains, float thr2, long long ni,
+                                unsigned* __restrict__ cntg, unsigned short* __restrict__ masks, long long g, long long jt, long long JT)
 {
     const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
     const long long lf = (long long)blockIdx.y * DT + fl;
@@ -865,134 +866,161 @@ MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, l
         if constexpr (SMALL) return mk_load_f32_base_soffset(coords, (atom * 3u + (unsigned)ax) * F4, fb);
         else return mk_load_f32_uniform_base(coords + ((size_t)atom * 3 + (size_t)ax) * (size_t)F, fb);
     };
-    const long long i0 = ig * CR_I, ni = n1 - i0 < CR_I ? n1 - i0 : CR_I;       // block-uniform, >= 1
+    const long long i0 = g * ni, rows = n1 - i0 < ni ? n1 - i0 : ni;            // block-uniform, >= 1
     const long long jw = jt * DT + (long long)pq * CT_RUN;           // the wave's first second atom
     const int nv = n2 - jw >= CT_RUN ? CT_RUN : (n2 - jw > 0 ? (int)(n2 - jw) : 0);     // wave-uniform: how many of its 16 exist
-    if (nv > 0) {
-        // lane k holds second atom k and its chain (past the row's end: the last one again -- computed, masked out)
-        const long long jk = jw + (fl & (CT_RUN - 1)) < n2 ? jw + (fl & (CT_RUN - 1)) : n2 - 1;
-        const unsigned vb = sel2[jk], vcb = PBC ? chains[vb] : 0u;
-        constexpr int H = CT_RUN / 2;
-        mk_f2 BX[H], BY[H], BZ[H];
+    auto mask_at = [&](long long ii) -> unsigned short& {
+        return masks[(((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf];
+    };
+    if (nv == 0) {                                                   // a run past the row's end: nothing, said explicitly (the fill pass reads it)
+        for (long long ii = 0; ii < rows; ++ii) mask_at(ii) = 0;
+        return;
+    }
+    // lane k holds second atom k and its chain (past the row's end: the last one again -- computed, masked out)
+    const long long jk = jw + (fl & (CT_RUN - 1)) < n2 ? jw + (fl & (CT_RUN - 1)) : n2 - 1;
+    const unsigned vb = sel2[jk], vcb = PBC ? chains[vb] : 0u;
+    constexpr int H = CT_RUN / 2;
+    mk_f2 BX[H], BY[H], BZ[H];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const unsigned b0 = mk_readlane(vb, 2 * h), b1 = mk_readlane(vb, 2 * h + 1);
-            BX[h] = mk_f2{at(b0, 0), at(b1, 0)}; BY[h] = mk_f2{at(b0, 1), at(b1, 1)}; BZ[h] = mk_f2{at(b0, 2), at(b1, 2)};
-        }
-        float bx = 1.f, by = 1.f, bz = 1.f, ibx = 1.f, iby = 1.f, ibz = 1.f;
-        if (PBC) {
-            bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
-            ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
-        }
-        const unsigned valid = nv >= CT_RUN ? 0xffffu : (1u << (unsigned)nv) - 1u;
-        unsigned a = sel1[i0];
-        float xa = at(a, 0), ya = at(a, 1), za = at(a, 2);
-        for (long long ii = 0; ii < ni; ++ii) {
-            // the next first atom's coordinates are requested before this one's distances are computed
-            const unsigned a_next = sel1[ii + 1 < ni ? i0 + ii + 1 : i0 + ii];
-            const float xn = at(a_next, 0), yn = at(a_next, 1), zn = at(a_next, 2);
-            // which of the 16 second atoms wrap against this first atom (pbc and different chains, distance_utils.pyx:49): wave-uniform bits
-            unsigned wm = 0u;
-            if (PBC) { const unsigned ca = chains[a]; wm = (unsigned)(mk_ballot(vcb != ca) & 0xffffull); }
-            unsigned m = 0u;
-            bool redo = false;
-            if (PBC && wm != 0u) {
-                // every pair in packed arithmetic WITH the image shift; where only some of the sixteen wrap (wave-uniform bits) the
-                // others are computed without it as well and chosen per pair -- no branch, four packed instructions more per two pairs
-                const bool all = wm == 0xffffu;
-                float risk = 0.f, none = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const unsigned b0 = mk_readlane(vb, 2 * h), b1 = mk_readlane(vb, 2 * h + 1);
+        BX[h] = mk_f2{at(b0, 0), at(b1, 0)}; BY[h] = mk_f2{at(b0, 1), at(b1, 1)}; BZ[h] = mk_f2{at(b0, 2), at(b1, 2)};
+    }
+    float bx = 1.f, by = 1.f, bz = 1.f, ibx = 1.f, iby = 1.f, ibz = 1.f;
+    if (PBC) {
+        bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+        ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
+    }
+    const unsigned valid = nv >= CT_RUN ? 0xffffu : (1u << (unsigned)nv) - 1u;
+    unsigned a = sel1[i0], total = 0u, redo_rows = 0u;
+    float xa = at(a, 0), ya = at(a, 1), za = at(a, 2);
+    for (long long ii = 0; ii < rows; ++ii) {
+        // the next first atom's coordinates are requested before this one's distances are computed
+        const unsigned a_next = sel1[ii + 1 < rows ? i0 + ii + 1 : i0 + ii];
+        const float xn = at(a_next, 0), yn = at(a_next, 1), zn = at(a_next, 2);
+        // which of the 16 second atoms wrap against this first atom (pbc and different chains, distance_utils.pyx:49): wave-uniform bits
+        unsigned wm = 0u;
+        if (PBC) { const unsigned ca = chains[a]; wm = (unsigned)(mk_ballot(vcb != ca) & 0xffffull); }
+        unsigned m = 0u;
+        bool redo = false;
+        float none = 0.f;
+        if (PBC && wm == 0xffffu) {
+            float risk = 0.f;
 #pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    mk_f2 d2 = dist2_pk<true>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, risk);
-                    if (!all) {
-                        const mk_f2 o2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
-                        d2 = mk_f2{((wm >> (2 * h)) & 1u) ? d2[0] : o2[0], ((wm >> (2 * h + 1)) & 1u) ? d2[1] : o2[1]};
-                    }
-                    m |= (d2[0] <= thr2 ? 1u << (2 * h) : 0u) | (d2[1] <= thr2 ? 2u << (2 * h) : 0u);     // distance_utils.pyx:82 (NaN: no contact)
-                }
-                redo = mk_ballot(!(risk < DRC_RISK)) != 0ull;        // an image integer may differ from round(d / b) (rare)
-            } else {
-                float none = 0.f;
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const mk_f2 d2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
-                    m |= (d2[0] <= thr2 ? 1u << (2 * h) : 0u) | (d2[1] <= thr2 ? 2u << (2 * h) : 0u);
-                }
+            for (int h = 0; h < H; ++h) {
+                const mk_f2 d2 = dist2_pk<true>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, risk);
+                m |= (d2[0] <= thr2 ? 1u << (2 * h) : 0u) | (d2[1] <= thr2 ? 2u << (2 * h) : 0u);         // distance_utils.pyx:82 (NaN: no contact)
+                if (h & 1) mk_sched_barrier();                     // (two packed calls at a time: left alone the scheduler interleaves all eight -- 215 registers)
             }
-            if (redo) {
-                // pair by pair with the per-pair test and the correctly rounded divisions behind it; the second atoms are loaded again
-                // (a loop, not sixteen inlined copies: with those the kernel held 182 registers -- two waves per SIMD)
-                mk_stay_in_branch();
-                m = 0u;
+            redo = mk_ballot(!(risk < DRC_RISK)) != 0ull;            // an image integer may differ from round(d / b) (rare)
+        } else if (PBC && wm != 0u) {
+            // only some of the sixteen wrap (wave-uniform bits): both forms, chosen per pair -- no branch, four packed instructions more
+            float risk = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const mk_f2 w2 = dist2_pk<true>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, risk);
+                const mk_f2 o2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
+                const float d0 = ((wm >> (2 * h)) & 1u) ? w2[0] : o2[0], d1 = ((wm >> (2 * h + 1)) & 1u) ? w2[1] : o2[1];
+                m |= (d0 <= thr2 ? 1u << (2 * h) : 0u) | (d1 <= thr2 ? 2u << (2 * h) : 0u);
+                mk_sched_barrier();
+            }
+            redo = mk_ballot(!(risk < DRC_RISK)) != 0ull;
+        } else {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const mk_f2 d2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
+                m |= (d2[0] <= thr2 ? 1u << (2 * h) : 0u) | (d2[1] <= thr2 ? 2u << (2 * h) : 0u);
+                if ((h & 3) == 3) mk_sched_barrier();
+            }
+        }
+        if (redo) redo_rows |= 1u << (unsigned)ii;                  // (wave-uniform; at most 32 rows per group)
+        m = fin ? m & valid : 0u;
+        mask_at(ii) = (unsigned short)m;
+        total += (unsigned)__builtin_popcount(m);
+        a = a_next; xa = xn; ya = yn; za = zn;
+    }
+    while (redo_rows) {
+        // rows whose accumulated test failed in some lane, once more: pair by pair with the per-pair test and the correctly rounded
+        // divisions behind it, the atoms loaded again.  (AFTER the walk and as loops: inside it, as sixteen inlined pairs, the kernel held
+        // 182 registers, as a loop 209 -- two waves per SIMD; out here the walk keeps ~100.)
+        mk_stay_in_branch();
+        const int ii = __builtin_ctz(redo_rows);
+        redo_rows &= redo_rows - 1u;
+        const unsigned ar = sel1[i0 + ii];
+        const unsigned wm = (unsigned)(mk_ballot(vcb != chains[ar]) & 0xffffull);
+        const float xr = at(ar, 0), yr = at(ar, 1), zr = at(ar, 2);
+        unsigned m = 0u;
 #pragma unroll 1
-                for (int k = 0; k < CT_RUN; ++k) {
-                    const unsigned bk = mk_readlane(vb, k);
-                    const float d = dist2_min_image_f32(xa, ya, za, at(bk, 0), at(bk, 1), at(bk, 2), bx, by, bz, ibx, iby, ibz, ((wm >> k) & 1u) != 0u);
-                    m |= d <= thr2 ? 1u << k : 0u;
-                }
-            }
-            m = fin ? m & valid : 0u;
-            masks[(((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf] = (unsigned short)m;
-            s_c[ii][pq][fl] = (unsigned)__builtin_popcount(m);
-            a = a_next; xa = xn; ya = yn; za = zn;
+        for (int k = 0; k < CT_RUN; ++k) {
+            const unsigned bk = mk_readlane(vb, k);
+            const float d = dist2_min_image_f32(xr, yr, zr, at(bk, 0), at(bk, 1), at(bk, 2), bx, by, bz, ibx, iby, ibz, ((wm >> k) & 1u) != 0u);
+            m |= d <= thr2 ? 1u << k : 0u;
         }
-    } else {
-        for (long long ii = 0; ii < ni; ++ii) {                      // a run past the row's end: nothing, said explicitly (the fill pass reads it)
-            masks[(((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf] = 0;
-            s_c[ii][pq][fl] = 0u;
-        }
+        m = fin ? m & valid : 0u;
+        const unsigned old = mask_at(ii);
+        mask_at(ii) = (unsigned short)m;
+        total += (unsigned)__builtin_popcount(m) - (unsigned)__builtin_popcount(old);
     }
-    mk_block_sync();
-    for (long long ii = pq; ii < ni; ii += DT_THREADS / DT) {        // ONE count per (row tile, frame)
-        unsigned t = 0;
-#pragma unroll
-        for (int w = 0; w < DT_THREADS / DT; ++w) t += s_c[ii][w][fl];
-        cnt[((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (size_t)fc_pad + (size_t)lf] = t;
-    }
+    if (total) mk_atomic_add(&cntg[(size_t)g * (size_t)fc_pad + (size_t)lf], total);
 }
 
-// blockIdx.x = (group of CR_I first atoms) * JT + tile of 64 second atoms, blockIdx.y = 64-frame slab of the chunk; cnt is
-// [n1 * JT][fc_pad], masks [n1 * JT * 4 runs][fc_pad] -- the layouts of k_contacts_count with row tiles for pair tiles
+// blockIdx.x = (group of `ni` first atoms) * JT + tile of 64 second atoms, blockIdx.y = 64-frame slab of the chunk; cntg (zeroed by the
+// host sequence) is [groups][fc_pad]
 template <bool PBC>
 MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coords, long long F, long long f_begin, long long fc, long long fc_pad,
                                                  const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
                                                  const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains,
-                                                 float thr2, unsigned* __restrict__ cnt, unsigned short* __restrict__ masks)
+                                                 float thr2, long long ni, unsigned* __restrict__ cntg, unsigned short* __restrict__ masks)
 {
-    __shared__ unsigned s_c[CR_I][DT_THREADS / DT][DT];
-    const long long JT = (n2 + DT - 1) / DT, ig = (long long)blockIdx.x / JT, jt = (long long)blockIdx.x % JT;
+    const long long JT = (n2 + DT - 1) / DT, g = (long long)blockIdx.x / JT, jt = (long long)blockIdx.x % JT;
     // every row this BLOCK touches ends below 4 GiB from the start of the array?  (block-uniform: every wave looks at the tile's 64
-    // second atoms and the block's first atoms)
+    // second atoms and at first atoms of the group, lane l at the l-th of them as far as they go)
     const int l = threadIdx.x & (DT - 1);
-    const long long jl = jt * DT + l, il = ig * CR_I + (l & (CR_I - 1));
-    const unsigned hb = sel2[jl < n2 ? jl : n2 - 1], ha = sel1[il < n1 ? il : n1 - 1];
-    const unsigned hi_atom = hb > ha ? hb : ha;
+    const long long jl = jt * DT + l;
+    unsigned hi_atom = sel2[jl < n2 ? jl : n2 - 1];
+    for (long long il = g * ni + l; il < n1 && il < (g + 1) * ni; il += DT) { const unsigned ha = sel1[il]; hi_atom = ha > hi_atom ? ha : hi_atom; }
     const bool small_rows = mk_ballot(((unsigned long long)hi_atom * 3ull + 3ull) * ((unsigned long long)F * 4ull) > 0xffffffffull) == 0ull;
-    if (small_rows) contacts_rect_block<PBC, true>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, cnt, masks, s_c, ig, jt, JT);
-    else contacts_rect_block<PBC, false>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, cnt, masks, s_c, ig, jt, JT);
+    if (small_rows) contacts_rect_block<PBC, true>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, cntg, masks, g, jt, JT);
+    else contacts_rect_block<PBC, false>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, cntg, masks, g, jt, JT);
 }
 
-// k_contacts_fill for row tiles: the pair behind bit k of run pq of tile t is (sel1[t / JT], sel2[(t % JT) * 64 + 16 pq + k])
-MK_KERNEL(DT_THREADS) void k_contacts_fill_rect(long long fc, long long fc_pad, const unsigned* __restrict__ sel1, const unsigned* __restrict__ sel2,
-                                                long long n2, const unsigned short* __restrict__ masks, const unsigned* __restrict__ prefix,
-                                                const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
+// The fill pass of a rectangular call: blockIdx.x = group of first atoms, blockIdx.y = 64-frame slab; lanes = frames.  The group's masks of a
+// frame -- rows x JT * 4 runs, in the reference's (i, j) order -- are split among the block's CF_WAVES waves: a wave counts its stretch,
+// the stretches' counts meet in LDS, then it walks the stretch again and writes (a, b) from
+//   frame_base[frame] + gprefix[group][frame] (k_contacts_scan over the groups) + the stretches before its own.
+// The pair behind bit k of run r of row i is (sel1[i], sel2[16 r + k]).
+constexpr int CF_WAVES = 16;
+MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_pad, const unsigned* __restrict__ sel1, long long n1,
+                                                     const unsigned* __restrict__ sel2, long long n2, long long ni,
+                                                     const unsigned short* __restrict__ masks, const unsigned* __restrict__ gprefix,
+                                                     const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
 {
-    __shared__ unsigned s_c[DT_THREADS / DT][DT];
-    const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
-    const long long lf = (long long)blockIdx.y * DT + fl;
-    const bool fin = lf < fc;
-    const long long JT = (n2 + DT - 1) / DT, i = (long long)blockIdx.x / JT, j_first = ((long long)blockIdx.x % JT) * DT + pq * CT_RUN;
-    unsigned m = masks[((size_t)blockIdx.x * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf];   // (0 for padded frames and past a row's end)
-    s_c[pq][fl] = (unsigned)__builtin_popcount(m);
+    __shared__ unsigned s_seg[CF_WAVES][DT];
+    const int fl = threadIdx.x & (DT - 1), w = threadIdx.x >> 6;
+    const long long lf = (long long)blockIdx.y * DT + fl, g = blockIdx.x;
+    const long long R4 = ((n2 + DT - 1) / DT) * (DT_THREADS / DT);   // runs per row, padded to whole tiles
+    const long long i0 = g * ni, rows = n1 - i0 < ni ? n1 - i0 : ni, M = rows * R4;
+    const long long per = (M + CF_WAVES - 1) / CF_WAVES, q0 = w * per < M ? w * per : M, q1 = q0 + per < M ? q0 + per : M;
+    const unsigned short* __restrict__ mrow = masks + (size_t)i0 * (size_t)R4 * (size_t)fc_pad + (size_t)lf;   // mask q of this frame: mrow[q * fc_pad]
+    unsigned sum = 0u;
+    for (long long q = q0; q < q1; ++q) sum += (unsigned)__builtin_popcount((unsigned)mrow[(size_t)q * (size_t)fc_pad]);
+    s_seg[w][fl] = sum;
     mk_block_sync();
-    if (!fin || m == 0u) return;
-    unsigned long long pos = frame_base[lf] + prefix[(size_t)blockIdx.x * fc_pad + lf];
-    for (int w = 0; w < pq; ++w) pos += s_c[w][fl];
-    const unsigned a = sel1[i];
-    while (m) {                                                    // ascending j = the reference's (i, j) order
-        const int k = __builtin_ctz(m);
-        m &= m - 1u;
-        out[pos++] = make_uint2(a, sel2[j_first + k]);
+    if (lf >= fc || sum == 0u) return;
+    unsigned long long pos = frame_base[lf] + gprefix[(size_t)g * (size_t)fc_pad + (size_t)lf];
+    for (int v = 0; v < w; ++v) pos += s_seg[v][fl];
+    long long i = i0 + q0 / R4, r = q0 % R4;
+    for (long long q = q0; q < q1; ++q) {
+        unsigned m = mrow[(size_t)q * (size_t)fc_pad];
+        if (m) {
+            const unsigned a = sel1[i];
+            while (m) {                                                // ascending j = the reference's (i, j) order
+                const int k = __builtin_ctz(m);
+                m &= m - 1u;
+                out[pos++] = make_uint2(a, sel2[r * CT_RUN + k]);
+            }
+        }
+        if (++r == R4) { r = 0; ++i; }
     }
 }
 

@@ -243,7 +243,7 @@ struct DevicePairSink {
     }
     int commit(void*, size_t n) { size += n; return 0; }
 };
-enum { CONTACTS_AVOID_RECT = 1 };      // `avoid`: the tests walk both walks over the same shapes
+enum { CONTACTS_AVOID_RECT = 1 };      // `avoid`: the tests walk both walks over the same shapes; bits 8-15: rows per group of the rectangular walk
 template <class BE, class Sink>
 int run_contacts(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                  const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, float dist_threshold,
@@ -269,13 +269,20 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
                             chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
     }
     // frames per chunk: the per-(tile, frame) counters stay within the budget whatever the number of pairs
-    const long long tiles = rect ? n1 * JT : ceil_div(P, DT);
-    long long chunk = ((long long)budget_bytes / (tiles * 12)) / DT * DT;     // 4 B of counter + 4 x 2 B of contact masks per (tile, frame)
+    // (a rectangular call: counters per GROUP of `ni` first atoms -- as many rows per block of the count kernel as still leave
+    //  ~6 000 blocks (the second atoms' 48 loads per wave are amortised over them), at most 32 -- and masks per row tile)
+    const long long slabs_all = ceil_div(F, DT);
+    const long long ni_forced = std::min(32, (avoid >> 8) & 0xff);   // (the tests walk group sizes the small cases would never get; <= 32: a bit per row)
+    const long long ni = !rect ? 0 : ni_forced ? ni_forced : std::max<long long>(1, std::min<long long>(32, n1 * JT * slabs_all / 6000));
+    const long long groups = rect ? ceil_div(n1, ni) : 0;
+    const long long tiles = rect ? groups : ceil_div(P, DT);         // what k_contacts_scan runs over
+    const long long mask_rows = rect ? n1 * JT * (DT_THREADS / DT) : tiles * (DT_THREADS / DT);
+    long long chunk = ((long long)budget_bytes / (tiles * 4 + mask_rows * 2)) / DT * DT;      // 4 B per counter + 2 B per run of 16 pairs, per frame
     chunk = std::max<long long>(DT, std::min<long long>(chunk, (F + DT - 1) / DT * DT));
     chunk = std::min<long long>(chunk, 65535LL * DT);
     const float thr2 = dist_threshold * dist_threshold;              // `float dist_threshold` squared in float (:73)
     if ((st = be.ensure(WS_D_CNT, (size_t)tiles * chunk * 4, &cnt, 0))) return st;
-    if ((st = be.ensure(WS_D_MASK, (size_t)tiles * (DT_THREADS / DT) * chunk * 2, &msk, 0))) return st;
+    if ((st = be.ensure(WS_D_MASK, (size_t)mask_rows * chunk * 2, &msk, 0))) return st;
     if ((st = be.ensure(WS_D_TOT, (size_t)chunk * 8, &tot, 0))) return st;
     if ((st = be.ensure(WS_D_BASE, (size_t)chunk * 8, &base, 0))) return st;
     std::vector<unsigned long long> totals((size_t)chunk), bases((size_t)chunk);
@@ -283,10 +290,11 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
         const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
         if (rect) {
-            const dim3 cgrid((unsigned)(ceil_div(n1, CR_I) * JT), (unsigned)(fc_pad / DT));
-            st = pbc ? be.launch(k_contacts_count_rect<true>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2,
+            const dim3 cgrid((unsigned)(groups * JT), (unsigned)(fc_pad / DT));
+            if ((st = be.fill(cnt, 0, (size_t)groups * (size_t)fc_pad * 4))) return st;
+            st = pbc ? be.launch(k_contacts_count_rect<true>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni,
                                  (unsigned*)cnt, (unsigned short*)msk)
-                     : be.launch(k_contacts_count_rect<false>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2,
+                     : be.launch(k_contacts_count_rect<false>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni,
                                  (unsigned*)cnt, (unsigned short*)msk);
             if (st) return st;
         } else if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
@@ -301,8 +309,8 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         if ((st = sink.reserve((size_t)run, &dout))) return st;
         if ((st = be.to_device(base, bases.data(), (size_t)fc_pad * 8))) return st;
         if (rect) {
-            if ((st = be.launch(k_contacts_fill_rect, grid, dim3(DT_THREADS), fc, fc_pad, sel1, sel2, n2, (const unsigned short*)msk, (const unsigned*)cnt,
-                                (const unsigned long long*)base, (uint2*)dout))) return st;
+            if ((st = be.launch(k_contacts_fill_rect, grid, dim3(CF_WAVES * WAVE), fc, fc_pad, sel1, n1, sel2, n2, ni, (const unsigned short*)msk,
+                                (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
         } else if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), fc, fc_pad, (const unsigned*)pa, (const unsigned*)pb, (const unsigned short*)msk,
                                    (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
         if ((st = sink.commit(dout, (size_t)run))) return st;

@@ -12,6 +12,7 @@
 
 #define MK_DEV __device__ __forceinline__
 #define MK_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define MK_KERNEL_OCC(bounds, waves) __global__ __launch_bounds__(bounds, waves)   // at least `waves` waves per SIMD: a register budget of 512 / waves
 #define MK_DEVFN __device__                       // a member function of a device-side struct
 #define MK_DEV_CONST __device__ const             // a table in device memory
 
@@ -53,6 +54,8 @@ MK_DEV float mk_max3_raw(float m, float a, float b) { float r; asm("v_max3_f32 %
 MK_DEV float mk_max3_abs_raw(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 // keeps what follows inside its (wave-uniform) branch: a volatile asm is never speculated, so the branch is not if-converted
 MK_DEV void mk_stay_in_branch() { asm volatile(""); }
+// nothing is scheduled across this point (a bound on how many independent chains the scheduler interleaves -- and keeps in registers)
+MK_DEV void mk_sched_barrier() { __builtin_amdgcn_sched_barrier(0); }
 // the value stays in its register from here on: the compiler forgets that it is a constant it could build again (it
 // re-materialised the eight +inf of an accumulator set in front of every loop that uses them)
 MK_DEV void mk_keep(float& x) { asm("" : "+v"(x)); }

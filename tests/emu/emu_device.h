@@ -22,6 +22,7 @@
 
 #define MK_DEV static inline
 #define MK_KERNEL(bounds)
+#define MK_KERNEL_OCC(bounds, waves)
 #define MK_DEVFN
 #define MK_DEV_CONST static const
 #define __shared__ static
@@ -212,6 +213,7 @@ MK_DEV float mk_max3_raw(float m, float a, float b) { return fmaxf(fmaxf(a, b), 
 MK_DEV float mk_max3_abs_raw(float a, float b, float c) { return fmaxf(fmaxf(fabsf(a), fabsf(b)), fabsf(c)); }
 MK_DEV void mk_keep(float&) {}
 MK_DEV void mk_stay_in_branch() {}
+MK_DEV void mk_sched_barrier() {}
 MK_DEV unsigned mk_float_bits(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 MK_DEV float mk_abs(float a) { return fabsf(a); }
 MK_DEV float mk_max(float a, float b) { return fmaxf(a, b); }

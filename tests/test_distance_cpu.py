@@ -630,6 +630,8 @@ def test_rectangular_contact_kernel_is_the_reference_order_and_image(ids):
                     got = E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr, budget_bytes=budget, device_sink=sink)
                     assert got == want, (n2, thr, budget)
                 assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr, avoid=1) == want
+                for ni in (5, 8, 32):                                # rows per group (a large call gets up to 32; 5: the last group is short)
+                    assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr, avoid=ni << 8, budget_bytes=12 * 64 * 8 if ni == 5 else 256 << 20) == want, ni
             # pbc = False: no image at all
             d2o = oracle.dist_trajectory(c, b, s1, s2, ch, False, False, squared=True)
             assert E.contacts_trajectory(c, b, s1, s2, ch, False, False, 6.0) == _contact_lists(d2o, s1, s2, 6.0)
