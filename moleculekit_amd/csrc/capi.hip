@@ -52,6 +52,8 @@ static int hip_fail(hipError_t e, const char* what) noexcept
 
 struct mkamd_ctx {
     int device = 0;
+    int n_cus = 256;                       // compute units of the device (launch plans that count wave slots: dist_pipeline.h)
+    int compute_units() const { return n_cus; }
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;          // stream the launches of the current call go to (main or side)
     hipStream_t main_stream = nullptr;     // the caller-visible stream
@@ -381,6 +383,7 @@ try {
     HIP_TRY(hipSetDevice(device));
     mkamd_ctx* c = new mkamd_ctx();
     c->device = device;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = cus; }
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate"); }
     c->stream = c->main_stream = c->own_stream;

@@ -990,37 +990,70 @@ MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coord
 //   frame_base[frame] + gprefix[group][frame] (k_contacts_scan over the groups) + the stretches before its own.
 // The pair behind bit k of run r of row i is (sel1[i], sel2[16 r + k]).
 constexpr int CF_WAVES = 16;
+constexpr int CF_CHUNK = 16;              // masks a lane has in flight
+constexpr int CF_SEL2 = 4096;             // second atoms a block stages in LDS (16 KB)
 MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_pad, const unsigned* __restrict__ sel1, long long n1,
                                                      const unsigned* __restrict__ sel2, long long n2, long long ni,
                                                      const unsigned short* __restrict__ masks, const unsigned* __restrict__ gprefix,
                                                      const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
 {
     __shared__ unsigned s_seg[CF_WAVES][DT];
+    __shared__ unsigned s_sel2[CF_SEL2];
     const int fl = threadIdx.x & (DT - 1), w = threadIdx.x >> 6;
     const long long lf = (long long)blockIdx.y * DT + fl, g = blockIdx.x;
     const long long R4 = ((n2 + DT - 1) / DT) * (DT_THREADS / DT);   // runs per row, padded to whole tiles
     const long long i0 = g * ni, rows = n1 - i0 < ni ? n1 - i0 : ni, M = rows * R4;
     const long long per = (M + CF_WAVES - 1) / CF_WAVES, q0 = w * per < M ? w * per : M, q1 = q0 + per < M ? q0 + per : M;
     const unsigned short* __restrict__ mrow = masks + (size_t)i0 * (size_t)R4 * (size_t)fc_pad + (size_t)lf;   // mask q of this frame: mrow[q * fc_pad]
+    // the atoms behind the bits: the group's first atoms in the lanes of a register (at most 32 rows), the second atoms in LDS -- as
+    // loads from memory inside the walk every contact cost a round trip to the L2 before its store (38 us for 1.5 M contacts)
+    const bool staged = n2 <= CF_SEL2;                               // block-uniform
+    if (staged) for (long long j = threadIdx.x; j < n2; j += CF_WAVES * WAVE) s_sel2[j] = sel2[j];
+    const unsigned va = sel1[i0 + (fl < rows ? fl : 0)];
+    // CF_CHUNK masks at a time, their loads issued together; the first chunk stays in registers for the second walk
     unsigned sum = 0u;
-    for (long long q = q0; q < q1; ++q) sum += (unsigned)__builtin_popcount((unsigned)mrow[(size_t)q * (size_t)fc_pad]);
+    unsigned first[CF_CHUNK];
+    for (long long q = q0; q < q1; q += CF_CHUNK) {
+        unsigned t[CF_CHUNK];
+#pragma unroll
+        for (int u = 0; u < CF_CHUNK; ++u) t[u] = q + u < q1 ? (unsigned)mrow[(size_t)(q + u) * (size_t)fc_pad] : 0u;
+#pragma unroll
+        for (int u = 0; u < CF_CHUNK; ++u) sum += (unsigned)__builtin_popcount(t[u]);
+        if (q == q0) {
+#pragma unroll
+            for (int u = 0; u < CF_CHUNK; ++u) first[u] = t[u];
+        }
+    }
     s_seg[w][fl] = sum;
     mk_block_sync();
-    if (lf >= fc || sum == 0u) return;
+    const bool live = lf < fc && sum != 0u;                          // (no lane leaves: the row's atom is handed out by readlane below)
+    if (mk_ballot(live) == 0ull) return;                             // wave-uniform
     unsigned long long pos = frame_base[lf] + gprefix[(size_t)g * (size_t)fc_pad + (size_t)lf];
     for (int v = 0; v < w; ++v) pos += s_seg[v][fl];
     long long i = i0 + q0 / R4, r = q0 % R4;
-    for (long long q = q0; q < q1; ++q) {
-        unsigned m = mrow[(size_t)q * (size_t)fc_pad];
-        if (m) {
-            const unsigned a = sel1[i];
-            while (m) {                                                // ascending j = the reference's (i, j) order
-                const int k = __builtin_ctz(m);
-                m &= m - 1u;
-                out[pos++] = make_uint2(a, sel2[r * CT_RUN + k]);
+    for (long long q = q0; q < q1; q += CF_CHUNK) {
+        unsigned t[CF_CHUNK];
+        if (q == q0) {
+#pragma unroll
+            for (int u = 0; u < CF_CHUNK; ++u) t[u] = first[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < CF_CHUNK; ++u) t[u] = q + u < q1 ? (unsigned)mrow[(size_t)(q + u) * (size_t)fc_pad] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < CF_CHUNK; ++u) {
+            if (q + u < q1) {                                          // wave-uniform
+                const unsigned a = mk_readlane(va, (int)(i - i0));
+                unsigned m = live ? t[u] : 0u;
+                while (m) {                                            // ascending j = the reference's (i, j) order
+                    const int k = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const long long j = r * CT_RUN + k;
+                    out[pos++] = make_uint2(a, staged ? s_sel2[j] : sel2[j]);
+                }
+                if (++r == R4) { r = 0; ++i; }
             }
         }
-        if (++r == R4) { r = 0; ++i; }
     }
 }
 

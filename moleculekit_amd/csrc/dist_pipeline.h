@@ -269,11 +269,22 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
                             chains, selfdist, pbc, (unsigned*)pa, (unsigned*)pb, (unsigned*)wr))) return st;
     }
     // frames per chunk: the per-(tile, frame) counters stay within the budget whatever the number of pairs
-    // (a rectangular call: counters per GROUP of `ni` first atoms -- as many rows per block of the count kernel as still leave
-    //  ~6 000 blocks (the second atoms' 48 loads per wave are amortised over them), at most 32 -- and masks per row tile)
+    // (a rectangular call: counters per GROUP of `ni` first atoms, masks per row tile.  A block of the count kernel walks the ni rows of a
+    //  group for its 64 second atoms: the more rows, the better its start -- 48 loads per wave, three divisions, ~0.6 of a row's work -- is
+    //  amortised; the fewer, the smaller the last, partly filled round of blocks (four blocks per CU are resident at 121 registers).
+    //  ni <= 32 that minimises rounds x (ni + 0.6); measured on 200 x 500 x 2 048: 8 rows 129 us, 25 rows -- two full rounds -- ... )
     const long long slabs_all = ceil_div(F, DT);
     const long long ni_forced = std::min(32, (avoid >> 8) & 0xff);   // (the tests walk group sizes the small cases would never get; <= 32: a bit per row)
-    const long long ni = !rect ? 0 : ni_forced ? ni_forced : std::max<long long>(1, std::min<long long>(32, n1 * JT * slabs_all / 6000));
+    long long ni = 0;
+    if (rect) {
+        const long long slots = 4LL * std::max(1, be.compute_units());
+        double best = 0.0;
+        for (long long c = 1; c <= std::min<long long>(32, n1); ++c) {
+            const double cost = (double)ceil_div(ceil_div(n1, c) * JT * slabs_all, slots) * ((double)c + 0.6);
+            if (ni == 0 || cost <= best) { best = cost; ni = c; }     // (ties: the larger group)
+        }
+        if (ni_forced) ni = ni_forced;
+    }
     const long long groups = rect ? ceil_div(n1, ni) : 0;
     const long long tiles = rect ? groups : ceil_div(P, DT);         // what k_contacts_scan runs over
     const long long mask_rows = rect ? n1 * JT * (DT_THREADS / DT) : tiles * (DT_THREADS / DT);

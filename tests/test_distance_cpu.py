@@ -643,3 +643,19 @@ def test_rectangular_contact_kernel_trapped_pairs_decide_contacts():
     cases, ch, s1, s2 = _trapped_threshold_cases()
     for c, b, thr, want in cases:
         assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, thr) == want
+
+
+def test_rectangular_contact_kernel_with_more_second_atoms_than_the_fill_pass_stages():
+    """n2 = 4 200 (> 4 096: the fill pass reads the second atoms from memory instead of its LDS copy), three first atoms, five frames."""
+    rng = np.random.default_rng(8)
+    n1, n2, F = 3, 4200, 5
+    N = n1 + n2
+    c = rng.uniform(0, 30, size=(N, 3, F)).astype(np.float32)
+    b = np.full((3, F), 30.0, np.float32)
+    ch = np.ones(N, np.uint32); ch[n1:] = 2
+    s1, s2 = np.arange(n1, dtype=np.uint32), rng.permutation(np.arange(n1, N)).astype(np.uint32)
+    d2 = oracle.dist_trajectory(c, b, s1, s2, ch, False, True, squared=True)
+    want = _contact_lists(d2, s1, s2, 5.0)
+    assert sum(len(x) for x in want) > 100
+    assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, 5.0) == want
+    assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, 5.0, avoid=2 << 8) == want

@@ -312,8 +312,8 @@ def bench_cdist_pdist(args, ctx, dev, busy, check):
 
 def bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s1, s2, d1, d2, F):
     """contacts_trajectory (distance_utils.pyx:59-93) on device pointers: the dist leg's 200 x 500 pairs over its F frames,
-    threshold 8 A, periodic by chain -- counted (every distance once; the contact masks are kept), scanned and compacted on the device, the list
-    stays in HBM.  Algorithmic bytes: the selected atoms' coordinates once + 8 B per contact + the frame offsets."""
+    threshold 8 A, periodic by chain -- counted (every distance once, second atoms in registers: dist_kernels.h, the rectangular contact kernels;
+    the contact masks are kept), scanned per group of rows and compacted on the device, the list stays in HBM.  Algorithmic bytes: the selected atoms' coordinates once + 8 B per contact + the frame offsets."""
     import torch
     n1, n2 = len(s1), len(s2)
     thr = 8.0
@@ -341,8 +341,8 @@ def bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s
     return {"shape": f"{n1} x {n2} pairs x {F} frames, threshold {thr} A, periodic: {n} contacts", "ms_per_call": round(ms, 4),
             "pair_tests_per_s_G": round(n1 * n2 * F / ms / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 5),
-                         "algorithmic_bytes_per_launch": alg, "note": "instruction-bound (the count pass computes every pair once and keeps 16-bit masks for the fill pass); wall clock incl. the count read-back"},
-            "kernel": "mkamd::k_contacts_count + k_contacts_scan + k_contacts_fill"}
+                         "algorithmic_bytes_per_launch": alg, "note": "VALU-bound: k_contacts_count_rect spends 18.9 lane-instructions on a periodic pair (packed arithmetic, the image integers behind one accumulated test, 2.4 of them the contact bit) = 118 us of issue at 2.0 GHz for this shape, measured 127; the fill pass reads the 16-bit masks the count pass kept; wall clock incl. the count read-back"},
+            "kernel": "mkamd::k_contacts_count_rect<true> + k_contacts_scan + k_contacts_fill_rect"}
 
 
 def _standin_distances(kind, coords, box, sel1, sel2, chains, selfdist, pbc):

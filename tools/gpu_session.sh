@@ -1,4 +1,4 @@
-# round 6, session 31: rectangular contacts, redo rows after the walk (121 registers): tests, A-B, per-kernel times
+# round 6, session 34: rows per group from a rounds model (25 rows: two full rounds): tests, A-B, per-kernel times
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 (timeout 1500 python -m pytest tests/test_gpu_distance.py -m gpu -q -x -k "contact or pair_table" 2>&1 | tail -3)
