@@ -100,7 +100,8 @@ int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_ba
 
 /* Which kernels dist_trajectory may take (default 0: all; the choice depends on the shape of the call): bits of `avoid_mask` --
  * 1 the block-per-frame kernel (rectangular calls with short rows -- the small calls MetricDistance makes: one launch), 2 the row
- * kernel (rectangular calls with rows of >= 64 second atoms), 4 the rectangular tile kernel, 8 the row kernel's 16-byte stores
+ * kernel (rectangular calls with rows of >= 64 second atoms), 4 the rectangular tile kernel, 8 the row kernel's 16-byte stores,
+ * 16 (not an exclusion) the row kernel wherever it applies, also where the tile kernel is the measured better choice
  * (selfdist always takes the pair-table kernel).  Every kernel produces the same
  * bits; for tests (every kernel over the same shapes) and same-box A-B timing. */
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask);

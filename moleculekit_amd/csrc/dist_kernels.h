@@ -389,11 +389,14 @@ MK_DEV void dist_rect_block(const float* __restrict__ coords, long long F, const
     const long long jw = j0 + wq * DR_PW;
     const long long jk = jw + (fl & (DR_PW - 1)) < n2 ? jw + (fl & (DR_PW - 1)) : n2 - 1;
     const unsigned vb = sel2[jk], vcb = PBC ? chains[vb] : 0u;
-    float B3[DR_PW][3];
+    // (round 6) the wave's second atoms as packed PAIRS: two pairs of the result per instruction (dist2_pk), the image integers of a
+    // row's DR_PW pairs behind one accumulated test
+    constexpr int H = DR_PW / 2;
+    mk_f2 BX[H], BY[H], BZ[H];
 #pragma unroll
-    for (int k = 0; k < DR_PW; ++k) {
-        const unsigned b = mk_readlane(vb, k);
-        B3[k][0] = at(b, 0); B3[k][1] = at(b, 1); B3[k][2] = at(b, 2);
+    for (int h = 0; h < H; ++h) {
+        const unsigned b0 = mk_readlane(vb, 2 * h), b1 = mk_readlane(vb, 2 * h + 1);
+        BX[h] = mk_f2{at(b0, 0), at(b1, 0)}; BY[h] = mk_f2{at(b0, 1), at(b1, 1)}; BZ[h] = mk_f2{at(b0, 2), at(b1, 2)};
     }
     float bx = 0.f, by = 0.f, bz = 0.f, ibx = 0.f, iby = 0.f, ibz = 0.f;
     if (PBC) {
@@ -411,24 +414,60 @@ MK_DEV void dist_rect_block(const float* __restrict__ coords, long long F, const
         // the next first atom's coordinates are requested before this one's distances are computed
         const unsigned a_next = sel1[ii + 1 < ni ? i0 + ii + 1 : i0 + ii];
         const float xn = at(a_next, 0), yn = at(a_next, 1), zn = at(a_next, 2);
-        const unsigned ca = PBC ? chains[a] : 0u;                    // wave-uniform (scalar load)
+        // which of the wave's second atoms wrap against this first atom (distance_utils.pyx:49): wave-uniform bits
+        unsigned wm = 0u;
+        if (PBC) { const unsigned ca = chains[a]; wm = (unsigned)(mk_ballot(vcb != ca) & ((1ull << DR_PW) - 1ull)); }
         float d2[DR_PW];
+        bool redo = false;
+        float none = 0.f;
+        if (PBC && wm == (1u << DR_PW) - 1u) {
+            float risk = 0.f;
 #pragma unroll
-        for (int k = 0; k < DR_PW; ++k) {
-            const bool wrap = PBC && mk_readlane(vcb, k) != ca;      // distance_utils.pyx:49
-            d2[k] = dist2_min_image_f32(xa, ya, za, B3[k][0], B3[k][1], B3[k][2], bx, by, bz, ibx, iby, ibz, wrap);
-        }
-        const bool ordinary = mk_sqrt_ordinary_all(d2);
-        // the roots of the batch behind ONE wave-uniform test (all values ordinary numbers: practically always)
-        if (squared) {
+            for (int h = 0; h < H; ++h) {
+                const mk_f2 e = dist2_pk<true>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, risk);   // (b - a: d^2 is even in the separation)
+                d2[2 * h] = e[0]; d2[2 * h + 1] = e[1];
+            }
+            redo = mk_ballot(!(risk < DRC_RISK)) != 0ull;            // an image integer may differ from round(d / b) (rare)
+        } else if (PBC && wm != 0u) {
+            // only some of the row's pairs wrap: both forms, chosen per pair (wave-uniform bits: no branch)
+            float risk = 0.f;
 #pragma unroll
-            for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = d2[k];
-        } else if (mk_ballot(!ordinary) == 0ull) {
-#pragma unroll
-            for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = mk_fsqrt_rn_ordinary(d2[k]);
+            for (int h = 0; h < H; ++h) {
+                const mk_f2 w2 = dist2_pk<true>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, risk);
+                const mk_f2 o2 = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
+                d2[2 * h] = ((wm >> (2 * h)) & 1u) ? w2[0] : o2[0]; d2[2 * h + 1] = ((wm >> (2 * h + 1)) & 1u) ? w2[1] : o2[1];
+            }
+            redo = mk_ballot(!(risk < DRC_RISK)) != 0ull;
         } else {
 #pragma unroll
-            for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = mk_fsqrt_rn(d2[k]);
+            for (int h = 0; h < H; ++h) {
+                const mk_f2 e = dist2_pk<false>(BX[h], BY[h], BZ[h], xa, ya, za, bx, by, bz, ibx, iby, ibz, none);
+                d2[2 * h] = e[0]; d2[2 * h + 1] = e[1];
+            }
+        }
+        if (redo) {
+            // pair by pair with the per-pair test and the correctly rounded divisions behind it, the second atoms loaded again (a loop:
+            // sixteen inlined copies of the division path cost the walk its registers), straight into the tile
+            mk_stay_in_branch();
+#pragma unroll 1
+            for (int k = 0; k < DR_PW; ++k) {
+                const unsigned bk = mk_readlane(vb, k);
+                const float d = dist2_min_image_f32(xa, ya, za, at(bk, 0), at(bk, 1), at(bk, 2), bx, by, bz, ibx, iby, ibz, ((wm >> k) & 1u) != 0u);
+                tile[wq * DR_PW + k][fl] = squared ? d : mk_fsqrt_rn(d);
+            }
+        } else {
+            const bool ordinary = mk_sqrt_ordinary_all(d2);
+            // the roots of the batch behind ONE wave-uniform test (all values ordinary numbers: practically always)
+            if (squared) {
+#pragma unroll
+                for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = d2[k];
+            } else if (mk_ballot(!ordinary) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = mk_fsqrt_rn_ordinary(d2[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < DR_PW; ++k) tile[wq * DR_PW + k][fl] = mk_fsqrt_rn(d2[k]);
+            }
         }
         mk_block_sync();
         // the row of 64 pairs (i, j0 .. j0 + 63) of every frame of the slab (pairs past the row's end -- j >= n2 -- belong to the

@@ -33,7 +33,7 @@ inline int dist_rows_jpl(long long n1, long long n2, long long F)
 
 // dist_trajectory on device pointers (coords [N,3,F], box [3,F], sel/chains uint32) -> out [F, P]
 // `avoid`: kernels NOT to take (tests walk every kernel over the same shapes; A-B timing) -- the choice below is made among the rest
-enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8 };
+enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8, DIST_PREFER_ROWS = 16 };
 template <class BE>
 int run_dist_trajectory(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                         const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
@@ -52,8 +52,19 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     const bool no_frame = (avoid & DIST_AVOID_FRAME) != 0, no_rows = (avoid & DIST_AVOID_ROWS) != 0, no_rect = (avoid & DIST_AVOID_RECT) != 0;
     // One launch for rectangular calls whose rows are too short for the row kernel (k_dist_frame: a block per frame stages both
     // selections in LDS and walks the pair list in memory order).  (selfdist keeps the pair-table kernel: dist_kernels.h)
-    const int rows_jpl = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
-    if (!no_frame && !selfdist && rows_jpl == 0 && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
+    // Which of the three rectangular kernels (round 6, tools/dist_shapes_probe.py over 13 shapes, profiles/r6_dist_crossover.txt):
+    //  * the row kernel pays its frame-major pre-pass (13 us) and, with ONE second atom per lane, 4-byte stores: with two or four per lane
+    //    it wins wherever it applies; with one only on rows of >= 128 atoms of a result of >= 256 MB (150 x 300 x 2 048: 92 us against the
+    //    tile kernel's 119) -- below that the tile kernel does (300 x 60: 37 against 48 us, 5 000 x 60: 0.91 against 1.24 ms);
+    //  * rows too short for it go to the block-per-frame kernel (300 x 30: 33 against 36 us), except open calls with full 64-wide tiles and
+    //    a small result, where the tile kernel is 15-27 % faster (300 x 100: 75 against 88 us, 100 x 100: 27 against 36).
+    // DIST_PREFER_ROWS (tests): the row kernel wherever it applies, as in rounds 4-5.
+    const int jpl_any = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
+    const bool small_result = (double)F * (double)n1 * (double)n2 * 4.0 < 268435456.0;
+    const bool rows_ok = jpl_any >= 2 || (jpl_any == 1 && ((avoid & DIST_PREFER_ROWS) || (n2 >= 128 && !small_result)));
+    const int rows_jpl = rows_ok ? jpl_any : 0;
+    const bool rect_first = !selfdist && !no_rect && ((jpl_any >= 1 && !rows_ok) || (jpl_any == 0 && !pbc && n2 >= DT && small_result && !no_rows));
+    if (!no_frame && !selfdist && rows_jpl == 0 && !rect_first && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
         // four consecutive frames per block while both selections fit 32 KB of LDS (they share the cache lines of their atoms' rows),
         // one beyond; slices of the pair list so that ~1 280 blocks exist, of at least four steps each (measured with 512 ... 4 096:
         // 300 x 30 x 2 048 is flat, 300 x 60 64-65 -> 59-60 us against 2 048 blocks, 1 000 x 30 +25 % beyond 2 048;
@@ -79,7 +90,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     }
     if (!selfdist && !no_rows) {
         // rows of >= 64 second atoms are written directly by a wave per frame, from selections turned frame-major first
-        const int jpl = dist_rows_jpl(n1, n2, F);
+        const int jpl = rows_jpl;
         if (jpl) {
             const long long np1 = ceil_div(n1, DT) * DT, np2 = ceil_div(n2, 64 * jpl) * 64 * jpl;
             const long long tasks = F * ceil_div(n1, ROWS_CI) * ceil_div(n2, 64 * jpl);

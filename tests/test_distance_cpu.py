@@ -230,9 +230,10 @@ def test_row_kernel_shapes_and_modes_match_oracle():
             s2 = rng.integers(0, N, size=n2).astype(np.uint32)
             for pbc in (False, True):
                 for sq in (False, True):
-                    got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
                     exp = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq)
-                    assert got.shape == (F, n1 * n2) and np.array_equal(got, exp), (F, n1, n2, pbc, sq)
+                    for avoid in (16, 0):                        # the row kernel wherever it applies (rounds 4-5), then round 6's choice among the three
+                        got = E.dist_trajectory(c, b, s1, s2, ch, False, pbc, squared=sq, avoid=avoid)
+                        assert got.shape == (F, n1 * n2) and np.array_equal(got, exp), (F, n1, n2, pbc, sq, avoid)
     # a zero box edge (the reference divides by it: NaN), NaN and huge coordinates: the extraordinary roots' branch
     F = 5
     c = rng.uniform(-30, 30, size=(N, 3, F)).astype(np.float32)
@@ -267,8 +268,9 @@ def test_row_kernel_image_shift_is_bit_exact_at_every_boundary():
         c = (rng.random((N, 3, F)).astype(np.float32) * boxes[None, None, :]).astype(np.float32)
         ch = rng.integers(0, 3, size=N).astype(np.uint32)
         s1, s2 = np.arange(n1, dtype=np.uint32), np.arange(n1, N, dtype=np.uint32)
-        got = E.dist_trajectory(c, b, s1, s2, ch, False, True)
-        assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True))
+        for avoid in (16, 0):                                  # the row kernel (rounds 4-5: wherever it applies), then round 6's choice (the tile kernel)
+            got = E.dist_trajectory(c, b, s1, s2, ch, False, True, avoid=avoid)
+            assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True)), avoid
     # (2) separations at the boundaries: first atoms at the origin, second atoms at +-k * box (k = 0.5, 1.0) and neighbours
     n1, n2 = 40, 64
     ch = np.concatenate([np.zeros(n1, np.uint32), np.ones(n2, np.uint32)])     # every pair across chains: always shifted
@@ -289,15 +291,17 @@ def test_row_kernel_image_shift_is_bit_exact_at_every_boundary():
             s = seps[j % len(seps)] * np.float32(-1.0 if (j // len(seps)) % 2 else 1.0)
             c[n1 + j, j % 3] = s
             c[n1 + j, (j + 1) % 3] = seps[(j + 5) % len(seps)] * np.float32(0.5)
-        got = E.dist_trajectory(c, b, s1, s2, ch, False, True)
-        assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True)), beyond
+        for avoid in (16, 0):
+            got = E.dist_trajectory(c, b, s1, s2, ch, False, True, avoid=avoid)
+            assert np.array_equal(got, oracle.dist_trajectory(c, b, s1, s2, ch, False, True)), (beyond, avoid)
     # (3) boxes that are not ordinary positive numbers: the general path, NaN where the reference gives NaN
     b2 = b.copy()
     b2[0, 0] = 0.0; b2[1, 1] = np.inf; b2[2, 2] = np.nan; b2[0, 3] = -7.0; b2[1, 4] = 1e-42
     c3 = (rng.random((n1 + n2, 3, F)).astype(np.float32) * np.float32(9.0)).astype(np.float32)
-    got = E.dist_trajectory(c3, b2, s1, s2, ch, False, True)
     exp = oracle.dist_trajectory(c3, b2, s1, s2, ch, False, True)
-    assert np.array_equal(got, exp, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(exp))
+    for avoid in (16, 0):
+        got = E.dist_trajectory(c3, b2, s1, s2, ch, False, True, avoid=avoid)
+        assert np.array_equal(got, exp, equal_nan=True) and np.array_equal(np.isnan(got), np.isnan(exp)), avoid
 
 
 # ------------------------------------------------------------------------------------------------
@@ -485,7 +489,8 @@ def test_periodic_row_kernel_image_integers_are_the_references(mixed):
     with np.errstate(all="ignore"):
         for sq in (False, True):
             want = oracle.dist_trajectory(c, b, s1, s2, ch, False, True, squared=sq)
-            for avoid in (1, 1 | 8):                             # (not the block-per-frame kernel: the row kernel, with / without 16-byte stores)
+            for avoid in (1, 1 | 8, 3):                          # (not the block-per-frame kernel: the row kernel, with / without 16-byte stores;
+                #  3: the rectangular tile kernel -- round 6: its pairs are packed behind the accumulated test as well, mutation-checked)
                 got = E.dist_trajectory(c, b, s1, s2, ch, False, True, squared=sq, avoid=avoid)
                 assert np.array_equal(got, want, equal_nan=True), (sq, avoid)
         assert np.isnan(want).any()                              # (the zero box, the NaN coordinate; an inf coordinate wraps to NaN as well)

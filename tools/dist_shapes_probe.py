@@ -23,6 +23,8 @@ def t(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 SHAPES_ODD = ((450, 450, True), (300, 300, True), (1000, 1000, True), (17, 130, False)) if os.environ.get("PROBE_ODD") else None
+if os.environ.get("PROBE_SHAPES"):                                    # "300x60,30x300": rectangular shapes of one's own
+    SHAPES_ODD = tuple(tuple(int(v) for v in sh.split("x")) + (False,) for sh in os.environ["PROBE_SHAPES"].split(","))
 for n1, n2, selfd in SHAPES_ODD or ((300, 30, False), (30, 300, False), (300, 60, False), (1000, 30, False), (300, 300, True), (450, 450, True), (1000, 1000, True), (300, 300, False),
                       (200, 500, False)):
     s2 = np.sort(rng.choice(N, n2, replace=False)).astype(np.int32)

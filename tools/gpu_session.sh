@@ -1,21 +1,14 @@
-# round 6, session 34: rows per group from a rounds model (25 rows: two full rounds): tests, A-B, per-kernel times
+# round 6, session 37: the new choice among the three rectangular kernels: GPU distance tests, the shape probe (free choice), the dist line
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 1500 python -m pytest tests/test_gpu_distance.py -m gpu -q -x -k "contact or pair_table" 2>&1 | tail -3)
-for rep in 1 2; do
-  MKAMD_ALLOW_DIAGNOSTICS=1 MKAMD_LIB=$GRAFT_REPO_ROOT/.variants/libmkamd_prev.so timeout 300 python tools/pair_walk_ab.py 2>&1 | grep -v amdgpu
-  timeout 300 python tools/pair_walk_ab.py 2>&1 | grep -v amdgpu
-done | tee gpurun_out/pair_walk_ab.txt
-for only in "all wrap" "none wraps" "30 chains"; do
-  rm -rf gpurun_out/prof_pw
-  (cd /tmp && PAIR_WALK_ONLY="$only" timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_pw -o pw --output-format csv -- python $GRAFT_REPO_ROOT/tools/pair_walk_ab.py > /dev/null 2>&1)
-  echo "== $only"
-  python - <<'PY'
-import csv, glob
-for f in glob.glob("gpurun_out/prof_pw/**/*kernel_stats.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "contacts" in r["Name"] or "k_dist_pairs" in r["Name"] or "k_build" in r["Name"]:
-            print("   ", r["Name"].split("(")[0][-50:], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1), "us")
+(timeout 1500 python -m pytest tests/test_gpu_distance.py -m gpu -q -x 2>&1 | tail -3)
+PROBE_AVOID=0 PROBE_SHAPES=300x30,300x60,30x300,60x300,300x100,100x300,300x150,150x300,300x200,100x100,64x640,1000x30,1000x60,2000x100,5000x60,300x300,200x500 timeout 600 python tools/dist_shapes_probe.py 2>&1 | grep -v amdgpu | cut -c1-170 | tee gpurun_out/dist_choice.txt
+(timeout 600 python bench.py --workload dist --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | grep '^{' > gpurun_out/dist_line.json)
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/dist_line.json"))
+print("periodic rows", d["ms_per_step"], d["roofline"]["frac"], "open", d["nonperiodic"]["ms_per_step"], d["nonperiodic"]["roofline"]["frac"])
+for k in ("nonperiodic", "periodic"):
+    print("selfdist", k, d["selfdist"][k]["us_per_call"], d["selfdist"][k]["frac"], "small", d["small_call"][k]["us_per_call"], d["small_call"][k]["kernel"])
+print("contacts", d["contacts"]["ms_per_call"], d["contacts"]["pair_tests_per_s_G"])
 PY
-done
-rm -rf gpurun_out/prof_pw
