@@ -90,15 +90,16 @@ def bench_stream_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256):
     return out
 
 
-def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=2048, ramp_gpu=0):
+def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu=16384, chunk_gpu=2048, ramp_gpu=512):
     """Secondary leg `xtc_cfg4`: the cfg4 FEEDER -- a synthetic 30 000-atom XTC trajectory (64 frames of the cfg4 random walk
     written with moleculekit_amd.xtc.write_xtc, the records repeated: XTC frames are self-contained) voxelized through
     batch.iterVoxelizeXTC, with the coordinates decompressed ON THE DEVICE (decode="auto": csrc/xtc_gpu.h, large chunks) and,
     beside it, by libmkamd.so's host threads (decode="host", the round-3 path).  Reports the end-to-end rates, the host
     decoder's rate alone and how idle the GPU is (the voxelizer's share of the wall time at the raw cfg4 step).
     Round 6: the feed's copy/decode stream is a high-priority stream (batch._stream_voxelize: on a hardware queue shared with the voxelizer's
-    streams the walk and the tile kernel were time-sliced and the leg flipped between two rates); 2 048 frames per chunk is the best plan for a
-    16 384-frame job, 4 096 the best steady rate (docs/EXPERIMENTS_r6.md section 12)."""
+    streams the walk and the tile kernel were time-sliced and the leg flipped between two rates); 2 048 frames per chunk approached through 512 and
+    1 024 is the best plan for a 16 384-frame job (194 k frames/s three times out of three; 175-192 k without the ramp), 4 096 the best steady rate
+    (docs/EXPERIMENTS_r6.md section 12)."""
     import tempfile
     import torch
     from moleculekit_amd import _lib, batch, xtc
