@@ -893,7 +893,7 @@ MK_KERNEL(DT_THREADS) void k_contacts_fill(long long fc, long long fc_pad, const
 template <bool PBC, bool SMALL>
 MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, long long f_begin, long long fc, long long fc_pad,
                                 const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
-                                const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains, float thr2, long long ni,
+                                const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains, float thr2, long long ni, int selfdist,
                                 unsigned* __restrict__ cntg, unsigned short* __restrict__ masks, long long g, long long jt, long long JT)
 {
     const int fl = threadIdx.x & (DT - 1), pq = threadIdx.x >> 6;
@@ -911,7 +911,9 @@ MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, l
     auto mask_at = [&](long long ii) -> unsigned short& {
         return masks[(((size_t)(i0 + ii) * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)pq) * (size_t)fc_pad + (size_t)lf];
     };
-    if (nv == 0) {                                                   // a run past the row's end: nothing, said explicitly (the fill pass reads it)
+    // selfdist (distance_utils.pyx:76: j from i + 1): a pair exists where j > i -- a run whose last atom is not beyond the group's FIRST row
+    // holds none for any of its rows
+    if (nv == 0 || (selfdist && jw + CT_RUN - 1 <= i0)) {            // nothing here, said explicitly (the fill pass reads it)
         for (long long ii = 0; ii < rows; ++ii) mask_at(ii) = 0;
         return;
     }
@@ -931,6 +933,13 @@ MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, l
         ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
     }
     const unsigned valid = nv >= CT_RUN ? 0xffffu : (1u << (unsigned)nv) - 1u;
+    // the bits of row i that are pairs of a selfdist call: second atoms jw + k with jw + k > i (wave-uniform).  (Rows of a run that straddles
+    // the diagonal are computed whole and masked: skipping them -- an `if` around the arithmetic -- cost the walk 80 registers.)
+    auto upper = [&](long long i) -> unsigned {
+        if (!selfdist) return 0xffffu;
+        const long long first = i + 1 - jw;                          // the first bit that counts
+        return first <= 0 ? 0xffffu : first >= CT_RUN ? 0u : (0xffffu << (unsigned)first) & 0xffffu;
+    };
     unsigned a = sel1[i0], total = 0u, redo_rows = 0u;
     float xa = at(a, 0), ya = at(a, 1), za = at(a, 2);
     for (long long ii = 0; ii < rows; ++ii) {
@@ -973,7 +982,7 @@ MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, l
             }
         }
         if (redo) redo_rows |= 1u << (unsigned)ii;                  // (wave-uniform; at most 32 rows per group)
-        m = fin ? m & valid : 0u;
+        m = fin ? m & valid & upper(i0 + ii) : 0u;
         mask_at(ii) = (unsigned short)m;
         total += (unsigned)__builtin_popcount(m);
         a = a_next; xa = xn; ya = yn; za = zn;
@@ -995,7 +1004,7 @@ MK_DEV void contacts_rect_block(const float* __restrict__ coords, long long F, l
             const float d = dist2_min_image_f32(xr, yr, zr, at(bk, 0), at(bk, 1), at(bk, 2), bx, by, bz, ibx, iby, ibz, ((wm >> k) & 1u) != 0u);
             m |= d <= thr2 ? 1u << k : 0u;
         }
-        m = fin ? m & valid : 0u;
+        m = fin ? m & valid & upper(i0 + ii) : 0u;
         const unsigned old = mask_at(ii);
         mask_at(ii) = (unsigned short)m;
         total += (unsigned)__builtin_popcount(m) - (unsigned)__builtin_popcount(old);
@@ -1009,9 +1018,12 @@ template <bool PBC>
 MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coords, long long F, long long f_begin, long long fc, long long fc_pad,
                                                  const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
                                                  const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains,
-                                                 float thr2, long long ni, unsigned* __restrict__ cntg, unsigned short* __restrict__ masks)
+                                                 float thr2, long long ni, int selfdist, unsigned* __restrict__ cntg, unsigned short* __restrict__ masks)
 {
-    const long long JT = (n2 + DT - 1) / DT, g = (long long)blockIdx.x / JT, jt = (long long)blockIdx.x % JT;
+    // (the tiles of a group ROTATED by the group's number: consecutive blocks go round-robin to the 8 XCDs, and with JT a multiple of 8 XCD k
+    //  would be handed tile k of every group -- in a selfdist call, where the low tiles of most groups lie below the diagonal and are not computed,
+    //  XCD 7 then had 512 full blocks and XCD 0 sixty: 289 us for 450 x 450 x 2 048 where an even deal takes 180)
+    const long long JT = (n2 + DT - 1) / DT, g = (long long)blockIdx.x / JT, jt = ((long long)blockIdx.x % JT + g) % JT;
     // every row this BLOCK touches ends below 4 GiB from the start of the array?  (block-uniform: every wave looks at the tile's 64
     // second atoms and at first atoms of the group, lane l at the l-th of them as far as they go)
     const int l = threadIdx.x & (DT - 1);
@@ -1019,8 +1031,8 @@ MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coord
     unsigned hi_atom = sel2[jl < n2 ? jl : n2 - 1];
     for (long long il = g * ni + l; il < n1 && il < (g + 1) * ni; il += DT) { const unsigned ha = sel1[il]; hi_atom = ha > hi_atom ? ha : hi_atom; }
     const bool small_rows = mk_ballot(((unsigned long long)hi_atom * 3ull + 3ull) * ((unsigned long long)F * 4ull) > 0xffffffffull) == 0ull;
-    if (small_rows) contacts_rect_block<PBC, true>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, cntg, masks, g, jt, JT);
-    else contacts_rect_block<PBC, false>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, cntg, masks, g, jt, JT);
+    if (small_rows) contacts_rect_block<PBC, true>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist, cntg, masks, g, jt, JT);
+    else contacts_rect_block<PBC, false>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist, cntg, masks, g, jt, JT);
 }
 
 // The fill pass of a rectangular call: blockIdx.x = group of first atoms, blockIdx.y = 64-frame slab; lanes = frames.  The group's masks of a

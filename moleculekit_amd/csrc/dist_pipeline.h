@@ -268,10 +268,12 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     void *pa = nullptr, *pb = nullptr, *wr = nullptr, *cnt = nullptr, *tot = nullptr, *base = nullptr, *dout = nullptr, *msk = nullptr;
     int st;
-    // A rectangular call (no selfdist) whose rows fill at least three eighths of their 64-wide row tiles: second atoms in registers,
-    // no pair table (k_contacts_count_rect; a 30-atom ligand: 30 of 64, a single ion: the pair-table walk)
+    // Calls whose rows fill at least three eighths of their 64-wide row tiles: second atoms in registers, no pair table
+    // (k_contacts_count_rect; a 30-atom ligand: 30 of 64; a single ion: the pair-table walk).  selfdist as well: the rows' bits with
+    // j <= i do not count, runs wholly below the diagonal are not computed -- calculate_contacts with sel1 == sel2 (distance.py:364)
+    // over a whole protein is millions of pairs, and the pair-table form scans their 64-pair tiles one after the other per 64-frame slab
     const long long JT = ceil_div(n2, DT);
-    const bool rect = !selfdist && !(avoid & CONTACTS_AVOID_RECT) && n2 * 8 >= JT * DT * 3 && n1 * JT <= 0x7ffffff0LL;
+    const bool rect = !(avoid & CONTACTS_AVOID_RECT) && n2 * 8 >= JT * DT * 3 && n1 * JT <= 0x7ffffff0LL;
     if (!rect) {
         if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &pa, 0))) return st;
         if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &pb, 0))) return st;
@@ -291,7 +293,12 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         const long long slots = 4LL * std::max(1, be.compute_units());
         double best = 0.0;
         for (long long c = 1; c <= std::min<long long>(32, n1); ++c) {
-            const double cost = (double)ceil_div(ceil_div(n1, c) * JT * slabs_all, slots) * ((double)c + 0.6);
+            long long blocks = ceil_div(n1, c) * JT;                 // per slab; selfdist: only the tiles that reach beyond a group's first row compute
+            if (selfdist) {
+                blocks = 0;
+                for (long long g = 0; g * c < n1; ++g) blocks += std::max<long long>(0, JT - (g * c < DT - 1 ? 0 : (g * c - (DT - 1)) / DT + 1));
+            }
+            const double cost = (double)ceil_div(std::max<long long>(1, blocks) * slabs_all, slots) * ((double)c + 0.6);
             if (ni == 0 || cost <= best) { best = cost; ni = c; }     // (ties: the larger group)
         }
         if (ni_forced) ni = ni_forced;
@@ -314,9 +321,9 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         if (rect) {
             const dim3 cgrid((unsigned)(groups * JT), (unsigned)(fc_pad / DT));
             if ((st = be.fill(cnt, 0, (size_t)groups * (size_t)fc_pad * 4))) return st;
-            st = pbc ? be.launch(k_contacts_count_rect<true>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni,
+            st = pbc ? be.launch(k_contacts_count_rect<true>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist,
                                  (unsigned*)cnt, (unsigned short*)msk)
-                     : be.launch(k_contacts_count_rect<false>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni,
+                     : be.launch(k_contacts_count_rect<false>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist,
                                  (unsigned*)cnt, (unsigned short*)msk);
             if (st) return st;
         } else if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,

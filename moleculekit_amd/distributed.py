@@ -336,9 +336,10 @@ class ShardedVoxelizer:
         cb = [chunk_bounds(int(s), nchunks) for s in sizes]               # per rank: its chunk boundaries (same count)
         tail = (self.V, self.C)
         cuda = self.device.type == "cuda"
-        # a high-priority stream: the exchange of chunk c has to run BESIDE the voxelization of chunk c + 1; streams of one priority share
-        # hardware queues, and on the main stream's queue the two would take turns (batch._stream_voxelize, round 6)
-        comm = torch.cuda.Stream(device=self.device, priority=-1) if cuda else None
+        # (a NORMAL-priority stream.  Round 6 tried a high-priority one, as the streamed drivers' copy stream has (batch._stream_voxelize): on
+        #  the one-rank RCCL loopback -- the only exchange a one-GPU box can run -- the chunk-overlapped gather cost 10.5 ms beside the compute
+        #  instead of 4.6 (two runs each, same box): RCCL's copy kernels then take the CUs ahead of the voxelizer's)
+        comm = torch.cuda.Stream(device=self.device) if cuda else None
         main = torch.cuda.current_stream(self.device) if cuda else None
 
         if exchange == "p2p":

@@ -550,11 +550,12 @@ def test_pair_table_walk_packed_batches_redo_image_integer_traps(mixed):
             differ += r_fast != r_ref
         assert differ > 40
         d2 = oracle.dist_trajectory(c, b, sel, sel, ch, True, True, squared=True)
-        res = E.contacts_trajectory(c, b, sel, sel, ch, True, True, 9.0)
         iu, ju = np.triu_indices(len(sel), 1)
-        for f in range(c.shape[2]):
-            hit = np.nonzero(d2[f] <= f32(81.0))[0]
-            assert res[f] == np.stack([sel[iu[hit]], sel[ju[hit]]], 1).astype(np.int64).ravel().tolist(), f
+        for avoid in (1, 0, 5 << 8):                             # the pair-table walk; the rectangular kernels' triangular form (round 6), groups of 1 and 5 rows
+            res = E.contacts_trajectory(c, b, sel, sel, ch, True, True, 9.0, avoid=avoid)
+            for f in range(c.shape[2]):
+                hit = np.nonzero(d2[f] <= f32(81.0))[0]
+                assert res[f] == np.stack([sel[iu[hit]], sel[ju[hit]]], 1).astype(np.int64).ravel().tolist(), (f, avoid)
 
 
 def _contact_lists(d2, s1, s2, thr):
@@ -664,3 +665,25 @@ def test_rectangular_contact_kernel_with_more_second_atoms_than_the_fill_pass_st
     assert sum(len(x) for x in want) > 100
     assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, 5.0) == want
     assert E.contacts_trajectory(c, b, s1, s2, ch, False, True, 5.0, avoid=2 << 8) == want
+
+
+def test_selfdist_contacts_through_the_rectangular_kernels_unequal_selections():
+    """contacts_trajectory(selfdist=True) pairs (sel1[i], sel2[j]) for j > i (distance_utils.pyx:76) -- also when the two selections differ in
+    length and content; rows around the diagonal end inside runs of 16 and tiles of 64; every group size; equal to the pair-table walk."""
+    rng = np.random.default_rng(41)
+    N, F = 260, 70
+    c = rng.uniform(0, 25, size=(N, 3, F)).astype(np.float32)
+    b = np.full((3, F), 25.0, np.float32)
+    ch = rng.integers(0, 3, N).astype(np.uint32)
+    for n1, n2 in ((200, 200), (70, 150), (150, 70), (33, 64), (1, 40)):
+        s1 = rng.permutation(N)[:n1].astype(np.uint32); s2 = rng.permutation(N)[:n2].astype(np.uint32)
+        d2 = oracle.dist_trajectory(c, b, s1, s2, ch, True, True, squared=True)
+        pairs = [(i, j) for i in range(n1) for j in range(i + 1, n2)]
+        assert d2.shape[1] == len(pairs)
+        want = []
+        for f in range(F):
+            hit = np.nonzero(d2[f] <= np.float32(36.0))[0]
+            want.append([int(v) for k in hit for v in (s1[pairs[k][0]], s2[pairs[k][1]])])
+        assert sum(len(x) for x in want) > 0 or n1 == 1
+        for avoid in (1, 0, 5 << 8, 32 << 8):
+            assert E.contacts_trajectory(c, b, s1, s2, ch, True, True, 6.0, avoid=avoid, budget_bytes=12 * 64 * 8 if avoid == 0 else 256 << 20) == want, (n1, n2, avoid)

@@ -1,16 +1,8 @@
-# round 6, session 40: the XTC-fed leg at 2 048 frames per chunk with a small first chunk
+# round 6, session 44: selfdist contacts through the rectangular kernels (tiles rotated over the XCDs, rounds model over computing blocks): tests, A-B
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-cat > /tmp/xtcchunks.py <<'PY'
-import sys, os, json
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-import torch, bench
-from moleculekit_amd import _lib
-ctx = _lib.default_context(0); dev = torch.device("cuda", 0)
-for rep in range(3):
-    for chunk, ramp in ((2048, 0), (2048, 256), (2048, 512), (2048, 1024)):
-        r = bench.bench_xtc_cfg4(ctx, dev, 0.92, frames_gpu=16384, chunk_gpu=chunk, ramp_gpu=ramp)
-        x = r["device_decode"]
-        print("chunk", x["frames_per_call"], "ramp", ramp, "frames/s", x["frames_per_s"], "steady", x.get("steady_frames_per_s"), "busy", x["gpu_busy_fraction"], flush=True)
-PY
-timeout 900 python /tmp/xtcchunks.py 2>&1 | grep -v amdgpu | tail -12
+(timeout 1500 python -m pytest tests/test_gpu_distance.py -m gpu -q -x 2>&1 | tail -3)
+for rep in 1 2; do
+  MKAMD_ALLOW_DIAGNOSTICS=1 MKAMD_LIB=$GRAFT_REPO_ROOT/.variants/libmkamd_prev.so timeout 600 python tools/pair_walk_ab.py 2>&1 | grep -v amdgpu
+  timeout 600 python tools/pair_walk_ab.py 2>&1 | grep -v amdgpu
+done | tee gpurun_out/pair_walk_ab2.txt

@@ -43,5 +43,12 @@ for name, ch in (("30 chains", (np.arange(N) // 1000).astype(np.int32)), ("all w
     dch = torch.as_tensor(ch, device=dev)
     t_self = timed(lambda: ctx.dist_trajectory_dev(coords.data_ptr(), F, box.data_ptr(), ds.data_ptr(), 450, ds.data_ptr(), 450, dch.data_ptr(), True, True, False, out.data_ptr()))
     t_con = timed(lambda: ctx.contacts_trajectory_dev(coords, F, box, d1, 200, d2, 500, dch, False, True, 8.0), n=20)
-    row.append(f"{name}: selfdist {t_self:.1f} us, contacts {t_con:.1f} us")
+    t_cs = timed(lambda: ctx.contacts_trajectory_dev(coords, F, box, ds, 450, ds, 450, dch, True, True, 8.0), n=20)
+    row.append(f"{name}: selfdist {t_self:.1f} us, contacts {t_con:.1f} us, selfdist contacts 450^2 {t_cs:.1f} us")
+# calculate_contacts with sel1 == sel2 over a whole protein (distance.py:364): 3 000 atoms, 4.5 M pairs, 256 frames
+big = torch.as_tensor(np.sort(rng.choice(N, 3000, replace=False)).astype(np.int32), device=dev)
+dch = torch.as_tensor((np.arange(N) // 1000).astype(np.int32), device=dev)
+c256, b256 = coords[:, :, :256].contiguous(), box[:, :256].contiguous()
+t_big = timed(lambda: ctx.contacts_trajectory_dev(c256, 256, b256, big, 3000, big, 3000, dch, True, True, 4.0), n=3)
+row.append(f"selfdist contacts 3 000^2 x 256 frames {t_big / 1e3:.2f} ms")
 print(f"{os.path.basename(os.environ.get('MKAMD_LIB', 'libmkamd.so')):20s} " + " | ".join(row), flush=True)
