@@ -103,6 +103,8 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu
     import tempfile
     import torch
     from moleculekit_amd import _lib, batch, xtc
+    if os.environ.get("MKAMD_BENCH_XTC_PLAN"):                        # "chunk,ramp": A-B of chunk plans inside the whole line (tools/gpu_session.sh)
+        chunk_gpu, ramp_gpu = (int(v) for v in os.environ["MKAMD_BENCH_XTC_PLAN"].split(","))
     base = 64
     p, _, _ = make_workload("cfg4", base, seed=4001)
     N = int(p["atom_offsets"][1])
@@ -179,6 +181,30 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu
             gpu["decode_kernels_ms_per_call"] = round(e0.elapsed_time(e1) / 2, 3)
             gpu["decode_kernels_frames_per_s"] = round(chunk_gpu / (e0.elapsed_time(e1) / 2) * 1e3, 1)
             del d_raw, d_desc, d_st, xyz, work
+            # the HOST side of one chunk alone: frame headers parsed, record bytes copied from the file (page cache) into pinned memory by the
+            # library's threads, the upload -- what a chunk costs whatever the GPU does (the feed's period is the largest of these, the device
+            # decode beside the voxelizer and the voxelization itself)
+            lo_hi = {}
+            t0 = time.perf_counter()
+            for _ in range(3):
+                desc, lo, hi, _, _, _ = xtc.chunk_desc(fn, sel, N)
+            lo_hi["header_parse_ms_per_call"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            pinned = torch.empty(hi - lo + xtc.XTC_PAD, dtype=torch.uint8, pin_memory=True)
+            path = os.fsencode(fn)
+            _lib._check(lib.mkamd_xtc_copy_bytes(path, lo, hi, pinned.data_ptr(), 0))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                _lib._check(lib.mkamd_xtc_copy_bytes(path, lo, hi, pinned.data_ptr(), 0))
+            t_copy = (time.perf_counter() - t0) / 3
+            d_up = torch.empty_like(pinned, device=dev)
+            d_up.copy_(pinned, non_blocking=True)
+            e0.record(st); d_up.copy_(pinned, non_blocking=True); d_up.copy_(pinned, non_blocking=True); e1.record(st)
+            torch.cuda.synchronize(dev)
+            t_up = e0.elapsed_time(e1) / 2 * 1e-3
+            gpu.update(lo_hi, host_byte_copy_ms_per_call=round(t_copy * 1e3, 3), host_byte_copy_GBs=round((hi - lo) / t_copy / 1e9, 1),
+                       upload_ms_per_call=round(t_up * 1e3, 3), upload_GBs=round((hi - lo) / t_up / 1e9, 1),
+                       voxelizer_ms_per_call=round(chunk_gpu * per_frame_s * 1e3, 3) if per_frame_s else None)
+            del pinned, d_up
         except Exception as e:                     # noqa: BLE001
             gpu = {"error": f"{type(e).__name__}: {e}"[:300]}
     out = {"atoms": N, "file_MB": round(len(blob) * (max(frames, frames_gpu) // base) / 1e6, 1), "bytes_per_atom": round(len(blob) / base / N, 2),
@@ -198,7 +224,16 @@ def bench_xtc_cfg4(ctx, dev, raw_ms_per_step, frames=2048, chunk=256, frames_gpu
         steady = gpu.get("steady_frames_per_s")
         if steady:
             out["steady_vs_kernels_alone"] = round(steady * per_frame_s, 4)
-        out["bottleneck"] = ("GPU (voxelizer)" if (steady or fps) * per_frame_s > 0.9 else
-                             ("device XTC walk (one lane per frame)" if "frames_per_s" in gpu else "host XTC decode"))
+        if (steady or fps) * per_frame_s > 0.9 or "frames_per_s" not in gpu:
+            out["bottleneck"] = "GPU (voxelizer)" if (steady or fps) * per_frame_s > 0.9 else "host XTC decode"
+        else:
+            # which stage of a chunk is the longest (each measured alone above; they overlap in the feed)
+            stages = {"host byte copy (file -> pinned memory)": gpu.get("host_byte_copy_ms_per_call", 0.0) + gpu.get("header_parse_ms_per_call", 0.0),
+                      "upload (PCIe)": gpu.get("upload_ms_per_call", 0.0),
+                      "device XTC decode": gpu.get("decode_kernels_ms_per_call", 0.0),
+                      "GPU (voxelizer)": gpu.get("voxelizer_ms_per_call") or 0.0}
+            worst = max(stages, key=stages.get)
+            out["bottleneck"] = f"{worst}: {stages[worst]:.1f} ms of a {1e3 * chunk_gpu / (steady or fps):.1f}-ms period per {chunk_gpu} frames"
+            out["stage_ms_per_call"] = {k: round(v, 2) for k, v in stages.items()}
     torch.cuda.empty_cache()
     return out
