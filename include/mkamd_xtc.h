@@ -36,7 +36,11 @@ int mkamd_xtc_read(const char* path, const int64_t* frames, int64_t n_sel, int64
  *                          layout of mkamd::XtcFrameDesc in csrc/xtc_gpu.h; data offsets relative to *byte_lo), the byte range
  *                          [*byte_lo, *byte_hi) of the file that holds their records, and what the host path returns besides the
  *                          coordinates: box vectors f32 [3,3,n_sel] (nm), time f32 [n_sel] (ps), step i32 [n_sel]
- *   mkamd_xtc_copy_bytes   that byte range into caller memory (pinned staging), by a few host threads
+ *   mkamd_xtc_copy_bytes   that byte range into caller memory (pinned staging), by a few host threads (pread)
+ *   mkamd_xtc_byte_range   (round 6) the byte range of the selection from the frame index alone -- a streaming reader copies the
+ *                          bytes FIRST and then parses the headers out of its copy:
+ *   mkamd_xtc_chunk_desc_mem   mkamd_xtc_chunk_desc from a host copy of the file's bytes [bytes_lo, bytes_hi) (the same results and
+ *                          checks; a header read through a fresh mapping of the file costs a page fault: 2 ms per 2 048 frames)
  *   mkamd_xtc_decode_work_bytes   size of the device work buffer a decode of n_frames x n_atoms needs (8 bytes per atom: the
  *                          group records)
  *   mkamd_xtc_decode_dev   (needs mkamd_voxel.h's context) d_bytes / d_desc = device copies of the two, d_bytes
@@ -51,6 +55,9 @@ int mkamd_xtc_read(const char* path, const int64_t* frames, int64_t n_sel, int64
 int mkamd_xtc_chunk_desc(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, void* desc_out,
                          int64_t* byte_lo, int64_t* byte_hi, float* box, float* time, int32_t* step);
 int mkamd_xtc_copy_bytes(const char* path, int64_t byte_lo, int64_t byte_hi, void* dst, int32_t n_threads);
+int mkamd_xtc_byte_range(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, int64_t* byte_lo, int64_t* byte_hi);
+int mkamd_xtc_chunk_desc_mem(const char* path, const int64_t* frames, int64_t n_sel, int64_t n_atoms, const void* bytes, int64_t bytes_lo,
+                             int64_t bytes_hi, void* desc_out, int64_t* byte_lo, int64_t* byte_hi, float* box, float* time, int32_t* step);
 uint64_t mkamd_xtc_decode_work_bytes(int64_t n_frames, int64_t n_atoms);
 struct mkamd_ctx;
 int mkamd_xtc_decode_dev(struct mkamd_ctx* ctx, void* hip_stream, const void* d_bytes, const void* d_desc, int64_t n_frames,

@@ -39,6 +39,9 @@ SIGNATURES = {
     "mkamd_xtc_chunk_desc": (_c_int, [ctypes.c_char_p, _vp, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_int64),
                                       ctypes.POINTER(ctypes.c_int64), _vp, _vp, _vp]),
     "mkamd_xtc_copy_bytes": (_c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int32]),
+    "mkamd_xtc_byte_range": (_c_int, [ctypes.c_char_p, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "mkamd_xtc_chunk_desc_mem": (_c_int, [ctypes.c_char_p, _vp, ctypes.c_int64, ctypes.c_int64, _vp, ctypes.c_int64, ctypes.c_int64, _vp,
+                                          ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _vp, _vp, _vp]),
     "mkamd_xtc_decode_work_bytes": (ctypes.c_uint64, [ctypes.c_int64, ctypes.c_int64]),
     "mkamd_xtc_decode_dev": (_c_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_float, _vp, _vp, _vp, ctypes.c_uint64]),
     "mkamd_ctx_set_lds_tier": (_c_int, [_vp, _c_int]),

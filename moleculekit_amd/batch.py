@@ -731,7 +731,9 @@ def _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, has_box, cha
         check(ss, True)                                           # chunk k-4: long done; frees the small pinned buffers
         up[slot].synchronize()                                    # chunk k-2's upload: h_raw[slot] may be overwritten
         n = len(idx)
-        desc, lo, hi, bv, _, _ = _xtc.chunk_desc(filename, idx, natoms)
+        # the records' bytes first (their range comes from the frame index alone), then the headers out of the COPY: read through a fresh
+        # mapping of the file every header costs a page fault -- 2 ms per 2 048 frames of a host side that is the feed's pace (round 6)
+        lo, hi = _xtc.byte_range(filename, idx, natoms)
         need = hi - lo + _xtc.XTC_PAD
         if h_raw[slot] is None or h_raw[slot].numel() < need:
             h_raw[slot] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
@@ -741,6 +743,9 @@ def _iter_xtc_gpu(filename, path, natoms, fr, box_lengths, nvoxels, has_box, cha
                 d_raw[slot] = torch.empty(h_raw[slot].numel(), dtype=torch.uint8, device=dev)
         _lib._check(lib.mkamd_xtc_copy_bytes(path, lo, hi, h_raw[slot].data_ptr(), nthreads))
         h_raw[slot][hi - lo:need].zero_()                         # (the read-ahead pad: never used, but not left to chance)
+        desc, lo_d, hi_d, bv, _, _ = _xtc.chunk_desc_mem(filename, idx, natoms, h_raw[slot].data_ptr(), lo, hi)
+        if lo_d != lo or hi_d > hi:                               # (the descriptors' offsets count from lo_d: the copy must start there)
+            raise RuntimeError(f"{filename}: the frame index and the record headers disagree about the byte range of frames {int(idx[0])}..{int(idx[-1])}")
         h_desc[ss][:n].numpy()[...] = desc
         images = max_images
         if has_box:

@@ -135,6 +135,30 @@ def chunk_desc(filename, frames, natoms):
     return desc, int(lo.value), int(hi.value), box, time, step
 
 
+def byte_range(filename, frames, natoms):
+    """``(byte_lo, byte_hi)`` of the records of ``frames`` from the frame index alone (no record is read)."""
+    sel = np.ascontiguousarray(frames, dtype=np.int64).reshape(-1)
+    lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib._check(_lib.load().mkamd_xtc_byte_range(_path(filename), _lib._ptr(sel), len(sel), int(natoms), ctypes.byref(lo), ctypes.byref(hi)))
+    return int(lo.value), int(hi.value)
+
+
+def chunk_desc_mem(filename, frames, natoms, bytes_ptr, bytes_lo, bytes_hi):
+    """``chunk_desc`` from a host COPY of the file's bytes ``[bytes_lo, bytes_hi)`` at address ``bytes_ptr`` (the pinned staging buffer
+    ``mkamd_xtc_copy_bytes`` has just filled): the same tuple, without touching the file's pages once more."""
+    sel = np.ascontiguousarray(frames, dtype=np.int64).reshape(-1)
+    n = len(sel)
+    desc = np.empty((n, DESC_BYTES), dtype=np.uint8)
+    box = np.empty((3, 3, n), dtype=np.float32)
+    time = np.empty(n, dtype=np.float32)
+    step = np.empty(n, dtype=np.int32)
+    lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib._check(_lib.load().mkamd_xtc_chunk_desc_mem(_path(filename), _lib._ptr(sel), n, int(natoms), ctypes.c_void_p(int(bytes_ptr)), int(bytes_lo),
+                                                     int(bytes_hi), _lib._ptr(desc), ctypes.byref(lo), ctypes.byref(hi), _lib._ptr(box), _lib._ptr(time),
+                                                     _lib._ptr(step)))
+    return desc, int(lo.value), int(hi.value), box, time, step
+
+
 def read_xtc_frames_dev(filename, frames=None, scale: float = 1.0, ctx=None):
     """``read_xtc_frames`` with the coordinates decoded ON THE GPU: returns ``(xyz, boxvectors, time, step)`` with ``xyz`` a
     float32 CUDA tensor ``[n, natoms, 3]`` (frame-major: the voxelizer's packed items; ``scale`` 10 gives Angstrom) whose

@@ -240,3 +240,40 @@ def test_device_decoder_kernels_emulated_bit_exact_with_the_host_decoder(tmp_pat
         got, st = emu_build.xtc_decode(r2, desc0, na, 10.0)
         assert st[0] == 0 and st[2] == 0 and np.array_equal(got[0], ok[0]) and np.array_equal(got[2], ok[2])
         assert st[1] in (0, 1)
+
+
+@pytest.mark.parametrize("name", ["metricdistance_traj.xtc"])
+def test_headers_parsed_from_a_copy_of_the_bytes_equal_the_ones_parsed_from_the_file(name, tmp_path):
+    """Round 6: a streaming reader copies the records' bytes first (their range from the frame index alone: mkamd_xtc_byte_range; the copy by
+    pread in threads) and parses the headers out of the copy (mkamd_xtc_chunk_desc_mem): the same descriptors, range, boxes, times and steps
+    as mkamd_xtc_chunk_desc reads from the file -- for contiguous chunks, single frames, reversed and scattered selections, the file's last
+    frame; and the refusals (a copy that does not hold a selected frame, a range outside the file)."""
+    import ctypes
+    from moleculekit_amd import _lib
+    fn = os.path.join(os.path.dirname(__file__), "golden", "xtc", name)
+    na, nf = xtc.get_xtc_natoms(fn), xtc.get_xtc_nframes(fn)
+    rng = np.random.default_rng(3)
+    sels = [np.arange(nf), np.arange(min(3, nf)), np.array([nf - 1]), np.arange(nf)[::-1], np.sort(rng.choice(nf, max(1, nf // 2), replace=False)),
+            np.array([0, nf - 1])]
+    for sel in sels:
+        want = xtc.chunk_desc(fn, sel, na)
+        lo, hi = xtc.byte_range(fn, sel, na)
+        assert lo == want[1] and hi >= want[2]
+        for threads in (1, 3):
+            raw = np.full(hi - lo + 7, 0xAB, np.uint8)
+            _lib._check(_lib.load().mkamd_xtc_copy_bytes(xtc._path(fn), lo, hi, raw.ctypes.data_as(ctypes.c_void_p), threads))
+            assert np.array_equal(raw[:hi - lo], np.fromfile(fn, np.uint8, count=hi - lo, offset=lo)) and (raw[hi - lo:] == 0xAB).all()
+        got = xtc.chunk_desc_mem(fn, sel, na, raw.ctypes.data, lo, hi)
+        assert got[1] == want[1] and got[2] == want[2]
+        for a, b in zip(got, want):
+            if isinstance(a, np.ndarray):
+                assert np.array_equal(a, b)
+    if nf >= 2:
+        lo1, hi1 = xtc.byte_range(fn, np.array([1]), na)
+        raw = np.fromfile(fn, np.uint8, count=hi1 - lo1, offset=lo1)
+        with pytest.raises(Exception, match="outside the bytes"):
+            xtc.chunk_desc_mem(fn, np.array([0, 1]), na, raw.ctypes.data, lo1, hi1)
+    with pytest.raises(Exception, match="outside the file"):
+        xtc.chunk_desc_mem(fn, np.array([0]), na, raw.ctypes.data, 0, os.path.getsize(fn) + 1)
+    with pytest.raises(Exception, match="outside the file"):
+        _lib._check(_lib.load().mkamd_xtc_copy_bytes(xtc._path(fn), 0, os.path.getsize(fn) + 1, raw.ctypes.data_as(ctypes.c_void_p), 1))
