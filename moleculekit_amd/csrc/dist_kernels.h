@@ -830,7 +830,8 @@ MK_KERNEL(DT_THREADS) void k_contacts_count(const float* __restrict__ coords, lo
 // tiles of every frame, totals[frame] = its number of contacts.  (Round 6: sixteen waves instead of four -- with 1 563 tiles a wave
 // walked 390 of them twice, one dependent load after the other: 134 us of a 370-us contacts call, profiles/r6_dist_rocprofv3_kernel_stats.csv.)
 constexpr int CS_WAVES = 16;
-MK_KERNEL(CS_WAVES * WAVE) void k_contacts_scan(unsigned* __restrict__ cnt, long long tiles, long long fc_pad,
+MK_KERNEL(CS_WAVES * WAVE) void k_contacts_scan(unsigned* __restrict__ cnt, long long tiles, long long fc_pad /* row pitch of cnt */,
+                                                long long lanes /* frames that exist in a row: <= the pitch, or the pitch itself (padded rows) */,
                                                 unsigned long long* __restrict__ totals)
 {
     __shared__ unsigned long long s_seg[CS_WAVES][DT];
@@ -839,13 +840,14 @@ MK_KERNEL(CS_WAVES * WAVE) void k_contacts_scan(unsigned* __restrict__ cnt, long
     const long long lf = (long long)blockIdx.x * DT + fl;
     const long long per = (tiles + NW - 1) / NW, t0 = w * per < tiles ? w * per : tiles, t1 = t0 + per < tiles ? t0 + per : tiles;
     unsigned long long sum = 0;
-    for (long long t = t0; t < t1; ++t) sum += cnt[(size_t)t * fc_pad + lf];
+    const bool on = lf < lanes;
+    for (long long t = t0; t < t1; ++t) sum += on ? cnt[(size_t)t * fc_pad + lf] : 0u;
     s_seg[w][fl] = sum;
     mk_block_sync();
     unsigned long long run = 0, total = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { if (i < w) run += s_seg[i][fl]; total += s_seg[i][fl]; }
-    for (long long t = t0; t < t1; ++t) {
+    for (long long t = t0; on && t < t1; ++t) {
         const unsigned c = cnt[(size_t)t * fc_pad + lf];
         cnt[(size_t)t * fc_pad + lf] = (unsigned)run;              // per-frame prefix: < 2^32 pairs per frame (host checks P)
         run += c;
@@ -1035,6 +1037,49 @@ MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coord
     else contacts_rect_block<PBC, false>(coords, F, f_begin, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist, cntg, masks, g, jt, JT);
 }
 
+// The count pass for calls of FEW frames (get_collisions: one; a single structure's contact list): with lanes along frames such a call
+// uses one lane in 64.  Here lanes run along the SECOND ATOMS of a row tile: a wave keeps its 64 second atoms of ONE frame in three
+// registers and walks the group's first atoms (their coordinates arrive through scalar loads); a row's 64 contact bits are one ballot =
+// the tile's four 16-bit masks, in the layout of k_contacts_count_rect -- scan and fill do not know the difference.  Per pair
+// dist2_min_image_f32 (the pair's own image test: lanes are different pairs here).
+// blockIdx.x = group * JT + tile (rotated as above), blockIdx.y = frame of the chunk; one wave per block.
+template <bool PBC>
+MK_KERNEL(WAVE) void k_contacts_count_rect_few(const float* __restrict__ coords, long long F, long long f_begin, long long fc_pad,
+                                               const float* __restrict__ box, const unsigned* __restrict__ sel1, long long n1,
+                                               const unsigned* __restrict__ sel2, long long n2, const unsigned* __restrict__ chains,
+                                               float thr2, long long ni, int selfdist, unsigned* __restrict__ cntg, unsigned short* __restrict__ masks)
+{
+    const long long JT = (n2 + DT - 1) / DT, g = (long long)blockIdx.x / JT, jt = ((long long)blockIdx.x % JT + g) % JT;
+    const long long lf = blockIdx.y, f = f_begin + lf;
+    const int l = threadIdx.x & (WAVE - 1);
+    const long long j = jt * DT + l;
+    const bool has = j < n2;
+    const unsigned b = sel2[has ? j : n2 - 1];
+    const float x2 = coords[((size_t)b * 3 + 0) * (size_t)F + (size_t)f], y2 = coords[((size_t)b * 3 + 1) * (size_t)F + (size_t)f],
+                z2 = coords[((size_t)b * 3 + 2) * (size_t)F + (size_t)f];
+    const unsigned cb = PBC ? chains[b] : 0u;
+    float bx = 1.f, by = 1.f, bz = 1.f, ibx = 1.f, iby = 1.f, ibz = 1.f;
+    if (PBC) {
+        bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
+        ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
+    }
+    const long long i0 = g * ni, rows = n1 - i0 < ni ? n1 - i0 : ni;
+    unsigned total = 0u;
+    for (long long ii = 0; ii < rows; ++ii) {
+        const long long i = i0 + ii;
+        const unsigned a = sel1[i];                                  // wave-uniform: scalar loads
+        const float xa = coords[((size_t)a * 3 + 0) * (size_t)F + (size_t)f], ya = coords[((size_t)a * 3 + 1) * (size_t)F + (size_t)f],
+                    za = coords[((size_t)a * 3 + 2) * (size_t)F + (size_t)f];
+        const bool wrap = PBC && cb != chains[a];                    // distance_utils.pyx:49
+        const float d2 = dist2_min_image_f32(xa, ya, za, x2, y2, z2, bx, by, bz, ibx, iby, ibz, wrap);
+        const unsigned long long m = mk_ballot(has && d2 <= thr2 && (!selfdist || j > i));       // :82 (NaN: no contact); :76 (j from i + 1)
+        if (l < DT_THREADS / DT)
+            masks[(((size_t)i * (size_t)JT + (size_t)jt) * (DT_THREADS / DT) + (size_t)l) * (size_t)fc_pad + (size_t)lf] = (unsigned short)((m >> (16 * l)) & 0xffffull);
+        total += (unsigned)mk_popc64(m);
+    }
+    if (l == 0 && total) mk_atomic_add(&cntg[(size_t)g * (size_t)fc_pad + (size_t)lf], total);
+}
+
 // The fill pass of a rectangular call: blockIdx.x = group of first atoms, blockIdx.y = 64-frame slab; lanes = frames.  The group's masks of a
 // frame -- rows x JT * 4 runs, in the reference's (i, j) order -- are split among the block's CF_WAVES waves: a wave counts its stretch,
 // the stretches' counts meet in LDS, then it walks the stretch again and writes (a, b) from
@@ -1043,7 +1088,7 @@ MK_KERNEL(DT_THREADS) void k_contacts_count_rect(const float* __restrict__ coord
 constexpr int CF_WAVES = 16;
 constexpr int CF_CHUNK = 16;              // masks a lane has in flight
 constexpr int CF_SEL2 = 4096;             // second atoms a block stages in LDS (16 KB)
-MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_pad, const unsigned* __restrict__ sel1, long long n1,
+MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_pad /* row pitch of masks / gprefix: >= fc */, const unsigned* __restrict__ sel1, long long n1,
                                                      const unsigned* __restrict__ sel2, long long n2, long long ni,
                                                      const unsigned short* __restrict__ masks, const unsigned* __restrict__ gprefix,
                                                      const unsigned long long* __restrict__ frame_base, uint2* __restrict__ out)
@@ -1062,12 +1107,13 @@ MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_
     if (staged) for (long long j = threadIdx.x; j < n2; j += CF_WAVES * WAVE) s_sel2[j] = sel2[j];
     const unsigned va = sel1[i0 + (fl < rows ? fl : 0)];
     // CF_CHUNK masks at a time, their loads issued together; the first chunk stays in registers for the second walk
+    const bool on = lf < fc;                                         // (rows of few-frame calls are not padded to 64 frames: lanes past the end load nothing)
     unsigned sum = 0u;
     unsigned first[CF_CHUNK];
     for (long long q = q0; q < q1; q += CF_CHUNK) {
         unsigned t[CF_CHUNK];
 #pragma unroll
-        for (int u = 0; u < CF_CHUNK; ++u) t[u] = q + u < q1 ? (unsigned)mrow[(size_t)(q + u) * (size_t)fc_pad] : 0u;
+        for (int u = 0; u < CF_CHUNK; ++u) t[u] = (on && q + u < q1) ? (unsigned)mrow[(size_t)(q + u) * (size_t)fc_pad] : 0u;
 #pragma unroll
         for (int u = 0; u < CF_CHUNK; ++u) sum += (unsigned)__builtin_popcount(t[u]);
         if (q == q0) {
@@ -1079,7 +1125,7 @@ MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_
     mk_block_sync();
     const bool live = lf < fc && sum != 0u;                          // (no lane leaves: the row's atom is handed out by readlane below)
     if (mk_ballot(live) == 0ull) return;                             // wave-uniform
-    unsigned long long pos = frame_base[lf] + gprefix[(size_t)g * (size_t)fc_pad + (size_t)lf];
+    unsigned long long pos = live ? frame_base[lf] + gprefix[(size_t)g * (size_t)fc_pad + (size_t)lf] : 0ull;
     for (int v = 0; v < w; ++v) pos += s_seg[v][fl];
     long long i = i0 + q0 / R4, r = q0 % R4;
     for (long long q = q0; q < q1; q += CF_CHUNK) {
@@ -1089,7 +1135,7 @@ MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_
             for (int u = 0; u < CF_CHUNK; ++u) t[u] = first[u];
         } else {
 #pragma unroll
-            for (int u = 0; u < CF_CHUNK; ++u) t[u] = q + u < q1 ? (unsigned)mrow[(size_t)(q + u) * (size_t)fc_pad] : 0u;
+            for (int u = 0; u < CF_CHUNK; ++u) t[u] = (on && q + u < q1) ? (unsigned)mrow[(size_t)(q + u) * (size_t)fc_pad] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < CF_CHUNK; ++u) {

@@ -254,7 +254,8 @@ struct DevicePairSink {
     }
     int commit(void*, size_t n) { size += n; return 0; }
 };
-enum { CONTACTS_AVOID_RECT = 1 };      // `avoid`: the tests walk both walks over the same shapes; bits 8-15: rows per group of the rectangular walk
+enum { CONTACTS_AVOID_RECT = 1, CONTACTS_AVOID_FEW = 2 };
+constexpr long long CONTACTS_FEW_FRAMES = 16;        // calls of at most this many frames count with lanes along the second atoms      // `avoid`: the tests walk both walks over the same shapes; bits 8-15: rows per group of the rectangular walk
 template <class BE, class Sink>
 int run_contacts(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                  const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, float dist_threshold,
@@ -287,18 +288,21 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     //  amortised; the fewer, the smaller the last, partly filled round of blocks (four blocks per CU are resident at 121 registers).
     //  ni <= 32 that minimises rounds x (ni + 0.6); measured on 200 x 500 x 2 048: 8 rows 129 us, 25 rows -- two full rounds -- ... )
     const long long slabs_all = ceil_div(F, DT);
+    const bool few = rect && F <= CONTACTS_FEW_FRAMES && !(avoid & CONTACTS_AVOID_FEW);
     const long long ni_forced = std::min(32, (avoid >> 8) & 0xff);   // (the tests walk group sizes the small cases would never get; <= 32: a bit per row)
     long long ni = 0;
     if (rect) {
-        const long long slots = 4LL * std::max(1, be.compute_units());
+        // (few frames -- get_collisions has one: lanes along the second atoms instead of the frames, k_contacts_count_rect_few; its blocks
+        //  are single waves, thirty-two to a CU, one per (group, tile, FRAME))
+        const long long slots = (few ? 32LL : 4LL) * std::max(1, be.compute_units());
         double best = 0.0;
         for (long long c = 1; c <= std::min<long long>(32, n1); ++c) {
-            long long blocks = ceil_div(n1, c) * JT;                 // per slab; selfdist: only the tiles that reach beyond a group's first row compute
+            long long blocks = ceil_div(n1, c) * JT;                 // per slab (or frame); selfdist: only the tiles that reach beyond a group's first row compute
             if (selfdist) {
                 blocks = 0;
                 for (long long g = 0; g * c < n1; ++g) blocks += std::max<long long>(0, JT - (g * c < DT - 1 ? 0 : (g * c - (DT - 1)) / DT + 1));
             }
-            const double cost = (double)ceil_div(std::max<long long>(1, blocks) * slabs_all, slots) * ((double)c + 0.6);
+            const double cost = (double)ceil_div(std::max<long long>(1, blocks) * (few ? F : slabs_all), slots) * ((double)c + 0.6);
             if (ni == 0 || cost <= best) { best = cost; ni = c; }     // (ties: the larger group)
         }
         if (ni_forced) ni = ni_forced;
@@ -318,9 +322,19 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
     for (long long f0 = 0; f0 < F; f0 += chunk) {
         const long long fc = std::min<long long>(chunk, F - f0), fc_pad = (fc + DT - 1) / DT * DT;
         const dim3 grid((unsigned)tiles, (unsigned)(fc_pad / DT));
+        // (the rows of the counters and masks: 64-frame slabs -- lanes are frames -- except in a call of few frames, whose rows hold just its frames:
+        //  get_collisions of 60 000 x 3 000 atoms would otherwise read and write 1.4 GB of masks for 22 MB of bits)
+        const long long pitch = few ? fc : fc_pad;
         if (rect) {
             const dim3 cgrid((unsigned)(groups * JT), (unsigned)(fc_pad / DT));
-            if ((st = be.fill(cnt, 0, (size_t)groups * (size_t)fc_pad * 4))) return st;
+            if ((st = be.fill(cnt, 0, (size_t)groups * (size_t)pitch * 4))) return st;
+            if (few) {
+                const dim3 fgrid((unsigned)(groups * JT), (unsigned)fc);
+                st = pbc ? be.launch(k_contacts_count_rect_few<true>, fgrid, dim3(WAVE), coords, F, f0, pitch, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist,
+                                     (unsigned*)cnt, (unsigned short*)msk)
+                         : be.launch(k_contacts_count_rect_few<false>, fgrid, dim3(WAVE), coords, F, f0, pitch, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist,
+                                     (unsigned*)cnt, (unsigned short*)msk);
+            } else
             st = pbc ? be.launch(k_contacts_count_rect<true>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist,
                                  (unsigned*)cnt, (unsigned short*)msk)
                      : be.launch(k_contacts_count_rect<false>, cgrid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, sel1, n1, sel2, n2, chains, thr2, ni, selfdist,
@@ -328,7 +342,7 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
             if (st) return st;
         } else if ((st = be.launch(k_contacts_count, grid, dim3(DT_THREADS), coords, F, f0, fc, fc_pad, box, (const unsigned*)pa, (const unsigned*)pb,
                                    (const unsigned*)wr, P, thr2, (unsigned*)cnt, (unsigned short*)msk))) return st;
-        if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(CS_WAVES * WAVE), (unsigned*)cnt, tiles, fc_pad,
+        if ((st = be.launch(k_contacts_scan, dim3((unsigned)(fc_pad / DT)), dim3(CS_WAVES * WAVE), (unsigned*)cnt, tiles, pitch, pitch,
                             (unsigned long long*)tot))) return st;
         if ((st = be.to_host(totals.data(), tot, (size_t)fc_pad * 8))) return st;
         unsigned long long run = 0;
@@ -338,7 +352,7 @@ int run_contacts(BE& be, const float* coords, long long F, const float* box, con
         if ((st = sink.reserve((size_t)run, &dout))) return st;
         if ((st = be.to_device(base, bases.data(), (size_t)fc_pad * 8))) return st;
         if (rect) {
-            if ((st = be.launch(k_contacts_fill_rect, grid, dim3(CF_WAVES * WAVE), fc, fc_pad, sel1, n1, sel2, n2, ni, (const unsigned short*)msk,
+            if ((st = be.launch(k_contacts_fill_rect, grid, dim3(CF_WAVES * WAVE), fc, pitch, sel1, n1, sel2, n2, ni, (const unsigned short*)msk,
                                 (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;
         } else if ((st = be.launch(k_contacts_fill, grid, dim3(DT_THREADS), fc, fc_pad, (const unsigned*)pa, (const unsigned*)pb, (const unsigned short*)msk,
                                    (const unsigned*)cnt, (const unsigned long long*)base, (uint2*)dout))) return st;

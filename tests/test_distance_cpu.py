@@ -687,3 +687,35 @@ def test_selfdist_contacts_through_the_rectangular_kernels_unequal_selections():
         assert sum(len(x) for x in want) > 0 or n1 == 1
         for avoid in (1, 0, 5 << 8, 32 << 8):
             assert E.contacts_trajectory(c, b, s1, s2, ch, True, True, 6.0, avoid=avoid, budget_bytes=12 * 64 * 8 if avoid == 0 else 256 << 20) == want, (n1, n2, avoid)
+
+
+@pytest.mark.parametrize("ids", ["selections", "chains", "one"])
+def test_contact_lists_of_few_frames_take_lanes_along_the_second_atoms(ids):
+    """Calls of at most 16 frames (get_collisions has one) count with lanes along the SECOND ATOMS (k_contacts_count_rect_few, round 6): slices
+    of the rectangular case -- one frame, the frames with the zero box / inf / NaN coordinates, sixteen frames with their image-integer traps --
+    against the oracle and equal to the lanes-along-frames kernel; selfdist too; rows per group 1 / 5 / 32."""
+    for n2 in (70, 150):
+        c, b, ch, s1, s2 = _rect_contact_case(ids, n2)
+        for lo, hi in ((0, 1), (10, 14), (0, 16), (54, 70)):
+            cs, bs = np.ascontiguousarray(c[:, :, lo:hi]), np.ascontiguousarray(b[:, lo:hi])
+            with np.errstate(all="ignore"):
+                for pbc in (True, False):
+                    d2 = oracle.dist_trajectory(cs, bs, s1, s2, ch, False, pbc, squared=True)
+                    for thr in (6.0, 21.5):
+                        want = _contact_lists(d2, s1, s2, thr)
+                        for avoid in (0, 2, 5 << 8, 32 << 8):            # few-frames kernel; lanes along frames; groups of 5 and 32 rows
+                            assert E.contacts_trajectory(cs, bs, s1, s2, ch, False, pbc, thr, avoid=avoid) == want, (n2, lo, hi, pbc, thr, avoid)
+    # selfdist, unequal selections, one and three frames
+    rng = np.random.default_rng(43)
+    N = 200
+    c = rng.uniform(0, 20, size=(N, 3, 3)).astype(np.float32)
+    b = np.full((3, 3), 20.0, np.float32)
+    ch = rng.integers(0, 3, N).astype(np.uint32)
+    for n1, n2 in ((150, 150), (70, 130), (130, 70)):
+        s1 = rng.permutation(N)[:n1].astype(np.uint32); s2 = rng.permutation(N)[:n2].astype(np.uint32)
+        pairs = [(i, j) for i in range(n1) for j in range(i + 1, n2)]
+        for F in (1, 3):
+            d2 = oracle.dist_trajectory(c[:, :, :F].copy(), b[:, :F].copy(), s1, s2, ch, True, True, squared=True)
+            want = [[int(v) for k in np.nonzero(d2[f] <= np.float32(25.0))[0] for v in (s1[pairs[k][0]], s2[pairs[k][1]])] for f in range(F)]
+            for avoid in (0, 2, 1):
+                assert E.contacts_trajectory(c[:, :, :F].copy(), b[:, :F].copy(), s1, s2, ch, True, True, 5.0, avoid=avoid) == want, (n1, n2, F, avoid)
