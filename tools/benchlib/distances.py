@@ -338,7 +338,20 @@ def bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s
     torch.cuda.synchronize(dev)                      # (every call ends with its own wait for the counts: wall clock = device time + read-backs)
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     alg = (n1 + n2) * 3 * F * 4 + 3 * F * 4 + n * 8 + (F + 1) * 8
-    return {"shape": f"{n1} x {n2} pairs x {F} frames, threshold {thr} A, periodic: {n} contacts", "ms_per_call": round(ms, 4),
+    # get_collisions (distance_utils.pyx:98-121; molecule.py:3731: what Molecule.append(collisiondist=...) sends): ONE frame, no box, host arrays in and
+    # the Python list out -- calls of few frames count with lanes along the second atoms (k_contacts_count_rect_few)
+    from moleculekit_amd.distance_utils import get_collisions
+    rng = np.random.default_rng(2)
+    ca, cb = rng.uniform(0, 60, size=(20000, 3)).astype(np.float32), rng.uniform(0, 60, size=(3000, 3)).astype(np.float32)
+    hits = get_collisions(ca, cb, 1.3)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        get_collisions(ca, cb, 1.3)
+    coll_ms = (time.perf_counter() - t0) / 5 * 1e3
+    collisions = {"shape": "20000 x 3000 atoms, one frame, 1.3 A", "ms_per_call": round(coll_ms, 3), "collisions": len(hits) // 2,
+                  "pair_tests_per_s_G": round(20000 * 3000 / coll_ms / 1e6, 1), "what": "the whole Python call: host arrays in, list out"}
+    return {"get_collisions": collisions,
+            "shape": f"{n1} x {n2} pairs x {F} frames, threshold {thr} A, periodic: {n} contacts", "ms_per_call": round(ms, 4),
             "pair_tests_per_s_G": round(n1 * n2 * F / ms / 1e6, 1),
             "roofline": {"bound": "hbm", "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 5),
                          "algorithmic_bytes_per_launch": alg, "note": "VALU-bound: k_contacts_count_rect spends 18.9 lane-instructions on a periodic pair (packed arithmetic, the image integers behind one accumulated test, 2.4 of them the contact bit) = 118 us of issue at 2.0 GHz for this shape, measured 127; the fill pass reads the 16-bit masks the count pass kept; wall clock incl. the count read-back"},
