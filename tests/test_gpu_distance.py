@@ -600,6 +600,30 @@ def test_rectangular_contact_kernel_redoes_trapped_batches_on_the_device():
         assert contacts_trajectory(c, b, s1, s2, ch, False, True, thr) == want
 
 
+@pytest.mark.parametrize("ids", ["selections", "chains"])
+def test_contact_lists_of_few_frames_on_the_device(ids):
+    """Calls of at most 16 frames count with lanes along the second atoms (k_contacts_count_rect_few) and keep unpadded mask rows: slices of the
+    rectangular case (one frame; the frames with the zero box, inf, NaN; sixteen frames with their traps) against the oracle; get_collisions
+    (one frame, no box) at a few thousand atoms against a brute-force count."""
+    from moleculekit_amd.distance_utils import contacts_trajectory, get_collisions
+    from tests.test_distance_cpu import _contact_lists, _rect_contact_case
+    c, b, ch, s1, s2 = _rect_contact_case(ids, 150)
+    with np.errstate(all="ignore"):
+        for lo, hi in ((0, 1), (10, 14), (0, 16)):
+            cs, bs = np.ascontiguousarray(c[:, :, lo:hi]), np.ascontiguousarray(b[:, lo:hi])
+            for pbc in (True, False):
+                d2 = oracle.dist_trajectory(cs, bs, s1, s2, ch, False, pbc, squared=True)
+                for thr in (6.0, 21.5):
+                    assert contacts_trajectory(cs, bs, s1, s2, ch, False, pbc, thr) == _contact_lists(d2, s1, s2, thr), (lo, hi, pbc, thr)
+    rng = np.random.default_rng(6)
+    a, bb = rng.uniform(0, 25, size=(3000, 3)).astype(np.float32), rng.uniform(0, 25, size=(700, 3)).astype(np.float32)
+    got = np.asarray(get_collisions(a, bb, 1.5), np.int64).reshape(-1, 2)
+    diff = a[:, None, :] - bb[None, :, :]
+    exact = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]       # float32, the reference's order (:107-110)
+    want = np.argwhere(exact <= np.float32(1.5) * np.float32(1.5))
+    assert np.array_equal(got, want) and len(want) > 100
+
+
 @pytest.mark.parametrize("mixed", [False, True])
 def test_pair_table_walk_packed_batches_on_the_device(mixed):
     """for_pair_run's packed batches (round 6) on the hardware: selfdist with an image-integer trap in every frame, a zero box, inf / NaN;
