@@ -1,4 +1,4 @@
-# round 6, session 53: the whole GPU tier with the few-frame contact tests
+# round 6, session 54: random sweep of the contact lists against the oracle
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-(timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -3)
+timeout 1500 python tests/sweep_gpu_contacts.py 400 2000 2>&1 | grep -v amdgpu | tail -12 | tee gpurun_out/sweep_contacts.txt
