@@ -363,8 +363,9 @@ MK_KERNEL(DT_THREADS) void k_dist_pairs(const float* __restrict__ coords, long l
 // the same 0.30 ms -- 92 % and 58 % VALU-busy).  Here a block owns 64 consecutive sel2 atoms x DR_I consecutive sel1 atoms x 64
 // frames: a wave keeps the coordinates of ITS 16 second atoms (lane = frame) in 48 registers and walks the first atoms --
 // three loads per first atom instead of 51 -- transposing one 64-pair row of the result through LDS per first atom, so the
-// stores are k_dist_pairs' (whole 256-byte rows of out[f, i * n2 + j0 ..]).  No pair table is built.  Same arithmetic per
-// pair (dist2_min_image_f32, mk_fsqrt_rn): the same bits.
+// stores are k_dist_pairs' (whole 256-byte rows of out[f, i * n2 + j0 ..]).  No pair table is built.  Round 6: the second atoms sit in
+// registers as packed pairs and a row's pairs go through dist2_pk behind one accumulated image test (dist2_min_image_f32 where it fails):
+// the same bits; no faster -- the kernel is bound by its turn through LDS, not by its arithmetic (profiles/r6_dist_rect_packed_ab.txt).
 // ------------------------------------------------------------------------------------------------
 constexpr int DR_I = 8;                // first atoms per block (the second atoms' loads are amortised over them)
 constexpr int DR_WAVES = 8;            // waves per block: 8 second atoms each -- 24 registers of coordinates, not 48 (sixteen per wave: 129-141
@@ -778,7 +779,10 @@ MK_KERNEL(DF_THREADS) void k_dist_frame(const float* __restrict__ coords, long l
 //   k_contacts_fill  : the same tiles again; a lane keeps its 16 hits as a bit mask, ranks them behind the tile's
 //                      prefix and the lower waves of its block, and writes (a, b) at frame_base + rank: (i, j) order
 //                      (round 6: from the 16-bit masks the count pass left -- no distance is computed twice)
-// Frames are processed in chunks (host loop, capi.hip) so that the counters stay within a fixed memory budget.
+// Frames are processed in chunks (host loop, dist_pipeline.h: run_contacts) so that the counters stay within a fixed memory budget.
+// (Round 6: these three serve the calls the kernels further down do not take -- rows that fill less than three eighths of their
+//  64-wide tiles, i.e. fewer than 24 second atoms; everything else counts with its second atoms in registers: k_contacts_count_rect,
+//  k_contacts_count_rect_few, k_contacts_fill_rect.)
 // ------------------------------------------------------------------------------------------------
 constexpr int CT_RUN = DT / (DT_THREADS / DT);        // consecutive pairs per wave of a tile (16)
 
