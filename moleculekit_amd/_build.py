@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libmkamd.so")
 HOST_LIB = os.path.join(CSRC, "libmkamd_host.so")          # the host entry point alone, plain C++ (no ROCm): build_host()
-SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "mk_diagnostics.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h", "xtc_gpu.h", "cpu_occupancy.h"]
+SOURCES = ["capi.hip", "pipeline.h", "kernels.h", "mk_device.h", "mk_diagnostics.h", "dist_kernels.h", "dist_pipeline.h", "xtc_reader.h", "xtc_gpu.h", "cpu_occupancy.h", "host_pack.h"]
 HEADER = os.path.join(_HERE, "..", "include", "mkamd_voxel.h")
 HEADER2 = os.path.join(_HERE, "..", "include", "mkamd_distance.h")
 HEADER3 = os.path.join(_HERE, "..", "include", "mkamd_xtc.h")

@@ -9,6 +9,7 @@
 #include <atomic>
 #include "pipeline.h"
 #include "dist_pipeline.h"
+#include "host_pack.h"
 #include "xtc_gpu.h"
 #include "cpu_occupancy.h"
 
@@ -92,6 +93,7 @@ struct mkamd_ctx {
     void* stage_host_dev = nullptr;        // device-side address of the same memory (mapped): tiny inputs are read in place
     size_t stage_cap = 0;
     std::vector<uint32_t> contacts_host;   // result of the last mkamd_contacts_trajectory_host call (owned here)
+    std::vector<float> packed_coords;      // the selected atoms' rows of a host distance call (host_pack.h), kept between calls
     std::vector<float> f32_stage;          // host staging of big float64-out results
     struct PendingHostCall { bool active = false; size_t out_bytes = 0; bool mapped_out = false; unsigned seq = 0; void* dout = nullptr; hipEvent_t done = nullptr; };
     PendingHostCall pending;               // a host call between its begin and its end (voxelize_lattice_host_begin_impl)
@@ -1427,11 +1429,23 @@ try {
     for (int64_t i = 0; i < n1; ++i) if (sel1[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel1 index out of range");
     for (int64_t i = 0; i < n2; ++i) if (sel2[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel2 index out of range");
     void *dc, *db, *d1, *d2, *dch, *dout;
-    if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+    // only the selected atoms' rows go up when they are few (host_pack.h); the selections and chain ids in the packed numbering
+    mkamd::PackedAtoms pk;
+    pk.collect(sel1, n1); pk.collect(sel2, n2);
+    if (pk.finish(coords, N, F, ctx->packed_coords)) {
+        const std::vector<uint32_t> p1 = pk.remap(sel1, n1), p2 = pk.remap(sel2, n2), pc = pk.gather(chains);
+        if ((st = upload(ctx, WS_H_COORDS, ctx->packed_coords.data(), (size_t)pk.size() * 3 * F * 4, &dc))) return st;
+        if ((st = upload(ctx, WS_D_SEL1, p1.data(), (size_t)n1 * 4, &d1))) return st;
+        if ((st = upload(ctx, WS_D_SEL2, p2.data(), (size_t)n2 * 4, &d2))) return st;
+        if ((st = upload(ctx, WS_D_CHAINS, pc.data(), (size_t)pk.size() * 4, &dch))) return st;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));                  // (the temporaries above are read by then)
+    } else {
+        if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+        if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
+        if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
+        if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
+    }
     if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
-    if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
-    if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
-    if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
     if ((st = ctx->ensure(WS_H_OUT, (size_t)F * P * 4, &dout, 0))) return st;
     st = mkamd_dist_trajectory_dev(ctx, (const float*)dc, F, (const float*)db, (const uint32_t*)d1, n1, (const uint32_t*)d2, n2,
                                    (const uint32_t*)dch, selfdist, pbc, squared, (float*)dout);
@@ -1461,11 +1475,22 @@ try {
     for (int64_t i = 0; i < n1; ++i) if (sel1[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel1 index out of range");
     for (int64_t i = 0; i < n2; ++i) if (sel2[i] >= (uint64_t)N) return fail(MKAMD_EINVAL, "sel2 index out of range");
     void *dc, *db, *d1, *d2, *dch;
-    if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+    mkamd::PackedAtoms pk;                                           // (host_pack.h: only the selected atoms' rows go up when they are few)
+    pk.collect(sel1, n1); pk.collect(sel2, n2);
+    if (pk.finish(coords, N, F, ctx->packed_coords)) {
+        const std::vector<uint32_t> p1 = pk.remap(sel1, n1), p2 = pk.remap(sel2, n2), pc = pk.gather(chains);
+        if ((st = upload(ctx, WS_H_COORDS, ctx->packed_coords.data(), (size_t)pk.size() * 3 * F * 4, &dc))) return st;
+        if ((st = upload(ctx, WS_D_SEL1, p1.data(), (size_t)n1 * 4, &d1))) return st;
+        if ((st = upload(ctx, WS_D_SEL2, p2.data(), (size_t)n2 * 4, &d2))) return st;
+        if ((st = upload(ctx, WS_D_CHAINS, pc.data(), (size_t)pk.size() * 4, &dch))) return st;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else {
+        if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+        if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
+        if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
+        if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
+    }
     if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
-    if ((st = upload(ctx, WS_D_SEL1, sel1, (size_t)n1 * 4, &d1))) return st;
-    if ((st = upload(ctx, WS_D_SEL2, sel2, (size_t)n2 * 4, &d2))) return st;
-    if ((st = upload(ctx, WS_D_CHAINS, chains, (size_t)N * 4, &dch))) return st;
     std::string err;
     static_assert(sizeof(long long) == sizeof(int64_t), "frame offsets are int64");
     st = run_contacts(*ctx, (const float*)dc, (long long)F, (const float*)db, (const unsigned*)d1, (long long)n1, (const unsigned*)d2,
@@ -1473,6 +1498,7 @@ try {
                       (long long*)frame_offsets, HostPairSink<mkamd_ctx>{*ctx, ctx->contacts_host}, err);
     if (st) return err.empty() ? st : fail(st, err);
     if (ctx->contacts_host.empty()) return MKAMD_OK;
+    if (pk.on) pk.unpack_in_place(ctx->contacts_host.data(), ctx->contacts_host.size());     // the list names atoms of the caller's array
     *pairs = ctx->contacts_host.data();
     return MKAMD_OK;
 } MK_API_CATCH
@@ -1496,18 +1522,35 @@ try {
     for (int64_t k = 0; k < g1_off[ng1]; ++k) if (g1_atoms[k] < 0 || g1_atoms[k] >= N) return fail(MKAMD_EINVAL, "groups1 atom index out of range");
     for (int64_t k = 0; k < g2_off[ng2]; ++k) if (g2_atoms[k] < 0 || g2_atoms[k] >= N) return fail(MKAMD_EINVAL, "groups2 atom index out of range");
     void *dc, *db, *a1, *o1, *a2, *o2, *c1, *c2, *dm = nullptr, *dout;
-    if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+    int64_t n_up = N;                                                // atoms of the array that goes up
+    mkamd::PackedAtoms pk;                                           // (host_pack.h: only the groups' atoms when they are few)
+    pk.collect(g1_atoms, g1_off[ng1]); pk.collect(g2_atoms, g2_off[ng2]);
+    if (pk.finish(coords, N, F, ctx->packed_coords)) {
+        const std::vector<int32_t> p1 = pk.remap(g1_atoms, g1_off[ng1]), p2 = pk.remap(g2_atoms, g2_off[ng2]);
+        n_up = pk.size();
+        if ((st = upload(ctx, WS_H_COORDS, ctx->packed_coords.data(), (size_t)n_up * 3 * F * 4, &dc))) return st;
+        if ((st = upload(ctx, WS_D_G1A, p1.data(), (size_t)g1_off[ng1] * 4, &a1))) return st;
+        if ((st = upload(ctx, WS_D_G2A, p2.data(), (size_t)g2_off[ng2] * 4, &a2))) return st;
+        if (masses) {
+            const std::vector<float> pm = pk.gather(masses);
+            if ((st = upload(ctx, WS_D_MASS, pm.data(), (size_t)n_up * 4, &dm))) return st;
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));                  // (the temporaries above are read by then)
+    } else {
+        if ((st = upload(ctx, WS_H_COORDS, coords, (size_t)N * 3 * F * 4, &dc))) return st;
+        if ((st = upload(ctx, WS_D_G1A, g1_atoms, (size_t)g1_off[ng1] * 4, &a1))) return st;
+        if ((st = upload(ctx, WS_D_G2A, g2_atoms, (size_t)g2_off[ng2] * 4, &a2))) return st;
+        if (masses && (st = upload(ctx, WS_D_MASS, masses, (size_t)N * 4, &dm))) return st;
+    }
     if ((st = upload(ctx, WS_H_BOX, box, (size_t)3 * F * 4, &db))) return st;
-    if ((st = upload(ctx, WS_D_G1A, g1_atoms, (size_t)g1_off[ng1] * 4, &a1))) return st;
     if ((st = upload(ctx, WS_D_G1O, g1_off, (size_t)(ng1 + 1) * 8, &o1))) return st;
-    if ((st = upload(ctx, WS_D_G2A, g2_atoms, (size_t)g2_off[ng2] * 4, &a2))) return st;
     if ((st = upload(ctx, WS_D_G2O, g2_off, (size_t)(ng2 + 1) * 8, &o2))) return st;
     if ((st = upload(ctx, WS_D_CHAINS, chains1, (size_t)ng1 * 4, &c1))) return st;
     if ((st = upload(ctx, WS_D_CHAINS2, chains2, (size_t)ng2 * 4, &c2))) return st;
-    if (masses && (st = upload(ctx, WS_D_MASS, masses, (size_t)N * 4, &dm))) return st;
     if ((st = ctx->ensure(WS_H_OUT, (size_t)F * P * 4, &dout, 0))) return st;
     std::string err;
-    st = run_dist_reduction(*ctx, (const float*)dc, N, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, g1_off[ng1], (const int*)a2,
+    st = run_dist_reduction(*ctx, (const float*)dc, n_up, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, g1_off[ng1], (const int*)a2,
                             (const long long*)o2, ng2, (const unsigned*)c1, (const unsigned*)c2, selfdist, pairs, pbc,
                             (const float*)dm, reduction1, reduction2, (float*)dout, err,
                             ctx->reduction_block ? ctx->reduction_block : reduction_block_for((const long long*)g1_off, ng1));

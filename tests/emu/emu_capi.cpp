@@ -6,6 +6,7 @@
 #include "../../moleculekit_amd/csrc/pipeline.h"
 #include "../../moleculekit_amd/csrc/dist_pipeline.h"
 #include "../../moleculekit_amd/csrc/xtc_gpu.h"
+#include "../../moleculekit_amd/csrc/host_pack.h"
 
 #include <string>
 #include <algorithm>
@@ -279,6 +280,31 @@ int emu_contacts(const float* coords, long long F, const float* box, const unsig
     *n_out = (long long)(pairs.size() / 2);
     if (!st && (long long)(pairs.size() / 2) <= cap) memcpy(pairs_out, pairs.data(), pairs.size() * sizeof(unsigned));
     return st;
+}
+
+// csrc/host_pack.h as the host entry points use it: returns 1 when the call would upload the packed rows (then out_coords [M,3,F], out_uniq [M],
+// out_remap [n] = the selection in the packed numbering are filled), 0 when the array goes up as it is (out_uniq / *M still say which atoms)
+int emu_pack_atoms(const float* coords, long long N, long long F, const unsigned* sel, long long n, float* out_coords, unsigned* out_uniq,
+                   unsigned* out_remap, long long* M)
+{
+    PackedAtoms pk;
+    pk.collect(sel, n);
+    std::vector<float> buf;
+    const bool on = pk.finish(coords, N, F, buf);
+    *M = pk.size();
+    for (long long k = 0; k < pk.size(); ++k) out_uniq[k] = pk.uniq[(size_t)k];
+    if (!on) return 0;
+    memcpy(out_coords, buf.data(), (size_t)pk.size() * 3 * (size_t)F * sizeof(float));
+    const std::vector<unsigned> r = pk.remap(sel, n);
+    for (long long i = 0; i < n; ++i) out_remap[i] = r[(size_t)i];
+    return 1;
+}
+
+void emu_unpack_atoms(const unsigned* uniq, long long M, unsigned* atoms, long long n)
+{
+    PackedAtoms pk;
+    pk.uniq.assign(uniq, uniq + M);
+    pk.unpack_in_place(atoms, (size_t)n);
 }
 
 int emu_cdist(const float* c1, long long n1, const float* c2, long long n2, int D, float* out)

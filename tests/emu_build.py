@@ -22,7 +22,8 @@ _lib = None
 def build(force=False):
     srcs = [os.path.join(_EMU, "emu_capi.cpp"), os.path.join(_EMU, "emu_device.h"),
             os.path.join(_CSRC, "kernels.h"), os.path.join(_CSRC, "pipeline.h"),
-            os.path.join(_CSRC, "dist_kernels.h"), os.path.join(_CSRC, "dist_pipeline.h"), os.path.join(_CSRC, "xtc_gpu.h")]
+            os.path.join(_CSRC, "dist_kernels.h"), os.path.join(_CSRC, "dist_pipeline.h"), os.path.join(_CSRC, "xtc_gpu.h"),
+            os.path.join(_CSRC, "host_pack.h")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if force or stale:
         subprocess.check_call(
@@ -214,6 +215,25 @@ def contacts_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, threshol
     assert st == 0, lib().emu_last_error()
     flat = pairs[:2 * n.value].astype(np.int64)
     return [flat[2 * offs[f]:2 * offs[f + 1]].tolist() for f in range(F)]
+
+
+def pack_atoms(coords, sels, per_atom=None):
+    """csrc/host_pack.h (what the library's host entry points of the distance functions do before the upload): -> (on, uniq, packed coords
+    [M, 3, F], the selections in the packed numbering, `per_atom` gathered) for selections `sels` (a list of index arrays)."""
+    coords = np.ascontiguousarray(coords, np.float32)
+    N, _, F = coords.shape
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(s, np.uint32).ravel() for s in sels]) if sels else np.zeros(0, np.uint32), np.uint32)
+    uniq = np.zeros(max(len(flat), 1), np.uint32)
+    out = np.full((max(len(flat), 1), 3, F), np.nan, np.float32)
+    remap = np.zeros(max(len(flat), 1), np.uint32)
+    M = ctypes.c_longlong(0)
+    on = lib().emu_pack_atoms(_p(coords), ctypes.c_longlong(N), ctypes.c_longlong(F), _p(flat), ctypes.c_longlong(len(flat)), _p(out), _p(uniq), _p(remap),
+                              ctypes.byref(M))
+    m = M.value
+    back = remap[:len(flat)].copy()
+    if on:
+        lib().emu_unpack_atoms(_p(uniq), ctypes.c_longlong(m), _p(back), ctypes.c_longlong(len(back)))
+    return bool(on), uniq[:m].copy(), out[:m].copy(), remap[:len(flat)].copy(), back
 
 
 def cdist(c1, c2):

@@ -719,3 +719,25 @@ def test_contact_lists_of_few_frames_take_lanes_along_the_second_atoms(ids):
             want = [[int(v) for k in np.nonzero(d2[f] <= np.float32(25.0))[0] for v in (s1[pairs[k][0]], s2[pairs[k][1]])] for f in range(F)]
             for avoid in (0, 2, 1):
                 assert E.contacts_trajectory(c[:, :, :F].copy(), b[:, :F].copy(), s1, s2, ch, True, True, 5.0, avoid=avoid) == want, (n1, n2, F, avoid)
+
+
+def test_host_calls_pack_the_selected_atoms_before_the_upload():
+    """csrc/host_pack.h (round 6): the host entry points upload only the rows of the atoms a call selects when those are at most a quarter
+    of a (> 1 MB) coordinate array -- unsorted selections with repeats, the packed numbering, the coordinates' rows, the way back for
+    contact lists; and the cases that upload the array as it is (small arrays, selections of more than a quarter of the atoms)."""
+    rng = np.random.default_rng(17)
+    N, F = 3000, 40                                              # 1.44 MB
+    c = rng.normal(size=(N, 3, F)).astype(np.float32)
+    s1 = rng.integers(0, N, size=200).astype(np.uint32); s2 = np.array([7, 7, 2999, 0, 1500, 7], np.uint32)
+    on, uniq, packed, remap, back = E.pack_atoms(c, [s1, s2])
+    flat = np.concatenate([s1, s2])
+    assert on and np.array_equal(uniq, np.unique(flat)) and len(uniq) * 4 <= N
+    assert np.array_equal(packed, c[uniq.astype(np.int64)])                 # the rows, in the packed order
+    assert np.array_equal(uniq[remap.astype(np.int64)], flat)               # the selection names the same atoms
+    assert np.array_equal(back, flat)                                       # and packed indices translate back (contact lists)
+    on, uniq, _, _, _ = E.pack_atoms(c, [rng.permutation(N)[:800].astype(np.uint32)])
+    assert not on and len(uniq) == 800                                      # more than a quarter of the atoms: as it is
+    on, _, _, _, _ = E.pack_atoms(c[:, :, :20].copy(), [s1])
+    assert not on                                                           # an array of less than a megabyte: as it is
+    on, uniq, packed, _, _ = E.pack_atoms(c, [np.array([5], np.uint32)])
+    assert on and uniq.tolist() == [5] and np.array_equal(packed[0], c[5])

@@ -740,3 +740,45 @@ def test_sharded_distances_on_the_device_single_rank():
     assert np.array_equal(pairs.cpu().numpy().astype(np.int64), keep)
     with pytest.raises(ValueError):
         sd.dist_trajectory(np.array([N], np.uint32), s2, chains, False, True)
+
+
+def test_host_calls_that_pack_the_selected_atoms_equal_the_unpacked_calls():
+    """csrc/host_pack.h (round 6): a host call whose selections are at most a quarter of a > 1-MB coordinate array uploads only the
+    selected atoms' rows, in a packed numbering.  Unsorted selections with repeats, chain ids and masses gathered, contact lists
+    translated back to the caller's atom numbers: dist_trajectory, contacts_trajectory and the group reductions (closest atom and
+    centre of mass) against the oracle on the whole array, bit for bit."""
+    from moleculekit_amd import distance_utils as du
+    rng = np.random.default_rng(29)
+    N, F = 3000, 40                                              # 1.44 MB: packed
+    c = rng.uniform(0, 40.0, size=(N, 3, F)).astype(np.float32)
+    b = np.full((3, F), 40.0, np.float32)
+    ch = rng.integers(0, 4, size=N).astype(np.uint32)
+    m = rng.uniform(1, 32, size=N).astype(np.float32)
+    s1 = rng.integers(0, N, size=130).astype(np.uint32); s1[5] = s1[6]          # unsorted, a repeat
+    s2 = rng.permutation(N)[:70].astype(np.uint32)
+    for selfd, a, bb in ((False, s1, s2), (True, s2, s2)):
+        for pbc in (True, False):
+            exp = oracle.dist_trajectory(c, b, a, bb, ch, selfd, pbc)
+            got = np.full_like(exp, -1.0)
+            du.dist_trajectory(c, b, a, bb, ch, selfd, pbc, got)
+            assert np.array_equal(got, exp), (selfd, pbc)
+        d2 = oracle.dist_trajectory(c, b, a, bb, ch, selfd, True, squared=True)
+        table = ([(a[i], bb[j]) for i in range(len(a)) for j in range(i + 1, len(bb))] if selfd else
+                 [(a[i], bb[j]) for i in range(len(a)) for j in range(len(bb))])
+        lists = du.contacts_trajectory(c, b, a, bb, ch, selfd, True, 9.0)
+        n_hits = 0
+        for f in range(F):
+            hits = np.nonzero(d2[f] <= np.float32(81.0))[0]
+            assert lists[f] == [int(v) for k in hits for v in table[k]], (selfd, f)
+            n_hits += len(hits)
+        assert n_hits > 50
+    atoms = rng.permutation(N)[:240]
+    g1 = [list(map(int, atoms[i * 8:(i + 1) * 8])) for i in range(12)]
+    g2 = [list(map(int, atoms[96 + i * 9:96 + (i + 1) * 9])) for i in range(16)]
+    c1 = rng.integers(0, 3, size=12).astype(np.uint32); c2 = rng.integers(0, 3, size=16).astype(np.uint32)
+    for r1, r2 in ((0, 0), (1, 1), (0, 1)):
+        for pbc in (True, False):
+            exp = oracle.dist_trajectory_reduction(c, b, g1, g2, c1, c2, False, pbc, m, r1, r2)
+            got = np.full_like(exp, -1.0)
+            du.dist_trajectory_reduction(c, b, g1, g2, c1, c2, False, pbc, m, r1, r2, got)
+            assert np.array_equal(got, exp), (r1, r2, pbc)

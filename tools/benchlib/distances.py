@@ -187,11 +187,35 @@ def bench_distances(args, emit=True):
         line["cdist_pdist"] = bench_cdist_pdist(args, ctx, dev, busy, check)
         line["reduction"] = bench_reductions(args, ctx, dev, busy, check)
         line["contacts"] = bench_contacts(args, ctx, dev, busy, check, coords, box, chains, chains_h, s1, s2, d1, d2, F)
+        line["host_call"] = bench_host_call(coords, box, chains_h, s1, s2, F)
     del coords, out
     torch.cuda.empty_cache()
     if emit:
         print(json.dumps(line), flush=True)
     return line
+
+
+def bench_host_call(coords, box, chains_h, s1, s2, F):
+    """The PCIe-inclusive figure of the f-1 row (never `value`): the reference-shaped call itself -- moleculekit_amd.distance_utils.dist_trajectory
+    with HOST arrays in and out, what `install()` puts under MetricDistance -- for the headline call (819 MB of distances down) and for
+    MetricDistance's usual small one (300 x 30: 74 MB down).  Of the 737-MB coordinate array only the selected atoms' rows go up
+    (csrc/host_pack.h: 700 and 330 of 30 000 atoms)."""
+    from moleculekit_amd import distance_utils as du
+    ch, bh = coords.cpu().numpy(), box.cpu().numpy()
+    out = {}
+    for name, a, b in (("200 x 500", s1, s2), ("300 x 30", s2[:300].copy(), s1[:30].copy())):
+        res = np.empty((F, len(a) * len(b)), np.float32)
+        du.dist_trajectory(ch, bh, a, b, chains_h, False, True, res)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            du.dist_trajectory(ch, bh, a, b, chains_h, False, True, res)
+        dt = (time.perf_counter() - t0) / 2
+        out[name] = {"ms_per_call": round(dt * 1e3, 2), "Mdist_per_s": round(F * len(a) * len(b) / dt / 1e6, 1),
+                     "coords_array_MB": round(ch.nbytes / 1e6, 1),
+                     "bytes_over_pcie_MB": round((len(np.union1d(a, b)) * 3 * F * 4 + res.nbytes) / 1e6, 1)}
+    out["what"] = ("host numpy arrays in and out (pageable memory), periodic by chain; only the selected atoms' rows of the trajectory "
+                   "are uploaded (host_pack.h)")
+    return out
 
 
 def bench_reductions(args, ctx, dev, busy, check, only_periodic=False):
