@@ -106,8 +106,10 @@ int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_ba
  * bits; for tests (every kernel over the same shapes) and same-box A-B timing. */
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask);
 /* Which kernel the "closest"/"closest" group reductions take (default 0: k_dist_reduction_closest with 4 or 8 first-group atoms in
- * registers, chosen from the mean size of the first groups; 4 / 8: that many (+ 100: in blocks of four waves instead of eight);
- * -1: the generic kernel the centre-of-mass modes use).  Every choice produces the same bits; for tests and same-box A-B timing. */
+ * registers, chosen from the mean size of the first groups -- and, for calls of at most 16 frames (8 when not periodic) in any reduction mode,
+ * k_dist_reduction_few, whose lanes run along the second groups instead of the frames; 4 / 8: that many (+ 100: in blocks of four
+ * waves instead of eight); -1: the generic kernel the centre-of-mass modes use; -2: the few-frame kernel at any number of frames).
+ * Every choice produces the same bits; for tests and same-box A-B timing. */
 int mkamd_ctx_set_reduction_block(mkamd_ctx* ctx, int block);
 /* Names of the kernels the last dist_trajectory call on this context launched, as a profiler prints them (e.g.
  * "mkamd::k_sel_to_frames + mkamd::k_dist_rows<true, 4, true>"; empty before the first call): what bench.py reports as

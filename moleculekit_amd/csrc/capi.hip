@@ -682,8 +682,8 @@ try {
 int mkamd_ctx_set_reduction_block(mkamd_ctx* ctx, int block)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (block != 0 && block != 4 && block != 8 && block != -1 && block != 104 && block != 108)
-        return fail(MKAMD_EINVAL, "reduction block: 0 (choose), 4, 8 (+ 100: blocks of four waves), or -1 (the generic kernel)");
+    if (block != 0 && block != 4 && block != 8 && block != -1 && block != -2 && block != 104 && block != 108)
+        return fail(MKAMD_EINVAL, "reduction block: 0 (choose), 4, 8 (+ 100: blocks of four waves), -1 (the generic kernel) or -2 (the few-frame kernel)");
     ctx->reduction_block = block;
     return MKAMD_OK;
 } MK_API_CATCH
@@ -1553,7 +1553,8 @@ try {
     st = run_dist_reduction(*ctx, (const float*)dc, n_up, F, (const float*)db, (const int*)a1, (const long long*)o1, ng1, g1_off[ng1], (const int*)a2,
                             (const long long*)o2, ng2, (const unsigned*)c1, (const unsigned*)c2, selfdist, pairs, pbc,
                             (const float*)dm, reduction1, reduction2, (float*)dout, err,
-                            ctx->reduction_block ? ctx->reduction_block : reduction_block_for((const long long*)g1_off, ng1));
+                            ctx->reduction_block ? ctx->reduction_block : reduction_block_for((const long long*)g1_off, ng1),
+                            ctx->reduction_block == -2 ? 1 : ctx->reduction_block ? -1 : 0);
     if (st) return err.empty() ? st : fail(st, err);
     prefault_big_result(results, (size_t)F * P * 4);
     HIP_TRY(hipMemcpyAsync(results, dout, (size_t)F * P * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1603,7 +1604,8 @@ try {
     static_assert(sizeof(long long) == sizeof(int64_t), "group offsets are int64");
     st = run_dist_reduction(*ctx, d_coords, N, F, d_box, (const int*)d_g1_atoms, (const long long*)d_g1_off, ng1, n_g1_atoms,
                             (const int*)d_g2_atoms, (const long long*)d_g2_off, ng2, d_chains1, d_chains2, selfdist, pairs, pbc, d_masses,
-                            reduction1, reduction2, d_results, err, ctx->reduction_block);
+                            reduction1, reduction2, d_results, err, ctx->reduction_block,
+                            ctx->reduction_block == -2 ? 1 : ctx->reduction_block ? -1 : 0);
     if (st) return err.empty() ? st : fail(st, err);
     return MKAMD_OK;
 } MK_API_CATCH

@@ -1281,6 +1281,112 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
     store_tile_rows(tile, f0, p0, F, P, P, out);
 }
 
+// dist_trajectory_reduction of FEW frames (distance_utils.pyx:211-281; round 6): the residue-contact map of ONE structure, or of
+// a handful of frames.  The kernels above and below run their lanes along frames -- one frame is one lane in 64, and a call of
+// 1 to 64 frames costs what 64 frames cost (200 groups of 15 atoms: 0.14 ms whatever F <= 64 is).  Here the lanes run along the
+// SECOND groups: a block is (first group a, 256 consecutive second groups, frame f).
+//  * The atoms of group a (frame f) are staged in LDS once per block, DRF_CAP at a time (larger groups take several passes), and
+//    read back as broadcasts (every lane the same address): nothing about the first group is loaded per atom pair.
+//  * A lane walks the atoms of ITS second group (per-lane trip counts; the index of the atom after next and the coordinates of
+//    the next one are loaded while this one's pairs are computed) and takes every pair through dist2_min_image_f32 -- the
+//    per-pair exactness test, the reference's roundings; whether the group pair wraps is per lane (pbc and different chains).
+//  * The reference's update `if dist2 < mindist or mindist < 0` is kept verbatim.  Its result depends on the order of the pairs
+//    only through WHICH pair is first (a NaN there stays; afterwards it is a minimum that ignores NaN), and (first atom of a,
+//    first atom of b) is the first pair of this walk (second atoms outer, first atoms inner) as it is of the reference's.
+//  * No pair table: the result index is computed (the reference's order; selfdist rows are the b > a part), lanes are
+//    consecutive results of one frame's row: coalesced stores.
+// The centre-of-mass modes come through the same kernel like they do through k_dist_reduction (c1 / c2 are then the COM arrays,
+// a group is the one pseudo-atom of its own index).  The pairs mode (a result per group, not per group pair) has no second
+// axis to put lanes on and stays with the kernels whose lanes are frames.
+constexpr int DRF_THREADS = 256;
+constexpr int DRF_CAP = 256;                         // first-group atoms staged per pass
+constexpr int DRF_MAX_FRAMES = 16;                   // periodic calls of up to this many frames take this kernel, open ones of up to half as many
+                                                     // (measured: profiles/r6_reduction_few_probe.txt)
+
+MK_KERNEL(DRF_THREADS) void k_dist_reduction_few(const float* __restrict__ c1, const float* __restrict__ c2, long long F,
+                                                 const float* __restrict__ box,
+                                                 const int* __restrict__ g1_atoms, const long long* __restrict__ g1_off, long long ng1,
+                                                 const int* __restrict__ g2_atoms, const long long* __restrict__ g2_off, long long ng2,
+                                                 int com1, int com2, const unsigned* __restrict__ chains1,
+                                                 const unsigned* __restrict__ chains2, int selfdist, int pbc, long long P,
+                                                 float* __restrict__ out)
+{
+    __shared__ float4 s_at[DRF_CAP];                                 // {x, y, z, -}: one 16-byte LDS read per atom pair
+    const long long b_lo = (long long)blockIdx.x * DRF_THREADS, b = b_lo + threadIdx.x;
+    for (long long f = blockIdx.z; f < F; f += gridDim.z) {          // (grid strides: block-uniform trip counts, the barriers stay uniform)
+        const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
+        const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
+        for (long long a = blockIdx.y; a < ng1; a += gridDim.y) {
+            if (selfdist && b_lo + DRF_THREADS - 1 <= a) continue;   // block-uniform: no second group of this block lies behind a
+            const bool live = b < ng2 && (!selfdist || b > a);
+            const long long i0 = com1 ? a : g1_off[a], i1 = com1 ? a + 1 : g1_off[a + 1];
+            long long j0 = 0, j1 = 0;
+            bool w = false;
+            if (live) {
+                j0 = com2 ? b : g2_off[b]; j1 = com2 ? b + 1 : g2_off[b + 1];
+                w = pbc && chains1[a] != chains2[b];
+            }
+            float mindist = -1.f;
+            for (long long ib = i0; ib < i1 || ib == i0; ib += DRF_CAP) {        // (an empty group: one pass over nothing, no barrier skipped)
+                const int n = (int)(i1 - ib < DRF_CAP ? i1 - ib : DRF_CAP);
+                mk_block_sync();                                     // the previous pass (or first group) has been read
+                for (int k = (int)threadIdx.x; k < n; k += DRF_THREADS) {
+                    const size_t at1 = com1 ? (size_t)(ib + k) : (size_t)g1_atoms[ib + k];
+                    s_at[k] = make_float4(c1[(at1 * 3 + 0) * (size_t)F + (size_t)f], c1[(at1 * 3 + 1) * (size_t)F + (size_t)f],
+                                          c1[(at1 * 3 + 2) * (size_t)F + (size_t)f], 0.f);
+                }
+                mk_block_sync();
+                auto atom2 = [&](long long j) { return com2 ? (size_t)j : (size_t)g2_atoms[j]; };
+                size_t at_next = j0 < j1 ? atom2(j0) : 0, at_after = j0 + 1 < j1 ? atom2(j0 + 1) : 0;
+                float nx = 0.f, ny = 0.f, nz = 0.f;
+                if (j0 < j1) {
+                    nx = c2[(at_next * 3 + 0) * (size_t)F + (size_t)f];
+                    ny = c2[(at_next * 3 + 1) * (size_t)F + (size_t)f];
+                    nz = c2[(at_next * 3 + 2) * (size_t)F + (size_t)f];
+                }
+                for (long long j = j0; j < j1; ++j) {
+                    const float x2 = nx, y2 = ny, z2 = nz;
+                    if (j + 1 < j1) {
+                        at_next = at_after;
+                        if (j + 2 < j1) at_after = atom2(j + 2);
+                        nx = c2[(at_next * 3 + 0) * (size_t)F + (size_t)f];
+                        ny = c2[(at_next * 3 + 1) * (size_t)F + (size_t)f];
+                        nz = c2[(at_next * 3 + 2) * (size_t)F + (size_t)f];
+                    }
+                    int k = 0;
+                    for (; k + 4 <= n; k += 4) {                     // four reads in flight (a SIMD may hold this wave alone)
+                        const float4 A0 = s_at[k], A1 = s_at[k + 1], A2 = s_at[k + 2], A3 = s_at[k + 3];
+                        const float d0 = dist2_min_image_f32(A0.x, A0.y, A0.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
+                        const float d1 = dist2_min_image_f32(A1.x, A1.y, A1.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
+                        const float d2 = dist2_min_image_f32(A2.x, A2.y, A2.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
+                        const float d3 = dist2_min_image_f32(A3.x, A3.y, A3.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
+                        if (d0 < mindist || mindist < 0.f) mindist = d0;
+                        if (d1 < mindist || mindist < 0.f) mindist = d1;
+                        if (d2 < mindist || mindist < 0.f) mindist = d2;
+                        if (d3 < mindist || mindist < 0.f) mindist = d3;
+                    }
+                    for (; k < n; ++k) {
+                        const float4 A = s_at[k];
+                        const float d2 = dist2_min_image_f32(A.x, A.y, A.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
+                        if (d2 < mindist || mindist < 0.f) mindist = d2;
+                    }
+                }
+                if (i1 <= i0) break;
+            }
+            if (live) {
+                long long idx;
+                if (selfdist) {
+                    const long long full = a < ng2 ? a : ng2;
+                    idx = full * (ng2 - 1) - full * (full - 1) / 2 + (b - a - 1);
+                } else {
+                    idx = a * ng2 + b;
+                }
+                out[(size_t)f * (size_t)P + (size_t)idx] = mk_fsqrt_rn(mindist);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dist_trajectory_reduction[_pairs] with the "closest" reduction on BOTH sides (distance_utils.pyx:211-281, :286-350 with
 // reduction1 = reduction2 = 0): the residue-contact maps of MetricDistance -- for every (frame, group pair) the smallest d^2

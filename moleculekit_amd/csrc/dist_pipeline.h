@@ -156,11 +156,13 @@ inline int reduction_block_for(const long long* g1_off, long long ng1)
 // `n_atoms` (rows of coords) and `n_g1_atoms` (length of g1_atoms) are what the HOST knows about arrays that live on the device:
 // they choose the kernel variant (32-bit row offsets; how many first-group atoms a wave keeps in registers), never the result.
 // `closest_block`: 0 = choose, 4 / 8 = that many first-group atoms in registers (tests, A-B timing; + 100: blocks of four waves), -1 = the generic kernel.
+// `few_frames`: 0 = calls of up to DRF_MAX_FRAMES frames (half as many when not periodic) take k_dist_reduction_few, 1 = every call does (but the pairs mode), -1 = none.
 template <class BE>
 int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long F, const float* box, const int* g1_atoms,
                        const long long* g1_off, long long ng1, long long n_g1_atoms, const int* g2_atoms, const long long* g2_off,
                        long long ng2, const unsigned* chains1, const unsigned* chains2, int selfdist, int pairs, int pbc,
-                       const float* masses, int reduction1, int reduction2, float* out, std::string& err, int closest_block = 0)
+                       const float* masses, int reduction1, int reduction2, float* out, std::string& err, int closest_block = 0,
+                       int few_frames = 0)
 {
     if (F < 0 || ng1 < 0 || ng2 < 0) { err = "negative size"; return ST_EINVAL; }
     if (pairs && ng1 != ng2) { err = "pairs mode needs the same number of groups on both sides"; return ST_EINVAL; }
@@ -170,11 +172,15 @@ int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     void *ga = nullptr, *gb = nullptr, *wr = nullptr, *com1 = nullptr, *com2 = nullptr;
     int st;
-    if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &ga, 0))) return st;
-    if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &gb, 0))) return st;
-    if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
-    if ((st = be.launch(k_build_group_pairs, dim3((unsigned)ceil_div(ng2, 256), (unsigned)std::min<long long>(ng1, 65535)), dim3(256), ng1, ng2, chains1,
-                        chains2, selfdist, pairs, pbc, (unsigned*)ga, (unsigned*)gb, (unsigned*)wr))) return st;
+    // few frames (one structure's residue-contact map): lanes along the second groups, no pair table (k_dist_reduction_few)
+    const bool few = !pairs && ceil_div(ng2, DRF_THREADS) <= 0x7fffffffLL && (few_frames > 0 || (few_frames == 0 && F <= (pbc ? DRF_MAX_FRAMES : DRF_MAX_FRAMES / 2)));
+    if (!few) {
+        if ((st = be.ensure(WS_D_PA, (size_t)P * 4, &ga, 0))) return st;
+        if ((st = be.ensure(WS_D_PB, (size_t)P * 4, &gb, 0))) return st;
+        if ((st = be.ensure(WS_D_WRAP, (size_t)P * 4, &wr, 0))) return st;
+        if ((st = be.launch(k_build_group_pairs, dim3((unsigned)ceil_div(ng2, 256), (unsigned)std::min<long long>(ng1, 65535)), dim3(256), ng1, ng2, chains1,
+                            chains2, selfdist, pairs, pbc, (unsigned*)ga, (unsigned*)gb, (unsigned*)wr))) return st;
+    }
     const float *c1 = coords, *c2 = coords;
     if (reduction1 == 1) {
         if ((st = be.ensure(WS_D_COM1, (size_t)ng1 * 3 * F * 4, &com1, 0))) return st;
@@ -188,6 +194,10 @@ int run_dist_reduction(BE& be, const float* coords, long long n_atoms, long long
                             ng2, masses, (float*)com2))) return st;
         c2 = (const float*)com2;
     }
+    if (few)
+        return be.launch(k_dist_reduction_few, dim3((unsigned)ceil_div(ng2, DRF_THREADS), (unsigned)std::min<long long>(ng1, 65535),
+                                                    (unsigned)std::min<long long>(F, 65535)), dim3(DRF_THREADS), c1, c2, F, box, g1_atoms, g1_off,
+                         ng1, g2_atoms, g2_off, ng2, reduction1, reduction2, chains1, chains2, selfdist, pbc, P, out);
     if (ceil_div(P, DT) * ceil_div(F, DT) > 0x7ffffff0LL) { err = "too many tiles (groups pairs x frames / 4096 >= 2^31)"; return ST_EINVAL; }
     const dim3 grid((unsigned)(((ceil_div(P, DT) * ceil_div(F, DT) + 7) / 8) * 8));
     if (reduction1 == 0 && reduction2 == 0 && closest_block >= 0) {

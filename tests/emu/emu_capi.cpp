@@ -253,11 +253,11 @@ int emu_dist_trajectory(const float* coords, long long F, const float* box, cons
 int emu_dist_reduction(const float* coords, long long F, const float* box, const int* g1a, const long long* g1o, long long ng1,
                        const int* g2a, const long long* g2o, long long ng2, const unsigned* ch1, const unsigned* ch2,
                        int selfdist, int pairs, int pbc, const float* masses, int r1, int r2, float* out, long long n_atoms,
-                       int closest_block /* 0 choose, 4 / 8, -1 the generic kernel */)
+                       int closest_block /* 0 choose, 4 / 8, -1 the generic kernel, -2 the few-frame kernel (as mkamd_ctx_set_reduction_block) */)
 {
     EmuBackend be;
     return run_dist_reduction(be, coords, n_atoms, F, box, g1a, g1o, ng1, g1o[ng1], g2a, g2o, ng2, ch1, ch2, selfdist, pairs, pbc, masses, r1, r2, out,
-                              g_err, closest_block);
+                              g_err, closest_block, closest_block == -2 ? 1 : closest_block ? -1 : 0);
 }
 
 // contacts_trajectory: frame_offsets [F+1]; pairs_out (capacity 2*cap uint32) gets the (a, b) pairs; returns the count in *n_out

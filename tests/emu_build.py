@@ -178,7 +178,8 @@ def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=Fals
 
 
 def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masses, r1, r2, pairs=False, block=0, n_atoms=None):
-    """block: 0 = the library's choice, 4 / 8 = first-group atoms in registers (closest / closest only), -1 = the generic kernel;
+    """block: 0 = the library's choice, 4 / 8 = first-group atoms in registers (closest / closest only), -1 = the generic kernel,
+    -2 = the few-frame kernel (lanes along the second groups) at any number of frames;
     n_atoms: what the host believes the number of coordinate rows is (decides 32-bit row offsets: a huge value forces the 64-bit form)."""
     coords = np.ascontiguousarray(coords, np.float32); box = np.ascontiguousarray(box, np.float32)
     a1, o1 = _csr(groups1); a2, o2 = _csr(groups2)

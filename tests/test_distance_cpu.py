@@ -357,7 +357,7 @@ def test_closest_reduction_kernel_every_block_size_is_the_oracle(selfdist, pairs
     ch2 = ch1 if selfdist else rng.integers(0, 3, len(g2)).astype(np.uint32)
     for pbc in (True, False):
         want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs)
-        for block in (4, 8, -1, 0, 104, 108):       # (+ 100: blocks of four waves)
+        for block in (4, 8, -1, 0, 104, 108, -2):   # (+ 100: blocks of four waves; -2: the few-frame kernel, lanes along second groups)
             got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, selfdist, pbc, masses, 0, 0, pairs=pairs, block=block)
             assert np.array_equal(got, want), (pbc, block)
     # 64-bit row addressing (what a trajectory of more than 4 GiB takes): same bits
@@ -409,7 +409,7 @@ def test_closest_reduction_kernel_redoes_stretches_near_half_a_box_exactly():
         dd = np.float32(coords[0, ax, f] - coords[1, ax, f])
         fast.append(dd == d)
     assert sum(fast) > F // 2                                  # (the subtraction reproduces the trap's separation in most frames)
-    for block in (4, 8):
+    for block in (4, 8, -2):
         assert np.array_equal(E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, True, masses, 0, 0, block=block), want)
 
 
@@ -432,9 +432,38 @@ def test_closest_reduction_kernel_nan_and_infinite_semantics():
         for pbc in (True, False):
             want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0)
             assert np.isnan(want).any() and np.isfinite(want).any()
-            for block in (4, 8, -1):
+            for block in (4, 8, -1, -2):
                 got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0, block=block)
                 assert np.array_equal(got, want, equal_nan=True), (pbc, block)
+
+
+def test_reductions_of_few_frames_take_lanes_along_the_second_groups():
+    """k_dist_reduction_few (round 6): calls of up to 8 frames (16 when periodic) -- one structure's residue-contact map -- run their
+    lanes along the second groups.  The library's own choice (block 0) at 1, 3 and 8 frames: more second groups than one block holds (several
+    blocks along a row, selfdist rows that skip the blocks in front of their diagonal), a first group larger than one LDS pass
+    (300 atoms > 256), single-atom groups, every reduction mode (closest / centre of mass on either side), periodic with mixed
+    chains and open; bit for bit the oracle, and the kernels whose lanes are frames (block 8 / -1) on the same call."""
+    rng = np.random.default_rng(811)
+    N = 700
+    masses = rng.uniform(1, 32, size=N).astype(np.float32)
+    big = rng.choice(N, 300, replace=False).tolist()
+    for F in (1, 3, 8):
+        coords = rng.uniform(-20, 20, size=(N, 3, F)).astype(np.float32)
+        box = rng.uniform(22, 31, size=(3, F)).astype(np.float32)
+        g1 = [big] + _ragged_groups(rng, N, 4, 1, 9)
+        g2 = _ragged_groups(rng, N, 290, 1, 4)
+        ch1 = rng.integers(0, 3, len(g1)).astype(np.uint32); ch2 = rng.integers(0, 3, len(g2)).astype(np.uint32)
+        for r1, r2 in ((0, 0), (1, 0), (0, 1), (1, 1)) if F == 3 else ((0, 0),):
+            for pbc in (True, False):
+                want = oracle.dist_trajectory_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, r1, r2)
+                assert np.array_equal(E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, r1, r2), want), (F, r1, r2, pbc)
+        gs = _ragged_groups(rng, N, 270, 1, 3)
+        chs = rng.integers(0, 4, len(gs)).astype(np.uint32)
+        want = oracle.dist_trajectory_reduction(coords, box, gs, gs, chs, chs, True, True, masses, 0, 0)
+        assert np.array_equal(E.dist_reduction(coords, box, gs, gs, chs, chs, True, True, masses, 0, 0), want), F
+        if F == 1:
+            assert np.array_equal(E.dist_reduction(coords, box, gs, gs, chs, chs, True, True, masses, 0, 0, block=8), want)
+            assert np.array_equal(E.dist_reduction(coords, box, gs, gs, chs, chs, True, True, masses, 0, 0, block=-1), want)
 
 
 @pytest.mark.parametrize("D", [2, 3])

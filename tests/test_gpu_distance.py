@@ -782,3 +782,51 @@ def test_host_calls_that_pack_the_selected_atoms_equal_the_unpacked_calls():
             got = np.full_like(exp, -1.0)
             du.dist_trajectory_reduction(c, b, g1, g2, c1, c2, False, pbc, m, r1, r2, got)
             assert np.array_equal(got, exp), (r1, r2, pbc)
+
+
+def test_reductions_of_few_frames_take_lanes_along_the_second_groups():
+    """k_dist_reduction_few (round 6): calls of at most 8 frames (one structure's residue-contact map) run their lanes along the
+    second groups (16 when periodic).  The library's choice at 1 ... 17 frames, against the oracle bit for bit: 300 residue-like groups (several
+    blocks along a row; selfdist rows that skip the blocks in front of the diagonal), a first group larger than an LDS pass,
+    every reduction mode, periodic with mixed chains and open; the kernels whose lanes are frames beside them; the
+    kernel forced onto 70 frames; NaN / zero-box semantics (`dist2 < mindist or mindist < 0`: only the first pair's NaN stays)."""
+    from moleculekit_amd import distance_utils as du, _lib
+    rng = np.random.default_rng(53)
+    N = 4000
+    m = rng.uniform(1, 32, size=N).astype(np.float32)
+    perm = rng.permutation(N)
+    res = [sorted(map(int, perm[i * 11:i * 11 + int(rng.integers(4, 12))])) for i in range(300)]
+    chs = (np.arange(300) // 100).astype(np.uint32)
+    big = [list(map(int, rng.choice(N, 300, replace=False)))] + res[:3]
+    chb = np.array([0, 1, 2, 0], np.uint32)
+    for F in (1, 5, 8, 9, 16, 17):
+        c = rng.uniform(0, 60.0, size=(N, 3, F)).astype(np.float32)
+        b = rng.uniform(40, 60, size=(3, F)).astype(np.float32)
+        for pbc in (True, False):
+            exp = oracle.dist_trajectory_reduction(c, b, res, res, chs, chs, True, pbc, m, 0, 0)
+            got = np.full_like(exp, -1.0)
+            du.dist_trajectory_reduction(c, b, res, res, chs, chs, True, pbc, m, 0, 0, got)
+            assert np.array_equal(got, exp), (F, pbc)
+        for r1, r2 in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            exp = oracle.dist_trajectory_reduction(c, b, big, res, chb, chs, False, True, m, r1, r2)
+            got = np.full_like(exp, -1.0)
+            du.dist_trajectory_reduction(c, b, big, res, chb, chs, False, True, m, r1, r2, got)
+            assert np.array_equal(got, exp), (F, r1, r2)
+    ctx = _lib.default_context(0)
+    F = 70
+    c = rng.uniform(0, 60.0, size=(N, 3, F)).astype(np.float32)
+    b = rng.uniform(40, 60, size=(3, F)).astype(np.float32)
+    b[:, 7] = 0.0
+    c[res[0][0], 1, ::3] = np.nan                          # a first atom of a first group: NaN rows
+    c[res[5][-1], 2, ::4] = np.nan                         # a later atom: ignored by the minimum
+    with np.errstate(all="ignore"):
+        exp = oracle.dist_trajectory_reduction(c, b, res[:40], res, chs[:40], chs, False, True, m, 0, 0)
+    assert np.isnan(exp).any() and np.isfinite(exp).any()
+    try:
+        for block in (-2, 0):
+            ctx.set_reduction_block(block)
+            got = np.full_like(exp, -1.0)
+            du.dist_trajectory_reduction(c, b, res[:40], res, chs[:40], chs, False, True, m, 0, 0, got)
+            assert np.array_equal(got, exp, equal_nan=True), block
+    finally:
+        ctx.set_reduction_block(0)

@@ -287,10 +287,49 @@ def bench_reductions(args, ctx, dev, busy, check, only_periodic=False):
                              "block8_four_waves": round(leg(True, 0, 0, block=108), 4), "generic_kernel": round(leg(True, 0, 0, block=-1), 4)}
     res["com_com_periodic_ms"] = round(leg(True, 1, 1), 4)
     res["pairs_closest_periodic_ms"] = round(leg(True, 0, 0, pairs=True), 4)
+    res["one_frame"] = bench_reduction_one_frame(args, ctx, dev, busy, check)
     pmc = reduction_pmc()
     if pmc:
         res["periodic"]["valu"].update(pmc)
     return res
+
+
+def bench_reduction_one_frame(args, ctx, dev, busy, check):
+    """The residue-contact map of ONE structure (200 residues of 15 atoms, all 19 900 pairs, 4.5 M atom pairs; periodic): calls of few
+    frames take k_dist_reduction_few (lanes along the second groups) -- timed beside the kernel whose lanes are frames (one lane in 64
+    at work), the whole result checked against the oracle bit for bit."""
+    import torch
+    G, A = 200, 15
+    out = {}
+    for F in (1, 8):
+        coords, box, atoms, offs, chains, masses = reduction_workload(G, A, F)
+        N = coords.shape[0]
+        t = lambda a: torch.as_tensor(a, device=dev)
+        d_c, d_b, d_a, d_o, d_m, d_ch = t(coords), t(box), t(atoms), t(offs), t(masses), t(chains.astype(np.int32))
+        P = G * (G - 1) // 2
+        o = torch.empty((F, P), device=dev, dtype=torch.float32)
+        call = lambda: ctx.dist_reduction_dev(d_c, N, F, d_b, d_a, d_o, G, N, d_a, d_o, G, d_ch, d_ch, True, False, True, d_m, 0, 0, o)
+        entry = {}
+        for name, block in (("us_per_call", 0), ("frame_lane_kernel_us", 8)):
+            ctx.set_reduction_block(block)
+            busy(call, 0.15)
+            if check and block == 0:
+                from oracle import oracle
+                groups = [atoms[offs[g]:offs[g + 1]].tolist() for g in range(G)]
+                ref = oracle.dist_trajectory_reduction(coords, box, groups, groups, chains, chains, True, True, masses, 0, 0)
+                if not np.array_equal(o.cpu().numpy(), ref, equal_nan=True):
+                    raise SystemExit(f"dist_trajectory_reduction of {F} frame(s) on the GPU is not bit-exact with the oracle")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                call()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            entry[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 1)
+        ctx.set_reduction_block(0)
+        out[f"{F}_frame" + ("s" if F > 1 else "")] = entry
+    out["kernel"] = "mkamd::k_dist_reduction_few"
+    return out
 
 
 def bench_cdist_pdist(args, ctx, dev, busy, check):
