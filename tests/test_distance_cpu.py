@@ -317,6 +317,22 @@ class _OracleFns:
         res[...] = oracle.dist_trajectory_reduction(coords, box, g1, g2, c1, c2, selfdist, pbc, masses, r1, r2)
 
 
+    @staticmethod
+    def dist_trajectory_reduction_pairs(coords, box, g1, g2, c1, c2, pbc, masses, r1, r2, res):
+        res[...] = oracle.dist_trajectory_reduction(coords, box, g1, g2, c1, c2, False, pbc, masses, r1, r2, pairs=True)
+
+
+def test_oracle_on_the_known_answers_of_the_references_metricdistance_tests():
+    """tests/metricdistance_known.py: the analytic molecules, the four 3PTB numbers (8.978174, 3.8286476, 2.8153415, the distance of the
+    centres of mass), pairs mode, the three meanings of `periodic` on the trajectory and `truncate` -- every call the reference's
+    projections made, replayed through the oracle: bit for bit the compiled reference, and the reference tests' own assertions."""
+    from tests import metricdistance_known as K, metricdistance_real as M
+    g = K.load()
+    traj = M.read_trajectory(M.load())
+    with_answer = sum(K.verify(K.replay(_OracleFns, g, key, traj), g, key) for key in map(str, g["names"]))
+    assert len(g["names"]) == 22 and with_answer == 17
+
+
 def test_oracle_on_the_reference_held_metricdistance_projections():
     """Host XTC reader -> oracle == the compiled reference bit for bit, and within the reference's own 1e-3 of the arrays the
     reference holds (they were written by an older build: 7.6e-6 / 3.8e-6 away from today's reference too)."""

@@ -360,6 +360,18 @@ def test_the_short_square_root_is_the_correctly_rounded_one_for_every_float():
 # the reference's OWN answers on its real trajectory (tests/metricdistance_real.py): own XTC reader ->
 # own kernels, the calls MetricDistance makes (arguments as the reference's drivers built them)
 # ------------------------------------------------------------------------------------------------
+def test_known_answers_of_the_references_metricdistance_tests_on_the_gpu():
+    """tests/metricdistance_known.py (test_metricdistance.py:99-181, :213-229, :329-352, :355-464, :467-493): every call those tests'
+    projections make into distance_utils, through this package's functions: bit for bit the compiled reference, and the numbers the
+    reference's tests assert (analytic molecules, 3PTB's 8.978174 / 3.8286476 / 2.8153415, pairs mode, periodic modes, truncate)."""
+    from moleculekit_amd import distance_utils as du
+    from tests import metricdistance_known as K, metricdistance_real as M
+    g = K.load()
+    traj = M.read_trajectory(M.load())
+    with_answer = sum(K.verify(K.replay(du, g, key, traj), g, key) for key in map(str, g["names"]))
+    assert len(g["names"]) == 22 and with_answer == 17
+
+
 def test_reference_held_metricdistance_projections_on_the_gpu():
     from moleculekit_amd import distance_utils as du
     from tests import metricdistance_real as M
