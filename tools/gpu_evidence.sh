@@ -60,6 +60,7 @@ rpmc sq2 $SQ2
 # the device XTC decoder: kernels alone per chunk size
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
 (timeout 600 python tools/reduction_probe.py > gpurun_out/reduction_probe.txt 2>&1)
+(timeout 600 python tools/reduction_few_probe.py 2>&1 | grep -v amdgpu > gpurun_out/reduction_few_probe.txt)
 grep -a "cutoff shell" gpurun_out/pytest_gpu.log | sort -u; tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
 python tools/collect_profiles.py $TAG > /dev/null      # the PMC summaries of THIS build first: the bench lines below then carry roofline.traffic
 # the bench lines proper (the default one exactly as the driver runs it), after the counters so that they can quote them
