@@ -674,7 +674,7 @@ try {
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (avoid_mask < 0 || avoid_mask > 31) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores), 16 (the row kernel wherever it applies)");
+    if (avoid_mask < 0 || avoid_mask > 63) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores), 16 (the row kernel wherever it applies), 32 (host calls upload the whole coordinate array)");
     ctx->dist_avoid = avoid_mask;
     return MKAMD_OK;
 } MK_API_CATCH
@@ -1432,7 +1432,7 @@ try {
     // only the selected atoms' rows go up when they are few (host_pack.h); the selections and chain ids in the packed numbering
     mkamd::PackedAtoms pk;
     pk.collect(sel1, n1); pk.collect(sel2, n2);
-    if (pk.finish(coords, N, F, ctx->packed_coords)) {
+    if (!(ctx->dist_avoid & 32) && pk.finish(coords, N, F, ctx->packed_coords)) {
         const std::vector<uint32_t> p1 = pk.remap(sel1, n1), p2 = pk.remap(sel2, n2), pc = pk.gather(chains);
         if ((st = upload(ctx, WS_H_COORDS, ctx->packed_coords.data(), (size_t)pk.size() * 3 * F * 4, &dc))) return st;
         if ((st = upload(ctx, WS_D_SEL1, p1.data(), (size_t)n1 * 4, &d1))) return st;
@@ -1477,7 +1477,7 @@ try {
     void *dc, *db, *d1, *d2, *dch;
     mkamd::PackedAtoms pk;                                           // (host_pack.h: only the selected atoms' rows go up when they are few)
     pk.collect(sel1, n1); pk.collect(sel2, n2);
-    if (pk.finish(coords, N, F, ctx->packed_coords)) {
+    if (!(ctx->dist_avoid & 32) && pk.finish(coords, N, F, ctx->packed_coords)) {
         const std::vector<uint32_t> p1 = pk.remap(sel1, n1), p2 = pk.remap(sel2, n2), pc = pk.gather(chains);
         if ((st = upload(ctx, WS_H_COORDS, ctx->packed_coords.data(), (size_t)pk.size() * 3 * F * 4, &dc))) return st;
         if ((st = upload(ctx, WS_D_SEL1, p1.data(), (size_t)n1 * 4, &d1))) return st;
@@ -1525,7 +1525,7 @@ try {
     int64_t n_up = N;                                                // atoms of the array that goes up
     mkamd::PackedAtoms pk;                                           // (host_pack.h: only the groups' atoms when they are few)
     pk.collect(g1_atoms, g1_off[ng1]); pk.collect(g2_atoms, g2_off[ng2]);
-    if (pk.finish(coords, N, F, ctx->packed_coords)) {
+    if (!(ctx->dist_avoid & 32) && pk.finish(coords, N, F, ctx->packed_coords)) {
         const std::vector<int32_t> p1 = pk.remap(g1_atoms, g1_off[ng1]), p2 = pk.remap(g2_atoms, g2_off[ng2]);
         n_up = pk.size();
         if ((st = upload(ctx, WS_H_COORDS, ctx->packed_coords.data(), (size_t)n_up * 3 * F * 4, &dc))) return st;

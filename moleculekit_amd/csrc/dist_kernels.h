@@ -1288,11 +1288,16 @@ MK_KERNEL(DT_THREADS) void k_dist_reduction(const float* __restrict__ c1, const 
 //  * The atoms of group a (frame f) are staged in LDS once per block, DRF_CAP at a time (larger groups take several passes), and
 //    read back as broadcasts (every lane the same address): nothing about the first group is loaded per atom pair.
 //  * A lane walks the atoms of ITS second group (per-lane trip counts; the index of the atom after next and the coordinates of
-//    the next one are loaded while this one's pairs are computed) and takes every pair through dist2_min_image_f32 -- the
-//    per-pair exactness test, the reference's roundings; whether the group pair wraps is per lane (pbc and different chains).
-//  * The reference's update `if dist2 < mindist or mindist < 0` is kept verbatim.  Its result depends on the order of the pairs
-//    only through WHICH pair is first (a NaN there stays; afterwards it is a minimum that ignores NaN), and (first atom of a,
-//    first atom of b) is the first pair of this walk (second atoms outer, first atoms inner) as it is of the reference's.
+//    the next one are loaded while this one's pairs are computed).  The first group's atoms lie in LDS two by two, as the packed
+//    operands of dist2_pk (the arithmetic of k_dist_reduction_closest below: v_pk_add / v_pk_mul, separately rounded, the image
+//    integers behind an ACCUMULATED exactness test): 17 instead of 35 instructions per wrapped pair.  Whether a group pair wraps
+//    is per lane here (pbc and different chains): a wave in which any pair wraps walks the wrapping arithmetic with 1 / box = 0
+//    in the lanes whose pair does not; the risk is accumulated per (lane, second atom), and a row that fails it is redone with
+//    dist2_min_image_f32 and its correctly rounded divisions.  (First version of this kernel: every pair through
+//    dist2_min_image_f32 -- 32 us per 200-residue map of one frame, 101 us for 16 frames; profiles/r6_reduction_few_probe.txt.)
+//  * The reference's update `if dist2 < mindist or mindist < 0` depends on the order of the pairs only through WHICH pair is first
+//    (a NaN there stays; afterwards it is a minimum that ignores NaN): v_min3_f32 over all pairs plus the NaN-ness of (first atom
+//    of a, first atom of b) -- component 0 of the first packed pair of the lane's first second atom, as in the kernel below.
 //  * No pair table: the result index is computed (the reference's order; selfdist rows are the b > a part), lanes are
 //    consecutive results of one frame's row: coalesced stores.
 // The centre-of-mass modes come through the same kernel like they do through k_dist_reduction (c1 / c2 are then the COM arrays,
@@ -1311,11 +1316,14 @@ MK_KERNEL(DRF_THREADS) void k_dist_reduction_few(const float* __restrict__ c1, c
                                                  const unsigned* __restrict__ chains2, int selfdist, int pbc, long long P,
                                                  float* __restrict__ out)
 {
-    __shared__ float4 s_at[DRF_CAP];                                 // {x, y, z, -}: one 16-byte LDS read per atom pair
+    __shared__ float4 s_xy[DRF_CAP / 2];                             // {x, x', y, y'} of two first-group atoms side by side (packed operands)
+    __shared__ float2 s_z[DRF_CAP / 2];                              // {z, z'}
     const long long b_lo = (long long)blockIdx.x * DRF_THREADS, b = b_lo + threadIdx.x;
     for (long long f = blockIdx.z; f < F; f += gridDim.z) {          // (grid strides: block-uniform trip counts, the barriers stay uniform)
         const float bx = box[0 * F + f], by = box[1 * F + f], bz = box[2 * F + f];
         const float ibx = mk_fdiv_rn(1.f, bx), iby = mk_fdiv_rn(1.f, by), ibz = mk_fdiv_rn(1.f, bz);
+        auto row1 = [&](size_t atom, int ax) { return c1[(atom * 3 + (size_t)ax) * (size_t)F + (size_t)f]; };
+        auto row2 = [&](size_t atom, int ax) { return c2[(atom * 3 + (size_t)ax) * (size_t)F + (size_t)f]; };
         for (long long a = blockIdx.y; a < ng1; a += gridDim.y) {
             if (selfdist && b_lo + DRF_THREADS - 1 <= a) continue;   // block-uniform: no second group of this block lies behind a
             const bool live = b < ng2 && (!selfdist || b > a);
@@ -1326,52 +1334,91 @@ MK_KERNEL(DRF_THREADS) void k_dist_reduction_few(const float* __restrict__ c1, c
                 j0 = com2 ? b : g2_off[b]; j1 = com2 ? b + 1 : g2_off[b + 1];
                 w = pbc && chains1[a] != chains2[b];
             }
-            float mindist = -1.f;
-            for (long long ib = i0; ib < i1 || ib == i0; ib += DRF_CAP) {        // (an empty group: one pass over nothing, no barrier skipped)
-                const int n = (int)(i1 - ib < DRF_CAP ? i1 - ib : DRF_CAP);
+            auto atom1 = [&](long long i) { return com1 ? (size_t)i : (size_t)g1_atoms[i]; };
+            auto atom2 = [&](long long j) { return com2 ? (size_t)j : (size_t)g2_atoms[j]; };
+            float acc = -1.f;                                        // the reference's `mindist = -1` (:252)
+            for (long long ib = i0; ib < i1; ib += DRF_CAP) {        // block-uniform
+                const int n = (int)(i1 - ib < DRF_CAP ? i1 - ib : DRF_CAP), nh = (n + 1) / 2;
                 mk_block_sync();                                     // the previous pass (or first group) has been read
-                for (int k = (int)threadIdx.x; k < n; k += DRF_THREADS) {
-                    const size_t at1 = com1 ? (size_t)(ib + k) : (size_t)g1_atoms[ib + k];
-                    s_at[k] = make_float4(c1[(at1 * 3 + 0) * (size_t)F + (size_t)f], c1[(at1 * 3 + 1) * (size_t)F + (size_t)f],
-                                          c1[(at1 * 3 + 2) * (size_t)F + (size_t)f], 0.f);
+                for (int k = (int)threadIdx.x; k < nh; k += DRF_THREADS) {
+                    const size_t e0 = atom1(ib + 2 * k), e1 = atom1(ib + (2 * k + 1 < n ? 2 * k + 1 : n - 1));   // (padding: the last atom once more)
+                    s_xy[k] = make_float4(row1(e0, 0), row1(e1, 0), row1(e0, 1), row1(e1, 1));
+                    s_z[k] = make_float2(row1(e0, 2), row1(e1, 2));
                 }
                 mk_block_sync();
-                auto atom2 = [&](long long j) { return com2 ? (size_t)j : (size_t)g2_atoms[j]; };
-                size_t at_next = j0 < j1 ? atom2(j0) : 0, at_after = j0 + 1 < j1 ? atom2(j0 + 1) : 0;
-                float nx = 0.f, ny = 0.f, nz = 0.f;
-                if (j0 < j1) {
-                    nx = c2[(at_next * 3 + 0) * (size_t)F + (size_t)f];
-                    ny = c2[(at_next * 3 + 1) * (size_t)F + (size_t)f];
-                    nz = c2[(at_next * 3 + 2) * (size_t)F + (size_t)f];
+                const bool any_wraps = mk_ballot(w) != 0ull;         // wave-uniform (every lane of the wave is here)
+                if (j1 <= j0) continue;                              // (per lane, after the barriers) an empty second group: -1 stays
+                // One walk for the whole wave: if ANY of its group pairs wraps, every lane takes the wrapping arithmetic -- a lane whose
+                // pair does not wrap with a zero in place of 1 / box (quotient 0, image integer 0, shift b * 0 = 0: the separation
+                // unchanged).  (Two walks -- wrapping lanes, then the others -- doubled the loads and the LDS reads of nearly every wave of
+                // a multi-chain call: 59 against 32 us per 200-residue map.)
+                const float lbx = w ? ibx : 0.f, lby = w ? iby : 0.f, lbz = w ? ibz : 0.f;
+                float m = mk_inf(), first = 0.f;
+                auto exact_row = [&](float x2, float y2, float z2, bool is_first, float& mj) {     // one second atom, pair by pair
+                    mj = mk_inf();
+                    for (int k = 0; k < n; ++k) {
+                        const float4 A = s_xy[k >> 1]; const float2 Zp = s_z[k >> 1];
+                        const float d2 = (k & 1) ? dist2_min_image_f32(A.y, A.w, Zp.y, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w)
+                                                 : dist2_min_image_f32(A.x, A.z, Zp.x, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
+                        if (k == 0 && is_first) first = d2;
+                        mj = mk_min_raw(mj, d2);
+                    }
+                };
+                auto sweep = [&](auto wraps_) {
+                    constexpr bool WR = decltype(wraps_)::value;
+                    size_t at_next = atom2(j0), at_after = j0 + 1 < j1 ? atom2(j0 + 1) : 0;
+                    float nx = row2(at_next, 0), ny = row2(at_next, 1), nz = row2(at_next, 2);
+                    for (long long j = j0; j < j1; ++j) {
+                        const float x2 = nx, y2 = ny, z2 = nz;
+                        if (j + 1 < j1) {                            // the next atom's coordinates and the index after it: in flight during this atom's pairs
+                            at_next = at_after;
+                            if (j + 2 < j1) at_after = atom2(j + 2);
+                            nx = row2(at_next, 0); ny = row2(at_next, 1); nz = row2(at_next, 2);
+                        }
+                        float mj = mk_inf(), risk = 0.f;             // this second atom's minimum and its accumulated image-integer risk
+                        int k = 0;
+                        if (j == j0) {                               // component 0 of the first packed pair is the reference's first pair
+                            const float4 A = s_xy[0]; const float2 Zp = s_z[0];
+                            const mk_f2 d2 = dist2_pk<WR>(mk_f2{A.x, A.y}, mk_f2{A.z, A.w}, mk_f2{Zp.x, Zp.y}, x2, y2, z2, bx, by, bz, lbx, lby, lbz, risk);
+                            first = d2[0];
+                            mj = mk_min3_raw(mj, d2[0], d2[1]);
+                            k = 1;
+                        }
+                        for (; k + 2 <= nh; k += 2) {                // two packed pairs (four atom pairs) per step: four LDS reads in flight
+                            const float4 A = s_xy[k], B = s_xy[k + 1]; const float2 Za = s_z[k], Zb = s_z[k + 1];
+                            const mk_f2 d2 = dist2_pk<WR>(mk_f2{A.x, A.y}, mk_f2{A.z, A.w}, mk_f2{Za.x, Za.y}, x2, y2, z2, bx, by, bz, lbx, lby, lbz, risk);
+                            const mk_f2 e2 = dist2_pk<WR>(mk_f2{B.x, B.y}, mk_f2{B.z, B.w}, mk_f2{Zb.x, Zb.y}, x2, y2, z2, bx, by, bz, lbx, lby, lbz, risk);
+                            mj = mk_min3_raw(mj, d2[0], d2[1]);
+                            mj = mk_min3_raw(mj, e2[0], e2[1]);
+                        }
+                        if (k < nh) {
+                            const float4 A = s_xy[k]; const float2 Zp = s_z[k];
+                            const mk_f2 d2 = dist2_pk<WR>(mk_f2{A.x, A.y}, mk_f2{A.z, A.w}, mk_f2{Zp.x, Zp.y}, x2, y2, z2, bx, by, bz, lbx, lby, lbz, risk);
+                            mj = mk_min3_raw(mj, d2[0], d2[1]);
+                        }
+                        if constexpr (WR) {
+                            // an image integer of this atom's pairs may differ from the reference's round(d / b) (a separation within 3e-7 of half
+                            // a box length, an infinite quotient): once more, pair by pair, with the per-pair test and the divisions behind it (rare)
+                            if (!(risk < DRC_RISK)) exact_row(x2, y2, z2, j == j0, mj);
+                        }
+                        m = mk_min_raw(m, mj);
+                    }
+                };
+                if (any_wraps) sweep(DistFlag<true>{}); else sweep(DistFlag<false>{});
+                if (any_wraps && !w && (first != first || !(m < mk_inf()))) {
+                    // a lane that rode along without wrapping and met something that is not a number: 0 * inf is NaN where the reference,
+                    // which does not form the quotient for this pair at all, keeps the infinite separation -- its pairs once more, as they are
+                    m = mk_inf();
+                    for (long long j = j0; j < j1; ++j) {
+                        const size_t c = atom2(j);
+                        float mj;
+                        exact_row(row2(c, 0), row2(c, 1), row2(c, 2), j == j0, mj);
+                        m = mk_min_raw(m, mj);
+                    }
                 }
-                for (long long j = j0; j < j1; ++j) {
-                    const float x2 = nx, y2 = ny, z2 = nz;
-                    if (j + 1 < j1) {
-                        at_next = at_after;
-                        if (j + 2 < j1) at_after = atom2(j + 2);
-                        nx = c2[(at_next * 3 + 0) * (size_t)F + (size_t)f];
-                        ny = c2[(at_next * 3 + 1) * (size_t)F + (size_t)f];
-                        nz = c2[(at_next * 3 + 2) * (size_t)F + (size_t)f];
-                    }
-                    int k = 0;
-                    for (; k + 4 <= n; k += 4) {                     // four reads in flight (a SIMD may hold this wave alone)
-                        const float4 A0 = s_at[k], A1 = s_at[k + 1], A2 = s_at[k + 2], A3 = s_at[k + 3];
-                        const float d0 = dist2_min_image_f32(A0.x, A0.y, A0.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
-                        const float d1 = dist2_min_image_f32(A1.x, A1.y, A1.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
-                        const float d2 = dist2_min_image_f32(A2.x, A2.y, A2.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
-                        const float d3 = dist2_min_image_f32(A3.x, A3.y, A3.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
-                        if (d0 < mindist || mindist < 0.f) mindist = d0;
-                        if (d1 < mindist || mindist < 0.f) mindist = d1;
-                        if (d2 < mindist || mindist < 0.f) mindist = d2;
-                        if (d3 < mindist || mindist < 0.f) mindist = d3;
-                    }
-                    for (; k < n; ++k) {
-                        const float4 A = s_at[k];
-                        const float d2 = dist2_min_image_f32(A.x, A.y, A.z, x2, y2, z2, bx, by, bz, ibx, iby, ibz, w);
-                        if (d2 < mindist || mindist < 0.f) mindist = d2;
-                    }
-                }
-                if (i1 <= i0) break;
+                // `if dist2 < mindist or mindist < 0` over the passes: the first pass's first pair decides about NaN, later passes join the minimum
+                if (acc < 0.f) acc = (first != first) ? first : m;
+                else if (acc == acc) acc = mk_min_raw(acc, m);
             }
             if (live) {
                 long long idx;
@@ -1381,7 +1428,7 @@ MK_KERNEL(DRF_THREADS) void k_dist_reduction_few(const float* __restrict__ c1, c
                 } else {
                     idx = a * ng2 + b;
                 }
-                out[(size_t)f * (size_t)P + (size_t)idx] = mk_fsqrt_rn(mindist);
+                out[(size_t)f * (size_t)P + (size_t)idx] = mk_fsqrt_rn(acc);                  // ONE root per (frame, group pair) (:276)
             }
         }
     }

@@ -451,6 +451,16 @@ def test_closest_reduction_kernel_nan_and_infinite_semantics():
             for block in (4, 8, -1, -2):
                 got = E.dist_reduction(coords, box, g1, g2, ch1, ch2, False, pbc, masses, 0, 0, block=block)
                 assert np.array_equal(got, want, equal_nan=True), (pbc, block)
+        # mixed chains: in the few-frame kernel (-2) the lanes whose pair does NOT wrap ride along the wrapping walk with 1 / box = 0 --
+        # an infinite separation there must stay infinite (0 * inf is NaN), a first-pair NaN must stay the reference's
+        coords[20, 2, 2::7] = -np.inf
+        g1m, g2m = [[12], [4, 5, 6], [13, 12]], [[14, 15], [18, 9], [20], [21, 22]]
+        ch1m, ch2m = np.zeros(3, np.uint32), np.array([0, 1, 0, 0], np.uint32)
+        want = oracle.dist_trajectory_reduction(coords, box, g1m, g2m, ch1m, ch2m, False, True, masses, 0, 0)
+        assert np.isinf(want).any() and np.isnan(want).any() and np.isfinite(want).any()
+        for block in (-2, 8, -1):
+            got = E.dist_reduction(coords, box, g1m, g2m, ch1m, ch2m, False, True, masses, 0, 0, block=block)
+            assert np.array_equal(got, want, equal_nan=True), block
 
 
 def test_reductions_of_few_frames_take_lanes_along_the_second_groups():

@@ -203,14 +203,22 @@ def bench_host_call(coords, box, chains_h, s1, s2, F):
     from moleculekit_amd import distance_utils as du
     ch, bh = coords.cpu().numpy(), box.cpu().numpy()
     out = {}
+    from moleculekit_amd import _lib
+    ctx = _lib.default_context(0)
     for name, a, b in (("200 x 500", s1, s2), ("300 x 30", s2[:300].copy(), s1[:30].copy())):
         res = np.empty((F, len(a) * len(b)), np.float32)
-        du.dist_trajectory(ch, bh, a, b, chains_h, False, True, res)
-        t0 = time.perf_counter()
-        for _ in range(2):
+        ms = {}
+        for label, mask in (("packed", 0), ("whole_array", 32)):       # same-box A-B: bit 32 = upload the whole trajectory (before round 6's host_pack.h)
+            ctx.set_dist_kernels(mask)
             du.dist_trajectory(ch, bh, a, b, chains_h, False, True, res)
-        dt = (time.perf_counter() - t0) / 2
-        out[name] = {"ms_per_call": round(dt * 1e3, 2), "Mdist_per_s": round(F * len(a) * len(b) / dt / 1e6, 1),
+            t0 = time.perf_counter()
+            for _ in range(2):
+                du.dist_trajectory(ch, bh, a, b, chains_h, False, True, res)
+            ms[label] = (time.perf_counter() - t0) / 2
+        ctx.set_dist_kernels(0)
+        dt = ms["packed"]
+        out[name] = {"ms_per_call": round(dt * 1e3, 2), "ms_per_call_whole_array_uploaded": round(ms["whole_array"] * 1e3, 2),
+                     "Mdist_per_s": round(F * len(a) * len(b) / dt / 1e6, 1),
                      "coords_array_MB": round(ch.nbytes / 1e6, 1),
                      "bytes_over_pcie_MB": round((len(np.union1d(a, b)) * 3 * F * 4 + res.nbytes) / 1e6, 1)}
     out["what"] = ("host numpy arrays in and out (pageable memory), periodic by chain; only the selected atoms' rows of the trajectory "
