@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tests/sweep_gpu_reduction.py [first_seed] [count] -- random dist_trajectory_reduction[_pairs] calls on the GPU against the oracle, bit for bit
-(the evidence session runs it on the final build; every seed draws its own atom count, frame count, ragged groups of 1-24 atoms, chain ids,
+(the evidence session runs it on the final build; every seed draws its own atom count, frame count (two in five: 1-17 frames), ragged groups of 1-24 atoms, chain ids,
 reductions closest / com, self / pairs modes, periodic or open, boxes that put some separations near half a box length)."""
 import os, sys
 import numpy as np
@@ -14,12 +14,16 @@ bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     N, F = int(rng.integers(5, 400)), int(rng.integers(1, 150))
+    if rng.random() < 0.4:
+        F = int(rng.integers(1, 18))                              # calls of few frames: k_dist_reduction_few (lanes along the second groups)
     L = float(rng.uniform(12, 60))
     coords = rng.uniform(-0.7 * L, 0.7 * L, size=(N, 3, F)).astype(np.float32)
     box = (L * rng.uniform(0.9, 1.1, size=(3, F))).astype(np.float32)
     masses = rng.uniform(1, 40, N).astype(np.float32)
     hi = int(rng.choice([1, 4, 9, 24]))
     ng1, ng2 = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    if rng.random() < 0.15:
+        ng2 = int(rng.integers(200, 600))                         # several blocks along a row of second groups
     mk = lambda n: [rng.choice(N, int(rng.integers(1, min(hi, N) + 1)), replace=False).tolist() for _ in range(n)]
     mode = int(rng.integers(3))                                   # 0 all-vs-all, 1 self, 2 pairs
     g1 = mk(ng1)
