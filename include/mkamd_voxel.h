@@ -123,6 +123,11 @@ int mkamd_ctx_set_tile_team(mkamd_ctx* ctx, int mode);
  * once for all its tiles (once per chunk of its tiles while the batch is too small to fill the chip) instead of once
  * per tile.  Results are bit-identical either way. */
 int mkamd_ctx_set_tile_items(mkamd_ctx* ctx, int mode);
+/* The exact cut-off fix-up of a TOPOLOGY call whose molecule has wide sigmas (ions: sigma > 1.81 A): 0 (default) = the call's last
+ * launch lists the (voxel, channel) values to re-decide and one more launch recomputes them with many waves per value (the item's
+ * atoms in slices of 2 048, joined by an atomic maximum); -1 = they are recomputed inside the last launch, one wave per value over
+ * all of the item's atoms (rounds 3-5; what every other kind of call does).  Results are bit-identical either way. */
+int mkamd_ctx_set_exact_redo(mkamd_ctx* ctx, int mode);
 /* Opt-in software pipelining ACROSS calls of mkamd_voxelize_lattice_dev (off by default): the binning
  * pre-pass of a call (latency / atomic bound) runs on an internal stream beside the tile kernel (VALU bound)
  * of the previous call, on a second workspace set.  Results still appear in order on the context's stream.

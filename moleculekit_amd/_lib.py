@@ -55,6 +55,7 @@ SIGNATURES = {
     "mkamd_frames_to_items_dev": (_c_int, [_vp, _vp, _vp, _c_i64, _c_i64, _c_i64, ctypes.c_float, _vp]),
     "mkamd_ctx_set_tile_team": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_tile_items": (_c_int, [_vp, _c_int]),
+    "mkamd_ctx_set_exact_redo": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_fine_cells": (_c_int, [_vp, _c_int]),
     "mkamd_ctx_set_value_tolerance": (_c_int, [_vp, ctypes.c_double]),
     "mkamd_ctx_set_direct_binning": (_c_int, [_vp, _c_int]),
@@ -271,6 +272,11 @@ class Context:
         """-1 automatic (default), 0 tiles on their own, 1 a workgroup per item that sorts the item's entries once
         (batches of ligand-sized items; include/mkamd_voxel.h)."""
         _check(load().mkamd_ctx_set_tile_items(self._h, int(mode)))
+
+    def set_exact_redo(self, mode: int = 0):
+        """0 (default): a topology call with wide sigmas hands its exact cut-off hits to a launch of their own (many waves per value);
+        -1: recomputed inside the call's last launch (include/mkamd_voxel.h).  Same bits either way."""
+        _check(load().mkamd_ctx_set_exact_redo(self._h, int(mode)))
 
     def set_fine_cells(self, on: bool):
         """Half-cutoff cells instead of cutoff-sized ones (A-B benchmarking; same values to float32 noise)."""

@@ -82,6 +82,7 @@ struct mkamd_ctx {
     int lds_tier = -1;                     // -1 = adaptive
     int prepass_mode = -1;                 // -1 = automatic
     int tile_items = -1;                   // -1 = automatic
+    int exact_redo = 0;                    // 0 = automatic (mkamd_ctx_set_exact_redo), -1 = never
     int tile_team = -1;                    // -1 = automatic
     int fine_cells = 0;                    // 1 = half-cutoff cells (A-B benchmarking)
     int direct = -1;                       // direct binning: -1 automatic, 0 never, 1 whenever possible (mkamd_ctx_set_direct_binning)
@@ -543,6 +544,14 @@ try {
     return MKAMD_OK;
 } MK_API_CATCH
 
+int mkamd_ctx_set_exact_redo(mkamd_ctx* ctx, int mode)
+try {
+    if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
+    if (mode != 0 && mode != -1) return fail(MKAMD_EINVAL, "exact redo mode must be 0 (automatic) or -1 (recompute inside the last launch)");
+    ctx->exact_redo = mode;
+    return MKAMD_OK;
+} MK_API_CATCH
+
 int mkamd_ctx_set_fine_cells(mkamd_ctx* ctx, int on)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
@@ -879,7 +888,7 @@ static int voxelize_lattice_dev_impl(mkamd_ctx* ctx, int32_t B, const float* d_c
     P.B = B; P.total_atoms = total_atoms; P.C = C; P.sigmas_f64 = sigmas_are_f64;
     P.nvox[0] = nvoxels[0]; P.nvox[1] = nvoxels[1]; P.nvox[2] = nvoxels[2];
     P.voxelsize = voxelsize; P.pbc = d_box ? 1 : 0; P.max_images = d_box ? max_images : 1;
-    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol; P.direct = ctx->direct; P.seq = ctx->seq_next; ctx->seq_next = 0u;
+    P.tile_k = ctx->tile_k; P.force_general = ctx->force_general; P.lds_tier = ctx->lds_tier; P.prepass_mode = ctx->prepass_mode; P.tile_team = ctx->tile_team; P.tile_items = ctx->tile_items; P.exact_redo_list = ctx->exact_redo; P.fine_cells = ctx->fine_cells; P.value_tol = ctx->value_tol; P.direct = ctx->direct; P.seq = ctx->seq_next; ctx->seq_next = 0u;
     P.coords = d_coords; P.atom_offsets = (const long long*)d_atom_offsets; P.sigmas = d_sigmas;
     P.origins = d_origins; P.box = d_box; P.affine = d_affine; P.out = d_features;
     P.topo = topo ? &topo->dev : nullptr;

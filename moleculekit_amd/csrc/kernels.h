@@ -2750,7 +2750,9 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, un
                             const float* __restrict__ coords,
                             const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
                             const double* __restrict__ origins, const float* __restrict__ box,
-                            const double* __restrict__ affine, float* __restrict__ out, double* s_best, unsigned* s_near /* [EXACT_LIST] */)
+                            const double* __restrict__ affine, float* __restrict__ out, double* s_best, unsigned* s_near /* [EXACT_LIST] */,
+                            long long s_lo = 0, long long s_hi = 0x7fffffffffffffffLL /* the atoms [s_lo, s_hi) of the item only ... */,
+                            bool accumulate = false /* ... joined to the stored value by an atomic maximum (k_exact_redo: a wave per slice) */)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const double cx = mk_dadd_rn(mk_dmul_rn((double)ix, g.res), origins[3 * (size_t)b + 0]);
@@ -2758,7 +2760,8 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, un
     const double cz = mk_dadd_rn(mk_dmul_rn((double)iz, g.res), origins[3 * (size_t)b + 2]);
     double L[3] = {1.0, 1.0, 1.0};
     if (g.pbc) { L[0] = (double)box[3 * (size_t)b]; L[1] = (double)box[3 * (size_t)b + 1]; L[2] = (double)box[3 * (size_t)b + 2]; }
-    const long long a_lo = atom_offsets[b], a_hi = atom_offsets[b + 1];
+    const long long a_lo = atom_offsets[b], a_end = atom_offsets[b + 1];
+    const long long a_hi = a_end - a_lo > s_hi ? a_lo + s_hi : a_end;     // (the end of this wave's slice)
     const long long sshift = g.topo_n ? a_lo : 0;                         // topology calls: the molecule's one sigma matrix
     const float fcx = (float)cx, fcy = (float)cy, fcz = (float)cz;
     const float fL[3] = {(float)L[0], (float)L[1], (float)L[2]};
@@ -2837,7 +2840,7 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, un
         }
         if (cnt > (unsigned)(EXACT_LIST - WAVE * EXACT_BATCH)) flush();   // (not inside the unrolled scan: the batch's 24 registers would live across it)
     };
-    long long base = a_lo;
+    long long base = a_lo + s_lo;
     for (; base + (long long)WAVE * EXACT_BATCH <= a_hi; base += (long long)WAVE * EXACT_BATCH) scan(base, ExactFull<true>{});   // wave-uniform
     for (; base < a_hi; base += (long long)WAVE * EXACT_BATCH) scan(base, ExactFull<false>{});
     flush();
@@ -2850,19 +2853,28 @@ MK_DEV void exact_recompute(const GridDesc& g, int b, int ix, int iy, int iz, un
             double m = s_best[0];
             for (int j = 1; j < WAVE; ++j) m = s_best[j] > m ? s_best[j] : m;
             const size_t vox = (size_t)b * (size_t)g.V + ((size_t)ix * g.ny + iy) * g.nz + iz;
-            out[vox * (size_t)g.C + (size_t)((chs >> (16 * k)) & 0xffffull)] = (float)m;
+            float* dst = out + vox * (size_t)g.C + (size_t)((chs >> (16 * k)) & 0xffffull);
+            // (occupancies are >= +0: their bit patterns order like the values, so the slices of k_exact_redo meet in an integer maximum)
+            if (accumulate) mk_atomic_max(reinterpret_cast<unsigned*>(dst), mk_float_bits((float)m));
+            else *dst = (float)m;
         }
         mk_block_sync();
     }
 }
 
+// The list of hits a topology call with wide atoms leaves for k_exact_redo: REDO_HEAD words (the count, then "a hit did not fit"), then
+// REDO_ENTRY words per hit: item, voxel x / y / z, the channel indices (16 bits each, two words), their number.
+enum { REDO_COUNT = 0, REDO_OVERFLOW = 1, REDO_HEAD = 4, REDO_ENTRY = 8 };
+constexpr int REDO_SLICE = WAVE * EXACT_BATCH * 4;   // atoms per wave of k_exact_redo (four batches: 2 048)
+
 // The cut-off shell of ONE wide atom `a` of item `b` (all 64 lanes): every (voxel, wide channel) the shell passes is recomputed
 // exactly.  `srow` = the atom's row in `sigmas` (a topology call: its index inside the molecule).
-template <typename SigT>
+template <typename SigT, int LIST_ONLY = 0 /* 1: hits go to the list or, when it is full, raise its overflow word -- no recompute in this code at all */>
 MK_DEV void exact_fixup_atom(const GridDesc& g, const int b, const long long a, const long long srow, const float* __restrict__ coords,
                              const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                              const float* __restrict__ box, const double* __restrict__ affine, float* __restrict__ out, double* s_best,
-                             unsigned* s_near, unsigned* __restrict__ feedback, unsigned seq)
+                             unsigned* s_near, unsigned* __restrict__ feedback, unsigned seq,
+                             unsigned* __restrict__ redo_list = nullptr /* != nullptr: hits are listed for k_exact_redo */, unsigned redo_cap = 0u)
 {
     const int lane = threadIdx.x;
     const float wmax = g.w_exact_max;
@@ -2925,7 +2937,30 @@ MK_DEV void exact_fixup_atom(const GridDesc& g, const int b, const long long a, 
                     for (int c = 0; c < g.C; ++c) {
                         if (sigma_to_w(sigmas[(size_t)srow * g.C + c], g.w_scale) < wmax) { chs |= (unsigned long long)(c & 0xffff) << (16 * nch); ++nch; }
                         if (nch == EXACT_CH || (c == g.C - 1 && nch)) {
-                            exact_recompute<SigT>(g, b, vx, vy, vz, chs, nch, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near);
+                            // A topology call with wide atoms lists the hit for k_exact_redo (the item's atoms in slices, a wave each) and
+                            // zeroes the values it will rebuild; a full list: here and now, this wave over all of the item's atoms.
+                            bool listed = false;
+                            if (redo_list != nullptr) {
+                                unsigned slot = 0u;
+                                if (lane == 0) slot = mk_atomic_add(&redo_list[REDO_COUNT], 1u);
+                                slot = mk_uniform(mk_shfl(slot, 0));
+                                if (slot < redo_cap) {
+                                    const size_t vox = (size_t)b * (size_t)g.V + ((size_t)vx * g.ny + vy) * g.nz + vz;
+                                    if (lane == 0) {
+                                        unsigned* e = redo_list + REDO_HEAD + (size_t)slot * REDO_ENTRY;
+                                        e[0] = (unsigned)b; e[1] = (unsigned)vx; e[2] = (unsigned)vy; e[3] = (unsigned)vz;
+                                        e[4] = (unsigned)(chs & 0xffffffffull); e[5] = (unsigned)(chs >> 32); e[6] = (unsigned)nch; e[7] = 0u;
+                                    }
+                                    if (lane < nch) out[vox * (size_t)g.C + (size_t)((chs >> (16 * lane)) & 0xffffull)] = 0.f;
+                                    listed = true;
+                                }
+                            }
+                            if constexpr (LIST_ONLY) {
+                                if (!listed && lane == 0) redo_list[REDO_OVERFLOW] = 1u;      // (k_exact_shells<.., true> walks the shells once more, in place)
+                            } else {
+                                if (!listed)
+                                    exact_recompute<SigT>(g, b, vx, vy, vz, chs, nch, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near);
+                            }
                             chs = 0ull; nch = 0;
                         }
                     }
@@ -2942,13 +2977,14 @@ MK_DEV void exact_fixup_atom(const GridDesc& g, const int b, const long long a, 
 // walked all of the item's atoms 64 at a time and took its wide atoms one after the other -- for 30 000-atom frames with a
 // few ions ~470 dependent load / ballot rounds on B waves; now the B x n_wide shells are spread over all fix-up waves and
 // nobody looks at an atom that is not wide.)
-template <typename SigT>
+template <typename SigT, int LIST_ONLY = 0>
 MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_item, const unsigned* __restrict__ summary,
                               const float* __restrict__ coords, const long long* __restrict__ atom_offsets,
                               long long total_atoms, const SigT* __restrict__ sigmas, const double* __restrict__ origins,
                               const float* __restrict__ box, const double* __restrict__ affine,
                               const uint2* __restrict__ tmp_cls, float* __restrict__ out, double* s_best, unsigned* s_near,
-                              unsigned* __restrict__ feedback = nullptr, unsigned seq = 0u)
+                              unsigned* __restrict__ feedback = nullptr, unsigned seq = 0u,
+                              unsigned* __restrict__ redo_list = nullptr, unsigned redo_cap = 0u)
 {
     const int lane = threadIdx.x;
     const float wmax = g.w_exact_max;
@@ -2960,7 +2996,8 @@ MK_DEV void exact_fixup_block(const GridDesc& g, const unsigned blk, int per_ite
         // an item that is not the topology's atom count long: the binning has raised MK_ERR_TOPOLOGY; nothing of the handle's
         // is indexed with it (the C API promises a clean MKAMD_EINVAL at the next synchronize, not a read past the handle)
         if (a_hi - a_lo != (long long)g.topo_n || k >= (long long)g.topo_n) return;
-        exact_fixup_atom<SigT>(g, b, a_lo + k, k, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near, feedback, seq);
+        exact_fixup_atom<SigT, LIST_ONLY>(g, b, a_lo + k, k, coords, atom_offsets, sigmas, origins, box, affine, out, s_best, s_near, feedback, seq,
+                                          redo_list, redo_cap);
         return;
     }
     // ---- the summary: is there anything wide among this wave's atoms at all? ----
@@ -3088,6 +3125,62 @@ MK_KERNEL(64) void k_tail(GridDesc g, unsigned dense_wgs, const unsigned* __rest
     for (unsigned job = role - dense_wgs; job < fix_jobs; job += gridDim.x - dense_wgs)
         exact_fixup_block<SigT>(g, job, per_item, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine,
                                 tmp_cls, out, s_best, s_near, feedback, seq);
+}
+
+// The hits k_tail listed (a topology call with wide atoms), recomputed by MANY waves: job = (hit, slice of REDO_SLICE atoms of the
+// item); every wave runs exact_recompute over its slice and joins the stored value (zeroed by k_tail when it listed the hit) with an
+// atomic maximum.  Round 6: one wave per hit scanned all 30 000 atoms of a cfg4-sized frame -- 59 dependent round trips, ~40 us -- and
+// k_tail lasted as long as the wave with the most hits (300 ions: 317 us per 256-frame step); here a hit is 15 waves of four round trips.
+// (The list's counter is zeroed by a launch of its own in front of the next call's hot kernels: a done-ticket that let the last of these
+// blocks do it cost 4 096 atomics on one word -- 85 us, measured, where the recomputes themselves take ten.)
+template <typename SigT>
+MK_KERNEL(64) void k_exact_redo(GridDesc g, unsigned* __restrict__ redo_list, unsigned redo_cap, const float* __restrict__ coords,
+                                const long long* __restrict__ atom_offsets, const SigT* __restrict__ sigmas,
+                                const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
+                                float* __restrict__ out)
+{
+    __shared__ double s_best[WAVE];
+    __shared__ unsigned s_near[EXACT_LIST];
+    unsigned count = redo_list[REDO_COUNT];
+    count = count < redo_cap ? count : redo_cap;
+    const unsigned slices = (unsigned)((g.topo_n + REDO_SLICE - 1) / REDO_SLICE);
+    const unsigned long long jobs = (unsigned long long)count * slices;
+    for (unsigned long long job = blockIdx.x; job < jobs; job += gridDim.x) {          // block-uniform
+        const unsigned* e = redo_list + REDO_HEAD + (size_t)(job / slices) * REDO_ENTRY;
+        const long long s_lo = (long long)(job % slices) * REDO_SLICE;
+        const unsigned long long chs = (unsigned long long)e[4] | ((unsigned long long)e[5] << 32);
+        exact_recompute<SigT>(g, (int)e[0], (int)e[1], (int)e[2], (int)e[3], chs, (int)e[6], coords, atom_offsets, sigmas, origins, box, affine, out,
+                              s_best, s_near, s_lo, s_lo + REDO_SLICE, true);
+    }
+}
+
+// The fix-up jobs of a topology call with wide atoms -- (item, wide atom) shells -- in launches of their own.  Inside k_tail a fix-up
+// wave carries the dense-tile role's LDS and the in-place recompute's registers (191: two waves per SIMD), and 76 800 shells of a
+// 256-frame batch with 300 ions took 135 us.  INPLACE = false: walk the shells, LIST the hits (k_exact_redo follows) -- no recompute in
+// this code; a hit that does not fit the list raises its overflow word.  INPLACE = true, launched behind k_exact_redo: leaves at once
+// unless that word is up, else walks every shell once more and recomputes each hit where it stands (the round-3 way: always right).
+template <typename SigT, bool INPLACE>
+MK_KERNEL(64) void k_exact_shells(GridDesc g, unsigned fix_jobs, const unsigned* __restrict__ summary, const float* __restrict__ coords,
+                                  const long long* __restrict__ atom_offsets, long long total_atoms, const SigT* __restrict__ sigmas,
+                                  const double* __restrict__ origins, const float* __restrict__ box, const double* __restrict__ affine,
+                                  const uint2* __restrict__ tmp_cls, float* __restrict__ out, unsigned* __restrict__ redo_list, unsigned redo_cap)
+{
+    __shared__ double s_best[WAVE];
+    __shared__ unsigned s_near[EXACT_LIST];
+    if constexpr (INPLACE) {
+        if (redo_list[REDO_OVERFLOW] == 0u) return;                        // block-uniform: nearly always
+        for (unsigned job = blockIdx.x; job < fix_jobs; job += gridDim.x)
+            exact_fixup_block<SigT, 0>(g, job, 2, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine, tmp_cls, out, s_best, s_near);
+    } else {
+        for (unsigned job = blockIdx.x; job < fix_jobs; job += gridDim.x)
+            exact_fixup_block<SigT, 1>(g, job, 2, summary, coords, atom_offsets, total_atoms, sigmas, origins, box, affine, tmp_cls, out, s_best, s_near,
+                                       nullptr, 0u, redo_list, redo_cap);
+    }
+}
+
+MK_KERNEL(64) void k_zero_words(unsigned* __restrict__ p, unsigned n)
+{
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -131,6 +131,7 @@ MK_DEV void mk_atomic_or(int* p, int v) { atomicOr(p, v); }
 
 MK_DEV unsigned mk_atomic_cas(unsigned* p, unsigned expect, unsigned val) { return atomicCAS(p, expect, val); }
 MK_DEV void mk_atomic_min(unsigned* p, unsigned v) { atomicMin(p, v); }
+MK_DEV void mk_atomic_max(unsigned* p, unsigned v) { atomicMax(p, v); }
 // device-scope relaxed load (bypasses this CU's L1: sees other CUs' atomics)
 MK_DEV unsigned mk_load_relaxed(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { return atomicCAS(p, expect, val); }  // ds_cmpst_rtn

@@ -33,7 +33,7 @@ constexpr int SOLO_CNT_SHIFT = 3;   // k_bin_solo's cell counters 32 bytes apart
 enum Status { ST_OK = 0, ST_EINVAL = 1, ST_EHIP = 2, ST_ENODEV = 3, ST_EOVERFLOW = 4, ST_EBOX = 5 };
 
 enum WsSlot {
-    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT, WS_DENSE_WORDS, WS_DIRECT_COUNT,
+    WS_CELL_COUNT = 0, WS_CELL_START, WS_SCAN_CHUNKS, WS_REC_POS, WS_REC_W, WS_REC_CLS, WS_CLS_TABLE, WS_CLS_BLOCKS, WS_CLS_L1, WS_TMP_POS, WS_TMP_IDX, WS_TMP_CLS, WS_DENSE_LIST, WS_ERR, WS_W_EXPLICIT, WS_DENSE_WORDS, WS_DIRECT_COUNT, WS_REDO_LIST,
     // staging for the "_host" entry points
     WS_H_COORDS, WS_H_SIGMAS, WS_H_OFFSETS, WS_H_ORIGINS, WS_H_BOX, WS_H_OUT, WS_H_CENTERS, WS_H_STAGE,
     // distance_utils row (dist_pipeline.h)
@@ -82,6 +82,8 @@ struct LatticeProblem {
     unsigned seq = 0;                       // != 0: k_tail reports this number in the host-visible feedback words as it starts (FB_TILES_DONE)
     int tile_team = -1;                     // -1 = automatic (a team of waves per tile when the launch is tiny), 0 = never, 1 = always (4, 8, 16: with that many waves)
     int tile_items = -1;                    // -1 = automatic (a workgroup per item for batches of ligand-sized items), 0 = never, 1 = always
+    int exact_redo_list = 0;                // 0 = a topology call with wide atoms hands its exact cut-off hits to k_exact_redo, -1 = k_tail recomputes them in place;
+                                            // n > 0 (tests): as 0 with a list of n hits
     // device pointers
     const float* coords = nullptr;
     const long long* atom_offsets = nullptr;
@@ -218,6 +220,9 @@ inline int choose_tier(int forced, const volatile unsigned* feedback)
 
 enum TileFlavour { TILES_PLAIN = 0, TILES_LEAN = 1, TILES_TEAM = 2, TILES_ITEMS = 3 };
 
+constexpr unsigned REDO_BLOCKS = 4096;       // waves of k_exact_redo (they share the jobs)
+constexpr unsigned SHELL_BLOCKS = 16384;     // waves of k_exact_shells (they share the (item, wide atom) jobs)
+constexpr unsigned REDO_CAP = 32768;         // hits the list holds (1 MB); a call with more walks its shells once more and recomputes in place (k_exact_shells<.., true>)
 // what the call's last launch (k_tail: dense tiles + exact cut-off fix-up) needs besides the tile kernel's arguments
 struct TailArgs {
     unsigned dense_wgs = 0, fix_waves = 0, fix_jobs = 0;
@@ -231,6 +236,8 @@ struct TailArgs {
     unsigned solo_n = 0;
     const void* sigmas = nullptr;           // != nullptr: the sigma matrix k_tail recomputes from (a topology call: the handle's copy)
     int sigmas_f64 = 0;
+    unsigned* redo_list = nullptr;          // a topology call with wide atoms: k_tail lists its cut-off hits here, k_exact_redo recomputes them
+    unsigned redo_cap = 0;
 };
 
 template <int K, int T, class BE>
@@ -278,16 +285,42 @@ int launch_tiles_tier(BE& be, int flavour, dim3 tgrid, const TailArgs& ta, const
     // the tiles left behind (usually none), the statistics for the next call and the exact cut-off fix-up: one launch
     if (!st && ta.dense_wgs + ta.fix_waves != 0u) {
         const LatticeProblem& P = *ta.P;
+        // a topology call with wide atoms: k_tail keeps its dense tiles and bookkeeping, the shells of the wide atoms run in a launch of
+        // their own (k_exact_shells: waves without the dense role's LDS footprint), their hits in a third (k_exact_redo)
+        const bool split = ta.redo_list != nullptr;
+        const unsigned tail_fix_waves = split ? 1u : ta.fix_waves, tail_fix_jobs = split ? 0u : ta.fix_jobs;   // (one wave stays for k_tail's housekeeping)
         auto tail = [&](auto kern, auto* sig) {
-            return be.launch(kern, dim3(ta.dense_wgs + ta.fix_waves), dim3(WAVE), g, ta.dense_wgs, (const unsigned*)start, (const float4*)rpos,
+            return be.launch(kern, dim3(ta.dense_wgs + tail_fix_waves), dim3(WAVE), g, ta.dense_wgs, (const unsigned*)start, (const float4*)rpos,
                              (const unsigned*)rcls, (const unsigned*)ctab, out, dcount, ta.other_words, (const unsigned*)dlist,
                              g.force_general ? (unsigned*)nullptr : be.feedback_dev(), (const int*)eflag, ta.per_item, ta.summary, P.coords,
                              P.atom_offsets, P.total_atoms, sig, P.origins, P.box, P.affine, (const uint2*)ta.tcls, ta.solo_counts, ta.solo_n,
-                             (unsigned*)ctab, g.force_general ? 0u : P.seq, ta.fix_jobs);
+                             (unsigned*)ctab, g.force_general ? 0u : P.seq, tail_fix_jobs);
         };
         const void* sig = ta.sigmas ? ta.sigmas : P.sigmas;
         const int sig64 = ta.sigmas ? ta.sigmas_f64 : P.sigmas_f64;
         st = sig64 ? tail(k_tail<K, E, double>, (const double*)sig) : tail(k_tail<K, E, float>, (const float*)sig);
+        if (!st && split) {
+            auto shells = [&](auto kern, auto* sg) {
+                return be.launch(kern, dim3(ta.fix_jobs < SHELL_BLOCKS ? ta.fix_jobs : SHELL_BLOCKS), dim3(WAVE), g, ta.fix_jobs, ta.summary, P.coords, P.atom_offsets,
+                                 P.total_atoms, sg, P.origins, P.box, P.affine, (const uint2*)ta.tcls, out, ta.redo_list, ta.redo_cap);
+            };
+            st = sig64 ? shells(k_exact_shells<double, false>, (const double*)sig) : shells(k_exact_shells<float, false>, (const float*)sig);
+        }
+        if (!st && split) {
+            // the listed hits, a wave per (hit, slice of the item's atoms); blocks that find the list empty leave at once
+            auto redo = [&](auto kern, auto* sg) {
+                return be.launch(kern, dim3(REDO_BLOCKS), dim3(WAVE), g, ta.redo_list, ta.redo_cap, P.coords, P.atom_offsets, sg, P.origins, P.box, P.affine, out);
+            };
+            st = sig64 ? redo(k_exact_redo<double>, (const double*)sig) : redo(k_exact_redo<float>, (const float*)sig);
+        }
+        if (!st && split) {
+            // the list was full (REDO_CAP hits in one call)?  Then every shell once more, recomputed in place; else these blocks leave at once
+            auto again = [&](auto kern, auto* sg) {
+                return be.launch(kern, dim3(ta.fix_jobs < 8192u ? ta.fix_jobs : 8192u), dim3(WAVE), g, ta.fix_jobs, ta.summary, P.coords, P.atom_offsets,
+                                 P.total_atoms, sg, P.origins, P.box, P.affine, (const uint2*)ta.tcls, out, ta.redo_list, ta.redo_cap);
+            };
+            st = sig64 ? again(k_exact_shells<double, true>, (const double*)sig) : again(k_exact_shells<float, true>, (const float*)sig);
+        }
     }
     return st;
 }
@@ -582,6 +615,15 @@ int run_lattice(BE& be, const LatticeProblem& P, std::string& err)
     if (topo) { ctab = const_cast<unsigned*>(P.topo->table); ta.sigmas = P.topo->sigmas; ta.sigmas_f64 = P.topo->sigmas_f64; }
     ta.team_waves = (P.tile_team == 4 || P.tile_team == 8 || P.tile_team == 16) ? P.tile_team : 0;
     if (solo) { ta.solo_counts = (unsigned*)dcnt; ta.solo_n = (unsigned)(DIRECT_HEAD + (ncells << g.cnt_shift)); }
+    if (topo && g.topo_wide != 0u && P.seq == 0u && !g.force_general && P.exact_redo_list >= 0) {
+        // a trajectory of a molecule with wide sigmas (ions): the exact recomputes of k_tail's hits are spread over many waves (k_exact_redo)
+        void* rl = nullptr;
+        if ((st = be.ensure(WS_REDO_LIST, (size_t)(REDO_HEAD + (size_t)REDO_CAP * REDO_ENTRY) * sizeof(unsigned), &rl, set))) return st;
+        // (the list's counter back to zero: queued behind the previous call's k_exact_redo on this stream, in front of this call's hot kernels)
+        if ((st = be.launch(k_zero_words, dim3(1), dim3(WAVE), (unsigned*)rl, (unsigned)REDO_HEAD))) return st;
+        ta.redo_list = (unsigned*)rl;
+        ta.redo_cap = P.exact_redo_list > 0 && (unsigned)P.exact_redo_list < REDO_CAP ? (unsigned)P.exact_redo_list : REDO_CAP;   // (a tiny list: tests of the overflow pass)
+    }
     be.hot_begin(flavour, g.K, ECAP_TIER[tier]);
     st = g.K == 8 ? launch_tiles<8>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag)
                   : launch_tiles<4>(be, tier, flavour, tgrid, ta, g, start, rpos, rw, rcls, ctab, P.out, dcount, dlist, eflag);

@@ -126,7 +126,8 @@ int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offse
 // by the product's kernels, then B sets of coordinates of it through run_lattice with P.topo.  *wide_out: the handle's wide flag.
 int emu_voxelize_lattice_topo(int B, const float* coords, const long long* atom_offsets, const void* sigmas, int sigmas_f64, long long n, int C,
                               const double* origins, const int* nvox, double voxelsize, const float* box, int max_images, int tile_k,
-                              const double* affine, float* features, int* err_flag_out, int* wide_out, int repeat)
+                              const double* affine, float* features, int* err_flag_out, int* wide_out, int repeat,
+                              int exact_redo /* 0: the hits of wide atoms go to k_exact_redo (the default), -1: recomputed inside k_tail */)
 {
     EmuBackend be;
     void* eflag = nullptr;
@@ -156,7 +157,7 @@ int emu_voxelize_lattice_topo(int B, const float* coords, const long long* atom_
     }
     P.max_images = box ? max_images : 1;
     P.coords = coords; P.atom_offsets = atom_offsets; P.sigmas = nullptr; P.origins = origins;
-    P.box = box; P.affine = affine; P.out = features; P.topo = &T;
+    P.box = box; P.affine = affine; P.out = features; P.topo = &T; P.exact_redo_list = exact_redo;
     const size_t nout = (size_t)B * nvox[0] * nvox[1] * nvox[2] * C;
     for (int r = 0; r < (repeat > 0 ? repeat : 1) && !st; ++r) {
         for (size_t i = 0; i < nout; ++i) features[i] = -123.0f;

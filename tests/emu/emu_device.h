@@ -248,6 +248,7 @@ MK_DEV unsigned mk_atomic_sub(unsigned* p, unsigned v) { const unsigned o = *p; 
 MK_DEV void mk_atomic_or(int* p, int v) { *p |= v; }
 MK_DEV unsigned mk_atomic_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
 MK_DEV void mk_atomic_min(unsigned* p, unsigned v) { if (v < *p) *p = v; }
+MK_DEV void mk_atomic_max(unsigned* p, unsigned v) { if (v > *p) *p = v; }
 MK_DEV unsigned mk_load_relaxed(unsigned* p) { return *p; }
 MK_DEV unsigned mk_lds_cas(unsigned* p, unsigned expect, unsigned val) { const unsigned o = *p; if (o == expect) *p = val; return o; }
 MK_DEV float mk_fma(float a, float b, float c) { return fmaf(a, b, c); }

@@ -80,7 +80,7 @@ def voxelize_lattice(coords, atom_offsets, sigmas, origins, nvox, voxelsize, box
 
 
 def voxelize_lattice_topo(coords, sigmas_one, n_items, origins, nvox, voxelsize, box=None, max_images=0, tile_k=0, affine=None, repeat=1,
-                          atom_offsets=None):
+                          atom_offsets=None, exact_redo=0):
     """B sets of coordinates of ONE molecule (sigmas_one [n, C]) through the topology path (run_topology_build + run_lattice with
     P.topo) on the emulated kernels -> (features [B, V, C], device error flag, the handle's wide flag)."""
     coords = np.ascontiguousarray(coords, np.float32).reshape(-1, 3)
@@ -97,7 +97,7 @@ def voxelize_lattice_topo(coords, sigmas_one, n_items, origins, nvox, voxelsize,
     st = lib().emu_voxelize_lattice_topo(ctypes.c_int(B), _p(coords), _p(offs), _p(sigmas_one), ctypes.c_int(int(sig64)), ctypes.c_longlong(n),
                                          ctypes.c_int(C), _p(origins), _p(nvox), ctypes.c_double(voxelsize), _p(bx), ctypes.c_int(max_images),
                                          ctypes.c_int(tile_k), _p(None if affine is None else np.ascontiguousarray(affine, np.float64)), _p(out),
-                                         ctypes.byref(err), ctypes.byref(wide), ctypes.c_int(int(repeat)))
+                                         ctypes.byref(err), ctypes.byref(wide), ctypes.c_int(int(repeat)), ctypes.c_int(int(exact_redo)))
     if st != 0:
         raise RuntimeError(f"emu status {st}: {lib().emu_last_error().decode()}")
     return out, err.value, bool(wide.value)

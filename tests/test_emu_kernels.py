@@ -712,6 +712,27 @@ def test_topology_fixup_jobs_are_per_wide_atom_and_decide_the_shell_exactly():
     assert np.abs(topo - exp).max() <= TOL
     for c in (1, 7):
         assert not ((topo[:, :, c] == 0) != (exp[:, :, c] == 0)).any(), c
+    # the hits recomputed inside k_tail (one wave per value over all atoms, rounds 3-5) instead of by k_exact_redo: the same bits
+    inplace, err, _ = E.voxelize_lattice_topo(coords, sig, F, origins, nv, 1.0, exact_redo=-1)
+    assert err == 0 and np.array_equal(inplace, topo)
+    # a list of FIVE hits (the call has hundreds): the overflow word sends every shell through the in-place pass behind k_exact_redo
+    tiny, err, _ = E.voxelize_lattice_topo(coords, sig, F, origins, nv, 1.0, exact_redo=5)
+    assert err == 0 and np.array_equal(tiny, topo)
+    # a molecule of more than one slice of k_exact_redo (2 048 atoms): the lattice atoms between two halves of filler, wide sigmas on
+    # both sides of the slice boundary, so that a re-decided value is the maximum of what two waves found
+    fill = rng.uniform(0.5, 23.5, size=(2200, 3)).astype(np.float32)
+    big = np.concatenate([fill[:1100], frames[0], fill[1100:]])
+    sigb = np.zeros((len(big), 8))
+    sigb[:, 0] = 1.5
+    sigb[::5, 7] = 2.0                        # wide, all over the molecule
+    sigb[1100:1100 + n] = sig
+    ob = np.array([0, len(big)])
+    t0, err0, w0 = E.voxelize_lattice_topo(big, sigb, 1, origins[:1], nv, 1.0)
+    t1, err1, _ = E.voxelize_lattice_topo(big, sigb, 1, origins[:1], nv, 1.0, exact_redo=-1)
+    assert err0 == 0 and err1 == 0 and w0 and np.array_equal(t0, t1)
+    expb = oracle_lattice(big, ob, sigb, origins[:1], np.array(nv), 1.0)
+    assert np.abs(t0 - expb).max() <= TOL
+    assert not ((t0[:, :, 7] == 0) != (expb[:, :, 7] == 0)).any()
     # ragged offsets with wide atoms: flagged on the device, and the fix-up jobs do not index the handle with them
     bad = np.array([0, n - 2, 2 * n + 1, 3 * n])
     _, err, _ = E.voxelize_lattice_topo(coords, sig, F, origins, nv, 1.0, atom_offsets=bad)

@@ -36,12 +36,13 @@ for label, nwide in CONFIGS:
     topo = _lib.Topology(ctx, d_sig1, 1.0)
     row = []
     ref = None
-    for mode in ("topology", "plain"):
+    for mode in ("topology", "topology, hits redone inside k_tail", "plain"):
+        ctx.set_exact_redo(-1 if "inside" in mode else 0)           # (round 6, late: the hits of a topology call go to k_exact_redo by default)
         for pipelined in (False, True):
             def step():
                 if pipelined:
                     ctx.promise_inputs(None)
-                if mode == "topology":
+                if mode.startswith("topology"):
                     batch.voxelize_lattice_torch(d_xyz, d_offs, None, d_org, nv, 1.0, box=d_box, out=out, ctx=ctx, topology=topo)
                 else:
                     batch.voxelize_lattice_torch(d_xyz, d_offs, d_rep, d_org, nv, 1.0, box=d_box, out=out, ctx=ctx)
@@ -57,5 +58,6 @@ for label, nwide in CONFIGS:
         chk = float(out.double().sum())
         ref = chk if ref is None else ref
         assert chk == ref, "topology and plain calls differ"
+    ctx.set_exact_redo(0)
     topo.close()
     print(f"{label:>22} ({nwide} of {n} atoms): " + " | ".join(row), flush=True)
