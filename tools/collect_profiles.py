@@ -118,7 +118,7 @@ if o:
             print(f"{tag}_reduction: {k[:60]} VALU wave-instructions {v['SQ_INSTS_VALU']:.0f} = {v['SQ_INSTS_VALU'] * 64 / pairs:.2f} lane-instructions per atom pair; "
                   f"VALU-busy {v['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / clk:.3f}")
 for src, dst in (("single_latency.txt", "single_latency.txt"), ("dropin_profile.txt", "dropin_profile.txt"), ("graph_latency.txt", "graph_latency.txt"),
-                 ("reduction_probe.txt", "reduction_probe.txt"), ("reduction_few_probe.txt", "reduction_few_probe.txt"),
+                 ("reduction_probe.txt", "reduction_probe.txt"), ("reduction_few_probe.txt", "reduction_few_probe.txt"), ("topology_wide_ab_final.txt", "topology_wide_ab_final.txt"),
                  ("xtc_gpu_probe.txt", "xtc_gpu_probe.txt"), ("dist_shapes_probe.txt", "dist_shapes_probe.txt"), ("random_sweeps.txt", "random_sweeps_final.txt"),
                  ("sqrt_exact.txt", "sqrt_exact.txt")):
     f = f"gpurun_out/{src}"

@@ -61,6 +61,8 @@ rpmc sq2 $SQ2
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
 (timeout 600 python tools/reduction_probe.py > gpurun_out/reduction_probe.txt 2>&1)
 (timeout 600 python tools/reduction_few_probe.py 2>&1 | grep -v amdgpu > gpurun_out/reduction_few_probe.txt)
+# topology calls with wide atoms (ions): the split fix-up (k_exact_shells / k_exact_redo) against the in-k_tail form, same process
+(timeout 600 python tools/topology_wide_ab.py 2>&1 | grep -v amdgpu > gpurun_out/topology_wide_ab_final.txt)
 grep -a "cutoff shell" gpurun_out/pytest_gpu.log | sort -u; tail -3 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/smoke.log
 python tools/collect_profiles.py $TAG > /dev/null      # the PMC summaries of THIS build first: the bench lines below then carry roofline.traffic
 # the bench lines proper (the default one exactly as the driver runs it), after the counters so that they can quote them
