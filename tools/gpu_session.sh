@@ -1,15 +1,20 @@
-# round 6, session 61: k_exact_redo (the exact cut-off hits of a topology call recomputed by many waves): GPU tests, A-B, k_tail / k_exact_redo durations
+# round 6, session 62: the multi-process path on ONE GPU (ranks share the device: a rehearsal, not a scaling measurement): bench.py as the driver launches it
+# for N = 2 and 4, the voxel headline and the distance row -- rendezvous, gloo fences, max over ranks, the gather legs' handling of RCCL's refusal of one device twice
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests/test_gpu_api.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -4 | tee gpurun_out/s61_tests.txt
-timeout 900 python tools/topology_wide_ab.py 2>&1 | grep -v amdgpu | tee gpurun_out/topology_wide_ab.txt
-for nw in 8 300; do
-  (cd /tmp && AB_ONLY=$nw timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_wide_$nw -- python $GRAFT_REPO_ROOT/tools/topology_wide_ab.py > /dev/null 2>&1)
-  python - <<PY
-import csv, glob
-import os; f = sorted(glob.glob("gpurun_out/prof_wide_$nw/*/*_kernel_stats.csv"), key=os.path.getmtime)[-1]
-for r in csv.DictReader(open(f)):
-    if "k_tail" in r["Name"] or "k_exact" in r["Name"] or "k_zero" in r["Name"]:
-        print("$nw ions:", r["Name"][:60], "calls", r["Calls"], "avg us", round(float(r["AverageNs"]) / 1e3, 1), "min", round(float(r["MinNs"]) / 1e3, 1), "max", round(float(r["MaxNs"]) / 1e3, 1))
+export MKAMD_BENCH_SHARE_DEVICES=1
+for n in 2 4; do
+  (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29540 + n)) bench.py --gpus $n --steps 10 --warmup 3 --no-cpu-baseline --no-extra --min-seconds 1 2> gpurun_out/rehearsal_cfg2_$n.err | grep '^{' > gpurun_out/rehearsal_cfg2_$n.json; echo "cfg2 N=$n rc=${PIPESTATUS[0]}")
+  (timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29550 + n)) bench.py --workload dist --gpus $n --steps 10 --warmup 3 --no-cpu-baseline 2> gpurun_out/rehearsal_dist_$n.err | grep '^{' > gpurun_out/rehearsal_dist_$n.json; echo "dist N=$n rc=${PIPESTATUS[0]}")
+done
+python - <<'PY'
+import json
+for n in (2, 4):
+    for wl in ("cfg2", "dist"):
+        try:
+            d = json.load(open(f"gpurun_out/rehearsal_{wl}_{n}.json"))
+            print(wl, n, "value", d["value"], d["unit"], "ms_per_step", d["ms_per_step"], "ranks_alive", d.get("ranks_alive"), "gather_error", str(d.get("gather_error"))[:80], "scaling", d.get("scaling"))
+        except Exception as e:
+            print(wl, n, "NO LINE:", e)
 PY
-done 2>&1 | tee gpurun_out/topology_wide_kernels.txt
+tail -3 gpurun_out/rehearsal_*_4.err | cut -c1-300
