@@ -56,7 +56,7 @@ rpmc sq2 $SQ2
 # dist_trajectory at the shapes the projections call it with, under every kernel choice
 (timeout 300 python tools/dist_shapes_probe.py > gpurun_out/dist_shapes_probe.txt 2>&1)
 # random parity sweeps on this build: the voxelizer (automatic mode and the workgroup-per-item kernel) and dist_trajectory
-(timeout 600 python tests/sweep_gpu_random.py 9000 600; MKAMD_TILE_ITEMS=1 timeout 300 python tests/sweep_gpu_random.py 9600 200; timeout 600 python tests/sweep_gpu_dist.py 0 600; timeout 600 python tests/sweep_gpu_reduction.py 0 600; timeout 600 python tests/sweep_gpu_contacts.py 0 600) > gpurun_out/random_sweeps.txt 2>&1
+(timeout 600 python tests/sweep_gpu_random.py 9000 600; MKAMD_TILE_ITEMS=1 timeout 300 python tests/sweep_gpu_random.py 9600 200; timeout 600 python tests/sweep_gpu_dist.py 0 600; timeout 600 python tests/sweep_gpu_reduction.py 0 600; timeout 600 python tests/sweep_gpu_contacts.py 0 600; timeout 600 python tests/sweep_gpu_topology.py 0 1000) > gpurun_out/random_sweeps.txt 2>&1
 # the device XTC decoder: kernels alone per chunk size
 (timeout 200 python tools/xtc_gpu_probe.py > gpurun_out/xtc_gpu_probe.txt 2>&1)
 (timeout 600 python tools/reduction_probe.py > gpurun_out/reduction_probe.txt 2>&1)
