@@ -773,3 +773,15 @@ def test_clock_probe_reports_a_plausible_shader_clock():
     with pytest.raises(Exception):
         ctx.clock_probe_dev(st.cuda_stream, 0, ticks.data_ptr())
 
+
+
+def test_random_topology_calls_with_wide_atoms_split_fixup_equals_k_tail_equals_plain():
+    """Round 6 (late): a topology call whose molecule has wide sigmas re-decides its cut-off shell in launches of its own (k_exact_shells lists
+    the hits, k_exact_redo recomputes each with a wave per 2 048-atom slice, joined by an atomic maximum).  Sixty random calls of
+    tests/sweep_gpu_topology.py (50 ... 7 000 atoms, wide atoms on lattice points nudged by ulps: hundreds of hits per call): the split form,
+    the hits recomputed inside k_tail and the plain call agree bit for bit (the evidence session runs 1 000; profiles/r6_random_sweep_topology.txt: 6 000)."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "sweep_gpu_topology.py"), "100000", "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "60 of 60 calls bit-identical" in r.stdout
