@@ -61,7 +61,11 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     // DIST_PREFER_ROWS (tests): the row kernel wherever it applies, as in rounds 4-5.
     const int jpl_any = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
     const bool small_result = (double)F * (double)n1 * (double)n2 * 4.0 < 268435456.0;
-    const bool rows_ok = jpl_any >= 2 || (jpl_any == 1 && ((avoid & DIST_PREFER_ROWS) || (n2 >= 128 && !small_result)));
+    // Calls of FEW frames (one structure, a handful of poses): the tile kernel and the block-per-frame kernel run their lanes / blocks along frames
+    // (3 000 x 300 atoms, one frame: 37 us in the tile kernel whatever F <= 64 is); the row kernel's lanes run along the second atoms
+    // (profiles/r6_dist_few_frames_probe.txt)
+    const bool few_frames = F <= 32;
+    const bool rows_ok = jpl_any >= 2 || (jpl_any == 1 && ((avoid & DIST_PREFER_ROWS) || few_frames || (n2 >= 128 && !small_result)));
     const int rows_jpl = rows_ok ? jpl_any : 0;
     const bool rect_first = !selfdist && !no_rect && ((jpl_any >= 1 && !rows_ok) || (jpl_any == 0 && !pbc && n2 >= DT && small_result && !no_rows));
     if (!no_frame && !selfdist && rows_jpl == 0 && !rect_first && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
