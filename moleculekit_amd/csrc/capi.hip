@@ -116,6 +116,7 @@ struct mkamd_ctx {
     int reduction_block = 0;               // k_dist_reduction_closest's first-group atoms in registers (mkamd_ctx_set_reduction_block)
     char last_dist_kernel[96] = "";        // what the last dist_trajectory call launched (mkamd_ctx_last_dist_kernel)
     void note_dist_kernel(const char* name) { snprintf(last_dist_kernel, sizeof last_dist_kernel, "%s", name); }
+    void note_dist_kernel_append(const char* more) { strncat(last_dist_kernel, more, sizeof last_dist_kernel - strlen(last_dist_kernel) - 1); }
     bool tail_reports = false;             // the last lattice call's k_tail writes FB_TILES_DONE / FB_TAIL_WROTE with seq_next
     unsigned seq_next = 0, seq_counter = 0; // sequence number handed to the next lattice call (0 = none)
     int ensure(int slot, size_t bytes, void** ptr, int set = 0)
@@ -683,7 +684,7 @@ try {
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (avoid_mask < 0 || avoid_mask > 63) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores), 16 (the row kernel wherever it applies), 32 (host calls upload the whole coordinate array)");
+    if (avoid_mask < 0 || avoid_mask > 127) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores), 16 (the row kernel wherever it applies), 32 (host calls upload the whole coordinate array), 64 (selfdist calls of few frames keep the pair-table kernel)");
     ctx->dist_avoid = avoid_mask;
     return MKAMD_OK;
 } MK_API_CATCH

@@ -33,7 +33,8 @@ inline int dist_rows_jpl(long long n1, long long n2, long long F)
 
 // dist_trajectory on device pointers (coords [N,3,F], box [3,F], sel/chains uint32) -> out [F, P]
 // `avoid`: kernels NOT to take (tests walk every kernel over the same shapes; A-B timing) -- the choice below is made among the rest
-enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8, DIST_PREFER_ROWS = 16 };
+enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8, DIST_PREFER_ROWS = 16, DIST_NO_PACKING = 32 /* capi.hip: host calls */,
+       DIST_AVOID_SELF_ROWS = 64 /* selfdist calls of few frames keep the pair-table kernel */ };
 template <class BE>
 int run_dist_trajectory(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                         const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
@@ -45,6 +46,19 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     if (P > 0x7fffffffLL * 32) { err = "too many pairs"; return ST_EINVAL; }
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     int st;
+    // selfdist on ONE structure or a handful of frames: the rectangle through the row kernel, then its (i, j > i) part into the condensed order
+    // (k_triangle_pack; the pair-table kernel's lanes are frames: 5 000 atoms of one frame 0.63 ms against 0.05)
+    // (measured, profiles/r6_dist_few_frames_probe.txt: this way costs ~F x the rectangle, the pair-table kernel the same for any F <= 64 -- they meet at
+    //  6-8 frames: 1 000 atoms 15 + 3.1 F against 33 us, 5 000 atoms 84 F against 627 us)
+    if (selfdist && F <= 6 && !(avoid & (DIST_AVOID_SELF_ROWS | DIST_AVOID_ROWS)) && n1 >= 128 && n2 >= 128 && dist_rows_jpl(n1, n2, F) >= 1 &&
+        (double)F * (double)n1 * (double)n2 * 4.0 <= 1073741824.0) {
+        void* rect = nullptr;
+        if ((st = be.ensure(WS_D_MASK, (size_t)F * (size_t)n1 * (size_t)n2 * 4, &rect, 0))) return st;
+        if ((st = run_dist_trajectory(be, coords, F, box, sel1, n1, sel2, n2, chains, 0, pbc, squared, (float*)rect, err, (avoid & ~DIST_AVOID_ROWS) | DIST_PREFER_ROWS))) return st;
+        be.note_dist_kernel_append(" + mkamd::k_triangle_pack");
+        return be.launch(k_triangle_pack, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535), (unsigned)std::min<long long>(F, 32)), dim3(256),
+                         (const float*)rect, n1, n2, F, P, out);
+    }
     // every sel1 atom against every sel2 atom (no selfdist: the common MetricDistance call): the rectangular kernel -- no pair
     // table, the second atoms of a tile stay in registers while the block walks DR_I first atoms (dist_kernels.h)
     // (both tile kernels: a 1-D grid padded to a multiple of 8, every XCD a contiguous range of tiles -- xcd_contiguous_tile)

@@ -26,6 +26,7 @@ struct EmuBackend {
     void note_error_flag_mirrored(bool) {}
     void note_tail_reports(bool) {}
     void note_dist_kernel(const char*) {}
+    void note_dist_kernel_append(const char*) {}
     int compute_units() const { return 256; }
     const volatile unsigned* feedback_host() const { return feedback; }
     unsigned* feedback_dev() { return feedback; }

@@ -796,3 +796,25 @@ def test_host_calls_pack_the_selected_atoms_before_the_upload():
     assert not on                                                           # an array of less than a megabyte: as it is
     on, uniq, packed, _, _ = E.pack_atoms(c, [np.array([5], np.uint32)])
     assert on and uniq.tolist() == [5] and np.array_equal(packed[0], c[5])
+
+
+def test_selfdist_of_few_frames_goes_through_the_row_kernel_and_the_triangle_pack():
+    """Round 6 (late): a selfdist call of at most 6 frames with >= 128 atoms on both sides computes the n1 x n2 rectangle with the row kernel
+    (lanes along the second atoms) and copies its (i, j > i) part into the reference's condensed order (k_triangle_pack) -- the pair-table
+    kernel runs its lanes along frames.  Equal and UNEQUAL selections (pairs i < j over sel1[i], sel2[j]: distance_utils.pyx:140-150), one and
+    three frames, periodic with mixed chains and open, squared; the oracle's bits, and the pair-table kernel's (avoid bit 64) on the same call."""
+    rng = np.random.default_rng(91)
+    N = 500
+    ch = rng.integers(0, 3, size=N).astype(np.uint32)
+    sa = rng.permutation(N)[:150].astype(np.uint32)
+    sb = rng.permutation(N)[:190].astype(np.uint32)
+    for F in (1, 3):
+        c = rng.uniform(-25, 25, size=(N, 3, F)).astype(np.float32)
+        b = rng.uniform(18, 30, size=(3, F)).astype(np.float32)
+        for a1, a2 in ((sa, sa), (sa, sb), (sb, sa)):
+            for pbc in (True, False):
+                want = oracle.dist_trajectory(c, b, a1, a2, ch, True, pbc)
+                assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc), want), (F, len(a1), len(a2), pbc)
+                assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc, avoid=64), want)
+        want = oracle.dist_trajectory(c, b, sa, sa, ch, True, True, squared=True)
+        assert np.array_equal(E.dist_trajectory(c, b, sa, sa, ch, True, True, squared=True), want)
