@@ -838,7 +838,7 @@ def test_reductions_of_few_frames_take_lanes_along_the_second_groups():
         for block in (-2, 0):
             ctx.set_reduction_block(block)
             got = np.full_like(exp, -1.0)
-            du.dist_trajectory_reduction(c, b, res[:40], res, chs[:40], chs, False, True, m, 0, 0, got)
+            du.dist_trajectory_reduction(c, b, res[:40], res, chs[:40], chs, False, True, m, 0, 0, got, ctx=ctx)
             assert np.array_equal(got, exp, equal_nan=True), block
     finally:
         ctx.set_reduction_block(0)
@@ -863,18 +863,18 @@ def test_dist_trajectory_of_few_frames_takes_lanes_along_atoms():
             for a1, a2 in ((sa, sa), (sb, sa)) if F <= 7 else ((sb, sb),):
                 exp = oracle.dist_trajectory(c, b, a1, a2, ch, True, pbc)
                 got = np.full_like(exp, -1.0)
-                du.dist_trajectory(c, b, a1, a2, ch, True, pbc, got)
+                du.dist_trajectory(c, b, a1, a2, ch, True, pbc, got, ctx=ctx)
                 assert np.array_equal(got, exp), ("self", F, pbc, len(a1), len(a2))
                 assert ("k_triangle_pack" in ctx.last_dist_kernel()) == (F <= 6), (F, ctx.last_dist_kernel())
                 if F <= 6:
                     ctx.set_dist_kernels(64)
                     try:
-                        du.dist_trajectory(c, b, a1, a2, ch, True, pbc, got)
+                        du.dist_trajectory(c, b, a1, a2, ch, True, pbc, got, ctx=ctx)
                     finally:
                         ctx.set_dist_kernels(0)
                     assert np.array_equal(got, exp) and "k_dist_pairs" in ctx.last_dist_kernel()
-            exp = oracle.dist_trajectory(c, b, sa[:300], sb[:200], ch, False, pbc)          # rows of one atom per lane, a small result
+            exp = oracle.dist_trajectory(c, b, sa[:300], sb[:60], ch, False, pbc)           # rows of one atom per lane, a small result
             got = np.full_like(exp, -1.0)
-            du.dist_trajectory(c, b, sa[:300], sb[:200], ch, False, pbc, got)
+            du.dist_trajectory(c, b, sa[:300], sb[:60], ch, False, pbc, got, ctx=ctx)
             assert np.array_equal(got, exp), ("rect", F, pbc)
             assert ("k_dist_rows" in ctx.last_dist_kernel()) == (F <= 32), (F, ctx.last_dist_kernel())
