@@ -103,8 +103,8 @@ int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_ba
  * kernel (rectangular calls with rows of >= 64 second atoms), 4 the rectangular tile kernel, 8 the row kernel's 16-byte stores,
  * 16 (not an exclusion) the row kernel wherever it applies, also where the tile kernel is the measured better choice
  * (selfdist always takes the pair-table kernel); 32 (not a kernel): the host entry points upload the whole coordinate array instead
- * of the selected atoms' rows (csrc/host_pack.h); 64: selfdist calls of at most 6 frames keep the pair-table kernel instead of
- * going through the row kernel and k_triangle_pack.  Calls of at most 32 frames take the row kernel wherever it applies (its lanes
+ * of the selected atoms' rows (csrc/host_pack.h); 64: selfdist calls keep the pair-table kernel where the triangular form of the row kernel
+ * would be taken (selections of >= 700 atoms up to 32 frames, of >= 1 500 atoms at any frame count).  Calls of at most 32 frames take the row kernel wherever it applies (its lanes
  * run along the second atoms; the other kernels' along frames).  Every kernel produces the same
  * bits; for tests (every kernel over the same shapes) and same-box A-B timing. */
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask);

@@ -554,10 +554,15 @@ MK_KERNEL(256) void k_sel_to_frames(const float* __restrict__ coords, long long 
 // + k: ONE store of 1 KB per first atom, 16 bytes per lane at whatever alignment the row has).  Wave tasks are numbered in the
 // result's memory order (frame, then chunk of first atoms, then block of second atoms) and dealt to the XCDs in contiguous
 // ranges, like the tiles of the other kernels.
-template <bool PBC, int JPL, bool VEC>
+// TRI (round 6, late): the selfdist form -- only the pairs (i, j > i) exist, and they go out in the reference's condensed order
+// (distance_utils.pyx:140-150: row i starts at i (n2 - 1) - i (i - 1) / 2 and holds j = i + 1 ... n2 - 1).  Same first / second atom, same
+// arithmetic and wrap rule as the rectangle's pair (i, j): the same bits.  Tasks wholly on or below the diagonal leave at once, rows of a
+// task on it store what lies above; P = the condensed row length.  (The pair-table kernel this replaces for few frames and for large
+// selections runs its lanes along frames and loads two table entries and six gathered coordinates per pair.)
+template <bool PBC, int JPL, bool VEC, bool TRI = false>
 MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, const unsigned* __restrict__ c1, const float* __restrict__ T2,
                                 long long np2, const unsigned* __restrict__ c2, const float* __restrict__ box, long long F, long long n1,
-                                long long n2, int squared, float* __restrict__ out)
+                                long long n2, int squared, float* __restrict__ out, long long P_tri = 0)
 {
     static_assert(!VEC || JPL == 4, "four neighbours per lane");
     const long long NJ = (n2 + 64 * JPL - 1) / (64 * JPL), NI = (n1 + ROWS_CI - 1) / ROWS_CI;
@@ -568,6 +573,9 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
     if (task >= tasks) return;
     const int lane = threadIdx.x & (WAVE - 1);
     const long long jb = task % NJ, ic = (task / NJ) % NI, f = task / (NJ * NI);
+    if constexpr (TRI) {
+        if (jb * 64 * JPL + 64 * JPL - 1 <= ic * ROWS_CI) return;   // wave-uniform: no pair of this task lies above the diagonal
+    }
     const long long j0 = jb * 64 * JPL + (VEC ? 4 * lane : lane);
     constexpr int JS = VEC ? 1 : 64;                                // distance between a lane's second atoms
     float B[JPL][3];
@@ -585,12 +593,15 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
         bx = box[0 * F + f]; by = box[1 * F + f]; bz = box[2 * F + f];
         ibx = mk_fdiv_rn(1.f, bx); iby = mk_fdiv_rn(1.f, by); ibz = mk_fdiv_rn(1.f, bz);
     }
-    const long long P = n1 * n2;
+    const long long P = TRI ? P_tri : n1 * n2;
     const long long i_begin = ic * ROWS_CI, i_end = i_begin + ROWS_CI < n1 ? i_begin + ROWS_CI : n1;
     const float* __restrict__ t1 = T1 + (size_t)f * 3 * (size_t)np1;
-    float* __restrict__ o = out + (size_t)f * (size_t)P + (size_t)i_begin * (size_t)n2 + (size_t)j0;
+    float* __restrict__ o = out + (size_t)f * (size_t)P + (TRI ? (size_t)0 : (size_t)i_begin * (size_t)n2 + (size_t)j0);
     const bool whole = jb * 64 * JPL + 64 * JPL <= n2;              // wave-uniform: every lane's every pair exists
-    for (long long i = i_begin; i < i_end; ++i, o += n2) {
+    for (long long i = i_begin; i < i_end; ++i, o += (TRI ? 0 : n2)) {
+        if constexpr (TRI) {
+            if (jb * 64 * JPL + 64 * JPL - 1 <= i) break;            // wave-uniform: this row and the ones after it end left of the task
+        }
         const float xa = t1[i], ya = t1[(size_t)np1 + (size_t)i], za = t1[2 * (size_t)np1 + (size_t)i];   // wave-uniform: scalar loads
         const unsigned ca = PBC ? c1[i] : 0u;
         float d[JPL];
@@ -615,7 +626,23 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
                 for (int k = 0; k < JPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
             }
         }
-        if constexpr (VEC) {
+        if constexpr (TRI) {
+            // the condensed row of i: element (i, j) at full (n2 - 1) - full (full - 1) / 2 + (j - i - 1), full = min(i, n2)
+            const long long full = i < n2 ? i : n2;
+            float* __restrict__ r = o + (full * (n2 - 1) - full * (full - 1) / 2 - i - 1);       // (+ j: only j > i is ever formed into an address below)
+            if constexpr (VEC) {
+                if (j0 > i && (whole || j0 + 3 < n2)) mk_store_f4_dword_aligned(r + j0, make_float4(d[0], d[1], d[2], d[3]));
+                else {
+#pragma unroll
+                    for (int k = 0; k < JPL; ++k)
+                        if (j0 + k > i && j0 + k < n2) r[j0 + k] = d[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < JPL; ++k)
+                    if (j0 + 64 * k > i && j0 + 64 * k < n2) r[j0 + 64 * k] = d[k];
+            }
+        } else if constexpr (VEC) {
             // (rows of any length and any float* result: a row starts on 4 bytes only when n2 is not a multiple of four;
             //  non-temporal stores measured: opposite signs for the two modes)
             if (whole || j0 + 3 < n2) mk_store_f4_dword_aligned(o, make_float4(d[0], d[1], d[2], d[3]));
@@ -1156,22 +1183,6 @@ MK_KERNEL(CF_WAVES * WAVE) void k_contacts_fill_rect(long long fc, long long fc_
             }
         }
     }
-}
-
-// selfdist calls of few frames through the rectangular row kernel (round 6, late): the pair-table kernel runs its lanes along frames -- one
-// frame of 5 000 atoms: 0.63 ms for 12.5 M distances -- while the row kernel (lanes along the second atoms) writes the full n1 x n2 rectangle of
-// a frame at 1 T distances/s.  The (i, j > i) part of that rectangle IS the selfdist result (same first / second atom, same arithmetic, same
-// wrap rule); this kernel copies it into the reference's condensed order (distance_utils.pyx:140-150).  Lanes along j: both sides coalesced.
-MK_KERNEL(256) void k_triangle_pack(const float* __restrict__ rect /* [F, n1, n2] */, long long n1, long long n2, long long F, long long P,
-                                    float* __restrict__ out /* [F, P] */)
-{
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n2) return;
-    for (long long f = blockIdx.z; f < F; f += gridDim.z)
-        for (long long i = blockIdx.y; i < n1 && i < j; i += gridDim.y) {
-            const long long full = i < n2 ? i : n2;
-            out[f * P + full * (n2 - 1) - full * (full - 1) / 2 + (j - i - 1)] = rect[(f * n1 + i) * n2 + j];
-        }
 }
 
 // Centre of mass of every group in every frame (distance_utils.pyx:160-183): sequential float32

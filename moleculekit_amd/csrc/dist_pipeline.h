@@ -33,6 +33,11 @@ inline int dist_rows_jpl(long long n1, long long n2, long long F)
 
 // dist_trajectory on device pointers (coords [N,3,F], box [3,F], sel/chains uint32) -> out [F, P]
 // `avoid`: kernels NOT to take (tests walk every kernel over the same shapes; A-B timing) -- the choice below is made among the rest
+// selfdist through the triangular row kernel (measured against the pair-table kernel per frame count and selection size, profiles/r6_dist_self_tri_probe.txt:
+// 450 atoms: the pair table at every frame count (12.6 against 14.2 us at one frame); 1 000: the rows up to 32 frames (15 against 35 us at one, 26 against 37 at
+// 32; even at 64); 2 000 and 5 000: the rows at every frame count (5 000 atoms: 27 against 624 us at one frame, 767 against 1 621 at 64))
+constexpr long long TRI_FEW_FRAMES = 32, TRI_MANY = 700;   // calls of up to 32 frames with selections of at least 700 atoms ...
+constexpr long long TRI_BIG = 1500;                        // ... and calls of any length whose selections are at least this long
 enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8, DIST_PREFER_ROWS = 16, DIST_NO_PACKING = 32 /* capi.hip: host calls */,
        DIST_AVOID_SELF_ROWS = 64 /* selfdist calls of few frames keep the pair-table kernel */ };
 template <class BE>
@@ -46,19 +51,12 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     if (P > 0x7fffffffLL * 32) { err = "too many pairs"; return ST_EINVAL; }
     if (F > 0x3fffffffLL) { err = "too many frames (>= 2^30)"; return ST_EINVAL; }
     int st;
-    // selfdist on ONE structure or a handful of frames: the rectangle through the row kernel, then its (i, j > i) part into the condensed order
-    // (k_triangle_pack; the pair-table kernel's lanes are frames: 5 000 atoms of one frame 0.63 ms against 0.05)
-    // (measured, profiles/r6_dist_few_frames_probe.txt: this way costs ~F x the rectangle, the pair-table kernel the same for any F <= 64 -- they meet at
-    //  6-8 frames: 1 000 atoms 15 + 3.1 F against 33 us, 5 000 atoms 84 F against 627 us)
-    if (selfdist && F <= 6 && !(avoid & (DIST_AVOID_SELF_ROWS | DIST_AVOID_ROWS)) && n1 >= 128 && n2 >= 128 && dist_rows_jpl(n1, n2, F) >= 1 &&
-        (double)F * (double)n1 * (double)n2 * 4.0 <= 1073741824.0) {
-        void* rect = nullptr;
-        if ((st = be.ensure(WS_D_MASK, (size_t)F * (size_t)n1 * (size_t)n2 * 4, &rect, 0))) return st;
-        if ((st = run_dist_trajectory(be, coords, F, box, sel1, n1, sel2, n2, chains, 0, pbc, squared, (float*)rect, err, (avoid & ~DIST_AVOID_ROWS) | DIST_PREFER_ROWS))) return st;
-        be.note_dist_kernel_append(" + mkamd::k_triangle_pack");
-        return be.launch(k_triangle_pack, dim3((unsigned)ceil_div(n2, 256), (unsigned)std::min<long long>(n1, 65535), (unsigned)std::min<long long>(F, 32)), dim3(256),
-                         (const float*)rect, n1, n2, F, P, out);
-    }
+    // selfdist through the row kernel's triangular form (k_dist_rows<.., TRI>: lanes along the second atoms, the condensed order written directly) --
+    // on ONE structure or a handful of frames, where the pair-table kernel's lanes (frames) are starved (5 000 atoms of one frame: 0.63 ms), and
+    // for large selections at any frame count, where its table loads and gathers cost more than the half tiles the triangle wastes
+    // (profiles/r6_dist_few_frames_probe.txt)
+    const bool tri_rows = selfdist && !(avoid & (DIST_AVOID_SELF_ROWS | DIST_AVOID_ROWS)) && n1 >= 128 && n2 >= 128 && dist_rows_jpl(n1, n2, F) >= 1 &&
+                          ((F <= TRI_FEW_FRAMES && n1 >= TRI_MANY && n2 >= TRI_MANY) || (n1 >= TRI_BIG && n2 >= TRI_BIG) || (avoid & DIST_PREFER_ROWS));
     // every sel1 atom against every sel2 atom (no selfdist: the common MetricDistance call): the rectangular kernel -- no pair
     // table, the second atoms of a tile stay in registers while the block walks DR_I first atoms (dist_kernels.h)
     // (both tile kernels: a 1-D grid padded to a multiple of 8, every XCD a contiguous range of tiles -- xcd_contiguous_tile)
@@ -73,13 +71,13 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     //  * rows too short for it go to the block-per-frame kernel (300 x 30: 33 against 36 us), except open calls with full 64-wide tiles and
     //    a small result, where the tile kernel is 15-27 % faster (300 x 100: 75 against 88 us, 100 x 100: 27 against 36).
     // DIST_PREFER_ROWS (tests): the row kernel wherever it applies, as in rounds 4-5.
-    const int jpl_any = (!selfdist && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
+    const int jpl_any = ((!selfdist || tri_rows) && !no_rows) ? dist_rows_jpl(n1, n2, F) : 0;
     const bool small_result = (double)F * (double)n1 * (double)n2 * 4.0 < 268435456.0;
     // Calls of FEW frames (one structure, a handful of poses): the tile kernel and the block-per-frame kernel run their lanes / blocks along frames
     // (3 000 x 300 atoms, one frame: 37 us in the tile kernel whatever F <= 64 is); the row kernel's lanes run along the second atoms
     // (profiles/r6_dist_few_frames_probe.txt)
     const bool few_frames = F <= 32;
-    const bool rows_ok = jpl_any >= 2 || (jpl_any == 1 && ((avoid & DIST_PREFER_ROWS) || few_frames || (n2 >= 128 && !small_result)));
+    const bool rows_ok = jpl_any >= 2 || (jpl_any == 1 && ((avoid & DIST_PREFER_ROWS) || few_frames || tri_rows || (n2 >= 128 && !small_result)));
     const int rows_jpl = rows_ok ? jpl_any : 0;
     const bool rect_first = !selfdist && !no_rect && ((jpl_any >= 1 && !rows_ok) || (jpl_any == 0 && !pbc && n2 >= DT && small_result && !no_rows));
     if (!no_frame && !selfdist && rows_jpl == 0 && !rect_first && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
@@ -106,7 +104,7 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
         if (big_p) return four ? go(k_dist_frame<false, 512, 4, long long>) : go(k_dist_frame<false, 4096, 1, long long>);
         return four ? go(k_dist_frame<false, 512, 4, unsigned>) : go(k_dist_frame<false, 4096, 1, unsigned>);
     }
-    if (!selfdist && !no_rows) {
+    if ((!selfdist || tri_rows) && !no_rows) {
         // rows of >= 64 second atoms are written directly by a wave per frame, from selections turned frame-major first
         const int jpl = rows_jpl;
         if (jpl) {
@@ -123,14 +121,20 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
             const dim3 grid(padded8(ceil_div(tasks, 4))), block(256);
             auto go = [&](auto kernel) {
                 return be.launch(kernel, grid, block, (const float*)t1, np1, (const unsigned*)cs1, (const float*)t2, np2, (const unsigned*)cs2, box, F,
-                                 n1, n2, squared, out);
+                                 n1, n2, squared, out, P);
             };
             const bool no_vec = (avoid & DIST_AVOID_VEC) != 0;
             const bool vec = jpl == 4 && !no_vec;      // (16-byte stores at 4-byte alignment: rows of any length, any float* result)
             {
                 char nm[96];
-                snprintf(nm, sizeof nm, "mkamd::k_sel_to_frames + mkamd::k_dist_rows<%s, %d, %s>", pbc ? "true" : "false", jpl, vec ? "true" : "false");
+                snprintf(nm, sizeof nm, "mkamd::k_sel_to_frames + mkamd::k_dist_rows<%s, %d, %s%s>", pbc ? "true" : "false", jpl, vec ? "true" : "false", selfdist ? ", true" : "");
                 be.note_dist_kernel(nm);
+            }
+            if (selfdist) {
+                if (pbc) return vec ? go(k_dist_rows<true, 4, true, true>) : jpl == 4 ? go(k_dist_rows<true, 4, false, true>) : jpl == 2 ? go(k_dist_rows<true, 2, false, true>)
+                                                                                                                                    : go(k_dist_rows<true, 1, false, true>);
+                return vec ? go(k_dist_rows<false, 4, true, true>) : jpl == 4 ? go(k_dist_rows<false, 4, false, true>) : jpl == 2 ? go(k_dist_rows<false, 2, false, true>)
+                                                                                                                             : go(k_dist_rows<false, 1, false, true>);
             }
             if (pbc) return vec ? go(k_dist_rows<true, 4, true>) : jpl == 4 ? go(k_dist_rows<true, 4, false>) : jpl == 2 ? go(k_dist_rows<true, 2, false>)
                                                                                                                           : go(k_dist_rows<true, 1, false>);

@@ -21,7 +21,7 @@ for seed in range(first, first + count):
     b = (L * rng.uniform(0.8, 1.2, size=(3, F))).astype(np.float32)
     ch = rng.integers(0, int(rng.integers(1, 6)), size=N).astype(np.uint32)
     selfdist = bool(rng.random() < 0.25)
-    n2 = int(rng.choice([1, 5, 52, 63, 64, 65, 100, 128, 200, 256, 260, 500, 1000]))
+    n2 = int(rng.choice([1, 5, 52, 63, 64, 65, 100, 128, 200, 256, 260, 500, 720, 1000, 1600]))
     n1 = n2 if selfdist else int(rng.choice([1, 7, 16, 17, 40, 100, 200]))
     n1, n2 = min(n1, 4 * N), min(n2, 4 * N)
     s2 = rng.integers(0, N, size=n2).astype(np.uint32)

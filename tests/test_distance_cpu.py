@@ -798,23 +798,33 @@ def test_host_calls_pack_the_selected_atoms_before_the_upload():
     assert on and uniq.tolist() == [5] and np.array_equal(packed[0], c[5])
 
 
-def test_selfdist_of_few_frames_goes_through_the_row_kernel_and_the_triangle_pack():
-    """Round 6 (late): a selfdist call of at most 6 frames with >= 128 atoms on both sides computes the n1 x n2 rectangle with the row kernel
-    (lanes along the second atoms) and copies its (i, j > i) part into the reference's condensed order (k_triangle_pack) -- the pair-table
-    kernel runs its lanes along frames.  Equal and UNEQUAL selections (pairs i < j over sel1[i], sel2[j]: distance_utils.pyx:140-150), one and
+def test_selfdist_of_few_frames_goes_through_the_triangular_row_kernel():
+    """Round 6 (late): a selfdist call of large selections (>= 700 atoms up to 32 frames, >= 1 500 at any frame count) takes the row kernel's triangular
+    form (k_dist_rows<.., TRI>: lanes along the second atoms, tasks below the diagonal skipped, the reference's condensed order written
+    directly) -- the pair-table kernel runs its lanes along frames.  Equal and UNEQUAL selections (pairs i < j over sel1[i], sel2[j]: distance_utils.pyx:140-150), one and
     three frames, periodic with mixed chains and open, squared; the oracle's bits, and the pair-table kernel's (avoid bit 64) on the same call."""
     rng = np.random.default_rng(91)
     N = 500
     ch = rng.integers(0, 3, size=N).astype(np.uint32)
-    sa = rng.permutation(N)[:150].astype(np.uint32)
-    sb = rng.permutation(N)[:190].astype(np.uint32)
+    sa = rng.permutation(N)[:250].astype(np.uint32)              # rows of four atoms per lane, 16-byte stores
+    sb = rng.permutation(N)[:190].astype(np.uint32)              # one atom per lane
+    sc = rng.permutation(N)[:330].astype(np.uint32)              # two
     for F in (1, 3):
         c = rng.uniform(-25, 25, size=(N, 3, F)).astype(np.float32)
         b = rng.uniform(18, 30, size=(3, F)).astype(np.float32)
-        for a1, a2 in ((sa, sa), (sa, sb), (sb, sa)):
+        for a1, a2 in ((sa, sa), (sa, sb), (sb, sa), (sc, sc), (sb, sc)):
             for pbc in (True, False):
                 want = oracle.dist_trajectory(c, b, a1, a2, ch, True, pbc)
-                assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc), want), (F, len(a1), len(a2), pbc)
+                # (the library's own choice takes the triangular form from 700 atoms on: avoid bit 16 = the row kernel wherever it applies)
+                assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc, avoid=16), want), (F, len(a1), len(a2), pbc)
+                assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc, avoid=16 | 8), want)      # (without the 16-byte stores)
                 assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc, avoid=64), want)
+                assert np.array_equal(E.dist_trajectory(c, b, a1, a2, ch, True, pbc), want)
         want = oracle.dist_trajectory(c, b, sa, sa, ch, True, True, squared=True)
-        assert np.array_equal(E.dist_trajectory(c, b, sa, sa, ch, True, True, squared=True), want)
+        assert np.array_equal(E.dist_trajectory(c, b, sa, sa, ch, True, True, squared=True, avoid=16), want)
+    # ... and at the library's own choice: 720 atoms of one frame
+    big = rng.permutation(N * 2)[:720].astype(np.uint32)
+    c = rng.uniform(-25, 25, size=(2 * N, 3, 1)).astype(np.float32)
+    b = rng.uniform(18, 30, size=(3, 1)).astype(np.float32)
+    ch2 = rng.integers(0, 3, size=2 * N).astype(np.uint32)
+    assert np.array_equal(E.dist_trajectory(c, b, big, big, ch2, True, True), oracle.dist_trajectory(c, b, big, big, ch2, True, True))

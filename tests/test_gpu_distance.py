@@ -846,27 +846,28 @@ def test_reductions_of_few_frames_take_lanes_along_the_second_groups():
 
 def test_dist_trajectory_of_few_frames_takes_lanes_along_atoms():
     """Round 6 (late): on one structure or a handful of frames the kernels whose lanes run along frames are starved.  Rectangular calls of <= 32
-    frames take the row kernel wherever it applies; selfdist calls of <= 6 frames with >= 128 atoms go through it and k_triangle_pack (the
-    (i, j > i) part of the rectangle in the reference's condensed order).  Both sides of both thresholds, equal and unequal selections, periodic
+    frames take the row kernel wherever it applies; selfdist calls of <= 32 frames with >= 700 atoms (>= 1 500: any frame count) take its triangular form (tasks below the
+    diagonal skipped, the reference's condensed order written directly).  Both sides of both thresholds, equal and unequal selections, periodic
     with mixed chains and open: the oracle's bits, the kernel names the library reports, and the pair-table kernel (avoid bit 64) on the same call."""
     from moleculekit_amd import distance_utils as du, _lib
     ctx = _lib.default_context(0)
     rng = np.random.default_rng(71)
     N = 2500
     ch = rng.integers(0, 4, size=N).astype(np.uint32)
-    sa = rng.permutation(N)[:700].astype(np.uint32)
-    sb = rng.permutation(N)[:333].astype(np.uint32)
-    for F in (1, 6, 7, 32, 33):
+    sa = rng.permutation(N)[:900].astype(np.uint32)
+    sb = rng.permutation(N)[:720].astype(np.uint32)
+    for F in (1, 32, 33):
         c = rng.uniform(0, 50.0, size=(N, 3, F)).astype(np.float32)
         b = rng.uniform(35, 50, size=(3, F)).astype(np.float32)
         for pbc in (True, False):
-            for a1, a2 in ((sa, sa), (sb, sa)) if F <= 7 else ((sb, sb),):
+            for a1, a2 in ((sa, sa), (sb, sa)):
                 exp = oracle.dist_trajectory(c, b, a1, a2, ch, True, pbc)
                 got = np.full_like(exp, -1.0)
                 du.dist_trajectory(c, b, a1, a2, ch, True, pbc, got, ctx=ctx)
                 assert np.array_equal(got, exp), ("self", F, pbc, len(a1), len(a2))
-                assert ("k_triangle_pack" in ctx.last_dist_kernel()) == (F <= 6), (F, ctx.last_dist_kernel())
-                if F <= 6:
+                tri = ctx.last_dist_kernel().count(",") == 3                       # k_dist_rows<PBC, JPL, VEC, true>: the triangular form
+                assert tri == (F <= 32) and (tri or "k_dist_pairs" in ctx.last_dist_kernel()), (F, ctx.last_dist_kernel())
+                if tri:
                     ctx.set_dist_kernels(64)
                     try:
                         du.dist_trajectory(c, b, a1, a2, ch, True, pbc, got, ctx=ctx)
