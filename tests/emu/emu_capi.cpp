@@ -25,7 +25,7 @@ struct EmuBackend {
     CounterState& counter_state(int set) { return counters[set & 1]; }
     void note_error_flag_mirrored(bool) {}
     void note_tail_reports(bool) {}
-    void note_dist_kernel(const char*) {}
+    void note_dist_kernel(const char* name);                // (kept for the tests: which kernels run_dist_trajectory chose)
     void note_dist_kernel_append(const char*) {}
     int compute_units() const { return 256; }
     const volatile unsigned* feedback_host() const { return feedback; }
@@ -81,6 +81,11 @@ thread_local std::string g_err;
 extern "C" {
 
 const char* emu_last_error(void) { return g_err.c_str(); }
+static std::string g_last_dist_kernel;
+const char* emu_last_dist_kernel(void) { return g_last_dist_kernel.c_str(); }
+}
+void EmuBackend::note_dist_kernel(const char* name) { g_last_dist_kernel = name; }
+extern "C" {
 
 // mirrors mkamd_voxelize_lattice_host (pointers are host pointers; features is poisoned first)
 int emu_voxelize_lattice(int B, const float* coords, const long long* atom_offsets, const void* sigmas,

@@ -39,6 +39,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(_LIB)
         _lib.emu_last_error.restype = ctypes.c_char_p
+        _lib.emu_last_dist_kernel.restype = ctypes.c_char_p
     return _lib
 
 
@@ -175,6 +176,11 @@ def dist_trajectory(coords, box, sel1, sel2, chains, selfdist, pbc, squared=Fals
                                    ctypes.c_int(int(squared)), _p(out), ctypes.c_int(int(avoid)))
     assert st == 0, lib().emu_last_error()
     return out
+
+
+def last_dist_kernel():
+    """The kernels the last dist_trajectory call chose (run_dist_trajectory's note, as mkamd_ctx_last_dist_kernel reports it on the device)."""
+    return lib().emu_last_dist_kernel().decode()
 
 
 def dist_reduction(coords, box, groups1, groups2, ch1, ch2, selfdist, pbc, masses, r1, r2, pairs=False, block=0, n_atoms=None):

@@ -828,3 +828,31 @@ def test_selfdist_of_few_frames_goes_through_the_triangular_row_kernel():
     b = rng.uniform(18, 30, size=(3, 1)).astype(np.float32)
     ch2 = rng.integers(0, 3, size=2 * N).astype(np.uint32)
     assert np.array_equal(E.dist_trajectory(c, b, big, big, ch2, True, True), oracle.dist_trajectory(c, b, big, big, ch2, True, True))
+
+
+def test_which_kernel_dist_trajectory_takes_at_few_frames_and_for_large_selfdist_calls():
+    """The choice rule of run_dist_trajectory (round 6, measured: profiles/r6_dist_few_frames_probe.txt, r6_dist_self_tri_probe.txt), pinned on the CPU tier
+    through the emulator's backend: rectangular calls of <= 32 frames take the row kernel wherever it applies (33 frames of a small result: the tile
+    kernel); selfdist takes the row kernel's triangular form from 700 atoms up to 32 frames and from 1 500 atoms at any frame count, else the pair table;
+    rows too short for the row kernel: the block-per-frame kernel.  (One frame each of tiny coordinates: the choice depends on the shape alone.)"""
+    rng = np.random.default_rng(3)
+    N = 1600
+    ch = np.zeros(N, np.uint32)
+    sel = np.arange(N, dtype=np.uint32)
+
+    def chosen(n1, n2, F, selfd, pbc=False, avoid=0):
+        c = rng.uniform(0, 9, size=(N, 3, F)).astype(np.float32)
+        b = np.full((3, F), 30.0, np.float32)
+        E.dist_trajectory(c, b, sel[:n1], sel[:n2], ch, selfd, pbc, avoid=avoid)
+        return E.last_dist_kernel()
+
+    assert "k_dist_rows<false, 1, false>" in chosen(70, 60, 1, False)
+    assert "k_dist_rows<false, 1, false>" in chosen(70, 60, 32, False)
+    assert "k_dist_rect" in chosen(70, 60, 33, False)
+    assert "k_dist_frame" in chosen(70, 30, 1, False)
+    assert "k_dist_pairs" in chosen(450, 450, 1, True)
+    assert "k_dist_rows<false, 4, true, true>" in chosen(720, 720, 1, True)
+    assert "k_dist_rows<true, 4, true, true>" in chosen(720, 720, 2, True, pbc=True)
+    assert "k_dist_pairs" in chosen(720, 720, 1, True, avoid=64)
+    assert "k_dist_pairs" in chosen(720, 720, 33, True)
+    assert "k_dist_rows<false, 4, true, true>" in chosen(1536, 1536, 1, True)
