@@ -104,7 +104,9 @@ int mkamd_selftest_sqrt(mkamd_ctx* ctx, uint64_t* mismatches, uint32_t* first_ba
  * 16 (not an exclusion) the row kernel wherever it applies, also where the tile kernel is the measured better choice
  * (selfdist always takes the pair-table kernel); 32 (not a kernel): the host entry points upload the whole coordinate array instead
  * of the selected atoms' rows (csrc/host_pack.h); 64: selfdist calls keep the pair-table kernel where the triangular form of the row kernel
- * would be taken (selections of >= 700 atoms up to 32 frames, of >= 1 500 atoms at any frame count).  Calls of at most 32 frames take the row kernel wherever it applies (its lanes
+ * would be taken (selections of >= 700 atoms up to 32 frames, of >= 1 500 atoms at any frame count).  128: rectangular calls of few frames whose rows are too short for the row kernel and whose first selection is long keep the tile
+ * kernel instead of the row kernel with the selections swapped (lanes along the first selection, transposed stores).
+ * Calls of at most 32 frames take the row kernel wherever it applies (its lanes
  * run along the second atoms; the other kernels' along frames).  Every kernel produces the same
  * bits; for tests (every kernel over the same shapes) and same-box A-B timing. */
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask);

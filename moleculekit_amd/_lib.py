@@ -340,7 +340,7 @@ class Context:
     def set_dist_kernels(self, avoid_mask: int = 0):
         """Kernels dist_trajectory must NOT take (include/mkamd_distance.h): 1 block-per-frame, 2 rows, 4 rectangular tiles, 8 the
         row kernel's 16-byte stores; 16: the row kernel wherever it applies; 32: host calls upload the whole coordinate array (no packing
-        of the selected atoms' rows); 64: selfdist calls of few frames keep the pair-table kernel; 0 = free choice.  Same bits whichever runs (tests, A-B timing)."""
+        of the selected atoms' rows); 64: selfdist calls keep the pair-table kernel (no triangular row kernel); 128: short-row calls of few frames keep the tile kernel (no swapped row kernel); 0 = free choice.  Same bits whichever runs (tests, A-B timing)."""
         _check(load().mkamd_ctx_set_dist_kernels(self._h, int(avoid_mask)))
 
     def set_reduction_block(self, block: int = 0):

@@ -684,7 +684,7 @@ try {
 int mkamd_ctx_set_dist_kernels(mkamd_ctx* ctx, int avoid_mask)
 try {
     if (!ctx) return fail(MKAMD_EINVAL, "ctx is NULL");
-    if (avoid_mask < 0 || avoid_mask > 127) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores), 16 (the row kernel wherever it applies), 32 (host calls upload the whole coordinate array), 64 (selfdist calls of few frames keep the pair-table kernel)");
+    if (avoid_mask < 0 || avoid_mask > 255) return fail(MKAMD_EINVAL, "avoid mask: bits 1 (block-per-frame kernel), 2 (row kernel), 4 (rectangular tile kernel), 8 (16-byte row stores), 16 (the row kernel wherever it applies), 32 (host calls upload the whole coordinate array), 64 (selfdist calls keep the pair-table kernel), 128 (short-row calls of few frames keep the tile kernel)");
     ctx->dist_avoid = avoid_mask;
     return MKAMD_OK;
 } MK_API_CATCH

@@ -559,7 +559,11 @@ MK_KERNEL(256) void k_sel_to_frames(const float* __restrict__ coords, long long 
 // arithmetic and wrap rule as the rectangle's pair (i, j): the same bits.  Tasks wholly on or below the diagonal leave at once, rows of a
 // task on it store what lies above; P = the condensed row length.  (The pair-table kernel this replaces for few frames and for large
 // selections runs its lanes along frames and loads two table entries and six gathered coordinates per pair.)
-template <bool PBC, int JPL, bool VEC, bool TRI = false>
+// SWAPPED (round 6, late): the caller handed the selections over the other way round -- the rows walk the reference's SECOND selection, the lanes
+// run along its FIRST (a receptor's 20 000 atoms against a ligand's 40 on one frame: rows of 40 are too short for the lanes, rows of 20 000 are
+// not) -- and the pair (row r, lane atom c) goes to out[f, c * n_rows + r], the reference's (first, second) order.  The separation enters with the
+// opposite sign; every operation on it is odd (the subtraction, the quotient, both roundings, the shift) and it ends squared: the same bits.
+template <bool PBC, int JPL, bool VEC, bool TRI = false, bool SWAPPED = false>
 MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, const unsigned* __restrict__ c1, const float* __restrict__ T2,
                                 long long np2, const unsigned* __restrict__ c2, const float* __restrict__ box, long long F, long long n1,
                                 long long n2, int squared, float* __restrict__ out, long long P_tri = 0)
@@ -626,7 +630,15 @@ MK_KERNEL(256) void k_dist_rows(const float* __restrict__ T1, long long np1, con
                 for (int k = 0; k < JPL; ++k) d[k] = mk_fsqrt_rn(d[k]);
             }
         }
-        if constexpr (TRI) {
+        if constexpr (SWAPPED) {
+            static_assert(!TRI, "selfdist has no long side to swap to");
+            float* __restrict__ cbase = out + (size_t)f * (size_t)P + (size_t)i;                 // out[f, j * n1 + i]: the lane's atom is the reference's first
+#pragma unroll
+            for (int k = 0; k < JPL; ++k) {
+                const long long j = j0 + JS * k;
+                if (j < n2) cbase[(size_t)j * (size_t)n1] = d[k];
+            }
+        } else if constexpr (TRI) {
             // the condensed row of i: element (i, j) at full (n2 - 1) - full (full - 1) / 2 + (j - i - 1), full = min(i, n2)
             const long long full = i < n2 ? i : n2;
             float* __restrict__ r = o + (full * (n2 - 1) - full * (full - 1) / 2 - i - 1);       // (+ j: only j > i is ever formed into an address below)

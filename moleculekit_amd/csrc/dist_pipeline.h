@@ -39,7 +39,8 @@ inline int dist_rows_jpl(long long n1, long long n2, long long F)
 constexpr long long TRI_FEW_FRAMES = 32, TRI_MANY = 700;   // calls of up to 32 frames with selections of at least 700 atoms ...
 constexpr long long TRI_BIG = 1500;                        // ... and calls of any length whose selections are at least this long
 enum { DIST_AVOID_FRAME = 1, DIST_AVOID_ROWS = 2, DIST_AVOID_RECT = 4, DIST_AVOID_VEC = 8, DIST_PREFER_ROWS = 16, DIST_NO_PACKING = 32 /* capi.hip: host calls */,
-       DIST_AVOID_SELF_ROWS = 64 /* selfdist calls of few frames keep the pair-table kernel */ };
+       DIST_AVOID_SELF_ROWS = 64 /* selfdist calls of few frames keep the pair-table kernel */,
+       DIST_AVOID_SWAPPED = 128 /* short-row calls of few frames keep the tile kernel */ };
 template <class BE>
 int run_dist_trajectory(BE& be, const float* coords, long long F, const float* box, const unsigned* sel1, long long n1,
                         const unsigned* sel2, long long n2, const unsigned* chains, int selfdist, int pbc, int squared,
@@ -78,7 +79,13 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
     // (profiles/r6_dist_few_frames_probe.txt)
     const bool few_frames = F <= 32;
     const bool rows_ok = jpl_any >= 2 || (jpl_any == 1 && ((avoid & DIST_PREFER_ROWS) || few_frames || tri_rows || (n2 >= 128 && !small_result)));
-    const int rows_jpl = rows_ok ? jpl_any : 0;
+    // few frames, rows too short for the row kernel, a long first selection that the block-per-frame kernel cannot stage (a receptor x a ligand on one
+    // frame): the row kernel the other way round, lanes along the FIRST selection, transposed stores (profiles/r6_dist_short_rows_probe.txt: 20 000 x 40
+    // atoms of one frame 45 / 86 us in the tile kernel, 11 / 15 for the transposed shape)
+    // (results of up to 8 MB: the transposed stores are 4 bytes per 4 n2 -- 20 000 x 40 atoms x EIGHT frames, 26 MB: 90 us this way, 47 in the tile kernel)
+    const bool swapped = !selfdist && !no_rows && few_frames && jpl_any == 0 && !(avoid & DIST_AVOID_SWAPPED) && n1 + n2 > 4096 && dist_rows_jpl(n2, n1, F) >= 1 &&
+                         (double)F * (double)n1 * (double)n2 * 4.0 <= 8388608.0;
+    const int rows_jpl = swapped ? dist_rows_jpl(n2, n1, F) : rows_ok ? jpl_any : 0;
     const bool rect_first = !selfdist && !no_rect && ((jpl_any >= 1 && !rows_ok) || (jpl_any == 0 && !pbc && n2 >= DT && small_result && !no_rows));
     if (!no_frame && !selfdist && rows_jpl == 0 && !rect_first && n1 + n2 <= 4096 && F * 64 <= 0x7ffffff0LL) {
         // four consecutive frames per block while both selections fit 32 KB of LDS (they share the cache lines of their atoms' rows),
@@ -108,27 +115,37 @@ int run_dist_trajectory(BE& be, const float* coords, long long F, const float* b
         // rows of >= 64 second atoms are written directly by a wave per frame, from selections turned frame-major first
         const int jpl = rows_jpl;
         if (jpl) {
-            const long long np1 = ceil_div(n1, DT) * DT, np2 = ceil_div(n2, 64 * jpl) * 64 * jpl;
-            const long long tasks = F * ceil_div(n1, ROWS_CI) * ceil_div(n2, 64 * jpl);
+            // (swapped: the kernel's rows are the reference's second selection, its lanes the first -- see k_dist_rows)
+            const unsigned *rsel = swapped ? sel2 : sel1, *lsel = swapped ? sel1 : sel2;
+            const long long rn = swapped ? n2 : n1, ln = swapped ? n1 : n2;
+            const long long np1 = ceil_div(rn, DT) * DT, np2 = ceil_div(ln, 64 * jpl) * 64 * jpl;
+            const long long tasks = F * ceil_div(rn, ROWS_CI) * ceil_div(ln, 64 * jpl);
             void *t1 = nullptr, *t2 = nullptr, *cs1 = nullptr, *cs2 = nullptr;
             if ((st = be.ensure(WS_D_COM1, (size_t)F * 3 * (size_t)np1 * 4, &t1, 0))) return st;
             if ((st = be.ensure(WS_D_COM2, (size_t)F * 3 * (size_t)np2 * 4, &t2, 0))) return st;
             if ((st = be.ensure(WS_D_PA, (size_t)np1 * 4, &cs1, 0))) return st;
             if ((st = be.ensure(WS_D_PB, (size_t)np2 * 4, &cs2, 0))) return st;
             const unsigned* ch = pbc ? chains : nullptr;
-            if ((st = be.launch(k_sel_to_frames, dim3((unsigned)ceil_div(F, DT), (unsigned)((np1 + np2) / DT), 3u), dim3(256), coords, F, sel1, n1, np1,
-                                sel2, n2, np2, ch, (float*)t1, (unsigned*)cs1, (float*)t2, (unsigned*)cs2))) return st;
+            if ((st = be.launch(k_sel_to_frames, dim3((unsigned)ceil_div(F, DT), (unsigned)((np1 + np2) / DT), 3u), dim3(256), coords, F, rsel, rn, np1,
+                                lsel, ln, np2, ch, (float*)t1, (unsigned*)cs1, (float*)t2, (unsigned*)cs2))) return st;
             const dim3 grid(padded8(ceil_div(tasks, 4))), block(256);
             auto go = [&](auto kernel) {
                 return be.launch(kernel, grid, block, (const float*)t1, np1, (const unsigned*)cs1, (const float*)t2, np2, (const unsigned*)cs2, box, F,
-                                 n1, n2, squared, out, P);
+                                 rn, ln, squared, out, P);
             };
             const bool no_vec = (avoid & DIST_AVOID_VEC) != 0;
             const bool vec = jpl == 4 && !no_vec;      // (16-byte stores at 4-byte alignment: rows of any length, any float* result)
             {
                 char nm[96];
-                snprintf(nm, sizeof nm, "mkamd::k_sel_to_frames + mkamd::k_dist_rows<%s, %d, %s%s>", pbc ? "true" : "false", jpl, vec ? "true" : "false", selfdist ? ", true" : "");
+                snprintf(nm, sizeof nm, "mkamd::k_sel_to_frames + mkamd::k_dist_rows<%s, %d, %s%s>", pbc ? "true" : "false", jpl, vec ? "true" : "false",
+                         selfdist ? ", true" : swapped ? ", false, true" : "");
                 be.note_dist_kernel(nm);
+            }
+            if (swapped) {
+                if (pbc) return vec ? go(k_dist_rows<true, 4, true, false, true>) : jpl == 4 ? go(k_dist_rows<true, 4, false, false, true>)
+                                    : jpl == 2 ? go(k_dist_rows<true, 2, false, false, true>) : go(k_dist_rows<true, 1, false, false, true>);
+                return vec ? go(k_dist_rows<false, 4, true, false, true>) : jpl == 4 ? go(k_dist_rows<false, 4, false, false, true>)
+                           : jpl == 2 ? go(k_dist_rows<false, 2, false, false, true>) : go(k_dist_rows<false, 1, false, false, true>);
             }
             if (selfdist) {
                 if (pbc) return vec ? go(k_dist_rows<true, 4, true, true>) : jpl == 4 ? go(k_dist_rows<true, 4, false, true>) : jpl == 2 ? go(k_dist_rows<true, 2, false, true>)

@@ -23,6 +23,9 @@ for seed in range(first, first + count):
     selfdist = bool(rng.random() < 0.25)
     n2 = int(rng.choice([1, 5, 52, 63, 64, 65, 100, 128, 200, 256, 260, 500, 720, 1000, 1600]))
     n1 = n2 if selfdist else int(rng.choice([1, 7, 16, 17, 40, 100, 200]))
+    if not selfdist and rng.random() < 0.06 and N >= 1200:            # a long first selection against a short second one on few frames: the swapped row kernel
+        n1, n2, F = 4500, int(rng.choice([5, 30, 51])), int(rng.choice([1, 2, 7]))
+        c, b = c[:, :, :F].copy(), b[:, :F].copy()
     n1, n2 = min(n1, 4 * N), min(n2, 4 * N)
     s2 = rng.integers(0, N, size=n2).astype(np.uint32)
     s1 = s2.copy() if selfdist else rng.integers(0, N, size=n1).astype(np.uint32)

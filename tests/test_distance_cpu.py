@@ -856,3 +856,31 @@ def test_which_kernel_dist_trajectory_takes_at_few_frames_and_for_large_selfdist
     assert "k_dist_pairs" in chosen(720, 720, 1, True, avoid=64)
     assert "k_dist_pairs" in chosen(720, 720, 33, True)
     assert "k_dist_rows<false, 4, true, true>" in chosen(1536, 1536, 1, True)
+
+
+def test_short_row_calls_of_few_frames_take_the_row_kernel_the_other_way_round():
+    """Round 6 (late): a rectangular call of few frames whose rows are too short for the row kernel and whose FIRST selection is long (a receptor's atoms
+    x a ligand's, beyond what the block-per-frame kernel stages) runs the row kernel with the selections swapped -- lanes along the first selection,
+    transposed stores; every operation on the separation is odd, so the swapped pair has the reference's bits.  One and three frames, periodic with
+    mixed chains and open, squared, a zero box and a NaN coordinate; the oracle's bits, the tile kernel's (avoid bit 128) and the kernel's name."""
+    rng = np.random.default_rng(23)
+    N = 4400
+    ch = rng.integers(0, 3, size=N).astype(np.uint32)
+    s1 = rng.permutation(N)[:4200].astype(np.uint32)
+    s2 = rng.permutation(N)[:30].astype(np.uint32)
+    for F in (1, 3):
+        c = rng.uniform(-25, 25, size=(N, 3, F)).astype(np.float32)
+        b = rng.uniform(18, 30, size=(3, F)).astype(np.float32)
+        if F == 3:
+            b[:, 1] = 0.0
+            c[int(s1[5]), 1, 2] = np.nan
+        for pbc in (True, False):
+            with np.errstate(all="ignore"):
+                want = oracle.dist_trajectory(c, b, s1, s2, ch, False, pbc)
+            assert np.array_equal(E.dist_trajectory(c, b, s1, s2, ch, False, pbc), want, equal_nan=True), (F, pbc)
+            assert ", false, true>" in E.last_dist_kernel(), E.last_dist_kernel()
+            assert np.array_equal(E.dist_trajectory(c, b, s1, s2, ch, False, pbc, avoid=128), want, equal_nan=True)
+            assert "k_dist_rect" in E.last_dist_kernel()
+        with np.errstate(all="ignore"):
+            want = oracle.dist_trajectory(c, b, s1, s2, ch, False, True, squared=True)
+        assert np.array_equal(E.dist_trajectory(c, b, s1, s2, ch, False, True, squared=True), want, equal_nan=True)
